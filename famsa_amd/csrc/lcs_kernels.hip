@@ -1,0 +1,280 @@
+// lcs_kernels.hip -- hand-written gfx950 (CDNA4) kernels for FAMSA's bit-parallel LCS.
+//
+// One lane = one PARTNER sequence (the streamed side), one workgroup = 4 waves = 256
+// partners x R REF sequences (the bit-mask side).  The refs' complemented occurrence masks
+// nM[ref][word][code] live in LDS; every lane keeps the bit-vector X of RG refs at a time
+// in VGPRs (2 x BV x RG registers) and walks its partner's residues.  Per 64-bit word-step
+// the lane does one conflict-free ds_read_b64 gather (address = residue code x 8 inside a
+// 256-byte row, so the 20 residue codes hit 20 distinct bank pairs) and six VALU ops:
+//     tB = V & ~nM'      v_bitop3_b32 x2   (nM' = ~M, so this is V & M)
+//     V2 = V + tB + c    v_add_co/v_addc_co_u32 x2 -- one carry chain through all words
+//     X  = V2 | (V & nM) v_bitop3_b32 x2
+// which is the recurrence of CLCSBP_Classic_Impl (reference lcs/lcsbp_classic.h:51-58,
+// 67-98) restated for 32-bit lanes.  No MFMA: this is integer/bit work.
+//
+// Exactness: the reference takes the carry out of a word as (V2 < V) AFTER adding the
+// carry-in (lcsbp_classic.h:55-56), which differs from a true 65-bit carry exactly when
+// tB == ~0 and carry-in == 1 -- only possible if the ref has an aligned 64-residue
+// homopolymer word at word index >= 1.  Such refs are flagged at upload and run through the
+// QUIRK instantiation, which evaluates the reference's rule literally; all other refs use
+// the hardware carry chain, which is provably identical for them.
+//
+// Partner residues are stored position-major per 64-sequence tile ("column" layout):
+// 16-byte chunk k of lane l of tile t sits at tile_base[t] + (k*64 + l)*16, so a wave's
+// load of one chunk for 64 consecutive partners is one contiguous 1 KiB.  Each stored byte
+// is (symbol code * 8) = the byte offset of that code inside an LDS mask row; padding is
+// code 22 (UNKNOWN_SYMBOL, reference core/defs.h:66) whose mask is empty => a no-op step,
+// exactly what the reference's `continue` (lcsbp_classic.h:82) / padded SIMD lanes do.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "lcs_kernels.h"
+
+namespace lcsgpu {
+
+typedef __attribute__((address_space(3))) unsigned char lds_u8;
+typedef __attribute__((address_space(3))) uint64_t lds_u64;
+
+static constexpr uint32_t PAD4 = 0xB0B0B0B0u; // four bytes of 22*8
+
+__device__ __forceinline__ uint32_t andn(uint32_t v, uint32_t n)
+{
+    return __builtin_amdgcn_bitop3_b32(v, n, 0u, 0x30); // v & ~n
+}
+__device__ __forceinline__ uint32_t or_and(uint32_t s, uint32_t v, uint32_t n)
+{
+    return __builtin_amdgcn_bitop3_b32(s, v, n, 0xF8); // s | (v & n)
+}
+
+// One partner residue against RG refs x BV words.  `row` = LDS address of this residue's
+// entry in mask row 0 of ref 0 of the group.
+template <int BV, int RG, bool QUIRK>
+__device__ __forceinline__ void residue_step(const lds_u8* row, uint32_t (&X)[RG][2 * BV])
+{
+#pragma unroll
+    for (int r = 0; r < RG; ++r) {
+        if constexpr (!QUIRK) {
+            unsigned cin = 0;
+#pragma unroll
+            for (int j = 0; j < BV; ++j) {
+                const uint64_t nn = *(const lds_u64*)(row + (r * BV + j) * 256);
+                const uint32_t n0 = (uint32_t)nn, n1 = (uint32_t)(nn >> 32);
+                unsigned co;
+                uint32_t V = X[r][2 * j];
+                uint32_t s = __builtin_addc(V, andn(V, n0), cin, &co);
+                X[r][2 * j] = or_and(s, V, n0);
+                cin = co;
+                V = X[r][2 * j + 1];
+                s = __builtin_addc(V, andn(V, n1), cin, &co);
+                X[r][2 * j + 1] = or_and(s, V, n1);
+                cin = co;
+            }
+        } else {
+            // the reference's rule, literally: V2 = V + tB + cin; cin' = (V2 < V)
+            uint64_t cin = 0;
+#pragma unroll
+            for (int j = 0; j < BV; ++j) {
+                const uint64_t nn = *(const lds_u64*)(row + (r * BV + j) * 256);
+                const uint64_t V = ((uint64_t)X[r][2 * j + 1] << 32) | X[r][2 * j];
+                const uint64_t tB = V & ~nn;
+                const uint64_t V2 = V + tB + cin;
+                cin = (V2 < V) ? 1u : 0u;
+                const uint64_t Xn = V2 | (V & nn);
+                X[r][2 * j] = (uint32_t)Xn;
+                X[r][2 * j + 1] = (uint32_t)(Xn >> 32);
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ int wave_max(int v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        int t = __shfl_xor(v, o, 64);
+        v = t > v ? t : v;
+    }
+    return v;
+}
+
+template <int BV, int RG, bool QUIRK>
+__global__ __launch_bounds__(256) void lcs_rows_kernel(RowsArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int R = a.refs_per_block;
+    const int ref0 = blockIdx.y * R;
+    const int nr = min(R, a.n_refs - ref0);
+    const int c0 = blockIdx.x * 256;
+
+    // Triangle mode: columns are sequence ids, only pairs col < ref are wanted.
+    if (a.mode == MODE_TRIANGLE) {
+        int max_rid = 0;
+        for (int r = 0; r < nr; ++r) {
+            const int rid = a.ref_ids ? a.ref_ids[ref0 + r] : a.ref_begin + ref0 + r;
+            max_rid = rid > max_rid ? rid : max_rid;
+        }
+        if (c0 >= max_rid)
+            return;
+    }
+
+    // ---- 1. complemented occurrence masks of the block's refs -> LDS ------------------
+    // nM[(r*BV + j)*32 + c] = ~M[c][j], M as CSequence::ComputeBitMasks builds it
+    // (reference core/sequence.cpp:190-201: bits only for codes < 20).  Slots of a partial
+    // last group are filled with "no match" so the group loop needs no tail case.
+    {
+        lds_u64* nM = (lds_u64*)smem;
+        const int nr_pad = (nr + RG - 1) / RG * RG;
+        for (int item = wave; item < nr_pad * BV; item += 4) {
+            const int r = item / BV, j = item - r * BV;
+            uint32_t code8 = 0xFFu;
+            if (r < nr) {
+                const int rid = a.ref_ids ? a.ref_ids[ref0 + r] : a.ref_begin + ref0 + r;
+                const uint32_t len = a.lens[rid];
+                const uint32_t p = j * 64 + lane;
+                if (p < len)
+                    code8 = a.tiles[a.tile_base[rid >> 6] + ((uint64_t)(p >> 4) * 64 + (rid & 63)) * 16 + (p & 15)];
+            }
+            uint64_t mine = 0;
+#pragma unroll
+            for (int c = 0; c < 20; ++c) {
+                const uint64_t b = __ballot(code8 == (uint32_t)(c * 8));
+                if (lane == c)
+                    mine = b;
+            }
+            if (lane < 32)
+                nM[(r * BV + j) * 32 + lane] = ~mine;
+        }
+    }
+    __syncthreads();
+
+    // ---- 2. this lane's partner -------------------------------------------------------
+    const int c = c0 + tid;
+    const bool valid = c < a.n_cols;
+    int pid = a.col_ids ? a.col_ids[valid ? c : 0] : a.col_begin + (valid ? c : 0);
+    const uint32_t len_p = valid ? a.lens[pid] : 0u;
+    const uint8_t* pbase = a.tiles + a.tile_base[pid >> 6] + (uint64_t)(pid & 63) * 16;
+    const int my_chunks = (int)((len_p + 15) >> 4);
+    const int wave_chunks = wave_max(my_chunks);
+
+    // ---- 3. RG refs at a time ---------------------------------------------------------
+    for (int g = 0; g < nr; g += RG) {
+        uint32_t X[RG][2 * BV];
+#pragma unroll
+        for (int r = 0; r < RG; ++r)
+#pragma unroll
+            for (int j = 0; j < 2 * BV; ++j)
+                X[r][j] = ~0u;
+
+        const lds_u8* grp = (const lds_u8*)smem + g * (BV * 256);
+        uint4 q = make_uint4(PAD4, PAD4, PAD4, PAD4);
+        if (0 < my_chunks)
+            q = *(const uint4*)pbase;
+        for (int k = 0; k < wave_chunks; ++k) {
+            uint4 qn = make_uint4(PAD4, PAD4, PAD4, PAD4);
+            if (k + 1 < my_chunks)
+                qn = *(const uint4*)(pbase + (size_t)(k + 1) * 1024);
+            const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int b = 0; b < 16; ++b) {
+                const uint32_t code8 = (w[b >> 2] >> (8 * (b & 3))) & 0xFFu;
+                residue_step<BV, RG, QUIRK>(grp + code8, X);
+            }
+            q = qn;
+        }
+
+        // result = number of zero bits (reference lcsbp_classic.h:60-65)
+#pragma unroll
+        for (int r = 0; r < RG; ++r) {
+            if (g + r >= nr || !valid)
+                continue;
+            uint32_t res = 0;
+#pragma unroll
+            for (int j = 0; j < 2 * BV; ++j)
+                res += __popc(~X[r][j]);
+            const int k = ref0 + g + r;
+            int64_t idx;
+            if (a.mode == MODE_TRIANGLE) {
+                const int64_t rid = a.ref_ids ? a.ref_ids[k] : a.ref_begin + k;
+                if (c >= rid)
+                    continue;
+                idx = rid * (rid - 1) / 2 + c - a.out_offset;
+            } else {
+                const int64_t row = a.ref_rows ? a.ref_rows[k] : (int64_t)k + a.row0;
+                idx = row * a.ld + c;
+            }
+            if (a.elem_size == 2)
+                ((uint16_t*)a.out)[idx] = (uint16_t)res;
+            else
+                ((uint32_t*)a.out)[idx] = res;
+        }
+    }
+}
+
+// ---- host-side dispatch ---------------------------------------------------------------
+
+int bv_class(uint32_t len)
+{
+    // word counts that have their own instantiation; others round up (extra words are
+    // all-ones no-ops, costing time but not changing the result)
+    const int bv = (int)((len + 63) / 64);
+    if (bv <= 1) return 1;
+    if (bv <= 16) return bv;
+    if (bv <= 32) return (bv + 1) & ~1;
+    return 0; // needs the long-sequence path
+}
+
+int quirk_bv_class(uint32_t len)
+{
+    const int bv = (int)((len + 63) / 64);
+    if (bv <= 4) return 4;
+    if (bv <= 8) return 8;
+    if (bv <= 16) return 16;
+    if (bv <= 32) return 32;
+    return 0;
+}
+
+static int rg_of(int bv) { return bv <= 8 ? 4 : (bv <= 16 ? 2 : 1); }
+
+int refs_per_block(int bv, bool quirk)
+{
+    const int rg = quirk ? 1 : rg_of(bv);
+    int r = (32 * 1024) / (bv * 256);
+    if (r > 32) r = 32;
+    r = r / rg * rg;
+    if (r < rg) r = rg;
+    return r;
+}
+
+template <int BV, int RG, bool QUIRK>
+static hipError_t launch_one(const RowsArgs& a, dim3 grid, hipStream_t stream)
+{
+    const size_t lds = (size_t)a.refs_per_block * BV * 256;
+    hipLaunchKernelGGL((lcs_rows_kernel<BV, RG, QUIRK>), grid, dim3(256), lds, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_rows(int bv, bool quirk, const RowsArgs& a, int grid_x, int grid_y, hipStream_t stream)
+{
+    const dim3 grid((unsigned)grid_x, (unsigned)grid_y);
+    if (quirk) {
+        switch (bv) {
+        case 4: return launch_one<4, 1, true>(a, grid, stream);
+        case 8: return launch_one<8, 1, true>(a, grid, stream);
+        case 16: return launch_one<16, 1, true>(a, grid, stream);
+        case 32: return launch_one<32, 1, true>(a, grid, stream);
+        default: return hipErrorInvalidValue;
+        }
+    }
+    switch (bv) {
+#define LCS_CASE(B, G) case B: return launch_one<B, G, false>(a, grid, stream);
+        LCS_CASE(1, 4) LCS_CASE(2, 4) LCS_CASE(3, 4) LCS_CASE(4, 4) LCS_CASE(5, 4) LCS_CASE(6, 4)
+        LCS_CASE(7, 4) LCS_CASE(8, 4) LCS_CASE(9, 2) LCS_CASE(10, 2) LCS_CASE(11, 2) LCS_CASE(12, 2)
+        LCS_CASE(13, 2) LCS_CASE(14, 2) LCS_CASE(15, 2) LCS_CASE(16, 2) LCS_CASE(18, 1) LCS_CASE(20, 1)
+        LCS_CASE(22, 1) LCS_CASE(24, 1) LCS_CASE(26, 1) LCS_CASE(28, 1) LCS_CASE(30, 1) LCS_CASE(32, 1)
+#undef LCS_CASE
+    default: return hipErrorInvalidValue;
+    }
+}
+
+} // namespace lcsgpu

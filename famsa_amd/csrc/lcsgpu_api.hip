@@ -1,0 +1,537 @@
+// lcsgpu_api.hip -- the C-ABI of include/lcsgpu.h over the gfx950 kernels.
+// Context, HBM layout of the uploaded sequence set, launch planning.  No CPU compute path:
+// every LCS value this library returns was produced by a HIP kernel.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/lcsgpu.h"
+#include "lcs_kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                           \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess)                                                                   \
+            return fail(LCSGPU_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),    \
+                        __FILE__, __LINE__);                                                    \
+    } while (0)
+
+// grow-only device / pinned-host buffers
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t n)
+    {
+        if (n <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = n + n / 4 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+struct PinBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t n)
+    {
+        if (n <= cap) return hipSuccess;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = n + n / 4 + 256;
+        hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release()
+    {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+} // namespace
+
+struct lcsgpu_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    std::mutex mu;
+
+    // uploaded set
+    int32_t n = -1;
+    uint32_t max_len = 0;
+    std::vector<uint32_t> lens;
+    std::vector<uint8_t> quirk; // ref needs the literal (V2 < V) carry rule
+    DevBuf d_tiles, d_tile_base, d_lens;
+
+    // per-call scratch
+    DevBuf d_plan, d_out;
+    PinBuf h_plan;
+    bool plan_in_flight = false;
+    int last_launches = 0;
+    bool timing_valid = false;
+};
+
+namespace {
+
+using lcsgpu::RowsArgs;
+
+// A ref is "quirk-capable" iff some word w >= 1 that lies fully inside the sequence holds
+// 64 copies of one valid residue: only then can tB == ~0 meet a carry-in (SURVEY note Q).
+bool is_quirk_capable(const uint8_t* s, uint32_t len)
+{
+    for (uint32_t w = 1; (w + 1) * 64 <= len; ++w) {
+        const uint8_t c = s[w * 64];
+        if (c >= 20) continue;
+        bool all = true;
+        for (uint32_t i = 1; i < 64 && all; ++i)
+            all = s[w * 64 + i] == c;
+        if (all) return true;
+    }
+    return false;
+}
+
+struct RefItem {
+    int32_t id;
+    int64_t row;
+};
+
+struct Bucket {
+    int bv;
+    bool quirk;
+    std::vector<RefItem> items;
+};
+
+// Split the refs by instantiated kernel (word-count class, quirk flag), keeping order.
+int make_buckets(lcsgpu_ctx* ctx, const int32_t* ref_ids, int32_t ref_begin, int32_t n_refs,
+                 int64_t row0, std::vector<Bucket>& out)
+{
+    int index_of[128];
+    std::fill(index_of, index_of + 128, -1);
+    for (int32_t k = 0; k < n_refs; ++k) {
+        const int32_t id = ref_ids ? ref_ids[k] : ref_begin + k;
+        if (id < 0 || id >= ctx->n)
+            return fail(LCSGPU_E_INVALID, "ref id %d out of range [0,%d)", id, ctx->n);
+        const bool q = ctx->quirk[id] != 0;
+        const int bv = q ? lcsgpu::quirk_bv_class(ctx->lens[id]) : lcsgpu::bv_class(ctx->lens[id]);
+        if (bv == 0)
+            return fail(LCSGPU_E_INVALID, "sequence %d is longer than 2048 residues (not supported yet)", id);
+        const int key = bv * 2 + (q ? 1 : 0);
+        if (index_of[key] < 0) {
+            index_of[key] = (int)out.size();
+            out.push_back(Bucket{bv, q, {}});
+        }
+        out[index_of[key]].items.push_back(RefItem{id, row0 + k});
+    }
+    return LCSGPU_OK;
+}
+
+bool contiguous(const Bucket& b)
+{
+    for (size_t k = 1; k < b.items.size(); ++k)
+        if (b.items[k].id != b.items[0].id + (int32_t)k || b.items[k].row != b.items[0].row + (int64_t)k)
+            return false;
+    return true;
+}
+
+// Core: plan + launch.  d_out is a device pointer.
+int run_rows(lcsgpu_ctx* ctx, int mode, const int32_t* ref_ids, int32_t ref_begin, int32_t n_refs,
+             const int32_t* col_ids, int32_t col_begin, int32_t n_cols, void* d_out, int64_t ld,
+             int64_t out_offset, int elem_size)
+{
+    if (ctx->n < 0) return fail(LCSGPU_E_STATE, "no sequence set uploaded");
+    if (elem_size != 2 && elem_size != 4) return fail(LCSGPU_E_INVALID, "elem_size must be 2 or 4");
+    if (elem_size == 2 && ctx->max_len > 65535)
+        return fail(LCSGPU_E_INVALID, "uint16 output needs all sequences <= 65535 residues");
+    if (n_refs < 0 || n_cols < 0) return fail(LCSGPU_E_INVALID, "negative count");
+    ctx->last_launches = 0;
+    ctx->timing_valid = false;
+    if (n_refs == 0 || n_cols == 0) return LCSGPU_OK;
+    if (!col_ids && (col_begin < 0 || (int64_t)col_begin + n_cols > ctx->n))
+        return fail(LCSGPU_E_INVALID, "column range out of bounds");
+    if (col_ids)
+        for (int32_t c = 0; c < n_cols; ++c)
+            if (col_ids[c] < 0 || col_ids[c] >= ctx->n)
+                return fail(LCSGPU_E_INVALID, "col id %d out of range", col_ids[c]);
+
+    std::vector<Bucket> buckets;
+    int rc = make_buckets(ctx, ref_ids, ref_begin, n_refs, 0, buckets);
+    if (rc) return rc;
+
+    // staging: [col_ids][per non-contiguous bucket: rows(int64) then ids(int32)]
+    size_t bytes = 0;
+    auto align8 = [](size_t x) { return (x + 7) & ~(size_t)7; };
+    const size_t col_off = 0;
+    if (col_ids) bytes += align8((size_t)n_cols * 4);
+    std::vector<size_t> row_off(buckets.size(), 0), id_off(buckets.size(), 0);
+    std::vector<char> is_contig(buckets.size(), 0);
+    for (size_t b = 0; b < buckets.size(); ++b) {
+        is_contig[b] = contiguous(buckets[b]);
+        if (is_contig[b]) continue;
+        row_off[b] = bytes;
+        bytes += align8(buckets[b].items.size() * 8);
+        id_off[b] = bytes;
+        bytes += align8(buckets[b].items.size() * 4);
+    }
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (bytes) {
+        if (ctx->plan_in_flight) {
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+            ctx->plan_in_flight = false;
+        }
+        HIP_TRY(ctx->h_plan.reserve(bytes));
+        HIP_TRY(ctx->d_plan.reserve(bytes));
+        char* h = (char*)ctx->h_plan.p;
+        if (col_ids) memcpy(h + col_off, col_ids, (size_t)n_cols * 4);
+        for (size_t b = 0; b < buckets.size(); ++b) {
+            if (is_contig[b]) continue;
+            int64_t* hr = (int64_t*)(h + row_off[b]);
+            int32_t* hi = (int32_t*)(h + id_off[b]);
+            for (size_t k = 0; k < buckets[b].items.size(); ++k) {
+                hr[k] = buckets[b].items[k].row;
+                hi[k] = buckets[b].items[k].id;
+            }
+        }
+        HIP_TRY(hipMemcpyAsync(ctx->d_plan.p, h, bytes, hipMemcpyHostToDevice, ctx->stream));
+        ctx->plan_in_flight = true;
+    }
+
+    HIP_TRY(hipEventRecord(ctx->ev_start, ctx->stream));
+    for (size_t b = 0; b < buckets.size(); ++b) {
+        const Bucket& bk = buckets[b];
+        RowsArgs a{};
+        a.tiles = (const uint8_t*)ctx->d_tiles.p;
+        a.tile_base = (const uint64_t*)ctx->d_tile_base.p;
+        a.lens = (const uint32_t*)ctx->d_lens.p;
+        a.n_refs = (int32_t)bk.items.size();
+        if (is_contig[b]) {
+            a.ref_ids = nullptr;
+            a.ref_rows = nullptr;
+            a.ref_begin = bk.items[0].id;
+            a.row0 = bk.items[0].row;
+        } else {
+            a.ref_ids = (const int32_t*)((char*)ctx->d_plan.p + id_off[b]);
+            a.ref_rows = (const int64_t*)((char*)ctx->d_plan.p + row_off[b]);
+        }
+        a.col_ids = col_ids ? (const int32_t*)((char*)ctx->d_plan.p + col_off) : nullptr;
+        a.col_begin = col_begin;
+        a.n_cols = n_cols;
+        a.out = d_out;
+        a.ld = ld;
+        a.out_offset = out_offset;
+        a.elem_size = elem_size;
+        a.mode = mode;
+        a.refs_per_block = lcsgpu::refs_per_block(bk.bv, bk.quirk);
+        int32_t use_cols = n_cols;
+        if (mode == lcsgpu::MODE_TRIANGLE) { // columns at or beyond the largest ref id are never wanted
+            int32_t max_rid = 0;
+            for (const RefItem& it : bk.items) max_rid = std::max(max_rid, it.id);
+            use_cols = std::min(n_cols, max_rid);
+            if (use_cols <= 0) continue;
+        }
+        const int gx = (use_cols + 255) / 256;
+        const int gy = (a.n_refs + a.refs_per_block - 1) / a.refs_per_block;
+        if (gy > 65535) return fail(LCSGPU_E_INVALID, "too many ref tiles in one call (%d)", gy);
+        HIP_TRY(lcsgpu::launch_rows(bk.bv, bk.quirk, a, gx, gy, ctx->stream));
+        ++ctx->last_launches;
+    }
+    HIP_TRY(hipEventRecord(ctx->ev_stop, ctx->stream));
+    ctx->timing_valid = true;
+    return LCSGPU_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+const char* lcsgpu_version(void) { return "lcsgpu 0.1 gfx950"; }
+const char* lcsgpu_last_error(void) { return g_err.c_str(); }
+
+int lcsgpu_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int lcsgpu_create(int device_id, lcsgpu_ctx** out_ctx)
+{
+    if (!out_ctx) return fail(LCSGPU_E_INVALID, "out_ctx is NULL");
+    *out_ctx = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(LCSGPU_E_NODEVICE, "no HIP device available (%s)", hipGetErrorString(e));
+    if (device_id < 0 || device_id >= n)
+        return fail(LCSGPU_E_INVALID, "device %d not in [0,%d)", device_id, n);
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device_id));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(LCSGPU_E_NODEVICE, "device %d is %s; this library is built for gfx950 only", device_id,
+                    prop.gcnArchName);
+    HIP_TRY(hipSetDevice(device_id));
+    lcsgpu_ctx* ctx = new (std::nothrow) lcsgpu_ctx;
+    if (!ctx) return fail(LCSGPU_E_NOMEM, "out of host memory");
+    ctx->device = device_id;
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&ctx->ev_start) != hipSuccess || hipEventCreate(&ctx->ev_stop) != hipSuccess) {
+        delete ctx;
+        return fail(LCSGPU_E_HIP, "stream/event creation failed");
+    }
+    *out_ctx = ctx;
+    return LCSGPU_OK;
+}
+
+int lcsgpu_destroy(lcsgpu_ctx* ctx)
+{
+    if (!ctx) return LCSGPU_OK;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    ctx->d_tiles.release();
+    ctx->d_tile_base.release();
+    ctx->d_lens.release();
+    ctx->d_plan.release();
+    ctx->d_out.release();
+    ctx->h_plan.release();
+    if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
+    if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return LCSGPU_OK;
+}
+
+int lcsgpu_encode(const char* residues, size_t n, uint8_t* codes, size_t* n_codes)
+{
+    if ((!residues && n) || !codes || !n_codes) return fail(LCSGPU_E_INVALID, "NULL argument");
+    // The alphabet and the folding of characters above 'Z' of CSequence's constructor
+    // (reference core/sequence.cpp:17,53-79); the lookup covers the terminator too.
+    static const char alphabet[25] = "ARNDCQEGHILKMFPSTWYVBZX*";
+    uint8_t lut[256];
+    for (int ch = 0; ch < 256; ++ch) {
+        char c = (char)ch;
+        if (c > 'Z') c = (char)(c - 32);
+        uint8_t code = 22;
+        for (int i = 0; i < 25; ++i)
+            if (alphabet[i] == c) {
+                code = (uint8_t)i;
+                break;
+            }
+        lut[ch] = code;
+    }
+    size_t m = 0;
+    for (size_t i = 0; i < n; ++i)
+        if (residues[i] != '-') codes[m++] = lut[(unsigned char)residues[i]];
+    *n_codes = m;
+    return LCSGPU_OK;
+}
+
+int lcsgpu_upload(lcsgpu_ctx* ctx, const uint8_t* codes, const uint64_t* offsets, int32_t n)
+{
+    if (!ctx || !offsets || n < 0 || (!codes && n > 0 && offsets[n] > 0))
+        return fail(LCSGPU_E_INVALID, "bad argument");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->n = -1;
+    std::vector<uint32_t> lens(n);
+    std::vector<uint8_t> quirk(n);
+    uint32_t max_len = 0;
+    for (int32_t i = 0; i < n; ++i) {
+        if (offsets[i + 1] < offsets[i]) return fail(LCSGPU_E_INVALID, "offsets not monotone at %d", i);
+        const uint64_t len = offsets[i + 1] - offsets[i];
+        if (len > 0x7fffffffu) return fail(LCSGPU_E_INVALID, "sequence %d too long", i);
+        lens[i] = (uint32_t)len;
+        max_len = std::max(max_len, lens[i]);
+        const uint8_t* s = codes + offsets[i];
+        for (uint32_t k = 0; k < lens[i]; ++k)
+            if (s[k] >= 32) return fail(LCSGPU_E_INVALID, "symbol code %u out of range in sequence %d", s[k], i);
+        quirk[i] = is_quirk_capable(s, lens[i]) ? 1 : 0;
+    }
+    // position-major tiles of 64 sequences; chunk = 16 residues; byte = code*8; pad = 22*8
+    const int32_t n_tiles = (n + 63) / 64;
+    std::vector<uint64_t> tile_base((size_t)n_tiles + 1, 0);
+    for (int32_t t = 0; t < n_tiles; ++t) {
+        uint32_t tmax = 0;
+        for (int32_t s = t * 64; s < std::min(n, (t + 1) * 64); ++s) tmax = std::max(tmax, lens[s]);
+        const uint64_t chunks = std::max<uint64_t>(1, (tmax + 15) / 16);
+        tile_base[t + 1] = tile_base[t] + chunks * 1024;
+    }
+    const size_t total = (size_t)tile_base[n_tiles];
+    PinBuf stage;
+    if (total) {
+        HIP_TRY(stage.reserve(total));
+        uint8_t* img = (uint8_t*)stage.p;
+        memset(img, 22 * 8, total);
+        for (int32_t s = 0; s < n; ++s) {
+            uint8_t* base = img + tile_base[s >> 6] + (size_t)(s & 63) * 16;
+            const uint8_t* src = codes + offsets[s];
+            for (uint32_t p = 0; p < lens[s]; ++p)
+                base[(size_t)(p >> 4) * 1024 + (p & 15)] = (uint8_t)(src[p] * 8);
+        }
+    }
+    hipError_t e = hipSuccess;
+    if ((e = ctx->d_tiles.reserve(std::max<size_t>(total, 16))) != hipSuccess ||
+        (e = ctx->d_tile_base.reserve(((size_t)n_tiles + 1) * 8)) != hipSuccess ||
+        (e = ctx->d_lens.reserve(std::max<size_t>((size_t)n * 4, 16))) != hipSuccess) {
+        stage.release();
+        return fail(LCSGPU_E_NOMEM, "device allocation failed: %s", hipGetErrorString(e));
+    }
+    if (total) e = hipMemcpy(ctx->d_tiles.p, stage.p, total, hipMemcpyHostToDevice);
+    stage.release();
+    if (e != hipSuccess) return fail(LCSGPU_E_HIP, "tile upload failed: %s", hipGetErrorString(e));
+    HIP_TRY(hipMemcpy(ctx->d_tile_base.p, tile_base.data(), ((size_t)n_tiles + 1) * 8, hipMemcpyHostToDevice));
+    if (n) HIP_TRY(hipMemcpy(ctx->d_lens.p, lens.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+    ctx->lens.swap(lens);
+    ctx->quirk.swap(quirk);
+    ctx->max_len = max_len;
+    ctx->n = n;
+    return LCSGPU_OK;
+}
+
+int32_t lcsgpu_count(lcsgpu_ctx* ctx)
+{
+    if (!ctx) return fail(LCSGPU_E_INVALID, "NULL ctx");
+    return ctx->n;
+}
+
+int32_t lcsgpu_length(lcsgpu_ctx* ctx, int32_t i)
+{
+    if (!ctx || i < 0 || i >= ctx->n) return fail(LCSGPU_E_INVALID, "bad index");
+    return (int32_t)ctx->lens[i];
+}
+
+int lcsgpu_lcs_rect_dev(lcsgpu_ctx* ctx, const int32_t* ref_ids, int32_t ref_begin, int32_t n_refs,
+                        const int32_t* col_ids, int32_t col_begin, int32_t n_cols, void* d_out,
+                        int64_t ld, int elem_size, int sync)
+{
+    if (!ctx || (!d_out && n_refs > 0 && n_cols > 0)) return fail(LCSGPU_E_INVALID, "NULL argument");
+    if (ld < n_cols) return fail(LCSGPU_E_INVALID, "ld < n_cols");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    int rc = run_rows(ctx, lcsgpu::MODE_RECT, ref_ids, ref_begin, n_refs, col_ids, col_begin, n_cols, d_out, ld, 0,
+                      elem_size);
+    if (rc) return rc;
+    if (sync) HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return LCSGPU_OK;
+}
+
+int lcsgpu_lcs_rect(lcsgpu_ctx* ctx, const int32_t* ref_ids, int32_t ref_begin, int32_t n_refs,
+                    const int32_t* col_ids, int32_t col_begin, int32_t n_cols, void* out, int64_t ld,
+                    int elem_size)
+{
+    if (!ctx || (!out && n_refs > 0 && n_cols > 0)) return fail(LCSGPU_E_INVALID, "NULL argument");
+    if (ld < n_cols) return fail(LCSGPU_E_INVALID, "ld < n_cols");
+    if (n_refs <= 0 || n_cols <= 0) return (n_refs < 0 || n_cols < 0) ? fail(LCSGPU_E_INVALID, "negative count") : LCSGPU_OK;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t bytes = (size_t)n_refs * n_cols * elem_size;
+    HIP_TRY(ctx->d_out.reserve(bytes));
+    int rc = run_rows(ctx, lcsgpu::MODE_RECT, ref_ids, ref_begin, n_refs, col_ids, col_begin, n_cols, ctx->d_out.p,
+                      n_cols, 0, elem_size);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy2DAsync(out, (size_t)ld * elem_size, ctx->d_out.p, (size_t)n_cols * elem_size,
+                             (size_t)n_cols * elem_size, n_refs, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->plan_in_flight = false;
+    return LCSGPU_OK;
+}
+
+static int triangle_common(lcsgpu_ctx* ctx, int32_t row_begin, int32_t row_end, void* d_out, int elem_size)
+{
+    const int64_t off = (int64_t)row_begin * (row_begin - 1) / 2;
+    return run_rows(ctx, lcsgpu::MODE_TRIANGLE, nullptr, row_begin, row_end - row_begin, nullptr, 0,
+                    std::max(0, row_end - 1), d_out, 0, off, elem_size);
+}
+
+int lcsgpu_lcs_triangle_dev(lcsgpu_ctx* ctx, int32_t row_begin, int32_t row_end, void* d_out, int elem_size,
+                            int sync)
+{
+    if (!ctx) return fail(LCSGPU_E_INVALID, "NULL ctx");
+    if (ctx->n < 0) return fail(LCSGPU_E_STATE, "no sequence set uploaded");
+    if (row_begin < 0 || row_end < row_begin || row_end > ctx->n) return fail(LCSGPU_E_INVALID, "bad row range");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    int rc = triangle_common(ctx, row_begin, row_end, d_out, elem_size);
+    if (rc) return rc;
+    if (sync) HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return LCSGPU_OK;
+}
+
+int lcsgpu_lcs_triangle(lcsgpu_ctx* ctx, int32_t row_begin, int32_t row_end, void* out, int elem_size)
+{
+    if (!ctx) return fail(LCSGPU_E_INVALID, "NULL ctx");
+    if (ctx->n < 0) return fail(LCSGPU_E_STATE, "no sequence set uploaded");
+    if (row_begin < 0 || row_end < row_begin || row_end > ctx->n) return fail(LCSGPU_E_INVALID, "bad row range");
+    if (elem_size != 2 && elem_size != 4) return fail(LCSGPU_E_INVALID, "elem_size must be 2 or 4");
+    const int64_t count = (int64_t)row_end * (row_end - 1) / 2 - (int64_t)row_begin * (row_begin - 1) / 2;
+    if (count <= 0) return LCSGPU_OK;
+    if (!out) return fail(LCSGPU_E_INVALID, "NULL out");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(ctx->d_out.reserve((size_t)count * elem_size));
+    int rc = triangle_common(ctx, row_begin, row_end, ctx->d_out.p, elem_size);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(out, ctx->d_out.p, (size_t)count * elem_size, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->plan_in_flight = false;
+    return LCSGPU_OK;
+}
+
+int lcsgpu_sync(lcsgpu_ctx* ctx)
+{
+    if (!ctx) return fail(LCSGPU_E_INVALID, "NULL ctx");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->plan_in_flight = false;
+    return LCSGPU_OK;
+}
+
+int lcsgpu_last_kernel_ms(lcsgpu_ctx* ctx, double* ms, int32_t* n_launches)
+{
+    if (!ctx || !ms) return fail(LCSGPU_E_INVALID, "NULL argument");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    *ms = 0.0;
+    if (n_launches) *n_launches = ctx->last_launches;
+    if (!ctx->timing_valid || ctx->last_launches == 0) return LCSGPU_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipEventSynchronize(ctx->ev_stop));
+    float f = 0.f;
+    HIP_TRY(hipEventElapsedTime(&f, ctx->ev_start, ctx->ev_stop));
+    *ms = (double)f;
+    return LCSGPU_OK;
+}
+
+void* lcsgpu_stream(lcsgpu_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+} // extern "C"

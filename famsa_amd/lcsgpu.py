@@ -1,0 +1,160 @@
+"""ctypes binding of include/lcsgpu.h (one-to-one; no compute here)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class LcsGpuError(RuntimeError):
+    pass
+
+
+def library_path():
+    return os.path.join(_HERE, "liblcsgpu.so")
+
+
+def load_library():
+    """Load liblcsgpu.so from the package directory.  No fallback: a missing library is an error."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not os.path.exists(path):
+        raise LcsGpuError(
+            f"{path} not found: build it with `make -C famsa_amd/csrc` (or __graft_entry__.build()); "
+            "there is no CPU fallback")
+    lib = C.CDLL(path)
+    vp, i32, i64, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_size_t
+    pi32 = C.POINTER(C.c_int32)
+    sig = {
+        "lcsgpu_version": (C.c_char_p, []),
+        "lcsgpu_last_error": (C.c_char_p, []),
+        "lcsgpu_device_count": (C.c_int, []),
+        "lcsgpu_create": (C.c_int, [C.c_int, C.POINTER(vp)]),
+        "lcsgpu_destroy": (C.c_int, [vp]),
+        "lcsgpu_encode": (C.c_int, [C.c_char_p, sz, vp, C.POINTER(sz)]),
+        "lcsgpu_upload": (C.c_int, [vp, vp, vp, i32]),
+        "lcsgpu_count": (i32, [vp]),
+        "lcsgpu_length": (i32, [vp, i32]),
+        "lcsgpu_lcs_rect": (C.c_int, [vp, pi32, i32, i32, pi32, i32, i32, vp, i64, C.c_int]),
+        "lcsgpu_lcs_rect_dev": (C.c_int, [vp, pi32, i32, i32, pi32, i32, i32, vp, i64, C.c_int, C.c_int]),
+        "lcsgpu_lcs_triangle": (C.c_int, [vp, i32, i32, vp, C.c_int]),
+        "lcsgpu_lcs_triangle_dev": (C.c_int, [vp, i32, i32, vp, C.c_int, C.c_int]),
+        "lcsgpu_sync": (C.c_int, [vp]),
+        "lcsgpu_last_kernel_ms": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(i32)]),
+        "lcsgpu_stream": (vp, [vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _LIB = lib
+    return lib
+
+
+def _ids(a):
+    if a is None:
+        return None, None
+    arr = np.ascontiguousarray(a, dtype=np.int32)
+    return arr, arr.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+def encode(residues):
+    """Residue string -> uint8 symbol codes through the library's encoder (lcsgpu_encode)."""
+    lib = load_library()
+    raw = residues.encode("latin-1") if isinstance(residues, str) else bytes(residues)
+    out = np.empty(max(len(raw), 1), dtype=np.uint8)
+    n = C.c_size_t(0)
+    rc = lib.lcsgpu_encode(raw, len(raw), out.ctypes.data, C.byref(n))
+    if rc:
+        raise LcsGpuError(lib.lcsgpu_last_error().decode())
+    return out[: n.value].copy()
+
+
+class LcsGpu:
+    """One engine context on one GPU (mirrors `CLCSBP` + the batch-distance templates)."""
+
+    def __init__(self, device=0):
+        self._lib = load_library()
+        self._ctx = C.c_void_p()
+        self._check(self._lib.lcsgpu_create(int(device), C.byref(self._ctx)))
+        self.n = 0
+        self.lengths = np.zeros(0, dtype=np.uint32)
+
+    def _check(self, rc):
+        if rc != 0:
+            raise LcsGpuError(f"lcsgpu error {rc}: {self._lib.lcsgpu_last_error().decode()}")
+
+    def close(self):
+        if self._ctx:
+            self._lib.lcsgpu_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload(self, codes, offsets):
+        codes = np.ascontiguousarray(codes, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = len(offsets) - 1
+        self._check(self._lib.lcsgpu_upload(self._ctx, codes.ctypes.data if codes.size else None,
+                                            offsets.ctypes.data, n))
+        self.n = n
+        self.lengths = np.diff(offsets.astype(np.int64)).astype(np.uint32)
+
+    def upload_seqs(self, seqs):
+        """seqs: list of uint8 code arrays."""
+        lens = np.array([len(s) for s in seqs], dtype=np.uint64)
+        offsets = np.zeros(len(seqs) + 1, dtype=np.uint64)
+        np.cumsum(lens, out=offsets[1:])
+        codes = np.concatenate(seqs) if len(seqs) and offsets[-1] > 0 else np.zeros(0, dtype=np.uint8)
+        self.upload(codes, offsets)
+
+    def lcs_rect(self, refs, cols, dtype=np.uint16):
+        """refs / cols: (begin, count) tuple or id array.  Returns [n_refs, n_cols] host array."""
+        r_arr, r_ptr, r_begin, n_refs = self._spec(refs)
+        c_arr, c_ptr, c_begin, n_cols = self._spec(cols)
+        out = np.empty((n_refs, n_cols), dtype=dtype)
+        self._check(self._lib.lcsgpu_lcs_rect(self._ctx, r_ptr, r_begin, n_refs, c_ptr, c_begin, n_cols,
+                                              out.ctypes.data if out.size else None, n_cols, out.itemsize))
+        return out
+
+    def lcs_rect_dev(self, refs, cols, d_out_ptr, ld, elem_size, sync=False):
+        r_arr, r_ptr, r_begin, n_refs = self._spec(refs)
+        c_arr, c_ptr, c_begin, n_cols = self._spec(cols)
+        self._check(self._lib.lcsgpu_lcs_rect_dev(self._ctx, r_ptr, r_begin, n_refs, c_ptr, c_begin, n_cols,
+                                                  C.c_void_p(d_out_ptr), ld, elem_size, 1 if sync else 0))
+
+    def lcs_triangle(self, row_begin=0, row_end=None, dtype=np.uint16):
+        row_end = self.n if row_end is None else row_end
+        count = row_end * (row_end - 1) // 2 - row_begin * (row_begin - 1) // 2
+        out = np.empty(max(count, 0), dtype=dtype)
+        self._check(self._lib.lcsgpu_lcs_triangle(self._ctx, row_begin, row_end,
+                                                  out.ctypes.data if out.size else None, out.itemsize))
+        return out
+
+    def lcs_triangle_dev(self, row_begin, row_end, d_out_ptr, elem_size, sync=False):
+        self._check(self._lib.lcsgpu_lcs_triangle_dev(self._ctx, row_begin, row_end, C.c_void_p(d_out_ptr),
+                                                      elem_size, 1 if sync else 0))
+
+    def sync(self):
+        self._check(self._lib.lcsgpu_sync(self._ctx))
+
+    def last_kernel_ms(self):
+        ms = C.c_double(0)
+        n = C.c_int32(0)
+        self._check(self._lib.lcsgpu_last_kernel_ms(self._ctx, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    @staticmethod
+    def _spec(x):
+        if isinstance(x, tuple):
+            return None, None, int(x[0]), int(x[1])
+        arr, ptr = _ids(x)
+        return arr, ptr, 0, len(arr)

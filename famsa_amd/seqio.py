@@ -1,0 +1,99 @@
+"""Sequence input helpers shared by tests and bench.py: FASTA reading with the reference's
+line handling (reference core/io_service.h:84-127) and the deterministic synthetic sets of
+BASELINE.md.  Pure host-side data plumbing; encoding goes through lcsgpu_encode."""
+import numpy as np
+
+ALPHABET = "ARNDCQEGHILKMFPSTWYVBZX*"  # reference core/sequence.cpp:17
+
+
+def read_fasta(path):
+    """Returns (ids, residues) as lists of str; ids keep the leading '>'."""
+    ids, seqs = [], []
+    cur_id, cur = "", []
+    with open(path, "rb") as f:
+        data = f.read().decode("latin-1")
+    for line in data.split("\n"):
+        line = line.rstrip("\r\n")
+        if not line:
+            continue
+        if line[0] == ">":
+            if cur_id and cur:
+                ids.append(cur_id)
+                seqs.append("".join(cur))
+                cur = []
+            cur_id = line
+        else:
+            cur.append(line)
+    if cur_id and cur:
+        ids.append(cur_id)
+        seqs.append("".join(cur))
+    return ids, seqs
+
+
+def pack(seqs):
+    """list of uint8 arrays -> (codes, offsets[n+1] uint64)."""
+    lens = np.array([len(s) for s in seqs], dtype=np.uint64)
+    offsets = np.zeros(len(seqs) + 1, dtype=np.uint64)
+    np.cumsum(lens, out=offsets[1:])
+    codes = np.concatenate(seqs).astype(np.uint8) if len(seqs) and offsets[-1] > 0 else np.zeros(0, np.uint8)
+    return codes, offsets
+
+
+def sort_order(seqs):
+    """Order of CFAMSA::sortAndExtendSequences (reference msa.cpp:245-258): stable sort by
+    length descending, then lexicographic over the symbol codes ascending."""
+    keys = [(-len(s), bytes(s)) for s in seqs]
+    return sorted(range(len(seqs)), key=lambda i: keys[i])
+
+
+def _splitmix64(x):
+    x = (x + np.uint64(0x9E3779B97F4A7C15)).astype(np.uint64)
+    z = x
+    z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+    z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    return z ^ (z >> np.uint64(31))
+
+
+def synth_uniform(n, length=400, seed=None):
+    """n sequences of fixed length, residues i.i.d. uniform over the 20 valid codes.
+    Counter-based splitmix64 stream, seed 0xFA15A + n."""
+    if seed is None:
+        seed = 0xFA15A + n
+    with np.errstate(over="ignore"):
+        idx = np.arange(n * length, dtype=np.uint64)
+        z = _splitmix64(idx * np.uint64(0x9E3779B97F4A7C15) + np.uint64(seed))
+        z = _splitmix64(z)
+    codes = ((z >> np.uint64(11)) % np.uint64(20)).astype(np.uint8)
+    offsets = (np.arange(n + 1, dtype=np.uint64) * np.uint64(length)).astype(np.uint64)
+    return codes, offsets
+
+
+def synth_family(n, length=400, seed=None, sub=0.25, indel=0.05):
+    """'Family' set: one random ancestor, every member = ancestor with `sub` substitutions and
+    `indel` insertions/deletions; returned sorted like the reference sorts (length desc)."""
+    if seed is None:
+        seed = 0xFA15A + n + 7
+    rng = np.random.Generator(np.random.PCG64(seed))
+    anc = rng.integers(0, 20, size=length, dtype=np.uint8)
+    seqs = []
+    for _ in range(n):
+        s = anc.copy()
+        m = rng.random(length) < sub
+        s[m] = rng.integers(0, 20, size=int(m.sum()), dtype=np.uint8)
+        keep = rng.random(length) >= indel / 2
+        s = s[keep]
+        n_ins = int(rng.binomial(len(s), indel / 2))
+        pos = np.sort(rng.integers(0, len(s) + 1, size=n_ins))
+        s = np.insert(s, pos, rng.integers(0, 20, size=n_ins, dtype=np.uint8))
+        seqs.append(s.astype(np.uint8))
+    order = sort_order(seqs)
+    return [seqs[i] for i in order]
+
+
+def to_fasta(codes, offsets, path, prefix="s"):
+    with open(path, "w") as f:
+        for i in range(len(offsets) - 1):
+            s = codes[int(offsets[i]):int(offsets[i + 1])]
+            f.write(f">{prefix}{i}\n")
+            f.write("".join(ALPHABET[c] for c in s))
+            f.write("\n")

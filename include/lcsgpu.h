@@ -1,0 +1,123 @@
+/*
+ * lcsgpu.h -- C-ABI of the MI355X (gfx950) all-pairs bit-parallel LCS engine.
+ *
+ * This is the drop-in boundary for FAMSA's pairwise-similarity hot path.  FAMSA has
+ * no FFI/plugin layer of its own; the seam is C++-internal.  Each
+ * entry point below names the reference interface it replaces (paths relative to the
+ * reference's src/).  A maintainer would bind these from the batch-distance templates
+ * of tree/AbstractTreeGenerator.hpp -- INTEGRATION.md shows the binding.
+ *
+ * Conventions: plain C types only; every function returns 0 on success or a negative
+ * LCSGPU_E_* code, never throws; lcsgpu_last_error() gives a thread-local message.
+ * The caller owns every buffer it passes.  A context is bound to one GPU; calls on one
+ * context are serialised internally (a mutex), different contexts are independent --
+ * the multi-GPU model is one process (or one context) per GPU.
+ *
+ * Symbol codes are the reference's: index in "ARNDCQEGHILKMFPSTWYVBZX*"
+ * (core/sequence.cpp:17), 22 = unknown; only codes < 20 ever match
+ * (core/sequence.cpp:199).  All LCS values are ORIENTED: "ref" is the bit-mask side
+ * (CSequence::p_bit_masks), "partner" is streamed, exactly as in
+ * CLCSBP::GetLCSBP(ref, partners...) (lcs/lcsbp.h:36-46); the result reproduces the
+ * reference's carry rule (lcs/lcsbp_classic.h:51-58) bit for bit, so LCS(ref=a,
+ * partner=b) may differ from LCS(ref=b, partner=a) for sequences holding a 64-residue
+ * aligned homopolymer word (SURVEY.md note Q).
+ */
+#ifndef LCSGPU_H
+#define LCSGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LCSGPU_OK 0
+#define LCSGPU_E_INVALID (-1)  /* bad argument */
+#define LCSGPU_E_NODEVICE (-2) /* no usable gfx950 device / HIP runtime error at create */
+#define LCSGPU_E_HIP (-3)      /* a HIP call failed; see lcsgpu_last_error() */
+#define LCSGPU_E_NOMEM (-4)
+#define LCSGPU_E_STATE (-5)    /* e.g. compute before upload */
+
+typedef struct lcsgpu_ctx lcsgpu_ctx;
+
+/* Library / build information: "lcsgpu <version> gfx950". */
+const char* lcsgpu_version(void);
+const char* lcsgpu_last_error(void);
+
+/* Number of visible HIP devices (0 when there is no GPU); never fails. */
+int lcsgpu_device_count(void);
+
+/* Create / destroy an engine bound to HIP device `device_id`.
+ * Replaces: CLCSBP::CLCSBP(instruction_set_t) (lcs/lcsbp.cpp:24-45), one per worker. */
+int lcsgpu_create(int device_id, lcsgpu_ctx** out_ctx);
+int lcsgpu_destroy(lcsgpu_ctx* ctx);
+
+/* Residue characters -> symbol codes, gaps ('-') dropped.
+ * Replaces: the encoding loop of CSequence::CSequence (core/sequence.cpp:53-79).
+ * `codes` must hold n bytes; *n_codes receives the count written.  Host only. */
+int lcsgpu_encode(const char* residues, size_t n, uint8_t* codes, size_t* n_codes);
+
+/* Upload a sequence set (replaces any previous one): codes[offsets[i] .. offsets[i+1])
+ * is sequence i, unpadded, n sequences, ids 0..n-1 in the caller's order.
+ * Replaces: the per-sequence state the reference prepares on the host --
+ * CSequence::data/length (core/sequence.h:28-32), the padding of
+ * CFAMSA::sortAndExtendSequences/extendSequences (msa.cpp:245-317; the engine pads
+ * internally) and CSequence::ComputeBitMasks (core/sequence.cpp:190-201; masks are
+ * rebuilt on the device per launch). */
+int lcsgpu_upload(lcsgpu_ctx* ctx, const uint8_t* codes, const uint64_t* offsets, int32_t n);
+
+/* Number of sequences / length of sequence i currently uploaded (negative on error). */
+int32_t lcsgpu_count(lcsgpu_ctx* ctx);
+int32_t lcsgpu_length(lcsgpu_ctx* ctx, int32_t i);
+
+/* Rectangle of oriented LCS lengths into HOST memory:
+ *   out[r * ld + c] = LCS(ref = ref_ids[r], partner = col(c)),  r < n_refs, c < n_cols
+ * col(c) = col_ids[c] if col_ids != NULL, else col_begin + c.  elem_size is 2 (uint16_t)
+ * or 4 (uint32_t); 2 is rejected if any uploaded sequence is longer than 65535.
+ * ref_ids == NULL means refs ref_begin .. ref_begin+n_refs-1.
+ * Replaces: calculateDistanceVector (tree/AbstractTreeGenerator.hpp:130-182: one ref x a
+ * contiguous partner array) and calculateDistanceRange / calculateDistanceRangeSV
+ * (hpp:190-375: one ref x an id list), i.e. the CLCSBP::GetLCSBP groups of 8
+ * (lcs/lcsbp.cpp:163,267) for many refs at once, without the Transform. */
+int lcsgpu_lcs_rect(lcsgpu_ctx* ctx, const int32_t* ref_ids, int32_t ref_begin, int32_t n_refs,
+                    const int32_t* col_ids, int32_t col_begin, int32_t n_cols, void* out,
+                    int64_t ld, int elem_size);
+
+/* Same, result left in DEVICE memory (d_out is a device pointer on ctx's GPU, e.g. a
+ * torch tensor's data_ptr()); asynchronous on the context's stream unless `sync` != 0.
+ * ref_ids / col_ids are HOST arrays (copied by the call). */
+int lcsgpu_lcs_rect_dev(lcsgpu_ctx* ctx, const int32_t* ref_ids, int32_t ref_begin, int32_t n_refs,
+                        const int32_t* col_ids, int32_t col_begin, int32_t n_cols, void* d_out,
+                        int64_t ld, int elem_size, int sync);
+
+/* Rows [row_begin, row_end) of the lower triangle, ref = row i, partner = column j < i:
+ *   out[i*(i-1)/2 + j - row_begin*(row_begin-1)/2] = LCS(ref = i, partner = j)
+ * i.e. TriangleMatrix::access(i, j) (tree/TreeDefs.h:115-120) relative to the first row.
+ * Rows are independent, so a node's GPUs take disjoint row blocks (no data-path
+ * collective).  Host-memory and device-memory forms.
+ * Replaces: calculateDistanceMatrix (tree/AbstractTreeGenerator.hpp:378-398) and the row
+ * producers UPGMA::computeDistances (tree/UPGMA.cpp:75-109), SingleLinkage::run workers
+ * (tree/SingleLinkage.cpp:48-82), DistanceCalculator::run workers
+ * (tree/DistanceCalculator.cpp:28-82). */
+int lcsgpu_lcs_triangle(lcsgpu_ctx* ctx, int32_t row_begin, int32_t row_end, void* out,
+                        int elem_size);
+int lcsgpu_lcs_triangle_dev(lcsgpu_ctx* ctx, int32_t row_begin, int32_t row_end, void* d_out,
+                            int elem_size, int sync);
+
+/* Block until everything queued on the context's stream has finished. */
+int lcsgpu_sync(lcsgpu_ctx* ctx);
+
+/* Timing of the LCS kernels of the most recent *_dev / host call on this context, measured
+ * with HIP events on the stream the kernels were launched on: total milliseconds and the
+ * number of kernel launches it covers.  Used by bench.py for the roofline figure. */
+int lcsgpu_last_kernel_ms(lcsgpu_ctx* ctx, double* ms, int32_t* n_launches);
+
+/* Raw stream handle (hipStream_t) of the context, for callers that enqueue their own
+ * work behind the engine's. */
+void* lcsgpu_stream(lcsgpu_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LCSGPU_H */

@@ -1,0 +1,135 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path through the C-ABI against the
+committed golden fixtures (made from the reference itself) and against the oracle on the same
+seeded inputs.  Integer results: the bar is bit-exact."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_bind
+from famsa_amd import lcsgpu, seqio
+
+pytestmark = pytest.mark.gpu
+G = oracle_bind.GOLDEN
+
+
+def load_set(path):
+    ids, seqs = seqio.read_fasta(path)
+    return ids, [lcsgpu.encode(s) for s in seqs]
+
+
+def test_native_library_is_loaded(engine):
+    import famsa_amd
+    assert os.path.exists(famsa_amd.library_path())
+    assert b"gfx950" in famsa_amd.load_library().lcsgpu_version()
+
+
+def test_encode_matches_oracle(oracle):
+    s = "ARNDCQEGHILKMFPSTWYVBZX*arndbzx-?JOU{}~ \t1"
+    assert list(lcsgpu.encode(s)) == list(oracle.encode(s))
+
+
+def test_adeno_square_vs_reference_golden(engine):
+    ids, enc = load_set(os.path.join(G, "adeno_fiber", "adeno_fiber"))
+    engine.upload_seqs(enc)
+    n = len(enc)
+    gold = np.load(os.path.join(G, "adeno_fiber", "lcs_square.npz"))["lcs"]
+    got = engine.lcs_rect((0, n), (0, n))
+    assert got.dtype == np.uint16 and got.shape == (n, n)
+    assert (got == gold).all()
+    got32 = engine.lcs_rect(np.arange(n), np.arange(n), dtype=np.uint32)
+    assert (got32 == gold).all()
+
+
+def test_adversarial_quirk_and_edges_vs_reference_golden(engine):
+    """Homopolymer carry quirk (orientation dependent), lengths 1..2048, B/Z/X/*, duplicates."""
+    ids, enc = load_set(os.path.join(G, "adversarial.fasta"))
+    engine.upload_seqs(enc)
+    n = len(enc)
+    gold = np.load(os.path.join(G, "adversarial_lcs.npz"))["classic"]
+    got = engine.lcs_rect((0, n), (0, n))
+    bad = np.argwhere(got != gold)
+    assert len(bad) == 0, f"first mismatches (ref,partner): {bad[:10].tolist()}"
+    assert (got != got.T).any()  # the orientation dependence is really exercised
+    tri = engine.lcs_triangle()
+    il = np.tril_indices(n, -1)
+    assert (tri == gold[il]).all()
+
+
+def test_hemopexin_triangle_checksum_and_rows(engine, oracle):
+    ids, enc = load_set(os.path.join(G, "hemopexin", "hemopexin"))
+    engine.upload_seqs(enc)
+    n = len(enc)
+    meta = json.load(open(os.path.join(G, "meta.json")))
+    tri = engine.lcs_triangle()
+    assert hashlib.sha256(tri.tobytes()).hexdigest() == meta["hemopexin"]["triangle_u16_sha256"]
+    z = np.load(os.path.join(G, "hemopexin", "lcs_rows.npz"))
+    got = engine.lcs_rect(z["rows"], (0, n))
+    assert (got == z["lcs"]).all()
+    # row-block split (what each rank of a multi-GPU job computes) is the same triangle
+    cuts = [0, 1, 700, 701, 2048, n]
+    parts = [engine.lcs_triangle(a, b) for a, b in zip(cuts[:-1], cuts[1:])]
+    assert (np.concatenate(parts) == tri).all()
+
+
+def test_sorted_order_triangle_vs_oracle(engine, oracle):
+    """The tree builders run on the length-sorted set (reference msa.cpp:245-279)."""
+    ids, enc = load_set(os.path.join(G, "hemopexin", "hemopexin"))
+    order = seqio.sort_order(enc)[:1500]
+    enc = [enc[i] for i in order]
+    engine.upload_seqs(enc)
+    codes, offsets = seqio.pack(enc)
+    want = oracle.triangle(codes, offsets)
+    got = engine.lcs_triangle(dtype=np.uint32)
+    assert (got == want).all()
+
+
+def test_synthetic_2k_checksum(engine):
+    meta = json.load(open(os.path.join(G, "meta.json")))
+    codes, offsets = seqio.synth_uniform(2000, 400)
+    engine.upload(codes, offsets)
+    tri = engine.lcs_triangle()
+    assert hashlib.sha256(tri.tobytes()).hexdigest() == meta["synth2k"]["triangle_u16_sha256"]
+
+
+def test_gather_lists_ragged_shapes(engine, oracle):
+    """calculateDistanceRange-style calls: one or a few refs against an arbitrary id list."""
+    rng = np.random.Generator(np.random.PCG64(11))
+    seqs = [rng.integers(0, 24, size=int(l)).astype(np.uint8) for l in rng.integers(0, 700, size=333)]
+    seqs[5] = np.zeros(0, np.uint8)  # empty sequence
+    engine.upload_seqs(seqs)
+    codes, offsets = seqio.pack(seqs)
+    for n_refs, n_cols in [(1, 1), (1, 257), (3, 64), (17, 300), (40, 333), (5, 0), (0, 5)]:
+        refs = rng.integers(0, len(seqs), size=n_refs)
+        cols = rng.integers(0, len(seqs), size=n_cols)
+        got = engine.lcs_rect(refs, cols, dtype=np.uint32)
+        want = oracle.rect(codes, offsets, refs, cols) if n_refs and n_cols else np.zeros((n_refs, n_cols), np.uint32)
+        assert got.shape == want.shape
+        assert (got == want).all()
+
+
+def test_all_word_counts(engine, oracle):
+    """Every instantiated word count 1..32 (reference unrolls 1..32, lcs/lcsbp_classic.cpp:47-85)."""
+    rng = np.random.Generator(np.random.PCG64(5))
+    lens = [1 + 64 * k + int(rng.integers(0, 64)) for k in range(32)] + [64 * k for k in range(1, 33)]
+    seqs = [rng.integers(0, 20, size=l).astype(np.uint8) for l in lens]
+    engine.upload_seqs(seqs)
+    codes, offsets = seqio.pack(seqs)
+    n = len(seqs)
+    want = oracle.rect(codes, offsets, np.arange(n), np.arange(n))
+    got = engine.lcs_rect((0, n), (0, n))
+    bad = np.argwhere(got != want)
+    assert len(bad) == 0, bad[:10].tolist()
+
+
+def test_errors_are_reported(engine):
+    import famsa_amd
+    engine.upload_seqs([np.zeros(10, np.uint8)] * 3)
+    with pytest.raises(famsa_amd.LcsGpuError):
+        engine.lcs_rect(np.array([7]), (0, 3))
+    with pytest.raises(famsa_amd.LcsGpuError):
+        engine.lcs_rect((0, 3), (1, 3))
+    with pytest.raises(famsa_amd.LcsGpuError):
+        engine.upload_seqs([np.full(4, 40, np.uint8)])
