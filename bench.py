@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""bench.py -- all-pairs bit-parallel LCS throughput on MI355X (the metric of BASELINE.json).
+
+One "step" = one full pass of the hot path over the synthetic set already resident in HBM:
+every pair (ref = row i, partner = column j < i) of the lower triangle -> integer LCS (uint16,
+left in HBM), then the per-row minima of the distance keys (the single-linkage exchange payload).
+With N > 1 ranks (one process per GPU, torch.distributed over RCCL) the rows are split into N
+row blocks of equal pair count -- no data-path collective for the LCS itself -- and each step
+ends with the all-gather of the per-row minima (n x 16 bytes).  The total work is fixed, so the
+scaling is "strong".
+
+    python bench.py [--gpus N --steps K --warmup W] [--n 100000 --len 400]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line.  `cpu_baseline` times the REFERENCE's own AVX2 path
+(oracle/_ref/libfamsa_ref.so = /root/reference sources + oracle/ref_harness.cpp) on a bounded
+sample of the same workload on this host's cores; the oracle is only the reported baseline and
+is never on the measured GPU path.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ALGO_BYTES_PER_PAIR_EXTRA = 2  # uint16 result; + len_partner residue bytes
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def row_cuts(n, parts):
+    """Row-block boundaries with equal pair counts: row i has i pairs, so cut at n*sqrt(k/parts)."""
+    cuts = [int(round(n * math.sqrt(k / parts))) for k in range(parts + 1)]
+    cuts[0], cuts[-1] = 0, n
+    return cuts
+
+
+def cpu_baseline(n, length, target_s=12.0):
+    """The reference's UPGMA::computeDistances (tree/UPGMA.cpp:75-109, AVX2 dispatch) on the first
+    n_use sequences of the same synthetic set, all host cores."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_bind
+    from famsa_amd import seqio
+    if not oracle_bind.have_ref():
+        return None
+    ref = oracle_bind.Ref()
+    threads = len(os.sched_getaffinity(0))
+    n_probe = min(n, 3000)
+    codes, offsets = seqio.synth_uniform(n, length)
+    # the sample is a prefix of the same set (fixed length => already in the reference's order up to ties)
+    n_load = min(n, 60000)
+    path = f"/tmp/bench_synth_{n}_{length}_{n_load}.fasta"
+    seqio.to_fasta(codes[: int(offsets[n_load])], offsets[: n_load + 1], path)
+    h = ref.open_fasta(path)
+    sec, pairs, cells, _ = ref.time_triangle(h, n_probe, threads)
+    rate = pairs / max(sec, 1e-6)
+    n_use = int(min(n_load, max(n_probe, math.sqrt(2 * rate * target_s))))
+    if n_use > n_probe:
+        sec, pairs, cells, _ = ref.time_triangle(h, n_use, threads)
+    ref.close(h)
+    os.unlink(path)
+    return {
+        "value": cells / sec / 1e9,
+        "unit": "Gcell/s",
+        "cores": threads,
+        "kind": "reference",
+        "pairs_per_s": pairs / sec,
+        "seconds": sec,
+        "sample": f"reference UPGMA::computeDistances (AVX2 dispatch, {threads} threads) on the first "
+                  f"{n_use} of the {n} synthetic sequences = {int(pairs)} pairs",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n", type=int, default=100000)
+    ap.add_argument("--len", type=int, default=400)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import famsa_amd
+    from famsa_amd import seqio
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    n, L = args.n, args.len
+    codes, offsets = seqio.synth_uniform(n, L)
+    eng = famsa_amd.LcsGpu(local_rank)
+    eng.upload(codes, offsets)  # inputs resident in HBM before the timed region
+
+    cuts = row_cuts(n, world)
+    r0, r1 = cuts[rank], cuts[rank + 1]
+    my_pairs = r1 * (r1 - 1) // 2 - r0 * (r0 - 1) // 2
+    total_pairs = n * (n - 1) // 2
+    tri = torch.empty(max(my_pairs, 1), dtype=torch.int16, device=dev)
+    max_rows = max(cuts[k + 1] - cuts[k] for k in range(world))
+    mins = torch.zeros(max_rows * 2, dtype=torch.float64, device=dev)  # (double, int64) records
+    gathered = torch.zeros(world * max_rows * 2, dtype=torch.float64, device=dev) if world > 1 else None
+    ext = torch.cuda.ExternalStream(eng._lib.lcsgpu_stream(eng._ctx), device=dev)
+
+    kernel_ms = []
+
+    def step():
+        if world > 1:  # the previous step's all-gather still reads `mins`
+            ext.wait_stream(torch.cuda.current_stream())
+        eng.lcs_triangle_dev(r0, r1, tri.data_ptr(), 2)
+        eng.row_minima_dev(tri.data_ptr(), 2, r0, r1, 1, mins.data_ptr())
+        if world > 1:
+            torch.cuda.current_stream().wait_stream(ext)
+            dist.all_gather_into_tensor(gathered, mins)
+        ms, _ = eng.last_kernel_ms()  # HIP events on the engine's stream, around the LCS launch
+        kernel_ms.append(ms)
+
+    def fence():
+        eng.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    kernel_ms.clear()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # size-independent sanity property kept outside the timed region: every LCS <= min(len)
+    assert int(tri[: max(my_pairs, 1)].to(torch.int32).max().item()) <= L
+
+    if rank == 0:
+        cells = float(total_pairs) * L * L
+        ms_per_step = elapsed / args.steps * 1e3
+        value = cells * args.steps / elapsed / 1e9
+        k_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
+        algo_bytes = my_pairs * (L + ALGO_BYTES_PER_PAIR_EXTRA)
+        achieved = algo_bytes / (k_ms * 1e-3) / 1e9
+        word_steps = my_pairs * L * ((L + 63) // 64)
+        out = {
+            "metric": "lcs_gcell_updates_per_s",
+            "value": value,
+            "unit": "Gcell/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "u64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"synthetic {n} proteins x {L} aa (uniform over 20 residues), full all-pairs LCS "
+                            f"lower triangle -> uint16 in HBM + per-row distance minima",
+                "n_seqs": n, "seq_len": L, "pairs": total_pairs,
+                "parallelism": f"rowblock{world}" + ("+allgather(row minima)" if world > 1 else ""),
+            },
+            "pairs_per_s": total_pairs * args.steps / elapsed,
+            "roofline": {
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "kernel": "lcs_rows_kernel<7,4,false>",
+                "kernel_ms": k_ms,
+                "algorithmic_bytes_per_pair": L + ALGO_BYTES_PER_PAIR_EXTRA,
+                "note": "integer-VALU bound by construction (SURVEY 8d): see valu_* fields",
+                "valu_word_steps_per_s": word_steps / (k_ms * 1e-3),
+                "valu_ops_per_word_step": 6,
+            },
+        }
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                cb = cpu_baseline(n, L)
+            except Exception as e:  # the baseline is a report, never a reason to lose the GPU number
+                cb = {"error": repr(e)}
+            out["cpu_baseline"] = cb
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -38,4 +38,15 @@ int quirk_bv_class(uint32_t len);
 int refs_per_block(int bv, bool quirk);
 hipError_t launch_rows(int bv, bool quirk, const RowsArgs& a, int grid_x, int grid_y, hipStream_t stream);
 
+
+struct RowMin {
+    double dist;
+    int64_t index;
+};
+
+// per-row minima over a triangle slice (see lcsgpu_row_minima_dev in include/lcsgpu.h)
+hipError_t launch_row_minima(const void* tri, int elem_size, int32_t row_begin, int32_t row_end,
+                             const uint32_t* lens, const double* pow_table, int kind, RowMin* out,
+                             hipStream_t stream);
+
 } // namespace lcsgpu

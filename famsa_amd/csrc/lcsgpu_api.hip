@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cmath>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -94,7 +95,7 @@ struct lcsgpu_ctx {
     uint32_t max_len = 0;
     std::vector<uint32_t> lens;
     std::vector<uint8_t> quirk; // ref needs the literal (V2 < V) carry rule
-    DevBuf d_tiles, d_tile_base, d_lens;
+    DevBuf d_tiles, d_tile_base, d_lens, d_pow;
 
     // per-call scratch
     DevBuf d_plan, d_out;
@@ -322,6 +323,7 @@ int lcsgpu_destroy(lcsgpu_ctx* ctx)
     ctx->d_tiles.release();
     ctx->d_tile_base.release();
     ctx->d_lens.release();
+    ctx->d_pow.release();
     ctx->d_plan.release();
     ctx->d_out.release();
     ctx->h_plan.release();
@@ -413,6 +415,14 @@ int lcsgpu_upload(lcsgpu_ctx* ctx, const uint8_t* codes, const uint64_t* offsets
     if (e != hipSuccess) return fail(LCSGPU_E_HIP, "tile upload failed: %s", hipGetErrorString(e));
     HIP_TRY(hipMemcpy(ctx->d_tile_base.p, tile_base.data(), ((size_t)n_tiles + 1) * 8, hipMemcpyHostToDevice));
     if (n) HIP_TRY(hipMemcpy(ctx->d_lens.p, lens.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+    {
+        // pow(indel, 0.75) for every possible indel, from the host's libm -- the entries of
+        // Transform<double, indel075_div_lcs>::pp_pow075_rec (reference AbstractTreeGenerator.hpp:43-48)
+        std::vector<double> pw((size_t)2 * max_len + 1);
+        for (size_t i = 0; i < pw.size(); ++i) pw[i] = pow((double)(uint32_t)i, 0.75);
+        HIP_TRY(ctx->d_pow.reserve(pw.size() * 8));
+        HIP_TRY(hipMemcpy(ctx->d_pow.p, pw.data(), pw.size() * 8, hipMemcpyHostToDevice));
+    }
     ctx->lens.swap(lens);
     ctx->quirk.swap(quirk);
     ctx->max_len = max_len;
@@ -504,6 +514,26 @@ int lcsgpu_lcs_triangle(lcsgpu_ctx* ctx, int32_t row_begin, int32_t row_end, voi
     HIP_TRY(hipMemcpyAsync(out, ctx->d_out.p, (size_t)count * elem_size, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     ctx->plan_in_flight = false;
+    return LCSGPU_OK;
+}
+
+int lcsgpu_row_minima_dev(lcsgpu_ctx* ctx, const void* d_triangle, int elem_size, int32_t row_begin,
+                          int32_t row_end, int distance_kind, void* d_out, int sync)
+{
+    if (!ctx) return fail(LCSGPU_E_INVALID, "NULL ctx");
+    if (ctx->n < 0) return fail(LCSGPU_E_STATE, "no sequence set uploaded");
+    if (row_begin < 0 || row_end < row_begin || row_end > ctx->n) return fail(LCSGPU_E_INVALID, "bad row range");
+    if (elem_size != 2 && elem_size != 4) return fail(LCSGPU_E_INVALID, "elem_size must be 2 or 4");
+    if (distance_kind != LCSGPU_DIST_INDEL_DIV_LCS && distance_kind != LCSGPU_DIST_INDEL075_DIV_LCS)
+        return fail(LCSGPU_E_INVALID, "unknown distance kind %d", distance_kind);
+    if (row_end == row_begin) return LCSGPU_OK;
+    if (!d_triangle || !d_out) return fail(LCSGPU_E_INVALID, "NULL device pointer");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(lcsgpu::launch_row_minima(d_triangle, elem_size, row_begin, row_end, (const uint32_t*)ctx->d_lens.p,
+                                      (const double*)ctx->d_pow.p, distance_kind, (lcsgpu::RowMin*)d_out,
+                                      ctx->stream));
+    if (sync) HIP_TRY(hipStreamSynchronize(ctx->stream));
     return LCSGPU_OK;
 }
 

@@ -43,6 +43,7 @@ def load_library():
         "lcsgpu_lcs_rect_dev": (C.c_int, [vp, pi32, i32, i32, pi32, i32, i32, vp, i64, C.c_int, C.c_int]),
         "lcsgpu_lcs_triangle": (C.c_int, [vp, i32, i32, vp, C.c_int]),
         "lcsgpu_lcs_triangle_dev": (C.c_int, [vp, i32, i32, vp, C.c_int, C.c_int]),
+        "lcsgpu_row_minima_dev": (C.c_int, [vp, vp, C.c_int, i32, i32, C.c_int, vp, C.c_int]),
         "lcsgpu_sync": (C.c_int, [vp]),
         "lcsgpu_last_kernel_ms": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(i32)]),
         "lcsgpu_stream": (vp, [vp]),
@@ -142,6 +143,10 @@ class LcsGpu:
     def lcs_triangle_dev(self, row_begin, row_end, d_out_ptr, elem_size, sync=False):
         self._check(self._lib.lcsgpu_lcs_triangle_dev(self._ctx, row_begin, row_end, C.c_void_p(d_out_ptr),
                                                       elem_size, 1 if sync else 0))
+
+    def row_minima_dev(self, d_tri_ptr, elem_size, row_begin, row_end, kind, d_out_ptr, sync=False):
+        self._check(self._lib.lcsgpu_row_minima_dev(self._ctx, C.c_void_p(d_tri_ptr), elem_size, row_begin,
+                                                    row_end, kind, C.c_void_p(d_out_ptr), 1 if sync else 0))
 
     def sync(self):
         self._check(self._lib.lcsgpu_sync(self._ctx))

@@ -105,6 +105,32 @@ int lcsgpu_lcs_triangle(lcsgpu_ctx* ctx, int32_t row_begin, int32_t row_end, voi
 int lcsgpu_lcs_triangle_dev(lcsgpu_ctx* ctx, int32_t row_begin, int32_t row_end, void* d_out,
                             int elem_size, int sync);
 
+
+/* Distance measures of the reference's Transform functors (tree/AbstractTreeGenerator.hpp:28-82,
+ * enum Distance in tree/TreeDefs.h:20-27). */
+#define LCSGPU_DIST_INDEL_DIV_LCS 0    /* (double)indel / lcs                           */
+#define LCSGPU_DIST_INDEL075_DIV_LCS 1 /* pow(indel, 0.75) / lcs  (the CLI default)      */
+
+/* One row's nearest neighbour among the columns j < i of the lower triangle. */
+typedef struct lcsgpu_rowmin {
+    double dist;   /* Transform<double, kind>(lcs, len_i, len_j); DBL_MAX if the row is empty */
+    int64_t index; /* the column j attaining it; -1 if the row is empty                       */
+} lcsgpu_rowmin;
+
+/* Per-row minima over a DEVICE-resident triangle slice produced by lcsgpu_lcs_triangle_dev for
+ * the same [row_begin, row_end):  out[i - row_begin] = min over j < i of the key
+ *   (d(i,j), ~((uint64)j << 32 | i))   compared lexicographically,
+ * which is the edge order of MSTPrim (tree/MSTPrim.cpp:493-509, mst_edge_t / ids_to_uint64 in
+ * tree/MSTPrim.h:432-483): smaller distance first, and among equal distances the LARGER j.
+ * d is computed in double exactly as Transform<double, kind> does: indel = len_i + len_j - 2*lcs,
+ * pow(indel, 0.75) taken from a table the library fills on the HOST with libm's pow (so the
+ * values are the reference's), IEEE double division on the device; lcs == 0 gives
+ * nextafter(DBL_MAX, 0).  This is the payload of the single-linkage exchange step: each GPU
+ * reduces its own row block, then the ranks allgather n x 16 bytes (RCCL over xGMI).
+ * d_out is a device pointer to (row_end - row_begin) lcsgpu_rowmin records. */
+int lcsgpu_row_minima_dev(lcsgpu_ctx* ctx, const void* d_triangle, int elem_size, int32_t row_begin,
+                          int32_t row_end, int distance_kind, void* d_out, int sync);
+
 /* Block until everything queued on the context's stream has finished. */
 int lcsgpu_sync(lcsgpu_ctx* ctx);
 

@@ -133,3 +133,32 @@ def test_errors_are_reported(engine):
         engine.lcs_rect((0, 3), (1, 3))
     with pytest.raises(famsa_amd.LcsGpuError):
         engine.upload_seqs([np.full(4, 40, np.uint8)])
+
+
+def test_row_minima_vs_oracle(engine, oracle):
+    """Per-row nearest neighbour with MSTPrim's tie rule, distances as Transform<double,...>."""
+    import torch
+    ids, enc = load_set(os.path.join(G, "hemopexin", "hemopexin"))
+    order = seqio.sort_order(enc)[:1200]
+    enc = [enc[i] for i in order] + [np.full(40, 22, np.uint8)]  # last row: lcs 0 against everything
+    engine.upload_seqs(enc)
+    n = len(enc)
+    lens = np.array([len(e) for e in enc])
+    codes, offsets = seqio.pack(enc)
+    lcs = oracle.triangle(codes, offsets)
+    for kind, fn in [(1, oracle.lib.oracle_dist_indel075_f64), (0, oracle.lib.oracle_dist_indel_f64)]:
+        r0, r1 = 0, n
+        pairs = n * (n - 1) // 2
+        tri = torch.empty(pairs, dtype=torch.int16, device="cuda:0")
+        engine.lcs_triangle_dev(r0, r1, tri.data_ptr(), 2)
+        out = torch.zeros((n, 2), dtype=torch.float64, device="cuda:0")
+        engine.row_minima_dev(tri.data_ptr(), 2, r0, r1, kind, out.data_ptr(), sync=True)
+        d = out[:, 0].cpu().numpy()
+        j = out[:, 1].cpu().numpy().view(np.int64)
+        assert j[0] == -1 and d[0] == np.finfo(np.float64).max
+        for i in list(range(1, 40)) + list(range(40, n, 37)) + [n - 1]:
+            row = lcs[i * (i - 1) // 2: i * (i - 1) // 2 + i]
+            dd = np.array([fn(int(l), int(lens[i]), int(lens[k])) for k, l in enumerate(row)])
+            m = dd.min()
+            want_j = int(np.max(np.nonzero(dd == m)[0]))
+            assert d[i] == m and j[i] == want_j, (i, d[i], m, j[i], want_j)
