@@ -32,11 +32,15 @@ struct RowsArgs {
     int32_t refs_per_block;
 };
 
-// instantiated word counts: exact 1..16, even 18..32; 0 = needs the long-sequence path
-int bv_class(uint32_t len);
-int quirk_bv_class(uint32_t len);
-int refs_per_block(int bv, bool quirk);
-hipError_t launch_rows(int bv, bool quirk, const RowsArgs& a, int grid_x, int grid_y, hipStream_t stream);
+// instantiated half-word (32-bit) counts: exact 1..32, even 34..64; 0 = the long-sequence path
+int h_class(uint32_t len);
+int quirk_h_class(uint32_t len);
+int refs_per_block(int h, bool quirk);
+hipError_t launch_rows(int h, bool quirk, const RowsArgs& a, int grid_x, int grid_y, hipStream_t stream);
+// refs longer than 2048 residues: needs grid_x*grid_y*n_chunks_max*512 bytes of carry scratch
+size_t long_carry_bytes(int grid_x, int grid_y, int n_chunks_max);
+hipError_t launch_long(bool quirk, const RowsArgs& a, int grid_x, int grid_y, void* carry, int n_chunks_max,
+                       hipStream_t stream);
 
 
 struct RowMin {

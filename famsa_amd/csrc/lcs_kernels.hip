@@ -3,21 +3,24 @@
 // One lane = one PARTNER sequence (the streamed side), one workgroup = 4 waves = 256
 // partners x R REF sequences (the bit-mask side).  The refs' complemented occurrence masks
 // nM[ref][word][code] live in LDS; every lane keeps the bit-vector X of RG refs at a time
-// in VGPRs (2 x BV x RG registers) and walks its partner's residues.  Per 64-bit word-step
-// the lane does one conflict-free ds_read_b64 gather (address = residue code x 8 inside a
-// 256-byte row, so the 20 residue codes hit 20 distinct bank pairs) and six VALU ops:
-//     tB = V & ~nM'      v_bitop3_b32 x2   (nM' = ~M, so this is V & M)
-//     V2 = V + tB + c    v_add_co/v_addc_co_u32 x2 -- one carry chain through all words
-//     X  = V2 | (V & nM) v_bitop3_b32 x2
+// in VGPRs (H x RG registers, H = number of 32-bit half-words = ceil(len_ref/32)) and walks
+// its partner's residues.  Per 64-bit word-step the lane does one conflict-free ds_read_b64
+// gather (address = residue code x 8 inside a 256-byte row, so the 20 residue codes hit 20
+// distinct bank pairs) and six VALU ops, three per 32-bit half:
+//     tB = V & ~nM       v_bitop3_b32      (nM = ~M, so this is V & M)
+//     V2 = V + tB + c    v_add(c)_co_u32   -- one carry chain through all half-words
+//     X  = V2 | (V & nM) v_bitop3_b32
 // which is the recurrence of CLCSBP_Classic_Impl (reference lcs/lcsbp_classic.h:51-58,
-// 67-98) restated for 32-bit lanes.  No MFMA: this is integer/bit work.
+// 67-98) restated for 32-bit lanes.  Working in half-words saves the dead upper half of the
+// last 64-bit word (400 aa: 13 half-words instead of 14).  No MFMA: this is integer/bit work,
+// bounded by VALU issue, not by HBM.
 //
-// Exactness: the reference takes the carry out of a word as (V2 < V) AFTER adding the
+// Exactness: the reference takes the carry out of a 64-bit word as (V2 < V) AFTER adding the
 // carry-in (lcsbp_classic.h:55-56), which differs from a true 65-bit carry exactly when
 // tB == ~0 and carry-in == 1 -- only possible if the ref has an aligned 64-residue
 // homopolymer word at word index >= 1.  Such refs are flagged at upload and run through the
-// QUIRK instantiation, which evaluates the reference's rule literally; all other refs use
-// the hardware carry chain, which is provably identical for them.
+// QUIRK instantiations, which evaluate the reference's rule literally on 64-bit words; all
+// other refs use the hardware carry chain, which is provably identical for them.
 //
 // Partner residues are stored position-major per 64-sequence tile ("column" layout):
 // 16-byte chunk k of lane l of tile t sits at tile_base[t] + (k*64 + l)*16, so a wave's
@@ -25,6 +28,12 @@
 // is (symbol code * 8) = the byte offset of that code inside an LDS mask row; padding is
 // code 22 (UNKNOWN_SYMBOL, reference core/defs.h:66) whose mask is empty => a no-op step,
 // exactly what the reference's `continue` (lcsbp_classic.h:82) / padded SIMD lanes do.
+//
+// Refs longer than 2048 residues (the reference's LoopCalculate case, lcsbp_classic.cpp:83)
+// go through lcs_long_kernel: the ref is cut into segments of 32 words that are processed one
+// after another with the same register-resident step; the carry that leaves the last word of
+// a segment at partner position p is parked in a per-lane bit stream in global memory and
+// re-enters word 0 of the next segment at the same position.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -34,6 +43,7 @@ namespace lcsgpu {
 
 typedef __attribute__((address_space(3))) unsigned char lds_u8;
 typedef __attribute__((address_space(3))) uint64_t lds_u64;
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
 
 static constexpr uint32_t PAD4 = 0xB0B0B0B0u; // four bytes of 22*8
 
@@ -46,18 +56,19 @@ __device__ __forceinline__ uint32_t or_and(uint32_t s, uint32_t v, uint32_t n)
     return __builtin_amdgcn_bitop3_b32(s, v, n, 0xF8); // s | (v & n)
 }
 
-// One partner residue against RG refs x BV words.  `row` = LDS address of this residue's
-// entry in mask row 0 of ref 0 of the group.
-template <int BV, int RG, bool QUIRK>
-__device__ __forceinline__ void residue_step(const lds_u8* row, uint32_t (&X)[RG][2 * BV])
+// One partner residue against RG refs x H half-words.  `row` = LDS address of this residue's
+// entry in mask row 0 of ref 0 of the group; a ref's rows are (H+1)/2 x 256 bytes.
+template <int H, int RG, bool QUIRK>
+__device__ __forceinline__ void residue_step(const lds_u8* row, uint32_t (&X)[RG][H])
 {
+    constexpr int W = (H + 1) / 2; // 64-bit mask rows per ref
 #pragma unroll
     for (int r = 0; r < RG; ++r) {
         if constexpr (!QUIRK) {
             unsigned cin = 0;
 #pragma unroll
-            for (int j = 0; j < BV; ++j) {
-                const uint64_t nn = *(const lds_u64*)(row + (r * BV + j) * 256);
+            for (int j = 0; j < H / 2; ++j) {
+                const uint64_t nn = *(const lds_u64*)(row + (r * W + j) * 256);
                 const uint32_t n0 = (uint32_t)nn, n1 = (uint32_t)(nn >> 32);
                 unsigned co;
                 uint32_t V = X[r][2 * j];
@@ -69,12 +80,20 @@ __device__ __forceinline__ void residue_step(const lds_u8* row, uint32_t (&X)[RG
                 X[r][2 * j + 1] = or_and(s, V, n1);
                 cin = co;
             }
+            if constexpr (H & 1) {
+                const uint32_t n0 = *(const lds_u32*)(row + (r * W + H / 2) * 256);
+                unsigned co;
+                const uint32_t V = X[r][H - 1];
+                const uint32_t s = __builtin_addc(V, andn(V, n0), cin, &co);
+                X[r][H - 1] = or_and(s, V, n0);
+            }
         } else {
             // the reference's rule, literally: V2 = V + tB + cin; cin' = (V2 < V)
+            static_assert(!QUIRK || (H % 2 == 0), "quirk instantiations use whole 64-bit words");
             uint64_t cin = 0;
 #pragma unroll
-            for (int j = 0; j < BV; ++j) {
-                const uint64_t nn = *(const lds_u64*)(row + (r * BV + j) * 256);
+            for (int j = 0; j < H / 2; ++j) {
+                const uint64_t nn = *(const lds_u64*)(row + (r * W + j) * 256);
                 const uint64_t V = ((uint64_t)X[r][2 * j + 1] << 32) | X[r][2 * j];
                 const uint64_t tB = V & ~nn;
                 const uint64_t V2 = V + tB + cin;
@@ -97,53 +116,83 @@ __device__ __forceinline__ int wave_max(int v)
     return v;
 }
 
-template <int BV, int RG, bool QUIRK>
+// Complemented occurrence masks of `count` 64-bit words of ref `rid`, starting at word
+// `word0`, into LDS rows dst[(w)*32 + c] = ~M[c][word0 + w]; M as CSequence::ComputeBitMasks
+// builds it (reference core/sequence.cpp:190-201: bits only for codes < 20).  rid < 0 fills
+// "no match".  Called by all 4 waves of the workgroup; item = one word, one wave per item.
+__device__ __forceinline__ void build_mask_words(const RowsArgs& a, int rid, int word0, int count, lds_u64* dst,
+                                                 int wave, int lane)
+{
+    for (int w = wave; w < count; w += 4) {
+        uint32_t code8 = 0xFFu;
+        if (rid >= 0) {
+            const uint32_t len = a.lens[rid];
+            const uint32_t p = (uint32_t)(word0 + w) * 64 + lane;
+            if (p < len)
+                code8 = a.tiles[a.tile_base[rid >> 6] + ((uint64_t)(p >> 4) * 64 + (rid & 63)) * 16 + (p & 15)];
+        }
+        uint64_t mine = 0;
+#pragma unroll
+        for (int c = 0; c < 20; ++c) {
+            const uint64_t b = __ballot(code8 == (uint32_t)(c * 8));
+            if (lane == c)
+                mine = b;
+        }
+        if (lane < 32)
+            dst[w * 32 + lane] = ~mine;
+    }
+}
+
+__device__ __forceinline__ void store_result(const RowsArgs& a, int k, int c, uint32_t res)
+{
+    int64_t idx;
+    if (a.mode == MODE_TRIANGLE) {
+        const int64_t rid = a.ref_ids ? a.ref_ids[k] : a.ref_begin + k;
+        if (c >= rid)
+            return;
+        idx = rid * (rid - 1) / 2 + c - a.out_offset;
+    } else {
+        const int64_t row = a.ref_rows ? a.ref_rows[k] : (int64_t)k + a.row0;
+        idx = row * a.ld + c;
+    }
+    if (a.elem_size == 2)
+        ((uint16_t*)a.out)[idx] = (uint16_t)res;
+    else
+        ((uint32_t*)a.out)[idx] = res;
+}
+
+// Triangle mode: a block whose columns all lie at or beyond its largest ref id has no work.
+__device__ __forceinline__ bool block_is_above_diagonal(const RowsArgs& a, int ref0, int nr, int c0)
+{
+    if (a.mode != MODE_TRIANGLE)
+        return false;
+    int max_rid = 0;
+    for (int r = 0; r < nr; ++r) {
+        const int rid = a.ref_ids ? a.ref_ids[ref0 + r] : a.ref_begin + ref0 + r;
+        max_rid = rid > max_rid ? rid : max_rid;
+    }
+    return c0 >= max_rid;
+}
+
+template <int H, int RG, bool QUIRK>
 __global__ __launch_bounds__(256) void lcs_rows_kernel(RowsArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int W = (H + 1) / 2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int R = a.refs_per_block;
     const int ref0 = blockIdx.y * R;
     const int nr = min(R, a.n_refs - ref0);
     const int c0 = blockIdx.x * 256;
+    if (block_is_above_diagonal(a, ref0, nr, c0))
+        return;
 
-    // Triangle mode: columns are sequence ids, only pairs col < ref are wanted.
-    if (a.mode == MODE_TRIANGLE) {
-        int max_rid = 0;
-        for (int r = 0; r < nr; ++r) {
-            const int rid = a.ref_ids ? a.ref_ids[ref0 + r] : a.ref_begin + ref0 + r;
-            max_rid = rid > max_rid ? rid : max_rid;
-        }
-        if (c0 >= max_rid)
-            return;
-    }
-
-    // ---- 1. complemented occurrence masks of the block's refs -> LDS ------------------
-    // nM[(r*BV + j)*32 + c] = ~M[c][j], M as CSequence::ComputeBitMasks builds it
-    // (reference core/sequence.cpp:190-201: bits only for codes < 20).  Slots of a partial
-    // last group are filled with "no match" so the group loop needs no tail case.
+    // ---- 1. masks of the block's refs -> LDS; slots of a partial last group = "no match" --
     {
-        lds_u64* nM = (lds_u64*)smem;
         const int nr_pad = (nr + RG - 1) / RG * RG;
-        for (int item = wave; item < nr_pad * BV; item += 4) {
-            const int r = item / BV, j = item - r * BV;
-            uint32_t code8 = 0xFFu;
-            if (r < nr) {
-                const int rid = a.ref_ids ? a.ref_ids[ref0 + r] : a.ref_begin + ref0 + r;
-                const uint32_t len = a.lens[rid];
-                const uint32_t p = j * 64 + lane;
-                if (p < len)
-                    code8 = a.tiles[a.tile_base[rid >> 6] + ((uint64_t)(p >> 4) * 64 + (rid & 63)) * 16 + (p & 15)];
-            }
-            uint64_t mine = 0;
-#pragma unroll
-            for (int c = 0; c < 20; ++c) {
-                const uint64_t b = __ballot(code8 == (uint32_t)(c * 8));
-                if (lane == c)
-                    mine = b;
-            }
-            if (lane < 32)
-                nM[(r * BV + j) * 32 + lane] = ~mine;
+        for (int r = 0; r < nr_pad; ++r) {
+            const int rid = r < nr ? (a.ref_ids ? a.ref_ids[ref0 + r] : a.ref_begin + ref0 + r) : -1;
+            build_mask_words(a, rid, 0, W, (lds_u64*)smem + r * W * 32, wave, lane);
         }
     }
     __syncthreads();
@@ -151,7 +200,7 @@ __global__ __launch_bounds__(256) void lcs_rows_kernel(RowsArgs a)
     // ---- 2. this lane's partner -------------------------------------------------------
     const int c = c0 + tid;
     const bool valid = c < a.n_cols;
-    int pid = a.col_ids ? a.col_ids[valid ? c : 0] : a.col_begin + (valid ? c : 0);
+    const int pid = a.col_ids ? a.col_ids[valid ? c : 0] : a.col_begin + (valid ? c : 0);
     const uint32_t len_p = valid ? a.lens[pid] : 0u;
     const uint8_t* pbase = a.tiles + a.tile_base[pid >> 6] + (uint64_t)(pid & 63) * 16;
     const int my_chunks = (int)((len_p + 15) >> 4);
@@ -159,14 +208,14 @@ __global__ __launch_bounds__(256) void lcs_rows_kernel(RowsArgs a)
 
     // ---- 3. RG refs at a time ---------------------------------------------------------
     for (int g = 0; g < nr; g += RG) {
-        uint32_t X[RG][2 * BV];
+        uint32_t X[RG][H];
 #pragma unroll
         for (int r = 0; r < RG; ++r)
 #pragma unroll
-            for (int j = 0; j < 2 * BV; ++j)
+            for (int j = 0; j < H; ++j)
                 X[r][j] = ~0u;
 
-        const lds_u8* grp = (const lds_u8*)smem + g * (BV * 256);
+        const lds_u8* grp = (const lds_u8*)smem + g * (W * 256);
         uint4 q = make_uint4(PAD4, PAD4, PAD4, PAD4);
         if (0 < my_chunks)
             q = *(const uint4*)pbase;
@@ -178,7 +227,7 @@ __global__ __launch_bounds__(256) void lcs_rows_kernel(RowsArgs a)
 #pragma unroll
             for (int b = 0; b < 16; ++b) {
                 const uint32_t code8 = (w[b >> 2] >> (8 * (b & 3))) & 0xFFu;
-                residue_step<BV, RG, QUIRK>(grp + code8, X);
+                residue_step<H, RG, QUIRK>(grp + code8, X);
             }
             q = qn;
         }
@@ -190,90 +239,116 @@ __global__ __launch_bounds__(256) void lcs_rows_kernel(RowsArgs a)
                 continue;
             uint32_t res = 0;
 #pragma unroll
-            for (int j = 0; j < 2 * BV; ++j)
+            for (int j = 0; j < H; ++j)
                 res += __popc(~X[r][j]);
-            const int k = ref0 + g + r;
-            int64_t idx;
-            if (a.mode == MODE_TRIANGLE) {
-                const int64_t rid = a.ref_ids ? a.ref_ids[k] : a.ref_begin + k;
-                if (c >= rid)
-                    continue;
-                idx = rid * (rid - 1) / 2 + c - a.out_offset;
-            } else {
-                const int64_t row = a.ref_rows ? a.ref_rows[k] : (int64_t)k + a.row0;
-                idx = row * a.ld + c;
+            store_result(a, ref0 + g + r, c, res);
+        }
+    }
+}
+
+// ---- refs longer than 2048 residues -------------------------------------------------------
+// Segments of SEGW = 32 words; X of one segment in 64 VGPRs; carries between segments go
+// through a per-lane stream of 16-bit words (one per 16-residue chunk) in global scratch:
+// carry[(slot*n_chunks + k)*256 + tid], read and rewritten in place by each segment.
+static constexpr int SEGW = 32;
+
+template <bool QUIRK>
+__device__ __forceinline__ unsigned long_step(const lds_u8* row, uint32_t (&X)[2 * SEGW], unsigned cin_bit)
+{
+    if constexpr (!QUIRK) {
+        unsigned cin = cin_bit, co;
+#pragma unroll
+        for (int j = 0; j < SEGW; ++j) {
+            const uint64_t nn = *(const lds_u64*)(row + j * 256);
+            const uint32_t n0 = (uint32_t)nn, n1 = (uint32_t)(nn >> 32);
+            uint32_t V = X[2 * j];
+            uint32_t s = __builtin_addc(V, andn(V, n0), cin, &co);
+            X[2 * j] = or_and(s, V, n0);
+            cin = co;
+            V = X[2 * j + 1];
+            s = __builtin_addc(V, andn(V, n1), cin, &co);
+            X[2 * j + 1] = or_and(s, V, n1);
+            cin = co;
+        }
+        return cin;
+    } else {
+        uint64_t cin = cin_bit;
+#pragma unroll
+        for (int j = 0; j < SEGW; ++j) {
+            const uint64_t nn = *(const lds_u64*)(row + j * 256);
+            const uint64_t V = ((uint64_t)X[2 * j + 1] << 32) | X[2 * j];
+            const uint64_t tB = V & ~nn;
+            const uint64_t V2 = V + tB + cin;
+            cin = (V2 < V) ? 1u : 0u;
+            const uint64_t Xn = V2 | (V & nn);
+            X[2 * j] = (uint32_t)Xn;
+            X[2 * j + 1] = (uint32_t)(Xn >> 32);
+        }
+        return (unsigned)cin;
+    }
+}
+
+template <bool QUIRK>
+__global__ __launch_bounds__(256) void lcs_long_kernel(RowsArgs a, uint16_t* carry, int n_chunks_max)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[]; // SEGW x 256 bytes
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int R = a.refs_per_block;
+    const int ref0 = blockIdx.y * R;
+    const int nr = min(R, a.n_refs - ref0);
+    const int c0 = blockIdx.x * 256;
+    if (block_is_above_diagonal(a, ref0, nr, c0))
+        return;
+
+    const int c = c0 + tid;
+    const bool valid = c < a.n_cols;
+    const int pid = a.col_ids ? a.col_ids[valid ? c : 0] : a.col_begin + (valid ? c : 0);
+    const uint32_t len_p = valid ? a.lens[pid] : 0u;
+    const uint8_t* pbase = a.tiles + a.tile_base[pid >> 6] + (uint64_t)(pid & 63) * 16;
+    const int my_chunks = (int)((len_p + 15) >> 4);
+    const int wave_chunks = wave_max(my_chunks);
+    uint16_t* my_carry = carry + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * n_chunks_max) * 256 + tid;
+
+    for (int r = 0; r < nr; ++r) {
+        const int rid = a.ref_ids ? a.ref_ids[ref0 + r] : a.ref_begin + ref0 + r;
+        const int n_words = (int)((a.lens[rid] + 63) / 64);
+        const int n_seg = (n_words + SEGW - 1) / SEGW;
+        uint32_t res = 0;
+        for (int seg = 0; seg < n_seg; ++seg) {
+            __syncthreads(); // previous segment's readers are done with the masks
+            build_mask_words(a, rid, seg * SEGW, SEGW, (lds_u64*)smem, wave, lane);
+            __syncthreads();
+            uint32_t X[2 * SEGW];
+#pragma unroll
+            for (int j = 0; j < 2 * SEGW; ++j)
+                X[j] = ~0u;
+            for (int k = 0; k < wave_chunks; ++k) {
+                uint4 q = make_uint4(PAD4, PAD4, PAD4, PAD4);
+                if (k < my_chunks)
+                    q = *(const uint4*)(pbase + (size_t)k * 1024);
+                uint32_t cw = (seg > 0) ? my_carry[(size_t)k * 256] : 0u;
+                uint32_t cout = 0;
+                const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    uint32_t d = w[i];
+#pragma unroll 1
+                    for (int bb = 0; bb < 4; ++bb) {
+                        const int b = i * 4 + bb;
+                        const unsigned co = long_step<QUIRK>((const lds_u8*)smem + (d & 0xFFu), X, (cw >> b) & 1u);
+                        cout |= co << b;
+                        d >>= 8;
+                    }
+                }
+                if (seg + 1 < n_seg)
+                    my_carry[(size_t)k * 256] = (uint16_t)cout;
             }
-            if (a.elem_size == 2)
-                ((uint16_t*)a.out)[idx] = (uint16_t)res;
-            else
-                ((uint32_t*)a.out)[idx] = res;
+#pragma unroll
+            for (int j = 0; j < 2 * SEGW; ++j)
+                res += __popc(~X[j]);
         }
-    }
-}
-
-// ---- host-side dispatch ---------------------------------------------------------------
-
-int bv_class(uint32_t len)
-{
-    // word counts that have their own instantiation; others round up (extra words are
-    // all-ones no-ops, costing time but not changing the result)
-    const int bv = (int)((len + 63) / 64);
-    if (bv <= 1) return 1;
-    if (bv <= 16) return bv;
-    if (bv <= 32) return (bv + 1) & ~1;
-    return 0; // needs the long-sequence path
-}
-
-int quirk_bv_class(uint32_t len)
-{
-    const int bv = (int)((len + 63) / 64);
-    if (bv <= 4) return 4;
-    if (bv <= 8) return 8;
-    if (bv <= 16) return 16;
-    if (bv <= 32) return 32;
-    return 0;
-}
-
-static int rg_of(int bv) { return bv <= 8 ? 4 : (bv <= 16 ? 2 : 1); }
-
-int refs_per_block(int bv, bool quirk)
-{
-    const int rg = quirk ? 1 : rg_of(bv);
-    int r = (32 * 1024) / (bv * 256);
-    if (r > 32) r = 32;
-    r = r / rg * rg;
-    if (r < rg) r = rg;
-    return r;
-}
-
-template <int BV, int RG, bool QUIRK>
-static hipError_t launch_one(const RowsArgs& a, dim3 grid, hipStream_t stream)
-{
-    const size_t lds = (size_t)a.refs_per_block * BV * 256;
-    hipLaunchKernelGGL((lcs_rows_kernel<BV, RG, QUIRK>), grid, dim3(256), lds, stream, a);
-    return hipGetLastError();
-}
-
-hipError_t launch_rows(int bv, bool quirk, const RowsArgs& a, int grid_x, int grid_y, hipStream_t stream)
-{
-    const dim3 grid((unsigned)grid_x, (unsigned)grid_y);
-    if (quirk) {
-        switch (bv) {
-        case 4: return launch_one<4, 1, true>(a, grid, stream);
-        case 8: return launch_one<8, 1, true>(a, grid, stream);
-        case 16: return launch_one<16, 1, true>(a, grid, stream);
-        case 32: return launch_one<32, 1, true>(a, grid, stream);
-        default: return hipErrorInvalidValue;
-        }
-    }
-    switch (bv) {
-#define LCS_CASE(B, G) case B: return launch_one<B, G, false>(a, grid, stream);
-        LCS_CASE(1, 4) LCS_CASE(2, 4) LCS_CASE(3, 4) LCS_CASE(4, 4) LCS_CASE(5, 4) LCS_CASE(6, 4)
-        LCS_CASE(7, 4) LCS_CASE(8, 4) LCS_CASE(9, 2) LCS_CASE(10, 2) LCS_CASE(11, 2) LCS_CASE(12, 2)
-        LCS_CASE(13, 2) LCS_CASE(14, 2) LCS_CASE(15, 2) LCS_CASE(16, 2) LCS_CASE(18, 1) LCS_CASE(20, 1)
-        LCS_CASE(22, 1) LCS_CASE(24, 1) LCS_CASE(26, 1) LCS_CASE(28, 1) LCS_CASE(30, 1) LCS_CASE(32, 1)
-#undef LCS_CASE
-    default: return hipErrorInvalidValue;
+        if (valid)
+            store_result(a, ref0 + r, c, res);
     }
 }
 
@@ -328,6 +403,96 @@ __global__ __launch_bounds__(256) void row_minima_kernel(const T* __restrict__ t
         out[blockIdx.x].dist = s_d[0];
         out[blockIdx.x].index = s_j[0];
     }
+}
+
+// ---- host-side dispatch ---------------------------------------------------------------
+
+int h_class(uint32_t len)
+{
+    // half-word counts that have their own instantiation; others round up (extra half-words
+    // are all-ones no-ops: they cost time but cannot change the result)
+    const int h = (int)((len + 31) / 32);
+    if (h <= 1) return 1;
+    if (h <= 32) return h;
+    if (h <= 64) return (h + 1) & ~1;
+    return 0; // long path
+}
+
+int quirk_h_class(uint32_t len)
+{
+    const int h = (int)((len + 31) / 32);
+    if (h <= 8) return 8;
+    if (h <= 16) return 16;
+    if (h <= 32) return 32;
+    if (h <= 64) return 64;
+    return 0;
+}
+
+static int rg_of(int h) { return h <= 16 ? 4 : (h <= 32 ? 2 : 1); }
+
+int refs_per_block(int h, bool quirk)
+{
+    if (h == 0) return 8; // long path: refs are processed one after another
+    const int rg = quirk ? 1 : rg_of(h);
+    const int w = (h + 1) / 2;
+    int r = (32 * 1024) / (w * 256);
+    if (r > 32) r = 32;
+    r = r / rg * rg;
+    if (r < rg) r = rg;
+    return r;
+}
+
+template <int H, int RG, bool QUIRK>
+static hipError_t launch_one(const RowsArgs& a, dim3 grid, hipStream_t stream)
+{
+    const size_t lds = (size_t)a.refs_per_block * ((H + 1) / 2) * 256;
+    hipLaunchKernelGGL((lcs_rows_kernel<H, RG, QUIRK>), grid, dim3(256), lds, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_rows(int h, bool quirk, const RowsArgs& a, int grid_x, int grid_y, hipStream_t stream)
+{
+    const dim3 grid((unsigned)grid_x, (unsigned)grid_y);
+    if (quirk) {
+        switch (h) {
+        case 8: return launch_one<8, 1, true>(a, grid, stream);
+        case 16: return launch_one<16, 1, true>(a, grid, stream);
+        case 32: return launch_one<32, 1, true>(a, grid, stream);
+        case 64: return launch_one<64, 1, true>(a, grid, stream);
+        default: return hipErrorInvalidValue;
+        }
+    }
+    switch (h) {
+#define LCS_CASE(B, G) case B: return launch_one<B, G, false>(a, grid, stream);
+        LCS_CASE(1, 4) LCS_CASE(2, 4) LCS_CASE(3, 4) LCS_CASE(4, 4) LCS_CASE(5, 4) LCS_CASE(6, 4)
+        LCS_CASE(7, 4) LCS_CASE(8, 4) LCS_CASE(9, 4) LCS_CASE(10, 4) LCS_CASE(11, 4) LCS_CASE(12, 4)
+        LCS_CASE(13, 4) LCS_CASE(14, 4) LCS_CASE(15, 4) LCS_CASE(16, 4)
+        LCS_CASE(17, 2) LCS_CASE(18, 2) LCS_CASE(19, 2) LCS_CASE(20, 2) LCS_CASE(21, 2) LCS_CASE(22, 2)
+        LCS_CASE(23, 2) LCS_CASE(24, 2) LCS_CASE(25, 2) LCS_CASE(26, 2) LCS_CASE(27, 2) LCS_CASE(28, 2)
+        LCS_CASE(29, 2) LCS_CASE(30, 2) LCS_CASE(31, 2) LCS_CASE(32, 2)
+        LCS_CASE(34, 1) LCS_CASE(36, 1) LCS_CASE(38, 1) LCS_CASE(40, 1) LCS_CASE(42, 1) LCS_CASE(44, 1)
+        LCS_CASE(46, 1) LCS_CASE(48, 1) LCS_CASE(50, 1) LCS_CASE(52, 1) LCS_CASE(54, 1) LCS_CASE(56, 1)
+        LCS_CASE(58, 1) LCS_CASE(60, 1) LCS_CASE(62, 1) LCS_CASE(64, 1)
+#undef LCS_CASE
+    default: return hipErrorInvalidValue;
+    }
+}
+
+size_t long_carry_bytes(int grid_x, int grid_y, int n_chunks_max)
+{
+    return (size_t)grid_x * grid_y * (size_t)n_chunks_max * 256 * sizeof(uint16_t);
+}
+
+hipError_t launch_long(bool quirk, const RowsArgs& a, int grid_x, int grid_y, void* carry, int n_chunks_max,
+                       hipStream_t stream)
+{
+    const dim3 grid((unsigned)grid_x, (unsigned)grid_y);
+    const size_t lds = (size_t)SEGW * 256;
+    if (quirk)
+        hipLaunchKernelGGL(lcs_long_kernel<true>, grid, dim3(256), lds, stream, a, (uint16_t*)carry, n_chunks_max);
+    else
+        hipLaunchKernelGGL(lcs_long_kernel<false>, grid, dim3(256), lds, stream, a, (uint16_t*)carry, n_chunks_max);
+    return hipGetLastError();
 }
 
 hipError_t launch_row_minima(const void* tri, int elem_size, int32_t row_begin, int32_t row_end,

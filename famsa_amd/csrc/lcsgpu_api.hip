@@ -98,7 +98,7 @@ struct lcsgpu_ctx {
     DevBuf d_tiles, d_tile_base, d_lens, d_pow;
 
     // per-call scratch
-    DevBuf d_plan, d_out;
+    DevBuf d_plan, d_out, d_carry;
     PinBuf h_plan;
     bool plan_in_flight = false;
     int last_launches = 0;
@@ -139,16 +139,15 @@ struct Bucket {
 int make_buckets(lcsgpu_ctx* ctx, const int32_t* ref_ids, int32_t ref_begin, int32_t n_refs,
                  int64_t row0, std::vector<Bucket>& out)
 {
-    int index_of[128];
-    std::fill(index_of, index_of + 128, -1);
+    int index_of[160];
+    std::fill(index_of, index_of + 160, -1);
     for (int32_t k = 0; k < n_refs; ++k) {
         const int32_t id = ref_ids ? ref_ids[k] : ref_begin + k;
         if (id < 0 || id >= ctx->n)
             return fail(LCSGPU_E_INVALID, "ref id %d out of range [0,%d)", id, ctx->n);
         const bool q = ctx->quirk[id] != 0;
-        const int bv = q ? lcsgpu::quirk_bv_class(ctx->lens[id]) : lcsgpu::bv_class(ctx->lens[id]);
-        if (bv == 0)
-            return fail(LCSGPU_E_INVALID, "sequence %d is longer than 2048 residues (not supported yet)", id);
+        // bv = instantiated half-word count; 0 = the long-sequence kernel (> 2048 residues)
+        const int bv = q ? lcsgpu::quirk_h_class(ctx->lens[id]) : lcsgpu::h_class(ctx->lens[id]);
         const int key = bv * 2 + (q ? 1 : 0);
         if (index_of[key] < 0) {
             index_of[key] = (int)out.size();
@@ -264,9 +263,31 @@ int run_rows(lcsgpu_ctx* ctx, int mode, const int32_t* ref_ids, int32_t ref_begi
         }
         const int gx = (use_cols + 255) / 256;
         const int gy = (a.n_refs + a.refs_per_block - 1) / a.refs_per_block;
-        if (gy > 65535) return fail(LCSGPU_E_INVALID, "too many ref tiles in one call (%d)", gy);
-        HIP_TRY(lcsgpu::launch_rows(bk.bv, bk.quirk, a, gx, gy, ctx->stream));
-        ++ctx->last_launches;
+        if (bk.bv != 0) {
+            if (gy > 65535) return fail(LCSGPU_E_INVALID, "too many ref tiles in one call (%d)", gy);
+            HIP_TRY(lcsgpu::launch_rows(bk.bv, bk.quirk, a, gx, gy, ctx->stream));
+            ++ctx->last_launches;
+        } else {
+            // long refs: slices of ref blocks so the carry scratch stays bounded
+            const int n_chunks_max = (int)((ctx->max_len + 15) / 16);
+            const int gy_step = std::max(1, 1024 / gx);
+            HIP_TRY(ctx->d_carry.reserve(lcsgpu::long_carry_bytes(gx, std::min(gy, gy_step), n_chunks_max)));
+            for (int y0 = 0; y0 < gy; y0 += gy_step) {
+                RowsArgs s = a;
+                const int first = y0 * a.refs_per_block;
+                s.n_refs = std::min(a.n_refs - first, gy_step * a.refs_per_block);
+                if (is_contig[b]) {
+                    s.ref_begin = a.ref_begin + first;
+                    s.row0 = a.row0 + first;
+                } else {
+                    s.ref_ids = a.ref_ids + first;
+                    s.ref_rows = a.ref_rows + first;
+                }
+                const int sgy = (s.n_refs + s.refs_per_block - 1) / s.refs_per_block;
+                HIP_TRY(lcsgpu::launch_long(bk.quirk, s, gx, sgy, ctx->d_carry.p, n_chunks_max, ctx->stream));
+                ++ctx->last_launches;
+            }
+        }
     }
     HIP_TRY(hipEventRecord(ctx->ev_stop, ctx->stream));
     ctx->timing_valid = true;
@@ -326,6 +347,7 @@ int lcsgpu_destroy(lcsgpu_ctx* ctx)
     ctx->d_pow.release();
     ctx->d_plan.release();
     ctx->d_out.release();
+    ctx->d_carry.release();
     ctx->h_plan.release();
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
     if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);

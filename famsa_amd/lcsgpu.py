@@ -26,6 +26,12 @@ def load_library():
         raise LcsGpuError(
             f"{path} not found: build it with `make -C famsa_amd/csrc` (or __graft_entry__.build()); "
             "there is no CPU fallback")
+    # torch wheels carry their own libamdhip64; two HIP runtimes in one process do not coexist, so
+    # when torch is installed let it load its copy first and liblcsgpu.so bind to that one.
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     lib = C.CDLL(path)
     vp, i32, i64, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_size_t
     pi32 = C.POINTER(C.c_int32)

@@ -87,6 +87,31 @@ def main():
         open(os.path.join(G, f"adversarial_tree_{gt}.dnd"), "wb").write(ref.tree(h, gt))
     ref.close(h)
 
+    # 1b. long sequences (> 2048 residues: the reference's LoopCalculate path), with and without
+    #     carry-quirk words beyond the first 32-word segment
+    rng = np.random.Generator(np.random.PCG64(77))
+    A = seqio.ALPHABET
+
+    def rnd(n_):
+        return "".join(A[i] for i in rng.integers(0, 20, size=n_))
+
+    lseqs = [rnd(2049), rnd(2112), rnd(3000), rnd(4096), rnd(4097), rnd(6500),
+             rnd(2048) + "M" * 64 + rnd(100),            # quirk word exactly at word 32 (segment edge)
+             rnd(2048 + 640) + "G" * 128 + rnd(777),     # quirk words inside segment 1
+             rnd(100), rnd(2048), "M" * 300, rnd(5000)[:4500] + "G" * 70]
+    lids = [f">long{i}" for i in range(len(lseqs))]
+    with open(os.path.join(G, "adversarial_long.fasta"), "w") as f:
+        for i, s_ in zip(lids, lseqs):
+            f.write(f"{i}\n{s_}\n")
+    h = ref.open_seqs(lids, lseqs)
+    ln = len(lseqs)
+    lm0 = ref.lcs_rect(h, np.arange(ln), np.arange(ln), isa=0)
+    lm2 = ref.lcs_rect(h, np.arange(ln), np.arange(ln), isa=2)
+    np.savez_compressed(os.path.join(G, "adversarial_long_lcs.npz"), classic=lm0.astype(np.uint16),
+                        avx2=lm2.astype(np.uint16))
+    meta["adversarial_long"] = {"n": ln, "classic_eq_avx2": bool((lm0 == lm2).all())}
+    ref.close(h)
+
     # 2. adeno_fiber: full oriented square LCS (input order)
     h = ref.open_fasta(os.path.join(G, "adeno_fiber", "adeno_fiber"))
     n = ref.lib.ref_count(h)

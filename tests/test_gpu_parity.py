@@ -124,6 +124,49 @@ def test_all_word_counts(engine, oracle):
     assert len(bad) == 0, bad[:10].tolist()
 
 
+def test_long_sequences_vs_reference_golden(engine):
+    """Refs > 2048 residues go through the segmented kernel with carry streams."""
+    ids, enc = load_set(os.path.join(G, "adversarial_long.fasta"))
+    engine.upload_seqs(enc)
+    n = len(enc)
+    gold = np.load(os.path.join(G, "adversarial_long_lcs.npz"))["classic"]
+    got = engine.lcs_rect((0, n), (0, n))
+    bad = np.argwhere(got != gold)
+    assert len(bad) == 0, f"(ref,partner) mismatches: {bad[:10].tolist()}"
+    tri = engine.lcs_triangle()
+    assert (tri == gold[np.tril_indices(n, -1)]).all()
+
+
+def test_long_random_vs_oracle(engine, oracle):
+    rng = np.random.Generator(np.random.PCG64(21))
+    lens = [2049, 2500, 4096, 7000, 9000, 300, 64, 2048] + [int(x) for x in rng.integers(1, 6000, size=300)]
+    seqs = [rng.integers(0, 22, size=l).astype(np.uint8) for l in lens]
+    seqs[4][2048 + 64 * 3: 2048 + 64 * 5] = 7  # quirk words in the second segment of a long ref
+    engine.upload_seqs(seqs)
+    codes, offsets = seqio.pack(seqs)
+    n = len(seqs)
+    refs = np.arange(0, n, 3)
+    got = engine.lcs_rect(refs, (0, n), dtype=np.uint32)
+    want = oracle.rect(codes, offsets, refs, np.arange(n))
+    bad = np.argwhere(got != want)
+    assert len(bad) == 0, bad[:10].tolist()
+
+
+def test_every_halfword_count(engine, oracle):
+    """Every instantiated half-word count (lengths 1..2048 in steps of 32, both edges)."""
+    rng = np.random.Generator(np.random.PCG64(9))
+    lens = sorted(set([32 * k for k in range(1, 65)] + [32 * k + 1 for k in range(0, 64)] + [31, 33, 2047]))
+    seqs = [rng.integers(0, 20, size=l).astype(np.uint8) for l in lens]
+    engine.upload_seqs(seqs)
+    codes, offsets = seqio.pack(seqs)
+    n = len(seqs)
+    cols = np.arange(0, n, 5)
+    want = oracle.rect(codes, offsets, np.arange(n), cols)
+    got = engine.lcs_rect((0, n), cols)
+    bad = np.argwhere(got != want)
+    assert len(bad) == 0, bad[:10].tolist()
+
+
 def test_errors_are_reported(engine):
     import famsa_amd
     engine.upload_seqs([np.zeros(10, np.uint8)] * 3)

@@ -80,6 +80,17 @@ def test_adversarial_vs_reference(oracle):
     assert (got != got.T).any()
 
 
+def test_long_sequences_vs_reference(oracle):
+    """> 2048 residues: the reference's LoopCalculate path (lcs/lcsbp_classic.cpp:83-84)."""
+    ids, enc = load_set(oracle, os.path.join(G, "adversarial_long.fasta"))
+    z = np.load(os.path.join(G, "adversarial_long_lcs.npz"))
+    codes, offsets = seqio.pack(enc)
+    n = len(enc)
+    got = oracle.rect(codes, offsets, np.arange(n), np.arange(n))
+    assert (got == z["classic"]).all() and (got == z["avx2"]).all()
+    assert (got != got.T).any()
+
+
 def test_hemopexin_rows_and_triangle_checksum(oracle):
     ids, enc = load_set(oracle, os.path.join(G, "hemopexin", "hemopexin"))
     z = np.load(os.path.join(G, "hemopexin", "lcs_rows.npz"))
