@@ -56,6 +56,20 @@ __device__ __forceinline__ uint32_t or_and(uint32_t s, uint32_t v, uint32_t n)
     return __builtin_amdgcn_bitop3_b32(s, v, n, 0xF8); // s | (v & n)
 }
 
+// Mask read for the last, half-used word of an odd half-word count: only the low 32 bits are
+// consumed.  ds_read_b32 banks are (addr/4)%32, so residue codes c and c+16 collide (2-way
+// conflict on most of these reads; SQ_LDS_BANK_CONFLICT = 12% of LDS cycles), but a conflict-
+// free ds_read_b64 of the full word measured 2-3% SLOWER end to end (n=40000: 533k vs 515k
+// Gcell/s plain, 545k vs 540k pipelined) -- the extra LDS bytes cost more than the conflicts.
+__device__ __forceinline__ uint64_t odd_half_read(const lds_u8* p)
+{
+#ifdef LCS_ODD_B64
+    return *(const volatile lds_u64*)p;
+#else
+    return *(const lds_u32*)p;
+#endif
+}
+
 // One partner residue against RG refs x H half-words.  `row` = LDS address of this residue's
 // entry in mask row 0 of ref 0 of the group; a ref's rows are (H+1)/2 x 256 bytes.
 template <int H, int RG, bool QUIRK>
@@ -81,7 +95,9 @@ __device__ __forceinline__ void residue_step(const lds_u8* row, uint32_t (&X)[RG
                 cin = co;
             }
             if constexpr (H & 1) {
-                const uint32_t n0 = *(const lds_u32*)(row + (r * W + H / 2) * 256);
+                // a 64-bit read although only the low half is used: ds_read_b32 banks are
+                // (addr/4)%32, so codes c and c+16 would collide; ds_read_b64's are (addr/4)%64
+                const uint32_t n0 = (uint32_t)odd_half_read(row + (r * W + H / 2) * 256);
                 unsigned co;
                 const uint32_t V = X[r][H - 1];
                 const uint32_t s = __builtin_addc(V, andn(V, n0), cin, &co);
@@ -233,6 +249,152 @@ __global__ __launch_bounds__(256) void lcs_rows_kernel(RowsArgs a)
         }
 
         // result = number of zero bits (reference lcsbp_classic.h:60-65)
+#pragma unroll
+        for (int r = 0; r < RG; ++r) {
+            if (g + r >= nr || !valid)
+                continue;
+            uint32_t res = 0;
+#pragma unroll
+            for (int j = 0; j < H; ++j)
+                res += __popc(~X[r][j]);
+            store_result(a, ref0 + g + r, c, res);
+        }
+    }
+}
+
+// ---- software-pipelined inner loop -------------------------------------------------------
+// The compiler's own schedule issues the mask gathers in bursts right before their first use
+// and pays the LDS latency on every burst, and it orders the two halves of a word so that an
+// s_nop is needed between the dependent v_addc pair.  Here the instruction stream of one
+// 16-residue chunk (16 x RG x W word-steps) is laid out explicitly and pinned with
+// sched_barrier: the gather for word-step t+LOOKAHEAD is issued before the VALU work of
+// word-step t (ring of LOOKAHEAD mask registers, carried across the chunk loop), and each word
+// runs  tB.lo, add.lo, X.lo, tB.hi, addc.hi, X.hi  so two instructions always sit between a
+// carry producer and its consumer (the gfx950 VALU-writes-VCC -> VALU-reads-VCC distance).
+#define LCS_PIN() __builtin_amdgcn_sched_barrier(0)
+
+template <int H, int RG, int LOOKAHEAD>
+struct Pipe {
+    static constexpr int W = (H + 1) / 2;
+    static constexpr int PER_POS = RG * W;     // word-steps per residue
+    static constexpr int T = 16 * PER_POS;     // word-steps per chunk
+    static_assert(T % LOOKAHEAD == 0, "the ring phase must be the same at every chunk boundary");
+
+    static __device__ __forceinline__ uint32_t byte_of(const uint4& q, int b)
+    {
+        const uint32_t w = (b >> 2) == 0 ? q.x : (b >> 2) == 1 ? q.y : (b >> 2) == 2 ? q.z : q.w;
+        return (w >> (8 * (b & 3))) & 0xFFu;
+    }
+
+    // mask word of word-step t2 (t2 may run into the next chunk)
+    static __device__ __forceinline__ uint64_t gather(const lds_u8* grp, const uint4& q, const uint4& qn, int t2)
+    {
+        const int b2 = t2 / PER_POS, rem = t2 - b2 * PER_POS;
+        const uint32_t code8 = b2 < 16 ? byte_of(q, b2) : byte_of(qn, b2 - 16);
+        if ((H & 1) && (rem % W) == W - 1)
+            return odd_half_read(grp + code8 + rem * 256);
+        return *(const lds_u64*)(grp + code8 + rem * 256);
+    }
+
+    static __device__ __forceinline__ void prime(const lds_u8* grp, const uint4& q, uint64_t (&ring)[LOOKAHEAD])
+    {
+#pragma unroll
+        for (int t = 0; t < LOOKAHEAD; ++t)
+            ring[t] = gather(grp, q, q, t);
+    }
+
+    static __device__ __forceinline__ void chunk(const lds_u8* grp, const uint4& q, const uint4& qn,
+                                                 uint64_t (&ring)[LOOKAHEAD], uint32_t (&X)[RG][H])
+    {
+#pragma unroll
+        for (int b = 0; b < 16; ++b) {
+#pragma unroll
+            for (int r = 0; r < RG; ++r) {
+                unsigned cin = 0;
+#pragma unroll
+                for (int j = 0; j < W; ++j) {
+                    const int t = (b * RG + r) * W + j;
+                    const uint64_t nn = ring[t % LOOKAHEAD];
+                    ring[t % LOOKAHEAD] = gather(grp, q, qn, t + LOOKAHEAD);
+                    LCS_PIN();
+                    const uint32_t n0 = (uint32_t)nn, n1 = (uint32_t)(nn >> 32);
+                    unsigned co;
+                    {
+                        const uint32_t V = X[r][2 * j];
+                        const uint32_t tb = andn(V, n0);
+                        LCS_PIN();
+                        const uint32_t s = __builtin_addc(V, tb, cin, &co);
+                        LCS_PIN();
+                        X[r][2 * j] = or_and(s, V, n0);
+                        cin = co;
+                        LCS_PIN();
+                    }
+                    if (2 * j + 1 < H) {
+                        const uint32_t V = X[r][2 * j + 1];
+                        const uint32_t tb = andn(V, n1);
+                        LCS_PIN();
+                        const uint32_t s = __builtin_addc(V, tb, cin, &co);
+                        LCS_PIN();
+                        X[r][2 * j + 1] = or_and(s, V, n1);
+                        cin = co;
+                        LCS_PIN();
+                    }
+                }
+            }
+        }
+    }
+};
+
+template <int H, int RG, int LOOKAHEAD>
+__global__ __launch_bounds__(256) void lcs_rows_kernel_pipe(RowsArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int W = (H + 1) / 2;
+    using P = Pipe<H, RG, LOOKAHEAD>;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int R = a.refs_per_block;
+    const int ref0 = blockIdx.y * R;
+    const int nr = min(R, a.n_refs - ref0);
+    const int c0 = blockIdx.x * 256;
+    if (block_is_above_diagonal(a, ref0, nr, c0))
+        return;
+    {
+        const int nr_pad = (nr + RG - 1) / RG * RG;
+        for (int r = 0; r < nr_pad; ++r) {
+            const int rid = r < nr ? (a.ref_ids ? a.ref_ids[ref0 + r] : a.ref_begin + ref0 + r) : -1;
+            build_mask_words(a, rid, 0, W, (lds_u64*)smem + r * W * 32, wave, lane);
+        }
+    }
+    __syncthreads();
+
+    const int c = c0 + tid;
+    const bool valid = c < a.n_cols;
+    const int pid = a.col_ids ? a.col_ids[valid ? c : 0] : a.col_begin + (valid ? c : 0);
+    const uint32_t len_p = valid ? a.lens[pid] : 0u;
+    const uint8_t* pbase = a.tiles + a.tile_base[pid >> 6] + (uint64_t)(pid & 63) * 16;
+    const int my_chunks = (int)((len_p + 15) >> 4);
+    const int wave_chunks = wave_max(my_chunks);
+
+    for (int g = 0; g < nr; g += RG) {
+        uint32_t X[RG][H];
+#pragma unroll
+        for (int r = 0; r < RG; ++r)
+#pragma unroll
+            for (int j = 0; j < H; ++j)
+                X[r][j] = ~0u;
+        const lds_u8* grp = (const lds_u8*)smem + g * (W * 256);
+        uint4 q = make_uint4(PAD4, PAD4, PAD4, PAD4);
+        if (0 < my_chunks)
+            q = *(const uint4*)pbase;
+        uint64_t ring[LOOKAHEAD];
+        P::prime(grp, q, ring);
+        for (int k = 0; k < wave_chunks; ++k) {
+            uint4 qn = make_uint4(PAD4, PAD4, PAD4, PAD4);
+            if (k + 1 < my_chunks)
+                qn = *(const uint4*)(pbase + (size_t)(k + 1) * 1024);
+            P::chunk(grp, q, qn, ring, X);
+            q = qn;
+        }
 #pragma unroll
         for (int r = 0; r < RG; ++r) {
             if (g + r >= nr || !valid)
@@ -446,7 +608,10 @@ template <int H, int RG, bool QUIRK>
 static hipError_t launch_one(const RowsArgs& a, dim3 grid, hipStream_t stream)
 {
     const size_t lds = (size_t)a.refs_per_block * ((H + 1) / 2) * 256;
-    hipLaunchKernelGGL((lcs_rows_kernel<H, RG, QUIRK>), grid, dim3(256), lds, stream, a);
+    if constexpr (QUIRK)
+        hipLaunchKernelGGL((lcs_rows_kernel<H, RG, true>), grid, dim3(256), lds, stream, a);
+    else
+        hipLaunchKernelGGL((lcs_rows_kernel_pipe<H, RG, 8>), grid, dim3(256), lds, stream, a);
     return hipGetLastError();
 }
 

@@ -13,7 +13,7 @@ class LcsGpuError(RuntimeError):
 
 
 def library_path():
-    return os.path.join(_HERE, "liblcsgpu.so")
+    return os.environ.get("LCSGPU_LIB") or os.path.join(_HERE, "liblcsgpu.so")
 
 
 def load_library():
