@@ -465,6 +465,18 @@ int32_t lcsgpu_length(lcsgpu_ctx* ctx, int32_t i)
     return (int32_t)ctx->lens[i];
 }
 
+int32_t lcsgpu_orientation_flags(lcsgpu_ctx* ctx, uint8_t* flags)
+{
+    if (!ctx) return fail(LCSGPU_E_INVALID, "NULL ctx");
+    if (ctx->n < 0) return fail(LCSGPU_E_STATE, "no sequence set uploaded");
+    int32_t count = 0;
+    for (int32_t i = 0; i < ctx->n; ++i) {
+        if (flags) flags[i] = ctx->quirk[i];
+        count += ctx->quirk[i] ? 1 : 0;
+    }
+    return count;
+}
+
 int lcsgpu_lcs_rect_dev(lcsgpu_ctx* ctx, const int32_t* ref_ids, int32_t ref_begin, int32_t n_refs,
                         const int32_t* col_ids, int32_t col_begin, int32_t n_cols, void* d_out,
                         int64_t ld, int elem_size, int sync)

@@ -1,0 +1,115 @@
+// capi.cpp -- C entry points of libfamsa_host.so.
+// The host logic (tree builders, Newick / CSV writers, the working-order bookkeeping) behind a
+// plain C interface: used by the famsa-gpu tool's tests to drive it from Python, and usable by a
+// host program that already holds an LCS matrix.  `famsa_host_*_from_matrix` consume a
+// caller-supplied oriented matrix (the CPU tests pass the oracle's); `famsa_host_*_gpu` take the
+// values from the MI355X engine.
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "lcs_source.h"
+#include "pipeline.h"
+#include "seqset.h"
+#include "trees.h"
+
+using namespace famsa_host;
+
+namespace {
+thread_local std::string g_error;
+int fail(const std::exception& e)
+{
+    g_error = e.what();
+    return -1;
+}
+long give(const std::string& s, char* out, long cap)
+{
+    if ((long)s.size() + 1 > cap) return -(long)s.size() - 1;
+    memcpy(out, s.c_str(), s.size() + 1);
+    return (long)s.size();
+}
+} // namespace
+
+extern "C" {
+
+const char* famsa_host_last_error(void) { return g_error.c_str(); }
+
+// FAMSA's working order of a FASTA file: sorted2input[n], sorted2unique[n]; returns n_unique.
+int famsa_host_workset(const char* fasta, int keep_duplicates, int* sorted2input, int* sorted2unique, int cap)
+{
+    try {
+        SeqSet s = load_fasta(fasta);
+        WorkSet w = make_workset(s, keep_duplicates != 0);
+        if ((int)s.size() > cap) throw std::runtime_error("buffer too small");
+        for (int i = 0; i < w.n_sorted(); ++i) {
+            sorted2input[i] = w.sorted2input[i];
+            sorted2unique[i] = w.sorted2unique[i];
+        }
+        return w.n_unique();
+    } catch (const std::exception& e) {
+        return fail(e);
+    }
+}
+
+// Newick text of `-gt <method> -gt_export` for `fasta`, LCS values taken from `square`
+// (input order, square[ref*n + partner], n = number of FASTA records).
+long famsa_host_tree_from_matrix(const char* fasta, const uint32_t* square, const char* method, int distance,
+                                 int keep_duplicates, char* out, long cap)
+{
+    try {
+        SeqSet s = load_fasta(fasta);
+        return give(guide_tree_newick_from_matrix(s, square, gt_from_string(method), (Distance)distance,
+                                                   keep_duplicates != 0),
+                    out, cap);
+    } catch (const std::exception& e) {
+        return fail(e);
+    }
+}
+
+// `-dist_export [-pid] [-square_matrix]` written to `csv_path`, LCS values from `square`.
+int famsa_host_dist_export_from_matrix(const char* fasta, const uint32_t* square, int distance, int square_matrix,
+                                       int pid, const char* csv_path)
+{
+    try {
+        SeqSet s = load_fasta(fasta);
+        const int n = (int)s.size();
+        std::vector<uint32_t> lens(n);
+        for (int i = 0; i < n; ++i) lens[i] = s.length(i);
+        MatrixLcsSource src(n, lens.data(), square);
+        write_distance_csv(src, s.ids, (Distance)distance, square_matrix != 0, pid != 0, csv_path);
+        return 0;
+    } catch (const std::exception& e) {
+        return fail(e);
+    }
+}
+
+// The same two operations with the LCS computed on GPU `device`.
+long famsa_host_tree_gpu(const char* fasta, int device, const char* method, int distance, int keep_duplicates,
+                         char* out, long cap)
+{
+    try {
+        SeqSet s = load_fasta(fasta);
+        return give(guide_tree_newick_gpu(s, device, gt_from_string(method), (Distance)distance,
+                                           keep_duplicates != 0, nullptr),
+                    out, cap);
+    } catch (const std::exception& e) {
+        return fail(e);
+    }
+}
+
+int famsa_host_dist_export_gpu(const char* fasta, int device, int distance, int square_matrix, int pid,
+                               const char* csv_path)
+{
+    try {
+        SeqSet s = load_fasta(fasta);
+        dist_export_gpu(s, device, (Distance)distance, square_matrix != 0, pid != 0, csv_path, nullptr);
+        return 0;
+    } catch (const std::exception& e) {
+        return fail(e);
+    }
+}
+
+int famsa_host_format_distance(double v, char* out) { return format_distance(v, out); }
+
+} // extern "C"

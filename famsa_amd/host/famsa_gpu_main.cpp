@@ -1,0 +1,123 @@
+// famsa-gpu -- the guide-tree / distance-export front end of FAMSA on the MI355X LCS engine.
+// Accepts the reference CLI's flags for this path (reference core/params.cpp:136-294, help text
+// :60-134):   famsa-gpu [options] <input.fasta> <output>
+//   -gt <sl|slink|upgma|upgma_modified|nj>   guide tree method (default sl)
+//   -gt_export                               write the guide tree in Newick format and stop
+//   -dist_export [-pid] [-square_matrix]     write the distance (or identity) matrix as CSV
+//   -dist <indel_div_lcs|indel075_div_lcs>   distance measure (default indel075_div_lcs)
+//   -keep-duplicates, -t <n>, -v / -vv, -gpu <id>
+// Everything downstream of the guide tree (profile alignment, refinement, -medoidtree, gz I/O)
+// is outside this engine's scope and is refused with an error, not silently ignored.
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "pipeline.h"
+
+using namespace famsa_host;
+
+namespace {
+
+bool find_switch(std::vector<std::string>& p, const std::string& name)
+{
+    auto it = std::find(p.begin(), p.end(), name);
+    if (it == p.end()) return false;
+    p.erase(it);
+    return true;
+}
+
+bool find_option(std::vector<std::string>& p, const std::string& name, std::string& value)
+{
+    auto it = std::find(p.begin(), p.end(), name);
+    if (it == p.end() || it + 1 == p.end()) return false;
+    value = *(it + 1);
+    p.erase(it, it + 2);
+    return true;
+}
+
+void usage()
+{
+    std::cerr << "Usage: famsa-gpu [options] <input_file> <output_file>\n"
+                 "  -gt <sl | slink | upgma | upgma_modified | nj>  guide tree method (default: sl)\n"
+                 "  -gt_export            export the guide tree to the output file in Newick format\n"
+                 "  -dist_export          export the distance matrix to the output file in CSV format\n"
+                 "  -square_matrix        generate a square distance matrix instead of the lower triangle\n"
+                 "  -pid                  export pairwise identity (the number of matching residues divided\n"
+                 "                        by the shorter sequence length) instead of distance\n"
+                 "  -dist <measure>       indel_div_lcs | indel075_div_lcs (default)\n"
+                 "  -keep-duplicates      keep duplicated sequences during tree construction\n"
+                 "  -gpu <id>             HIP device (default 0)\n"
+                 "  -t <n>, -v, -vv       accepted for compatibility / verbosity\n";
+}
+
+} // namespace
+
+int main(int argc, char** argv)
+{
+    try {
+        std::vector<std::string> params(argv + 1, argv + argc);
+        if (params.size() < 2 || find_switch(params, "-help")) {
+            usage();
+            return 0;
+        }
+        std::string aux;
+        GT method = GT::MST_Prim;
+        Distance dist = Distance::indel075_div_lcs;
+        int device = 0;
+        if (find_option(params, "-gt", aux)) {
+            if (aux == "import") throw std::runtime_error("-gt import needs the alignment stage, which is outside this tool");
+            method = gt_from_string(aux);
+        }
+        if (find_option(params, "-dist", aux)) {
+            if (aux == "indel_div_lcs") dist = Distance::indel_div_lcs;
+            else if (aux == "indel075_div_lcs") dist = Distance::indel075_div_lcs;
+            else throw std::runtime_error("Error: Illegal pairwise distance measure.");
+        }
+        if (find_option(params, "-gpu", aux)) device = std::stoi(aux);
+        find_option(params, "-t", aux);
+        const bool very_verbose = find_switch(params, "-vv");
+        const bool verbose = find_switch(params, "-v") || very_verbose;
+        const bool export_tree = find_switch(params, "-gt_export");
+        const bool export_dist = find_switch(params, "-dist_export");
+        const bool square = find_switch(params, "-square_matrix");
+        const bool pid = find_switch(params, "-pid");
+        const bool keep_dups = find_switch(params, "-keep-duplicates");
+        for (const char* unsupported : {"-medoidtree", "-parttree", "-gz", "-refine_mode", "-trim_columns"})
+            if (std::find(params.begin(), params.end(), unsupported) != params.end())
+                throw std::runtime_error(std::string(unsupported) + " is outside the scope of famsa-gpu (guide tree / distance stage only)");
+        if (params.size() != 2) {
+            usage();
+            return 1;
+        }
+        if (!export_tree && !export_dist)
+            throw std::runtime_error("famsa-gpu covers -gt_export and -dist_export; the alignment stage is not part of this engine");
+
+        const std::string input = params[0], output = params[1];
+        SeqSet s = load_fasta(input);
+        if (s.size() == 0) throw std::runtime_error("no sequences in " + input);
+        Timings t;
+        if (export_dist) {
+            dist_export_gpu(s, device, dist, square, pid, output, &t);
+        } else {
+            const std::string nwk = guide_tree_newick_gpu(s, device, method, dist, keep_dups, &t);
+            std::ofstream f(output, std::ios::binary);
+            if (!f.good()) throw std::runtime_error("cannot open " + output);
+            f << nwk;
+        }
+        if (verbose) {
+            std::cerr << "time.sort=" << t.sort_s << "\n"
+                      << "time.gpu_upload=" << t.upload_s << "\n"
+                      << "time.tree_build=" << t.tree_s << "\n"
+                      << "gpu.lcs_kernel_ms=" << t.kernel_ms << "\n";
+        }
+        return 0;
+    } catch (const std::exception& e) {
+        std::cerr << "[ERROR] " << e.what() << std::endl;
+        return -1;
+    }
+}

@@ -1,0 +1,97 @@
+#include "lcs_source.h"
+
+#include <algorithm>
+#include <stdexcept>
+
+#include "../../include/lcsgpu.h"
+
+namespace famsa_host {
+
+bool LcsSource::wide() const
+{
+    uint32_t m = 0;
+    for (int i = 0; i < n(); ++i) m = std::max(m, length(i));
+    return m > 65535;
+}
+
+GpuLcsSource::GpuLcsSource(int device)
+{
+    check(lcsgpu_create(device, &ctx_), "lcsgpu_create");
+}
+
+GpuLcsSource::~GpuLcsSource()
+{
+    if (ctx_) lcsgpu_destroy(ctx_);
+}
+
+void GpuLcsSource::check(int rc, const char* what)
+{
+    if (rc != LCSGPU_OK)
+        throw std::runtime_error(std::string(what) + " failed (" + std::to_string(rc) + "): " + lcsgpu_last_error());
+}
+
+void GpuLcsSource::upload(const std::vector<uint8_t>& codes, const std::vector<uint64_t>& offsets)
+{
+    const int32_t n = (int32_t)offsets.size() - 1;
+    check(lcsgpu_upload(ctx_, codes.data(), offsets.data(), n), "lcsgpu_upload");
+    lens_.resize(n);
+    for (int i = 0; i < n; ++i) lens_[i] = (uint32_t)(offsets[i + 1] - offsets[i]);
+    std::vector<uint8_t> flags(n ? n : 1);
+    int32_t nq = lcsgpu_orientation_flags(ctx_, flags.data());
+    if (nq < 0) check(nq, "lcsgpu_orientation_flags");
+    sensitive_ = nq > 0;
+}
+
+void GpuLcsSource::triangle(int r0, int r1, LcsBuf& out)
+{
+    const size_t count = (size_t)r1 * (r1 - 1) / 2 - (size_t)r0 * (r0 > 0 ? r0 - 1 : 0) / 2;
+    out.resize(count, wide());
+    check(lcsgpu_lcs_triangle(ctx_, r0, r1, out.data(), out.elem_size()), "lcsgpu_lcs_triangle");
+    double ms = 0;
+    int32_t nl = 0;
+    if (lcsgpu_last_kernel_ms(ctx_, &ms, &nl) == LCSGPU_OK) kernel_ms_ += ms;
+}
+
+void GpuLcsSource::rect(const int* refs, int n_refs, const int* cols, int n_cols, LcsBuf& out)
+{
+    out.resize((size_t)n_refs * n_cols, wide());
+    check(lcsgpu_lcs_rect(ctx_, refs, 0, n_refs, cols, 0, n_cols, out.data(), n_cols, out.elem_size()),
+          "lcsgpu_lcs_rect");
+    double ms = 0;
+    int32_t nl = 0;
+    if (lcsgpu_last_kernel_ms(ctx_, &ms, &nl) == LCSGPU_OK) kernel_ms_ += ms;
+}
+
+MatrixLcsSource::MatrixLcsSource(int n, const uint32_t* lens, const uint32_t* square)
+    : n_(n), lens_(lens, lens + n), m_(square, square + (size_t)n * n), sensitive_(false)
+{
+    for (int i = 0; i < n && !sensitive_; ++i)
+        for (int j = 0; j < i; ++j)
+            if (m_[(size_t)i * n + j] != m_[(size_t)j * n + i]) {
+                sensitive_ = true;
+                break;
+            }
+}
+
+void MatrixLcsSource::triangle(int r0, int r1, LcsBuf& out)
+{
+    const size_t off = (size_t)r0 * (r0 > 0 ? r0 - 1 : 0) / 2;
+    out.resize((size_t)r1 * (r1 - 1) / 2 - off, wide());
+    for (int i = std::max(r0, 1); i < r1; ++i)
+        for (int j = 0; j < i; ++j) {
+            const size_t k = (size_t)i * (i - 1) / 2 + j - off;
+            if (out.wide) out.v32[k] = m_[(size_t)i * n_ + j]; else out.v16[k] = (uint16_t)m_[(size_t)i * n_ + j];
+        }
+}
+
+void MatrixLcsSource::rect(const int* refs, int n_refs, const int* cols, int n_cols, LcsBuf& out)
+{
+    out.resize((size_t)n_refs * n_cols, wide());
+    for (int r = 0; r < n_refs; ++r)
+        for (int c = 0; c < n_cols; ++c) {
+            const uint32_t v = m_[(size_t)refs[r] * n_ + (cols ? cols[c] : c)];
+            if (out.wide) out.v32[(size_t)r * n_cols + c] = v; else out.v16[(size_t)r * n_cols + c] = (uint16_t)v;
+        }
+}
+
+} // namespace famsa_host

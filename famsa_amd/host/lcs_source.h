@@ -1,0 +1,83 @@
+// lcs_source.h -- where the tree builders get oriented LCS lengths from.
+// The product implementation (GpuLcsSource) is the C-ABI of include/lcsgpu.h; MatrixLcsSource
+// serves a caller-supplied matrix so the host logic can be exercised without a GPU (tests feed
+// it the oracle's matrix).  There is no CPU LCS implementation on this side of the boundary.
+#pragma once
+#include <cstdint>
+#include <memory>
+#include <string>
+#include <vector>
+
+struct lcsgpu_ctx;
+
+namespace famsa_host {
+
+// LCS values as uint16 (all sequences <= 65535 residues) or uint32.
+struct LcsBuf {
+    bool wide = false;
+    std::vector<uint16_t> v16;
+    std::vector<uint32_t> v32;
+    void resize(size_t n, bool wide_)
+    {
+        wide = wide_;
+        if (wide) { v32.resize(n); v16.clear(); } else { v16.resize(n); v32.clear(); }
+    }
+    size_t size() const { return wide ? v32.size() : v16.size(); }
+    uint32_t operator[](size_t i) const { return wide ? v32[i] : v16[i]; }
+    void* data() { return wide ? (void*)v32.data() : (void*)v16.data(); }
+    int elem_size() const { return wide ? 4 : 2; }
+};
+
+class LcsSource {
+public:
+    virtual ~LcsSource() {}
+    virtual int n() const = 0;
+    virtual uint32_t length(int i) const = 0;
+    // true if some sequence, used as the ref, can give an orientation-dependent value
+    // (reference carry rule, SURVEY note Q): then LCS(ref=a,partner=b) != LCS(ref=b,partner=a) may hold
+    virtual bool orientation_sensitive() const = 0;
+    // rows [r0, r1) of the lower triangle, ref = row i, partner = column j < i; out[i*(i-1)/2 + j - r0*(r0-1)/2]
+    virtual void triangle(int r0, int r1, LcsBuf& out) = 0;
+    // out[r*n_cols + c] = LCS(ref = refs[r], partner = cols ? cols[c] : c)
+    virtual void rect(const int* refs, int n_refs, const int* cols, int n_cols, LcsBuf& out) = 0;
+    bool wide() const;
+};
+
+// The MI355X engine.  Throws std::runtime_error if the library reports an error (no fallback).
+class GpuLcsSource : public LcsSource {
+public:
+    explicit GpuLcsSource(int device);
+    ~GpuLcsSource() override;
+    void upload(const std::vector<uint8_t>& codes, const std::vector<uint64_t>& offsets);
+    int n() const override { return (int)lens_.size(); }
+    uint32_t length(int i) const override { return lens_[i]; }
+    bool orientation_sensitive() const override { return sensitive_; }
+    void triangle(int r0, int r1, LcsBuf& out) override;
+    void rect(const int* refs, int n_refs, const int* cols, int n_cols, LcsBuf& out) override;
+    double kernel_ms_total() const { return kernel_ms_; }
+
+private:
+    void check(int rc, const char* what);
+    lcsgpu_ctx* ctx_ = nullptr;
+    std::vector<uint32_t> lens_;
+    bool sensitive_ = false;
+    double kernel_ms_ = 0;
+};
+
+// A full oriented square matrix supplied by the caller: m[ref*n + partner].
+class MatrixLcsSource : public LcsSource {
+public:
+    MatrixLcsSource(int n, const uint32_t* lens, const uint32_t* square);
+    int n() const override { return n_; }
+    uint32_t length(int i) const override { return lens_[i]; }
+    bool orientation_sensitive() const override { return sensitive_; }
+    void triangle(int r0, int r1, LcsBuf& out) override;
+    void rect(const int* refs, int n_refs, const int* cols, int n_cols, LcsBuf& out) override;
+
+private:
+    int n_;
+    std::vector<uint32_t> lens_, m_;
+    bool sensitive_;
+};
+
+} // namespace famsa_host

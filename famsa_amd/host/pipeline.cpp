@@ -1,0 +1,89 @@
+#include "pipeline.h"
+
+#include <chrono>
+#include <stdexcept>
+
+namespace famsa_host {
+
+static double now_s()
+{
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+std::string guide_tree_newick(const SeqSet& s, const WorkSet& w, LcsSource& src, GT method, Distance dist)
+{
+    // names of the leaves = ids in sorted order (the reference reorders its sequence vector)
+    std::vector<std::string> names(w.n_sorted());
+    for (int k = 0; k < w.n_sorted(); ++k) names[k] = s.ids[w.sorted2input[k]];
+    if (w.n_unique() == 1) return std::string(); // the reference skips the tree stage entirely (msa.cpp:549-556)
+    tree_structure tree;
+    build_tree(src, method, dist, tree, 1);
+    tree_from_unique(tree, w.sorted2unique);
+    return tree_to_newick(tree, names);
+}
+
+std::string guide_tree_newick_from_matrix(const SeqSet& s, const uint32_t* sq, GT method, Distance dist,
+                                          bool keep_duplicates)
+{
+    const int n_in = (int)s.size();
+    WorkSet w = make_workset(s, keep_duplicates);
+    const int u = w.n_unique();
+    std::vector<uint32_t> lens(u), m((size_t)u * u);
+    std::vector<int> in_of(u);
+    for (int a = 0; a < u; ++a) {
+        in_of[a] = w.sorted2input[w.unique2sorted[a]];
+        lens[a] = s.length(in_of[a]);
+    }
+    for (int a = 0; a < u; ++a)
+        for (int b = 0; b < u; ++b) m[(size_t)a * u + b] = sq[(size_t)in_of[a] * n_in + in_of[b]];
+    MatrixLcsSource src(u, lens.data(), m.data());
+    return guide_tree_newick(s, w, src, method, dist);
+}
+
+std::string guide_tree_newick_gpu(const SeqSet& s, int device, GT method, Distance dist, bool keep_duplicates,
+                                  Timings* t)
+{
+    double t0 = now_s();
+    WorkSet w = make_workset(s, keep_duplicates);
+    std::vector<int> in_of(w.n_unique());
+    for (int a = 0; a < w.n_unique(); ++a) in_of[a] = w.sorted2input[w.unique2sorted[a]];
+    std::vector<uint8_t> codes;
+    std::vector<uint64_t> offsets;
+    pack(s, in_of, codes, offsets);
+    double t1 = now_s();
+    GpuLcsSource src(device);
+    src.upload(codes, offsets);
+    double t2 = now_s();
+    std::string nwk = guide_tree_newick(s, w, src, method, dist);
+    double t3 = now_s();
+    if (t) {
+        t->sort_s = t1 - t0;
+        t->upload_s = t2 - t1;
+        t->tree_s = t3 - t2;
+        t->kernel_ms = src.kernel_ms_total();
+    }
+    return nwk;
+}
+
+void dist_export_gpu(const SeqSet& s, int device, Distance dist, bool square, bool pid, const std::string& path,
+                     Timings* t)
+{
+    std::vector<int> all(s.size());
+    for (size_t i = 0; i < s.size(); ++i) all[i] = (int)i;
+    std::vector<uint8_t> codes;
+    std::vector<uint64_t> offsets;
+    pack(s, all, codes, offsets);
+    double t1 = now_s();
+    GpuLcsSource src(device);
+    src.upload(codes, offsets);
+    double t2 = now_s();
+    write_distance_csv(src, s.ids, dist, square, pid, path);
+    double t3 = now_s();
+    if (t) {
+        t->upload_s = t2 - t1;
+        t->tree_s = t3 - t2;
+        t->kernel_ms = src.kernel_ms_total();
+    }
+}
+
+} // namespace famsa_host

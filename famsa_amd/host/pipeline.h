@@ -1,0 +1,28 @@
+// pipeline.h -- the slice of CFAMSA::ComputeMSA (reference msa.cpp:470-584) that surrounds the
+// guide-tree generators: working order, duplicate removal, generator call, fromUnique, Newick;
+// and the -dist_export early branch (msa.cpp:518-526: input order, no sort, no dedup).
+#pragma once
+#include <string>
+
+#include "lcs_source.h"
+#include "seqset.h"
+#include "trees.h"
+
+namespace famsa_host {
+
+struct Timings {
+    double sort_s = 0, upload_s = 0, tree_s = 0, kernel_ms = 0, store_s = 0;
+};
+
+// Newick for the whole input (duplicates re-attached), LCS values from `src_of_unique`, whose
+// sequence ids are the sorted unique working order.
+std::string guide_tree_newick(const SeqSet& s, const WorkSet& w, LcsSource& src_of_unique, GT method, Distance dist);
+
+std::string guide_tree_newick_from_matrix(const SeqSet& s, const uint32_t* square_input_order, GT method,
+                                          Distance dist, bool keep_duplicates);
+std::string guide_tree_newick_gpu(const SeqSet& s, int device, GT method, Distance dist, bool keep_duplicates,
+                                  Timings* t);
+void dist_export_gpu(const SeqSet& s, int device, Distance dist, bool square, bool pid, const std::string& path,
+                     Timings* t);
+
+} // namespace famsa_host

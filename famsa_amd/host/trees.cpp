@@ -1,0 +1,538 @@
+#include "trees.h"
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <limits>
+#include <queue>
+#include <stdexcept>
+
+namespace famsa_host {
+
+GT gt_from_string(const std::string& name)
+{
+    if (name == "sl") return GT::MST_Prim;
+    if (name == "slink") return GT::SLINK;
+    if (name == "upgma") return GT::UPGMA;
+    if (name == "upgma_modified") return GT::UPGMA_modified;
+    if (name == "nj") return GT::NJ;
+    throw std::runtime_error("Error: Illegal guide tree method.");
+}
+
+static inline size_t tri(size_t i, size_t j) // TriangleMatrix::access, reference tree/TreeDefs.h:115-120
+{
+    return i >= j ? j + i * (i - 1) / 2 : i + j * (j - 1) / 2;
+}
+
+static inline uint64_t pack_ids(int a, int b) // ids_to_uint64, reference tree/MSTPrim.h:432-439
+{
+    if (a < 0 || b < 0) return 0;
+    if (a > b) std::swap(a, b);
+    return ((uint64_t)a << 32) + (uint64_t)b;
+}
+
+// ---------------------------------------------------------------------------------------------
+// -gt sl : Prim's MST on the complete graph + MST -> dendrogram
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+struct Key { // MSTPrim::dist_t = pair<double, uint64_t>, compared lexicographically
+    double d;
+    uint64_t id;
+    bool operator<(const Key& o) const { return d < o.d || (d == o.d && id < o.id); }
+};
+
+struct Edge { // MSTPrim::mst_edge_t (reference tree/MSTPrim.h:452-483): dist holds -d
+    int from, to, prim_order;
+    double dist;
+};
+inline bool edge_less(const Edge& x, const Edge& y)
+{
+    if (x.dist != y.dist) return x.dist > y.dist;
+    return pack_ids(x.from, x.to) > pack_ids(y.from, y.to);
+}
+
+// oriented LCS lookup for Prim: value for (ref = cur, partner = v)
+struct PrimLcs {
+    const LcsBuf* tri_buf = nullptr; // symmetric case: lower triangle
+    const LcsBuf* sq_buf = nullptr;  // orientation-sensitive case: full square
+    int n = 0;
+    uint32_t operator()(int ref, int partner) const
+    {
+        if (sq_buf) return (*sq_buf)[(size_t)ref * n + partner];
+        return (*tri_buf)[tri(ref, partner)];
+    }
+};
+
+template <Distance D>
+void mst_prim(LcsSource& src, tree_structure& tree)
+{
+    const int n = src.n();
+    LcsBuf buf;
+    PrimLcs lcs;
+    lcs.n = n;
+    if (src.orientation_sensitive()) {
+        // ref = the node just added, partner = the candidate (reference MSTPrim.cpp:478-485): the
+        // triangle's fixed orientation is not enough, take both orientations
+        std::vector<int> all(n);
+        for (int i = 0; i < n; ++i) all[i] = i;
+        src.rect(all.data(), n, nullptr, n, buf);
+        lcs.sq_buf = &buf;
+    } else {
+        src.triangle(0, n, buf);
+        lcs.tri_buf = &buf;
+    }
+
+    Transform<double, D> transform;
+    std::vector<Key> key(n, Key{std::numeric_limits<double>::max(), 0});
+    std::vector<int> alive;
+    alive.reserve(n);
+    for (int v = 1; v < n; ++v) alive.push_back(v);
+    std::vector<int> prim_order(n, n);
+    std::vector<Edge> edges;
+    edges.reserve(n);
+    edges.push_back(Edge{0, 0, 0, 0.0}); // the dummy the reference inserts at index 0
+    int cur = 0, next_order = 0;
+    prim_order[cur] = next_order++;
+
+    while (!alive.empty()) {
+        const uint32_t len_cur = src.length(cur);
+        size_t best_pos = 0;
+        for (size_t p = 0; p < alive.size(); ++p) {
+            const int v = alive[p];
+            const double d = transform(lcs(cur, v), len_cur, src.length(v));
+            if (d <= key[v].d) {
+                const Key s{d, ~pack_ids(cur, v)};
+                if (s < key[v]) key[v] = s;
+            }
+            if (key[v] < key[alive[best_pos]]) best_pos = p;
+        }
+        const int best = alive[best_pos];
+        const uint64_t packed = ~key[best].id;
+        int a = (int)(packed >> 32), b = (int)(packed & 0xffffffffull);
+        if (a > b) std::swap(a, b);
+        edges.push_back(Edge{a, b, next_order, -key[best].d});
+        if (prim_order[a] == n) prim_order[a] = next_order++; else prim_order[b] = next_order++;
+        alive[best_pos] = alive.back();
+        alive.pop_back();
+        cur = best;
+    }
+
+    // mst_to_dendogram (reference MSTPrim.cpp:784-833): split every range of the Prim order at
+    // its heaviest edge, breadth first, node ids handed out from 2n-2 downwards
+    std::vector<int> rev(n);
+    for (int i = 0; i < n; ++i) rev[prim_order[i]] = i;
+    // sparse table of "max" edges (CMaxRangeQueries, reference MSTPrim.h:370-417)
+    const int m = (int)edges.size(); // == n
+    int levels = 1;
+    while ((1 << levels) <= m) ++levels;
+    std::vector<std::vector<int>> st(levels);
+    st[0].resize(m);
+    for (int i = 0; i < m; ++i) st[0][i] = i;
+    auto greater = [&](int x, int y) { return edge_less(edges[y], edges[x]); }; // edges[x] > edges[y]
+    for (int l = 1; l < levels; ++l) {
+        const int len = m - (1 << l) + 1;
+        if (len <= 0) { st[l].clear(); continue; }
+        st[l].resize(len);
+        for (int j = 0; j < len; ++j) {
+            const int x = st[l - 1][j], y = st[l - 1][j + (1 << (l - 1))];
+            st[l][j] = greater(x, y) ? x : y;
+        }
+    }
+    auto max_element = [&](int begin, int end) {
+        int lev = 0;
+        while ((1 << (lev + 1)) <= end - begin) ++lev;
+        const int x = st[lev][begin], y = st[lev][end - (1 << lev)];
+        return greater(x, y) ? x : y;
+    };
+
+    tree.assign((size_t)2 * n - 1, node_t(-1, -1));
+    struct Range { int id, from, to; };
+    std::queue<Range> q;
+    int cur_id = 2 * n - 2;
+    q.push(Range{cur_id--, 0, n});
+    while (!q.empty()) {
+        const Range r = q.front();
+        q.pop();
+        const int split = edges[max_element(r.from + 1, r.to)].prim_order;
+        int left, right;
+        if (r.from + 1 == split) left = rev[r.from];
+        else {
+            left = cur_id--;
+            q.push(Range{left, std::min(r.from, split), std::max(r.from, split)});
+        }
+        if (split + 1 == r.to) right = rev[split];
+        else {
+            right = cur_id--;
+            q.push(Range{right, std::min(split, r.to), std::max(split, r.to)});
+        }
+        tree[r.id] = node_t(left, right);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// -gt slink : SLINK pointer representation, rows consumed in order
+// ---------------------------------------------------------------------------------------------
+struct SlinkDist { // slink_dist_t (reference tree/SingleLinkage.h:19-38): by distance, then by LARGER id
+    double first;
+    uint64_t second;
+    bool operator<(const SlinkDist& r) const { return first == r.first ? second > r.second : first < r.first; }
+    bool operator<=(const SlinkDist& r) const { return first == r.first ? second >= r.second : first <= r.first; }
+};
+
+template <Distance D>
+void slink(LcsSource& src, tree_structure& tree)
+{
+    const int n = src.n();
+    Transform<double, D> transform;
+    std::vector<int> pi(n, 0);
+    std::vector<SlinkDist> lambda(n), M(n);
+    // rows are fetched in blocks from the engine (ref = row i, partner = column j < i)
+    const int block = std::max(1, std::min(n, 4096));
+    LcsBuf buf;
+    int b0 = 0, b1 = 0;
+    for (int i = 0; i < n; ++i) {
+        if (i >= b1) {
+            b0 = i;
+            b1 = std::min(n, i + block);
+            src.triangle(b0, b1, buf);
+        }
+        const size_t base = (size_t)i * (i - 1) / 2 - (size_t)b0 * (b0 > 0 ? b0 - 1 : 0) / 2;
+        pi[i] = i;
+        lambda[i] = SlinkDist{std::numeric_limits<double>::max(), 0};
+        const uint32_t len_i = src.length(i);
+        for (int j = 0; j < i; ++j)
+            M[j] = SlinkDist{transform(buf[base + j], len_i, src.length(j)), pack_ids(j, i)};
+        for (int j = 0; j < i; ++j) {
+            const int next = pi[j];
+            SlinkDist& x = M[next];
+            if (lambda[j] < M[j]) {
+                x = std::min(x, M[j]);
+            } else {
+                x = std::min(x, lambda[j]);
+                pi[j] = i;
+                lambda[j] = M[j];
+            }
+        }
+        for (int j = 0; j < i; ++j)
+            if (lambda[pi[j]] <= lambda[j]) pi[j] = i;
+    }
+    std::vector<int> elements(n - 1);
+    for (int i = 0; i < n - 1; ++i) elements[i] = i;
+    std::stable_sort(elements.begin(), elements.end(), [&](int x, int y) { return lambda[x] < lambda[y]; });
+    std::vector<int> index(n);
+    for (int i = 0; i < n; ++i) index[i] = i;
+    tree.assign(n, node_t(-1, -1));
+    for (int i = 0; i < n - 1; ++i) {
+        const int j = elements[i];
+        const int next = pi[j];
+        tree.emplace_back(index[j], index[next]);
+        index[next] = n + i;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// float distance triangle (UPGMA, NJ): d[i*(i-1)/2 + j] = Transform<float>(LCS(ref=i, partner=j))
+// ---------------------------------------------------------------------------------------------
+template <Distance D>
+void float_triangle(LcsSource& src, std::vector<float>& dist)
+{
+    const int n = src.n();
+    dist.resize((size_t)n * (n - 1) / 2);
+    Transform<float, D> transform;
+    const int block = 8192;
+    LcsBuf buf;
+    for (int r0 = 0; r0 < n; r0 += block) {
+        const int r1 = std::min(n, r0 + block);
+        src.triangle(r0, r1, buf);
+        const size_t off = (size_t)r0 * (r0 > 0 ? r0 - 1 : 0) / 2;
+        for (int i = std::max(r0, 1); i < r1; ++i) {
+            const uint32_t len_i = src.length(i);
+            const size_t row = (size_t)i * (i - 1) / 2;
+            for (int j = 0; j < i; ++j) dist[row + j] = transform(buf[row + j - off], len_i, src.length(j));
+        }
+    }
+}
+
+// -gt upgma / upgma_modified : the nearest-neighbour-array formulation the reference uses
+template <bool MODIFIED>
+void upgma_tree(std::vector<float>& D, int n, tree_structure& tree)
+{
+    const float BIG = 1e29f;
+    const uint64_t NONE = 0x7FFFFFFF;
+    auto average = [](float x, float y) -> float {
+        if (MODIFIED) return 0.05f * (x + y) + 0.9f * std::min(x, y);
+        return (x + y) * 0.5f;
+    };
+    std::vector<uint64_t> node_index(n), nearest(n, NONE), left(n - 1, NONE), right(n - 1, NONE);
+    std::vector<float> min_dist(n, BIG);
+    for (int i = 0; i < n; ++i) node_index[i] = i;
+    for (int i = 1; i < n; ++i) {
+        const float* row = D.data() + tri(i, 0);
+        for (int j = 0; j < i; ++j) {
+            const float d = row[j];
+            if (d < min_dist[i]) { min_dist[i] = d; nearest[i] = j; }
+            if (d < min_dist[j]) { min_dist[j] = d; nearest[j] = i; }
+        }
+    }
+    for (int it = 0; it < n - 1; ++it) {
+        uint64_t Lmin = NONE, Rmin = NONE;
+        float best = BIG;
+        for (int j = 0; j < n; ++j) {
+            if (node_index[j] == NONE) continue;
+            if (min_dist[j] < best) { best = min_dist[j]; Lmin = j; Rmin = nearest[j]; }
+        }
+        if (Lmin == NONE || Rmin == NONE)
+            throw std::runtime_error("UPGMA: no finite nearest neighbour (a pair with LCS 0?) -- the reference's "
+                                     "algorithm is undefined for this input");
+        float new_min = BIG;
+        uint64_t new_nearest = NONE;
+        for (uint64_t j = 0; j < (uint64_t)n; ++j) {
+            if (j == Lmin || j == Rmin || node_index[j] == NONE) continue;
+            const size_t vL = tri(Lmin, j), vR = tri(Rmin, j);
+            const float nd = average(D[vL], D[vR]);
+            if (nearest[j] == Rmin) nearest[j] = Lmin;
+            D[vL] = nd;
+            if (nd < new_min) { new_min = nd; new_nearest = j; }
+        }
+        left[it] = node_index[Lmin];
+        right[it] = node_index[Rmin];
+        node_index[Lmin] = (uint64_t)n + it;
+        nearest[Lmin] = new_nearest;
+        min_dist[Lmin] = new_min;
+        node_index[Rmin] = NONE;
+    }
+    tree.assign(n, node_t(-1, -1));
+    for (int i = 0; i < n - 1; ++i) tree.emplace_back((int)left[i], (int)right[i]);
+}
+
+// -gt nj
+void nj_tree(std::vector<float>& D, int n, tree_structure& tree)
+{
+    struct Cluster { float sum; int row, node; };
+    std::vector<Cluster> cl(n);
+    for (int i = 0; i < n; ++i) {
+        cl[i].row = cl[i].node = i;
+        cl[i].sum = 0;
+        for (int j = 0; j < n; ++j)
+            if (i != j) cl[i].sum += D[tri(i, j)];
+    }
+    tree.assign(n, node_t(-1, -1));
+    int iter = 0;
+    for (int n_clusters = n; n_clusters > 2; ++iter) {
+        float min_q = std::numeric_limits<float>::max();
+        int mi = 0, mj = 0;
+        for (int i = 0; i < n_clusters; ++i)
+            for (int j = i + 1; j < n_clusters; ++j) {
+                const float q = (n_clusters - 2) * D[tri(cl[i].row, cl[j].row)] - cl[i].sum - cl[j].sum;
+                if (q < min_q) { min_q = q; mi = i; mj = j; }
+            }
+        Cluster& ci = cl[mi];
+        Cluster& cj = cl[mj];
+        const float Dij = D[tri(ci.row, cj.row)];
+        tree.emplace_back(ci.node, cj.node);
+        ci.sum = 0;
+        ci.node = n + iter;
+        for (int k = 0; k < n_clusters; ++k) {
+            if (k == mi || k == mj) continue;
+            Cluster& ck = cl[k];
+            float Dik = D[tri(ci.row, ck.row)];
+            const float Djk = D[tri(cj.row, ck.row)];
+            ck.sum -= Dik + Djk;
+            Dik = (Dik + Djk - Dij) / 2;
+            ck.sum += Dik;
+            ci.sum += Dik;
+            D[tri(ci.row, ck.row)] = Dik;
+        }
+        cl.erase(cl.begin() + mj);
+        --n_clusters;
+    }
+    tree.emplace_back(cl[0].node, cl[1].node);
+}
+
+template <Distance D>
+void build_tree_d(LcsSource& src, GT method, tree_structure& tree)
+{
+    const int n = src.n();
+    switch (method) {
+    case GT::MST_Prim: mst_prim<D>(src, tree); break;
+    case GT::SLINK: slink<D>(src, tree); break;
+    case GT::UPGMA:
+    case GT::UPGMA_modified: {
+        std::vector<float> dist;
+        float_triangle<D>(src, dist);
+        if (method == GT::UPGMA) upgma_tree<false>(dist, n, tree); else upgma_tree<true>(dist, n, tree);
+        break;
+    }
+    case GT::NJ: {
+        std::vector<float> dist;
+        float_triangle<D>(src, dist);
+        nj_tree(dist, n, tree);
+        break;
+    }
+    }
+}
+
+} // namespace
+
+void build_tree(LcsSource& src, GT method, Distance dist, tree_structure& tree, int /*n_threads*/)
+{
+    const int n = src.n();
+    if (n < 2) {
+        tree.assign(std::max(n, 0), node_t(-1, -1));
+        return;
+    }
+    if (dist == Distance::indel_div_lcs) build_tree_d<Distance::indel_div_lcs>(src, method, tree);
+    else if (dist == Distance::indel075_div_lcs) build_tree_d<Distance::indel075_div_lcs>(src, method, tree);
+    else throw std::runtime_error("Error: Illegal pairwise distance measure.");
+}
+
+// ---------------------------------------------------------------------------------------------
+void tree_from_unique(tree_structure& vt, const std::vector<int>& sorted2unique)
+{
+    const int n_total = (int)sorted2unique.size();
+    const int n_uniques = (int)(vt.size() + 1) / 2; // GuideTree::getSequenceCount
+    const int n_dups = n_total - n_uniques;
+    std::vector<std::vector<int>> occ(n_uniques);
+    for (int i = 0; i < n_total; ++i) occ[sorted2unique[i]].push_back(i);
+    std::vector<int> out_ids(n_uniques);
+    vt.insert(vt.begin() + n_uniques, (size_t)2 * n_dups, node_t(-1, -1));
+    int node_id = n_uniques + n_dups;
+    for (int u = 0; u < n_uniques; ++u) {
+        const std::vector<int>& o = occ[u];
+        for (int i = 1; i < (int)o.size(); ++i, ++node_id) {
+            if (i == 1) vt[node_id] = node_t(o[0], o[1]);
+            else vt[node_id] = node_t(o[i], node_id - 1);
+        }
+        out_ids[u] = o.size() > 1 ? node_id - 1 : o[0];
+    }
+    for (int i = node_id; i < (int)vt.size(); ++i) {
+        node_t& nd = vt[i];
+        nd.first = nd.first < n_uniques ? out_ids[nd.first] : nd.first + 2 * n_dups;
+        nd.second = nd.second < n_uniques ? out_ids[nd.second] : nd.second + 2 * n_dups;
+    }
+}
+
+std::string tree_to_newick(const tree_structure& tree, const std::vector<std::string>& names)
+{
+    const int n_leaves = (int)names.size();
+    std::string out;
+    if (tree.empty()) return out;
+    const int root = (int)tree.size() - 1;
+    // explicit stack: (node, state) with state 0 = open, 1 = between children, 2 = close
+    std::vector<std::pair<int, int>> st;
+    st.emplace_back(root, 0);
+    while (!st.empty()) {
+        auto& top = st.back();
+        const int node = top.first;
+        if (node < n_leaves) {
+            const char* name = names[node].c_str();
+            if (*name == '>') ++name;
+            out += name;
+            out += ":1.0";
+            st.pop_back();
+            continue;
+        }
+        if (top.second == 0) {
+            out += '(';
+            top.second = 1;
+            st.emplace_back(tree[node].first, 0);
+        } else if (top.second == 1) {
+            out += ',';
+            top.second = 2;
+            st.emplace_back(tree[node].second, 0);
+        } else {
+            out += node == root ? ");" : "):1.0";
+            st.pop_back();
+        }
+    }
+    return out;
+}
+
+// ---------------------------------------------------------------------------------------------
+// double -> int64 as the reference's x86-64 build converts it (cvttsd2si: out-of-range values,
+// e.g. the lcs == 0 distance, become INT64_MIN); in range it is plain truncation
+static inline int64_t trunc_i64(double v)
+{
+    if (!(v >= -9223372036854775808.0 && v < 9223372036854775808.0)) return INT64_MIN;
+    return (int64_t)v;
+}
+
+static int put_u64(uint64_t v, char* out)
+{
+    char tmp[24];
+    int n = 0, k = 0;
+    if (v == 0) tmp[n++] = '0';
+    for (; v; v /= 10) tmp[n++] = (char)('0' + v % 10);
+    while (n) out[k++] = tmp[--n];
+    return k;
+}
+
+int format_distance(double val, char* out)
+{
+    // NumericConversions::Double2PChar(val, 6, out) (reference utils/conversion.h:109-119)
+    const int64_t a = trunc_i64(val);
+    const int64_t b = trunc_i64((1.0 + (val - (double)a)) * 1000000.0 + 0.5);
+    const int r1 = put_u64((uint64_t)a, out);
+    const int r2 = put_u64((uint64_t)b, out + r1);
+    out[r1] = '.';
+    return r1 + r2;
+}
+
+template <Distance D>
+static void write_csv_d(LcsSource& src, const std::vector<std::string>& ids, bool square, bool pid,
+                        const std::string& path)
+{
+    const int n = src.n();
+    std::ofstream ofs(path, std::ios::binary);
+    if (!ofs.good()) throw std::runtime_error("cannot open " + path);
+    if (square) {
+        for (const auto& id : ids) ofs << ',' << (id.c_str() + 1);
+        ofs << std::endl;
+    }
+    Transform<double, D> t_dist;
+    Transform<float, Distance::pairwise_identity> t_pid;
+    std::vector<char> line(10000 + (size_t)n * 100);
+    const int block = std::max(1, std::min(n, 2048));
+    LcsBuf buf;
+    std::vector<int> refs;
+    for (int r0 = 0; r0 < n; r0 += block) {
+        const int r1 = std::min(n, r0 + block);
+        if (square) {
+            refs.resize(r1 - r0);
+            for (int i = r0; i < r1; ++i) refs[i - r0] = i;
+            src.rect(refs.data(), r1 - r0, nullptr, n, buf);
+        } else {
+            src.triangle(r0, r1, buf);
+        }
+        const size_t off = (size_t)r0 * (r0 > 0 ? r0 - 1 : 0) / 2;
+        for (int i = r0; i < r1; ++i) {
+            char* p = line.data();
+            p += sprintf(p, "%s,", ids[i].c_str() + 1);
+            const int cols = square ? n : i;
+            const uint32_t len_i = src.length(i);
+            for (int j = 0; j < cols; ++j) {
+                const uint32_t l = square ? buf[(size_t)(i - r0) * n + j] : buf[(size_t)i * (i - 1) / 2 + j - off];
+                // the reference stores both kinds as float before printing (DistanceCalculator.cpp:44-76)
+                const float v = pid ? t_pid(l, len_i, src.length(j)) : (float)t_dist(l, len_i, src.length(j));
+                p += format_distance((double)v, p);
+                *p++ = ',';
+            }
+            --p;
+            *p++ = '\n';
+            ofs.write(line.data(), p - line.data());
+        }
+    }
+}
+
+void write_distance_csv(LcsSource& src, const std::vector<std::string>& ids, Distance dist, bool square, bool pid,
+                        const std::string& path)
+{
+    if (dist == Distance::indel_div_lcs) write_csv_d<Distance::indel_div_lcs>(src, ids, square, pid, path);
+    else write_csv_d<Distance::indel075_div_lcs>(src, ids, square, pid, path);
+}
+
+} // namespace famsa_host

@@ -1,0 +1,42 @@
+// trees.h -- guide-tree builders over GPU-computed LCS lengths.
+// Each builder restates one reference generator's algorithm on top of an LcsSource; the
+// distances are produced with the reference's Transform types and operand order so that tie
+// breaking and float/double rounding, hence the tree topology, are identical.
+// Tree representation = the reference's tree_structure (tree/TreeDefs.h:15-16): node i < n is a
+// leaf (-1,-1); internal nodes are appended as (left, right) child ids.
+#pragma once
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "lcs_source.h"
+#include "transform.h"
+
+namespace famsa_host {
+
+using node_t = std::pair<int, int>;
+using tree_structure = std::vector<node_t>;
+
+enum class GT { MST_Prim, SLINK, UPGMA, UPGMA_modified, NJ };
+GT gt_from_string(const std::string& name); // "sl" | "slink" | "upgma" | "upgma_modified" | "nj"
+
+// Build the guide tree over src's sequences (ids 0..n-1 = the sorted unique working order).
+// Result has 2n-1 nodes.  Restates (reference, src/tree/): MSTPrim.cpp:280-549 + 784-833,
+// SingleLinkage.cpp:31-189, UPGMA.cpp:39-51 + 114-295, NeighborJoining.cpp:10-118.
+void build_tree(LcsSource& src, GT method, Distance dist, tree_structure& tree, int n_threads);
+
+// GuideTree::fromUnique (reference tree/GuideTree.cpp:146-208): re-attach removed duplicates.
+void tree_from_unique(tree_structure& tree, const std::vector<int>& sorted2unique);
+
+// NewickParser::store (reference tree/NewickParser.cpp:103-165); names[i] = id of leaf i
+// (a leading '>' is dropped), every branch ":1.0", no trailing newline.
+std::string tree_to_newick(const tree_structure& tree, const std::vector<std::string>& names);
+
+// -dist_export writer (reference tree/DistanceCalculator.cpp:11-122 with
+// utils/conversion.h:109-119): rows in input order, ref = row, partner = column.
+void write_distance_csv(LcsSource& src, const std::vector<std::string>& ids, Distance dist, bool square,
+                        bool pid, const std::string& path);
+// the number format alone (exposed for tests): returns characters written
+int format_distance(double val, char* out);
+
+} // namespace famsa_host

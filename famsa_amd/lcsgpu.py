@@ -45,6 +45,7 @@ def load_library():
         "lcsgpu_upload": (C.c_int, [vp, vp, vp, i32]),
         "lcsgpu_count": (i32, [vp]),
         "lcsgpu_length": (i32, [vp, i32]),
+        "lcsgpu_orientation_flags": (i32, [vp, vp]),
         "lcsgpu_lcs_rect": (C.c_int, [vp, pi32, i32, i32, pi32, i32, i32, vp, i64, C.c_int]),
         "lcsgpu_lcs_rect_dev": (C.c_int, [vp, pi32, i32, i32, pi32, i32, i32, vp, i64, C.c_int, C.c_int]),
         "lcsgpu_lcs_triangle": (C.c_int, [vp, i32, i32, vp, C.c_int]),
@@ -122,6 +123,13 @@ class LcsGpu:
         np.cumsum(lens, out=offsets[1:])
         codes = np.concatenate(seqs) if len(seqs) and offsets[-1] > 0 else np.zeros(0, dtype=np.uint8)
         self.upload(codes, offsets)
+
+    def orientation_flags(self):
+        flags = np.zeros(max(self.n, 1), dtype=np.uint8)
+        rc = self._lib.lcsgpu_orientation_flags(self._ctx, flags.ctypes.data)
+        if rc < 0:
+            self._check(rc)
+        return flags[: self.n]
 
     def lcs_rect(self, refs, cols, dtype=np.uint16):
         """refs / cols: (begin, count) tuple or id array.  Returns [n_refs, n_cols] host array."""

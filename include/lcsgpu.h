@@ -71,6 +71,14 @@ int lcsgpu_upload(lcsgpu_ctx* ctx, const uint8_t* codes, const uint64_t* offsets
 int32_t lcsgpu_count(lcsgpu_ctx* ctx);
 int32_t lcsgpu_length(lcsgpu_ctx* ctx, int32_t i);
 
+/* Which uploaded sequences are orientation sensitive AS A REF, i.e. hold an aligned 64-residue
+ * homopolymer word at word index >= 1, the only case in which the reference's carry rule
+ * (lcs/lcsbp_classic.h:55-56) departs from a true LCS.  flags (may be NULL) receives n bytes of
+ * 0/1; the return value is the number of such sequences (>= 0) or a negative error code.  When it
+ * is 0, LCS(ref=a, partner=b) == LCS(ref=b, partner=a) for every pair of the set, so a consumer
+ * that needs both orientations (MSTPrim: ref = the node just added) can use one triangle. */
+int32_t lcsgpu_orientation_flags(lcsgpu_ctx* ctx, uint8_t* flags);
+
 /* Rectangle of oriented LCS lengths into HOST memory:
  *   out[r * ld + c] = LCS(ref = ref_ids[r], partner = col(c)),  r < n_refs, c < n_cols
  * col(c) = col_ids[c] if col_ids != NULL, else col_begin + c.  elem_size is 2 (uint16_t)
