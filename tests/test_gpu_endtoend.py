@@ -1,0 +1,99 @@
+"""GPU end-to-end tests: FASTA in -> Newick / CSV out through the C++ host layer and the famsa-gpu CLI,
+LCS computed by the HIP kernels; byte-identical to the reference's outputs (committed goldens)."""
+import hashlib
+import json
+import os
+import subprocess
+
+import pytest
+
+import host_bind
+import oracle_bind
+from famsa_amd import seqio
+
+pytestmark = pytest.mark.gpu
+G = oracle_bind.GOLDEN
+
+
+@pytest.fixture(scope="module")
+def host():
+    return host_bind.Host()
+
+
+def run_cli(*args):
+    p = subprocess.run([host_bind.CLI, *args], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert p.returncode == 0, p.stderr
+    return p
+
+
+@pytest.mark.parametrize("gt", ["sl", "slink", "upgma", "nj"])
+def test_cli_adeno_tree(tmp_path, gt):
+    out = str(tmp_path / "t.dnd")
+    run_cli("-gt", gt, "-gt_export", os.path.join(G, "adeno_fiber", "adeno_fiber"), out)
+    assert open(out, "rb").read() == open(os.path.join(G, "adeno_fiber", gt + ".dnd"), "rb").read()
+
+
+def test_cli_default_is_sl_and_verbose_stats(tmp_path):
+    out = str(tmp_path / "t.dnd")
+    p = run_cli("-v", "-gt_export", os.path.join(G, "adeno_fiber", "adeno_fiber"), out)
+    assert open(out, "rb").read() == open(os.path.join(G, "adeno_fiber", "sl.dnd"), "rb").read()
+    assert "time.tree_build=" in p.stderr and "gpu.lcs_kernel_ms=" in p.stderr
+
+
+@pytest.mark.parametrize("name,flags", [("dist", []), ("pid", ["-pid"]), ("dist_sq", ["-square_matrix"]),
+                                        ("pid_sq", ["-square_matrix", "-pid"])])
+def test_cli_adeno_dist_export(tmp_path, name, flags):
+    out = str(tmp_path / "d.csv")
+    run_cli("-dist_export", *flags, os.path.join(G, "adeno_fiber", "adeno_fiber"), out)
+    assert open(out, "rb").read() == open(os.path.join(G, "adeno_fiber", name + ".csv"), "rb").read()
+
+
+def test_cli_duplicates(tmp_path):
+    out = str(tmp_path / "t.dnd")
+    run_cli("-gt", "sl", "-gt_export", os.path.join(G, "adeno_fiber_duplicates", "adeno_fiber_duplicates"), out)
+    assert open(out, "rb").read() == open(os.path.join(G, "adeno_fiber_duplicates", "sl.dnd"), "rb").read()
+
+
+@pytest.mark.parametrize("gt", ["sl", "slink", "upgma", "nj"])
+def test_hemopexin_tree(host, gt):
+    got = host.tree_gpu(os.path.join(G, "hemopexin", "hemopexin"), gt)
+    assert got == open(os.path.join(G, "hemopexin", gt + ".dnd"), "rb").read()
+
+
+def test_hemopexin_dist_export_checksum(host, tmp_path):
+    """BASELINE config 2: hemopexin -dist_export, 79 MB of CSV, byte-identical (sha256 from the reference)."""
+    meta = json.load(open(os.path.join(G, "meta.json")))["hemopexin"]
+    out = str(tmp_path / "d.csv")
+    host.dist_export_gpu(os.path.join(G, "hemopexin", "hemopexin"), out)
+    data = open(out, "rb").read()
+    assert len(data) == meta["dist_csv_bytes"]
+    assert hashlib.sha256(data).hexdigest() == meta["dist_csv_sha256"]
+
+
+@pytest.mark.parametrize("gt", ["sl", "slink", "upgma", "nj"])
+def test_adversarial_tree_with_carry_quirk(host, gt):
+    got = host.tree_gpu(os.path.join(G, "adversarial_tree.fasta"), gt)
+    assert got == open(os.path.join(G, f"adversarial_tree_{gt}.dnd"), "rb").read()
+
+
+def test_adversarial_csv(host, tmp_path):
+    out = str(tmp_path / "d.csv")
+    f = os.path.join(G, "adversarial.fasta")
+    host.dist_export_gpu(f, out, square_matrix=True)
+    assert open(out, "rb").read() == open(os.path.join(G, "adversarial_dist_sq.csv"), "rb").read()
+    host.dist_export_gpu(f, out, pid=True)
+    assert open(out, "rb").read() == open(os.path.join(G, "adversarial_pid.csv"), "rb").read()
+
+
+@pytest.mark.parametrize("gt", ["sl", "upgma"])
+def test_synthetic_2k_tree(host, tmp_path, gt):
+    codes, offsets = seqio.synth_uniform(2000, 400)
+    f = str(tmp_path / "s.fasta")
+    seqio.to_fasta(codes, offsets, f)
+    assert host.tree_gpu(f, gt) == open(os.path.join(G, f"synth2k_{gt}.dnd"), "rb").read()
+
+
+def test_cli_refuses_out_of_scope_flags(tmp_path):
+    p = subprocess.run([host_bind.CLI, "-medoidtree", "-gt_export", os.path.join(G, "adeno_fiber", "adeno_fiber"),
+                        str(tmp_path / "x")], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert p.returncode != 0 and "outside the scope" in p.stderr
