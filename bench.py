@@ -33,13 +33,6 @@ ALGO_BYTES_PER_PAIR_EXTRA = 2  # uint16 result; + len_partner residue bytes (SUR
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 
 
-def row_cuts(n, parts):
-    """Row-block boundaries with equal pair counts: row i has i pairs, so cut at n*sqrt(k/parts)."""
-    cuts = [int(round(n * math.sqrt(k / parts))) for k in range(parts + 1)]
-    cuts[0], cuts[-1] = 0, n
-    return cuts
-
-
 def cpu_baseline(n, length, target_s=12.0):
     """The reference's UPGMA::computeDistances (tree/UPGMA.cpp:75-109, AVX2 dispatch) on the first
     n_use sequences of the same synthetic set, all host cores."""
@@ -89,6 +82,7 @@ def main():
     import torch
     import famsa_amd
     from famsa_amd import seqio
+    from famsa_amd.rowblock import row_cuts, pairs_in_rows, max_block_rows
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -111,10 +105,10 @@ def main():
 
     cuts = row_cuts(n, world)
     r0, r1 = cuts[rank], cuts[rank + 1]
-    my_pairs = r1 * (r1 - 1) // 2 - r0 * (r0 - 1) // 2
+    my_pairs = pairs_in_rows(r0, r1)
     total_pairs = n * (n - 1) // 2
     tri = torch.empty(max(my_pairs, 1), dtype=torch.int16, device=dev)
-    max_rows = max(cuts[k + 1] - cuts[k] for k in range(world))
+    max_rows = max_block_rows(cuts)
     mins = torch.zeros(max_rows * 2, dtype=torch.float64, device=dev)  # (double, int64) records
     gathered = torch.zeros(world * max_rows * 2, dtype=torch.float64, device=dev) if world > 1 else None
     ext = torch.cuda.ExternalStream(eng._lib.lcsgpu_stream(eng._ctx), device=dev)
