@@ -157,7 +157,15 @@ def main():
         k_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
         algo_bytes = my_pairs * (L + ALGO_BYTES_PER_PAIR_EXTRA)
         achieved = algo_bytes / (k_ms * 1e-3) / 1e9
-        word_steps = my_pairs * L * ((L + 63) // 64)
+        halfword_steps = my_pairs * L * ((L + 31) // 32)
+        # HBM-side bytes per launch from the committed PMC passes (same workload only), else null
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_r01.json")))
+            if (pmc["n_seqs"], pmc["seq_len"], pmc["n_gpus"]) == (n, L, world):
+                traffic = pmc["traffic_bytes"] / 1e9
+        except Exception:
+            pass
         out = {
             "metric": "lcs_gcell_updates_per_s",
             "value": value,
@@ -184,13 +192,16 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
-                "kernel": "lcs_rows_kernel<7,4,false>",
+                "traffic": traffic,
+                "kernel": f"lcsgpu::lcs_rows_kernel_pipe<{(L + 31) // 32}, 4, 8>",
                 "kernel_ms": k_ms,
                 "algorithmic_bytes_per_pair": L + ALGO_BYTES_PER_PAIR_EXTRA,
-                "note": "integer-VALU bound by construction (SURVEY 8d): see valu_* fields",
-                "valu_word_steps_per_s": word_steps / (k_ms * 1e-3),
-                "valu_ops_per_word_step": 6,
+                "note": "achieved/peak/traffic in GB/s resp. GB per launch; the kernel is integer-VALU bound by "
+                        "construction (SURVEY 8d): valu_* fields give half-word-steps/s against the measured "
+                        "VALU-only ceiling of scripts/ubench.hip (profiles/ubench_r01.txt)",
+                "valu_halfword_steps_per_s": halfword_steps / (k_ms * 1e-3),
+                "valu_ops_per_halfword_step": 3,
+                "valu_ceiling_halfword_steps_per_s": 20.2e12,
             },
         }
         if not args.no_cpu_baseline and world == 1:

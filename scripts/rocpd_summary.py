@@ -16,8 +16,8 @@ for path in sys.argv[1:]:
     print(f"== {path}")
     try:
         rows = list(cur.execute("select name,total_calls,total_duration,average,percentage from top_kernels"))
-        print("kernel-trace stats (durations in ns):")
-        print(f"{'calls':>6} {'total_ns':>16} {'avg_ns':>16} {'pct':>7}  name")
+        print("kernel-trace stats (durations in us):")
+        print(f"{'calls':>6} {'total_us':>16} {'avg_us':>16} {'pct':>7}  name")
         for name, calls, tot, avg, pct in rows[:12]:
             print(f"{calls:>6} {tot:>16.0f} {avg:>16.1f} {pct:>7.2f}  {short(name)}")
     except sqlite3.Error as e:
