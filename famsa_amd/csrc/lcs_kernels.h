@@ -53,4 +53,35 @@ hipError_t launch_row_minima(const void* tri, int elem_size, int32_t row_begin, 
                              const uint32_t* lens, const double* pow_table, int kind, RowMin* out,
                              hipStream_t stream);
 
+
+// ---- device-side Prim (tree_kernels.hip) ----
+struct PrimPartial {
+    double d;
+    uint64_t id;
+    int32_t v; // -1 = no unprocessed vertex in this workgroup
+    int32_t pad;
+};
+struct MstEdge { // = lcsgpu_mst_edge
+    int32_t from, to;
+    double dist;
+};
+struct PrimArgs {
+    const void* tri;          // lower triangle, ref = larger id
+    const uint32_t* lens;
+    const double* pow_table;
+    const int32_t* qindex;    // per sequence: index among the orientation-sensitive ones or -1 (null if none)
+    const uint32_t* q_rows;   // [n_q][n]  LCS(ref = q, partner = v)
+    const uint32_t* q_cols;   // [n][n_q]  LCS(ref = v, partner = q)
+    int32_t n_q;
+    int32_t n;
+    int32_t kind;
+    int32_t n_blocks;
+    double* key_d;
+    uint64_t* key_id;
+    uint8_t* processed;
+    PrimPartial* partials;    // [2][n_blocks]
+    MstEdge* edges;           // [n-1]
+};
+hipError_t launch_prim(const PrimArgs& a, int elem_size, hipStream_t stream);
+
 } // namespace lcsgpu

@@ -99,7 +99,7 @@ struct lcsgpu_ctx {
     DevBuf d_tiles, d_tile_base, d_lens, d_pow;
 
     // per-call scratch
-    DevBuf d_plan, d_out, d_carry;
+    DevBuf d_plan, d_out, d_carry, d_prim, d_qrows, d_qcols;
     PinBuf h_plan;
     bool plan_in_flight = false;
     int last_launches = 0;
@@ -349,6 +349,9 @@ int lcsgpu_destroy(lcsgpu_ctx* ctx)
     ctx->d_plan.release();
     ctx->d_out.release();
     ctx->d_carry.release();
+    ctx->d_prim.release();
+    ctx->d_qrows.release();
+    ctx->d_qcols.release();
     ctx->h_plan.release();
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
     if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
@@ -569,6 +572,75 @@ int lcsgpu_row_minima_dev(lcsgpu_ctx* ctx, const void* d_triangle, int elem_size
                                       (const double*)ctx->d_pow.p, distance_kind, (lcsgpu::RowMin*)d_out,
                                       ctx->stream));
     if (sync) HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return LCSGPU_OK;
+}
+
+int lcsgpu_mst_prim(lcsgpu_ctx* ctx, int distance_kind, lcsgpu_mst_edge* out_edges)
+{
+    if (!ctx) return fail(LCSGPU_E_INVALID, "NULL ctx");
+    if (ctx->n < 0) return fail(LCSGPU_E_STATE, "no sequence set uploaded");
+    if (distance_kind != LCSGPU_DIST_INDEL_DIV_LCS && distance_kind != LCSGPU_DIST_INDEL075_DIV_LCS)
+        return fail(LCSGPU_E_INVALID, "unknown distance kind %d", distance_kind);
+    const int32_t n = ctx->n;
+    if (n < 2) return LCSGPU_OK;
+    if (!out_edges) return fail(LCSGPU_E_INVALID, "NULL out_edges");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIP_TRY(hipSetDevice(ctx->device));
+    const int elem = ctx->max_len > 65535 ? 4 : 2;
+    const size_t pairs = (size_t)n * (n - 1) / 2;
+    HIP_TRY(ctx->d_out.reserve(pairs * elem));
+    int rc = run_rows(ctx, lcsgpu::MODE_TRIANGLE, nullptr, 0, n, nullptr, 0, n - 1, ctx->d_out.p, 0, 0, elem);
+    if (rc) return rc;
+
+    // orientation-sensitive sequences: their values in both roles, as side tables
+    std::vector<int32_t> qindex(n, -1), qlist;
+    for (int32_t i = 0; i < n; ++i)
+        if (ctx->quirk[i]) {
+            qindex[i] = (int32_t)qlist.size();
+            qlist.push_back(i);
+        }
+    const int32_t nq = (int32_t)qlist.size();
+    if (nq) {
+        HIP_TRY(ctx->d_qrows.reserve((size_t)nq * n * 4));
+        HIP_TRY(ctx->d_qcols.reserve((size_t)nq * n * 4));
+        rc = run_rows(ctx, lcsgpu::MODE_RECT, qlist.data(), 0, nq, nullptr, 0, n, ctx->d_qrows.p, n, 0, 4);
+        if (rc) return rc;
+        HIP_TRY(hipStreamSynchronize(ctx->stream)); // the staging buffer of the plan is reused by the next call
+        ctx->plan_in_flight = false;
+        rc = run_rows(ctx, lcsgpu::MODE_RECT, nullptr, 0, n, qlist.data(), 0, nq, ctx->d_qcols.p, nq, 0, 4);
+        if (rc) return rc;
+    }
+
+    const int blocks = (n + 255) / 256;
+    auto a8 = [](size_t x) { return (x + 15) & ~(size_t)15; };
+    const size_t o_keyd = 0, o_keyi = o_keyd + a8((size_t)n * 8), o_proc = o_keyi + a8((size_t)n * 8),
+                 o_part = o_proc + a8((size_t)n), o_edges = o_part + a8((size_t)2 * blocks * sizeof(lcsgpu::PrimPartial)),
+                 o_qidx = o_edges + a8((size_t)(n - 1) * sizeof(lcsgpu::MstEdge)), total = o_qidx + a8((size_t)n * 4);
+    HIP_TRY(ctx->d_prim.reserve(total));
+    char* base = (char*)ctx->d_prim.p;
+    if (nq) HIP_TRY(hipMemcpyAsync(base + o_qidx, qindex.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+    lcsgpu::PrimArgs a{};
+    a.tri = ctx->d_out.p;
+    a.lens = (const uint32_t*)ctx->d_lens.p;
+    a.pow_table = (const double*)ctx->d_pow.p;
+    a.qindex = nq ? (const int32_t*)(base + o_qidx) : nullptr;
+    a.q_rows = (const uint32_t*)ctx->d_qrows.p;
+    a.q_cols = (const uint32_t*)ctx->d_qcols.p;
+    a.n_q = nq;
+    a.n = n;
+    a.kind = distance_kind;
+    a.n_blocks = blocks;
+    a.key_d = (double*)(base + o_keyd);
+    a.key_id = (uint64_t*)(base + o_keyi);
+    a.processed = (uint8_t*)(base + o_proc);
+    a.partials = (lcsgpu::PrimPartial*)(base + o_part);
+    a.edges = (lcsgpu::MstEdge*)(base + o_edges);
+    HIP_TRY(lcsgpu::launch_prim(a, elem, ctx->stream));
+    static_assert(sizeof(lcsgpu_mst_edge) == sizeof(lcsgpu::MstEdge), "edge layout");
+    HIP_TRY(hipMemcpyAsync(out_edges, a.edges, (size_t)(n - 1) * sizeof(lcsgpu_mst_edge), hipMemcpyDeviceToHost,
+                           ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->plan_in_flight = false;
     return LCSGPU_OK;
 }
 

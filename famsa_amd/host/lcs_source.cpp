@@ -62,6 +62,17 @@ void GpuLcsSource::rect(const int* refs, int n_refs, const int* cols, int n_cols
     if (lcsgpu_last_kernel_ms(ctx_, &ms, &nl) == LCSGPU_OK) kernel_ms_ += ms;
 }
 
+bool GpuLcsSource::prim_edges(int distance_kind, std::vector<MstEdge>& edges)
+{
+    static_assert(sizeof(MstEdge) == sizeof(lcsgpu_mst_edge), "edge layout");
+    edges.resize(n() > 0 ? n() - 1 : 0);
+    check(lcsgpu_mst_prim(ctx_, distance_kind, (lcsgpu_mst_edge*)edges.data()), "lcsgpu_mst_prim");
+    double ms = 0;
+    int32_t nl = 0;
+    if (lcsgpu_last_kernel_ms(ctx_, &ms, &nl) == LCSGPU_OK) kernel_ms_ += ms;
+    return true;
+}
+
 MatrixLcsSource::MatrixLcsSource(int n, const uint32_t* lens, const uint32_t* square)
     : n_(n), lens_(lens, lens + n), m_(square, square + (size_t)n * n), sensitive_(false)
 {

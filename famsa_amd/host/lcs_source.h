@@ -41,6 +41,11 @@ public:
     // out[r*n_cols + c] = LCS(ref = refs[r], partner = cols ? cols[c] : c)
     virtual void rect(const int* refs, int n_refs, const int* cols, int n_cols, LcsBuf& out) = 0;
     bool wide() const;
+    // Prim's MST computed by the source itself (the GPU engine does it on the device): n-1 edges
+    // (from < to, distance) in the order they are added from vertex 0.  Returns false if the
+    // source cannot (then the caller runs Prim on the host over triangle()/rect()).
+    struct MstEdge { int32_t from, to; double dist; };
+    virtual bool prim_edges(int /*distance_kind*/, std::vector<MstEdge>& /*edges*/) { return false; }
 };
 
 // The MI355X engine.  Throws std::runtime_error if the library reports an error (no fallback).
@@ -54,6 +59,7 @@ public:
     bool orientation_sensitive() const override { return sensitive_; }
     void triangle(int r0, int r1, LcsBuf& out) override;
     void rect(const int* refs, int n_refs, const int* cols, int n_cols, LcsBuf& out) override;
+    bool prim_edges(int distance_kind, std::vector<MstEdge>& edges) override;
     double kernel_ms_total() const { return kernel_ms_; }
 
 private:

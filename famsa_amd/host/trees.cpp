@@ -71,54 +71,63 @@ template <Distance D>
 void mst_prim(LcsSource& src, tree_structure& tree)
 {
     const int n = src.n();
-    LcsBuf buf;
-    PrimLcs lcs;
-    lcs.n = n;
-    if (src.orientation_sensitive()) {
-        // ref = the node just added, partner = the candidate (reference MSTPrim.cpp:478-485): the
-        // triangle's fixed orientation is not enough, take both orientations
-        std::vector<int> all(n);
-        for (int i = 0; i < n; ++i) all[i] = i;
-        src.rect(all.data(), n, nullptr, n, buf);
-        lcs.sq_buf = &buf;
-    } else {
-        src.triangle(0, n, buf);
-        lcs.tri_buf = &buf;
-    }
-
-    Transform<double, D> transform;
-    std::vector<Key> key(n, Key{std::numeric_limits<double>::max(), 0});
-    std::vector<int> alive;
-    alive.reserve(n);
-    for (int v = 1; v < n; ++v) alive.push_back(v);
     std::vector<int> prim_order(n, n);
     std::vector<Edge> edges;
     edges.reserve(n);
     edges.push_back(Edge{0, 0, 0, 0.0}); // the dummy the reference inserts at index 0
-    int cur = 0, next_order = 0;
-    prim_order[cur] = next_order++;
+    int next_order = 0;
+    prim_order[0] = next_order++;
 
-    while (!alive.empty()) {
-        const uint32_t len_cur = src.length(cur);
-        size_t best_pos = 0;
-        for (size_t p = 0; p < alive.size(); ++p) {
-            const int v = alive[p];
-            const double d = transform(lcs(cur, v), len_cur, src.length(v));
-            if (d <= key[v].d) {
-                const Key s{d, ~pack_ids(cur, v)};
-                if (s < key[v]) key[v] = s;
-            }
-            if (key[v] < key[alive[best_pos]]) best_pos = p;
+    std::vector<LcsSource::MstEdge> dev_edges;
+    if (src.prim_edges((int)D, dev_edges)) {
+        // the engine ran the n-1 relaxation steps on the device; replay the bookkeeping
+        for (const auto& e : dev_edges) {
+            edges.push_back(Edge{e.from, e.to, next_order, -e.dist});
+            if (prim_order[e.from] == n) prim_order[e.from] = next_order++; else prim_order[e.to] = next_order++;
         }
-        const int best = alive[best_pos];
-        const uint64_t packed = ~key[best].id;
-        int a = (int)(packed >> 32), b = (int)(packed & 0xffffffffull);
-        if (a > b) std::swap(a, b);
-        edges.push_back(Edge{a, b, next_order, -key[best].d});
-        if (prim_order[a] == n) prim_order[a] = next_order++; else prim_order[b] = next_order++;
-        alive[best_pos] = alive.back();
-        alive.pop_back();
-        cur = best;
+    } else {
+        LcsBuf buf;
+        PrimLcs lcs;
+        lcs.n = n;
+        if (src.orientation_sensitive()) {
+            // ref = the node just added, partner = the candidate (reference MSTPrim.cpp:478-485): the
+            // triangle's fixed orientation is not enough, take both orientations
+            std::vector<int> all(n);
+            for (int i = 0; i < n; ++i) all[i] = i;
+            src.rect(all.data(), n, nullptr, n, buf);
+            lcs.sq_buf = &buf;
+        } else {
+            src.triangle(0, n, buf);
+            lcs.tri_buf = &buf;
+        }
+        Transform<double, D> transform;
+        std::vector<Key> key(n, Key{std::numeric_limits<double>::max(), 0});
+        std::vector<int> alive;
+        alive.reserve(n);
+        for (int v = 1; v < n; ++v) alive.push_back(v);
+        int cur = 0;
+        while (!alive.empty()) {
+            const uint32_t len_cur = src.length(cur);
+            size_t best_pos = 0;
+            for (size_t p = 0; p < alive.size(); ++p) {
+                const int v = alive[p];
+                const double d = transform(lcs(cur, v), len_cur, src.length(v));
+                if (d <= key[v].d) {
+                    const Key s{d, ~pack_ids(cur, v)};
+                    if (s < key[v]) key[v] = s;
+                }
+                if (key[v] < key[alive[best_pos]]) best_pos = p;
+            }
+            const int best = alive[best_pos];
+            const uint64_t packed = ~key[best].id;
+            int a = (int)(packed >> 32), b = (int)(packed & 0xffffffffull);
+            if (a > b) std::swap(a, b);
+            edges.push_back(Edge{a, b, next_order, -key[best].d});
+            if (prim_order[a] == n) prim_order[a] = next_order++; else prim_order[b] = next_order++;
+            alive[best_pos] = alive.back();
+            alive.pop_back();
+            cur = best;
+        }
     }
 
     // mst_to_dendogram (reference MSTPrim.cpp:784-833): split every range of the Prim order at

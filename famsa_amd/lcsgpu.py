@@ -51,6 +51,7 @@ def load_library():
         "lcsgpu_lcs_triangle": (C.c_int, [vp, i32, i32, vp, C.c_int]),
         "lcsgpu_lcs_triangle_dev": (C.c_int, [vp, i32, i32, vp, C.c_int, C.c_int]),
         "lcsgpu_row_minima_dev": (C.c_int, [vp, vp, C.c_int, i32, i32, C.c_int, vp, C.c_int]),
+        "lcsgpu_mst_prim": (C.c_int, [vp, C.c_int, vp]),
         "lcsgpu_sync": (C.c_int, [vp]),
         "lcsgpu_last_kernel_ms": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(i32)]),
         "lcsgpu_stream": (vp, [vp]),
@@ -161,6 +162,13 @@ class LcsGpu:
     def row_minima_dev(self, d_tri_ptr, elem_size, row_begin, row_end, kind, d_out_ptr, sync=False):
         self._check(self._lib.lcsgpu_row_minima_dev(self._ctx, C.c_void_p(d_tri_ptr), elem_size, row_begin,
                                                     row_end, kind, C.c_void_p(d_out_ptr), 1 if sync else 0))
+
+    def mst_prim(self, kind=1):
+        """Edges of Prim's MST in insertion order: structured array (from, to, dist)."""
+        dt = np.dtype([("from", np.int32), ("to", np.int32), ("dist", np.float64)])
+        out = np.zeros(max(self.n - 1, 0), dtype=dt)
+        self._check(self._lib.lcsgpu_mst_prim(self._ctx, kind, out.ctypes.data if out.size else None))
+        return out
 
     def sync(self):
         self._check(self._lib.lcsgpu_sync(self._ctx))

@@ -139,6 +139,24 @@ typedef struct lcsgpu_rowmin {
 int lcsgpu_row_minima_dev(lcsgpu_ctx* ctx, const void* d_triangle, int elem_size, int32_t row_begin,
                           int32_t row_end, int distance_kind, void* d_out, int sync);
 
+/* One edge of the minimum spanning tree, in the order Prim's algorithm adds them. */
+typedef struct lcsgpu_mst_edge {
+    int32_t from, to; /* from < to */
+    double dist;      /* Transform<double, kind> of the pair, ref = the endpoint that was in the tree */
+} lcsgpu_mst_edge;
+
+/* Prim's MST over the complete graph of the uploaded set, entirely on the device: the LCS
+ * triangle is computed into HBM, then n-1 relaxation steps run over it (one launch per step).
+ * out_edges (HOST, n-1 records) receives the edges in the order they are added, starting from
+ * vertex 0.  Semantics are those of MSTPrim::run_view (tree/MSTPrim.cpp:280-549): distance
+ * d(cur, v) uses LCS(ref = cur, partner = v); keys are (d, ~((uint64)min(cur,v) << 32 | max(cur,v)))
+ * compared lexicographically (mst_edge_t / dist_t, tree/MSTPrim.h:424-483), so the tree and the
+ * order are unique and identical to the reference's.  What stays on the host is the MST ->
+ * dendrogram conversion (tree/MSTPrim.cpp:784-833), which is O(n log n).
+ * Replaces: the per-step distance batches (calculateDistanceRangeSV, hpp:287-375), the key update
+ * and the candidate selection of MSTPrim::run_view. */
+int lcsgpu_mst_prim(lcsgpu_ctx* ctx, int distance_kind, lcsgpu_mst_edge* out_edges);
+
 /* Block until everything queued on the context's stream has finished. */
 int lcsgpu_sync(lcsgpu_ctx* ctx);
 

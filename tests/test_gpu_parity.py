@@ -167,6 +167,46 @@ def test_every_halfword_count(engine, oracle):
     assert len(bad) == 0, bad[:10].tolist()
 
 
+def _prim_reference(oracle, codes, offsets, kind_fn):
+    """MSTPrim::run_view's recurrence (reference tree/MSTPrim.cpp:356-533) in plain Python over oracle LCS."""
+    n = len(offsets) - 1
+    lens = np.diff(offsets.astype(np.int64))
+    sq = oracle.rect(codes, offsets, np.arange(n), np.arange(n))  # sq[ref, partner]
+    key = [(np.finfo(np.float64).max, 0)] * n
+    alive = set(range(1, n))
+    cur, edges = 0, []
+    M = (1 << 64) - 1
+    while alive:
+        for v in alive:
+            d = kind_fn(int(sq[cur, v]), int(lens[cur]), int(lens[v]))
+            if d <= key[v][0]:
+                a, b = min(cur, v), max(cur, v)
+                s = (d, M ^ ((a << 32) + b))
+                if s < key[v]:
+                    key[v] = s
+        best = min(alive, key=lambda v: key[v])
+        packed = M ^ key[best][1]
+        edges.append((packed >> 32, packed & 0xffffffff, key[best][0]))
+        alive.remove(best)
+        cur = best
+    return edges
+
+
+def test_device_prim_edges_vs_reference_recurrence(engine, oracle):
+    ids, enc = load_set(os.path.join(G, "adversarial_tree.fasta"))  # includes orientation-sensitive refs
+    enc = [enc[i] for i in seqio.sort_order(enc)]
+    rng = np.random.Generator(np.random.PCG64(3))
+    enc += [rng.integers(0, 20, size=int(l)).astype(np.uint8) for l in rng.integers(40, 300, size=500)]
+    engine.upload_seqs(enc)
+    assert engine.orientation_flags().sum() >= 2
+    codes, offsets = seqio.pack(enc)
+    for kind, fn in [(1, oracle.lib.oracle_dist_indel075_f64), (0, oracle.lib.oracle_dist_indel_f64)]:
+        got = engine.mst_prim(kind)
+        want = _prim_reference(oracle, codes, offsets, fn)
+        assert [(int(e["from"]), int(e["to"])) for e in got] == [(a, b) for a, b, _ in want]
+        assert [float(e["dist"]) for e in got] == [d for _, _, d in want]
+
+
 def test_errors_are_reported(engine):
     import famsa_amd
     engine.upload_seqs([np.zeros(10, np.uint8)] * 3)
