@@ -30,6 +30,11 @@ struct RowsArgs {
     int32_t elem_size;  // 2 or 4
     int32_t mode;
     int32_t refs_per_block;
+    // TRIANGLE with contiguous refs: compact 1-D grid over the workgroups that have work, rows in
+    // DESCENDING order (fullest first): tri_prefix[k] = first block of the k-th row from the bottom,
+    // tri_prefix[tri_rows] = grid size.  NULL = plain 2-D grid (x = column block, y = ref tile).
+    const int32_t* tri_prefix;
+    int32_t tri_rows;
 };
 
 // instantiated half-word (32-bit) counts: exact 1..32, even 34..64; 0 = the long-sequence path

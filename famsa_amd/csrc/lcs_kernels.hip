@@ -177,6 +177,27 @@ __device__ __forceinline__ void store_result(const RowsArgs& a, int k, int c, ui
         ((uint32_t*)a.out)[idx] = res;
 }
 
+// Workgroup -> (column block x, ref tile y).  In the compact triangle grid the rows are walked
+// from the bottom (most column blocks) to the top, so the chip fills at once and the workgroups
+// above the diagonal -- half of a 2-D grid, and nearly all of its first rows -- are never launched
+// (measured at n = 10 000: the dispatcher spent ~3 ms of an 18 ms launch retiring them).
+__device__ __forceinline__ void block_coords(const RowsArgs& a, int& x, int& y)
+{
+    if (!a.tri_prefix) {
+        x = blockIdx.x;
+        y = blockIdx.y;
+        return;
+    }
+    const int bid = blockIdx.x;
+    int lo = 0, hi = a.tri_rows - 1; // largest k with tri_prefix[k] <= bid
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (a.tri_prefix[mid] <= bid) lo = mid; else hi = mid - 1;
+    }
+    y = a.tri_rows - 1 - lo;
+    x = bid - a.tri_prefix[lo];
+}
+
 // Triangle mode: a block whose columns all lie at or beyond its largest ref id has no work.
 __device__ __forceinline__ bool block_is_above_diagonal(const RowsArgs& a, int ref0, int nr, int c0)
 {
@@ -197,9 +218,11 @@ __global__ __launch_bounds__(256) void lcs_rows_kernel(RowsArgs a)
     constexpr int W = (H + 1) / 2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int R = a.refs_per_block;
-    const int ref0 = blockIdx.y * R;
+    int bx, by;
+    block_coords(a, bx, by);
+    const int ref0 = by * R;
     const int nr = min(R, a.n_refs - ref0);
-    const int c0 = blockIdx.x * 256;
+    const int c0 = bx * 256;
     if (block_is_above_diagonal(a, ref0, nr, c0))
         return;
 
@@ -272,6 +295,9 @@ __global__ __launch_bounds__(256) void lcs_rows_kernel(RowsArgs a)
 // runs  tB.lo, add.lo, X.lo, tB.hi, addc.hi, X.hi  so two instructions always sit between a
 // carry producer and its consumer (the gfx950 VALU-writes-VCC -> VALU-reads-VCC distance).
 #define LCS_PIN() __builtin_amdgcn_sched_barrier(0)
+#ifndef LCS_LOOKAHEAD
+#define LCS_LOOKAHEAD 4 // measured at n=40000: 4 / 8 / 16 -> 553.8 / 550.1 / 550.2 Tcell/s
+#endif
 
 template <int H, int RG, int LOOKAHEAD>
 struct Pipe {
@@ -353,9 +379,11 @@ __global__ __launch_bounds__(256) void lcs_rows_kernel_pipe(RowsArgs a)
     using P = Pipe<H, RG, LOOKAHEAD>;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int R = a.refs_per_block;
-    const int ref0 = blockIdx.y * R;
+    int bx, by;
+    block_coords(a, bx, by);
+    const int ref0 = by * R;
     const int nr = min(R, a.n_refs - ref0);
-    const int c0 = blockIdx.x * 256;
+    const int c0 = bx * 256;
     if (block_is_above_diagonal(a, ref0, nr, c0))
         return;
     {
@@ -456,9 +484,11 @@ __global__ __launch_bounds__(256) void lcs_long_kernel(RowsArgs a, uint16_t* car
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[]; // SEGW x 256 bytes
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int R = a.refs_per_block;
-    const int ref0 = blockIdx.y * R;
+    int bx, by;
+    block_coords(a, bx, by);
+    const int ref0 = by * R;
     const int nr = min(R, a.n_refs - ref0);
-    const int c0 = blockIdx.x * 256;
+    const int c0 = bx * 256;
     if (block_is_above_diagonal(a, ref0, nr, c0))
         return;
 
@@ -611,7 +641,7 @@ static hipError_t launch_one(const RowsArgs& a, dim3 grid, hipStream_t stream)
     if constexpr (QUIRK)
         hipLaunchKernelGGL((lcs_rows_kernel<H, RG, true>), grid, dim3(256), lds, stream, a);
     else
-        hipLaunchKernelGGL((lcs_rows_kernel_pipe<H, RG, 8>), grid, dim3(256), lds, stream, a);
+        hipLaunchKernelGGL((lcs_rows_kernel_pipe<H, RG, LCS_LOOKAHEAD>), grid, dim3(256), lds, stream, a);
     return hipGetLastError();
 }
 

@@ -196,10 +196,32 @@ int run_rows(lcsgpu_ctx* ctx, int mode, const int32_t* ref_ids, int32_t ref_begi
     auto align8 = [](size_t x) { return (x + 7) & ~(size_t)7; };
     const size_t col_off = 0;
     if (col_ids) bytes += align8((size_t)n_cols * 4);
-    std::vector<size_t> row_off(buckets.size(), 0), id_off(buckets.size(), 0);
+    std::vector<size_t> row_off(buckets.size(), 0), id_off(buckets.size(), 0), pre_off(buckets.size(), 0);
     std::vector<char> is_contig(buckets.size(), 0);
+    std::vector<std::vector<int32_t>> tri_prefix(buckets.size());
     for (size_t b = 0; b < buckets.size(); ++b) {
         is_contig[b] = contiguous(buckets[b]);
+        if (is_contig[b] && mode == lcsgpu::MODE_TRIANGLE && buckets[b].bv != 0) {
+            // compact grid: only the workgroups at or below the diagonal, bottom row first
+            const Bucket& bk = buckets[b];
+            const int R = lcsgpu::refs_per_block(bk.bv, bk.quirk);
+            const int nrefs = (int)bk.items.size();
+            const int gy = (nrefs + R - 1) / R;
+            std::vector<int32_t>& pre = tri_prefix[b];
+            pre.resize((size_t)gy + 1);
+            int64_t acc = 0;
+            for (int k = 0; k < gy; ++k) {
+                const int y = gy - 1 - k;
+                const int64_t max_rid = (int64_t)bk.items[0].id + std::min(nrefs, (y + 1) * R) - 1;
+                const int64_t cols = std::min<int64_t>(n_cols, max_rid);
+                pre[k] = (int32_t)acc;
+                acc += cols > 0 ? (cols + 255) / 256 : 0;
+            }
+            if (acc > 0x7fffffff) return fail(LCSGPU_E_INVALID, "triangle grid too large (%lld workgroups)", (long long)acc);
+            pre[gy] = (int32_t)acc;
+            pre_off[b] = bytes;
+            bytes += align8(pre.size() * 4);
+        }
         if (is_contig[b]) continue;
         row_off[b] = bytes;
         bytes += align8(buckets[b].items.size() * 8);
@@ -217,6 +239,7 @@ int run_rows(lcsgpu_ctx* ctx, int mode, const int32_t* ref_ids, int32_t ref_begi
         char* h = (char*)ctx->h_plan.p;
         if (col_ids) memcpy(h + col_off, col_ids, (size_t)n_cols * 4);
         for (size_t b = 0; b < buckets.size(); ++b) {
+            if (!tri_prefix[b].empty()) memcpy(h + pre_off[b], tri_prefix[b].data(), tri_prefix[b].size() * 4);
             if (is_contig[b]) continue;
             int64_t* hr = (int64_t*)(h + row_off[b]);
             int32_t* hi = (int32_t*)(h + id_off[b]);
@@ -264,7 +287,15 @@ int run_rows(lcsgpu_ctx* ctx, int mode, const int32_t* ref_ids, int32_t ref_begi
         }
         const int gx = (use_cols + 255) / 256;
         const int gy = (a.n_refs + a.refs_per_block - 1) / a.refs_per_block;
-        if (bk.bv != 0) {
+        if (bk.bv != 0 && !tri_prefix[b].empty()) {
+            a.tri_prefix = (const int32_t*)((char*)ctx->d_plan.p + pre_off[b]);
+            a.tri_rows = (int32_t)tri_prefix[b].size() - 1;
+            const int total = tri_prefix[b].back();
+            if (total > 0) {
+                HIP_TRY(lcsgpu::launch_rows(bk.bv, bk.quirk, a, total, 1, ctx->stream));
+                ++ctx->last_launches;
+            }
+        } else if (bk.bv != 0) {
             if (gy > 65535) return fail(LCSGPU_E_INVALID, "too many ref tiles in one call (%d)", gy);
             HIP_TRY(lcsgpu::launch_rows(bk.bv, bk.quirk, a, gx, gy, ctx->stream));
             ++ctx->last_launches;
