@@ -77,6 +77,8 @@ def main():
     ap.add_argument("--n", type=int, default=100000)
     ap.add_argument("--len", type=int, default=400)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--emulate-ranks-on-one-gpu", action="store_true",
+                    help="functional test of the N>1 path on a 1-GPU box: all ranks use cuda:0, gloo exchange")
     args = ap.parse_args()
 
     import torch
@@ -91,10 +93,16 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     dist = None
+    emulate = args.emulate_ranks_on_one_gpu
+    if emulate:
+        local_rank = 0
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if emulate:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -120,9 +128,14 @@ def main():
             ext.wait_stream(torch.cuda.current_stream())
         eng.lcs_triangle_dev(r0, r1, tri.data_ptr(), 2)
         eng.row_minima_dev(tri.data_ptr(), 2, r0, r1, 1, mins.data_ptr())
-        if world > 1:
+        if world > 1 and not emulate:
             torch.cuda.current_stream().wait_stream(ext)
-            dist.all_gather_into_tensor(gathered, mins)
+            dist.all_gather_into_tensor(gathered, mins)  # RCCL over xGMI: n x 16 B
+        elif world > 1:
+            eng.sync()
+            g = torch.empty(gathered.shape, dtype=gathered.dtype)
+            dist.all_gather_into_tensor(g, mins.cpu())
+            gathered.copy_(g)
         ms, _ = eng.last_kernel_ms()  # HIP events on the engine's stream, around the LCS launch
         kernel_ms.append(ms)
 
@@ -143,12 +156,21 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if emulate else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # size-independent sanity property kept outside the timed region: every LCS <= min(len)
-    assert int(tri[: max(my_pairs, 1)].to(torch.int32).max().item()) <= L
+    # size-independent sanity properties, outside the timed region: every LCS <= min(len); with
+    # N > 1 every rank must hold all n per-row minima after the exchange, rows >= 1 having a
+    # neighbour among the columns below them
+    if my_pairs:
+        assert int(tri[:my_pairs].to(torch.int32).max().item()) <= L
+    if world > 1:
+        from famsa_amd.rowblock import assemble_row_minima
+        d_all, j_all = assemble_row_minima(gathered, cuts)
+        assert d_all.numel() == n
+        rows = torch.arange(n, device=j_all.device)
+        assert bool(((j_all[1:] >= 0) & (j_all[1:] < rows[1:])).all()) and int(j_all[0].item()) == -1
 
     if rank == 0:
         cells = float(total_pairs) * L * L
