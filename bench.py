@@ -9,7 +9,7 @@ row blocks of equal pair count -- no data-path collective for the LCS itself -- 
 ends with the all-gather of the per-row minima (n x 16 bytes).  The total work is fixed, so the
 scaling is "strong".
 
-    python bench.py [--gpus N --steps K --warmup W] [--n 100000 --len 400]
+    python bench.py [--gpus N --steps K --warmup W] [--n-seqs 100000 --seq-len 400]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Rank 0 prints ONE JSON line.  `cpu_baseline` times the REFERENCE's own AVX2 path
@@ -74,8 +74,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=100000)
-    ap.add_argument("--len", type=int, default=400)
+    ap.add_argument("--n-seqs", dest="n", type=int, default=100000)
+    ap.add_argument("--seq-len", dest="len", type=int, default=400)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--emulate-ranks-on-one-gpu", action="store_true",
                     help="functional test of the N>1 path on a 1-GPU box: all ranks use cuda:0, gloo exchange")
