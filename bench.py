@@ -215,7 +215,7 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
-                "kernel": f"lcsgpu::lcs_rows_kernel_pipe<{(L + 31) // 32}, 4, 8>",
+                "kernel": f"lcsgpu::lcs_rows_kernel_pipe<{(L + 31) // 32}, 4, 4>",
                 "kernel_ms": k_ms,
                 "algorithmic_bytes_per_pair": L + ALGO_BYTES_PER_PAIR_EXTRA,
                 "note": "achieved/peak/traffic in GB/s resp. GB per launch; the kernel is integer-VALU bound by "
