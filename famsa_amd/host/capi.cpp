@@ -18,6 +18,23 @@ using namespace famsa_host;
 
 namespace {
 thread_local std::string g_error;
+
+// heuristic: 0 none, 1 parttree, 2 medoidtree; the int/float params override CParams::medoid when > 0
+TreeOptions make_options(const char* method, int distance, int keep_duplicates, int heuristic, int subtree_size,
+                         int sample_size, int threshold, float cluster_fraction, int cluster_iters)
+{
+    TreeOptions o;
+    o.method = gt_from_string(method);
+    o.dist = (Distance)distance;
+    o.keep_duplicates = keep_duplicates != 0;
+    o.heuristic = heuristic;
+    if (subtree_size > 0) o.fast.subtree_size = subtree_size;
+    if (sample_size > 0) o.fast.sample_size = sample_size;
+    if (threshold > 0) o.fast.threshold = threshold;
+    if (cluster_fraction > 0) o.fast.cluster_fraction = cluster_fraction;
+    if (cluster_iters > 0) o.fast.cluster_iters = cluster_iters;
+    return o;
+}
 int fail(const std::exception& e)
 {
     g_error = e.what();
@@ -55,12 +72,14 @@ int famsa_host_workset(const char* fasta, int keep_duplicates, int* sorted2input
 // Newick text of `-gt <method> -gt_export` for `fasta`, LCS values taken from `square`
 // (input order, square[ref*n + partner], n = number of FASTA records).
 long famsa_host_tree_from_matrix(const char* fasta, const uint32_t* square, const char* method, int distance,
-                                 int keep_duplicates, char* out, long cap)
+                                 int keep_duplicates, int heuristic, int subtree_size, int sample_size,
+                                 int threshold, float cluster_fraction, int cluster_iters, char* out, long cap)
 {
     try {
         SeqSet s = load_fasta(fasta);
-        return give(guide_tree_newick_from_matrix(s, square, gt_from_string(method), (Distance)distance,
-                                                   keep_duplicates != 0),
+        return give(guide_tree_newick_from_matrix(s, square,
+                                                   make_options(method, distance, keep_duplicates, heuristic, subtree_size,
+                                                                sample_size, threshold, cluster_fraction, cluster_iters)),
                     out, cap);
     } catch (const std::exception& e) {
         return fail(e);
@@ -86,12 +105,15 @@ int famsa_host_dist_export_from_matrix(const char* fasta, const uint32_t* square
 
 // The same two operations with the LCS computed on GPU `device`.
 long famsa_host_tree_gpu(const char* fasta, int device, const char* method, int distance, int keep_duplicates,
-                         char* out, long cap)
+                         int heuristic, int subtree_size, int sample_size, int threshold, float cluster_fraction,
+                         int cluster_iters, char* out, long cap)
 {
     try {
         SeqSet s = load_fasta(fasta);
-        return give(guide_tree_newick_gpu(s, device, gt_from_string(method), (Distance)distance,
-                                           keep_duplicates != 0, nullptr),
+        return give(guide_tree_newick_gpu(s, device,
+                                           make_options(method, distance, keep_duplicates, heuristic, subtree_size,
+                                                        sample_size, threshold, cluster_fraction, cluster_iters),
+                                           nullptr),
                     out, cap);
     } catch (const std::exception& e) {
         return fail(e);

@@ -6,7 +6,8 @@
 //   -dist_export [-pid] [-square_matrix]     write the distance (or identity) matrix as CSV
 //   -dist <indel_div_lcs|indel075_div_lcs>   distance measure (default indel075_div_lcs)
 //   -keep-duplicates, -t <n>, -v / -vv, -gpu <id>
-// Everything downstream of the guide tree (profile alignment, refinement, -medoidtree, gz I/O)
+//   -medoidtree | -parttree [-medoid_threshold n -subtree_size n -sample_size n -cluster_fraction f -cluster_iters n]
+// Everything downstream of the guide tree (profile alignment, refinement, gz I/O)
 // is outside this engine's scope and is refused with an error, not silently ignored.
 #include <algorithm>
 #include <cstdio>
@@ -51,6 +52,8 @@ void usage()
                  "                        by the shorter sequence length) instead of distance\n"
                  "  -dist <measure>       indel_div_lcs | indel075_div_lcs (default)\n"
                  "  -keep-duplicates      keep duplicated sequences during tree construction\n"
+                 "  -medoidtree | -parttree   MedoidTree / PartTree heuristic (with -medoid_threshold, -subtree_size,\n"
+                 "                        -sample_size, -cluster_fraction, -cluster_iters as in FAMSA)\n"
                  "  -gpu <id>             HIP device (default 0)\n"
                  "  -t <n>, -v, -vv       accepted for compatibility / verbosity\n";
 }
@@ -66,18 +69,25 @@ int main(int argc, char** argv)
             return 0;
         }
         std::string aux;
-        GT method = GT::MST_Prim;
-        Distance dist = Distance::indel075_div_lcs;
+        TreeOptions opt;
         int device = 0;
         if (find_option(params, "-gt", aux)) {
             if (aux == "import") throw std::runtime_error("-gt import needs the alignment stage, which is outside this tool");
-            method = gt_from_string(aux);
+            opt.method = gt_from_string(aux);
         }
         if (find_option(params, "-dist", aux)) {
-            if (aux == "indel_div_lcs") dist = Distance::indel_div_lcs;
-            else if (aux == "indel075_div_lcs") dist = Distance::indel075_div_lcs;
+            if (aux == "indel_div_lcs") opt.dist = Distance::indel_div_lcs;
+            else if (aux == "indel075_div_lcs") opt.dist = Distance::indel075_div_lcs;
             else throw std::runtime_error("Error: Illegal pairwise distance measure.");
         }
+        // MedoidTree / PartTree heuristic and its parameters (reference core/params.cpp:195-208)
+        if (find_switch(params, "-parttree")) opt.heuristic = 1;
+        if (find_switch(params, "-medoidtree")) opt.heuristic = 2;
+        if (find_option(params, "-medoid_threshold", aux)) opt.fast.threshold = std::stoi(aux);
+        if (find_option(params, "-subtree_size", aux)) opt.fast.subtree_size = std::stoi(aux);
+        if (find_option(params, "-sample_size", aux)) opt.fast.sample_size = std::stoi(aux);
+        if (find_option(params, "-cluster_fraction", aux)) opt.fast.cluster_fraction = std::stof(aux);
+        if (find_option(params, "-cluster_iters", aux)) opt.fast.cluster_iters = std::stoi(aux);
         if (find_option(params, "-gpu", aux)) device = std::stoi(aux);
         find_option(params, "-t", aux);
         const bool very_verbose = find_switch(params, "-vv");
@@ -86,8 +96,8 @@ int main(int argc, char** argv)
         const bool export_dist = find_switch(params, "-dist_export");
         const bool square = find_switch(params, "-square_matrix");
         const bool pid = find_switch(params, "-pid");
-        const bool keep_dups = find_switch(params, "-keep-duplicates");
-        for (const char* unsupported : {"-medoidtree", "-parttree", "-gz", "-refine_mode", "-trim_columns"})
+        opt.keep_duplicates = find_switch(params, "-keep-duplicates");
+        for (const char* unsupported : {"-gz", "-refine_mode", "-trim_columns", "-go", "-ge", "-r"})
             if (std::find(params.begin(), params.end(), unsupported) != params.end())
                 throw std::runtime_error(std::string(unsupported) + " is outside the scope of famsa-gpu (guide tree / distance stage only)");
         if (params.size() != 2) {
@@ -102,9 +112,9 @@ int main(int argc, char** argv)
         if (s.size() == 0) throw std::runtime_error("no sequences in " + input);
         Timings t;
         if (export_dist) {
-            dist_export_gpu(s, device, dist, square, pid, output, &t);
+            dist_export_gpu(s, device, opt.dist, square, pid, output, &t);
         } else {
-            const std::string nwk = guide_tree_newick_gpu(s, device, method, dist, keep_dups, &t);
+            const std::string nwk = guide_tree_newick_gpu(s, device, opt, &t);
             std::ofstream f(output, std::ios::binary);
             if (!f.good()) throw std::runtime_error("cannot open " + output);
             f << nwk;

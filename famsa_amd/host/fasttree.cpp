@@ -1,0 +1,392 @@
+// fasttree.cpp -- MedoidTree / PartTree guide-tree heuristic over GPU-computed LCS lengths.
+// Restates the control flow of the reference's FastTree (tree/FastTree.cpp:56-436) and its CLARANS
+// k-medoids (tree/Clustering.cpp:17-305) with the deterministic random helpers of
+// utils/deterministic_random.h, so that seeds, assignments and therefore the tree are identical.
+// All LCS values come from the LcsSource in three call shapes: one ref x all (row of the longest
+// sequence), the sample triangle, and seeds x all rectangles (FastTree.cpp:309-324, 347, 385, 415).
+#include <algorithm>
+#include <limits>
+#include <numeric>
+#include <random>
+#include <stdexcept>
+
+#include "trees.h"
+
+namespace famsa_host {
+namespace {
+
+inline size_t tri(size_t i, size_t j) { return i >= j ? j + i * (i - 1) / 2 : i + j * (j - 1) / 2; }
+
+// det_uniform_int_distribution<IntType>::operator() (reference utils/deterministic_random.h:62-76).
+// The parameters travel as pair<int,int>; the arithmetic is done in the unsigned twin of IntType.
+template <class UInt, class Gen>
+inline long long det_uniform(Gen& g, int lo, int hi)
+{
+    const UInt diff = (UInt)hi - (UInt)lo + 1;
+    if (diff == 0) return (long long)g();
+    const UInt bad = std::numeric_limits<UInt>::max() / diff;
+    for (;;) {
+        const UInt r = (UInt)g();
+        if (r / diff < bad) return (long long)((r % diff) + (UInt)lo);
+    }
+}
+
+// partial_shuffle (deterministic_random.h:113-127); the distribution there is over
+// iterator difference_type (64-bit)
+template <class Gen>
+void partial_shuffle(int* first, int* middle, int* last, Gen& g)
+{
+    const long n = middle - first, N = last - first - 1;
+    for (long i = 0; i < n; ++i) std::swap(first[i], first[det_uniform<unsigned long>(g, (int)i, (int)N)]);
+}
+
+// ---- CLARANS (FastPAM-style swaps), Clustering.cpp:17-305 ------------------------------------
+struct Clarans {
+    float explore_fraction;
+    int num_local;
+    static constexpr int min_max_neighbor = 250;
+
+    static void update_assignment(int x, const int* candidate, int n_medoids, const float* D, float& dist_nearest,
+                                  float& dist_second, int& assign_nearest, int& assign_second)
+    {
+        float dn = std::numeric_limits<float>::max(), ds = std::numeric_limits<float>::max();
+        int an = -1, as = -1;
+        for (int mm = 0; mm < n_medoids; ++mm) {
+            const float d = D[tri(candidate[mm], x)];
+            if (d < dn) { ds = dn; as = an; dn = d; an = mm; }
+            else if (d < ds) { ds = d; as = mm; }
+        }
+        dist_nearest = dn; dist_second = ds; assign_nearest = an; assign_second = as;
+    }
+
+    void operator()(const float* D, int n_elems, int n_medoids, int n_fixed, int* medoids) const
+    {
+        const int n_swaps = (n_elems - n_medoids) * n_medoids;
+        const int max_neighbor = n_swaps < min_max_neighbor
+                                     ? n_swaps
+                                     : std::max((int)(explore_fraction * n_swaps), (int)min_max_neighbor);
+        const int corrected = max_neighbor / n_medoids;
+
+        std::vector<int> candidate(n_elems), current(n_elems);
+        std::iota(candidate.begin(), candidate.end(), 0);
+        float best_cost = std::numeric_limits<float>::max();
+        std::vector<float> dists_nearest(n_elems), dists_second(n_elems), deltas(n_elems);
+        std::vector<int> assign_nearest(n_elems), assign_second(n_elems);
+        std::mt19937 gen_nodes, gen_positions;
+
+        for (int iter = 0; iter < num_local; ++iter) {
+            partial_shuffle(candidate.data() + n_fixed, candidate.data() + n_elems, candidate.data() + n_elems, gen_nodes);
+            current = candidate;
+            for (int mm = 0; mm < n_medoids; ++mm) {
+                const int m = candidate[mm];
+                dists_nearest[m] = 0; dists_second[m] = -1; assign_nearest[m] = -1; assign_second[m] = -1;
+            }
+            float cost = 0;
+            for (int xx = n_medoids; xx < n_elems; ++xx) {
+                const int x = candidate[xx];
+                update_assignment(x, candidate.data(), n_medoids, D, dists_nearest[x], dists_second[x],
+                                  assign_nearest[x], assign_second[x]);
+                cost += dists_nearest[x];
+            }
+            for (int step = 0; step < corrected; ++step) {
+                const int xx = (int)det_uniform<unsigned int>(gen_positions, n_medoids, n_elems - 1);
+                const int x = candidate[xx];
+                std::fill_n(deltas.begin(), n_medoids, 0.0f);
+                for (int yy = n_medoids; yy < n_elems; ++yy) {
+                    if (yy == xx) continue;
+                    const int y = candidate[yy];
+                    const float dxy = D[tri(x, y)];
+                    const int nn = assign_nearest[y];
+                    const float dn = dists_nearest[y], ds = dists_second[y];
+                    deltas[nn] += std::min(dxy, ds) - dn;
+                    const float change = dxy - dn;
+                    if (change < 0) {
+                        for (int kk = 0; kk < nn; ++kk) deltas[kk] += change;
+                        for (int kk = nn + 1; kk < n_medoids; ++kk) deltas[kk] += change;
+                    }
+                }
+                const int mm_new = (int)(std::min_element(deltas.begin() + n_fixed, deltas.begin() + n_medoids) - deltas.begin());
+                const float delta = deltas[mm_new];
+                if (delta < 0) {
+                    std::swap(candidate[mm_new], candidate[xx]);
+                    const int m_new = candidate[mm_new];
+                    cost -= dists_nearest[m_new];
+                    dists_nearest[m_new] = 0; dists_second[m_new] = -1; assign_nearest[m_new] = -1; assign_second[m_new] = -1;
+                    for (int yy = n_medoids; yy < n_elems; ++yy) {
+                        const int y = candidate[yy];
+                        const float d_new = D[tri(m_new, y)];
+                        const float dn = dists_nearest[y];
+                        const int an = assign_nearest[y];
+                        if (yy == xx) {
+                            update_assignment(y, candidate.data(), n_medoids, D, dists_nearest[y], dists_second[y],
+                                              assign_nearest[y], assign_second[y]);
+                            cost += dists_nearest[y];
+                            continue;
+                        }
+                        if (an == mm_new) {
+                            const float ds = dists_second[y];
+                            if (d_new < ds) {
+                                dists_nearest[y] = d_new;
+                                assign_nearest[y] = mm_new;
+                                cost += d_new - dn;
+                            } else {
+                                update_assignment(y, candidate.data(), n_medoids, D, dists_nearest[y], dists_second[y],
+                                                  assign_nearest[y], assign_second[y]);
+                                cost += ds - dn;
+                            }
+                        } else if (d_new < dn) {
+                            dists_second[y] = dn; assign_second[y] = an;
+                            dists_nearest[y] = d_new; assign_nearest[y] = mm_new;
+                            cost += d_new - dn;
+                        } else {
+                            const float ds = dists_second[y];
+                            const float as = (float)assign_second[y];
+                            if (as != (float)mm_new && d_new < ds) {
+                                dists_second[y] = d_new;
+                                assign_second[y] = mm_new;
+                            } else {
+                                update_assignment(y, candidate.data(), n_medoids, D, dists_nearest[y], dists_second[y],
+                                                  assign_nearest[y], assign_second[y]);
+                            }
+                        }
+                    }
+                    std::swap(current[mm_new], current[xx]);
+                    step = 0; // the for-increment makes the next step 1, as in the reference
+                }
+            }
+            if (cost < best_cost) {
+                best_cost = cost;
+                std::copy_n(current.begin(), n_medoids, medoids);
+            }
+        }
+    }
+};
+
+// ---- a view of a subset of the parent source, local ids 0..m-1 --------------------------------
+class SubsetSource : public LcsSource {
+public:
+    SubsetSource(LcsSource& parent, const std::vector<int>& ids) : p_(parent), ids_(ids) {}
+    int n() const override { return (int)ids_.size(); }
+    uint32_t length(int i) const override { return p_.length(ids_[i]); }
+    bool orientation_sensitive() const override { return p_.orientation_sensitive(); }
+    void triangle(int r0, int r1, LcsBuf& out) override
+    {
+        const size_t off = (size_t)r0 * (r0 > 0 ? r0 - 1 : 0) / 2;
+        out.resize((size_t)r1 * (r1 - 1) / 2 - off, p_.wide());
+        if (r1 <= 1 || r1 <= r0) return;
+        LcsBuf rect;
+        const int cols = r1 - 1;
+        p_.rect(ids_.data() + r0, r1 - r0, ids_.data(), cols, rect); // ref = row, partner = column
+        for (int i = std::max(r0, 1); i < r1; ++i)
+            for (int j = 0; j < i; ++j) {
+                const uint32_t v = rect[(size_t)(i - r0) * cols + j];
+                const size_t k = (size_t)i * (i - 1) / 2 + j - off;
+                if (out.wide) out.v32[k] = v; else out.v16[k] = (uint16_t)v;
+            }
+    }
+    void rect(const int* refs, int n_refs, const int* cols, int n_cols, LcsBuf& out) override
+    {
+        std::vector<int> r(n_refs), c(n_cols);
+        for (int i = 0; i < n_refs; ++i) r[i] = ids_[refs[i]];
+        for (int i = 0; i < n_cols; ++i) c[i] = ids_[cols ? cols[i] : i];
+        p_.rect(r.data(), n_refs, c.data(), n_cols, out);
+    }
+
+private:
+    LcsSource& p_;
+    const std::vector<int>& ids_;
+};
+
+template <Distance D>
+struct FastTree {
+    LcsSource& src;
+    GT partial;
+    FastTreeParams prm;
+    Transform<float, D> transform; // FastTree uses float distances throughout
+
+    // distances of subset member `ref_local` to every member: calculateDistanceVector(ref, all)
+    void row_distances(const std::vector<int>& ids, int ref_local, float* out)
+    {
+        LcsBuf buf;
+        const int ref = ids[ref_local];
+        src.rect(&ref, 1, ids.data(), (int)ids.size(), buf);
+        const uint32_t len_ref = src.length(ref);
+        for (size_t j = 0; j < ids.size(); ++j) out[j] = transform(buf[j], len_ref, src.length(ids[j]));
+    }
+
+    int random_seeds(const std::vector<int>& ids, int n_seeds, std::vector<int>& seed_ids, float* dist_row)
+    { // FastTree::randomSeeds, FastTree.cpp:335-362
+        const int n = (int)ids.size();
+        row_distances(ids, 0, dist_row);
+        std::mt19937 mt;
+        std::vector<int> rnd(n);
+        std::iota(rnd.begin(), rnd.end(), 0);
+        const size_t furthest = std::max_element(dist_row + 1, dist_row + n) - dist_row;
+        std::swap(rnd[1], rnd[furthest]);
+        partial_shuffle(rnd.data() + 2, rnd.data() + n_seeds, rnd.data() + n, mt);
+        seed_ids.assign(rnd.begin(), rnd.begin() + n_seeds);
+        std::sort(seed_ids.begin(), seed_ids.end());
+        return n_seeds;
+    }
+
+    int cluster_seeds(const std::vector<int>& ids, int n_seeds, int n_samples, std::vector<int>& seed_ids,
+                      float* dist_row, uint32_t seed)
+    { // FastTree::clusterSeeds, FastTree.cpp:366-436
+        const int n = (int)ids.size();
+        row_distances(ids, 0, dist_row);
+        std::vector<int> sample_ids;
+        std::vector<int> sample_global;
+        if (n_samples >= n) {
+            n_samples = n;
+            sample_global = ids;
+        } else {
+            std::mt19937 mt(seed);
+            std::vector<int> rnd(n);
+            std::iota(rnd.begin(), rnd.end(), 0);
+            partial_shuffle(rnd.data() + 1, rnd.data() + n_samples, rnd.data() + n, mt);
+            sample_ids.assign(rnd.begin(), rnd.begin() + n_samples);
+            std::sort(sample_ids.begin(), sample_ids.end());
+            sample_global.resize(n_samples);
+            for (int j = 0; j < n_samples; ++j) sample_global[j] = ids[sample_ids[j]];
+        }
+        // sample distance matrix: calculateDistanceMatrix over the samples (float)
+        std::vector<float> dist((size_t)n_samples * (n_samples - 1) / 2);
+        {
+            SubsetSource sub(src, sample_global);
+            LcsBuf buf;
+            sub.triangle(0, n_samples, buf);
+            for (int i = 1; i < n_samples; ++i)
+                for (int j = 0; j < i; ++j)
+                    dist[tri(i, j)] = transform(buf[tri(i, j)], sub.length(i), sub.length(j));
+        }
+        seed_ids.assign(n_seeds, 0);
+        Clarans{prm.cluster_fraction, prm.cluster_iters}(dist.data(), n_samples, n_seeds, 1, seed_ids.data());
+        if (!sample_ids.empty())
+            for (int k = 0; k < n_seeds; ++k) seed_ids[k] = sample_ids[seed_ids[k]];
+        return n_seeds;
+    }
+
+    float make_evaluation(const std::vector<int>& ids, int eval_num, int& n_seeds, std::vector<int>& seed_ids,
+                          std::vector<int>& assignments)
+    { // FastTree::makeEvaluation, FastTree.cpp:271-331
+        const int n = (int)ids.size();
+        std::vector<float> dist_row(n);
+        const uint32_t seed = eval_num == 0 ? std::mt19937::default_seed : (uint32_t)std::hash<uint32_t>()((uint32_t)eval_num);
+        if (!prm.use_clustering) n_seeds = random_seeds(ids, prm.subtree_size, seed_ids, dist_row.data());
+        else n_seeds = cluster_seeds(ids, prm.subtree_size, prm.sample_size, seed_ids, dist_row.data(), seed);
+
+        assignments.assign(n, 0);
+        // seeds 1.. x all, in column chunks to bound host memory; per column the seeds are visited
+        // in increasing k, exactly as the reference's row-by-row sweep
+        std::vector<int> refs(n_seeds - 1);
+        for (int k = 1; k < n_seeds; ++k) refs[k - 1] = ids[seed_ids[k]];
+        const int chunk = 1 << 18;
+        LcsBuf buf;
+        for (int c0 = 0; c0 < n && n_seeds > 1; c0 += chunk) {
+            const int c1 = std::min(n, c0 + chunk);
+            src.rect(refs.data(), n_seeds - 1, ids.data() + c0, c1 - c0, buf);
+            for (int k = 1; k < n_seeds; ++k) {
+                const uint32_t len_k = src.length(refs[k - 1]);
+                for (int j = c0; j < c1; ++j) {
+                    const float d = transform(buf[(size_t)(k - 1) * (c1 - c0) + (j - c0)], len_k, src.length(ids[j]));
+                    if (d < dist_row[j]) {
+                        dist_row[j] = d;
+                        assignments[j] = k;
+                    }
+                }
+            }
+        }
+        return std::accumulate(dist_row.begin(), dist_row.end(), 0.0f);
+    }
+
+    // FastTree::doStep, FastTree.cpp:56-266.  `ids` = global ids (sequence_no) of this subset.
+    void do_step(const std::vector<int>& ids, tree_structure& tree, int previous_top)
+    {
+        const int n = (int)ids.size();
+        const bool split = prm.use_clustering ? n > prm.threshold : n > prm.subtree_size;
+        if (!split) {
+            SubsetSource sub(src, ids);
+            build_tree_partial(sub, partial, D, tree);
+            if (previous_top > n) {
+                for (int node = 0; node < n - 1; ++node) {
+                    node_t& nd = tree[node];
+                    nd.first = nd.first < n ? ids[nd.first] : nd.first + previous_top - n;
+                    nd.second = nd.second < n ? ids[nd.second] : nd.second + previous_top - n;
+                }
+            }
+            return;
+        }
+        float best_cost = std::numeric_limits<float>::max();
+        int n_seeds = -1;
+        std::vector<int> seed_ids, assignments;
+        for (int eval = 0; eval < prm.num_evaluations; ++eval) {
+            int ns;
+            std::vector<int> s, a;
+            const float cost = make_evaluation(ids, eval, ns, s, a);
+            if (cost < best_cost) {
+                best_cost = cost;
+                n_seeds = ns;
+                seed_ids.swap(s);
+                assignments.swap(a);
+            }
+        }
+        if (n_seeds < 0) throw std::runtime_error("FastTree: no evaluation produced a finite cost");
+        std::vector<int> seeds(n_seeds);
+        for (int k = 0; k < n_seeds; ++k) {
+            seeds[k] = ids[seed_ids[k]];
+            assignments[seed_ids[k]] = k; // seeds belong to themselves
+        }
+        std::vector<std::vector<int>> subgroups(n_seeds);
+        for (int j = 0; j < n; ++j) subgroups[assignments[j]].push_back(ids[j]);
+
+        std::vector<int> subroots(n_seeds, -1);
+        for (int k = 0; k < n_seeds; ++k) {
+            if (subgroups[k].size() > 1) {
+                tree_structure local;
+                do_step(subgroups[k], local, previous_top);
+                tree.insert(tree.end(), local.begin(), local.end());
+                previous_top += (int)subgroups[k].size() - 1;
+                subroots[k] = previous_top - 1;
+            }
+        }
+        tree_structure local;
+        {
+            SubsetSource sub(src, seeds);
+            build_tree_partial(sub, partial, D, local);
+        }
+        for (int node = 0; node < n_seeds - 1; ++node) {
+            node_t& nd = local[node];
+            nd.first = nd.first < n_seeds ? (subgroups[nd.first].size() > 1 ? subroots[nd.first] : seeds[nd.first])
+                                          : nd.first + previous_top - n_seeds;
+            nd.second = nd.second < n_seeds ? (subgroups[nd.second].size() > 1 ? subroots[nd.second] : seeds[nd.second])
+                                            : nd.second + previous_top - n_seeds;
+        }
+        tree.insert(tree.end(), local.begin(), local.end());
+    }
+};
+
+template <Distance D>
+void run_fast(LcsSource& src, GT partial, const FastTreeParams& p, tree_structure& tree)
+{
+    const int n = src.n();
+    tree.assign(n, node_t(-1, -1));
+    if (n < 2) return;
+    FastTree<D> ft{src, partial, p, {}};
+    std::vector<int> ids(n);
+    std::iota(ids.begin(), ids.end(), 0);
+    tree_structure local;
+    ft.do_step(ids, local, (int)tree.size());
+    tree.insert(tree.end(), local.begin(), local.end());
+}
+
+} // namespace
+
+void build_tree_fast(LcsSource& src, GT partial, Distance dist, const FastTreeParams& p, tree_structure& tree)
+{
+    if (partial == GT::MST_Prim) partial = GT::SLINK; // reference msa.cpp:134: MST+Prim is not a partial generator
+    if (dist == Distance::indel_div_lcs) run_fast<Distance::indel_div_lcs>(src, partial, p, tree);
+    else if (dist == Distance::indel075_div_lcs) run_fast<Distance::indel075_div_lcs>(src, partial, p, tree);
+    else throw std::runtime_error("Error: Illegal pairwise distance measure.");
+}
+
+} // namespace famsa_host

@@ -10,23 +10,32 @@ static double now_s()
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
-std::string guide_tree_newick(const SeqSet& s, const WorkSet& w, LcsSource& src, GT method, Distance dist)
+std::string guide_tree_newick(const SeqSet& s, const WorkSet& w, LcsSource& src, const TreeOptions& opt)
 {
     // names of the leaves = ids in sorted order (the reference reorders its sequence vector)
     std::vector<std::string> names(w.n_sorted());
     for (int k = 0; k < w.n_sorted(); ++k) names[k] = s.ids[w.sorted2input[k]];
     if (w.n_unique() == 1) return std::string(); // the reference skips the tree stage entirely (msa.cpp:549-556)
     tree_structure tree;
-    build_tree(src, method, dist, tree, 1);
+    // CFAMSA::adjustParams (msa.cpp:83-88): the heuristic is dropped for inputs below the threshold
+    // (counted on ALL input records); createTreeGenerator (msa.cpp:134-239) wraps the partial generator
+    int heuristic = opt.heuristic;
+    if (heuristic != 0 && (int)s.size() < opt.fast.threshold) heuristic = 0;
+    if (heuristic != 0) {
+        FastTreeParams fp = opt.fast;
+        fp.use_clustering = heuristic == 2;
+        build_tree_fast(src, opt.method, opt.dist, fp, tree);
+    } else {
+        build_tree(src, opt.method, opt.dist, tree, 1);
+    }
     tree_from_unique(tree, w.sorted2unique);
     return tree_to_newick(tree, names);
 }
 
-std::string guide_tree_newick_from_matrix(const SeqSet& s, const uint32_t* sq, GT method, Distance dist,
-                                          bool keep_duplicates)
+std::string guide_tree_newick_from_matrix(const SeqSet& s, const uint32_t* sq, const TreeOptions& opt)
 {
     const int n_in = (int)s.size();
-    WorkSet w = make_workset(s, keep_duplicates);
+    WorkSet w = make_workset(s, opt.keep_duplicates);
     const int u = w.n_unique();
     std::vector<uint32_t> lens(u), m((size_t)u * u);
     std::vector<int> in_of(u);
@@ -37,14 +46,13 @@ std::string guide_tree_newick_from_matrix(const SeqSet& s, const uint32_t* sq, G
     for (int a = 0; a < u; ++a)
         for (int b = 0; b < u; ++b) m[(size_t)a * u + b] = sq[(size_t)in_of[a] * n_in + in_of[b]];
     MatrixLcsSource src(u, lens.data(), m.data());
-    return guide_tree_newick(s, w, src, method, dist);
+    return guide_tree_newick(s, w, src, opt);
 }
 
-std::string guide_tree_newick_gpu(const SeqSet& s, int device, GT method, Distance dist, bool keep_duplicates,
-                                  Timings* t)
+std::string guide_tree_newick_gpu(const SeqSet& s, int device, const TreeOptions& opt, Timings* t)
 {
     double t0 = now_s();
-    WorkSet w = make_workset(s, keep_duplicates);
+    WorkSet w = make_workset(s, opt.keep_duplicates);
     std::vector<int> in_of(w.n_unique());
     for (int a = 0; a < w.n_unique(); ++a) in_of[a] = w.sorted2input[w.unique2sorted[a]];
     std::vector<uint8_t> codes;
@@ -54,7 +62,7 @@ std::string guide_tree_newick_gpu(const SeqSet& s, int device, GT method, Distan
     GpuLcsSource src(device);
     src.upload(codes, offsets);
     double t2 = now_s();
-    std::string nwk = guide_tree_newick(s, w, src, method, dist);
+    std::string nwk = guide_tree_newick(s, w, src, opt);
     double t3 = now_s();
     if (t) {
         t->sort_s = t1 - t0;

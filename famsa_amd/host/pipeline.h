@@ -16,12 +16,19 @@ struct Timings {
 
 // Newick for the whole input (duplicates re-attached), LCS values from `src_of_unique`, whose
 // sequence ids are the sorted unique working order.
-std::string guide_tree_newick(const SeqSet& s, const WorkSet& w, LcsSource& src_of_unique, GT method, Distance dist);
+// Tree-stage options of the reference CLI (core/params.h:81-104)
+struct TreeOptions {
+    GT method = GT::MST_Prim;
+    Distance dist = Distance::indel075_div_lcs;
+    bool keep_duplicates = false;
+    int heuristic = 0; // 0 none, 1 -parttree, 2 -medoidtree
+    FastTreeParams fast;
+};
 
-std::string guide_tree_newick_from_matrix(const SeqSet& s, const uint32_t* square_input_order, GT method,
-                                          Distance dist, bool keep_duplicates);
-std::string guide_tree_newick_gpu(const SeqSet& s, int device, GT method, Distance dist, bool keep_duplicates,
-                                  Timings* t);
+std::string guide_tree_newick(const SeqSet& s, const WorkSet& w, LcsSource& src_of_unique, const TreeOptions& opt);
+
+std::string guide_tree_newick_from_matrix(const SeqSet& s, const uint32_t* square_input_order, const TreeOptions& opt);
+std::string guide_tree_newick_gpu(const SeqSet& s, int device, const TreeOptions& opt, Timings* t);
 void dist_export_gpu(const SeqSet& s, int device, Distance dist, bool square, bool pid, const std::string& path,
                      Timings* t);
 

@@ -234,7 +234,6 @@ void slink(LcsSource& src, tree_structure& tree)
     std::stable_sort(elements.begin(), elements.end(), [&](int x, int y) { return lambda[x] < lambda[y]; });
     std::vector<int> index(n);
     for (int i = 0; i < n; ++i) index[i] = i;
-    tree.assign(n, node_t(-1, -1));
     for (int i = 0; i < n - 1; ++i) {
         const int j = elements[i];
         const int next = pi[j];
@@ -314,7 +313,6 @@ void upgma_tree(std::vector<float>& D, int n, tree_structure& tree)
         min_dist[Lmin] = new_min;
         node_index[Rmin] = NONE;
     }
-    tree.assign(n, node_t(-1, -1));
     for (int i = 0; i < n - 1; ++i) tree.emplace_back((int)left[i], (int)right[i]);
 }
 
@@ -329,7 +327,6 @@ void nj_tree(std::vector<float>& D, int n, tree_structure& tree)
         for (int j = 0; j < n; ++j)
             if (i != j) cl[i].sum += D[tri(i, j)];
     }
-    tree.assign(n, node_t(-1, -1));
     int iter = 0;
     for (int n_clusters = n; n_clusters > 2; ++iter) {
         float min_q = std::numeric_limits<float>::max();
@@ -362,12 +359,12 @@ void nj_tree(std::vector<float>& D, int n, tree_structure& tree)
     tree.emplace_back(cl[0].node, cl[1].node);
 }
 
+// the partial generators: append n-1 internal nodes (local ids)
 template <Distance D>
-void build_tree_d(LcsSource& src, GT method, tree_structure& tree)
+void build_partial_d(LcsSource& src, GT method, tree_structure& tree)
 {
     const int n = src.n();
     switch (method) {
-    case GT::MST_Prim: mst_prim<D>(src, tree); break;
     case GT::SLINK: slink<D>(src, tree); break;
     case GT::UPGMA:
     case GT::UPGMA_modified: {
@@ -382,21 +379,32 @@ void build_tree_d(LcsSource& src, GT method, tree_structure& tree)
         nj_tree(dist, n, tree);
         break;
     }
+    default: throw std::runtime_error("not a partial generator");
     }
 }
 
 } // namespace
 
+void build_tree_partial(LcsSource& src, GT method, Distance dist, tree_structure& tree)
+{
+    if (src.n() < 2) return;
+    if (dist == Distance::indel_div_lcs) build_partial_d<Distance::indel_div_lcs>(src, method, tree);
+    else if (dist == Distance::indel075_div_lcs) build_partial_d<Distance::indel075_div_lcs>(src, method, tree);
+    else throw std::runtime_error("Error: Illegal pairwise distance measure.");
+}
+
 void build_tree(LcsSource& src, GT method, Distance dist, tree_structure& tree, int /*n_threads*/)
 {
     const int n = src.n();
-    if (n < 2) {
-        tree.assign(std::max(n, 0), node_t(-1, -1));
+    tree.assign(std::max(n, 0), node_t(-1, -1));
+    if (n < 2) return;
+    if (method == GT::MST_Prim) {
+        if (dist == Distance::indel_div_lcs) mst_prim<Distance::indel_div_lcs>(src, tree);
+        else if (dist == Distance::indel075_div_lcs) mst_prim<Distance::indel075_div_lcs>(src, tree);
+        else throw std::runtime_error("Error: Illegal pairwise distance measure.");
         return;
     }
-    if (dist == Distance::indel_div_lcs) build_tree_d<Distance::indel_div_lcs>(src, method, tree);
-    else if (dist == Distance::indel075_div_lcs) build_tree_d<Distance::indel075_div_lcs>(src, method, tree);
-    else throw std::runtime_error("Error: Illegal pairwise distance measure.");
+    build_tree_partial(src, method, dist, tree);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -25,6 +25,25 @@ GT gt_from_string(const std::string& name); // "sl" | "slink" | "upgma" | "upgma
 // SingleLinkage.cpp:31-189, UPGMA.cpp:39-51 + 114-295, NeighborJoining.cpp:10-118.
 void build_tree(LcsSource& src, GT method, Distance dist, tree_structure& tree, int n_threads);
 
+// IPartialGenerator::runPartial (reference tree/IPartialGenerator.h:13): APPEND the n-1 internal
+// nodes of the tree over src's n sequences to `tree`, with local ids (leaves 0..n-1, internal
+// nodes n..2n-2).  Only SLINK, UPGMA(_modified) and NJ are partial generators.
+void build_tree_partial(LcsSource& src, GT method, Distance dist, tree_structure& tree);
+
+// MedoidTree / PartTree heuristic (reference tree/FastTree.cpp + tree/Clustering.cpp): recursive
+// seed selection (CLARANS k-medoids on a sample, or random seeds), assignment of every sequence to
+// its nearest seed, sub-trees per cluster with `partial`, stitched by a tree over the seeds.
+struct FastTreeParams { // CParams::medoid, reference core/params.h:88-97
+    bool use_clustering = true; // true: -medoidtree (CLARANS), false: -parttree (random seeds)
+    int subtree_size = 100;
+    int sample_size = 2000;
+    int num_evaluations = 1;
+    int threshold = 2000;
+    float cluster_fraction = 0.1f;
+    int cluster_iters = 2;
+};
+void build_tree_fast(LcsSource& src, GT partial, Distance dist, const FastTreeParams& p, tree_structure& tree);
+
 // GuideTree::fromUnique (reference tree/GuideTree.cpp:146-208): re-attach removed duplicates.
 void tree_from_unique(tree_structure& tree, const std::vector<int>& sorted2unique);
 

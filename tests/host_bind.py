@@ -17,12 +17,14 @@ class Host:
         lib = C.CDLL(HOST_SO)
         lib.famsa_host_last_error.restype = C.c_char_p
         lib.famsa_host_tree_from_matrix.restype = C.c_long
-        lib.famsa_host_tree_from_matrix.argtypes = [C.c_char_p, C.c_void_p, C.c_char_p, C.c_int, C.c_int,
+        heur = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int]
+        lib.famsa_host_tree_from_matrix.argtypes = [C.c_char_p, C.c_void_p, C.c_char_p, C.c_int, C.c_int, *heur,
                                                     C.c_char_p, C.c_long]
         lib.famsa_host_dist_export_from_matrix.argtypes = [C.c_char_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                                            C.c_char_p]
         lib.famsa_host_tree_gpu.restype = C.c_long
-        lib.famsa_host_tree_gpu.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_char_p, C.c_long]
+        lib.famsa_host_tree_gpu.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_int, *heur, C.c_char_p,
+                                            C.c_long]
         lib.famsa_host_dist_export_gpu.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p]
         lib.famsa_host_workset.argtypes = [C.c_char_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
         lib.famsa_host_format_distance.argtypes = [C.c_double, C.c_char_p]
@@ -31,11 +33,17 @@ class Host:
     def _err(self):
         return RuntimeError(self.lib.famsa_host_last_error().decode())
 
-    def tree_from_matrix(self, fasta, square, method, distance="indel075_div_lcs", keep_duplicates=False):
+    HEUR = {None: 0, "parttree": 1, "medoidtree": 2}
+
+    def tree_from_matrix(self, fasta, square, method, distance="indel075_div_lcs", keep_duplicates=False,
+                         heuristic=None, subtree_size=0, sample_size=0, threshold=0, cluster_fraction=0.0,
+                         cluster_iters=0):
         sq = np.ascontiguousarray(square, np.uint32)
         buf = C.create_string_buffer(1 << 25)
         n = self.lib.famsa_host_tree_from_matrix(fasta.encode(), sq.ctypes.data, method.encode(), DIST[distance],
-                                                 int(keep_duplicates), buf, len(buf))
+                                                 int(keep_duplicates), self.HEUR[heuristic], subtree_size,
+                                                 sample_size, threshold, cluster_fraction, cluster_iters, buf,
+                                                 len(buf))
         if n < 0:
             raise self._err()
         return buf.raw[:n]
@@ -47,10 +55,12 @@ class Host:
                                                        int(square_matrix), int(pid), path.encode()) != 0:
             raise self._err()
 
-    def tree_gpu(self, fasta, method, distance="indel075_div_lcs", keep_duplicates=False, device=0):
+    def tree_gpu(self, fasta, method, distance="indel075_div_lcs", keep_duplicates=False, device=0, heuristic=None,
+                 subtree_size=0, sample_size=0, threshold=0, cluster_fraction=0.0, cluster_iters=0):
         buf = C.create_string_buffer(1 << 25)
         n = self.lib.famsa_host_tree_gpu(fasta.encode(), device, method.encode(), DIST[distance],
-                                         int(keep_duplicates), buf, len(buf))
+                                         int(keep_duplicates), self.HEUR[heuristic], subtree_size, sample_size,
+                                         threshold, cluster_fraction, cluster_iters, buf, len(buf))
         if n < 0:
             raise self._err()
         return buf.raw[:n]

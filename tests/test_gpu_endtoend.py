@@ -94,6 +94,29 @@ def test_synthetic_2k_tree(host, tmp_path, gt):
 
 
 def test_cli_refuses_out_of_scope_flags(tmp_path):
-    p = subprocess.run([host_bind.CLI, "-medoidtree", "-gt_export", os.path.join(G, "adeno_fiber", "adeno_fiber"),
+    p = subprocess.run([host_bind.CLI, "-gz", "-gt_export", os.path.join(G, "adeno_fiber", "adeno_fiber"),
                         str(tmp_path / "x")], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     assert p.returncode != 0 and "outside the scope" in p.stderr
+
+
+@pytest.mark.parametrize("gt", ["sl", "upgma", "nj"])
+def test_hemopexin_medoidtree(host, gt):
+    got = host.tree_gpu(os.path.join(G, "hemopexin", "hemopexin"), gt, heuristic="medoidtree")
+    assert got == open(os.path.join(G, "hemopexin", f"medoid-{gt}.dnd"), "rb").read()
+
+
+def test_cli_medoidtree_nondefault_params(tmp_path):
+    out = str(tmp_path / "t.dnd")
+    run_cli("-medoidtree", "-gt", "slink", "-gt_export", "-subtree_size", "10", "-sample_size", "100",
+            "-medoid_threshold", "100", "-cluster_fraction", "0.2", "-cluster_iters", "1",
+            os.path.join(G, "hemopexin", "hemopexin"), out)
+    assert open(out, "rb").read() == open(os.path.join(G, "hemopexin", "medoid-slink-params.dnd"), "rb").read()
+
+
+def test_cli_medoidtree_duplicates(tmp_path):
+    out = str(tmp_path / "t.dnd")
+    f = os.path.join(G, "hemopexin_duplicates", "hemopexin_duplicates")
+    run_cli("-medoidtree", "-gt", "sl", "-gt_export", f, out)
+    assert open(out, "rb").read() == open(os.path.join(G, "hemopexin_duplicates", "medoid-sl.dnd"), "rb").read()
+    run_cli("-keep-duplicates", "-medoidtree", "-gt", "sl", "-gt_export", f, out)
+    assert open(out, "rb").read() == open(os.path.join(G, "hemopexin_duplicates", "medoid-sl-dups.dnd"), "rb").read()

@@ -121,3 +121,41 @@ def test_workset_matches_python_order(host, oracle):
     u, s2i, s2u = host.workset(f, len(ids))
     assert list(s2i) == seqio.sort_order(enc)
     assert u == len({bytes(e) for e in enc})
+
+
+# ---- MedoidTree / PartTree heuristic (reference tree/FastTree.cpp, tree/Clustering.cpp) ----------------
+@pytest.mark.parametrize("gt", ["sl", "slink", "upgma", "nj"])
+def test_hemopexin_medoid_trees_vs_reference_goldens(host, oracle, gt):
+    """The reference's own goldens test/hemopexin/medoid-*.dnd (CLARANS seeds, assignment, stitching)."""
+    f = os.path.join(G, "hemopexin", "hemopexin")
+    got = host.tree_from_matrix(f, square(oracle, f), gt, heuristic="medoidtree")
+    assert got == open(os.path.join(G, "hemopexin", f"medoid-{gt}.dnd"), "rb").read()
+
+
+@pytest.mark.parametrize("gt", ["sl", "slink", "upgma", "nj"])
+def test_hemopexin_medoid_nondefault_params(host, oracle, gt):
+    """.github/workflows/main.yml:136-139: -subtree_size 10 -sample_size 100 -medoid_threshold 100
+    -cluster_fraction 0.2 -cluster_iters 1 (deep recursion, sampled clustering)."""
+    f = os.path.join(G, "hemopexin", "hemopexin")
+    got = host.tree_from_matrix(f, square(oracle, f), gt, heuristic="medoidtree", subtree_size=10, sample_size=100,
+                                threshold=100, cluster_fraction=0.2, cluster_iters=1)
+    assert got == open(os.path.join(G, "hemopexin", f"medoid-{gt}-params.dnd"), "rb").read()
+
+
+@pytest.mark.parametrize("keep,name", [(False, "medoid-sl.dnd"), (True, "medoid-sl-dups.dnd")])
+def test_hemopexin_duplicates_medoid(host, oracle, keep, name):
+    f = os.path.join(G, "hemopexin_duplicates", "hemopexin_duplicates")
+    got = host.tree_from_matrix(f, square(oracle, f), "sl", heuristic="medoidtree", keep_duplicates=keep)
+    assert got == open(os.path.join(G, "hemopexin_duplicates", name), "rb").read()
+
+
+@pytest.mark.skipif(not oracle_bind.have_ref(), reason="oracle/_ref not built (needs /root/reference)")
+def test_parttree_vs_reference_library(host, oracle):
+    """-parttree has no upstream golden: compare with the reference itself (random seeds path)."""
+    f = os.path.join(G, "hemopexin", "hemopexin")
+    ref = oracle_bind.Ref()
+    h = ref.open_fasta(f)
+    want = ref.tree(h, "upgma", heuristic=1, threshold=100)
+    ref.close(h)
+    got = host.tree_from_matrix(f, square(oracle, f), "upgma", heuristic="parttree", threshold=100)
+    assert got == want
