@@ -4,6 +4,8 @@
 // host program that already holds an LCS matrix.  `famsa_host_*_from_matrix` consume a
 // caller-supplied oriented matrix (the CPU tests pass the oracle's); `famsa_host_*_gpu` take the
 // values from the MI355X engine.
+#include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 #include <string>
@@ -33,6 +35,7 @@ TreeOptions make_options(const char* method, int distance, int keep_duplicates, 
     if (threshold > 0) o.fast.threshold = threshold;
     if (cluster_fraction > 0) o.fast.cluster_fraction = cluster_fraction;
     if (cluster_iters > 0) o.fast.cluster_iters = cluster_iters;
+    if (const char* t = getenv("FAMSA_HOST_THREADS")) o.fast.n_threads = std::max(1, atoi(t));
     return o;
 }
 int fail(const std::exception& e)

@@ -16,6 +16,7 @@
 #include <iostream>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "pipeline.h"
@@ -89,7 +90,11 @@ int main(int argc, char** argv)
         if (find_option(params, "-cluster_fraction", aux)) opt.fast.cluster_fraction = std::stof(aux);
         if (find_option(params, "-cluster_iters", aux)) opt.fast.cluster_iters = std::stoi(aux);
         if (find_option(params, "-gpu", aux)) device = std::stoi(aux);
-        find_option(params, "-t", aux);
+        // -t <n>: host worker threads (0 = half of the hardware threads, reference core/params.cpp:285-291)
+        int n_threads = 0;
+        if (find_option(params, "-t", aux)) n_threads = std::stoi(aux);
+        if (n_threads <= 0) n_threads = std::max(1u, std::thread::hardware_concurrency() / 2);
+        opt.fast.n_threads = n_threads;
         const bool very_verbose = find_switch(params, "-vv");
         const bool verbose = find_switch(params, "-v") || very_verbose;
         const bool export_tree = find_switch(params, "-gt_export");

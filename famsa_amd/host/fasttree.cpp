@@ -10,10 +10,40 @@
 #include <random>
 #include <stdexcept>
 
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <mutex>
+#include <thread>
+
 #include "trees.h"
 
 namespace famsa_host {
 namespace {
+
+// coarse phase timers, printed when FAMSA_GPU_PROFILE is set (dev aid)
+struct PhaseTimers {
+    double lcs = 0, clarans = 0, partial = 0, assign = 0;
+    ~PhaseTimers()
+    {
+        if (getenv("FAMSA_GPU_PROFILE") && (lcs + clarans + partial + assign) > 0)
+            fprintf(stderr, "fasttree.lcs_calls=%.3f\nfasttree.clarans=%.3f\nfasttree.partial_trees=%.3f\nfasttree.assign=%.3f\n",
+                    lcs, clarans, partial, assign);
+    }
+} g_phase;
+std::mutex g_phase_mu;
+struct Scope { // thread-seconds, summed over the worker threads
+    double& acc;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    explicit Scope(double& a) : acc(a) {}
+    ~Scope()
+    {
+        const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        std::lock_guard<std::mutex> lk(g_phase_mu);
+        acc += dt;
+    }
+};
 
 inline size_t tri(size_t i, size_t j) { return i >= j ? j + i * (i - 1) / 2 : i + j * (j - 1) / 2; }
 
@@ -209,7 +239,10 @@ struct FastTree {
     {
         LcsBuf buf;
         const int ref = ids[ref_local];
-        src.rect(&ref, 1, ids.data(), (int)ids.size(), buf);
+        {
+            Scope t(g_phase.lcs);
+            src.rect(&ref, 1, ids.data(), (int)ids.size(), buf);
+        }
         const uint32_t len_ref = src.length(ref);
         for (size_t j = 0; j < ids.size(); ++j) out[j] = transform(buf[j], len_ref, src.length(ids[j]));
     }
@@ -254,13 +287,19 @@ struct FastTree {
         {
             SubsetSource sub(src, sample_global);
             LcsBuf buf;
-            sub.triangle(0, n_samples, buf);
+            {
+                Scope t(g_phase.lcs);
+                sub.triangle(0, n_samples, buf);
+            }
             for (int i = 1; i < n_samples; ++i)
                 for (int j = 0; j < i; ++j)
                     dist[tri(i, j)] = transform(buf[tri(i, j)], sub.length(i), sub.length(j));
         }
         seed_ids.assign(n_seeds, 0);
-        Clarans{prm.cluster_fraction, prm.cluster_iters}(dist.data(), n_samples, n_seeds, 1, seed_ids.data());
+        {
+            Scope t(g_phase.clarans);
+            Clarans{prm.cluster_fraction, prm.cluster_iters}(dist.data(), n_samples, n_seeds, 1, seed_ids.data());
+        }
         if (!sample_ids.empty())
             for (int k = 0; k < n_seeds; ++k) seed_ids[k] = sample_ids[seed_ids[k]];
         return n_seeds;
@@ -284,7 +323,11 @@ struct FastTree {
         LcsBuf buf;
         for (int c0 = 0; c0 < n && n_seeds > 1; c0 += chunk) {
             const int c1 = std::min(n, c0 + chunk);
-            src.rect(refs.data(), n_seeds - 1, ids.data() + c0, c1 - c0, buf);
+            {
+                Scope t(g_phase.lcs);
+                src.rect(refs.data(), n_seeds - 1, ids.data() + c0, c1 - c0, buf);
+            }
+            Scope t2(g_phase.assign);
             for (int k = 1; k < n_seeds; ++k) {
                 const uint32_t len_k = src.length(refs[k - 1]);
                 for (int j = c0; j < c1; ++j) {
@@ -300,13 +343,19 @@ struct FastTree {
     }
 
     // FastTree::doStep, FastTree.cpp:56-266.  `ids` = global ids (sequence_no) of this subset.
-    void do_step(const std::vector<int>& ids, tree_structure& tree, int previous_top)
+    // parallel = true only at the top level, like the reference: the sub-trees of the first split
+    // are built by worker threads (each with its own Transform tables; the GPU engine serialises
+    // their LCS calls internally), then gathered in seed order.
+    void do_step(const std::vector<int>& ids, tree_structure& tree, int previous_top, bool parallel = false)
     {
         const int n = (int)ids.size();
         const bool split = prm.use_clustering ? n > prm.threshold : n > prm.subtree_size;
         if (!split) {
             SubsetSource sub(src, ids);
-            build_tree_partial(sub, partial, D, tree);
+            {
+                Scope t(g_phase.partial);
+                build_tree_partial(sub, partial, D, tree);
+            }
             if (previous_top > n) {
                 for (int node = 0; node < n - 1; ++node) {
                     node_t& nd = tree[node];
@@ -340,18 +389,49 @@ struct FastTree {
         for (int j = 0; j < n; ++j) subgroups[assignments[j]].push_back(ids[j]);
 
         std::vector<int> subroots(n_seeds, -1);
-        for (int k = 0; k < n_seeds; ++k) {
-            if (subgroups[k].size() > 1) {
-                tree_structure local;
-                do_step(subgroups[k], local, previous_top);
-                tree.insert(tree.end(), local.begin(), local.end());
-                previous_top += (int)subgroups[k].size() - 1;
-                subroots[k] = previous_top - 1;
+        if (parallel && prm.n_threads > 1) {
+            struct Task { int k, top; };
+            std::vector<Task> tasks;
+            for (int k = 0; k < n_seeds; ++k)
+                if (subgroups[k].size() > 1) {
+                    tasks.push_back(Task{k, previous_top});
+                    previous_top += (int)subgroups[k].size() - 1;
+                    subroots[k] = previous_top - 1;
+                }
+            std::vector<tree_structure> locals(tasks.size());
+            std::atomic<size_t> next{0};
+            std::vector<std::string> errors(prm.n_threads);
+            std::vector<std::thread> workers;
+            for (int w = 0; w < prm.n_threads; ++w)
+                workers.emplace_back([&, w] {
+                    try {
+                        FastTree<D> child{src, partial, prm, {}};
+                        for (size_t t = next++; t < tasks.size(); t = next++)
+                            child.do_step(subgroups[tasks[t].k], locals[t], tasks[t].top, false);
+                    } catch (const std::exception& e) {
+                        errors[w] = e.what();
+                        next = tasks.size();
+                    }
+                });
+            for (auto& w : workers) w.join();
+            for (const auto& e : errors)
+                if (!e.empty()) throw std::runtime_error(e);
+            for (const auto& lt : locals) tree.insert(tree.end(), lt.begin(), lt.end());
+        } else {
+            for (int k = 0; k < n_seeds; ++k) {
+                if (subgroups[k].size() > 1) {
+                    tree_structure local;
+                    do_step(subgroups[k], local, previous_top, false);
+                    tree.insert(tree.end(), local.begin(), local.end());
+                    previous_top += (int)subgroups[k].size() - 1;
+                    subroots[k] = previous_top - 1;
+                }
             }
         }
         tree_structure local;
         {
             SubsetSource sub(src, seeds);
+            Scope t(g_phase.partial);
             build_tree_partial(sub, partial, D, local);
         }
         for (int node = 0; node < n_seeds - 1; ++node) {
@@ -375,7 +455,7 @@ void run_fast(LcsSource& src, GT partial, const FastTreeParams& p, tree_structur
     std::vector<int> ids(n);
     std::iota(ids.begin(), ids.end(), 0);
     tree_structure local;
-    ft.do_step(ids, local, (int)tree.size());
+    ft.do_step(ids, local, (int)tree.size(), true);
     tree.insert(tree.end(), local.begin(), local.end());
 }
 

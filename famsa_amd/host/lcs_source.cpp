@@ -42,14 +42,20 @@ void GpuLcsSource::upload(const std::vector<uint8_t>& codes, const std::vector<u
     sensitive_ = nq > 0;
 }
 
+void GpuLcsSource::add_kernel_ms()
+{
+    double ms = 0;
+    int32_t nl = 0;
+    std::lock_guard<std::mutex> lk(mu_);
+    if (lcsgpu_last_kernel_ms(ctx_, &ms, &nl) == LCSGPU_OK) kernel_ms_ += ms;
+}
+
 void GpuLcsSource::triangle(int r0, int r1, LcsBuf& out)
 {
     const size_t count = (size_t)r1 * (r1 - 1) / 2 - (size_t)r0 * (r0 > 0 ? r0 - 1 : 0) / 2;
     out.resize(count, wide());
     check(lcsgpu_lcs_triangle(ctx_, r0, r1, out.data(), out.elem_size()), "lcsgpu_lcs_triangle");
-    double ms = 0;
-    int32_t nl = 0;
-    if (lcsgpu_last_kernel_ms(ctx_, &ms, &nl) == LCSGPU_OK) kernel_ms_ += ms;
+    add_kernel_ms();
 }
 
 void GpuLcsSource::rect(const int* refs, int n_refs, const int* cols, int n_cols, LcsBuf& out)
@@ -57,9 +63,7 @@ void GpuLcsSource::rect(const int* refs, int n_refs, const int* cols, int n_cols
     out.resize((size_t)n_refs * n_cols, wide());
     check(lcsgpu_lcs_rect(ctx_, refs, 0, n_refs, cols, 0, n_cols, out.data(), n_cols, out.elem_size()),
           "lcsgpu_lcs_rect");
-    double ms = 0;
-    int32_t nl = 0;
-    if (lcsgpu_last_kernel_ms(ctx_, &ms, &nl) == LCSGPU_OK) kernel_ms_ += ms;
+    add_kernel_ms();
 }
 
 bool GpuLcsSource::prim_edges(int distance_kind, std::vector<MstEdge>& edges)
@@ -67,9 +71,7 @@ bool GpuLcsSource::prim_edges(int distance_kind, std::vector<MstEdge>& edges)
     static_assert(sizeof(MstEdge) == sizeof(lcsgpu_mst_edge), "edge layout");
     edges.resize(n() > 0 ? n() - 1 : 0);
     check(lcsgpu_mst_prim(ctx_, distance_kind, (lcsgpu_mst_edge*)edges.data()), "lcsgpu_mst_prim");
-    double ms = 0;
-    int32_t nl = 0;
-    if (lcsgpu_last_kernel_ms(ctx_, &ms, &nl) == LCSGPU_OK) kernel_ms_ += ms;
+    add_kernel_ms();
     return true;
 }
 

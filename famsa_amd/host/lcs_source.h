@@ -5,6 +5,7 @@
 #pragma once
 #include <cstdint>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -61,6 +62,7 @@ public:
     void rect(const int* refs, int n_refs, const int* cols, int n_cols, LcsBuf& out) override;
     bool prim_edges(int distance_kind, std::vector<MstEdge>& edges) override;
     double kernel_ms_total() const { return kernel_ms_; }
+    void add_kernel_ms();
 
 private:
     void check(int rc, const char* what);
@@ -68,6 +70,7 @@ private:
     std::vector<uint32_t> lens_;
     bool sensitive_ = false;
     double kernel_ms_ = 0;
+    std::mutex mu_; // the tree builders may call from several threads
 };
 
 // A full oriented square matrix supplied by the caller: m[ref*n + partner].

@@ -41,6 +41,7 @@ struct FastTreeParams { // CParams::medoid, reference core/params.h:88-97
     int threshold = 2000;
     float cluster_fraction = 0.1f;
     int cluster_iters = 2;
+    int n_threads = 1; // worker threads for the sub-trees of the top-level split
 };
 void build_tree_fast(LcsSource& src, GT partial, Distance dist, const FastTreeParams& p, tree_structure& tree);
 

@@ -159,3 +159,12 @@ def test_parttree_vs_reference_library(host, oracle):
     ref.close(h)
     got = host.tree_from_matrix(f, square(oracle, f), "upgma", heuristic="parttree", threshold=100)
     assert got == want
+
+
+def test_medoid_subtrees_built_by_worker_threads(host, oracle, monkeypatch):
+    """The top-level sub-trees run on worker threads (as in the reference); the result must not change."""
+    monkeypatch.setenv("FAMSA_HOST_THREADS", "6")
+    f = os.path.join(G, "hemopexin", "hemopexin")
+    got = host.tree_from_matrix(f, square(oracle, f), "upgma", heuristic="medoidtree", subtree_size=10,
+                                sample_size=100, threshold=100, cluster_fraction=0.2, cluster_iters=1)
+    assert got == open(os.path.join(G, "hemopexin", "medoid-upgma-params.dnd"), "rb").read()
