@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Tree-stage wall time: famsa-gpu vs the reference's own generators (oracle/_ref) on the same box.
+Writes a JSON summary (copied to profiles/e2e_r01.json).  Dev/measurement tool: the oracle is the baseline."""
+import json, os, subprocess, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import oracle_bind
+from famsa_amd import seqio
+
+cli = os.path.join(ROOT, "famsa_amd", "famsa-gpu")
+import multiprocessing as mp
+threads = min(32, len(os.sched_getaffinity(0)))  # the reference's published setup; its spin barriers degrade beyond
+out = {"host_threads": threads, "cases": []}
+
+
+def _ref_worker(fasta, gt, heuristic, q):
+    ref = oracle_bind.Ref()
+    h = ref.open_fasta(fasta)
+    t0 = time.time()
+    want = ref.tree(h, gt, heuristic=heuristic, threads=threads)
+    q.put((time.time() - t0, want))
+
+
+def ref_tree(fasta, gt, heuristic, limit=150):
+    q = mp.Queue()
+    p = mp.Process(target=_ref_worker, args=(fasta, gt, heuristic, q))
+    p.start()
+    try:
+        res = q.get(timeout=limit)
+    except Exception:
+        res = (None, None)
+    p.join(timeout=1)
+    if p.is_alive():
+        p.kill()
+    return res
+
+
+def gpu(args, fasta):
+    t0 = time.time()
+    p = subprocess.run([cli, "-v", *args, "-gt_export", fasta, "/tmp/cmp_gpu.dnd"], stderr=subprocess.PIPE, text=True)
+    assert p.returncode == 0, p.stderr
+    kv = dict(l.split("=") for l in p.stderr.split() if "=" in l)
+    return time.time() - t0, float(kv["time.tree_build"]), open("/tmp/cmp_gpu.dnd", "rb").read()
+
+
+def case(name, fasta, gt, heuristic=0, cli_args=()):
+    t_ref, want = ref_tree(fasta, gt, heuristic)
+    wall, tb, got = gpu(["-gt", gt, *cli_args], fasta)
+    rec = {"case": name, "gt": gt, "identical_newick": (got == want) if want is not None else None,
+           "reference_tree_s": round(t_ref, 3) if t_ref else "> 150 (stopped)",
+           "gpu_tree_build_s": round(tb, 3), "gpu_cli_wall_s": round(wall, 3),
+           "speedup_tree_stage": round(t_ref / tb, 1) if t_ref else None}
+    print(rec, flush=True)
+    out["cases"].append(rec)
+    json.dump(out, open(os.path.join(ROOT, "gpurun_out", "e2e_r01.json"), "w"), indent=1)
+
+
+codes, offsets = seqio.synth_uniform(10000, 400)
+seqio.to_fasta(codes, offsets, "/tmp/cmp_10k.fasta")
+case("synthetic 10000 x 400 aa", "/tmp/cmp_10k.fasta", "sl")
+case("synthetic 10000 x 400 aa", "/tmp/cmp_10k.fasta", "upgma")
+case("synthetic 10000 x 400 aa", "/tmp/cmp_10k.fasta", "slink")
+fam = "/tmp/family_200000_300.fasta"
+if os.path.exists(fam):
+    case("synthetic family 200000 x ~255 aa, -medoidtree", fam, "upgma", heuristic=2, cli_args=["-medoidtree"])
+json.dump(out, open(os.path.join(ROOT, "gpurun_out", "e2e_r01.json"), "w"), indent=1)

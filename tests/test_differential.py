@@ -1,0 +1,99 @@
+"""Randomised differential tests of the host layer against the REFERENCE ITSELF (oracle/_ref): many small
+inputs with heavy distance ties, duplicates, unknown symbols and short sequences -- the regime where tie
+breaking and float/double rounding decide the topology.  Needs oracle/_ref (built only where
+/root/reference exists), so these run in the build container and are skipped on the GPU box."""
+import os
+
+import numpy as np
+import pytest
+
+import host_bind
+import oracle_bind
+from famsa_amd import seqio
+
+pytestmark = pytest.mark.skipif(not oracle_bind.have_ref(), reason="oracle/_ref not built (needs /root/reference)")
+
+
+@pytest.fixture(scope="module")
+def host():
+    return host_bind.Host()
+
+
+@pytest.fixture(scope="module")
+def ref():
+    return oracle_bind.Ref()
+
+
+def random_set(rng, n, max_len, alphabet, dup_frac):
+    seqs = []
+    for _ in range(n):
+        if seqs and rng.random() < dup_frac:
+            s = seqs[int(rng.integers(0, len(seqs)))]
+            if rng.random() < 0.5:  # near duplicate
+                s = s[: max(1, len(s) - int(rng.integers(0, 3)))]
+        else:
+            L = int(rng.integers(1, max_len + 1))
+            s = "".join(alphabet[i] for i in rng.integers(0, len(alphabet), size=L))
+        seqs.append(s)
+    # every pair needs a common matching residue (the reference is undefined for LCS 0 in the tree stage)
+    seqs = [s + "A" for s in seqs]
+    return [f">r{i}" for i in range(n)], seqs
+
+
+CASES = [(seed, n, max_len, alpha) for seed, (n, max_len, alpha) in enumerate([
+    (2, 5, "AC"), (3, 8, "AC"), (7, 12, "ACD"), (16, 20, "AC"), (33, 30, "ARNDX"), (40, 70, "ACDEFGHIKL"),
+    (64, 15, "AC"), (65, 40, "ARND"), (90, 100, "ARNDCQEGHILKMFPSTWYVBZX"), (129, 25, "ACD"), (150, 140, "ACDE"),
+    (257, 10, "AC")])]
+
+
+@pytest.mark.parametrize("seed,n,max_len,alpha", CASES)
+def test_trees_and_csv_match_reference(host, ref, oracle, tmp_path, seed, n, max_len, alpha):
+    rng = np.random.Generator(np.random.PCG64(1000 + seed))
+    ids, seqs = random_set(rng, n, max_len, alpha, 0.25)
+    fasta = str(tmp_path / "in.fasta")
+    with open(fasta, "w") as f:
+        for i, s in zip(ids, seqs):
+            f.write(f"{i}\n{s}\n")
+    enc = [oracle.encode(s) for s in seqs]
+    codes, offsets = seqio.pack(enc)
+    sq = oracle.rect(codes, offsets, np.arange(n), np.arange(n))
+    h = ref.open_fasta(fasta)
+    try:
+        for dist_id, dist in [(1, "indel075_div_lcs"), (0, "indel_div_lcs")]:
+            for gt in ("sl", "slink", "upgma", "nj", "upgma_modified"):
+                for keep in (False, True):
+                    want = ref.tree(h, gt, distance=dist_id, keep_dups=int(keep), threads=2)
+                    got = host.tree_from_matrix(fasta, sq, gt, distance=dist, keep_duplicates=keep)
+                    assert got == want, (gt, dist, keep)
+        for square, pid in [(False, False), (True, False), (False, True), (True, True)]:
+            a, b = str(tmp_path / "a.csv"), str(tmp_path / "b.csv")
+            ref.dist_export(h, a, square=square, pid=pid, threads=2)
+            host.dist_export_from_matrix(fasta, sq, b, square_matrix=square, pid=pid)
+            assert open(a, "rb").read() == open(b, "rb").read(), (square, pid)
+    finally:
+        ref.close(h)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_medoid_and_parttree_match_reference(host, ref, oracle, tmp_path, seed):
+    rng = np.random.Generator(np.random.PCG64(77 + seed))
+    n = int(rng.integers(150, 400))
+    ids, seqs = random_set(rng, n, 60, "ACDEFG", 0.1)
+    fasta = str(tmp_path / "in.fasta")
+    with open(fasta, "w") as f:
+        for i, s in zip(ids, seqs):
+            f.write(f"{i}\n{s}\n")
+    enc = [oracle.encode(s) for s in seqs]
+    codes, offsets = seqio.pack(enc)
+    sq = oracle.rect(codes, offsets, np.arange(n), np.arange(n))
+    h = ref.open_fasta(fasta)
+    try:
+        for gt in ("sl", "upgma", "nj"):
+            for heur_id, heur in [(2, "medoidtree"), (1, "parttree")]:
+                kw = dict(subtree=8, sample=40, threshold=30, cluster_fraction=0.3, cluster_iters=2)
+                want = ref.tree(h, gt, heuristic=heur_id, threads=3, **kw)
+                got = host.tree_from_matrix(fasta, sq, gt, heuristic=heur, subtree_size=8, sample_size=40, threshold=30,
+                                            cluster_fraction=0.3, cluster_iters=2)
+                assert got == want, (gt, heur)
+    finally:
+        ref.close(h)
