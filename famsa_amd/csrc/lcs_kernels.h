@@ -89,4 +89,21 @@ struct PrimArgs {
 };
 hipError_t launch_prim(const PrimArgs& a, int elem_size, hipStream_t stream);
 
+// ---- device-side UPGMA (tree_kernels.hip) ----
+struct UpgmaArgs {
+    float* D;             // float distance triangle (updated in place)
+    float* min_dist;      // [n]
+    uint32_t* nearest;    // [n]
+    uint32_t* node_index; // [n]
+    float* part_d;        // [n_blocks] per-workgroup minima of the last update
+    uint32_t* part_j;
+    uint32_t* sel;        // [0] Lmin, [1] Rmin, [2] error flag
+    int32_t* left;        // [n-1] children of the internal nodes
+    int32_t* right;
+    int32_t n;
+    int32_t n_blocks;
+};
+hipError_t launch_upgma(const UpgmaArgs& a, const void* lcs, int elem_size, const uint32_t* lens,
+                        const float* pow_f32, int kind, bool modified, hipStream_t stream);
+
 } // namespace lcsgpu

@@ -96,10 +96,10 @@ struct lcsgpu_ctx {
     uint32_t max_len = 0;
     std::vector<uint32_t> lens;
     std::vector<uint8_t> quirk; // ref needs the literal (V2 < V) carry rule
-    DevBuf d_tiles, d_tile_base, d_lens, d_pow;
+    DevBuf d_tiles, d_tile_base, d_lens, d_pow, d_powf;
 
     // per-call scratch
-    DevBuf d_plan, d_out, d_carry, d_prim, d_qrows, d_qcols;
+    DevBuf d_plan, d_out, d_carry, d_prim, d_qrows, d_qcols, d_dist;
     PinBuf h_plan;
     bool plan_in_flight = false;
     int last_launches = 0;
@@ -377,10 +377,12 @@ int lcsgpu_destroy(lcsgpu_ctx* ctx)
     ctx->d_tile_base.release();
     ctx->d_lens.release();
     ctx->d_pow.release();
+    ctx->d_powf.release();
     ctx->d_plan.release();
     ctx->d_out.release();
     ctx->d_carry.release();
     ctx->d_prim.release();
+    ctx->d_dist.release();
     ctx->d_qrows.release();
     ctx->d_qcols.release();
     ctx->h_plan.release();
@@ -479,6 +481,11 @@ int lcsgpu_upload(lcsgpu_ctx* ctx, const uint8_t* codes, const uint64_t* offsets
         for (size_t i = 0; i < pw.size(); ++i) pw[i] = pow((double)(uint32_t)i, 0.75);
         HIP_TRY(ctx->d_pow.reserve(pw.size() * 8));
         HIP_TRY(hipMemcpy(ctx->d_pow.p, pw.data(), pw.size() * 8, hipMemcpyHostToDevice));
+        // the float table of Transform<float, indel075_div_lcs>: (float) pow((double) i, 0.75)
+        std::vector<float> pf(pw.size());
+        for (size_t i = 0; i < pw.size(); ++i) pf[i] = (float)pw[i];
+        HIP_TRY(ctx->d_powf.reserve(pf.size() * 4));
+        HIP_TRY(hipMemcpy(ctx->d_powf.p, pf.data(), pf.size() * 4, hipMemcpyHostToDevice));
     }
     ctx->lens.swap(lens);
     ctx->quirk.swap(quirk);
@@ -672,6 +679,58 @@ int lcsgpu_mst_prim(lcsgpu_ctx* ctx, int distance_kind, lcsgpu_mst_edge* out_edg
                            ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     ctx->plan_in_flight = false;
+    return LCSGPU_OK;
+}
+
+int lcsgpu_upgma(lcsgpu_ctx* ctx, int distance_kind, int modified, int32_t* out_left, int32_t* out_right)
+{
+    if (!ctx) return fail(LCSGPU_E_INVALID, "NULL ctx");
+    if (ctx->n < 0) return fail(LCSGPU_E_STATE, "no sequence set uploaded");
+    if (distance_kind != LCSGPU_DIST_INDEL_DIV_LCS && distance_kind != LCSGPU_DIST_INDEL075_DIV_LCS)
+        return fail(LCSGPU_E_INVALID, "unknown distance kind %d", distance_kind);
+    const int32_t n = ctx->n;
+    if (n < 2) return LCSGPU_OK;
+    if (!out_left || !out_right) return fail(LCSGPU_E_INVALID, "NULL output");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIP_TRY(hipSetDevice(ctx->device));
+    const int elem = ctx->max_len > 65535 ? 4 : 2;
+    const size_t pairs = (size_t)n * (n - 1) / 2;
+    HIP_TRY(ctx->d_out.reserve(pairs * elem));
+    HIP_TRY(ctx->d_dist.reserve(pairs * sizeof(float)));
+    int rc = run_rows(ctx, lcsgpu::MODE_TRIANGLE, nullptr, 0, n, nullptr, 0, n - 1, ctx->d_out.p, 0, 0, elem);
+    if (rc) return rc;
+    const int blocks = (n + 255) / 256;
+    auto a16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
+    const size_t o_min = 0, o_near = o_min + a16((size_t)n * 4), o_node = o_near + a16((size_t)n * 4),
+                 o_pd = o_node + a16((size_t)n * 4), o_pj = o_pd + a16((size_t)blocks * 4),
+                 o_sel = o_pj + a16((size_t)blocks * 4), o_left = o_sel + 16, o_right = o_left + a16((size_t)n * 4),
+                 total = o_right + a16((size_t)n * 4);
+    HIP_TRY(ctx->d_prim.reserve(total));
+    char* base = (char*)ctx->d_prim.p;
+    HIP_TRY(hipMemsetAsync(base + o_sel, 0, 16, ctx->stream));
+    lcsgpu::UpgmaArgs a{};
+    a.D = (float*)ctx->d_dist.p;
+    a.min_dist = (float*)(base + o_min);
+    a.nearest = (uint32_t*)(base + o_near);
+    a.node_index = (uint32_t*)(base + o_node);
+    a.part_d = (float*)(base + o_pd);
+    a.part_j = (uint32_t*)(base + o_pj);
+    a.sel = (uint32_t*)(base + o_sel);
+    a.left = (int32_t*)(base + o_left);
+    a.right = (int32_t*)(base + o_right);
+    a.n = n;
+    a.n_blocks = blocks;
+    HIP_TRY(lcsgpu::launch_upgma(a, ctx->d_out.p, elem, (const uint32_t*)ctx->d_lens.p, (const float*)ctx->d_powf.p,
+                                 distance_kind, modified != 0, ctx->stream));
+    uint32_t sel[4] = {0, 0, 0, 0};
+    HIP_TRY(hipMemcpyAsync(out_left, a.left, (size_t)(n - 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(out_right, a.right, (size_t)(n - 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(sel, a.sel, 16, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->plan_in_flight = false;
+    if (sel[2])
+        return fail(LCSGPU_E_INVALID, "UPGMA: no finite nearest neighbour (a pair with LCS 0?) -- the reference's "
+                                      "algorithm is undefined for this input");
     return LCSGPU_OK;
 }
 

@@ -166,3 +166,209 @@ hipError_t launch_prim(const PrimArgs& a, int elem_size, hipStream_t stream)
 }
 
 } // namespace lcsgpu
+
+// =============================================================================================
+// Device-side UPGMA over the resident triangle: the nearest-neighbour-array formulation the
+// reference took from MUSCLE (tree/UPGMA.cpp:114-295), kept operation for operation because its
+// tie rules (strict '<' in ascending scans => the smallest index wins) and its deliberately stale
+// row minima decide the topology.  n-1 sequential merges, two small launches per merge:
+//   upgma_select_kernel (1 workgroup): apply the previous merge's row statistics, then pick
+//                                      Lmin = argmin_j min_dist[j] (first minimum), Rmin = nearest[Lmin]
+//   upgma_update_kernel (n/256 workgroups): D[Lmin,j] = average(D[Lmin,j], D[Rmin,j]) for every
+//                                      active j, nearest-pointer rename, per-workgroup new minimum
+// Distances are float, produced on the device from the LCS triangle with the reference's
+// Transform<float,...>: a host-built (float)pow(indel,0.75) table and IEEE float division.
+// =============================================================================================
+namespace lcsgpu {
+
+static constexpr uint32_t UPGMA_NONE = 0x7FFFFFFFu;
+static constexpr float UPGMA_BIG = 1e29f; // UPGMA::BIG_DIST, reference tree/UPGMA.h:106
+
+__device__ __forceinline__ size_t tri_index(uint64_t i, uint64_t j) // TriangleMatrix::access
+{
+    return i >= j ? j + i * (i - 1) / 2 : i + j * (j - 1) / 2;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void upgma_dist_kernel(const T* __restrict__ lcs, const uint32_t* __restrict__ lens,
+                                                         const float* __restrict__ pow_f32, int kind, int n,
+                                                         float* __restrict__ D)
+{
+    const int i = blockIdx.x + 1; // row
+    const uint32_t len_i = lens[i];
+    const size_t row = (size_t)i * (i - 1) / 2;
+    for (int j = threadIdx.x; j < i; j += 256) {
+        const uint32_t l = lcs[row + j];
+        const uint32_t indel = len_i + lens[j] - 2u * l;
+        float d;
+        if (l == 0)
+            d = 3.40282347e38f; // (float) nextafter((double) FLT_MAX, 0) rounds back to FLT_MAX
+        else if (kind == 1)
+            d = __fdiv_rn(pow_f32[indel], (float)l);
+        else
+            d = __fdiv_rn((float)indel, (float)l);
+        D[row + j] = d;
+    }
+}
+
+// initial row minima over the FULL row of x (columns y != x), first strict minimum in ascending y
+__global__ __launch_bounds__(256) void upgma_init_kernel(UpgmaArgs a)
+{
+    __shared__ float s_d[256];
+    __shared__ uint32_t s_j[256];
+    const int x = blockIdx.x, tid = threadIdx.x;
+    float best = UPGMA_BIG;
+    uint32_t bj = UPGMA_NONE;
+    for (int y = tid; y < a.n; y += 256) {
+        if (y == x) continue;
+        const float d = a.D[tri_index(x, y)];
+        if (d < best) { best = d; bj = y; } // ascending y within the thread
+    }
+    s_d[tid] = best;
+    s_j[tid] = bj;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) {
+            const float d2 = s_d[tid + s];
+            const uint32_t j2 = s_j[tid + s];
+            if (d2 < s_d[tid] || (d2 == s_d[tid] && j2 < s_j[tid])) { s_d[tid] = d2; s_j[tid] = j2; }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        a.min_dist[x] = s_d[0];
+        a.nearest[x] = s_j[0];
+        a.node_index[x] = x;
+    }
+}
+
+__global__ __launch_bounds__(1024) void upgma_select_kernel(UpgmaArgs a, int it)
+{
+    __shared__ float s_d[1024];
+    __shared__ uint32_t s_j[1024];
+    const int tid = threadIdx.x;
+    // ---- finish merge it-1: statistics of the row that now holds the new cluster ----
+    if (it > 0) {
+        float bd = UPGMA_BIG;
+        uint32_t bj = UPGMA_NONE;
+        for (int b = tid; b < a.n_blocks; b += 1024) {
+            const float d = a.part_d[b];
+            const uint32_t j = a.part_j[b];
+            if (d < bd || (d == bd && j < bj)) { bd = d; bj = j; }
+        }
+        s_d[tid] = bd;
+        s_j[tid] = bj;
+        __syncthreads();
+        for (int s = 512; s > 0; s >>= 1) {
+            if (tid < s) {
+                const float d2 = s_d[tid + s];
+                const uint32_t j2 = s_j[tid + s];
+                if (d2 < s_d[tid] || (d2 == s_d[tid] && j2 < s_j[tid])) { s_d[tid] = d2; s_j[tid] = j2; }
+            }
+            __syncthreads();
+        }
+        if (tid == 0) {
+            const uint32_t L = a.sel[0], R = a.sel[1];
+            a.left[it - 1] = (int32_t)a.node_index[L];
+            a.right[it - 1] = (int32_t)a.node_index[R];
+            a.node_index[L] = (uint32_t)a.n + (uint32_t)(it - 1);
+            a.nearest[L] = s_j[0];
+            a.min_dist[L] = s_d[0];
+            a.node_index[R] = UPGMA_NONE;
+        }
+        __syncthreads();
+    }
+    if (it >= a.n - 1) return;
+    // ---- pick the closest pair: first strict minimum of min_dist over the active rows ----
+    float bd = UPGMA_BIG;
+    uint32_t bj = UPGMA_NONE;
+    for (int j = tid; j < a.n; j += 1024) {
+        if (a.node_index[j] == UPGMA_NONE) continue;
+        const float d = a.min_dist[j];
+        if (d < bd) { bd = d; bj = j; }
+    }
+    s_d[tid] = bd;
+    s_j[tid] = bj;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) {
+        if (tid < s) {
+            const float d2 = s_d[tid + s];
+            const uint32_t j2 = s_j[tid + s];
+            if (d2 < s_d[tid] || (d2 == s_d[tid] && j2 < s_j[tid])) { s_d[tid] = d2; s_j[tid] = j2; }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const uint32_t L = s_j[0];
+        a.sel[0] = L;
+        a.sel[1] = L == UPGMA_NONE ? UPGMA_NONE : a.nearest[L];
+        if (L == UPGMA_NONE || a.sel[1] == UPGMA_NONE) a.sel[2] = 1; // degenerate input (reference: UB)
+    }
+}
+
+template <bool MODIFIED>
+__global__ __launch_bounds__(256) void upgma_update_kernel(UpgmaArgs a)
+{
+    __shared__ float s_d[256];
+    __shared__ uint32_t s_j[256];
+    const int tid = threadIdx.x;
+    const uint32_t L = a.sel[0], R = a.sel[1];
+    const uint32_t j = blockIdx.x * 256 + tid;
+    float nd = UPGMA_BIG;
+    uint32_t nj = UPGMA_NONE;
+    if (L != UPGMA_NONE && R != UPGMA_NONE && j < (uint32_t)a.n && j != L && j != R && a.node_index[j] != UPGMA_NONE) {
+        const size_t vL = tri_index(L, j), vR = tri_index(R, j);
+        const float dL = a.D[vL], dR = a.D[vR];
+        float v;
+        if (MODIFIED) // 0.05f * (x + y) + 0.9f * min(x, y), no contraction (reference UPGMA.cpp:32-34)
+            v = __fadd_rn(__fmul_rn(0.05f, __fadd_rn(dL, dR)), __fmul_rn(0.9f, fminf(dL, dR)));
+        else
+            v = __fmul_rn(__fadd_rn(dL, dR), 0.5f);
+        if (a.nearest[j] == R) a.nearest[j] = L;
+        a.D[vL] = v;
+        nd = v;
+        nj = j;
+    }
+    s_d[tid] = nd;
+    s_j[tid] = nj;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) {
+            const float d2 = s_d[tid + s];
+            const uint32_t j2 = s_j[tid + s];
+            // "dtNewDist < dtNewMinDist" starting from BIG_DIST: values >= BIG never win
+            if (d2 < s_d[tid] || (d2 == s_d[tid] && j2 < s_j[tid])) { s_d[tid] = d2; s_j[tid] = j2; }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const bool ok = s_d[0] < UPGMA_BIG;
+        a.part_d[blockIdx.x] = ok ? s_d[0] : UPGMA_BIG;
+        a.part_j[blockIdx.x] = ok ? s_j[0] : UPGMA_NONE;
+    }
+}
+
+hipError_t launch_upgma(const UpgmaArgs& a, const void* lcs, int elem_size, const uint32_t* lens,
+                        const float* pow_f32, int kind, bool modified, hipStream_t stream)
+{
+    const int n = a.n;
+    if (elem_size == 2)
+        hipLaunchKernelGGL(upgma_dist_kernel<uint16_t>, dim3(n - 1), dim3(256), 0, stream, (const uint16_t*)lcs, lens,
+                           pow_f32, kind, n, a.D);
+    else
+        hipLaunchKernelGGL(upgma_dist_kernel<uint32_t>, dim3(n - 1), dim3(256), 0, stream, (const uint32_t*)lcs, lens,
+                           pow_f32, kind, n, a.D);
+    hipLaunchKernelGGL(upgma_init_kernel, dim3(n), dim3(256), 0, stream, a);
+    for (int it = 0; it < n; ++it) {
+        hipLaunchKernelGGL(upgma_select_kernel, dim3(1), dim3(1024), 0, stream, a, it);
+        if (it < n - 1) {
+            if (modified)
+                hipLaunchKernelGGL(upgma_update_kernel<true>, dim3(a.n_blocks), dim3(256), 0, stream, a);
+            else
+                hipLaunchKernelGGL(upgma_update_kernel<false>, dim3(a.n_blocks), dim3(256), 0, stream, a);
+        }
+    }
+    return hipGetLastError();
+}
+
+} // namespace lcsgpu

@@ -47,6 +47,9 @@ public:
     // source cannot (then the caller runs Prim on the host over triangle()/rect()).
     struct MstEdge { int32_t from, to; double dist; };
     virtual bool prim_edges(int /*distance_kind*/, std::vector<MstEdge>& /*edges*/) { return false; }
+    // UPGMA computed by the source itself (device): children of internal nodes n..2n-2.
+    virtual bool upgma_nodes(int /*distance_kind*/, bool /*modified*/, std::vector<int32_t>& /*left*/,
+                             std::vector<int32_t>& /*right*/) { return false; }
 };
 
 // The MI355X engine.  Throws std::runtime_error if the library reports an error (no fallback).
@@ -61,6 +64,7 @@ public:
     void triangle(int r0, int r1, LcsBuf& out) override;
     void rect(const int* refs, int n_refs, const int* cols, int n_cols, LcsBuf& out) override;
     bool prim_edges(int distance_kind, std::vector<MstEdge>& edges) override;
+    bool upgma_nodes(int distance_kind, bool modified, std::vector<int32_t>& left, std::vector<int32_t>& right) override;
     double kernel_ms_total() const { return kernel_ms_; }
     void add_kernel_ms();
 

@@ -368,6 +368,11 @@ void build_partial_d(LcsSource& src, GT method, tree_structure& tree)
     case GT::SLINK: slink<D>(src, tree); break;
     case GT::UPGMA:
     case GT::UPGMA_modified: {
+        std::vector<int32_t> left, right;
+        if (src.upgma_nodes((int)D, method == GT::UPGMA_modified, left, right)) { // merges ran on the device
+            for (int i = 0; i < n - 1; ++i) tree.emplace_back(left[i], right[i]);
+            break;
+        }
         std::vector<float> dist;
         float_triangle<D>(src, dist);
         if (method == GT::UPGMA) upgma_tree<false>(dist, n, tree); else upgma_tree<true>(dist, n, tree);

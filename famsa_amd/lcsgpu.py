@@ -52,6 +52,7 @@ def load_library():
         "lcsgpu_lcs_triangle_dev": (C.c_int, [vp, i32, i32, vp, C.c_int, C.c_int]),
         "lcsgpu_row_minima_dev": (C.c_int, [vp, vp, C.c_int, i32, i32, C.c_int, vp, C.c_int]),
         "lcsgpu_mst_prim": (C.c_int, [vp, C.c_int, vp]),
+        "lcsgpu_upgma": (C.c_int, [vp, C.c_int, C.c_int, vp, vp]),
         "lcsgpu_sync": (C.c_int, [vp]),
         "lcsgpu_last_kernel_ms": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(i32)]),
         "lcsgpu_stream": (vp, [vp]),
@@ -169,6 +170,13 @@ class LcsGpu:
         out = np.zeros(max(self.n - 1, 0), dtype=dt)
         self._check(self._lib.lcsgpu_mst_prim(self._ctx, kind, out.ctypes.data if out.size else None))
         return out
+
+    def upgma(self, kind=1, modified=False):
+        """Children (left, right) of internal nodes n..2n-2 of the UPGMA tree."""
+        left = np.zeros(max(self.n - 1, 1), dtype=np.int32)
+        right = np.zeros(max(self.n - 1, 1), dtype=np.int32)
+        self._check(self._lib.lcsgpu_upgma(self._ctx, kind, int(modified), left.ctypes.data, right.ctypes.data))
+        return left[: max(self.n - 1, 0)], right[: max(self.n - 1, 0)]
 
     def sync(self):
         self._check(self._lib.lcsgpu_sync(self._ctx))

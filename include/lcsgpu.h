@@ -157,6 +157,17 @@ typedef struct lcsgpu_mst_edge {
  * and the candidate selection of MSTPrim::run_view. */
 int lcsgpu_mst_prim(lcsgpu_ctx* ctx, int distance_kind, lcsgpu_mst_edge* out_edges);
 
+/* UPGMA (or MAFFT-style "modified" UPGMA) over the uploaded set, entirely on the device: LCS
+ * triangle -> float distances (Transform<float, kind>: host-built (float)pow(indel,0.75) table,
+ * IEEE float division) -> n-1 merges with the nearest-neighbour-array algorithm of the reference,
+ * operation for operation (strict '<' scans, stale row minima, (x+y)*0.5f resp.
+ * 0.05f*(x+y)+0.9f*min(x,y) without contraction), so the result equals UPGMA::computeTree's.
+ * out_left/out_right (HOST, n-1 entries each): children of internal node n+k, k = 0..n-2, ids as in
+ * tree_structure (leaves 0..n-1).  Returns LCSGPU_E_INVALID for inputs on which the reference's
+ * algorithm is undefined (no finite nearest neighbour, e.g. a sequence with LCS 0 to all others).
+ * Replaces: UPGMA::computeDistances + UPGMA::computeTree (tree/UPGMA.cpp:75-109, 114-295). */
+int lcsgpu_upgma(lcsgpu_ctx* ctx, int distance_kind, int modified, int32_t* out_left, int32_t* out_right);
+
 /* Block until everything queued on the context's stream has finished. */
 int lcsgpu_sync(lcsgpu_ctx* ctx);
 

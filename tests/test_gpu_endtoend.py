@@ -120,3 +120,28 @@ def test_cli_medoidtree_duplicates(tmp_path):
     assert open(out, "rb").read() == open(os.path.join(G, "hemopexin_duplicates", "medoid-sl.dnd"), "rb").read()
     run_cli("-keep-duplicates", "-medoidtree", "-gt", "sl", "-gt_export", f, out)
     assert open(out, "rb").read() == open(os.path.join(G, "hemopexin_duplicates", "medoid-sl-dups.dnd"), "rb").read()
+
+
+@pytest.mark.parametrize("gt", ["upgma", "upgma_modified"])
+def test_device_upgma_on_tie_heavy_inputs(host, tmp_path, gt):
+    """Device UPGMA vs the host restatement (itself pinned against the reference on tie-heavy random inputs):
+    small alphabets give many equal float distances, so every '<' / first-minimum rule is exercised."""
+    import numpy as np
+    import oracle_bind as ob
+    oracle = ob.Oracle()
+    for seed, (n, max_len, alpha) in enumerate([(2, 5, "AC"), (3, 8, "AC"), (40, 12, "AC"), (257, 20, "ACD"),
+                                                (700, 60, "ACDE"), (1500, 150, "ARNDCQEGHILKMFPSTWYV")]):
+        rng = np.random.Generator(np.random.PCG64(500 + seed))
+        seqs = ["".join(alpha[i] for i in rng.integers(0, len(alpha), size=int(rng.integers(1, max_len + 1)))) + "A"
+                for _ in range(n)]
+        fasta = str(tmp_path / f"in{seed}.fasta")
+        with open(fasta, "w") as f:
+            for i, s in enumerate(seqs):
+                f.write(f">r{i}\n{s}\n")
+        enc = [oracle.encode(s) for s in seqs]
+        codes, offsets = seqio.pack(enc)
+        sq = oracle.rect(codes, offsets, np.arange(n), np.arange(n))
+        for dist in ("indel075_div_lcs", "indel_div_lcs"):
+            want = host.tree_from_matrix(fasta, sq, gt, distance=dist)   # host algorithm over oracle LCS
+            got = host.tree_gpu(fasta, gt, distance=dist)                # LCS + UPGMA on the device
+            assert got == want, (seed, dist)
