@@ -42,19 +42,24 @@ def cpu_baseline(n, length, target_s=12.0):
     if not oracle_bind.have_ref():
         return None
     ref = oracle_bind.Ref()
-    threads = len(os.sched_getaffinity(0))
-    n_probe = min(n, 3000)
+    avail = len(os.sched_getaffinity(0))
+    n_probe = min(n, 4000)
     codes, offsets = seqio.synth_uniform(n, length)
     # the sample is a prefix of the same set (fixed length => already in the reference's order up to ties)
     n_load = min(n, 60000)
     path = f"/tmp/bench_synth_{n}_{length}_{n_load}.fasta"
     seqio.to_fasta(codes[: int(offsets[n_load])], offsets[: n_load + 1], path)
     h = ref.open_fasta(path)
-    sec, pairs, cells, _ = ref.time_triangle(h, n_probe, threads)
-    rate = pairs / max(sec, 1e-6)
+    # the reference's row queue does not scale to every hardware thread of a big host: probe a few
+    # thread counts on a short sample and time the long sample with the best one
+    best = None
+    for threads in sorted({t for t in (16, 32, 64, 128, avail) if t <= avail}):
+        sec, pairs, cells, _ = ref.time_triangle(h, n_probe, threads)
+        if best is None or pairs / sec > best[0]:
+            best = (pairs / sec, threads)
+    rate, threads = best
     n_use = int(min(n_load, max(n_probe, math.sqrt(2 * rate * target_s))))
-    if n_use > n_probe:
-        sec, pairs, cells, _ = ref.time_triangle(h, n_use, threads)
+    sec, pairs, cells, _ = ref.time_triangle(h, n_use, threads)
     ref.close(h)
     os.unlink(path)
     return {
@@ -64,8 +69,9 @@ def cpu_baseline(n, length, target_s=12.0):
         "kind": "reference",
         "pairs_per_s": pairs / sec,
         "seconds": sec,
-        "sample": f"reference UPGMA::computeDistances (AVX2 dispatch, {threads} threads) on the first "
-                  f"{n_use} of the {n} synthetic sequences = {int(pairs)} pairs",
+        "host_threads_available": avail,
+        "sample": f"reference UPGMA::computeDistances (AVX2 dispatch, {threads} threads = the fastest of a "
+                  f"16/32/64/128/{avail} probe) on the first {n_use} of the {n} synthetic sequences = {int(pairs)} pairs",
     }
 
 
