@@ -15,7 +15,7 @@ struct RowsArgs {
     const uint32_t* lens;      // length per sequence
     // refs (bit-mask side): ids ref_ids[k] or ref_begin + k, k < n_refs
     const int32_t* ref_ids;
-    const int64_t* ref_rows; // RECT: output row of ref k (else row0 + k)
+    const int64_t* ref_rows; // output row of ref k (else row0 + k)
     int32_t ref_begin;
     int32_t n_refs;
     // partners (streamed side): ids col_ids[c] or col_begin + c, c < n_cols
@@ -25,8 +25,8 @@ struct RowsArgs {
     // output
     void* out;
     int64_t ld;         // RECT: out[row*ld + c]
-    int64_t row0;       // RECT: first output row for contiguous refs
-    int64_t out_offset; // TRIANGLE: out[rid*(rid-1)/2 + c - out_offset]
+    int64_t row0;       // first output row for contiguous refs
+    int64_t out_offset; // TRIANGLE: out[row*(row-1)/2 + c - out_offset] for c < row (row as in RECT)
     int32_t elem_size;  // 2 or 4
     int32_t mode;
     int32_t refs_per_block;

@@ -161,14 +161,13 @@ __device__ __forceinline__ void build_mask_words(const RowsArgs& a, int rid, int
 
 __device__ __forceinline__ void store_result(const RowsArgs& a, int k, int c, uint32_t res)
 {
+    const int64_t row = a.ref_rows ? a.ref_rows[k] : (int64_t)k + a.row0;
     int64_t idx;
-    if (a.mode == MODE_TRIANGLE) {
-        const int64_t rid = a.ref_ids ? a.ref_ids[k] : a.ref_begin + k;
-        if (c >= rid)
+    if (a.mode == MODE_TRIANGLE) { // rows/columns are POSITIONS in the caller's lists; only column < row
+        if (c >= row)
             return;
-        idx = rid * (rid - 1) / 2 + c - a.out_offset;
+        idx = row * (row - 1) / 2 + c - a.out_offset;
     } else {
-        const int64_t row = a.ref_rows ? a.ref_rows[k] : (int64_t)k + a.row0;
         idx = row * a.ld + c;
     }
     if (a.elem_size == 2)
@@ -198,17 +197,17 @@ __device__ __forceinline__ void block_coords(const RowsArgs& a, int& x, int& y)
     x = bid - a.tri_prefix[lo];
 }
 
-// Triangle mode: a block whose columns all lie at or beyond its largest ref id has no work.
+// Triangle mode: a block whose columns all lie at or beyond its largest row has no work.
 __device__ __forceinline__ bool block_is_above_diagonal(const RowsArgs& a, int ref0, int nr, int c0)
 {
     if (a.mode != MODE_TRIANGLE)
         return false;
-    int max_rid = 0;
+    int64_t max_row = 0;
     for (int r = 0; r < nr; ++r) {
-        const int rid = a.ref_ids ? a.ref_ids[ref0 + r] : a.ref_begin + ref0 + r;
-        max_rid = rid > max_rid ? rid : max_rid;
+        const int64_t row = a.ref_rows ? a.ref_rows[ref0 + r] : (int64_t)(ref0 + r) + a.row0;
+        max_row = row > max_row ? row : max_row;
     }
-    return c0 >= max_rid;
+    return c0 >= max_row;
 }
 
 template <int H, int RG, bool QUIRK>

@@ -170,7 +170,7 @@ bool contiguous(const Bucket& b)
 // Core: plan + launch.  d_out is a device pointer.
 int run_rows(lcsgpu_ctx* ctx, int mode, const int32_t* ref_ids, int32_t ref_begin, int32_t n_refs,
              const int32_t* col_ids, int32_t col_begin, int32_t n_cols, void* d_out, int64_t ld,
-             int64_t out_offset, int elem_size)
+             int64_t out_offset, int elem_size, int64_t first_row = 0)
 {
     if (ctx->n < 0) return fail(LCSGPU_E_STATE, "no sequence set uploaded");
     if (elem_size != 2 && elem_size != 4) return fail(LCSGPU_E_INVALID, "elem_size must be 2 or 4");
@@ -188,7 +188,7 @@ int run_rows(lcsgpu_ctx* ctx, int mode, const int32_t* ref_ids, int32_t ref_begi
                 return fail(LCSGPU_E_INVALID, "col id %d out of range", col_ids[c]);
 
     std::vector<Bucket> buckets;
-    int rc = make_buckets(ctx, ref_ids, ref_begin, n_refs, 0, buckets);
+    int rc = make_buckets(ctx, ref_ids, ref_begin, n_refs, first_row, buckets);
     if (rc) return rc;
 
     // staging: [col_ids][per non-contiguous bucket: rows(int64) then ids(int32)]
@@ -212,8 +212,8 @@ int run_rows(lcsgpu_ctx* ctx, int mode, const int32_t* ref_ids, int32_t ref_begi
             int64_t acc = 0;
             for (int k = 0; k < gy; ++k) {
                 const int y = gy - 1 - k;
-                const int64_t max_rid = (int64_t)bk.items[0].id + std::min(nrefs, (y + 1) * R) - 1;
-                const int64_t cols = std::min<int64_t>(n_cols, max_rid);
+                const int64_t max_row = bk.items[0].row + std::min(nrefs, (y + 1) * R) - 1;
+                const int64_t cols = std::min<int64_t>(n_cols, max_row);
                 pre[k] = (int32_t)acc;
                 acc += cols > 0 ? (cols + 255) / 256 : 0;
             }
@@ -279,10 +279,10 @@ int run_rows(lcsgpu_ctx* ctx, int mode, const int32_t* ref_ids, int32_t ref_begi
         a.mode = mode;
         a.refs_per_block = lcsgpu::refs_per_block(bk.bv, bk.quirk);
         int32_t use_cols = n_cols;
-        if (mode == lcsgpu::MODE_TRIANGLE) { // columns at or beyond the largest ref id are never wanted
-            int32_t max_rid = 0;
-            for (const RefItem& it : bk.items) max_rid = std::max(max_rid, it.id);
-            use_cols = std::min(n_cols, max_rid);
+        if (mode == lcsgpu::MODE_TRIANGLE) { // columns at or beyond the largest row are never wanted
+            int64_t max_row = 0;
+            for (const RefItem& it : bk.items) max_row = std::max(max_row, it.row);
+            use_cols = (int32_t)std::min<int64_t>(n_cols, max_row);
             if (use_cols <= 0) continue;
         }
         const int gx = (use_cols + 255) / 256;
@@ -557,7 +557,7 @@ static int triangle_common(lcsgpu_ctx* ctx, int32_t row_begin, int32_t row_end, 
 {
     const int64_t off = (int64_t)row_begin * (row_begin - 1) / 2;
     return run_rows(ctx, lcsgpu::MODE_TRIANGLE, nullptr, row_begin, row_end - row_begin, nullptr, 0,
-                    std::max(0, row_end - 1), d_out, 0, off, elem_size);
+                    std::max(0, row_end - 1), d_out, 0, off, elem_size, row_begin);
 }
 
 int lcsgpu_lcs_triangle_dev(lcsgpu_ctx* ctx, int32_t row_begin, int32_t row_end, void* d_out, int elem_size,
@@ -731,6 +731,27 @@ int lcsgpu_upgma(lcsgpu_ctx* ctx, int distance_kind, int modified, int32_t* out_
     if (sel[2])
         return fail(LCSGPU_E_INVALID, "UPGMA: no finite nearest neighbour (a pair with LCS 0?) -- the reference's "
                                       "algorithm is undefined for this input");
+    return LCSGPU_OK;
+}
+
+int lcsgpu_lcs_triangle_ids(lcsgpu_ctx* ctx, const int32_t* ids, int32_t n_ids, void* out, int elem_size)
+{
+    if (!ctx) return fail(LCSGPU_E_INVALID, "NULL ctx");
+    if (ctx->n < 0) return fail(LCSGPU_E_STATE, "no sequence set uploaded");
+    if (n_ids < 0 || (n_ids > 0 && !ids)) return fail(LCSGPU_E_INVALID, "bad id list");
+    if (elem_size != 2 && elem_size != 4) return fail(LCSGPU_E_INVALID, "elem_size must be 2 or 4");
+    const int64_t count = (int64_t)n_ids * (n_ids - 1) / 2;
+    if (count <= 0) return LCSGPU_OK;
+    if (!out) return fail(LCSGPU_E_INVALID, "NULL out");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(ctx->d_out.reserve((size_t)count * elem_size));
+    // row k = ids[k] as the ref, column c = ids[c] as the partner, c < k
+    int rc = run_rows(ctx, lcsgpu::MODE_TRIANGLE, ids, 0, n_ids, ids, 0, n_ids - 1, ctx->d_out.p, 0, 0, elem_size, 0);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(out, ctx->d_out.p, (size_t)count * elem_size, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->plan_in_flight = false;
     return LCSGPU_OK;
 }
 

@@ -204,6 +204,10 @@ public:
         const size_t off = (size_t)r0 * (r0 > 0 ? r0 - 1 : 0) / 2;
         out.resize((size_t)r1 * (r1 - 1) / 2 - off, p_.wide());
         if (r1 <= 1 || r1 <= r0) return;
+        if (r0 == 0) { // the whole subset: the engine's triangle over an id list
+            p_.triangle_ids(ids_.data(), r1, out);
+            return;
+        }
         LcsBuf rect;
         const int cols = r1 - 1;
         p_.rect(ids_.data() + r0, r1 - r0, ids_.data(), cols, rect); // ref = row, partner = column

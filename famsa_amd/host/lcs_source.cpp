@@ -14,6 +14,20 @@ bool LcsSource::wide() const
     return m > 65535;
 }
 
+void LcsSource::triangle_ids(const int* ids, int n_ids, LcsBuf& out)
+{ // generic form: a rectangle, lower part kept
+    out.resize(n_ids > 1 ? (size_t)n_ids * (n_ids - 1) / 2 : 0, wide());
+    if (n_ids < 2) return;
+    LcsBuf r;
+    rect(ids, n_ids, ids, n_ids - 1, r);
+    for (int i = 1; i < n_ids; ++i)
+        for (int j = 0; j < i; ++j) {
+            const uint32_t v = r[(size_t)i * (n_ids - 1) + j];
+            const size_t k = (size_t)i * (i - 1) / 2 + j;
+            if (out.wide) out.v32[k] = v; else out.v16[k] = (uint16_t)v;
+        }
+}
+
 GpuLcsSource::GpuLcsSource(int device)
 {
     check(lcsgpu_create(device, &ctx_), "lcsgpu_create");
@@ -63,6 +77,14 @@ void GpuLcsSource::rect(const int* refs, int n_refs, const int* cols, int n_cols
     out.resize((size_t)n_refs * n_cols, wide());
     check(lcsgpu_lcs_rect(ctx_, refs, 0, n_refs, cols, 0, n_cols, out.data(), n_cols, out.elem_size()),
           "lcsgpu_lcs_rect");
+    add_kernel_ms();
+}
+
+void GpuLcsSource::triangle_ids(const int* ids, int n_ids, LcsBuf& out)
+{
+    out.resize(n_ids > 1 ? (size_t)n_ids * (n_ids - 1) / 2 : 0, wide());
+    if (n_ids < 2) return;
+    check(lcsgpu_lcs_triangle_ids(ctx_, ids, n_ids, out.data(), out.elem_size()), "lcsgpu_lcs_triangle_ids");
     add_kernel_ms();
 }
 

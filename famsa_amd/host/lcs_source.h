@@ -41,6 +41,8 @@ public:
     virtual void triangle(int r0, int r1, LcsBuf& out) = 0;
     // out[r*n_cols + c] = LCS(ref = refs[r], partner = cols ? cols[c] : c)
     virtual void rect(const int* refs, int n_refs, const int* cols, int n_cols, LcsBuf& out) = 0;
+    // lower triangle over an id list: out[k*(k-1)/2 + c] = LCS(ref = ids[k], partner = ids[c]), c < k
+    virtual void triangle_ids(const int* ids, int n_ids, LcsBuf& out);
     bool wide() const;
     // Prim's MST computed by the source itself (the GPU engine does it on the device): n-1 edges
     // (from < to, distance) in the order they are added from vertex 0.  Returns false if the
@@ -63,6 +65,7 @@ public:
     bool orientation_sensitive() const override { return sensitive_; }
     void triangle(int r0, int r1, LcsBuf& out) override;
     void rect(const int* refs, int n_refs, const int* cols, int n_cols, LcsBuf& out) override;
+    void triangle_ids(const int* ids, int n_ids, LcsBuf& out) override;
     bool prim_edges(int distance_kind, std::vector<MstEdge>& edges) override;
     bool upgma_nodes(int distance_kind, bool modified, std::vector<int32_t>& left, std::vector<int32_t>& right) override;
     double kernel_ms_total() const { return kernel_ms_; }

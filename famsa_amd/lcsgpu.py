@@ -50,6 +50,7 @@ def load_library():
         "lcsgpu_lcs_rect_dev": (C.c_int, [vp, pi32, i32, i32, pi32, i32, i32, vp, i64, C.c_int, C.c_int]),
         "lcsgpu_lcs_triangle": (C.c_int, [vp, i32, i32, vp, C.c_int]),
         "lcsgpu_lcs_triangle_dev": (C.c_int, [vp, i32, i32, vp, C.c_int, C.c_int]),
+        "lcsgpu_lcs_triangle_ids": (C.c_int, [vp, pi32, i32, vp, C.c_int]),
         "lcsgpu_row_minima_dev": (C.c_int, [vp, vp, C.c_int, i32, i32, C.c_int, vp, C.c_int]),
         "lcsgpu_mst_prim": (C.c_int, [vp, C.c_int, vp]),
         "lcsgpu_upgma": (C.c_int, [vp, C.c_int, C.c_int, vp, vp]),
@@ -154,6 +155,14 @@ class LcsGpu:
         out = np.empty(max(count, 0), dtype=dtype)
         self._check(self._lib.lcsgpu_lcs_triangle(self._ctx, row_begin, row_end,
                                                   out.ctypes.data if out.size else None, out.itemsize))
+        return out
+
+    def lcs_triangle_ids(self, ids, dtype=np.uint16):
+        arr, ptr = _ids(ids)
+        n = len(arr)
+        out = np.empty(max(n * (n - 1) // 2, 0), dtype=dtype)
+        self._check(self._lib.lcsgpu_lcs_triangle_ids(self._ctx, ptr, n, out.ctypes.data if out.size else None,
+                                                      out.itemsize))
         return out
 
     def lcs_triangle_dev(self, row_begin, row_end, d_out_ptr, elem_size, sync=False):

@@ -113,6 +113,11 @@ int lcsgpu_lcs_triangle(lcsgpu_ctx* ctx, int32_t row_begin, int32_t row_end, voi
 int lcsgpu_lcs_triangle_dev(lcsgpu_ctx* ctx, int32_t row_begin, int32_t row_end, void* d_out,
                             int elem_size, int sync);
 
+/* Lower triangle over an ID LIST (host memory): out[k*(k-1)/2 + c] = LCS(ref = ids[k], partner = ids[c]),
+ * c < k < n_ids -- calculateDistanceMatrix (tree/AbstractTreeGenerator.hpp:378-398) on a subset of the
+ * uploaded sequences: the sample matrix of FastTree::clusterSeeds (tree/FastTree.cpp:415) and the
+ * per-cluster matrices of the partial generators (UPGMA::runPartial, tree/UPGMA.cpp:55-70). */
+int lcsgpu_lcs_triangle_ids(lcsgpu_ctx* ctx, const int32_t* ids, int32_t n_ids, void* out, int elem_size);
 
 /* Distance measures of the reference's Transform functors (tree/AbstractTreeGenerator.hpp:28-82,
  * enum Distance in tree/TreeDefs.h:20-27). */

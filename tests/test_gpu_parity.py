@@ -245,3 +245,23 @@ def test_row_minima_vs_oracle(engine, oracle):
             m = dd.min()
             want_j = int(np.max(np.nonzero(dd == m)[0]))
             assert d[i] == m and j[i] == want_j, (i, d[i], m, j[i], want_j)
+
+
+def test_triangle_over_id_lists(engine, oracle):
+    """calculateDistanceMatrix on a subset (FastTree sample matrix / per-cluster matrices)."""
+    rng = np.random.Generator(np.random.PCG64(17))
+    lens = [int(x) for x in rng.integers(1, 900, size=700)] + [2300, 2600, 64 * 3, 64 * 5]
+    seqs = [rng.integers(0, 21, size=l).astype(np.uint8) for l in lens]
+    seqs[-2][64:128] = 3   # orientation-sensitive members
+    seqs[-1][128:256] = 9
+    engine.upload_seqs(seqs)
+    codes, offsets = seqio.pack(seqs)
+    n = len(seqs)
+    for m in (1, 2, 5, 300, n):
+        ids = rng.permutation(n)[:m]
+        if m == n:
+            ids = np.array(seqio.sort_order(seqs))  # length-sorted, the usual case
+        got = engine.lcs_triangle_ids(ids, dtype=np.uint32)
+        sq = oracle.rect(codes, offsets, ids, ids)
+        want = sq[np.tril_indices(m, -1)]
+        assert (got == want).all(), m
