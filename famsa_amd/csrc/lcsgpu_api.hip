@@ -7,6 +7,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cmath>
+#include <condition_variable>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -85,26 +86,94 @@ struct PinBuf {
 
 } // namespace
 
-struct lcsgpu_ctx {
-    int device = 0;
+// A lane = one HIP stream with its own staging / result buffers.  Host-memory calls (rect,
+// triangle, triangle over ids) take any free lane, so several host threads -- the reference runs
+// one CLCSBP per worker thread -- get their small LCS requests executed concurrently instead of
+// queueing behind one stream; device-memory calls and the tree reducers always use lane 0, whose
+// stream is the one lcsgpu_stream() hands out.
+struct Lane {
     hipStream_t stream = nullptr;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
-    std::mutex mu;
+    DevBuf d_plan, d_out, d_carry;
+    PinBuf h_plan;
+    bool plan_in_flight = false;
+    int last_launches = 0;
+    bool timing_valid = false;
+    bool busy = false;
+};
 
-    // uploaded set
+struct lcsgpu_ctx {
+    int device = 0;
+    std::mutex mu; // guards the lane table
+    std::condition_variable cv;
+    std::vector<Lane> lanes;
+
+    // uploaded set (read-only while any lane is busy)
     int32_t n = -1;
     uint32_t max_len = 0;
     std::vector<uint32_t> lens;
     std::vector<uint8_t> quirk; // ref needs the literal (V2 < V) carry rule
     DevBuf d_tiles, d_tile_base, d_lens, d_pow, d_powf;
 
-    // per-call scratch
-    DevBuf d_plan, d_out, d_carry, d_prim, d_qrows, d_qcols, d_dist;
-    PinBuf h_plan;
-    bool plan_in_flight = false;
-    int last_launches = 0;
-    bool timing_valid = false;
+    // scratch of the lane-0 tree reducers
+    DevBuf d_prim, d_qrows, d_qcols, d_dist;
+    double total_kernel_ms = 0; // completed host-memory calls
 };
+
+namespace {
+
+thread_local struct { // timing of this thread's most recent call, for lcsgpu_last_kernel_ms
+    lcsgpu_ctx* ctx = nullptr;
+    bool pending_on_lane0 = false;
+    double ms = 0;
+    int launches = 0;
+} g_last;
+
+// RAII ownership of one lane (index 0 on request, else any free one) or of all lanes.
+class LaneGuard {
+public:
+    enum Which { ANY, LANE0, ALL };
+    LaneGuard(lcsgpu_ctx* ctx, Which which) : ctx_(ctx), which_(which)
+    {
+        std::unique_lock<std::mutex> lk(ctx->mu);
+        if (which == ALL) {
+            ctx->cv.wait(lk, [&] {
+                for (auto& l : ctx->lanes) if (l.busy) return false;
+                return true;
+            });
+            for (auto& l : ctx->lanes) l.busy = true;
+            idx_ = 0;
+        } else if (which == LANE0) {
+            ctx->cv.wait(lk, [&] { return !ctx->lanes[0].busy; });
+            ctx->lanes[0].busy = true;
+            idx_ = 0;
+        } else {
+            ctx->cv.wait(lk, [&] {
+                for (size_t i = ctx->lanes.size(); i-- > 0;) // prefer the higher lanes, keep lane 0 free
+                    if (!ctx->lanes[i].busy) { idx_ = (int)i; return true; }
+                return false;
+            });
+            ctx->lanes[idx_].busy = true;
+        }
+    }
+    ~LaneGuard()
+    {
+        {
+            std::lock_guard<std::mutex> lk(ctx_->mu);
+            if (which_ == ALL) for (auto& l : ctx_->lanes) l.busy = false;
+            else ctx_->lanes[idx_].busy = false;
+        }
+        ctx_->cv.notify_all();
+    }
+    Lane& lane() { return ctx_->lanes[idx_]; }
+
+private:
+    lcsgpu_ctx* ctx_;
+    Which which_;
+    int idx_ = 0;
+};
+
+} // namespace
 
 namespace {
 
@@ -168,7 +237,7 @@ bool contiguous(const Bucket& b)
 }
 
 // Core: plan + launch.  d_out is a device pointer.
-int run_rows(lcsgpu_ctx* ctx, int mode, const int32_t* ref_ids, int32_t ref_begin, int32_t n_refs,
+int run_rows(lcsgpu_ctx* ctx, Lane& L, int mode, const int32_t* ref_ids, int32_t ref_begin, int32_t n_refs,
              const int32_t* col_ids, int32_t col_begin, int32_t n_cols, void* d_out, int64_t ld,
              int64_t out_offset, int elem_size, int64_t first_row = 0)
 {
@@ -177,8 +246,8 @@ int run_rows(lcsgpu_ctx* ctx, int mode, const int32_t* ref_ids, int32_t ref_begi
     if (elem_size == 2 && ctx->max_len > 65535)
         return fail(LCSGPU_E_INVALID, "uint16 output needs all sequences <= 65535 residues");
     if (n_refs < 0 || n_cols < 0) return fail(LCSGPU_E_INVALID, "negative count");
-    ctx->last_launches = 0;
-    ctx->timing_valid = false;
+    L.last_launches = 0;
+    L.timing_valid = false;
     if (n_refs == 0 || n_cols == 0) return LCSGPU_OK;
     if (!col_ids && (col_begin < 0 || (int64_t)col_begin + n_cols > ctx->n))
         return fail(LCSGPU_E_INVALID, "column range out of bounds");
@@ -230,13 +299,13 @@ int run_rows(lcsgpu_ctx* ctx, int mode, const int32_t* ref_ids, int32_t ref_begi
     }
     HIP_TRY(hipSetDevice(ctx->device));
     if (bytes) {
-        if (ctx->plan_in_flight) {
-            HIP_TRY(hipStreamSynchronize(ctx->stream));
-            ctx->plan_in_flight = false;
+        if (L.plan_in_flight) {
+            HIP_TRY(hipStreamSynchronize(L.stream));
+            L.plan_in_flight = false;
         }
-        HIP_TRY(ctx->h_plan.reserve(bytes));
-        HIP_TRY(ctx->d_plan.reserve(bytes));
-        char* h = (char*)ctx->h_plan.p;
+        HIP_TRY(L.h_plan.reserve(bytes));
+        HIP_TRY(L.d_plan.reserve(bytes));
+        char* h = (char*)L.h_plan.p;
         if (col_ids) memcpy(h + col_off, col_ids, (size_t)n_cols * 4);
         for (size_t b = 0; b < buckets.size(); ++b) {
             if (!tri_prefix[b].empty()) memcpy(h + pre_off[b], tri_prefix[b].data(), tri_prefix[b].size() * 4);
@@ -248,11 +317,11 @@ int run_rows(lcsgpu_ctx* ctx, int mode, const int32_t* ref_ids, int32_t ref_begi
                 hi[k] = buckets[b].items[k].id;
             }
         }
-        HIP_TRY(hipMemcpyAsync(ctx->d_plan.p, h, bytes, hipMemcpyHostToDevice, ctx->stream));
-        ctx->plan_in_flight = true;
+        HIP_TRY(hipMemcpyAsync(L.d_plan.p, h, bytes, hipMemcpyHostToDevice, L.stream));
+        L.plan_in_flight = true;
     }
 
-    HIP_TRY(hipEventRecord(ctx->ev_start, ctx->stream));
+    HIP_TRY(hipEventRecord(L.ev_start, L.stream));
     for (size_t b = 0; b < buckets.size(); ++b) {
         const Bucket& bk = buckets[b];
         RowsArgs a{};
@@ -266,10 +335,10 @@ int run_rows(lcsgpu_ctx* ctx, int mode, const int32_t* ref_ids, int32_t ref_begi
             a.ref_begin = bk.items[0].id;
             a.row0 = bk.items[0].row;
         } else {
-            a.ref_ids = (const int32_t*)((char*)ctx->d_plan.p + id_off[b]);
-            a.ref_rows = (const int64_t*)((char*)ctx->d_plan.p + row_off[b]);
+            a.ref_ids = (const int32_t*)((char*)L.d_plan.p + id_off[b]);
+            a.ref_rows = (const int64_t*)((char*)L.d_plan.p + row_off[b]);
         }
-        a.col_ids = col_ids ? (const int32_t*)((char*)ctx->d_plan.p + col_off) : nullptr;
+        a.col_ids = col_ids ? (const int32_t*)((char*)L.d_plan.p + col_off) : nullptr;
         a.col_begin = col_begin;
         a.n_cols = n_cols;
         a.out = d_out;
@@ -288,22 +357,22 @@ int run_rows(lcsgpu_ctx* ctx, int mode, const int32_t* ref_ids, int32_t ref_begi
         const int gx = (use_cols + 255) / 256;
         const int gy = (a.n_refs + a.refs_per_block - 1) / a.refs_per_block;
         if (bk.bv != 0 && !tri_prefix[b].empty()) {
-            a.tri_prefix = (const int32_t*)((char*)ctx->d_plan.p + pre_off[b]);
+            a.tri_prefix = (const int32_t*)((char*)L.d_plan.p + pre_off[b]);
             a.tri_rows = (int32_t)tri_prefix[b].size() - 1;
             const int total = tri_prefix[b].back();
             if (total > 0) {
-                HIP_TRY(lcsgpu::launch_rows(bk.bv, bk.quirk, a, total, 1, ctx->stream));
-                ++ctx->last_launches;
+                HIP_TRY(lcsgpu::launch_rows(bk.bv, bk.quirk, a, total, 1, L.stream));
+                ++L.last_launches;
             }
         } else if (bk.bv != 0) {
             if (gy > 65535) return fail(LCSGPU_E_INVALID, "too many ref tiles in one call (%d)", gy);
-            HIP_TRY(lcsgpu::launch_rows(bk.bv, bk.quirk, a, gx, gy, ctx->stream));
-            ++ctx->last_launches;
+            HIP_TRY(lcsgpu::launch_rows(bk.bv, bk.quirk, a, gx, gy, L.stream));
+            ++L.last_launches;
         } else {
             // long refs: slices of ref blocks so the carry scratch stays bounded
             const int n_chunks_max = (int)((ctx->max_len + 15) / 16);
             const int gy_step = std::max(1, 1024 / gx);
-            HIP_TRY(ctx->d_carry.reserve(lcsgpu::long_carry_bytes(gx, std::min(gy, gy_step), n_chunks_max)));
+            HIP_TRY(L.d_carry.reserve(lcsgpu::long_carry_bytes(gx, std::min(gy, gy_step), n_chunks_max)));
             for (int y0 = 0; y0 < gy; y0 += gy_step) {
                 RowsArgs s = a;
                 const int first = y0 * a.refs_per_block;
@@ -316,14 +385,34 @@ int run_rows(lcsgpu_ctx* ctx, int mode, const int32_t* ref_ids, int32_t ref_begi
                     s.ref_rows = a.ref_rows + first;
                 }
                 const int sgy = (s.n_refs + s.refs_per_block - 1) / s.refs_per_block;
-                HIP_TRY(lcsgpu::launch_long(bk.quirk, s, gx, sgy, ctx->d_carry.p, n_chunks_max, ctx->stream));
-                ++ctx->last_launches;
+                HIP_TRY(lcsgpu::launch_long(bk.quirk, s, gx, sgy, L.d_carry.p, n_chunks_max, L.stream));
+                ++L.last_launches;
             }
         }
     }
-    HIP_TRY(hipEventRecord(ctx->ev_stop, ctx->stream));
-    ctx->timing_valid = true;
+    HIP_TRY(hipEventRecord(L.ev_stop, L.stream));
+    L.timing_valid = true;
     return LCSGPU_OK;
+}
+
+// After a host-memory call has been synchronised: account its kernel time.
+void finish_host_call(lcsgpu_ctx* ctx, Lane& L)
+{
+    L.plan_in_flight = false;
+    float f = 0.f;
+    if (L.timing_valid && L.last_launches > 0 && hipEventElapsedTime(&f, L.ev_start, L.ev_stop) != hipSuccess) f = 0.f;
+    g_last.ctx = ctx;
+    g_last.pending_on_lane0 = false;
+    g_last.ms = f;
+    g_last.launches = L.last_launches;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    ctx->total_kernel_ms += f;
+}
+
+void note_async_call(lcsgpu_ctx* ctx)
+{
+    g_last.ctx = ctx;
+    g_last.pending_on_lane0 = true;
 }
 
 } // namespace
@@ -359,11 +448,15 @@ int lcsgpu_create(int device_id, lcsgpu_ctx** out_ctx)
     lcsgpu_ctx* ctx = new (std::nothrow) lcsgpu_ctx;
     if (!ctx) return fail(LCSGPU_E_NOMEM, "out of host memory");
     ctx->device = device_id;
-    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreate(&ctx->ev_start) != hipSuccess || hipEventCreate(&ctx->ev_stop) != hipSuccess) {
-        delete ctx;
-        return fail(LCSGPU_E_HIP, "stream/event creation failed");
-    }
+    int n_lanes = 8;
+    if (const char* e = getenv("LCSGPU_LANES")) n_lanes = std::max(1, std::min(64, atoi(e)));
+    ctx->lanes.resize(n_lanes);
+    for (Lane& l : ctx->lanes)
+        if (hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreate(&l.ev_start) != hipSuccess || hipEventCreate(&l.ev_stop) != hipSuccess) {
+            lcsgpu_destroy(ctx);
+            return fail(LCSGPU_E_HIP, "stream/event creation failed");
+        }
     *out_ctx = ctx;
     return LCSGPU_OK;
 }
@@ -372,23 +465,25 @@ int lcsgpu_destroy(lcsgpu_ctx* ctx)
 {
     if (!ctx) return LCSGPU_OK;
     (void)hipSetDevice(ctx->device);
-    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (Lane& l : ctx->lanes) {
+        if (l.stream) (void)hipStreamSynchronize(l.stream);
+        l.d_plan.release();
+        l.d_out.release();
+        l.d_carry.release();
+        l.h_plan.release();
+        if (l.ev_start) (void)hipEventDestroy(l.ev_start);
+        if (l.ev_stop) (void)hipEventDestroy(l.ev_stop);
+        if (l.stream) (void)hipStreamDestroy(l.stream);
+    }
     ctx->d_tiles.release();
     ctx->d_tile_base.release();
     ctx->d_lens.release();
     ctx->d_pow.release();
     ctx->d_powf.release();
-    ctx->d_plan.release();
-    ctx->d_out.release();
-    ctx->d_carry.release();
     ctx->d_prim.release();
-    ctx->d_dist.release();
     ctx->d_qrows.release();
     ctx->d_qcols.release();
-    ctx->h_plan.release();
-    if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
-    if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
-    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    ctx->d_dist.release();
     delete ctx;
     return LCSGPU_OK;
 }
@@ -422,9 +517,9 @@ int lcsgpu_upload(lcsgpu_ctx* ctx, const uint8_t* codes, const uint64_t* offsets
 {
     if (!ctx || !offsets || n < 0 || (!codes && n > 0 && offsets[n] > 0))
         return fail(LCSGPU_E_INVALID, "bad argument");
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    LaneGuard guard(ctx, LaneGuard::ALL); // nothing may run while the set is replaced
     HIP_TRY(hipSetDevice(ctx->device));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    for (Lane& l : ctx->lanes) HIP_TRY(hipStreamSynchronize(l.stream));
     ctx->n = -1;
     std::vector<uint32_t> lens(n);
     std::vector<uint8_t> quirk(n);
@@ -524,11 +619,13 @@ int lcsgpu_lcs_rect_dev(lcsgpu_ctx* ctx, const int32_t* ref_ids, int32_t ref_beg
 {
     if (!ctx || (!d_out && n_refs > 0 && n_cols > 0)) return fail(LCSGPU_E_INVALID, "NULL argument");
     if (ld < n_cols) return fail(LCSGPU_E_INVALID, "ld < n_cols");
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    int rc = run_rows(ctx, lcsgpu::MODE_RECT, ref_ids, ref_begin, n_refs, col_ids, col_begin, n_cols, d_out, ld, 0,
+    LaneGuard guard(ctx, LaneGuard::LANE0);
+    Lane& L = guard.lane();
+    int rc = run_rows(ctx, L, lcsgpu::MODE_RECT, ref_ids, ref_begin, n_refs, col_ids, col_begin, n_cols, d_out, ld, 0,
                       elem_size);
     if (rc) return rc;
-    if (sync) HIP_TRY(hipStreamSynchronize(ctx->stream));
+    note_async_call(ctx);
+    if (sync) HIP_TRY(hipStreamSynchronize(L.stream));
     return LCSGPU_OK;
 }
 
@@ -539,24 +636,26 @@ int lcsgpu_lcs_rect(lcsgpu_ctx* ctx, const int32_t* ref_ids, int32_t ref_begin, 
     if (!ctx || (!out && n_refs > 0 && n_cols > 0)) return fail(LCSGPU_E_INVALID, "NULL argument");
     if (ld < n_cols) return fail(LCSGPU_E_INVALID, "ld < n_cols");
     if (n_refs <= 0 || n_cols <= 0) return (n_refs < 0 || n_cols < 0) ? fail(LCSGPU_E_INVALID, "negative count") : LCSGPU_OK;
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (elem_size != 2 && elem_size != 4) return fail(LCSGPU_E_INVALID, "elem_size must be 2 or 4");
+    LaneGuard guard(ctx, LaneGuard::ANY);
+    Lane& L = guard.lane();
     HIP_TRY(hipSetDevice(ctx->device));
     const size_t bytes = (size_t)n_refs * n_cols * elem_size;
-    HIP_TRY(ctx->d_out.reserve(bytes));
-    int rc = run_rows(ctx, lcsgpu::MODE_RECT, ref_ids, ref_begin, n_refs, col_ids, col_begin, n_cols, ctx->d_out.p,
+    HIP_TRY(L.d_out.reserve(bytes));
+    int rc = run_rows(ctx, L, lcsgpu::MODE_RECT, ref_ids, ref_begin, n_refs, col_ids, col_begin, n_cols, L.d_out.p,
                       n_cols, 0, elem_size);
     if (rc) return rc;
-    HIP_TRY(hipMemcpy2DAsync(out, (size_t)ld * elem_size, ctx->d_out.p, (size_t)n_cols * elem_size,
-                             (size_t)n_cols * elem_size, n_refs, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    ctx->plan_in_flight = false;
+    HIP_TRY(hipMemcpy2DAsync(out, (size_t)ld * elem_size, L.d_out.p, (size_t)n_cols * elem_size,
+                             (size_t)n_cols * elem_size, n_refs, hipMemcpyDeviceToHost, L.stream));
+    HIP_TRY(hipStreamSynchronize(L.stream));
+    finish_host_call(ctx, L);
     return LCSGPU_OK;
 }
 
-static int triangle_common(lcsgpu_ctx* ctx, int32_t row_begin, int32_t row_end, void* d_out, int elem_size)
+static int triangle_common(lcsgpu_ctx* ctx, Lane& L, int32_t row_begin, int32_t row_end, void* d_out, int elem_size)
 {
     const int64_t off = (int64_t)row_begin * (row_begin - 1) / 2;
-    return run_rows(ctx, lcsgpu::MODE_TRIANGLE, nullptr, row_begin, row_end - row_begin, nullptr, 0,
+    return run_rows(ctx, L, lcsgpu::MODE_TRIANGLE, nullptr, row_begin, row_end - row_begin, nullptr, 0,
                     std::max(0, row_end - 1), d_out, 0, off, elem_size, row_begin);
 }
 
@@ -566,10 +665,12 @@ int lcsgpu_lcs_triangle_dev(lcsgpu_ctx* ctx, int32_t row_begin, int32_t row_end,
     if (!ctx) return fail(LCSGPU_E_INVALID, "NULL ctx");
     if (ctx->n < 0) return fail(LCSGPU_E_STATE, "no sequence set uploaded");
     if (row_begin < 0 || row_end < row_begin || row_end > ctx->n) return fail(LCSGPU_E_INVALID, "bad row range");
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    int rc = triangle_common(ctx, row_begin, row_end, d_out, elem_size);
+    LaneGuard guard(ctx, LaneGuard::LANE0);
+    Lane& L = guard.lane();
+    int rc = triangle_common(ctx, L, row_begin, row_end, d_out, elem_size);
     if (rc) return rc;
-    if (sync) HIP_TRY(hipStreamSynchronize(ctx->stream));
+    note_async_call(ctx);
+    if (sync) HIP_TRY(hipStreamSynchronize(L.stream));
     return LCSGPU_OK;
 }
 
@@ -582,14 +683,15 @@ int lcsgpu_lcs_triangle(lcsgpu_ctx* ctx, int32_t row_begin, int32_t row_end, voi
     const int64_t count = (int64_t)row_end * (row_end - 1) / 2 - (int64_t)row_begin * (row_begin - 1) / 2;
     if (count <= 0) return LCSGPU_OK;
     if (!out) return fail(LCSGPU_E_INVALID, "NULL out");
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    LaneGuard guard(ctx, LaneGuard::ANY);
+    Lane& L = guard.lane();
     HIP_TRY(hipSetDevice(ctx->device));
-    HIP_TRY(ctx->d_out.reserve((size_t)count * elem_size));
-    int rc = triangle_common(ctx, row_begin, row_end, ctx->d_out.p, elem_size);
+    HIP_TRY(L.d_out.reserve((size_t)count * elem_size));
+    int rc = triangle_common(ctx, L, row_begin, row_end, L.d_out.p, elem_size);
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(out, ctx->d_out.p, (size_t)count * elem_size, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    ctx->plan_in_flight = false;
+    HIP_TRY(hipMemcpyAsync(out, L.d_out.p, (size_t)count * elem_size, hipMemcpyDeviceToHost, L.stream));
+    HIP_TRY(hipStreamSynchronize(L.stream));
+    finish_host_call(ctx, L);
     return LCSGPU_OK;
 }
 
@@ -604,12 +706,12 @@ int lcsgpu_row_minima_dev(lcsgpu_ctx* ctx, const void* d_triangle, int elem_size
         return fail(LCSGPU_E_INVALID, "unknown distance kind %d", distance_kind);
     if (row_end == row_begin) return LCSGPU_OK;
     if (!d_triangle || !d_out) return fail(LCSGPU_E_INVALID, "NULL device pointer");
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    LaneGuard guard(ctx, LaneGuard::LANE0);
+    Lane& L = guard.lane();
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(lcsgpu::launch_row_minima(d_triangle, elem_size, row_begin, row_end, (const uint32_t*)ctx->d_lens.p,
-                                      (const double*)ctx->d_pow.p, distance_kind, (lcsgpu::RowMin*)d_out,
-                                      ctx->stream));
-    if (sync) HIP_TRY(hipStreamSynchronize(ctx->stream));
+                                      (const double*)ctx->d_pow.p, distance_kind, (lcsgpu::RowMin*)d_out, L.stream));
+    if (sync) HIP_TRY(hipStreamSynchronize(L.stream));
     return LCSGPU_OK;
 }
 
@@ -622,12 +724,13 @@ int lcsgpu_mst_prim(lcsgpu_ctx* ctx, int distance_kind, lcsgpu_mst_edge* out_edg
     const int32_t n = ctx->n;
     if (n < 2) return LCSGPU_OK;
     if (!out_edges) return fail(LCSGPU_E_INVALID, "NULL out_edges");
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    LaneGuard guard(ctx, LaneGuard::LANE0);
+    Lane& L = guard.lane();
     HIP_TRY(hipSetDevice(ctx->device));
     const int elem = ctx->max_len > 65535 ? 4 : 2;
     const size_t pairs = (size_t)n * (n - 1) / 2;
-    HIP_TRY(ctx->d_out.reserve(pairs * elem));
-    int rc = run_rows(ctx, lcsgpu::MODE_TRIANGLE, nullptr, 0, n, nullptr, 0, n - 1, ctx->d_out.p, 0, 0, elem);
+    HIP_TRY(L.d_out.reserve(pairs * elem));
+    int rc = run_rows(ctx, L, lcsgpu::MODE_TRIANGLE, nullptr, 0, n, nullptr, 0, n - 1, L.d_out.p, 0, 0, elem);
     if (rc) return rc;
 
     // orientation-sensitive sequences: their values in both roles, as side tables
@@ -641,11 +744,11 @@ int lcsgpu_mst_prim(lcsgpu_ctx* ctx, int distance_kind, lcsgpu_mst_edge* out_edg
     if (nq) {
         HIP_TRY(ctx->d_qrows.reserve((size_t)nq * n * 4));
         HIP_TRY(ctx->d_qcols.reserve((size_t)nq * n * 4));
-        rc = run_rows(ctx, lcsgpu::MODE_RECT, qlist.data(), 0, nq, nullptr, 0, n, ctx->d_qrows.p, n, 0, 4);
+        rc = run_rows(ctx, L, lcsgpu::MODE_RECT, qlist.data(), 0, nq, nullptr, 0, n, ctx->d_qrows.p, n, 0, 4);
         if (rc) return rc;
-        HIP_TRY(hipStreamSynchronize(ctx->stream)); // the staging buffer of the plan is reused by the next call
-        ctx->plan_in_flight = false;
-        rc = run_rows(ctx, lcsgpu::MODE_RECT, nullptr, 0, n, qlist.data(), 0, nq, ctx->d_qcols.p, nq, 0, 4);
+        HIP_TRY(hipStreamSynchronize(L.stream)); // the staging buffer of the plan is reused by the next call
+        L.plan_in_flight = false;
+        rc = run_rows(ctx, L, lcsgpu::MODE_RECT, nullptr, 0, n, qlist.data(), 0, nq, ctx->d_qcols.p, nq, 0, 4);
         if (rc) return rc;
     }
 
@@ -656,9 +759,9 @@ int lcsgpu_mst_prim(lcsgpu_ctx* ctx, int distance_kind, lcsgpu_mst_edge* out_edg
                  o_qidx = o_edges + a8((size_t)(n - 1) * sizeof(lcsgpu::MstEdge)), total = o_qidx + a8((size_t)n * 4);
     HIP_TRY(ctx->d_prim.reserve(total));
     char* base = (char*)ctx->d_prim.p;
-    if (nq) HIP_TRY(hipMemcpyAsync(base + o_qidx, qindex.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (nq) HIP_TRY(hipMemcpyAsync(base + o_qidx, qindex.data(), (size_t)n * 4, hipMemcpyHostToDevice, L.stream));
     lcsgpu::PrimArgs a{};
-    a.tri = ctx->d_out.p;
+    a.tri = L.d_out.p;
     a.lens = (const uint32_t*)ctx->d_lens.p;
     a.pow_table = (const double*)ctx->d_pow.p;
     a.qindex = nq ? (const int32_t*)(base + o_qidx) : nullptr;
@@ -673,12 +776,12 @@ int lcsgpu_mst_prim(lcsgpu_ctx* ctx, int distance_kind, lcsgpu_mst_edge* out_edg
     a.processed = (uint8_t*)(base + o_proc);
     a.partials = (lcsgpu::PrimPartial*)(base + o_part);
     a.edges = (lcsgpu::MstEdge*)(base + o_edges);
-    HIP_TRY(lcsgpu::launch_prim(a, elem, ctx->stream));
+    HIP_TRY(lcsgpu::launch_prim(a, elem, L.stream));
     static_assert(sizeof(lcsgpu_mst_edge) == sizeof(lcsgpu::MstEdge), "edge layout");
     HIP_TRY(hipMemcpyAsync(out_edges, a.edges, (size_t)(n - 1) * sizeof(lcsgpu_mst_edge), hipMemcpyDeviceToHost,
-                           ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    ctx->plan_in_flight = false;
+                           L.stream));
+    HIP_TRY(hipStreamSynchronize(L.stream));
+    L.plan_in_flight = false;
     return LCSGPU_OK;
 }
 
@@ -691,13 +794,14 @@ int lcsgpu_upgma(lcsgpu_ctx* ctx, int distance_kind, int modified, int32_t* out_
     const int32_t n = ctx->n;
     if (n < 2) return LCSGPU_OK;
     if (!out_left || !out_right) return fail(LCSGPU_E_INVALID, "NULL output");
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    LaneGuard guard(ctx, LaneGuard::LANE0);
+    Lane& L = guard.lane();
     HIP_TRY(hipSetDevice(ctx->device));
     const int elem = ctx->max_len > 65535 ? 4 : 2;
     const size_t pairs = (size_t)n * (n - 1) / 2;
-    HIP_TRY(ctx->d_out.reserve(pairs * elem));
+    HIP_TRY(L.d_out.reserve(pairs * elem));
     HIP_TRY(ctx->d_dist.reserve(pairs * sizeof(float)));
-    int rc = run_rows(ctx, lcsgpu::MODE_TRIANGLE, nullptr, 0, n, nullptr, 0, n - 1, ctx->d_out.p, 0, 0, elem);
+    int rc = run_rows(ctx, L, lcsgpu::MODE_TRIANGLE, nullptr, 0, n, nullptr, 0, n - 1, L.d_out.p, 0, 0, elem);
     if (rc) return rc;
     const int blocks = (n + 255) / 256;
     auto a16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
@@ -707,7 +811,7 @@ int lcsgpu_upgma(lcsgpu_ctx* ctx, int distance_kind, int modified, int32_t* out_
                  total = o_right + a16((size_t)n * 4);
     HIP_TRY(ctx->d_prim.reserve(total));
     char* base = (char*)ctx->d_prim.p;
-    HIP_TRY(hipMemsetAsync(base + o_sel, 0, 16, ctx->stream));
+    HIP_TRY(hipMemsetAsync(base + o_sel, 0, 16, L.stream));
     lcsgpu::UpgmaArgs a{};
     a.D = (float*)ctx->d_dist.p;
     a.min_dist = (float*)(base + o_min);
@@ -720,14 +824,14 @@ int lcsgpu_upgma(lcsgpu_ctx* ctx, int distance_kind, int modified, int32_t* out_
     a.right = (int32_t*)(base + o_right);
     a.n = n;
     a.n_blocks = blocks;
-    HIP_TRY(lcsgpu::launch_upgma(a, ctx->d_out.p, elem, (const uint32_t*)ctx->d_lens.p, (const float*)ctx->d_powf.p,
-                                 distance_kind, modified != 0, ctx->stream));
+    HIP_TRY(lcsgpu::launch_upgma(a, L.d_out.p, elem, (const uint32_t*)ctx->d_lens.p, (const float*)ctx->d_powf.p,
+                                 distance_kind, modified != 0, L.stream));
     uint32_t sel[4] = {0, 0, 0, 0};
-    HIP_TRY(hipMemcpyAsync(out_left, a.left, (size_t)(n - 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(out_right, a.right, (size_t)(n - 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(sel, a.sel, 16, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    ctx->plan_in_flight = false;
+    HIP_TRY(hipMemcpyAsync(out_left, a.left, (size_t)(n - 1) * 4, hipMemcpyDeviceToHost, L.stream));
+    HIP_TRY(hipMemcpyAsync(out_right, a.right, (size_t)(n - 1) * 4, hipMemcpyDeviceToHost, L.stream));
+    HIP_TRY(hipMemcpyAsync(sel, a.sel, 16, hipMemcpyDeviceToHost, L.stream));
+    HIP_TRY(hipStreamSynchronize(L.stream));
+    L.plan_in_flight = false;
     if (sel[2])
         return fail(LCSGPU_E_INVALID, "UPGMA: no finite nearest neighbour (a pair with LCS 0?) -- the reference's "
                                       "algorithm is undefined for this input");
@@ -743,43 +847,61 @@ int lcsgpu_lcs_triangle_ids(lcsgpu_ctx* ctx, const int32_t* ids, int32_t n_ids, 
     const int64_t count = (int64_t)n_ids * (n_ids - 1) / 2;
     if (count <= 0) return LCSGPU_OK;
     if (!out) return fail(LCSGPU_E_INVALID, "NULL out");
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    LaneGuard guard(ctx, LaneGuard::ANY);
+    Lane& L = guard.lane();
     HIP_TRY(hipSetDevice(ctx->device));
-    HIP_TRY(ctx->d_out.reserve((size_t)count * elem_size));
+    HIP_TRY(L.d_out.reserve((size_t)count * elem_size));
     // row k = ids[k] as the ref, column c = ids[c] as the partner, c < k
-    int rc = run_rows(ctx, lcsgpu::MODE_TRIANGLE, ids, 0, n_ids, ids, 0, n_ids - 1, ctx->d_out.p, 0, 0, elem_size, 0);
+    int rc = run_rows(ctx, L, lcsgpu::MODE_TRIANGLE, ids, 0, n_ids, ids, 0, n_ids - 1, L.d_out.p, 0, 0, elem_size, 0);
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(out, ctx->d_out.p, (size_t)count * elem_size, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    ctx->plan_in_flight = false;
+    HIP_TRY(hipMemcpyAsync(out, L.d_out.p, (size_t)count * elem_size, hipMemcpyDeviceToHost, L.stream));
+    HIP_TRY(hipStreamSynchronize(L.stream));
+    finish_host_call(ctx, L);
     return LCSGPU_OK;
 }
 
 int lcsgpu_sync(lcsgpu_ctx* ctx)
 {
     if (!ctx) return fail(LCSGPU_E_INVALID, "NULL ctx");
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    LaneGuard guard(ctx, LaneGuard::LANE0);
+    Lane& L = guard.lane();
     HIP_TRY(hipSetDevice(ctx->device));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    ctx->plan_in_flight = false;
+    HIP_TRY(hipStreamSynchronize(L.stream));
+    L.plan_in_flight = false;
     return LCSGPU_OK;
 }
 
 int lcsgpu_last_kernel_ms(lcsgpu_ctx* ctx, double* ms, int32_t* n_launches)
 {
     if (!ctx || !ms) return fail(LCSGPU_E_INVALID, "NULL argument");
-    std::lock_guard<std::mutex> lk(ctx->mu);
     *ms = 0.0;
-    if (n_launches) *n_launches = ctx->last_launches;
-    if (!ctx->timing_valid || ctx->last_launches == 0) return LCSGPU_OK;
+    if (n_launches) *n_launches = 0;
+    if (g_last.ctx != ctx) return LCSGPU_OK;
+    if (!g_last.pending_on_lane0) { // a completed host-memory call of this thread
+        *ms = g_last.ms;
+        if (n_launches) *n_launches = g_last.launches;
+        return LCSGPU_OK;
+    }
+    LaneGuard guard(ctx, LaneGuard::LANE0);
+    Lane& L = guard.lane();
+    if (n_launches) *n_launches = L.last_launches;
+    if (!L.timing_valid || L.last_launches == 0) return LCSGPU_OK;
     HIP_TRY(hipSetDevice(ctx->device));
-    HIP_TRY(hipEventSynchronize(ctx->ev_stop));
+    HIP_TRY(hipEventSynchronize(L.ev_stop));
     float f = 0.f;
-    HIP_TRY(hipEventElapsedTime(&f, ctx->ev_start, ctx->ev_stop));
+    HIP_TRY(hipEventElapsedTime(&f, L.ev_start, L.ev_stop));
     *ms = (double)f;
     return LCSGPU_OK;
 }
 
-void* lcsgpu_stream(lcsgpu_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+int lcsgpu_total_kernel_ms(lcsgpu_ctx* ctx, double* ms)
+{
+    if (!ctx || !ms) return fail(LCSGPU_E_INVALID, "NULL argument");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    *ms = ctx->total_kernel_ms;
+    return LCSGPU_OK;
+}
+
+void* lcsgpu_stream(lcsgpu_ctx* ctx) { return ctx && !ctx->lanes.empty() ? (void*)ctx->lanes[0].stream : nullptr; }
 
 } // extern "C"

@@ -372,6 +372,7 @@ struct FastTree {
         float best_cost = std::numeric_limits<float>::max();
         int n_seeds = -1;
         std::vector<int> seed_ids, assignments;
+        const auto t_top0 = std::chrono::steady_clock::now();
         for (int eval = 0; eval < prm.num_evaluations; ++eval) {
             int ns;
             std::vector<int> s, a;
@@ -393,6 +394,9 @@ struct FastTree {
         for (int j = 0; j < n; ++j) subgroups[assignments[j]].push_back(ids[j]);
 
         std::vector<int> subroots(n_seeds, -1);
+        const auto t_top1 = std::chrono::steady_clock::now();
+        if (parallel && getenv("FAMSA_GPU_PROFILE"))
+            fprintf(stderr, "fasttree.top_evaluation_wall=%.3f\n", std::chrono::duration<double>(t_top1 - t_top0).count());
         if (parallel && prm.n_threads > 1) {
             struct Task { int k, top; };
             std::vector<Task> tasks;
@@ -421,6 +425,9 @@ struct FastTree {
             for (const auto& e : errors)
                 if (!e.empty()) throw std::runtime_error(e);
             for (const auto& lt : locals) tree.insert(tree.end(), lt.begin(), lt.end());
+            if (getenv("FAMSA_GPU_PROFILE"))
+                fprintf(stderr, "fasttree.top_subtrees_wall=%.3f\n",
+                        std::chrono::duration<double>(std::chrono::steady_clock::now() - t_top1).count());
         } else {
             for (int k = 0; k < n_seeds; ++k) {
                 if (subgroups[k].size() > 1) {

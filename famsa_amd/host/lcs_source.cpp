@@ -60,8 +60,9 @@ void GpuLcsSource::add_kernel_ms()
 {
     double ms = 0;
     int32_t nl = 0;
+    if (lcsgpu_last_kernel_ms(ctx_, &ms, &nl) != LCSGPU_OK) return; // this thread's last call
     std::lock_guard<std::mutex> lk(mu_);
-    if (lcsgpu_last_kernel_ms(ctx_, &ms, &nl) == LCSGPU_OK) kernel_ms_ += ms;
+    kernel_ms_ += ms;
 }
 
 void GpuLcsSource::triangle(int r0, int r1, LcsBuf& out)

@@ -56,6 +56,7 @@ def load_library():
         "lcsgpu_upgma": (C.c_int, [vp, C.c_int, C.c_int, vp, vp]),
         "lcsgpu_sync": (C.c_int, [vp]),
         "lcsgpu_last_kernel_ms": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(i32)]),
+        "lcsgpu_total_kernel_ms": (C.c_int, [vp, C.POINTER(C.c_double)]),
         "lcsgpu_stream": (vp, [vp]),
     }
     for name, (res, args) in sig.items():

@@ -9,9 +9,13 @@
  *
  * Conventions: plain C types only; every function returns 0 on success or a negative
  * LCSGPU_E_* code, never throws; lcsgpu_last_error() gives a thread-local message.
- * The caller owns every buffer it passes.  A context is bound to one GPU; calls on one
- * context are serialised internally (a mutex), different contexts are independent --
- * the multi-GPU model is one process (or one context) per GPU.
+ * The caller owns every buffer it passes.  A context is bound to one GPU and may be used from
+ * several host threads at once (the reference runs one CLCSBP per worker thread): host-memory
+ * calls (lcsgpu_lcs_rect, lcsgpu_lcs_triangle, lcsgpu_lcs_triangle_ids) execute concurrently on
+ * internal lanes (HIP streams); device-memory calls, the tree reducers and lcsgpu_sync use one
+ * fixed stream (lcsgpu_stream) in call order; lcsgpu_upload waits for everything and is
+ * exclusive.  Different contexts are independent -- the multi-GPU model is one process (or one
+ * context) per GPU.
  *
  * Symbol codes are the reference's: index in "ARNDCQEGHILKMFPSTWYVBZX*"
  * (core/sequence.cpp:17), 22 = unknown; only codes < 20 ever match
@@ -176,10 +180,13 @@ int lcsgpu_upgma(lcsgpu_ctx* ctx, int distance_kind, int modified, int32_t* out_
 /* Block until everything queued on the context's stream has finished. */
 int lcsgpu_sync(lcsgpu_ctx* ctx);
 
-/* Timing of the LCS kernels of the most recent *_dev / host call on this context, measured
- * with HIP events on the stream the kernels were launched on: total milliseconds and the
- * number of kernel launches it covers.  Used by bench.py for the roofline figure. */
+/* Timing of the LCS kernels of the calling thread's most recent *_dev / host call on this context,
+ * measured with HIP events on the stream the kernels were launched on: total milliseconds and
+ * the number of kernel launches it covers.  Used by bench.py for the roofline figure. */
 int lcsgpu_last_kernel_ms(lcsgpu_ctx* ctx, double* ms, int32_t* n_launches);
+
+/* Sum of the LCS kernel milliseconds of all completed host-memory calls on this context (any thread). */
+int lcsgpu_total_kernel_ms(lcsgpu_ctx* ctx, double* ms);
 
 /* Raw stream handle (hipStream_t) of the context, for callers that enqueue their own
  * work behind the engine's. */

@@ -265,3 +265,44 @@ def test_triangle_over_id_lists(engine, oracle):
         sq = oracle.rect(codes, offsets, ids, ids)
         want = sq[np.tril_indices(m, -1)]
         assert (got == want).all(), m
+
+
+def test_concurrent_host_threads_share_one_context(engine, oracle):
+    """The reference runs one CLCSBP per worker thread; here many threads share the engine and their
+    host-memory calls run on separate lanes (streams).  Every thread must get its own results."""
+    import threading
+    rng = np.random.Generator(np.random.PCG64(101))
+    seqs = [rng.integers(0, 20, size=int(l)).astype(np.uint8) for l in rng.integers(20, 700, size=900)]
+    engine.upload_seqs(seqs)
+    codes, offsets = seqio.pack(seqs)
+    n = len(seqs)
+    jobs = []
+    for t in range(24):
+        r = np.random.Generator(np.random.PCG64(t))
+        jobs.append((r.integers(0, n, size=int(r.integers(1, 40))), r.integers(0, n, size=int(r.integers(1, 600))),
+                     r.permutation(n)[: int(r.integers(2, 200))]))
+    results = [None] * len(jobs)
+    errors = []
+
+    def work(k):
+        try:
+            out = []
+            for rep in range(5):
+                refs, cols, ids = jobs[k]
+                out.append((engine.lcs_rect(refs, cols, dtype=np.uint32), engine.lcs_triangle_ids(ids, dtype=np.uint32)))
+            results[k] = out
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(len(jobs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for k, (refs, cols, ids) in enumerate(jobs):
+        want_r = oracle.rect(codes, offsets, refs, cols)
+        sq = oracle.rect(codes, offsets, ids, ids)
+        want_t = sq[np.tril_indices(len(ids), -1)]
+        for got_r, got_t in results[k]:
+            assert (got_r == want_r).all() and (got_t == want_t).all(), k
