@@ -231,11 +231,30 @@ private:
     const std::vector<int>& ids_;
 };
 
+// Worker threads are a shared budget: a split at ANY depth may take idle threads for its
+// sub-trees (the reference parallelises the top-level split only, which leaves one thread to grind
+// through a dominant cluster; results do not depend on who computes a sub-tree).
+struct ThreadBudget {
+    std::atomic<int> free{0};
+    int acquire(int want)
+    {
+        int got = 0;
+        while (got < want) {
+            int cur = free.load();
+            if (cur <= 0) break;
+            if (free.compare_exchange_weak(cur, cur - 1)) ++got;
+        }
+        return got;
+    }
+    void release(int k) { free.fetch_add(k); }
+};
+
 template <Distance D>
 struct FastTree {
     LcsSource& src;
     GT partial;
     FastTreeParams prm;
+    ThreadBudget* budget;
     Transform<float, D> transform; // FastTree uses float distances throughout
 
     // distances of subset member `ref_local` to every member: calculateDistanceVector(ref, all)
@@ -397,7 +416,7 @@ struct FastTree {
         const auto t_top1 = std::chrono::steady_clock::now();
         if (parallel && getenv("FAMSA_GPU_PROFILE"))
             fprintf(stderr, "fasttree.top_evaluation_wall=%.3f\n", std::chrono::duration<double>(t_top1 - t_top0).count());
-        if (parallel && prm.n_threads > 1) {
+        {
             struct Task { int k, top; };
             std::vector<Task> tasks;
             for (int k = 0; k < n_seeds; ++k)
@@ -408,36 +427,36 @@ struct FastTree {
                 }
             std::vector<tree_structure> locals(tasks.size());
             std::atomic<size_t> next{0};
-            std::vector<std::string> errors(prm.n_threads);
-            std::vector<std::thread> workers;
-            for (int w = 0; w < prm.n_threads; ++w)
-                workers.emplace_back([&, w] {
-                    try {
-                        FastTree<D> child{src, partial, prm, {}};
-                        for (size_t t = next++; t < tasks.size(); t = next++)
-                            child.do_step(subgroups[tasks[t].k], locals[t], tasks[t].top, false);
-                    } catch (const std::exception& e) {
-                        errors[w] = e.what();
-                        next = tasks.size();
-                    }
+            std::mutex err_mu;
+            std::string error;
+            auto run = [&](FastTree<D>& ft) {
+                try {
+                    for (size_t t = next++; t < tasks.size(); t = next++)
+                        ft.do_step(subgroups[tasks[t].k], locals[t], tasks[t].top, false);
+                } catch (const std::exception& e) {
+                    std::lock_guard<std::mutex> lk(err_mu);
+                    if (error.empty()) error = e.what();
+                    next = tasks.size();
+                }
+            };
+            // helpers only when the split is big enough to amortise them
+            const int want = (budget && n >= 4 * std::max(prm.threshold, prm.subtree_size) && tasks.size() > 1)
+                                 ? (int)tasks.size() - 1 : 0;
+            const int extra = want > 0 ? budget->acquire(want) : 0;
+            std::vector<std::thread> helpers;
+            for (int w = 0; w < extra; ++w)
+                helpers.emplace_back([&] {
+                    FastTree<D> child{src, partial, prm, budget, {}};
+                    run(child);
                 });
-            for (auto& w : workers) w.join();
-            for (const auto& e : errors)
-                if (!e.empty()) throw std::runtime_error(e);
+            run(*this);
+            for (auto& h : helpers) h.join();
+            if (extra) budget->release(extra);
+            if (!error.empty()) throw std::runtime_error(error);
             for (const auto& lt : locals) tree.insert(tree.end(), lt.begin(), lt.end());
-            if (getenv("FAMSA_GPU_PROFILE"))
+            if (parallel && getenv("FAMSA_GPU_PROFILE"))
                 fprintf(stderr, "fasttree.top_subtrees_wall=%.3f\n",
                         std::chrono::duration<double>(std::chrono::steady_clock::now() - t_top1).count());
-        } else {
-            for (int k = 0; k < n_seeds; ++k) {
-                if (subgroups[k].size() > 1) {
-                    tree_structure local;
-                    do_step(subgroups[k], local, previous_top, false);
-                    tree.insert(tree.end(), local.begin(), local.end());
-                    previous_top += (int)subgroups[k].size() - 1;
-                    subroots[k] = previous_top - 1;
-                }
-            }
         }
         tree_structure local;
         {
@@ -462,7 +481,9 @@ void run_fast(LcsSource& src, GT partial, const FastTreeParams& p, tree_structur
     const int n = src.n();
     tree.assign(n, node_t(-1, -1));
     if (n < 2) return;
-    FastTree<D> ft{src, partial, p, {}};
+    ThreadBudget budget;
+    budget.free = std::max(0, p.n_threads - 1);
+    FastTree<D> ft{src, partial, p, &budget, {}};
     std::vector<int> ids(n);
     std::iota(ids.begin(), ids.end(), 0);
     tree_structure local;
