@@ -43,6 +43,13 @@ def cpu_baseline(n, length, target_s=12.0):
         return None
     ref = oracle_bind.Ref()
     avail = len(os.sched_getaffinity(0))
+    quota = None
+    try:  # cgroup v2 CPU quota of the container, if any
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = int(q) / int(period)
+    except Exception:
+        pass
     n_probe = min(n, 4000)
     codes, offsets = seqio.synth_uniform(n, length)
     # the sample is a prefix of the same set (fixed length => already in the reference's order up to ties)
@@ -70,6 +77,7 @@ def cpu_baseline(n, length, target_s=12.0):
         "pairs_per_s": pairs / sec,
         "seconds": sec,
         "host_threads_available": avail,
+        "host_cpu_quota_cores": quota,
         "sample": f"reference UPGMA::computeDistances (AVX2 dispatch, {threads} threads = the fastest of a "
                   f"16/32/64/128/{avail} probe) on the first {n_use} of the {n} synthetic sequences = {int(pairs)} pairs",
     }

@@ -94,6 +94,7 @@ struct PinBuf {
 struct Lane {
     hipStream_t stream = nullptr;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    hipEvent_t ev_done = nullptr; // blocking-sync event: host-memory calls sleep on it instead of spinning
     DevBuf d_plan, d_out, d_carry;
     PinBuf h_plan;
     bool plan_in_flight = false;
@@ -453,7 +454,8 @@ int lcsgpu_create(int device_id, lcsgpu_ctx** out_ctx)
     ctx->lanes.resize(n_lanes);
     for (Lane& l : ctx->lanes)
         if (hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking) != hipSuccess ||
-            hipEventCreate(&l.ev_start) != hipSuccess || hipEventCreate(&l.ev_stop) != hipSuccess) {
+            hipEventCreate(&l.ev_start) != hipSuccess || hipEventCreate(&l.ev_stop) != hipSuccess ||
+            hipEventCreateWithFlags(&l.ev_done, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess) {
             lcsgpu_destroy(ctx);
             return fail(LCSGPU_E_HIP, "stream/event creation failed");
         }
@@ -473,6 +475,7 @@ int lcsgpu_destroy(lcsgpu_ctx* ctx)
         l.h_plan.release();
         if (l.ev_start) (void)hipEventDestroy(l.ev_start);
         if (l.ev_stop) (void)hipEventDestroy(l.ev_stop);
+        if (l.ev_done) (void)hipEventDestroy(l.ev_done);
         if (l.stream) (void)hipStreamDestroy(l.stream);
     }
     ctx->d_tiles.release();
@@ -647,7 +650,8 @@ int lcsgpu_lcs_rect(lcsgpu_ctx* ctx, const int32_t* ref_ids, int32_t ref_begin, 
     if (rc) return rc;
     HIP_TRY(hipMemcpy2DAsync(out, (size_t)ld * elem_size, L.d_out.p, (size_t)n_cols * elem_size,
                              (size_t)n_cols * elem_size, n_refs, hipMemcpyDeviceToHost, L.stream));
-    HIP_TRY(hipStreamSynchronize(L.stream));
+    HIP_TRY(hipEventRecord(L.ev_done, L.stream));
+    HIP_TRY(hipEventSynchronize(L.ev_done)); // sleeps; worker threads must not burn a core per pending call
     finish_host_call(ctx, L);
     return LCSGPU_OK;
 }
@@ -690,7 +694,8 @@ int lcsgpu_lcs_triangle(lcsgpu_ctx* ctx, int32_t row_begin, int32_t row_end, voi
     int rc = triangle_common(ctx, L, row_begin, row_end, L.d_out.p, elem_size);
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(out, L.d_out.p, (size_t)count * elem_size, hipMemcpyDeviceToHost, L.stream));
-    HIP_TRY(hipStreamSynchronize(L.stream));
+    HIP_TRY(hipEventRecord(L.ev_done, L.stream));
+    HIP_TRY(hipEventSynchronize(L.ev_done)); // sleeps; worker threads must not burn a core per pending call
     finish_host_call(ctx, L);
     return LCSGPU_OK;
 }
@@ -855,7 +860,8 @@ int lcsgpu_lcs_triangle_ids(lcsgpu_ctx* ctx, const int32_t* ids, int32_t n_ids, 
     int rc = run_rows(ctx, L, lcsgpu::MODE_TRIANGLE, ids, 0, n_ids, ids, 0, n_ids - 1, L.d_out.p, 0, 0, elem_size, 0);
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(out, L.d_out.p, (size_t)count * elem_size, hipMemcpyDeviceToHost, L.stream));
-    HIP_TRY(hipStreamSynchronize(L.stream));
+    HIP_TRY(hipEventRecord(L.ev_done, L.stream));
+    HIP_TRY(hipEventSynchronize(L.ev_done)); // sleeps; worker threads must not burn a core per pending call
     finish_host_call(ctx, L);
     return LCSGPU_OK;
 }

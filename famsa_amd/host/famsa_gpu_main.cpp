@@ -93,7 +93,15 @@ int main(int argc, char** argv)
         // -t <n>: host worker threads (0 = half of the hardware threads, reference core/params.cpp:285-291)
         int n_threads = 0;
         if (find_option(params, "-t", aux)) n_threads = std::stoi(aux);
-        if (n_threads <= 0) n_threads = std::max(1u, std::thread::hardware_concurrency() / 2);
+        if (n_threads <= 0) {
+            n_threads = std::max(1u, std::thread::hardware_concurrency() / 2);
+            // a container may grant fewer cores than the machine has (cgroup v2 cpu.max = "<quota> <period>")
+            std::ifstream cg("/sys/fs/cgroup/cpu.max");
+            std::string quota;
+            long period = 0;
+            if (cg >> quota >> period && quota != "max" && period > 0)
+                n_threads = std::max(1, std::min(n_threads, (int)((std::stol(quota) + period - 1) / period)));
+        }
         opt.fast.n_threads = n_threads;
         const bool very_verbose = find_switch(params, "-vv");
         const bool verbose = find_switch(params, "-v") || very_verbose;

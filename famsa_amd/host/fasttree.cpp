@@ -426,13 +426,26 @@ struct FastTree {
                     subroots[k] = previous_top - 1;
                 }
             std::vector<tree_structure> locals(tasks.size());
+            if (parallel && getenv("FAMSA_GPU_PROFILE")) {
+                std::vector<size_t> sz;
+                for (auto& t : tasks) sz.push_back(subgroups[t.k].size());
+                std::sort(sz.rbegin(), sz.rend());
+                fprintf(stderr, "fasttree.top_groups=%zu largest:", sz.size());
+                for (size_t i = 0; i < std::min<size_t>(6, sz.size()); ++i) fprintf(stderr, " %zu", sz[i]);
+                fprintf(stderr, "\n");
+            }
             std::atomic<size_t> next{0};
             std::mutex err_mu;
             std::string error;
             auto run = [&](FastTree<D>& ft) {
                 try {
-                    for (size_t t = next++; t < tasks.size(); t = next++)
+                    for (size_t t = next++; t < tasks.size(); t = next++) {
+                        const auto t0 = std::chrono::steady_clock::now();
                         ft.do_step(subgroups[tasks[t].k], locals[t], tasks[t].top, false);
+                        const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                        if (parallel && dt > 2.0 && getenv("FAMSA_GPU_PROFILE"))
+                            fprintf(stderr, "fasttree.slow_task size=%zu wall=%.2f\n", subgroups[tasks[t].k].size(), dt);
+                    }
                 } catch (const std::exception& e) {
                     std::lock_guard<std::mutex> lk(err_mu);
                     if (error.empty()) error = e.what();

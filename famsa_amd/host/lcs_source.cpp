@@ -1,6 +1,9 @@
 #include "lcs_source.h"
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <stdexcept>
 
 #include "../../include/lcsgpu.h"
@@ -35,8 +38,23 @@ GpuLcsSource::GpuLcsSource(int device)
 
 GpuLcsSource::~GpuLcsSource()
 {
+    if (getenv("FAMSA_GPU_PROFILE"))
+        fprintf(stderr, "engine.rect: %ld calls %.3f thread-s %.3g pairs\nengine.triangle: %ld calls %.3f thread-s %.3g pairs\n"
+                        "engine.triangle_ids: %ld calls %.3f thread-s %.3g pairs\n",
+                st_rect_.calls, st_rect_.seconds, st_rect_.pairs, st_tri_.calls, st_tri_.seconds, st_tri_.pairs,
+                st_triids_.calls, st_triids_.seconds, st_triids_.pairs);
     if (ctx_) lcsgpu_destroy(ctx_);
 }
+
+void GpuLcsSource::note(CallStat& s, double sec, double pairs)
+{
+    std::lock_guard<std::mutex> lk(mu_);
+    s.calls++;
+    s.seconds += sec;
+    s.pairs += pairs;
+}
+
+static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 void GpuLcsSource::check(int rc, const char* what)
 {
@@ -69,15 +87,19 @@ void GpuLcsSource::triangle(int r0, int r1, LcsBuf& out)
 {
     const size_t count = (size_t)r1 * (r1 - 1) / 2 - (size_t)r0 * (r0 > 0 ? r0 - 1 : 0) / 2;
     out.resize(count, wide());
+    const double t0 = now_s();
     check(lcsgpu_lcs_triangle(ctx_, r0, r1, out.data(), out.elem_size()), "lcsgpu_lcs_triangle");
+    note(st_tri_, now_s() - t0, (double)count);
     add_kernel_ms();
 }
 
 void GpuLcsSource::rect(const int* refs, int n_refs, const int* cols, int n_cols, LcsBuf& out)
 {
     out.resize((size_t)n_refs * n_cols, wide());
+    const double t0 = now_s();
     check(lcsgpu_lcs_rect(ctx_, refs, 0, n_refs, cols, 0, n_cols, out.data(), n_cols, out.elem_size()),
           "lcsgpu_lcs_rect");
+    note(st_rect_, now_s() - t0, (double)n_refs * n_cols);
     add_kernel_ms();
 }
 
@@ -85,7 +107,9 @@ void GpuLcsSource::triangle_ids(const int* ids, int n_ids, LcsBuf& out)
 {
     out.resize(n_ids > 1 ? (size_t)n_ids * (n_ids - 1) / 2 : 0, wide());
     if (n_ids < 2) return;
+    const double t0 = now_s();
     check(lcsgpu_lcs_triangle_ids(ctx_, ids, n_ids, out.data(), out.elem_size()), "lcsgpu_lcs_triangle_ids");
+    note(st_triids_, now_s() - t0, (double)n_ids * (n_ids - 1) / 2);
     add_kernel_ms();
 }
 

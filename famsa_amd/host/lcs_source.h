@@ -78,6 +78,9 @@ private:
     bool sensitive_ = false;
     double kernel_ms_ = 0;
     std::mutex mu_; // the tree builders may call from several threads
+    // call statistics (printed at destruction when FAMSA_GPU_PROFILE is set)
+    struct CallStat { long calls = 0; double seconds = 0; double pairs = 0; } st_rect_, st_tri_, st_triids_;
+    void note(CallStat& s, double sec, double pairs);
 };
 
 // A full oriented square matrix supplied by the caller: m[ref*n + partner].
