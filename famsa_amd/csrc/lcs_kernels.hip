@@ -328,14 +328,19 @@ struct Pipe {
             ring[t] = gather(grp, q, q, t);
     }
 
+    // CARRY (long refs, one segment of the bit-vector per pass): bit b of `cw` enters word 0 at
+    // residue b, the carry leaving the last word is collected in bit b of `cout`.
+    template <bool CARRY = false>
     static __device__ __forceinline__ void chunk(const lds_u8* grp, const uint4& q, const uint4& qn,
-                                                 uint64_t (&ring)[LOOKAHEAD], uint32_t (&X)[RG][H])
+                                                 uint64_t (&ring)[LOOKAHEAD], uint32_t (&X)[RG][H], uint32_t cw = 0,
+                                                 uint32_t* cout = nullptr)
     {
+        static_assert(!CARRY || RG == 1, "carry streams are per (ref, partner)");
 #pragma unroll
         for (int b = 0; b < 16; ++b) {
 #pragma unroll
             for (int r = 0; r < RG; ++r) {
-                unsigned cin = 0;
+                unsigned cin = CARRY ? ((cw >> b) & 1u) : 0u;
 #pragma unroll
                 for (int j = 0; j < W; ++j) {
                     const int t = (b * RG + r) * W + j;
@@ -365,6 +370,7 @@ struct Pipe {
                         LCS_PIN();
                     }
                 }
+                if (CARRY) *cout |= cin << b;
             }
         }
     }
@@ -509,6 +515,33 @@ __global__ __launch_bounds__(256) void lcs_long_kernel(RowsArgs a, uint16_t* car
             __syncthreads(); // previous segment's readers are done with the masks
             build_mask_words(a, rid, seg * SEGW, SEGW, (lds_u64*)smem, wave, lane);
             __syncthreads();
+            if constexpr (!QUIRK) {
+                // the pipelined half-word step of the hot kernel, one 64-half-word segment per pass
+                using P = Pipe<2 * SEGW, 1, LCS_LOOKAHEAD>;
+                uint32_t X[1][2 * SEGW];
+#pragma unroll
+                for (int j = 0; j < 2 * SEGW; ++j)
+                    X[0][j] = ~0u;
+                uint4 q = make_uint4(PAD4, PAD4, PAD4, PAD4);
+                if (0 < my_chunks)
+                    q = *(const uint4*)pbase;
+                uint64_t ring[LCS_LOOKAHEAD];
+                P::prime((const lds_u8*)smem, q, ring);
+                for (int k = 0; k < wave_chunks; ++k) {
+                    uint4 qn = make_uint4(PAD4, PAD4, PAD4, PAD4);
+                    if (k + 1 < my_chunks)
+                        qn = *(const uint4*)(pbase + (size_t)(k + 1) * 1024);
+                    const uint32_t cw = (seg > 0) ? my_carry[(size_t)k * 256] : 0u;
+                    uint32_t cout = 0;
+                    P::template chunk<true>((const lds_u8*)smem, q, qn, ring, X, cw, &cout);
+                    if (seg + 1 < n_seg)
+                        my_carry[(size_t)k * 256] = (uint16_t)cout;
+                    q = qn;
+                }
+#pragma unroll
+                for (int j = 0; j < 2 * SEGW; ++j)
+                    res += __popc(~X[0][j]);
+            } else {
             uint32_t X[2 * SEGW];
 #pragma unroll
             for (int j = 0; j < 2 * SEGW; ++j)
@@ -537,6 +570,7 @@ __global__ __launch_bounds__(256) void lcs_long_kernel(RowsArgs a, uint16_t* car
 #pragma unroll
             for (int j = 0; j < 2 * SEGW; ++j)
                 res += __popc(~X[j]);
+            }
         }
         if (valid)
             store_result(a, ref0 + r, c, res);
