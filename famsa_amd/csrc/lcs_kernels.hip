@@ -333,14 +333,20 @@ struct Pipe {
     template <bool CARRY = false>
     static __device__ __forceinline__ void chunk(const lds_u8* grp, const uint4& q, const uint4& qn,
                                                  uint64_t (&ring)[LOOKAHEAD], uint32_t (&X)[RG][H], uint32_t cw = 0,
-                                                 uint32_t* cout = nullptr)
+                                                 uint32_t* cout_p = nullptr)
     {
         static_assert(!CARRY || RG == 1, "carry streams are per (ref, partner)");
+        uint32_t cout = 0;
 #pragma unroll
         for (int b = 0; b < 16; ++b) {
 #pragma unroll
             for (int r = 0; r < RG; ++r) {
-                unsigned cin = CARRY ? ((cw >> b) & 1u) : 0u;
+                unsigned cin = 0;
+                if (CARRY) {
+                    cin = cw & 1u;
+                    cw >>= 1;
+                    LCS_PIN();
+                }
 #pragma unroll
                 for (int j = 0; j < W; ++j) {
                     const int t = (b * RG + r) * W + j;
@@ -370,9 +376,14 @@ struct Pipe {
                         LCS_PIN();
                     }
                 }
-                if (CARRY) *cout |= cin << b;
+                if (CARRY) {
+                    cout = (cout >> 1) | (cin << 15);
+                    asm volatile("" : "+v"(cout)); // materialise now: otherwise 16 carries wait in SGPR pairs
+                    LCS_PIN();
+                }
             }
         }
+        if (CARRY) *cout_p = cout;
     }
 };
 

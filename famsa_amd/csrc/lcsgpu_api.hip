@@ -372,7 +372,9 @@ int run_rows(lcsgpu_ctx* ctx, Lane& L, int mode, const int32_t* ref_ids, int32_t
         } else {
             // long refs: slices of ref blocks so the carry scratch stays bounded
             const int n_chunks_max = (int)((ctx->max_len + 15) / 16);
-            const int gy_step = std::max(1, 1024 / gx);
+            // ref-tile rows per launch: as many as fit 2 GiB of carry scratch (512 B per chunk per workgroup)
+            const size_t per_block = (size_t)n_chunks_max * 512;
+            const int gy_step = (int)std::max<size_t>(1, ((size_t)2 << 30) / per_block / (size_t)gx);
             HIP_TRY(L.d_carry.reserve(lcsgpu::long_carry_bytes(gx, std::min(gy, gy_step), n_chunks_max)));
             for (int y0 = 0; y0 < gy; y0 += gy_step) {
                 RowsArgs s = a;
