@@ -106,4 +106,23 @@ struct UpgmaArgs {
 hipError_t launch_upgma(const UpgmaArgs& a, const void* lcs, int elem_size, const uint32_t* lens,
                         const float* pow_f32, int kind, bool modified, hipStream_t stream);
 
+
+// ---- device-side neighbour joining (tree_kernels.hip) ----
+struct NjArgs {
+    float* D;         // float distance triangle (updated in place)
+    float* sum;       // [n] sum of distances per cluster row
+    float* tmp;       // [n] new distances of the current merge
+    float* part_q;    // [n] per-row minima of q
+    int32_t* part_i;  // [n]
+    int32_t* node;    // [n] tree node id held by the row
+    uint8_t* active;  // [n]
+    int32_t* sel;     // [0] mi, [1] mj, [2] degenerate flag
+    int32_t* left;    // [n-1]
+    int32_t* right;
+    int32_t n;
+};
+hipError_t launch_nj(const NjArgs& a, hipStream_t stream);
+hipError_t launch_float_distances(const void* lcs, int elem_size, const uint32_t* lens, const float* pow_f32, int kind,
+                                  int n, float* D, hipStream_t stream);
+
 } // namespace lcsgpu

@@ -845,6 +845,60 @@ int lcsgpu_upgma(lcsgpu_ctx* ctx, int distance_kind, int modified, int32_t* out_
     return LCSGPU_OK;
 }
 
+int lcsgpu_nj(lcsgpu_ctx* ctx, int distance_kind, int32_t* out_left, int32_t* out_right)
+{
+    if (!ctx) return fail(LCSGPU_E_INVALID, "NULL ctx");
+    if (ctx->n < 0) return fail(LCSGPU_E_STATE, "no sequence set uploaded");
+    if (distance_kind != LCSGPU_DIST_INDEL_DIV_LCS && distance_kind != LCSGPU_DIST_INDEL075_DIV_LCS)
+        return fail(LCSGPU_E_INVALID, "unknown distance kind %d", distance_kind);
+    const int32_t n = ctx->n;
+    if (n < 2) return LCSGPU_OK;
+    if (!out_left || !out_right) return fail(LCSGPU_E_INVALID, "NULL output");
+    LaneGuard guard(ctx, LaneGuard::LANE0);
+    Lane& L = guard.lane();
+    HIP_TRY(hipSetDevice(ctx->device));
+    const int elem = ctx->max_len > 65535 ? 4 : 2;
+    const size_t pairs = (size_t)n * (n - 1) / 2;
+    HIP_TRY(L.d_out.reserve(pairs * elem));
+    HIP_TRY(ctx->d_dist.reserve(pairs * sizeof(float)));
+    int rc = run_rows(ctx, L, lcsgpu::MODE_TRIANGLE, nullptr, 0, n, nullptr, 0, n - 1, L.d_out.p, 0, 0, elem);
+    if (rc) return rc;
+    auto a16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
+    const size_t o_sum = 0, o_tmp = o_sum + a16((size_t)n * 4), o_pq = o_tmp + a16((size_t)n * 4),
+                 o_pi = o_pq + a16((size_t)n * 4), o_node = o_pi + a16((size_t)n * 4), o_act = o_node + a16((size_t)n * 4),
+                 o_sel = o_act + a16((size_t)n), o_left = o_sel + 16, o_right = o_left + a16((size_t)n * 4),
+                 total = o_right + a16((size_t)n * 4);
+    HIP_TRY(ctx->d_prim.reserve(total));
+    char* base = (char*)ctx->d_prim.p;
+    HIP_TRY(hipMemsetAsync(base + o_sel, 0, 16, L.stream));
+    lcsgpu::NjArgs a{};
+    a.D = (float*)ctx->d_dist.p;
+    a.sum = (float*)(base + o_sum);
+    a.tmp = (float*)(base + o_tmp);
+    a.part_q = (float*)(base + o_pq);
+    a.part_i = (int32_t*)(base + o_pi);
+    a.node = (int32_t*)(base + o_node);
+    a.active = (uint8_t*)(base + o_act);
+    a.sel = (int32_t*)(base + o_sel);
+    a.left = (int32_t*)(base + o_left);
+    a.right = (int32_t*)(base + o_right);
+    a.n = n;
+    HIP_TRY(lcsgpu::launch_float_distances(L.d_out.p, elem, (const uint32_t*)ctx->d_lens.p, (const float*)ctx->d_powf.p,
+                                           distance_kind, n, a.D, L.stream));
+    HIP_TRY(lcsgpu::launch_nj(a, L.stream));
+    int32_t sel[4] = {0, 0, 0, 0};
+    HIP_TRY(hipMemcpyAsync(out_left, a.left, (size_t)(n - 1) * 4, hipMemcpyDeviceToHost, L.stream));
+    HIP_TRY(hipMemcpyAsync(out_right, a.right, (size_t)(n - 1) * 4, hipMemcpyDeviceToHost, L.stream));
+    HIP_TRY(hipMemcpyAsync(sel, a.sel, 16, hipMemcpyDeviceToHost, L.stream));
+    HIP_TRY(hipStreamSynchronize(L.stream));
+    L.plan_in_flight = false;
+    note_async_call(ctx);
+    if (sel[2])
+        return fail(LCSGPU_E_INVALID, "NJ: no finite q (a pair with LCS 0?) -- the reference's result is degenerate "
+                                      "for this input");
+    return LCSGPU_OK;
+}
+
 int lcsgpu_lcs_triangle_ids(lcsgpu_ctx* ctx, const int32_t* ids, int32_t n_ids, void* out, int elem_size)
 {
     if (!ctx) return fail(LCSGPU_E_INVALID, "NULL ctx");

@@ -372,3 +372,188 @@ hipError_t launch_upgma(const UpgmaArgs& a, const void* lcs, int elem_size, cons
 }
 
 } // namespace lcsgpu
+
+// =============================================================================================
+// Device-side neighbour joining, operation for operation the reference's
+// NeighborJoining::computeTree (tree/NeighborJoining.cpp:33-118): float arithmetic with its
+// exact association and summation ORDER (the sums of distances are accumulated sequentially in
+// ascending cluster order, so they are here too), first strict minimum of
+//   q(i,j) = (n_clusters - 2) * D[i,j] - sum[i] - sum[j]     over i < j in lexicographic order.
+// The reference keeps its clusters in a vector it erases from; positions stay in ascending row
+// order, so "position order" == "ascending row id among the active rows".
+// Per merge: nj_rowmin (one workgroup per row j, scanning i < j: contiguous in the triangle),
+// nj_select (1 workgroup: global first minimum, bookkeeping), nj_update (all k: new distances,
+// sums of the other clusters), nj_sum (1 workgroup: the merged cluster's sum, in order).
+// =============================================================================================
+namespace lcsgpu {
+
+__global__ __launch_bounds__(256) void nj_init_kernel(NjArgs a)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.n) return;
+    float s = 0.0f;
+    for (int j = 0; j < a.n; ++j)
+        if (j != i) s = __fadd_rn(s, a.D[tri_index(i, j)]); // sequential, j ascending (NeighborJoining.cpp:47-53)
+    a.sum[i] = s;
+    a.node[i] = i;
+    a.active[i] = 1;
+}
+
+__global__ __launch_bounds__(256) void nj_rowmin_kernel(NjArgs a, int n_clusters)
+{
+    __shared__ float s_q[256];
+    __shared__ int s_i[256];
+    const int j = blockIdx.x, tid = threadIdx.x;
+    float bq = 3.40282347e38f; // numeric_limits<float>::max(): only q < max can win
+    int bi = -1;
+    if (a.active[j]) {
+        const float sj = a.sum[j];
+        const float f = (float)(n_clusters - 2);
+        const float* row = a.D + (size_t)j * (j - 1) / 2;
+        for (int i = tid; i < j; i += 256) {
+            if (!a.active[i]) continue;
+            const float q = __fsub_rn(__fsub_rn(__fmul_rn(f, row[i]), a.sum[i]), sj);
+            if (q < bq) { bq = q; bi = i; } // ascending i within the thread
+        }
+    }
+    s_q[tid] = bq;
+    s_i[tid] = bi;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) {
+            const float q2 = s_q[tid + s];
+            const int i2 = s_i[tid + s];
+            if (i2 >= 0 && (s_i[tid] < 0 || q2 < s_q[tid] || (q2 == s_q[tid] && i2 < s_i[tid]))) { s_q[tid] = q2; s_i[tid] = i2; }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        a.part_q[j] = s_q[0];
+        a.part_i[j] = s_i[0];
+    }
+}
+
+__global__ __launch_bounds__(1024) void nj_select_kernel(NjArgs a, int iter)
+{
+    __shared__ float s_q[1024];
+    __shared__ int s_i[1024], s_j[1024];
+    const int tid = threadIdx.x;
+    float bq = 3.40282347e38f;
+    int bi = -1, bj = -1;
+    for (int j = tid; j < a.n; j += 1024) {
+        const int i = a.part_i[j];
+        if (i < 0) continue;
+        const float q = a.part_q[j];
+        // first strict minimum in (i, j) lexicographic order
+        if (bi < 0 || q < bq || (q == bq && (i < bi || (i == bi && j < bj)))) { bq = q; bi = i; bj = j; }
+    }
+    s_q[tid] = bq; s_i[tid] = bi; s_j[tid] = bj;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) {
+        if (tid < s) {
+            const float q2 = s_q[tid + s];
+            const int i2 = s_i[tid + s], j2 = s_j[tid + s];
+            if (i2 >= 0 && (s_i[tid] < 0 || q2 < s_q[tid] ||
+                            (q2 == s_q[tid] && (i2 < s_i[tid] || (i2 == s_i[tid] && j2 < s_j[tid]))))) {
+                s_q[tid] = q2; s_i[tid] = i2; s_j[tid] = j2;
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        int mi = s_i[0], mj = s_j[0];
+        if (mi < 0) { // no q below FLT_MAX: the reference keeps min_i = min_j = 0 (degenerate input)
+            a.sel[2] = 1;
+            mi = 0; mj = 0;
+        }
+        a.sel[0] = mi;
+        a.sel[1] = mj;
+        a.left[iter] = a.node[mi];
+        a.right[iter] = a.node[mj];
+    }
+}
+
+__global__ __launch_bounds__(256) void nj_update_kernel(NjArgs a)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= a.n) return;
+    const int mi = a.sel[0], mj = a.sel[1];
+    float nd = 0.0f; // contribution to the merged cluster's sum (0 for clusters that do not take part)
+    if (a.active[k] && k != mi && k != mj) {
+        const size_t vi = tri_index(mi, k);
+        const float Dij = a.D[tri_index(mi, mj)];
+        const float Dik = a.D[vi], Djk = a.D[tri_index(mj, k)];
+        float sk = __fsub_rn(a.sum[k], __fadd_rn(Dik, Djk));          // ck.sum -= Dik + Djk
+        nd = __fmul_rn(__fsub_rn(__fadd_rn(Dik, Djk), Dij), 0.5f);    // (Dik + Djk - Dij) / 2
+        sk = __fadd_rn(sk, nd);                                       // ck.sum += Dik
+        a.sum[k] = sk;
+        a.D[vi] = nd;
+    }
+    a.tmp[k] = nd;
+}
+
+__global__ __launch_bounds__(256) void nj_sum_kernel(NjArgs a, int iter)
+{
+    // ci.sum = sum of the new distances in ascending cluster order (NeighborJoining.cpp:88-108)
+    __shared__ float buf[4096];
+    const int tid = threadIdx.x;
+    float s = 0.0f;
+    for (int base = 0; base < a.n; base += 4096) {
+        const int m = min(4096, a.n - base);
+        for (int t = tid; t < m; t += 256) buf[t] = a.tmp[base + t];
+        __syncthreads();
+        if (tid == 0)
+            for (int t = 0; t < m; ++t) s = __fadd_rn(s, buf[t]);
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const int mi = a.sel[0], mj = a.sel[1];
+        a.sum[mi] = s;
+        a.node[mi] = a.n + iter;
+        if (mj != mi) a.active[mj] = 0;
+    }
+}
+
+__global__ void nj_final_kernel(NjArgs a, int iter)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int first = -1, second = -1;
+    for (int k = 0; k < a.n; ++k)
+        if (a.active[k]) {
+            if (first < 0) first = k;
+            else if (second < 0) second = k;
+        }
+    a.left[iter] = a.node[first];
+    a.right[iter] = second >= 0 ? a.node[second] : a.node[first];
+}
+
+hipError_t launch_nj(const NjArgs& a, hipStream_t stream)
+{
+    const int n = a.n, blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(nj_init_kernel, dim3(blocks), dim3(256), 0, stream, a);
+    int iter = 0;
+    for (int n_clusters = n; n_clusters > 2; --n_clusters, ++iter) {
+        hipLaunchKernelGGL(nj_rowmin_kernel, dim3(n), dim3(256), 0, stream, a, n_clusters);
+        hipLaunchKernelGGL(nj_select_kernel, dim3(1), dim3(1024), 0, stream, a, iter);
+        hipLaunchKernelGGL(nj_update_kernel, dim3(blocks), dim3(256), 0, stream, a);
+        hipLaunchKernelGGL(nj_sum_kernel, dim3(1), dim3(256), 0, stream, a, iter);
+    }
+    hipLaunchKernelGGL(nj_final_kernel, dim3(1), dim3(64), 0, stream, a, iter);
+    return hipGetLastError();
+}
+
+// float distance triangle for the reducers (shared by UPGMA and NJ)
+hipError_t launch_float_distances(const void* lcs, int elem_size, const uint32_t* lens, const float* pow_f32, int kind,
+                                  int n, float* D, hipStream_t stream)
+{
+    if (n < 2) return hipSuccess;
+    if (elem_size == 2)
+        hipLaunchKernelGGL(upgma_dist_kernel<uint16_t>, dim3(n - 1), dim3(256), 0, stream, (const uint16_t*)lcs, lens,
+                           pow_f32, kind, n, D);
+    else
+        hipLaunchKernelGGL(upgma_dist_kernel<uint32_t>, dim3(n - 1), dim3(256), 0, stream, (const uint32_t*)lcs, lens,
+                           pow_f32, kind, n, D);
+    return hipGetLastError();
+}
+
+} // namespace lcsgpu

@@ -132,6 +132,16 @@ bool GpuLcsSource::upgma_nodes(int distance_kind, bool modified, std::vector<int
     return true;
 }
 
+bool GpuLcsSource::nj_nodes(int distance_kind, std::vector<int32_t>& left, std::vector<int32_t>& right)
+{
+    const int m = n() > 0 ? n() - 1 : 0;
+    left.resize(m);
+    right.resize(m);
+    check(lcsgpu_nj(ctx_, distance_kind, left.data(), right.data()), "lcsgpu_nj");
+    add_kernel_ms();
+    return true;
+}
+
 MatrixLcsSource::MatrixLcsSource(int n, const uint32_t* lens, const uint32_t* square)
     : n_(n), lens_(lens, lens + n), m_(square, square + (size_t)n * n), sensitive_(false)
 {

@@ -52,6 +52,7 @@ public:
     // UPGMA computed by the source itself (device): children of internal nodes n..2n-2.
     virtual bool upgma_nodes(int /*distance_kind*/, bool /*modified*/, std::vector<int32_t>& /*left*/,
                              std::vector<int32_t>& /*right*/) { return false; }
+    virtual bool nj_nodes(int /*distance_kind*/, std::vector<int32_t>& /*left*/, std::vector<int32_t>& /*right*/) { return false; }
 };
 
 // The MI355X engine.  Throws std::runtime_error if the library reports an error (no fallback).
@@ -68,6 +69,7 @@ public:
     void triangle_ids(const int* ids, int n_ids, LcsBuf& out) override;
     bool prim_edges(int distance_kind, std::vector<MstEdge>& edges) override;
     bool upgma_nodes(int distance_kind, bool modified, std::vector<int32_t>& left, std::vector<int32_t>& right) override;
+    bool nj_nodes(int distance_kind, std::vector<int32_t>& left, std::vector<int32_t>& right) override;
     double kernel_ms_total() const { return kernel_ms_; }
     void add_kernel_ms();
 

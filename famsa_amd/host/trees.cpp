@@ -379,6 +379,11 @@ void build_partial_d(LcsSource& src, GT method, tree_structure& tree)
         break;
     }
     case GT::NJ: {
+        std::vector<int32_t> left, right;
+        if (src.nj_nodes((int)D, left, right)) { // merges ran on the device
+            for (int i = 0; i < n - 1; ++i) tree.emplace_back(left[i], right[i]);
+            break;
+        }
         std::vector<float> dist;
         float_triangle<D>(src, dist);
         nj_tree(dist, n, tree);

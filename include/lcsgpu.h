@@ -177,6 +177,14 @@ int lcsgpu_mst_prim(lcsgpu_ctx* ctx, int distance_kind, lcsgpu_mst_edge* out_edg
  * Replaces: UPGMA::computeDistances + UPGMA::computeTree (tree/UPGMA.cpp:75-109, 114-295). */
 int lcsgpu_upgma(lcsgpu_ctx* ctx, int distance_kind, int modified, int32_t* out_left, int32_t* out_right);
 
+/* Neighbour joining over the uploaded set on the device: LCS triangle -> float distances ->
+ * n-2 merges, each the reference's (tree/NeighborJoining.cpp:33-118) float arithmetic in its
+ * exact association and summation order, first strict minimum of q over i < j.  Output as for
+ * lcsgpu_upgma (children of internal nodes n..2n-2).
+ * Replaces: calculateDistanceMatrix (single-threaded in the reference, NeighborJoining.cpp:16) +
+ * NeighborJoining::computeTree. */
+int lcsgpu_nj(lcsgpu_ctx* ctx, int distance_kind, int32_t* out_left, int32_t* out_right);
+
 /* Block until everything queued on the context's stream has finished. */
 int lcsgpu_sync(lcsgpu_ctx* ctx);
 

@@ -122,9 +122,9 @@ def test_cli_medoidtree_duplicates(tmp_path):
     assert open(out, "rb").read() == open(os.path.join(G, "hemopexin_duplicates", "medoid-sl-dups.dnd"), "rb").read()
 
 
-@pytest.mark.parametrize("gt", ["upgma", "upgma_modified"])
+@pytest.mark.parametrize("gt", ["upgma", "upgma_modified", "nj"])
 def test_device_upgma_on_tie_heavy_inputs(host, tmp_path, gt):
-    """Device UPGMA vs the host restatement (itself pinned against the reference on tie-heavy random inputs):
+    """Device UPGMA / NJ vs the host restatement (itself pinned against the reference on tie-heavy random inputs):
     small alphabets give many equal float distances, so every '<' / first-minimum rule is exercised."""
     import numpy as np
     import oracle_bind as ob
