@@ -60,6 +60,8 @@ seqio.to_fasta(codes, offsets, "/tmp/cmp_10k.fasta")
 case("synthetic 10000 x 400 aa", "/tmp/cmp_10k.fasta", "sl")
 case("synthetic 10000 x 400 aa", "/tmp/cmp_10k.fasta", "upgma")
 case("synthetic 10000 x 400 aa", "/tmp/cmp_10k.fasta", "slink")
+case("hemopexin (4188 seqs, 21-210 aa)", os.path.join(ROOT, "tests", "golden", "hemopexin", "hemopexin"), "nj")
+case("hemopexin (4188 seqs, 21-210 aa)", os.path.join(ROOT, "tests", "golden", "hemopexin", "hemopexin"), "upgma")
 fam = "/tmp/family_200000_300.fasta"
 if os.path.exists(fam):
     case("synthetic family 200000 x ~255 aa, -medoidtree", fam, "upgma", heuristic=2, cli_args=["-medoidtree"])
