@@ -724,6 +724,8 @@ int lcsgpu_row_minima_dev(lcsgpu_ctx* ctx, const void* d_triangle, int elem_size
 
 int lcsgpu_mst_prim(lcsgpu_ctx* ctx, int distance_kind, lcsgpu_mst_edge* out_edges)
 {
+    const bool triangle_orientation = (distance_kind & LCSGPU_MST_TRIANGLE_ORIENTATION) != 0;
+    distance_kind &= ~LCSGPU_MST_TRIANGLE_ORIENTATION;
     if (!ctx) return fail(LCSGPU_E_INVALID, "NULL ctx");
     if (ctx->n < 0) return fail(LCSGPU_E_STATE, "no sequence set uploaded");
     if (distance_kind != LCSGPU_DIST_INDEL_DIV_LCS && distance_kind != LCSGPU_DIST_INDEL075_DIV_LCS)
@@ -742,7 +744,7 @@ int lcsgpu_mst_prim(lcsgpu_ctx* ctx, int distance_kind, lcsgpu_mst_edge* out_edg
 
     // orientation-sensitive sequences: their values in both roles, as side tables
     std::vector<int32_t> qindex(n, -1), qlist;
-    for (int32_t i = 0; i < n; ++i)
+    for (int32_t i = 0; i < n && !triangle_orientation; ++i)
         if (ctx->quirk[i]) {
             qindex[i] = (int32_t)qlist.size();
             qlist.push_back(i);

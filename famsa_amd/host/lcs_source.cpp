@@ -113,11 +113,12 @@ void GpuLcsSource::triangle_ids(const int* ids, int n_ids, LcsBuf& out)
     add_kernel_ms();
 }
 
-bool GpuLcsSource::prim_edges(int distance_kind, std::vector<MstEdge>& edges)
+bool GpuLcsSource::prim_edges(int distance_kind, std::vector<MstEdge>& edges, bool triangle_orientation)
 {
     static_assert(sizeof(MstEdge) == sizeof(lcsgpu_mst_edge), "edge layout");
     edges.resize(n() > 0 ? n() - 1 : 0);
-    check(lcsgpu_mst_prim(ctx_, distance_kind, (lcsgpu_mst_edge*)edges.data()), "lcsgpu_mst_prim");
+    const int flags = triangle_orientation ? LCSGPU_MST_TRIANGLE_ORIENTATION : 0;
+    check(lcsgpu_mst_prim(ctx_, distance_kind | flags, (lcsgpu_mst_edge*)edges.data()), "lcsgpu_mst_prim");
     add_kernel_ms();
     return true;
 }

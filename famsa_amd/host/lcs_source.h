@@ -48,7 +48,9 @@ public:
     // (from < to, distance) in the order they are added from vertex 0.  Returns false if the
     // source cannot (then the caller runs Prim on the host over triangle()/rect()).
     struct MstEdge { int32_t from, to; double dist; };
-    virtual bool prim_edges(int /*distance_kind*/, std::vector<MstEdge>& /*edges*/) { return false; }
+    // triangle_orientation: every distance from LCS(ref = larger id, partner = smaller id) (what SLINK
+    // sees) instead of MSTPrim's LCS(ref = node just added, partner = candidate)
+    virtual bool prim_edges(int /*distance_kind*/, std::vector<MstEdge>& /*edges*/, bool /*triangle_orientation*/) { return false; }
     // UPGMA computed by the source itself (device): children of internal nodes n..2n-2.
     virtual bool upgma_nodes(int /*distance_kind*/, bool /*modified*/, std::vector<int32_t>& /*left*/,
                              std::vector<int32_t>& /*right*/) { return false; }
@@ -67,7 +69,7 @@ public:
     void triangle(int r0, int r1, LcsBuf& out) override;
     void rect(const int* refs, int n_refs, const int* cols, int n_cols, LcsBuf& out) override;
     void triangle_ids(const int* ids, int n_ids, LcsBuf& out) override;
-    bool prim_edges(int distance_kind, std::vector<MstEdge>& edges) override;
+    bool prim_edges(int distance_kind, std::vector<MstEdge>& edges, bool triangle_orientation) override;
     bool upgma_nodes(int distance_kind, bool modified, std::vector<int32_t>& left, std::vector<int32_t>& right) override;
     bool nj_nodes(int distance_kind, std::vector<int32_t>& left, std::vector<int32_t>& right) override;
     double kernel_ms_total() const { return kernel_ms_; }

@@ -4,6 +4,7 @@
 #include <cfloat>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <limits>
@@ -79,7 +80,7 @@ void mst_prim(LcsSource& src, tree_structure& tree)
     prim_order[0] = next_order++;
 
     std::vector<LcsSource::MstEdge> dev_edges;
-    if (src.prim_edges((int)D, dev_edges)) {
+    if (src.prim_edges((int)D, dev_edges, /*triangle_orientation=*/false)) {
         // the engine ran the n-1 relaxation steps on the device; replay the bookkeeping
         for (const auto& e : dev_edges) {
             edges.push_back(Edge{e.from, e.to, next_order, -e.dist});
@@ -192,10 +193,96 @@ struct SlinkDist { // slink_dist_t (reference tree/SingleLinkage.h:19-38): by di
     bool operator<=(const SlinkDist& r) const { return first == r.first ? second >= r.second : first <= r.first; }
 };
 
+// SLINK's output from the minimum spanning tree.  With the strict total order both generators put
+// on pair distances -- (d ascending, packed ids descending): slink_dist_t (SingleLinkage.h:19-38)
+// and MSTPrim's (d, ~pack) keys -- the single-linkage hierarchy is unique and SLINK's pointer
+// representation is its canonical encoding: processing the MST edges in that order, the component
+// whose largest member `a` is the smaller of the two maxima gets lambda[a] = edge, pi[a] = the
+// other maximum.  The distances must be SLINK's: ref = the larger index (the triangle orientation).
+struct SlinkEdge { int from, to; double d; };
+void slink_from_mst(std::vector<SlinkEdge>& edges, int n, tree_structure& tree)
+{
+    std::sort(edges.begin(), edges.end(), [](const SlinkEdge& x, const SlinkEdge& y) {
+        if (x.d != y.d) return x.d < y.d;
+        return pack_ids(x.from, x.to) > pack_ids(y.from, y.to);
+    });
+    std::vector<int> parent(n), top(n), pi(n);
+    for (int i = 0; i < n; ++i) parent[i] = top[i] = pi[i] = i;
+    auto find = [&](int x) {
+        while (parent[x] != x) { parent[x] = parent[parent[x]]; x = parent[x]; }
+        return x;
+    };
+    std::vector<int> elements;
+    elements.reserve(n - 1);
+    for (const SlinkEdge& e : edges) {
+        const int A = find(e.from), B = find(e.to);
+        const int a = std::min(top[A], top[B]), b = std::max(top[A], top[B]);
+        pi[a] = b;
+        elements.push_back(a);
+        parent[A] = B;
+        top[B] = b;
+    }
+    std::vector<int> index(n);
+    for (int i = 0; i < n; ++i) index[i] = i;
+    for (int i = 0; i < n - 1; ++i) {
+        const int j = elements[i];
+        const int next = pi[j];
+        tree.emplace_back(index[j], index[next]);
+        index[next] = n + i;
+    }
+}
+
+// Prim on the host over triangle-orientation distances (ref = larger index): test path for slink_from_mst
+template <Distance D>
+void host_prim_triangle(LcsSource& src, std::vector<SlinkEdge>& out)
+{
+    const int n = src.n();
+    LcsBuf buf;
+    src.triangle(0, n, buf);
+    Transform<double, D> transform;
+    std::vector<Key> key(n, Key{std::numeric_limits<double>::max(), 0});
+    std::vector<int> alive;
+    for (int v = 1; v < n; ++v) alive.push_back(v);
+    int cur = 0;
+    while (!alive.empty()) {
+        size_t best_pos = 0;
+        for (size_t p = 0; p < alive.size(); ++p) {
+            const int v = alive[p];
+            const int hi = std::max(cur, v), lo = std::min(cur, v);
+            const double d = transform(buf[tri(hi, lo)], src.length(hi), src.length(lo));
+            if (d <= key[v].d) {
+                const Key s{d, ~pack_ids(cur, v)};
+                if (s < key[v]) key[v] = s;
+            }
+            if (key[v] < key[alive[best_pos]]) best_pos = p;
+        }
+        const int best = alive[best_pos];
+        const uint64_t packed = ~key[best].id;
+        out.push_back(SlinkEdge{(int)(packed >> 32), (int)(packed & 0xffffffffull), key[best].d});
+        alive[best_pos] = alive.back();
+        alive.pop_back();
+        cur = best;
+    }
+}
+
 template <Distance D>
 void slink(LcsSource& src, tree_structure& tree)
 {
     const int n = src.n();
+    {
+        std::vector<LcsSource::MstEdge> dev_edges;
+        std::vector<SlinkEdge> edges;
+        if (src.prim_edges((int)D, dev_edges, /*triangle_orientation=*/true)) {
+            for (const auto& e : dev_edges) edges.push_back(SlinkEdge{e.from, e.to, e.dist});
+            slink_from_mst(edges, n, tree);
+            return;
+        }
+        if (getenv("FAMSA_SLINK_FROM_MST")) { // test hook: the same conversion with Prim on the host
+            host_prim_triangle<D>(src, edges);
+            slink_from_mst(edges, n, tree);
+            return;
+        }
+    }
     Transform<double, D> transform;
     std::vector<int> pi(n, 0);
     std::vector<SlinkDist> lambda(n), M(n);

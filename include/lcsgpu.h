@@ -165,6 +165,10 @@ typedef struct lcsgpu_mst_edge {
  * Replaces: the per-step distance batches (calculateDistanceRangeSV, hpp:287-375), the key update
  * and the candidate selection of MSTPrim::run_view. */
 int lcsgpu_mst_prim(lcsgpu_ctx* ctx, int distance_kind, lcsgpu_mst_edge* out_edges);
+/* OR this into distance_kind to take every distance from LCS(ref = larger id, partner = smaller id),
+ * the orientation SingleLinkage (SLINK) sees (tree/SingleLinkage.cpp:58-81), instead of MSTPrim's
+ * LCS(ref = the node just added).  The two differ only for orientation-sensitive sequences. */
+#define LCSGPU_MST_TRIANGLE_ORIENTATION 0x100
 
 /* UPGMA (or MAFFT-style "modified" UPGMA) over the uploaded set, entirely on the device: LCS
  * triangle -> float distances (Transform<float, kind>: host-built (float)pow(indel,0.75) table,
