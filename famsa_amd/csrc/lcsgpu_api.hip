@@ -791,6 +791,7 @@ int lcsgpu_mst_prim(lcsgpu_ctx* ctx, int distance_kind, lcsgpu_mst_edge* out_edg
                            L.stream));
     HIP_TRY(hipStreamSynchronize(L.stream));
     L.plan_in_flight = false;
+    note_async_call(ctx);
     return LCSGPU_OK;
 }
 
@@ -844,6 +845,7 @@ int lcsgpu_upgma(lcsgpu_ctx* ctx, int distance_kind, int modified, int32_t* out_
     if (sel[2])
         return fail(LCSGPU_E_INVALID, "UPGMA: no finite nearest neighbour (a pair with LCS 0?) -- the reference's "
                                       "algorithm is undefined for this input");
+    note_async_call(ctx);
     return LCSGPU_OK;
 }
 

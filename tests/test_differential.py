@@ -74,6 +74,29 @@ def test_trees_and_csv_match_reference(host, ref, oracle, tmp_path, seed, n, max
         ref.close(h)
 
 
+@pytest.mark.parametrize("seed,n,max_len,alpha", CASES[:8])
+def test_slink_via_mst_matches_reference(host, ref, oracle, tmp_path, monkeypatch, seed, n, max_len, alpha):
+    """The MST -> SLINK conversion used on the GPU path, on tie-heavy inputs, against the reference's SLINK."""
+    monkeypatch.setenv("FAMSA_SLINK_FROM_MST", "1")
+    rng = np.random.Generator(np.random.PCG64(1000 + seed))
+    ids, seqs = random_set(rng, n, max_len, alpha, 0.25)
+    fasta = str(tmp_path / "in.fasta")
+    with open(fasta, "w") as f:
+        for i, s in zip(ids, seqs):
+            f.write(f"{i}\n{s}\n")
+    enc = [oracle.encode(s) for s in seqs]
+    codes, offsets = seqio.pack(enc)
+    sq = oracle.rect(codes, offsets, np.arange(n), np.arange(n))
+    h = ref.open_fasta(fasta)
+    try:
+        for dist_id, dist in [(1, "indel075_div_lcs"), (0, "indel_div_lcs")]:
+            for keep in (False, True):
+                want = ref.tree(h, "slink", distance=dist_id, keep_dups=int(keep), threads=2)
+                assert host.tree_from_matrix(fasta, sq, "slink", distance=dist, keep_duplicates=keep) == want
+    finally:
+        ref.close(h)
+
+
 @pytest.mark.parametrize("seed", range(4))
 def test_medoid_and_parttree_match_reference(host, ref, oracle, tmp_path, seed):
     rng = np.random.Generator(np.random.PCG64(77 + seed))

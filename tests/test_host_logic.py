@@ -168,3 +168,16 @@ def test_medoid_subtrees_built_by_worker_threads(host, oracle, monkeypatch):
     got = host.tree_from_matrix(f, square(oracle, f), "upgma", heuristic="medoidtree", subtree_size=10,
                                 sample_size=100, threshold=100, cluster_fraction=0.2, cluster_iters=1)
     assert got == open(os.path.join(G, "hemopexin", "medoid-upgma-params.dnd"), "rb").read()
+
+
+def test_slink_equals_canonical_pointer_representation_of_the_mst(host, oracle, monkeypatch):
+    """On the GPU `-gt slink` = device Prim (triangle-orientation distances) + an O(n log n) conversion:
+    SLINK's output is the canonical pointer representation of the single-linkage hierarchy under the
+    strict (distance, packed ids) order.  Here the same conversion runs with Prim on the host."""
+    monkeypatch.setenv("FAMSA_SLINK_FROM_MST", "1")
+    for name in ("adeno_fiber/adeno_fiber", "adversarial_tree.fasta", "hemopexin/hemopexin"):
+        f = os.path.join(G, name)
+        gold = {"adeno_fiber/adeno_fiber": "adeno_fiber/slink.dnd", "adversarial_tree.fasta": "adversarial_tree_slink.dnd",
+                "hemopexin/hemopexin": "hemopexin/slink.dnd"}[name]
+        m = square(oracle, f, symmetric_ok=(name != "adversarial_tree.fasta"))
+        assert host.tree_from_matrix(f, m, "slink") == open(os.path.join(G, gold), "rb").read()
