@@ -1,0 +1,102 @@
+"""GPU tests at sizes the oracle cannot cover exhaustively: size-independent properties and sampled
+bit-exact checks (20 000 sequences = 2x10^8 pairs)."""
+import numpy as np
+import pytest
+
+from famsa_amd import seqio
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def big(engine):
+    rng = np.random.Generator(np.random.PCG64(2024))
+    n = 20000
+    anc = rng.integers(0, 20, size=140).astype(np.uint8)
+    seqs = []
+    for _ in range(n):
+        s = anc.copy()
+        m = rng.random(140) < 0.3
+        s[m] = rng.integers(0, 20, size=int(m.sum()))
+        seqs.append(s[: int(rng.integers(60, 141))])
+    seqs = [seqs[i] for i in seqio.sort_order(seqs)]
+    engine.upload_seqs(seqs)
+    return seqs
+
+
+def test_sampled_pairs_bit_exact_and_bounds(engine, oracle, big):
+    seqs = big
+    n = len(seqs)
+    tri = engine.lcs_triangle()
+    assert tri.size == n * (n - 1) // 2
+    lens = np.array([len(s) for s in seqs], dtype=np.int64)
+    rng = np.random.Generator(np.random.PCG64(5))
+    i = rng.integers(1, n, size=6000)
+    j = (rng.random(6000) * i).astype(np.int64)
+    got = tri[i * (i - 1) // 2 + j]
+    for k in range(len(i)):
+        assert got[k] == oracle.lcs(seqs[i[k]], seqs[j[k]]), (i[k], j[k])
+    # every LCS is bounded by the shorter sequence (rows are sorted by length descending: that is row i)
+    rows = np.repeat(np.arange(1, n), np.arange(1, n))
+    assert (tri <= lens[rows]).all()
+
+
+def test_mst_is_a_spanning_tree_with_exact_edge_weights(engine, oracle, big):
+    seqs = big
+    n = len(seqs)
+    edges = engine.mst_prim(1)
+    assert len(edges) == n - 1
+    seen = np.zeros(n, bool)
+    seen[0] = True
+    prev = 0.0
+    for e in edges:  # Prim order: every edge joins exactly one new vertex to the visited set
+        a, b = int(e["from"]), int(e["to"])
+        assert a < b and (seen[a] != seen[b])
+        seen[a] = seen[b] = True
+    assert seen.all()
+    for e in edges[:: max(1, (n - 1) // 3000)]:
+        a, b = int(e["from"]), int(e["to"])
+        l = oracle.lcs(seqs[b], seqs[a])  # no orientation-sensitive sequences in this set
+        assert float(e["dist"]) == oracle.lib.oracle_dist_indel075_f64(l, len(seqs[a]), len(seqs[b]))
+    # cut property on a sample: no sampled pair is lighter than the edge that attached its later endpoint
+    order = np.zeros(n, np.int64)
+    w = np.zeros(n)
+    t = 0
+    visited = {0}
+    for e in edges:
+        a, b = int(e["from"]), int(e["to"])
+        new = b if a in visited else a
+        visited.add(new)
+        t += 1
+        order[new] = t
+        w[new] = float(e["dist"])
+    rng = np.random.Generator(np.random.PCG64(6))
+    for _ in range(3000):
+        u, v = rng.integers(0, n, size=2)
+        if u == v:
+            continue
+        late, early = (u, v) if order[u] > order[v] else (v, u)
+        hi, lo = max(u, v), min(u, v)
+        d = oracle.lib.oracle_dist_indel075_f64(oracle.lcs(seqs[hi], seqs[lo]), len(seqs[hi]), len(seqs[lo]))
+        assert d >= w[late]  # when `late` was attached, `early` was already in the tree
+
+
+@pytest.mark.parametrize("which", ["upgma", "nj"])
+def test_device_reducers_produce_valid_trees(engine, big, which):
+    n = 6000
+    engine.upload_seqs(big[:n])
+    left, right = engine.upgma(1) if which == "upgma" else None, None
+    if which == "upgma":
+        left, right = engine.upgma(1)
+    else:
+        import ctypes as C
+        left = np.zeros(n - 1, np.int32)
+        right = np.zeros(n - 1, np.int32)
+        engine._check(engine._lib.lcsgpu_nj(engine._ctx, 1, left.ctypes.data, right.ctypes.data))
+    used = np.zeros(2 * n - 1, int)
+    for k in range(n - 1):
+        for c in (int(left[k]), int(right[k])):
+            assert 0 <= c < n + k
+            used[c] += 1
+    assert (used[: 2 * n - 2] == 1).all() and used[2 * n - 2] == 0
+    engine.upload_seqs(big)
