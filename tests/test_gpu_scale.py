@@ -85,11 +85,9 @@ def test_mst_is_a_spanning_tree_with_exact_edge_weights(engine, oracle, big):
 def test_device_reducers_produce_valid_trees(engine, big, which):
     n = 6000
     engine.upload_seqs(big[:n])
-    left, right = engine.upgma(1) if which == "upgma" else None, None
     if which == "upgma":
         left, right = engine.upgma(1)
     else:
-        import ctypes as C
         left = np.zeros(n - 1, np.int32)
         right = np.zeros(n - 1, np.int32)
         engine._check(engine._lib.lcsgpu_nj(engine._ctx, 1, left.ctypes.data, right.ctypes.data))
