@@ -70,56 +70,26 @@ __device__ __forceinline__ uint64_t odd_half_read(const lds_u8* p)
 #endif
 }
 
-// One partner residue against RG refs x H half-words.  `row` = LDS address of this residue's
-// entry in mask row 0 of ref 0 of the group; a ref's rows are (H+1)/2 x 256 bytes.
-template <int H, int RG, bool QUIRK>
-__device__ __forceinline__ void residue_step(const lds_u8* row, uint32_t (&X)[RG][H])
+// One partner residue against W 64-bit words of ONE ref with the reference's rule, literally
+// (lcs/lcsbp_classic.h:51-58):  V2 = V + tB + cin;  cin' = (V2 < V).  Used for orientation-sensitive
+// refs only (the QUIRK kernels); `row` = LDS address of the residue's entry in the ref's mask row 0.
+// Returns the carry leaving the last word (needed by the long-ref kernel).
+template <int W>
+__device__ __forceinline__ unsigned literal_step(const lds_u8* row, uint32_t (&X)[2 * W], unsigned cin_bit)
 {
-    constexpr int W = (H + 1) / 2; // 64-bit mask rows per ref
+    uint64_t cin = cin_bit;
 #pragma unroll
-    for (int r = 0; r < RG; ++r) {
-        if constexpr (!QUIRK) {
-            unsigned cin = 0;
-#pragma unroll
-            for (int j = 0; j < H / 2; ++j) {
-                const uint64_t nn = *(const lds_u64*)(row + (r * W + j) * 256);
-                const uint32_t n0 = (uint32_t)nn, n1 = (uint32_t)(nn >> 32);
-                unsigned co;
-                uint32_t V = X[r][2 * j];
-                uint32_t s = __builtin_addc(V, andn(V, n0), cin, &co);
-                X[r][2 * j] = or_and(s, V, n0);
-                cin = co;
-                V = X[r][2 * j + 1];
-                s = __builtin_addc(V, andn(V, n1), cin, &co);
-                X[r][2 * j + 1] = or_and(s, V, n1);
-                cin = co;
-            }
-            if constexpr (H & 1) {
-                // a 64-bit read although only the low half is used: ds_read_b32 banks are
-                // (addr/4)%32, so codes c and c+16 would collide; ds_read_b64's are (addr/4)%64
-                const uint32_t n0 = (uint32_t)odd_half_read(row + (r * W + H / 2) * 256);
-                unsigned co;
-                const uint32_t V = X[r][H - 1];
-                const uint32_t s = __builtin_addc(V, andn(V, n0), cin, &co);
-                X[r][H - 1] = or_and(s, V, n0);
-            }
-        } else {
-            // the reference's rule, literally: V2 = V + tB + cin; cin' = (V2 < V)
-            static_assert(!QUIRK || (H % 2 == 0), "quirk instantiations use whole 64-bit words");
-            uint64_t cin = 0;
-#pragma unroll
-            for (int j = 0; j < H / 2; ++j) {
-                const uint64_t nn = *(const lds_u64*)(row + (r * W + j) * 256);
-                const uint64_t V = ((uint64_t)X[r][2 * j + 1] << 32) | X[r][2 * j];
-                const uint64_t tB = V & ~nn;
-                const uint64_t V2 = V + tB + cin;
-                cin = (V2 < V) ? 1u : 0u;
-                const uint64_t Xn = V2 | (V & nn);
-                X[r][2 * j] = (uint32_t)Xn;
-                X[r][2 * j + 1] = (uint32_t)(Xn >> 32);
-            }
-        }
+    for (int j = 0; j < W; ++j) {
+        const uint64_t nn = *(const lds_u64*)(row + j * 256);
+        const uint64_t V = ((uint64_t)X[2 * j + 1] << 32) | X[2 * j];
+        const uint64_t tB = V & ~nn;
+        const uint64_t V2 = V + tB + cin;
+        cin = (V2 < V) ? 1u : 0u;
+        const uint64_t Xn = V2 | (V & nn);
+        X[2 * j] = (uint32_t)Xn;
+        X[2 * j + 1] = (uint32_t)(Xn >> 32);
     }
+    return (unsigned)cin;
 }
 
 __device__ __forceinline__ int wave_max(int v)
@@ -210,11 +180,15 @@ __device__ __forceinline__ bool block_is_above_diagonal(const RowsArgs& a, int r
     return c0 >= max_row;
 }
 
-template <int H, int RG, bool QUIRK>
-__global__ __launch_bounds__(256) void lcs_rows_kernel(RowsArgs a)
+// Orientation-sensitive refs (SURVEY note Q): one ref at a time, whole 64-bit words, literal rule.
+// Rare by construction (a ref needs an aligned 64-residue homopolymer), so this kernel is written
+// for exactness, not speed.
+template <int H>
+__global__ __launch_bounds__(256) void lcs_rows_kernel_quirk(RowsArgs a)
 {
+    static_assert(H % 2 == 0, "quirk instantiations use whole 64-bit words");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int W = (H + 1) / 2;
+    constexpr int W = H / 2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int R = a.refs_per_block;
     int bx, by;
@@ -224,18 +198,12 @@ __global__ __launch_bounds__(256) void lcs_rows_kernel(RowsArgs a)
     const int c0 = bx * 256;
     if (block_is_above_diagonal(a, ref0, nr, c0))
         return;
-
-    // ---- 1. masks of the block's refs -> LDS; slots of a partial last group = "no match" --
-    {
-        const int nr_pad = (nr + RG - 1) / RG * RG;
-        for (int r = 0; r < nr_pad; ++r) {
-            const int rid = r < nr ? (a.ref_ids ? a.ref_ids[ref0 + r] : a.ref_begin + ref0 + r) : -1;
-            build_mask_words(a, rid, 0, W, (lds_u64*)smem + r * W * 32, wave, lane);
-        }
+    for (int r = 0; r < nr; ++r) {
+        const int rid = a.ref_ids ? a.ref_ids[ref0 + r] : a.ref_begin + ref0 + r;
+        build_mask_words(a, rid, 0, W, (lds_u64*)smem + r * W * 32, wave, lane);
     }
     __syncthreads();
 
-    // ---- 2. this lane's partner -------------------------------------------------------
     const int c = c0 + tid;
     const bool valid = c < a.n_cols;
     const int pid = a.col_ids ? a.col_ids[valid ? c : 0] : a.col_begin + (valid ? c : 0);
@@ -244,43 +212,28 @@ __global__ __launch_bounds__(256) void lcs_rows_kernel(RowsArgs a)
     const int my_chunks = (int)((len_p + 15) >> 4);
     const int wave_chunks = wave_max(my_chunks);
 
-    // ---- 3. RG refs at a time ---------------------------------------------------------
-    for (int g = 0; g < nr; g += RG) {
-        uint32_t X[RG][H];
+    for (int r = 0; r < nr; ++r) {
+        uint32_t X[H];
 #pragma unroll
-        for (int r = 0; r < RG; ++r)
-#pragma unroll
-            for (int j = 0; j < H; ++j)
-                X[r][j] = ~0u;
-
-        const lds_u8* grp = (const lds_u8*)smem + g * (W * 256);
-        uint4 q = make_uint4(PAD4, PAD4, PAD4, PAD4);
-        if (0 < my_chunks)
-            q = *(const uint4*)pbase;
+        for (int j = 0; j < H; ++j)
+            X[j] = ~0u;
+        const lds_u8* masks = (const lds_u8*)smem + r * (W * 256);
         for (int k = 0; k < wave_chunks; ++k) {
-            uint4 qn = make_uint4(PAD4, PAD4, PAD4, PAD4);
-            if (k + 1 < my_chunks)
-                qn = *(const uint4*)(pbase + (size_t)(k + 1) * 1024);
+            uint4 q = make_uint4(PAD4, PAD4, PAD4, PAD4);
+            if (k < my_chunks)
+                q = *(const uint4*)(pbase + (size_t)k * 1024);
             const uint32_t w[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
-            for (int b = 0; b < 16; ++b) {
-                const uint32_t code8 = (w[b >> 2] >> (8 * (b & 3))) & 0xFFu;
-                residue_step<H, RG, QUIRK>(grp + code8, X);
-            }
-            q = qn;
+            for (int b = 0; b < 16; ++b)
+                literal_step<W>(masks + ((w[b >> 2] >> (8 * (b & 3))) & 0xFFu), X, 0u);
         }
-
-        // result = number of zero bits (reference lcsbp_classic.h:60-65)
+        if (!valid)
+            continue;
+        uint32_t res = 0; // number of zero bits (reference lcsbp_classic.h:60-65)
 #pragma unroll
-        for (int r = 0; r < RG; ++r) {
-            if (g + r >= nr || !valid)
-                continue;
-            uint32_t res = 0;
-#pragma unroll
-            for (int j = 0; j < H; ++j)
-                res += __popc(~X[r][j]);
-            store_result(a, ref0 + g + r, c, res);
-        }
+        for (int j = 0; j < H; ++j)
+            res += __popc(~X[j]);
+        store_result(a, ref0 + r, c, res);
     }
 }
 
@@ -459,42 +412,6 @@ __global__ __launch_bounds__(256) void lcs_rows_kernel_pipe(RowsArgs a)
 static constexpr int SEGW = 32;
 
 template <bool QUIRK>
-__device__ __forceinline__ unsigned long_step(const lds_u8* row, uint32_t (&X)[2 * SEGW], unsigned cin_bit)
-{
-    if constexpr (!QUIRK) {
-        unsigned cin = cin_bit, co;
-#pragma unroll
-        for (int j = 0; j < SEGW; ++j) {
-            const uint64_t nn = *(const lds_u64*)(row + j * 256);
-            const uint32_t n0 = (uint32_t)nn, n1 = (uint32_t)(nn >> 32);
-            uint32_t V = X[2 * j];
-            uint32_t s = __builtin_addc(V, andn(V, n0), cin, &co);
-            X[2 * j] = or_and(s, V, n0);
-            cin = co;
-            V = X[2 * j + 1];
-            s = __builtin_addc(V, andn(V, n1), cin, &co);
-            X[2 * j + 1] = or_and(s, V, n1);
-            cin = co;
-        }
-        return cin;
-    } else {
-        uint64_t cin = cin_bit;
-#pragma unroll
-        for (int j = 0; j < SEGW; ++j) {
-            const uint64_t nn = *(const lds_u64*)(row + j * 256);
-            const uint64_t V = ((uint64_t)X[2 * j + 1] << 32) | X[2 * j];
-            const uint64_t tB = V & ~nn;
-            const uint64_t V2 = V + tB + cin;
-            cin = (V2 < V) ? 1u : 0u;
-            const uint64_t Xn = V2 | (V & nn);
-            X[2 * j] = (uint32_t)Xn;
-            X[2 * j + 1] = (uint32_t)(Xn >> 32);
-        }
-        return (unsigned)cin;
-    }
-}
-
-template <bool QUIRK>
 __global__ __launch_bounds__(256) void lcs_long_kernel(RowsArgs a, uint16_t* carry, int n_chunks_max)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[]; // SEGW x 256 bytes
@@ -570,7 +487,7 @@ __global__ __launch_bounds__(256) void lcs_long_kernel(RowsArgs a, uint16_t* car
 #pragma unroll 1
                     for (int bb = 0; bb < 4; ++bb) {
                         const int b = i * 4 + bb;
-                        const unsigned co = long_step<QUIRK>((const lds_u8*)smem + (d & 0xFFu), X, (cw >> b) & 1u);
+                        const unsigned co = literal_step<SEGW>((const lds_u8*)smem + (d & 0xFFu), X, (cw >> b) & 1u);
                         cout |= co << b;
                         d >>= 8;
                     }
@@ -683,7 +600,7 @@ static hipError_t launch_one(const RowsArgs& a, dim3 grid, hipStream_t stream)
 {
     const size_t lds = (size_t)a.refs_per_block * ((H + 1) / 2) * 256;
     if constexpr (QUIRK)
-        hipLaunchKernelGGL((lcs_rows_kernel<H, RG, true>), grid, dim3(256), lds, stream, a);
+        hipLaunchKernelGGL((lcs_rows_kernel_quirk<H>), grid, dim3(256), lds, stream, a);
     else
         hipLaunchKernelGGL((lcs_rows_kernel_pipe<H, RG, LCS_LOOKAHEAD>), grid, dim3(256), lds, stream, a);
     return hipGetLastError();
