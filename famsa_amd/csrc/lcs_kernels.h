@@ -85,7 +85,6 @@ struct PrimArgs {
     uint64_t* key_id;
     uint8_t* processed;
     PrimPartial* partials;    // [2][n_blocks]
-    int32_t* state;           // [0] step, [1] workgroups finished in the current launch
     MstEdge* edges;           // [n-1]
 };
 hipError_t launch_prim(const PrimArgs& a, int elem_size, hipStream_t stream);
@@ -98,7 +97,7 @@ struct UpgmaArgs {
     uint32_t* node_index; // [n]
     float* part_d;        // [n_blocks] per-workgroup minima of the last update
     uint32_t* part_j;
-    uint32_t* sel;        // [0] Lmin, [1] Rmin, [2] error flag, [3] merge counter
+    uint32_t* sel;        // [0] Lmin, [1] Rmin, [2] error flag
     int32_t* left;        // [n-1] children of the internal nodes
     int32_t* right;
     int32_t n;

@@ -765,8 +765,7 @@ int lcsgpu_mst_prim(lcsgpu_ctx* ctx, int distance_kind, lcsgpu_mst_edge* out_edg
     auto a8 = [](size_t x) { return (x + 15) & ~(size_t)15; };
     const size_t o_keyd = 0, o_keyi = o_keyd + a8((size_t)n * 8), o_proc = o_keyi + a8((size_t)n * 8),
                  o_part = o_proc + a8((size_t)n), o_edges = o_part + a8((size_t)2 * blocks * sizeof(lcsgpu::PrimPartial)),
-                 o_qidx = o_edges + a8((size_t)(n - 1) * sizeof(lcsgpu::MstEdge)), o_state = o_qidx + a8((size_t)n * 4),
-                 total = o_state + 16;
+                 o_qidx = o_edges + a8((size_t)(n - 1) * sizeof(lcsgpu::MstEdge)), total = o_qidx + a8((size_t)n * 4);
     HIP_TRY(ctx->d_prim.reserve(total));
     char* base = (char*)ctx->d_prim.p;
     if (nq) HIP_TRY(hipMemcpyAsync(base + o_qidx, qindex.data(), (size_t)n * 4, hipMemcpyHostToDevice, L.stream));
@@ -786,7 +785,6 @@ int lcsgpu_mst_prim(lcsgpu_ctx* ctx, int distance_kind, lcsgpu_mst_edge* out_edg
     a.processed = (uint8_t*)(base + o_proc);
     a.partials = (lcsgpu::PrimPartial*)(base + o_part);
     a.edges = (lcsgpu::MstEdge*)(base + o_edges);
-    a.state = (int32_t*)(base + o_state);
     HIP_TRY(lcsgpu::launch_prim(a, elem, L.stream));
     static_assert(sizeof(lcsgpu_mst_edge) == sizeof(lcsgpu::MstEdge), "edge layout");
     HIP_TRY(hipMemcpyAsync(out_edges, a.edges, (size_t)(n - 1) * sizeof(lcsgpu_mst_edge), hipMemcpyDeviceToHost,

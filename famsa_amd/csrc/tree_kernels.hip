@@ -17,35 +17,6 @@
 
 namespace lcsgpu {
 
-// The reducers below are launch-bound loops of tiny, identical kernels (one to four per sequential
-// step, n steps).  The step index lives in device memory and is advanced by the kernels themselves,
-// so every launch has the same arguments: a chunk of the loop is captured once into a hipGraph and
-// replayed, which takes the per-launch host cost (~3.5 us eager) off the critical path.
-// `enqueue_chunk(k)` must enqueue k iterations on `stream`; iterations past the end are no-ops.
-template <class F>
-static hipError_t replay_loop(hipStream_t stream, int total_iters, int chunk, F enqueue_chunk)
-{
-    if (total_iters <= 0) return hipSuccess;
-    if (total_iters < 2 * chunk) { // short loop: not worth an instantiate
-        enqueue_chunk(total_iters);
-        return hipGetLastError();
-    }
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t exec = nullptr;
-    hipError_t e = hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal);
-    if (e != hipSuccess) return e;
-    enqueue_chunk(chunk);
-    e = hipStreamEndCapture(stream, &graph);
-    if (e != hipSuccess) return e;
-    e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-    if (e == hipSuccess)
-        for (int done = 0; done < total_iters && e == hipSuccess; done += chunk) e = hipGraphLaunch(exec, stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(stream); // the exec must outlive its replays
-    if (exec) (void)hipGraphExecDestroy(exec);
-    if (graph) (void)hipGraphDestroy(graph);
-    return e;
-}
-
 __device__ __forceinline__ bool key_less(double d1, uint64_t i1, double d2, uint64_t i2)
 {
     return d1 < d2 || (d1 == d2 && i1 < i2);
@@ -57,12 +28,8 @@ __device__ __forceinline__ uint64_t pack_ids(uint32_t a, uint32_t b) // ids_to_u
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void prim_step_kernel(PrimArgs a)
+__global__ __launch_bounds__(256) void prim_step_kernel(PrimArgs a, int step)
 {
-    // step index: advanced by the last workgroup of every launch to finish (see the end of the kernel);
-    // every workgroup of a launch has read it before any workgroup can be the last one to finish
-    const int step = a.state[0];
-    if (step >= a.n) return; // replayed past the end
     __shared__ double s_d[256];
     __shared__ uint64_t s_i[256];
     __shared__ int s_v[256];
@@ -106,7 +73,8 @@ __global__ __launch_bounds__(256) void prim_step_kernel(PrimArgs a)
         }
         __syncthreads();
     }
-    if (step < n - 1) { // (the finalising launch only records the last edge)
+    if (step >= n - 1) // the finalising launch only records the last edge
+        return;
 
     // ---- 2. relax my vertices against cur, keep my minimum ----
     const int v = blockIdx.x * 256 + tid;
@@ -172,15 +140,6 @@ __global__ __launch_bounds__(256) void prim_step_kernel(PrimArgs a)
         mine->id = s_i[0];
         mine->v = s_v[0];
     }
-    } // step < n - 1
-    // ---- 3. the last workgroup to finish advances the step for the next launch ----
-    if (tid == 0) {
-        __threadfence();
-        if (atomicAdd(&a.state[1], 1) == (int)gridDim.x - 1) {
-            a.state[1] = 0;
-            a.state[0] = step + 1;
-        }
-    }
 }
 
 __global__ void prim_init_kernel(PrimArgs a)
@@ -191,25 +150,19 @@ __global__ void prim_init_kernel(PrimArgs a)
         a.key_id[v] = 0;
         a.processed[v] = 0;
     }
-    if (v == 0) {
-        a.state[0] = 0;
-        a.state[1] = 0;
-    }
 }
 
 hipError_t launch_prim(const PrimArgs& a, int elem_size, hipStream_t stream)
 {
     const int blocks = a.n_blocks;
     hipLaunchKernelGGL(prim_init_kernel, dim3(blocks), dim3(256), 0, stream, a);
-    // n-1 relaxing launches + 1 finalising launch
-    return replay_loop(stream, a.n, 512, [&](int k) {
-        for (int i = 0; i < k; ++i) {
-            if (elem_size == 2)
-                hipLaunchKernelGGL(prim_step_kernel<uint16_t>, dim3(blocks), dim3(256), 0, stream, a);
-            else
-                hipLaunchKernelGGL(prim_step_kernel<uint32_t>, dim3(blocks), dim3(256), 0, stream, a);
-        }
-    });
+    for (int step = 0; step < a.n; ++step) { // n-1 relaxing launches + 1 finalising launch
+        if (elem_size == 2)
+            hipLaunchKernelGGL(prim_step_kernel<uint16_t>, dim3(step >= a.n - 1 ? 1 : blocks), dim3(256), 0, stream, a, step);
+        else
+            hipLaunchKernelGGL(prim_step_kernel<uint32_t>, dim3(step >= a.n - 1 ? 1 : blocks), dim3(256), 0, stream, a, step);
+    }
+    return hipGetLastError();
 }
 
 } // namespace lcsgpu
@@ -289,15 +242,11 @@ __global__ __launch_bounds__(256) void upgma_init_kernel(UpgmaArgs a)
     }
 }
 
-__global__ __launch_bounds__(1024) void upgma_select_kernel(UpgmaArgs a)
+__global__ __launch_bounds__(1024) void upgma_select_kernel(UpgmaArgs a, int it)
 {
     __shared__ float s_d[1024];
     __shared__ uint32_t s_j[1024];
     const int tid = threadIdx.x;
-    const int it = (int)a.sel[3]; // merge index, advanced at the end of this (single-workgroup) kernel
-    if (it >= a.n) return;        // replayed past the end
-    __syncthreads();
-    if (tid == 0) a.sel[3] = (uint32_t)(it + 1);
     // ---- finish merge it-1: statistics of the row that now holds the new cluster ----
     if (it > 0) {
         float bd = UPGMA_BIG;
@@ -329,10 +278,7 @@ __global__ __launch_bounds__(1024) void upgma_select_kernel(UpgmaArgs a)
         }
         __syncthreads();
     }
-    if (it >= a.n - 1) {
-        if (tid == 0) a.sel[0] = a.sel[1] = UPGMA_NONE; // nothing left to merge: later updates are no-ops
-        return;
-    }
+    if (it >= a.n - 1) return;
     // ---- pick the closest pair: first strict minimum of min_dist over the active rows ----
     float bd = UPGMA_BIG;
     uint32_t bj = UPGMA_NONE;
@@ -413,16 +359,16 @@ hipError_t launch_upgma(const UpgmaArgs& a, const void* lcs, int elem_size, cons
         hipLaunchKernelGGL(upgma_dist_kernel<uint32_t>, dim3(n - 1), dim3(256), 0, stream, (const uint32_t*)lcs, lens,
                            pow_f32, kind, n, a.D);
     hipLaunchKernelGGL(upgma_init_kernel, dim3(n), dim3(256), 0, stream, a);
-    // n-1 merges (select + update) and one finalising select; a.sel[3] (zeroed by the caller) counts them
-    return replay_loop(stream, n, 256, [&](int k) {
-        for (int i = 0; i < k; ++i) {
-            hipLaunchKernelGGL(upgma_select_kernel, dim3(1), dim3(1024), 0, stream, a);
+    for (int it = 0; it < n; ++it) {
+        hipLaunchKernelGGL(upgma_select_kernel, dim3(1), dim3(1024), 0, stream, a, it);
+        if (it < n - 1) {
             if (modified)
                 hipLaunchKernelGGL(upgma_update_kernel<true>, dim3(a.n_blocks), dim3(256), 0, stream, a);
             else
                 hipLaunchKernelGGL(upgma_update_kernel<false>, dim3(a.n_blocks), dim3(256), 0, stream, a);
         }
-    });
+    }
+    return hipGetLastError();
 }
 
 } // namespace lcsgpu
