@@ -306,3 +306,19 @@ def test_concurrent_host_threads_share_one_context(engine, oracle):
         want_t = sq[np.tril_indices(len(ids), -1)]
         for got_r, got_t in results[k]:
             assert (got_r == want_r).all() and (got_t == want_t).all(), k
+
+
+def test_degenerate_set_sizes(engine, oracle):
+    """0, 1 and 2 sequences; empty members; a call before any work exists."""
+    engine.upload_seqs([])
+    assert engine.lcs_triangle().size == 0
+    engine.upload_seqs([np.array([1, 2, 3], np.uint8)])
+    assert engine.lcs_triangle().size == 0
+    assert engine.lcs_rect((0, 1), (0, 1))[0, 0] == 3
+    assert len(engine.mst_prim(1)) == 0
+    a, b = np.array([0, 1, 2, 3, 4], np.uint8), np.array([9, 1, 2, 9], np.uint8)
+    engine.upload_seqs([a, b, np.zeros(0, np.uint8)])
+    tri = engine.lcs_triangle(dtype=np.uint32)
+    assert list(tri) == [oracle.lcs(b, a), 0, 0]
+    e = engine.mst_prim(1)
+    assert len(e) == 2 and {(int(x["from"]), int(x["to"])) for x in e} <= {(0, 1), (0, 2), (1, 2)}
