@@ -125,4 +125,27 @@ hipError_t launch_nj(const NjArgs& a, hipStream_t stream);
 hipError_t launch_float_distances(const void* lcs, int elem_size, const uint32_t* lens, const float* pow_f32, int kind,
                                   int n, float* D, hipStream_t stream);
 
+// ---- device-side CLARANS (clarans_kernels.hip) ----
+constexpr int CLARANS_MAX_MEDOIDS = 1024;
+struct ClaransArgs {
+    const float* D;      // float distance triangle over the sample members
+    float* DM;           // [n_elems * n_medoids] member-to-medoid-slot distances
+    int32_t* cand;       // [n_elems] permutation of the members; positions < n_medoids are the medoids
+    float* dn;           // [n_elems] by member: distance to the nearest medoid
+    float* ds;           //           ... to the second nearest
+    int32_t* an;         //           slot of the nearest medoid
+    int32_t* as_;        //           slot of the second nearest
+    const int32_t* draws; // pre-drawn positions xx of the steps (the position generator's output)
+    float* res_delta;    // [window] best delta of every pending step
+    int32_t* res_mm;     // [window] its medoid slot
+    float* cost_log;     // [1 + n_elems] addends of the running cost, in the reference's order
+    int32_t* state;      // [0] next draw  [1] done  [2] log length  [3] accepts  [4] arrivals  [5] cost bits  [6] error
+    int32_t n_elems, n_medoids, n_fixed, draws_len;
+};
+hipError_t launch_subset_distances(const void* lcs, int elem_size, const int32_t* ids, const uint32_t* lens,
+                                   const float* pow_f32, int kind, int n, float* D, hipStream_t stream);
+hipError_t launch_clarans_init(const ClaransArgs& a, hipStream_t stream);
+hipError_t launch_clarans_rounds(const ClaransArgs& a, int corrected, bool first_of_search, int rounds,
+                                 hipStream_t stream);
+
 } // namespace lcsgpu

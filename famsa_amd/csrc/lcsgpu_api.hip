@@ -10,7 +10,9 @@
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <mutex>
+#include <random>
 #include <string>
 #include <vector>
 
@@ -96,7 +98,8 @@ struct Lane {
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     hipEvent_t ev_done = nullptr; // blocking-sync event: host-memory calls sleep on it instead of spinning
     DevBuf d_plan, d_out, d_carry;
-    PinBuf h_plan;
+    DevBuf d_work, d_draws; // CLARANS state and its pre-drawn step positions
+    PinBuf h_plan, h_small;
     bool plan_in_flight = false;
     int last_launches = 0;
     bool timing_valid = false;
@@ -436,6 +439,17 @@ int lcsgpu_create(int device_id, lcsgpu_ctx** out_ctx)
 {
     if (!out_ctx) return fail(LCSGPU_E_INVALID, "out_ctx is NULL");
     *out_ctx = nullptr;
+    int n_lanes = 16;
+    if (const char* e = getenv("LCSGPU_LANES")) n_lanes = std::max(1, std::min(64, atoi(e)));
+    // One hardware queue per lane, so that the lanes' small kernels really overlap: the runtime's
+    // default of 4 queues makes 16 streams share them and serialises their launches (1 M-sequence
+    // MedoidTree: 4.7 s -> 2.6 s of tree stage).  Read by the HIP runtime when it initialises, i.e.
+    // effective if this is the process's first HIP call; an explicit setting by the user wins.
+    {
+        char buf[16];
+        snprintf(buf, sizeof buf, "%d", n_lanes);
+        setenv("GPU_MAX_HW_QUEUES", buf, 0);
+    }
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n <= 0)
@@ -451,8 +465,6 @@ int lcsgpu_create(int device_id, lcsgpu_ctx** out_ctx)
     lcsgpu_ctx* ctx = new (std::nothrow) lcsgpu_ctx;
     if (!ctx) return fail(LCSGPU_E_NOMEM, "out of host memory");
     ctx->device = device_id;
-    int n_lanes = 8;
-    if (const char* e = getenv("LCSGPU_LANES")) n_lanes = std::max(1, std::min(64, atoi(e)));
     ctx->lanes.resize(n_lanes);
     for (Lane& l : ctx->lanes)
         if (hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking) != hipSuccess ||
@@ -474,7 +486,10 @@ int lcsgpu_destroy(lcsgpu_ctx* ctx)
         l.d_plan.release();
         l.d_out.release();
         l.d_carry.release();
+        l.d_work.release();
+        l.d_draws.release();
         l.h_plan.release();
+        l.h_small.release();
         if (l.ev_start) (void)hipEventDestroy(l.ev_start);
         if (l.ev_stop) (void)hipEventDestroy(l.ev_stop);
         if (l.ev_done) (void)hipEventDestroy(l.ev_done);
@@ -922,6 +937,143 @@ int lcsgpu_lcs_triangle_ids(lcsgpu_ctx* ctx, const int32_t* ids, int32_t n_ids, 
     HIP_TRY(hipMemcpyAsync(out, L.d_out.p, (size_t)count * elem_size, hipMemcpyDeviceToHost, L.stream));
     HIP_TRY(hipEventRecord(L.ev_done, L.stream));
     HIP_TRY(hipEventSynchronize(L.ev_done)); // sleeps; worker threads must not burn a core per pending call
+    finish_host_call(ctx, L);
+    return LCSGPU_OK;
+}
+
+int lcsgpu_clarans(lcsgpu_ctx* ctx, const int32_t* ids, int32_t n_ids, int distance_kind, int32_t n_medoids,
+                   int32_t n_fixed, float explore_fraction, int32_t num_local, int32_t* medoids_out)
+{
+    if (!ctx) return fail(LCSGPU_E_INVALID, "NULL ctx");
+    if (ctx->n < 0) return fail(LCSGPU_E_STATE, "no sequence set uploaded");
+    if (distance_kind != LCSGPU_DIST_INDEL_DIV_LCS && distance_kind != LCSGPU_DIST_INDEL075_DIV_LCS)
+        return fail(LCSGPU_E_INVALID, "unknown distance kind %d", distance_kind);
+    if (!ids || !medoids_out || n_ids < 1) return fail(LCSGPU_E_INVALID, "bad sample / output");
+    if (n_medoids < 1 || n_medoids > n_ids || n_fixed < 0 || n_fixed >= n_medoids || num_local < 1)
+        return fail(LCSGPU_E_INVALID, "bad CLARANS shape: %d medoids (%d fixed) of %d, %d searches", n_medoids, n_fixed,
+                    n_ids, num_local);
+    for (int32_t i = 0; i < n_ids; ++i)
+        if (ids[i] < 0 || ids[i] >= ctx->n) return fail(LCSGPU_E_INVALID, "sample id %d out of range", ids[i]);
+    if (n_medoids > lcsgpu::CLARANS_MAX_MEDOIDS)
+        return fail(LCSGPU_E_UNSUPPORTED, "device CLARANS handles at most %d medoids", lcsgpu::CLARANS_MAX_MEDOIDS);
+
+    const int32_t n = n_ids, k = n_medoids;
+    // Clustering.cpp:21-29: how many non-improving steps end a local search
+    const int n_swaps = (n - k) * k;
+    const int min_max_neighbor = 250;
+    const int max_neighbor = n_swaps < min_max_neighbor
+                                 ? n_swaps
+                                 : std::max((int)(explore_fraction * n_swaps), min_max_neighbor);
+    const int corrected = max_neighbor / k;
+
+    LaneGuard guard(ctx, LaneGuard::ANY);
+    Lane& L = guard.lane();
+    HIP_TRY(hipSetDevice(ctx->device));
+    const int elem = ctx->max_len > 65535 ? 4 : 2;
+    const size_t pairs = (size_t)n * (n - 1) / 2;
+    auto a256 = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t window = (size_t)std::max(corrected, 1);
+    const size_t o_D = 0, o_DM = o_D + a256(pairs * 4), o_cand = o_DM + a256((size_t)n * k * 4),
+                 o_dn = o_cand + a256((size_t)n * 4), o_ds = o_dn + a256((size_t)n * 4), o_an = o_ds + a256((size_t)n * 4),
+                 o_as = o_an + a256((size_t)n * 4), o_rd = o_as + a256((size_t)n * 4), o_rm = o_rd + a256(window * 4),
+                 o_log = o_rm + a256(window * 4), o_state = o_log + a256((size_t)(n + 1) * 4), o_ids = o_state + 256,
+                 total = o_ids + a256((size_t)n * 4);
+    HIP_TRY(L.d_work.reserve(total));
+    HIP_TRY(L.h_small.reserve(64));
+    char* base = (char*)L.d_work.p;
+    HIP_TRY(hipMemsetAsync(base + o_state, 0, 256, L.stream));
+    HIP_TRY(hipMemcpyAsync(base + o_ids, ids, (size_t)n * 4, hipMemcpyHostToDevice, L.stream));
+    if (pairs > 0) {
+        HIP_TRY(L.d_out.reserve(pairs * elem));
+        int rc = run_rows(ctx, L, lcsgpu::MODE_TRIANGLE, ids, 0, n, ids, 0, n - 1, L.d_out.p, 0, 0, elem, 0);
+        if (rc) return rc;
+        HIP_TRY(lcsgpu::launch_subset_distances(L.d_out.p, elem, (const int32_t*)(base + o_ids),
+                                                (const uint32_t*)ctx->d_lens.p, (const float*)ctx->d_powf.p,
+                                                distance_kind, n, (float*)(base + o_D), L.stream));
+    }
+    lcsgpu::ClaransArgs a{};
+    a.D = (const float*)(base + o_D);
+    a.DM = (float*)(base + o_DM);
+    a.cand = (int32_t*)(base + o_cand);
+    a.dn = (float*)(base + o_dn);
+    a.ds = (float*)(base + o_ds);
+    a.an = (int32_t*)(base + o_an);
+    a.as_ = (int32_t*)(base + o_as);
+    a.res_delta = (float*)(base + o_rd);
+    a.res_mm = (int32_t*)(base + o_rm);
+    a.cost_log = (float*)(base + o_log);
+    a.state = (int32_t*)(base + o_state);
+    a.n_elems = n;
+    a.n_medoids = k;
+    a.n_fixed = n_fixed;
+
+    // The two generators of Clustering.cpp:43-44.  Neither looks at the search state, so the host
+    // runs them: gen_nodes shuffles the candidate order before every local search, gen_positions
+    // yields the step positions, handed to the device as a growing array of draws.
+    std::mt19937 gen_nodes, gen_positions;
+    std::vector<int32_t> cand(n), draws;
+    for (int32_t i = 0; i < n; ++i) cand[i] = i;
+    const uint32_t diff = (uint32_t)(n - k); // det_uniform_int_distribution<int>(n_medoids, n_elems - 1)
+    const uint32_t bad = diff ? 0xffffffffu / diff : 0;
+    auto extend_draws = [&](size_t want) -> int {
+        if (draws.size() >= want) return LCSGPU_OK;
+        const size_t old = draws.size();
+        want = std::max(want, old * 2);
+        draws.reserve(want);
+        while (draws.size() < want) {
+            const uint32_t r = gen_positions();
+            if (r / diff < bad) draws.push_back((int32_t)(r % diff) + k); // deterministic_random.h:62-76
+        }
+        const bool regrow = L.d_draws.cap < want * 4;
+        HIP_TRY(L.d_draws.reserve(want * 4));
+        const size_t from = regrow ? 0 : old;
+        HIP_TRY(hipMemcpyAsync((int32_t*)L.d_draws.p + from, draws.data() + from, (draws.size() - from) * 4,
+                               hipMemcpyHostToDevice, L.stream));
+        return LCSGPU_OK;
+    };
+    const int batch = 48; // rounds enqueued between two looks at the done flag
+    int32_t* h_state = (int32_t*)L.h_small.p;
+    float best_cost = std::numeric_limits<float>::max();
+    int32_t p_host = 0;
+    for (int iter = 0; iter < num_local; ++iter) {
+        // partial_shuffle(candidate + n_fixed, candidate + n, candidate + n, gen_nodes), deterministic_random.h:113-127
+        {
+            int32_t* first = cand.data() + n_fixed;
+            const long cnt = n - n_fixed, N = cnt - 1;
+            for (long i = 0; i < cnt; ++i) {
+                const unsigned long d = (unsigned long)N - (unsigned long)i + 1;
+                const unsigned long r = (unsigned long)gen_nodes(); // < 2^32: never in the rejected tail of a 64-bit range
+                std::swap(first[i], first[(r % d) + (unsigned long)i]);
+            }
+        }
+        HIP_TRY(hipMemcpyAsync(a.cand, cand.data(), (size_t)n * 4, hipMemcpyHostToDevice, L.stream));
+        HIP_TRY(lcsgpu::launch_clarans_init(a, L.stream));
+        bool first = true;
+        for (;;) {
+            if (diff) {
+                int rc = extend_draws((size_t)p_host + (size_t)batch * std::max(corrected, 1));
+                if (rc) return rc;
+            }
+            a.draws = (const int32_t*)L.d_draws.p;
+            a.draws_len = (int32_t)draws.size();
+            HIP_TRY(lcsgpu::launch_clarans_rounds(a, corrected, first, batch, L.stream));
+            first = false;
+            HIP_TRY(hipMemcpyAsync(h_state, a.state, 32, hipMemcpyDeviceToHost, L.stream));
+            HIP_TRY(hipEventRecord(L.ev_done, L.stream));
+            HIP_TRY(hipEventSynchronize(L.ev_done));
+            L.plan_in_flight = false;
+            if (h_state[6]) return fail(LCSGPU_E_STATE, "CLARANS: the device search ran out of pre-drawn steps");
+            p_host = h_state[0];
+            if (h_state[1]) break;
+        }
+        float cost;
+        memcpy(&cost, &h_state[5], 4);
+        HIP_TRY(hipMemcpy(cand.data(), a.cand, (size_t)n * 4, hipMemcpyDeviceToHost));
+        if (cost < best_cost) {
+            best_cost = cost;
+            std::copy(cand.begin(), cand.begin() + k, medoids_out);
+        }
+    }
     finish_host_call(ctx, L);
     return LCSGPU_OK;
 }

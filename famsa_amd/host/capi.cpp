@@ -137,4 +137,16 @@ int famsa_host_dist_export_gpu(const char* fasta, int device, int distance, int 
 
 int famsa_host_format_distance(double v, char* out) { return format_distance(v, out); }
 
+// The host CLARANS search over a caller-supplied float distance triangle (tests compare the device search with it).
+int famsa_host_clarans(const float* triangle, int n_elems, int n_medoids, int n_fixed, float explore_fraction,
+                       int num_local, int* medoids)
+{
+    try {
+        clarans_host(triangle, n_elems, n_medoids, n_fixed, explore_fraction, num_local, medoids);
+        return 0;
+    } catch (const std::exception& e) {
+        return fail(e);
+    }
+}
+
 } // extern "C"

@@ -12,6 +12,8 @@
 
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <functional>
 #include <cstdio>
 #include <cstdlib>
 #include <mutex>
@@ -118,7 +120,9 @@ struct Clarans {
                                   assign_nearest[x], assign_second[x]);
                 cost += dists_nearest[x];
             }
+            long n_steps = 0, n_improved = 0;
             for (int step = 0; step < corrected; ++step) {
+                ++n_steps;
                 const int xx = (int)det_uniform<unsigned int>(gen_positions, n_medoids, n_elems - 1);
                 const int x = candidate[xx];
                 std::fill_n(deltas.begin(), n_medoids, 0.0f);
@@ -182,8 +186,11 @@ struct Clarans {
                     }
                     std::swap(current[mm_new], current[xx]);
                     step = 0; // the for-increment makes the next step 1, as in the reference
+                    ++n_improved;
                 }
             }
+            if (getenv("FAMSA_CLARANS_TRACE"))
+                fprintf(stderr, "clarans n=%d k=%d corrected=%d steps=%ld improved=%ld\n", n_elems, n_medoids, corrected, n_steps, n_improved);
             if (cost < best_cost) {
                 best_cost = cost;
                 std::copy_n(current.begin(), n_medoids, medoids);
@@ -199,6 +206,7 @@ public:
     int n() const override { return (int)ids_.size(); }
     uint32_t length(int i) const override { return p_.length(ids_[i]); }
     bool orientation_sensitive() const override { return p_.orientation_sensitive(); }
+    bool wide() const override { return p_.wide(); }
     void triangle(int r0, int r1, LcsBuf& out) override
     {
         const size_t off = (size_t)r0 * (r0 > 0 ? r0 - 1 : 0) / 2;
@@ -225,28 +233,102 @@ public:
         for (int i = 0; i < n_cols; ++i) c[i] = ids_[cols ? cols[i] : i];
         p_.rect(r.data(), n_refs, c.data(), n_cols, out);
     }
+    bool clarans(const int* ids, int n_ids, int kind, int n_medoids, int n_fixed, float fraction, int num_local,
+                 int* medoids) override
+    {
+        std::vector<int> g(n_ids);
+        for (int i = 0; i < n_ids; ++i) g[i] = ids_[ids[i]];
+        return p_.clarans(g.data(), n_ids, kind, n_medoids, n_fixed, fraction, num_local, medoids);
+    }
 
 private:
     LcsSource& p_;
     const std::vector<int>& ids_;
 };
 
-// Worker threads are a shared budget: a split at ANY depth may take idle threads for its
-// sub-trees (the reference parallelises the top-level split only, which leaves one thread to grind
-// through a dominant cluster; results do not depend on who computes a sub-tree).
-struct ThreadBudget {
-    std::atomic<int> free{0};
-    int acquire(int want)
+// Sub-trees are independent, so every split at ANY depth hands its sub-trees to one shared pool
+// (largest first) and then works the pool itself until its own sub-trees are finished.  The
+// reference parallelises the top-level split only, which leaves one thread to grind through a
+// dominant cluster; results do not depend on who builds a sub-tree or when.
+class TaskPool {
+public:
+    explicit TaskPool(int n_threads)
     {
-        int got = 0;
-        while (got < want) {
-            int cur = free.load();
-            if (cur <= 0) break;
-            if (free.compare_exchange_weak(cur, cur - 1)) ++got;
-        }
-        return got;
+        for (int w = 1; w < n_threads; ++w)
+            workers_.emplace_back([this] {
+                std::unique_lock<std::mutex> lk(mu_);
+                for (;;) {
+                    cv_.wait(lk, [this] { return stop_ || !q_.empty(); });
+                    if (stop_) return;
+                    run_top(lk);
+                }
+            });
     }
-    void release(int k) { free.fetch_add(k); }
+    ~TaskPool()
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (auto& w : workers_) w.join();
+    }
+    // A batch of tasks whose completion one caller waits for.
+    struct Group {
+        int remaining = 0;
+        std::string error;
+    };
+    void submit(Group& g, size_t weight, std::function<void()> fn)
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            ++g.remaining;
+            q_.push_back(Item{weight, seq_++, &g, std::move(fn)});
+            std::push_heap(q_.begin(), q_.end());
+        }
+        cv_.notify_one();
+    }
+    // Work the pool (any group's tasks) until every task of `g` has finished.
+    void wait(Group& g)
+    {
+        std::unique_lock<std::mutex> lk(mu_);
+        while (g.remaining > 0) {
+            if (!q_.empty()) run_top(lk);
+            else cv_.wait(lk, [&] { return g.remaining == 0 || !q_.empty(); });
+        }
+        if (!g.error.empty()) throw std::runtime_error(g.error);
+    }
+
+private:
+    struct Item {
+        size_t weight;
+        uint64_t seq;
+        Group* group;
+        std::function<void()> fn;
+        bool operator<(const Item& o) const { return weight != o.weight ? weight < o.weight : seq > o.seq; }
+    };
+    void run_top(std::unique_lock<std::mutex>& lk)
+    { // called with the lock held; runs the heaviest queued task unlocked
+        std::pop_heap(q_.begin(), q_.end());
+        Item it = std::move(q_.back());
+        q_.pop_back();
+        lk.unlock();
+        std::string err;
+        try {
+            it.fn();
+        } catch (const std::exception& e) {
+            err = e.what();
+        }
+        lk.lock();
+        if (!err.empty() && it.group->error.empty()) it.group->error = err;
+        if (--it.group->remaining == 0) cv_.notify_all();
+    }
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::vector<Item> q_;
+    std::vector<std::thread> workers_;
+    uint64_t seq_ = 0;
+    bool stop_ = false;
 };
 
 template <Distance D>
@@ -254,7 +336,7 @@ struct FastTree {
     LcsSource& src;
     GT partial;
     FastTreeParams prm;
-    ThreadBudget* budget;
+    TaskPool* pool;
     Transform<float, D> transform; // FastTree uses float distances throughout
 
     // distances of subset member `ref_local` to every member: calculateDistanceVector(ref, all)
@@ -305,21 +387,27 @@ struct FastTree {
             sample_global.resize(n_samples);
             for (int j = 0; j < n_samples; ++j) sample_global[j] = ids[sample_ids[j]];
         }
-        // sample distance matrix: calculateDistanceMatrix over the samples (float)
-        std::vector<float> dist((size_t)n_samples * (n_samples - 1) / 2);
-        {
-            SubsetSource sub(src, sample_global);
-            LcsBuf buf;
-            {
-                Scope t(g_phase.lcs);
-                sub.triangle(0, n_samples, buf);
-            }
-            for (int i = 1; i < n_samples; ++i)
-                for (int j = 0; j < i; ++j)
-                    dist[tri(i, j)] = transform(buf[tri(i, j)], sub.length(i), sub.length(j));
-        }
         seed_ids.assign(n_seeds, 0);
-        {
+        bool on_device;
+        {   // sample matrix + CLARANS inside the engine when it offers that
+            Scope t(g_phase.clarans);
+            on_device = src.clarans(sample_global.data(), n_samples, (int)D, n_seeds, 1, prm.cluster_fraction,
+                                    prm.cluster_iters, seed_ids.data());
+        }
+        if (!on_device) {
+            // sample distance matrix: calculateDistanceMatrix over the samples (float)
+            std::vector<float> dist((size_t)n_samples * (n_samples - 1) / 2);
+            {
+                SubsetSource sub(src, sample_global);
+                LcsBuf buf;
+                {
+                    Scope t(g_phase.lcs);
+                    sub.triangle(0, n_samples, buf);
+                }
+                for (int i = 1; i < n_samples; ++i)
+                    for (int j = 0; j < i; ++j)
+                        dist[tri(i, j)] = transform(buf[tri(i, j)], sub.length(i), sub.length(j));
+            }
             Scope t(g_phase.clarans);
             Clarans{prm.cluster_fraction, prm.cluster_iters}(dist.data(), n_samples, n_seeds, 1, seed_ids.data());
         }
@@ -434,38 +522,19 @@ struct FastTree {
                 for (size_t i = 0; i < std::min<size_t>(6, sz.size()); ++i) fprintf(stderr, " %zu", sz[i]);
                 fprintf(stderr, "\n");
             }
-            std::atomic<size_t> next{0};
-            std::mutex err_mu;
-            std::string error;
-            auto run = [&](FastTree<D>& ft) {
-                try {
-                    for (size_t t = next++; t < tasks.size(); t = next++) {
-                        const auto t0 = std::chrono::steady_clock::now();
-                        ft.do_step(subgroups[tasks[t].k], locals[t], tasks[t].top, false);
-                        const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-                        if (parallel && dt > 2.0 && getenv("FAMSA_GPU_PROFILE"))
-                            fprintf(stderr, "fasttree.slow_task size=%zu wall=%.2f\n", subgroups[tasks[t].k].size(), dt);
-                    }
-                } catch (const std::exception& e) {
-                    std::lock_guard<std::mutex> lk(err_mu);
-                    if (error.empty()) error = e.what();
-                    next = tasks.size();
-                }
-            };
-            // helpers only when the split is big enough to amortise them
-            const int want = (budget && n >= 4 * std::max(prm.threshold, prm.subtree_size) && tasks.size() > 1)
-                                 ? (int)tasks.size() - 1 : 0;
-            const int extra = want > 0 ? budget->acquire(want) : 0;
-            std::vector<std::thread> helpers;
-            for (int w = 0; w < extra; ++w)
-                helpers.emplace_back([&] {
-                    FastTree<D> child{src, partial, prm, budget, {}};
-                    run(child);
-                });
-            run(*this);
-            for (auto& h : helpers) h.join();
-            if (extra) budget->release(extra);
-            if (!error.empty()) throw std::runtime_error(error);
+            // sub-trees only go through the pool when the split is big enough to amortise it
+            if (pool && tasks.size() > 1 && n >= 2 * std::max(prm.threshold, prm.subtree_size)) {
+                TaskPool::Group group;
+                for (size_t t = 0; t < tasks.size(); ++t)
+                    pool->submit(group, subgroups[tasks[t].k].size(), [this, t, &tasks, &subgroups, &locals] {
+                        FastTree<D> child{src, partial, prm, pool, {}};
+                        child.do_step(subgroups[tasks[t].k], locals[t], tasks[t].top, false);
+                    });
+                pool->wait(group);
+            } else {
+                for (size_t t = 0; t < tasks.size(); ++t)
+                    do_step(subgroups[tasks[t].k], locals[t], tasks[t].top, false);
+            }
             for (const auto& lt : locals) tree.insert(tree.end(), lt.begin(), lt.end());
             if (parallel && getenv("FAMSA_GPU_PROFILE"))
                 fprintf(stderr, "fasttree.top_subtrees_wall=%.3f\n",
@@ -494,9 +563,8 @@ void run_fast(LcsSource& src, GT partial, const FastTreeParams& p, tree_structur
     const int n = src.n();
     tree.assign(n, node_t(-1, -1));
     if (n < 2) return;
-    ThreadBudget budget;
-    budget.free = std::max(0, p.n_threads - 1);
-    FastTree<D> ft{src, partial, p, &budget, {}};
+    TaskPool pool(std::max(1, p.n_threads));
+    FastTree<D> ft{src, partial, p, &pool, {}};
     std::vector<int> ids(n);
     std::iota(ids.begin(), ids.end(), 0);
     tree_structure local;
@@ -505,6 +573,12 @@ void run_fast(LcsSource& src, GT partial, const FastTreeParams& p, tree_structur
 }
 
 } // namespace
+
+void clarans_host(const float* distances, int n_elems, int n_medoids, int n_fixed, float explore_fraction, int num_local,
+                  int* medoids)
+{
+    Clarans{explore_fraction, num_local}(distances, n_elems, n_medoids, n_fixed, medoids);
+}
 
 void build_tree_fast(LcsSource& src, GT partial, Distance dist, const FastTreeParams& p, tree_structure& tree)
 {

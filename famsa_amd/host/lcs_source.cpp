@@ -40,9 +40,10 @@ GpuLcsSource::~GpuLcsSource()
 {
     if (getenv("FAMSA_GPU_PROFILE"))
         fprintf(stderr, "engine.rect: %ld calls %.3f thread-s %.3g pairs\nengine.triangle: %ld calls %.3f thread-s %.3g pairs\n"
-                        "engine.triangle_ids: %ld calls %.3f thread-s %.3g pairs\n",
+                        "engine.triangle_ids: %ld calls %.3f thread-s %.3g pairs\nengine.clarans: %ld calls %.3f thread-s %.3g pairs\n",
                 st_rect_.calls, st_rect_.seconds, st_rect_.pairs, st_tri_.calls, st_tri_.seconds, st_tri_.pairs,
-                st_triids_.calls, st_triids_.seconds, st_triids_.pairs);
+                st_triids_.calls, st_triids_.seconds, st_triids_.pairs, st_clarans_.calls, st_clarans_.seconds,
+                st_clarans_.pairs);
     if (ctx_) lcsgpu_destroy(ctx_);
 }
 
@@ -68,6 +69,7 @@ void GpuLcsSource::upload(const std::vector<uint8_t>& codes, const std::vector<u
     check(lcsgpu_upload(ctx_, codes.data(), offsets.data(), n), "lcsgpu_upload");
     lens_.resize(n);
     for (int i = 0; i < n; ++i) lens_[i] = (uint32_t)(offsets[i + 1] - offsets[i]);
+    wide_ = LcsSource::wide();
     std::vector<uint8_t> flags(n ? n : 1);
     int32_t nq = lcsgpu_orientation_flags(ctx_, flags.data());
     if (nq < 0) check(nq, "lcsgpu_orientation_flags");
@@ -143,9 +145,24 @@ bool GpuLcsSource::nj_nodes(int distance_kind, std::vector<int32_t>& left, std::
     return true;
 }
 
+bool GpuLcsSource::clarans(const int* ids, int n_ids, int distance_kind, int n_medoids, int n_fixed,
+                           float explore_fraction, int num_local, int* medoids)
+{
+    static const bool host_search = getenv("FAMSA_CLARANS_HOST") != nullptr; // A/B aid: keep the search on the host
+    if (host_search) return false;
+    const double t0 = now_s();
+    const int rc = lcsgpu_clarans(ctx_, ids, n_ids, distance_kind, n_medoids, n_fixed, explore_fraction, num_local, medoids);
+    if (rc == LCSGPU_E_UNSUPPORTED) return false;
+    check(rc, "lcsgpu_clarans");
+    note(st_clarans_, now_s() - t0, (double)n_ids * (n_ids - 1) / 2);
+    add_kernel_ms();
+    return true;
+}
+
 MatrixLcsSource::MatrixLcsSource(int n, const uint32_t* lens, const uint32_t* square)
     : n_(n), lens_(lens, lens + n), m_(square, square + (size_t)n * n), sensitive_(false)
 {
+    wide_ = LcsSource::wide();
     for (int i = 0; i < n && !sensitive_; ++i)
         for (int j = 0; j < i; ++j)
             if (m_[(size_t)i * n + j] != m_[(size_t)j * n + i]) {

@@ -43,7 +43,8 @@ public:
     virtual void rect(const int* refs, int n_refs, const int* cols, int n_cols, LcsBuf& out) = 0;
     // lower triangle over an id list: out[k*(k-1)/2 + c] = LCS(ref = ids[k], partner = ids[c]), c < k
     virtual void triangle_ids(const int* ids, int n_ids, LcsBuf& out);
-    bool wide() const;
+    // values need 32 bits (some sequence longer than 65535 residues); sources cache this
+    virtual bool wide() const;
     // Prim's MST computed by the source itself (the GPU engine does it on the device): n-1 edges
     // (from < to, distance) in the order they are added from vertex 0.  Returns false if the
     // source cannot (then the caller runs Prim on the host over triangle()/rect()).
@@ -55,6 +56,10 @@ public:
     virtual bool upgma_nodes(int /*distance_kind*/, bool /*modified*/, std::vector<int32_t>& /*left*/,
                              std::vector<int32_t>& /*right*/) { return false; }
     virtual bool nj_nodes(int /*distance_kind*/, std::vector<int32_t>& /*left*/, std::vector<int32_t>& /*right*/) { return false; }
+    // CLARANS k-medoids over the sample `ids` computed by the source itself (device): medoids[k] =
+    // member numbers 0..n_ids-1.  False = not offered for this shape; the caller runs the host search.
+    virtual bool clarans(const int* /*ids*/, int /*n_ids*/, int /*distance_kind*/, int /*n_medoids*/, int /*n_fixed*/,
+                         float /*explore_fraction*/, int /*num_local*/, int* /*medoids*/) { return false; }
 };
 
 // The MI355X engine.  Throws std::runtime_error if the library reports an error (no fallback).
@@ -66,12 +71,15 @@ public:
     int n() const override { return (int)lens_.size(); }
     uint32_t length(int i) const override { return lens_[i]; }
     bool orientation_sensitive() const override { return sensitive_; }
+    bool wide() const override { return wide_; }
     void triangle(int r0, int r1, LcsBuf& out) override;
     void rect(const int* refs, int n_refs, const int* cols, int n_cols, LcsBuf& out) override;
     void triangle_ids(const int* ids, int n_ids, LcsBuf& out) override;
     bool prim_edges(int distance_kind, std::vector<MstEdge>& edges, bool triangle_orientation) override;
     bool upgma_nodes(int distance_kind, bool modified, std::vector<int32_t>& left, std::vector<int32_t>& right) override;
     bool nj_nodes(int distance_kind, std::vector<int32_t>& left, std::vector<int32_t>& right) override;
+    bool clarans(const int* ids, int n_ids, int distance_kind, int n_medoids, int n_fixed, float explore_fraction,
+                 int num_local, int* medoids) override;
     double kernel_ms_total() const { return kernel_ms_; }
     void add_kernel_ms();
 
@@ -79,11 +87,11 @@ private:
     void check(int rc, const char* what);
     lcsgpu_ctx* ctx_ = nullptr;
     std::vector<uint32_t> lens_;
-    bool sensitive_ = false;
+    bool sensitive_ = false, wide_ = false;
     double kernel_ms_ = 0;
     std::mutex mu_; // the tree builders may call from several threads
     // call statistics (printed at destruction when FAMSA_GPU_PROFILE is set)
-    struct CallStat { long calls = 0; double seconds = 0; double pairs = 0; } st_rect_, st_tri_, st_triids_;
+    struct CallStat { long calls = 0; double seconds = 0; double pairs = 0; } st_rect_, st_tri_, st_triids_, st_clarans_;
     void note(CallStat& s, double sec, double pairs);
 };
 
@@ -94,13 +102,14 @@ public:
     int n() const override { return n_; }
     uint32_t length(int i) const override { return lens_[i]; }
     bool orientation_sensitive() const override { return sensitive_; }
+    bool wide() const override { return wide_; }
     void triangle(int r0, int r1, LcsBuf& out) override;
     void rect(const int* refs, int n_refs, const int* cols, int n_cols, LcsBuf& out) override;
 
 private:
     int n_;
     std::vector<uint32_t> lens_, m_;
-    bool sensitive_;
+    bool sensitive_, wide_ = false;
 };
 
 } // namespace famsa_host

@@ -44,6 +44,9 @@ struct FastTreeParams { // CParams::medoid, reference core/params.h:88-97
     int n_threads = 1; // worker threads for the sub-trees of the top-level split
 };
 void build_tree_fast(LcsSource& src, GT partial, Distance dist, const FastTreeParams& p, tree_structure& tree);
+// the host form of the CLARANS search (used when the LcsSource does not run it itself)
+void clarans_host(const float* distances, int n_elems, int n_medoids, int n_fixed, float explore_fraction, int num_local,
+                  int* medoids);
 
 // GuideTree::fromUnique (reference tree/GuideTree.cpp:146-208): re-attach removed duplicates.
 void tree_from_unique(tree_structure& tree, const std::vector<int>& sorted2unique);

@@ -55,6 +55,7 @@ def load_library():
         "lcsgpu_mst_prim": (C.c_int, [vp, C.c_int, vp]),
         "lcsgpu_upgma": (C.c_int, [vp, C.c_int, C.c_int, vp, vp]),
         "lcsgpu_nj": (C.c_int, [vp, C.c_int, vp, vp]),
+        "lcsgpu_clarans": (C.c_int, [vp, pi32, i32, C.c_int, i32, i32, C.c_float, i32, pi32]),
         "lcsgpu_sync": (C.c_int, [vp]),
         "lcsgpu_last_kernel_ms": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(i32)]),
         "lcsgpu_total_kernel_ms": (C.c_int, [vp, C.POINTER(C.c_double)]),
@@ -188,6 +189,14 @@ class LcsGpu:
         right = np.zeros(max(self.n - 1, 1), dtype=np.int32)
         self._check(self._lib.lcsgpu_upgma(self._ctx, kind, int(modified), left.ctypes.data, right.ctypes.data))
         return left[: max(self.n - 1, 0)], right[: max(self.n - 1, 0)]
+
+    def clarans(self, ids, n_medoids, n_fixed=1, explore_fraction=0.1, num_local=2, kind=1):
+        """CLARANS medoids (member numbers within `ids`) of the sample `ids`, computed on the device."""
+        arr, ptr = _ids(ids)
+        out = np.zeros(max(n_medoids, 1), dtype=np.int32)
+        self._check(self._lib.lcsgpu_clarans(self._ctx, ptr, len(arr), kind, n_medoids, n_fixed, explore_fraction,
+                                             num_local, out.ctypes.data_as(C.POINTER(C.c_int32))))
+        return out[:n_medoids]
 
     def sync(self):
         self._check(self._lib.lcsgpu_sync(self._ctx))

@@ -42,6 +42,7 @@ extern "C" {
 #define LCSGPU_E_HIP (-3)      /* a HIP call failed; see lcsgpu_last_error() */
 #define LCSGPU_E_NOMEM (-4)
 #define LCSGPU_E_STATE (-5)    /* e.g. compute before upload */
+#define LCSGPU_E_UNSUPPORTED (-6) /* shape outside what a device reducer handles; the host form applies */
 
 typedef struct lcsgpu_ctx lcsgpu_ctx;
 
@@ -188,6 +189,20 @@ int lcsgpu_upgma(lcsgpu_ctx* ctx, int distance_kind, int modified, int32_t* out_
  * Replaces: calculateDistanceMatrix (single-threaded in the reference, NeighborJoining.cpp:16) +
  * NeighborJoining::computeTree. */
 int lcsgpu_nj(lcsgpu_ctx* ctx, int distance_kind, int32_t* out_left, int32_t* out_right);
+
+/* CLARANS k-medoids over a sample of the uploaded set, on the device: LCS triangle over `ids`
+ * (ref = ids[i], partner = ids[j], j < i) -> float distances (Transform<float>) -> `num_local`
+ * local searches, each the reference's swap search with its two mt19937 streams, its float
+ * operation order, comparison directions and tie rules, so the medoids are the reference's.
+ * ids (HOST, n_ids entries): the sample in the caller's order (the order defines the member
+ * numbers the result refers to).  medoids_out (HOST, n_medoids entries): member numbers 0..n_ids-1
+ * of the chosen medoids, slot order; slots < n_fixed are never swapped (the reference pins member 0).
+ * Returns LCSGPU_E_UNSUPPORTED when the shape is outside what the device search handles
+ * (n_medoids > 1024): the caller then runs its own host search.
+ * Replaces: the sample matrix + CLARANS::operator() in FastTree::clusterSeeds
+ * (tree/FastTree.cpp:412-417, tree/Clustering.cpp:17-305). */
+int lcsgpu_clarans(lcsgpu_ctx* ctx, const int32_t* ids, int32_t n_ids, int distance_kind, int32_t n_medoids,
+                   int32_t n_fixed, float explore_fraction, int32_t num_local, int32_t* medoids_out);
 
 /* Block until everything queued on the context's stream has finished. */
 int lcsgpu_sync(lcsgpu_ctx* ctx);

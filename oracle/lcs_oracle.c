@@ -222,7 +222,7 @@ float oracle_dist_indel075_f32(uint32_t lcs, uint32_t len1, uint32_t len2)
 {
     uint32_t indel = len1 + len2 - 2 * lcs;
     if (lcs == 0)
-        return nextafterf(FLT_MAX, 0.0f);
+        return (float)nextafter((double)FLT_MAX, 0.0); /* hpp:61: the int 0 promotes both operands to double */
     float p = (float)pow((double)indel, 0.75);
     return p / (float)lcs;
 }
@@ -240,8 +240,19 @@ float oracle_dist_indel_f32(uint32_t lcs, uint32_t len1, uint32_t len2)
 {
     uint32_t indel = len1 + len2 - 2 * lcs;
     if (lcs == 0)
-        return nextafterf(FLT_MAX, 0.0f);
+        return (float)nextafter((double)FLT_MAX, 0.0);
     return (float)indel / (float)lcs;
+}
+
+/* calculateDistanceMatrix<.., float, ..> (hpp:378-398) from an LCS triangle: out[i(i-1)/2 + j],
+ * ref = i, partner = j < i.  kind 0 = indel_div_lcs, 1 = indel075_div_lcs. */
+void oracle_dist_triangle_f32(const uint32_t *lcs, const uint32_t *lens, int32_t n, int kind, float *out)
+{
+    size_t k = 0;
+    for (int32_t i = 1; i < n; ++i)
+        for (int32_t j = 0; j < i; ++j, ++k)
+            out[k] = kind == 1 ? oracle_dist_indel075_f32(lcs[k], lens[i], lens[j])
+                               : oracle_dist_indel_f32(lcs[k], lens[i], lens[j]);
 }
 
 /* Transform<float, pairwise_identity>, hpp:77-82: (float)lcs / min(len1,len2). */

@@ -348,4 +348,12 @@ double ref_time_triangle(void* h, int n_use, int n_threads, int isa, double* pai
     return std::chrono::duration<double>(t1 - t0).count();
 }
 
+// The reference's CLARANS (tree/Clustering.cpp) over a caller-supplied float triangle.
+void ref_clarans(const float* triangle, int n_elems, int n_medoids, int n_fixed, float explore_fraction, int num_local,
+                 int* medoids)
+{
+    CLARANS search(explore_fraction, num_local);
+    search(triangle, n_elems, n_medoids, n_fixed, medoids);
+}
+
 } // extern "C"

@@ -28,4 +28,4 @@ cli = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 
 args = sys.argv[3:] or ["-medoidtree", "-gt", "upgma"]
 t0 = time.time()
 p = subprocess.run([cli, "-v", *args, "-gt_export", f, "/tmp/family_out.dnd"], stderr=subprocess.PIPE, text=True)
-print(" ".join(args), "rc", p.returncode, "wall %.2f s" % (time.time() - t0), p.stderr.replace("\n", " ")[:600])
+print(" ".join(args), "rc", p.returncode, "wall %.2f s" % (time.time() - t0), p.stderr.replace("\n", " ")[-1500:])

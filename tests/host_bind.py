@@ -28,6 +28,7 @@ class Host:
         lib.famsa_host_dist_export_gpu.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p]
         lib.famsa_host_workset.argtypes = [C.c_char_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
         lib.famsa_host_format_distance.argtypes = [C.c_double, C.c_char_p]
+        lib.famsa_host_clarans.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]
         self.lib = lib
 
     def _err(self):
@@ -82,3 +83,11 @@ class Host:
         buf = C.create_string_buffer(64)
         n = self.lib.famsa_host_format_distance(float(v), buf)
         return buf.raw[:n].decode()
+
+    def clarans(self, triangle, n_elems, n_medoids, n_fixed=1, explore_fraction=0.1, num_local=2):
+        tri = np.ascontiguousarray(triangle, np.float32)
+        out = np.zeros(n_medoids, np.int32)
+        if self.lib.famsa_host_clarans(tri.ctypes.data, n_elems, n_medoids, n_fixed, explore_fraction, num_local,
+                                       out.ctypes.data) != 0:
+            raise self._err()
+        return out

@@ -39,6 +39,7 @@ class Oracle:
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = [u32, u32, u32]
+        lib.oracle_dist_triangle_f32.argtypes = [vp, vp, i32, C.c_int, vp]
         lib.oracle_format_dist.restype = C.c_int
         lib.oracle_format_dist.argtypes = [C.c_double, C.c_char_p]
         self.lib = lib
@@ -77,6 +78,13 @@ class Oracle:
         self.lib.oracle_lcs_triangle(codes.ctypes.data, offsets.ctypes.data, n, out.ctypes.data)
         return out
 
+    def dist_triangle_f32(self, lcs_triangle, lens, kind=1):
+        lcs = np.ascontiguousarray(lcs_triangle, np.uint32)
+        lens = np.ascontiguousarray(lens, np.uint32)
+        out = np.empty(len(lcs), np.float32)
+        self.lib.oracle_dist_triangle_f32(lcs.ctypes.data, lens.ctypes.data, len(lens), kind, out.ctypes.data)
+        return out
+
     def format_dist(self, v):
         buf = C.create_string_buffer(64)
         n = self.lib.oracle_format_dist(float(v), buf)
@@ -108,6 +116,7 @@ class Ref:
         lib.ref_dist_export.argtypes = [vp, i, i, i, i, i, C.c_char_p]
         lib.ref_time_triangle.restype = C.c_double
         lib.ref_time_triangle.argtypes = [vp, i, i, i, C.POINTER(C.c_double), C.POINTER(C.c_double), vp]
+        lib.ref_clarans.argtypes = [vp, i, i, i, C.c_float, i, vp]
         self.lib = lib
 
     def open_fasta(self, path):
@@ -150,6 +159,12 @@ class Ref:
     def dist_export(self, h, path, distance=1, square=False, pid=False, threads=4, isa=2):
         rc = self.lib.ref_dist_export(h, distance, int(square), int(pid), threads, isa, path.encode())
         assert rc == 0
+
+    def clarans(self, triangle, n_elems, n_medoids, n_fixed=1, explore_fraction=0.1, num_local=2):
+        tri = np.ascontiguousarray(triangle, np.float32)
+        out = np.zeros(n_medoids, np.int32)
+        self.lib.ref_clarans(tri.ctypes.data, n_elems, n_medoids, n_fixed, explore_fraction, num_local, out.ctypes.data)
+        return out
 
     def time_triangle(self, h, n_use, threads, isa=2, want_matrix=False):
         pairs, cells = C.c_double(0), C.c_double(0)

@@ -120,3 +120,26 @@ def test_medoid_and_parttree_match_reference(host, ref, oracle, tmp_path, seed):
                 assert got == want, (gt, heur)
     finally:
         ref.close(h)
+
+
+def _random_triangle(rng, n, levels):
+    """Float distance triangle; `levels` > 0 quantises the values so that ties are everywhere."""
+    m = n * (n - 1) // 2
+    d = rng.random(m, dtype=np.float32) * np.float32(3.0) + np.float32(0.01)
+    if levels:
+        d = (np.floor(d * levels) / np.float32(levels)).astype(np.float32) + np.float32(1.0 / levels)
+    return d
+
+
+@pytest.mark.parametrize("seed,n,k,fixed,frac,iters,levels", [
+    (0, 40, 5, 1, 0.1, 2, 0), (1, 40, 5, 0, 0.5, 3, 4), (2, 120, 12, 1, 0.1, 2, 0), (3, 120, 12, 3, 1.0, 1, 8),
+    (4, 300, 30, 1, 0.1, 2, 0), (5, 300, 30, 1, 0.1, 2, 16), (6, 12, 12, 1, 0.1, 2, 0), (7, 9, 1, 0, 0.1, 2, 0),
+    (8, 600, 100, 1, 0.05, 2, 0), (9, 64, 2, 1, 0.3, 4, 2),
+])
+def test_host_clarans_matches_reference(host, ref, seed, n, k, fixed, frac, iters, levels):
+    """The host CLARANS search against the reference's CLARANS::operator() on the same float triangle."""
+    rng = np.random.default_rng(9100 + seed)
+    tri = _random_triangle(rng, n, levels)
+    want = ref.clarans(tri, n, k, fixed, frac, iters)
+    got = host.clarans(tri, n, k, fixed, frac, iters)
+    assert got.tolist() == want.tolist()

@@ -1,0 +1,88 @@
+"""Device CLARANS (lcsgpu_clarans) against the reference's CLARANS::operator() -- or, where oracle/_ref
+is not built, the host search that the CPU suite pins to it -- on the oracle's float distance triangle."""
+import time
+
+import numpy as np
+import pytest
+
+import host_bind
+import oracle_bind
+from famsa_amd import seqio
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def searcher():
+    if oracle_bind.have_ref():
+        return oracle_bind.Ref().clarans
+    return host_bind.Host().clarans
+
+
+def _family(rng, n, length, mut):
+    anc = rng.integers(0, 20, size=length, dtype=np.uint8)
+    out = []
+    for _ in range(n):
+        s = anc.copy()
+        m = rng.random(length) < mut
+        s[m] = rng.integers(0, 20, size=int(m.sum()), dtype=np.uint8)
+        out.append(s[: int(rng.integers(int(length * 0.7), length + 1))].copy())
+    return out
+
+
+def _short(rng, n, lo, hi, alpha):
+    return [rng.integers(0, alpha, size=int(rng.integers(lo, hi + 1)), dtype=np.uint8) for _ in range(n)]
+
+
+def _expected_triangle(oracle, seqs, ids, kind):
+    sub = [seqs[i] for i in ids]
+    codes, offsets = seqio.pack(sub)
+    lcs = oracle.triangle(codes, offsets)
+    lens = np.array([len(s) for s in sub], np.uint32)
+    return oracle.dist_triangle_f32(lcs, lens, kind)
+
+
+CASES = [
+    # name, generator, n_set, n_sample, k, fixed, fraction, searches, kind
+    ("family-default-shape", "family", 2300, 2000, 100, 1, 0.1, 2, 1),
+    ("family-small", "family", 400, 300, 20, 1, 0.1, 2, 1),
+    ("family-indel-div-lcs", "family", 400, 350, 25, 1, 0.2, 3, 0),
+    ("two-registers-per-lane", "family", 800, 700, 130, 1, 0.05, 2, 1),
+    ("no-fixed-medoid", "family", 300, 300, 10, 0, 0.1, 2, 1),
+    ("three-fixed", "family", 300, 256, 16, 3, 0.1, 2, 1),
+    ("whole-neighbourhood", "family", 200, 150, 8, 1, 1.0, 1, 1),
+    ("ties-everywhere", "short", 350, 300, 20, 1, 0.1, 2, 1),
+    ("all-medoids", "family", 40, 24, 24, 1, 0.1, 2, 1),
+    ("one-medoid", "family", 40, 30, 1, 0, 0.1, 2, 1),
+    ("tiny", "family", 8, 3, 2, 1, 0.1, 2, 1),
+    ("single-member", "family", 8, 1, 1, 0, 0.1, 1, 1),
+]
+
+
+@pytest.mark.parametrize("name,gen,n_set,n_sample,k,fixed,frac,iters,kind", CASES, ids=[c[0] for c in CASES])
+def test_device_clarans_matches_reference(engine, oracle, searcher, name, gen, n_set, n_sample, k, fixed, frac, iters,
+                                          kind):
+    rng = np.random.default_rng(int.from_bytes(name.encode(), "little") % (1 << 31))
+    seqs = _family(rng, n_set, 180, 0.25) if gen == "family" else _short(rng, n_set, 6, 14, 3)
+    engine.upload_seqs(seqs)
+    ids = np.sort(rng.permutation(n_set)[:n_sample]).astype(np.int32)
+    if name == "no-fixed-medoid":
+        ids = rng.permutation(n_set)[:n_sample].astype(np.int32)  # any order is a valid sample order
+    tri = _expected_triangle(oracle, seqs, ids, kind)
+    want = searcher(tri, n_sample, k, fixed, frac, iters)
+    t0 = time.time()
+    got = engine.clarans(ids, k, fixed, frac, iters, kind)
+    print(f"{name}: device search {1e3 * (time.time() - t0):.1f} ms")
+    assert got.tolist() == want.tolist()
+
+
+def test_device_clarans_rejects_bad_shapes(engine):
+    import famsa_amd
+    rng = np.random.default_rng(5)
+    engine.upload_seqs(_family(rng, 20, 60, 0.2))
+    ids = np.arange(10, dtype=np.int32)
+    for args in [(11, 1), (0, 0), (4, 4), (4, -1)]:
+        with pytest.raises(famsa_amd.LcsGpuError):
+            engine.clarans(ids, args[0], args[1])
+    with pytest.raises(famsa_amd.LcsGpuError):
+        engine.clarans(np.array([0, 25], np.int32), 1, 0)
