@@ -8,7 +8,7 @@
 // and the positions xx come from a generator that does not look at the state, so ALL steps up to
 // the next accept can be evaluated at once from the same state:
 //   clarans_eval_kernel   one workgroup per pending step (+1 that keeps the running cost), lane = medoid
-//                         slot k, every lane accumulates deltas[k] over the non-medoids in ascending
+//                         slot, every lane accumulates deltas[slot] over the non-medoids in ascending
 //                         position -- the reference's float additions in the reference's order;
 //   clarans_apply_kernel  takes the FIRST step of the window whose best delta is negative, swaps, and
 //                         re-derives nearest / second-nearest medoid of every non-medoid exactly as
@@ -17,9 +17,11 @@
 // between batches.  Ties, comparison directions and float operation order follow the reference
 // line by line; the running cost is summed sequentially from a per-round log of its addends.
 //
-// Layout: D = float triangle over the sample members (D[i*(i-1)/2 + j], j < i); DM[y*k + mm] =
-// distance of member y to the medoid in slot mm (kept in step with the swaps so that the reference's
-// updateAssignment scan reads one contiguous row instead of k scattered triangle entries).
+// Layout: D = float triangle over the sample members (D[i*(i-1)/2 + j], j < i).  All search state is
+// kept per candidate POSITION (not per member), so the lanes of a wave read it coalesced:
+// st[pos] = nearest / second-nearest bookkeeping, DMt[mm*n + pos] = distance of the member at pos to
+// the medoid in slot mm (kept in step with the swaps so that the reference's updateAssignment scan
+// is k coalesced loads instead of k scattered triangle entries per lane).
 #include <hip/hip_runtime.h>
 
 #include <cfloat>
@@ -37,20 +39,12 @@ __device__ __forceinline__ size_t tri_at(int i, int j)
     return i >= j ? (size_t)j + (size_t)i * (i - 1) / 2 : (size_t)i + (size_t)j * (j - 1) / 2;
 }
 
-// CLARANS::updateAssignment (Clustering.cpp:262-305) over the member's DM row
-__device__ __forceinline__ void scan_row(const float* __restrict__ row, int k, float& dn, float& ds, int& an, int& as)
-{
-    float bn = FLT_MAX, bs = FLT_MAX;
-    int in = -1, is = -1;
-    for (int mm = 0; mm < k; ++mm) {
-        const float d = row[mm];
-        if (d < bn) { bs = bn; is = in; bn = d; in = mm; }
-        else if (d < bs) { bs = d; is = mm; }
-    }
-    dn = bn; ds = bs; an = in; as = is;
-}
-
-enum { ST_P = 0, ST_DONE = 1, ST_LOG_LEN = 2, ST_ROUNDS = 3, ST_ARRIVE = 4, ST_COST = 5, ST_ERR = 6 };
+#ifdef CLARANS_TRACE
+#define TR(i) do { if (tid == 0 && b == 0) { const unsigned long long t_ = wall_clock64(); atomicAdd(&tr[i], t_ - t_prev); t_prev = t_; } } while (0)
+#else
+#define TR(i)
+#endif
+enum { ST_P = 0, ST_DONE = 1, ST_LOG_LEN = 2, ST_ROUNDS = 3, ST_ARRIVE = 4, ST_COST = 5, ST_ERR = 6, ST_WIN = 7 };
 
 } // namespace
 
@@ -76,61 +70,148 @@ __global__ __launch_bounds__(256) void subset_dist_kernel(const T* __restrict__ 
     }
 }
 
-// Start of one local search (Clustering.cpp:49-79): medoid bookkeeping, every non-medoid's DM row
-// and assignment, the addends of the initial cost in position order.
-__global__ __launch_bounds__(256) void clarans_init_kernel(ClaransArgs a)
+// Per-position state: st[pos] = {distance to the nearest medoid, to the second nearest, slot of the
+// nearest, slot of the second} of the member at candidate position pos (only positions >= n_medoids
+// are ever read; the reference's bookkeeping for the medoids themselves is write-only).
+__device__ __forceinline__ float4 pack_state(float dn, float ds, int an, int as)
+{
+    return make_float4(dn, ds, __int_as_float(an), __int_as_float(as));
+}
+
+// CLARANS::updateAssignment (Clustering.cpp:262-305) folded over slots in ascending order
+struct Nearest2 {
+    float dn = FLT_MAX, ds = FLT_MAX;
+    int an = -1, as = -1;
+    __device__ __forceinline__ void feed(float d, int mm)
+    {
+        if (d < dn) { ds = dn; as = an; dn = d; an = mm; }
+        else if (d < ds) { ds = d; as = mm; }
+    }
+};
+
+// Start of one local search (Clustering.cpp:49-79): every non-medoid's distances to the medoid
+// slots (DMt[mm * n + pos]) and assignment, the addends of the initial cost in position order, and
+// the first window of pending steps (position and member of each).
+__global__ __launch_bounds__(256) void clarans_init_kernel(ClaransArgs a, int W)
 {
     const int pos = blockIdx.x * 256 + threadIdx.x;
-    const int k = a.n_medoids;
+    const int k = a.n_medoids, n = a.n_elems;
+    const int p = a.state[ST_P];
     if (pos == 0) {
         a.state[ST_DONE] = 0;
-        a.state[ST_LOG_LEN] = a.n_elems - k;
+        a.state[ST_LOG_LEN] = n - k;
         a.state[ST_ROUNDS] = 0;
         a.state[ST_ARRIVE] = 0;
         a.state[ST_COST] = __float_as_int(0.0f);
+        a.state[ST_WIN] = 0;
+        if (p + W > a.draws_len) a.state[ST_ERR] = 1;
     }
-    if (pos >= a.n_elems) return;
+    if (p + W <= a.draws_len)
+        for (int j = pos; j < W; j += gridDim.x * 256) {
+            const int xx = a.draws[p + j];
+            a.win_xx[j] = xx;
+            a.win_x[j] = a.cand[xx];
+        }
+    if (pos < k || pos >= n) return;
     const int y = a.cand[pos];
-    if (pos < k) {
-        a.dn[y] = 0.0f; a.ds[y] = -1.0f; a.an[y] = -1; a.as_[y] = -1;
-        return;
+    Nearest2 nb;
+#pragma unroll 4
+    for (int mm = 0; mm < k; ++mm) {
+        const float d = a.D[tri_at(a.cand[mm], y)];
+        a.DMt[(size_t)mm * n + pos] = d;
+        nb.feed(d, mm);
     }
-    float* row = a.DM + (size_t)y * k;
-    for (int mm = 0; mm < k; ++mm) row[mm] = a.D[tri_at(a.cand[mm], y)];
-    float dn, ds;
-    int an, as;
-    scan_row(row, k, dn, ds, an, as);
-    a.dn[y] = dn; a.ds[y] = ds; a.an[y] = an; a.as_[y] = as;
-    a.cost_log[pos - k] = dn;
+    a.st[pos] = pack_state(nb.dn, nb.ds, nb.an, nb.as);
+    a.cost_log[pos - k] = nb.dn;
 }
 
-// One workgroup per pending step b of the window [p, p + W): deltas[k] of candidate[draws[p + b]]
+// A kernel boundary leaves nothing in the caches that another XCD wrote, so every DEPENDENT global
+// load of these small kernels costs a trip to memory (~1.5 us): both kernels are laid out to have as
+// few dependent levels as possible -- everything whose address does not depend on the step is
+// requested first, the pending steps' positions/members are precomputed by the previous kernel.
+
+// One workgroup per pending step b of the window: deltas[slot] of the member win_x[b]
 // (Clustering.cpp:93-118) and their first minimum over the free slots (cpp:121-122).
+// Every slot's delta is a sequential float sum over the non-medoids in position order.  A
+// non-medoid adds to its own nearest slot always and to all others only when the candidate is
+// closer to it than its medoid (rare), so each of the 8 waves -- wave w owns the slots
+// [w * kpw, (w + 1) * kpw) -- first compacts, in order, the entries that can change one of ITS
+// slots and then walks only those: skipped entries would add +0.0f, the identity.
 // Workgroup W adds the previous round's cost addends to the running cost, in order.
 template <int KPT>
-__global__ __launch_bounds__(128) void clarans_eval_kernel(ClaransArgs a, int W)
+__global__ __launch_bounds__(512) void clarans_eval_kernel(ClaransArgs a, int W)
 {
-    constexpr int CH = 512;
-    __shared__ float4 s_e[CH];
-    __shared__ float s_v[128];
-    __shared__ int s_k[128];
-    if (a.state[ST_DONE]) return;
-    const int b = blockIdx.x, tid = threadIdx.x;
+    constexpr int CH = 2048, PER = CH / 512;
+    constexpr int SUB = 256;
+    __shared__ float4 s_e[CH];          // 32 KB
+    __shared__ float4 s_we[8][SUB];     // 32 KB: per wave, the entries of one sub-chunk that concern its slots
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int k = a.n_medoids, n = a.n_elems;
+#ifdef CLARANS_TRACE
+    unsigned long long* tr = reinterpret_cast<unsigned long long*>(a.state + 16);
+    unsigned long long t_prev = wall_clock64();
+#endif
+    // level 1: state, this step, and the first chunk's per-position data
+    const int4 st0 = *reinterpret_cast<const int4*>(a.state);
+    const int4 st1 = *reinterpret_cast<const int4*>(a.state + 4);
+    const int win = st1.w & 1;
+    const int bb = b < W ? b : 0;
+    const int xx = a.win_xx[win * a.win_cap + bb];
+    const int x = a.win_x[win * a.win_cap + bb];
+    int y_pre[PER];
+    float4 s_pre[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int yy = k + tid + 512 * u;
+        y_pre[u] = yy < n ? a.cand[yy] : 0;
+        s_pre[u] = yy < n ? a.st[yy] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (st0.y) return; // done
+    TR(0);
+    const uint64_t lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
     if (b == W) {
-        const int len = a.state[ST_LOG_LEN];
+        // running cost: c += addend for every logged addend, in order; zeros are the identity
+        // (c starts at +0.0f and can never become -0.0f), so only the others are walked
+        const int len = st0.z;
         if (len == 0) return;
-        float c = __int_as_float(a.state[ST_COST]);
-        float* s_f = reinterpret_cast<float*>(s_e);
-        for (int c0 = 0; c0 < len; c0 += 4 * CH) {
-            const int cnt = min(4 * CH, len - c0);
-            for (int t = tid; t < 4 * CH; t += 128) s_f[t] = t < cnt ? a.cost_log[c0 + t] : 0.0f;
+        float c = __int_as_float(st1.y);
+        float* s_f = reinterpret_cast<float*>(s_e);      // CH floats: the addends of one pass
+        float* s_nz = reinterpret_cast<float*>(s_we);    // CH floats: the non-zero ones, in order
+        for (int c0 = 0; c0 < len; c0 += CH) {
+            const int cnt = min(CH, len - c0);
+            float v[PER];
+#pragma unroll
+            for (int u = 0; u < PER; ++u) { // one trip to memory for the whole pass
+                const int t = tid + 512 * u;
+                v[u] = t < cnt ? a.cost_log[c0 + t] : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < PER; ++u) s_f[tid + 512 * u] = v[u];
             __syncthreads();
-            if (tid == 0) {
-                const int q4 = (cnt + 3) / 4; // the padding adds +0.0f: identity on a non-negative-zero sum
-                for (int t = 0; t < q4; ++t) {
-                    const float4 v = s_e[t];
-                    c = __fadd_rn(c, v.x); c = __fadd_rn(c, v.y); c = __fadd_rn(c, v.z); c = __fadd_rn(c, v.w);
+            if (wave == 0) {
+                int m = 0;
+                for (int base = 0; base < cnt; base += 256) {
+                    float g[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) g[u] = s_f[base + 64 * u + lane]; // zero beyond cnt
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const uint64_t mask = __ballot(g[u] != 0.0f);
+                        if (g[u] != 0.0f) s_nz[m + __popcll(mask & lt_mask)] = g[u];
+                        m += __popcll(mask);
+                    }
+                }
+                __builtin_amdgcn_wave_barrier(); // same wave: its LDS writes are performed before its later reads
+                if (lane == 0) {
+                    int t = 0;
+                    for (; t + 8 <= m; t += 8) {
+                        float g[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) g[u] = s_nz[t + u];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) c = __fadd_rn(c, g[u]);
+                    }
+                    for (; t < m; ++t) c = __fadd_rn(c, s_nz[t]);
                 }
             }
             __syncthreads();
@@ -138,55 +219,101 @@ __global__ __launch_bounds__(128) void clarans_eval_kernel(ClaransArgs a, int W)
         if (tid == 0) a.state[ST_COST] = __float_as_int(c);
         return;
     }
-    const int p = a.state[ST_P];
-    if (p + W > a.draws_len) {
-        if (tid == 0) a.state[ST_ERR] = 1; // the host did not provide enough draws; apply ends the search
-        return;
-    }
-    const int xx = a.draws[p + b];
-    const int x = a.cand[xx];
+    if (st1.z) return; // error flagged: apply ends the search
+    const int kpw = (k + 7) >> 3;
+    const int klo = wave * kpw, khi = min(k, klo + kpw);
     float acc[KPT];
+    int slot[KPT];
 #pragma unroll
-    for (int q = 0; q < KPT; ++q) acc[q] = 0.0f;
+    for (int q = 0; q < KPT; ++q) {
+        acc[q] = 0.0f;
+        slot[q] = klo + lane + 64 * q;
+    }
     for (int c0 = k; c0 < n; c0 += CH) {
         const int cnt = min(CH, n - c0);
-        for (int t = tid; t < cnt; t += 128) {
-            const int yy = c0 + t;
-            float4 e = make_float4(0.0f, 0.0f, __int_as_float(-1), 0.0f); // yy == xx: contributes nothing
-            if (yy != xx) {
-                const int y = a.cand[yy];
-                const float dxy = a.D[tri_at(x, y)];
-                const float dn = a.dn[y], ds = a.ds[y];
-                const float m = ds < dxy ? ds : dxy;                // std::min(dxy, ds)
-                const float change = __fsub_rn(dxy, dn);
-                e.x = __fsub_rn(m, dn);                              // goes to deltas[nearest(y)]
-                e.y = change < 0.0f ? change : 0.0f;                 // goes to every other slot when negative
-                e.z = __int_as_float(a.an[y]);
-            }
-            s_e[t] = e;
-        }
-        __syncthreads();
-#pragma unroll 8
-        for (int t = 0; t < cnt; ++t) {
-            const float4 e = s_e[t];
-            const int nn = __float_as_int(e.z);
+        // entries of this chunk: (addend for the own slot, addend for the other slots, own slot)
+        float dxy[PER];
 #pragma unroll
-            for (int q = 0; q < KPT; ++q) acc[q] = __fadd_rn(acc[q], (tid + 128 * q) == nn ? e.x : e.y);
+        for (int u = 0; u < PER; ++u) { // level 2: the gathers from the triangle, all in flight together
+            const int t = tid + 512 * u;
+            if (c0 != k) {
+                y_pre[u] = t < cnt ? a.cand[c0 + t] : 0;
+                s_pre[u] = t < cnt ? a.st[c0 + t] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            dxy[u] = (t < cnt && c0 + t != xx) ? a.D[tri_at(x, y_pre[u])] : 0.0f;
         }
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int t = tid + 512 * u;
+            if (t < cnt) {
+                float4 e = make_float4(0.0f, 0.0f, __int_as_float(-1), 0.0f); // position xx: contributes nothing
+                if (c0 + t != xx) {
+                    const float dn = s_pre[u].x, ds = s_pre[u].y;
+                    const float m = ds < dxy[u] ? ds : dxy[u]; // std::min(dxy, ds)
+                    const float change = __fsub_rn(dxy[u], dn);
+                    e.x = __fsub_rn(m, dn);                     // goes to deltas[nearest(y)]
+                    e.y = change < 0.0f ? change : 0.0f;        // goes to every other slot when negative
+                    e.z = s_pre[u].z;
+                }
+                s_e[t] = e;
+            }
+        }
+        TR(1);
         __syncthreads();
+        TR(2);
+        for (int s0 = 0; s0 < cnt; s0 += SUB) {
+            float4 e[SUB / 64];
+#pragma unroll
+            for (int u = 0; u < SUB / 64; ++u) {
+                const int t = s0 + 64 * u + lane;
+                e[u] = t < cnt ? s_e[t] : make_float4(0.0f, 0.0f, __int_as_float(-1), 0.0f);
+            }
+            int m = 0;
+#pragma unroll
+            for (int u = 0; u < SUB / 64; ++u) {
+                const int nn = __float_as_int(e[u].z);
+                const bool mine = e[u].y < 0.0f || (nn >= klo && nn < khi);
+                const uint64_t mask = __ballot(mine);
+                if (mine) s_we[wave][m + __popcll(mask & lt_mask)] = e[u];
+                m += __popcll(mask);
+            }
+            __builtin_amdgcn_wave_barrier(); // same wave: its LDS writes are performed before its later reads
+            int i = 0;
+            for (; i + 8 <= m; i += 8) {
+                float4 f[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) f[u] = s_we[wave][i + u];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int nn = __float_as_int(f[u].z);
+#pragma unroll
+                    for (int q = 0; q < KPT; ++q) acc[q] = __fadd_rn(acc[q], slot[q] == nn ? f[u].x : f[u].y);
+                }
+            }
+            for (; i < m; ++i) {
+                const float4 f = s_we[wave][i];
+                const int nn = __float_as_int(f.z);
+#pragma unroll
+                for (int q = 0; q < KPT; ++q) acc[q] = __fadd_rn(acc[q], slot[q] == nn ? f.x : f.y);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        TR(3);
+        __syncthreads();
+        TR(4);
     }
     // std::min_element over slots [n_fixed, k): smallest value, earliest slot among equals
+    float* s_v = reinterpret_cast<float*>(&s_we[0][0]);
+    int* s_k = reinterpret_cast<int*>(&s_we[1][0]);
     float best = 0.0f;
     int bk = INT_MAX;
 #pragma unroll
-    for (int q = 0; q < KPT; ++q) {
-        const int kk = tid + 128 * q;
-        if (kk >= a.n_fixed && kk < k && (bk == INT_MAX || acc[q] < best)) { best = acc[q]; bk = kk; }
-    }
+    for (int q = 0; q < KPT; ++q)
+        if (slot[q] >= a.n_fixed && slot[q] < khi && (bk == INT_MAX || acc[q] < best)) { best = acc[q]; bk = slot[q]; }
     s_v[tid] = best;
     s_k[tid] = bk;
     __syncthreads();
-    for (int s = 64; s > 0; s >>= 1) {
+    for (int s = 256; s > 0; s >>= 1) {
         if (tid < s) {
             const float v2 = s_v[tid + s];
             const int k2 = s_k[tid + s];
@@ -202,82 +329,172 @@ __global__ __launch_bounds__(128) void clarans_eval_kernel(ClaransArgs a, int W)
         a.res_delta[b] = s_v[0];
         a.res_mm[b] = s_k[0];
     }
+    TR(5);
+#ifdef CLARANS_TRACE
+    if (tid == 0 && b == 0) atomicAdd(&tr[7], 1ull);
+#endif
 }
 
 // Accept the first improving step of the window (Clustering.cpp:124-238) or finish the search.
-// One lane per non-medoid position; the workgroup that arrives last commits the swap.
-__global__ __launch_bounds__(256) void clarans_apply_kernel(ClaransArgs a, int W)
+// Workgroups 0 .. gridDim-2 (one wave each): one lane per non-medoid position; the last workgroup
+// rebuilds the position that receives the replaced medoid and prepares the next window of pending
+// steps.  The workgroup that arrives last commits the swap.
+constexpr int APPLY_MT = 128; // medoid slots staged per pass
+__global__ __launch_bounds__(64) void clarans_apply_kernel(ClaransArgs a, int W, int W_next)
 {
     __shared__ int s_w;
     __shared__ int s_last;
-    __shared__ int s_med[CLARANS_MAX_MEDOIDS];
+    __shared__ float s_tile[APPLY_MT][64]; // 32 KB: [slot][lane]; the last workgroup uses it as one row
     int* st = a.state;
-    if (st[ST_DONE]) return;
     const int tid = threadIdx.x;
     const int k = a.n_medoids, n = a.n_elems;
+    const bool last_wg = blockIdx.x == gridDim.x - 1;
+    // level 1: everything whose address does not depend on the accepted step
+    const int4 st0 = *reinterpret_cast<const int4*>(st);
+    const int4 st1 = *reinterpret_cast<const int4*>(st + 4);
+    const int yy = k + blockIdx.x * 64 + tid;
+    const bool have = !last_wg && yy < n;
+    const int y_mine = have ? a.cand[yy] : 0;
+    int med_pre[CLARANS_MAX_MEDOIDS / 64]; // last workgroup: the current medoids, slots tid, tid + 64, ...
+#pragma unroll
+    for (int u = 0; u < CLARANS_MAX_MEDOIDS / 64; ++u) med_pre[u] = (last_wg && tid + 64 * u < k) ? a.cand[tid + 64 * u] : 0;
+    const float4 s = have ? a.st[yy] : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (have) {
+        const float* col = a.DMt + yy;
+        const int k0 = min(k, APPLY_MT);
+#pragma unroll 16
+        for (int mm = 0; mm < k0; ++mm) s_tile[mm][tid] = col[(size_t)mm * n];
+    }
+    int w_mine = INT_MAX;
+    for (int w = tid; w < W; w += 64)
+        if (a.res_delta[w] < 0.0f) { w_mine = w; break; } // ascending per lane: its first
+    if (st0.y) return; // done
     if (tid == 0) s_w = INT_MAX;
     __syncthreads();
-    if (!st[ST_ERR])
-        for (int w = tid; w < W; w += 256)
-            if (a.res_delta[w] < 0.0f) atomicMin(&s_w, w);
+    if (!st1.z && w_mine != INT_MAX) atomicMin(&s_w, w_mine);
     __syncthreads();
     const int w = s_w;
-    const int p = st[ST_P];
+    const int p = st0.x;
+    const int win = st1.w & 1;
     if (w == INT_MAX) { // `corrected` steps without an accept: this local search is over
         if (blockIdx.x == 0 && tid == 0) {
-            st[ST_P] = p + (st[ST_ERR] ? 0 : W);
+            st[ST_P] = p + (st1.z ? 0 : W);
             st[ST_LOG_LEN] = 0;
             st[ST_DONE] = 1;
         }
         return;
     }
-    const int xx = a.draws[p + w];
+    // level 2
+    const int xx = a.win_xx[win * a.win_cap + w];
+    const int x = a.win_x[win * a.win_cap + w]; // the new medoid
     const int mm_new = a.res_mm[w];
-    const int x = a.cand[xx];         // the new medoid
-    const int m_old = a.cand[mm_new]; // the medoid it replaces, now at position xx
-    for (int i = tid; i < k; i += 256) s_med[i] = i == mm_new ? x : a.cand[i];
-    __syncthreads();
-    const int yy = k + blockIdx.x * 256 + tid;
-    if (yy < n) {
-        const int y = yy == xx ? m_old : a.cand[yy];
-        float* row = a.DM + (size_t)y * k;
-        float addend = 0.0f;
-        float dn, ds;
-        int an, as;
-        if (yy == xx) {
-            for (int mm = 0; mm < k; ++mm) row[mm] = a.D[tri_at(s_med[mm], y)];
-            scan_row(row, k, dn, ds, an, as);
-            a.dn[y] = dn; a.ds[y] = ds; a.an[y] = an; a.as_[y] = as;
-            addend = dn;
+    int m_old = 0;
+    if (last_wg) {
+        // level 3: the medoid that is replaced; from now on it sits at position xx
+        m_old = a.cand[mm_new];
+        // next window of pending steps, against the candidate order after this swap
+        const int p_new = p + w + 1;
+        if (p_new + W_next > a.draws_len) {
+            if (tid == 0) st[ST_ERR] = 1;
         } else {
-            const float d_new = a.D[tri_at(x, y)];
-            row[mm_new] = d_new;
-            const float dn_y = a.dn[y];
-            const int an_y = a.an[y];
-            if (an_y == mm_new) { // its medoid is the one that left
-                const float ds_y = a.ds[y];
-                if (d_new < ds_y) {
-                    a.dn[y] = d_new;
-                    addend = __fsub_rn(d_new, dn_y);
-                } else {
-                    scan_row(row, k, dn, ds, an, as);
-                    a.dn[y] = dn; a.ds[y] = ds; a.an[y] = an; a.as_[y] = as;
-                    addend = __fsub_rn(ds_y, dn_y);
-                }
-            } else if (d_new < dn_y) {
-                a.ds[y] = dn_y; a.as_[y] = an_y;
-                a.dn[y] = d_new; a.an[y] = mm_new;
-                addend = __fsub_rn(d_new, dn_y);
-            } else {
-                const float ds_y = a.ds[y];
-                if (a.as_[y] != mm_new && d_new < ds_y) {
-                    a.ds[y] = d_new; a.as_[y] = mm_new;
-                } else {
-                    scan_row(row, k, dn, ds, an, as);
-                    a.dn[y] = dn; a.ds[y] = ds; a.an[y] = an; a.as_[y] = as;
-                }
+            int32_t* nxx = a.win_xx + (1 - win) * a.win_cap;
+            int32_t* nx = a.win_x + (1 - win) * a.win_cap;
+            for (int j = tid; j < W_next; j += 64) {
+                const int xn = a.draws[p_new + j];
+                nxx[j] = xn;
+                nx[j] = xn == xx ? m_old : a.cand[xn];
             }
         }
+        // position xx: cost -= dists_nearest[new medoid] first (cpp:131), then the replaced medoid
+        // gets its distances to the new medoid set and a fresh assignment (cpp:150-157)
+        const float old_dn = a.st[xx].x;
+        // updateAssignment over the new medoid set = first minimum over the slots, then first minimum
+        // over the slots without that one (what the sequential scan of cpp:262-305 arrives at)
+        float dv[CLARANS_MAX_MEDOIDS / 64];
+#pragma unroll
+        for (int u = 0; u < CLARANS_MAX_MEDOIDS / 64; ++u) {
+            const int mm = tid + 64 * u;
+            dv[u] = FLT_MAX;
+            if (mm < k) {
+                dv[u] = a.D[tri_at(mm == mm_new ? x : med_pre[u], m_old)];
+                a.DMt[(size_t)mm * n + xx] = dv[u];
+            }
+        }
+        float v1 = FLT_MAX, v2 = FLT_MAX;
+        int i1 = INT_MAX, i2 = INT_MAX;
+#pragma unroll
+        for (int u = 0; u < CLARANS_MAX_MEDOIDS / 64; ++u) {
+            const int mm = tid + 64 * u;
+            if (mm < k && (dv[u] < v1 || i1 == INT_MAX)) { v1 = dv[u]; i1 = mm; }
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            const float ov = __shfl_xor(v1, off);
+            const int oi = __shfl_xor(i1, off);
+            if (oi != INT_MAX && (i1 == INT_MAX || ov < v1 || (ov == v1 && oi < i1))) { v1 = ov; i1 = oi; }
+        }
+#pragma unroll
+        for (int u = 0; u < CLARANS_MAX_MEDOIDS / 64; ++u) {
+            const int mm = tid + 64 * u;
+            if (mm < k && mm != i1 && (dv[u] < v2 || i2 == INT_MAX)) { v2 = dv[u]; i2 = mm; }
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            const float ov = __shfl_xor(v2, off);
+            const int oi = __shfl_xor(i2, off);
+            if (oi != INT_MAX && (i2 == INT_MAX || ov < v2 || (ov == v2 && oi < i2))) { v2 = ov; i2 = oi; }
+        }
+        if (tid == 0) {
+            // the scan starts from (FLT_MAX, -1): a slot at FLT_MAX never replaces it
+            const bool has1 = i1 != INT_MAX && v1 < FLT_MAX, has2 = i2 != INT_MAX && v2 < FLT_MAX;
+            a.st[xx] = pack_state(has1 ? v1 : FLT_MAX, has2 ? v2 : FLT_MAX, has1 ? i1 : -1, has2 ? i2 : -1);
+            a.cost_log[0] = -old_dn;
+            a.cost_log[1 + xx - k] = has1 ? v1 : FLT_MAX;
+        }
+    } else if (have && yy != xx) {
+        const float d_new = a.D[tri_at(x, y_mine)]; // level 3
+        a.DMt[(size_t)mm_new * n + yy] = d_new;
+        const float dn_y = s.x, ds_y = s.y;
+        const int an_y = __float_as_int(s.z), as_y = __float_as_int(s.w);
+        float addend = 0.0f;
+        bool rescan = false;
+        float4 out = s;
+        if (an_y == mm_new) { // its medoid is the one that left
+            if (d_new < ds_y) {
+                out.x = d_new;
+                addend = __fsub_rn(d_new, dn_y);
+            } else {
+                rescan = true;
+                addend = __fsub_rn(ds_y, dn_y);
+            }
+        } else if (d_new < dn_y) {
+            out = pack_state(d_new, dn_y, mm_new, an_y);
+            addend = __fsub_rn(d_new, dn_y);
+        } else if (as_y != mm_new && d_new < ds_y) {
+            out.y = d_new;
+            out.w = __int_as_float(mm_new);
+        } else {
+            rescan = true;
+        }
+        if (rescan) {
+            Nearest2 nb;
+            const int k0 = min(k, APPLY_MT);
+            for (int m0 = 0; m0 < k0; m0 += 8) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = s_tile[min(m0 + u, k0 - 1)][tid];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (m0 + u < k0) nb.feed(m0 + u == mm_new ? d_new : v[u], m0 + u);
+            }
+            const float* col = a.DMt + yy;
+            for (int m0 = APPLY_MT; m0 < k; m0 += APPLY_MT) { // more slots than one staging pass holds
+                const int k1 = min(k, m0 + APPLY_MT);
+#pragma unroll 16
+                for (int mm = m0; mm < k1; ++mm) s_tile[mm - m0][tid] = col[(size_t)mm * n];
+                for (int mm = m0; mm < k1; ++mm) nb.feed(mm == mm_new ? d_new : s_tile[mm - m0][tid], mm);
+            }
+            out = pack_state(nb.dn, nb.ds, nb.an, nb.as);
+        }
+        a.st[yy] = out;
         a.cost_log[1 + yy - k] = addend;
     }
     __threadfence();
@@ -285,15 +502,14 @@ __global__ __launch_bounds__(256) void clarans_apply_kernel(ClaransArgs a, int W
     if (tid == 0) s_last = atomicAdd(&st[ST_ARRIVE], 1) == (int)gridDim.x - 1;
     __syncthreads();
     if (s_last && tid == 0) {
-        __threadfence();
-        a.cost_log[0] = -a.dn[x]; // cost -= dists_nearest[m_new], before the loop's addends
-        a.dn[x] = 0.0f; a.ds[x] = -1.0f; a.an[x] = -1; a.as_[x] = -1;
+        const int mo = a.cand[mm_new];
         a.cand[mm_new] = x;
-        a.cand[xx] = m_old;
+        a.cand[xx] = mo;
         st[ST_P] = p + w + 1;
         st[ST_LOG_LEN] = 1 + n - k;
-        st[ST_ROUNDS] = st[ST_ROUNDS] + 1;
+        st[ST_ROUNDS] = st0.w + 1;
         st[ST_ARRIVE] = 0;
+        st[ST_WIN] = 1 - win;
     }
 }
 
@@ -310,9 +526,9 @@ hipError_t launch_subset_distances(const void* lcs, int elem_size, const int32_t
     return hipGetLastError();
 }
 
-hipError_t launch_clarans_init(const ClaransArgs& a, hipStream_t stream)
+hipError_t launch_clarans_init(const ClaransArgs& a, int corrected, hipStream_t stream)
 {
-    hipLaunchKernelGGL(clarans_init_kernel, dim3((a.n_elems + 255) / 256), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(clarans_init_kernel, dim3((a.n_elems + 255) / 256), dim3(256), 0, stream, a, corrected);
     return hipGetLastError();
 }
 
@@ -321,16 +537,15 @@ hipError_t launch_clarans_init(const ClaransArgs& a, hipStream_t stream)
 hipError_t launch_clarans_rounds(const ClaransArgs& a, int corrected, bool first_of_search, int rounds,
                                  hipStream_t stream)
 {
-    const int kpt = (a.n_medoids + 127) / 128;
-    const int apply_blocks = (a.n_elems - a.n_medoids + 255) / 256;
+    const int kpt = ((a.n_medoids + 7) / 8 + 63) / 64; // slots per lane: 8 waves share the slots
+    const int apply_blocks = (a.n_elems - a.n_medoids + 63) / 64 + 1;
+    const int later = corrected > 0 ? corrected - 1 : 0;
     for (int r = 0; r < rounds; ++r) {
-        const int W = (first_of_search && r == 0) ? corrected : (corrected > 0 ? corrected - 1 : 0);
-        const dim3 grid(W + 1), block(128);
+        const int W = (first_of_search && r == 0) ? corrected : later;
+        const dim3 grid(W + 1), block(512);
         if (kpt <= 1) hipLaunchKernelGGL(clarans_eval_kernel<1>, grid, block, 0, stream, a, W);
-        else if (kpt <= 2) hipLaunchKernelGGL(clarans_eval_kernel<2>, grid, block, 0, stream, a, W);
-        else if (kpt <= 4) hipLaunchKernelGGL(clarans_eval_kernel<4>, grid, block, 0, stream, a, W);
-        else hipLaunchKernelGGL(clarans_eval_kernel<8>, grid, block, 0, stream, a, W);
-        hipLaunchKernelGGL(clarans_apply_kernel, dim3(apply_blocks > 0 ? apply_blocks : 1), dim3(256), 0, stream, a, W);
+        else hipLaunchKernelGGL(clarans_eval_kernel<2>, grid, block, 0, stream, a, W);
+        hipLaunchKernelGGL(clarans_apply_kernel, dim3(apply_blocks), dim3(64), 0, stream, a, W, later);
     }
     return hipGetLastError();
 }

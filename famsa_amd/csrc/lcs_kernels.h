@@ -35,6 +35,13 @@ struct RowsArgs {
     // tri_prefix[tri_rows] = grid size.  NULL = plain 2-D grid (x = column block, y = ref tile).
     const int32_t* tri_prefix;
     int32_t tri_rows;
+    // Several triangles in one launch (lcsgpu_lcs_triangles_batch): 1-D grid, workgroup b does
+    // jobs[b] = {first ref k0, ref count, first column, column limit}; rows and columns are positions
+    // in the concatenated id list col_ids, ref k belongs to the list that starts at position
+    // ref_col0[k] and writes its packed triangle at out + ref_out0[k].  NULL = the modes above.
+    const int4* jobs;
+    const int32_t* ref_col0;
+    const int64_t* ref_out0;
 };
 
 // instantiated half-word (32-bit) counts: exact 1..32, even 34..64; 0 = the long-sequence path
@@ -129,22 +136,21 @@ hipError_t launch_float_distances(const void* lcs, int elem_size, const uint32_t
 constexpr int CLARANS_MAX_MEDOIDS = 1024;
 struct ClaransArgs {
     const float* D;      // float distance triangle over the sample members
-    float* DM;           // [n_elems * n_medoids] member-to-medoid-slot distances
+    float* DMt;          // [n_medoids][n_elems] distance of the member at a position to the medoid in a slot
     int32_t* cand;       // [n_elems] permutation of the members; positions < n_medoids are the medoids
-    float* dn;           // [n_elems] by member: distance to the nearest medoid
-    float* ds;           //           ... to the second nearest
-    int32_t* an;         //           slot of the nearest medoid
-    int32_t* as_;        //           slot of the second nearest
+    float4* st;          // [n_elems] by position: {d(nearest), d(second), slot(nearest), slot(second)}
     const int32_t* draws; // pre-drawn positions xx of the steps (the position generator's output)
+    int32_t* win_xx;     // [2][win_cap] positions of the pending steps (double-buffered, state[7] = current)
+    int32_t* win_x;      // [2][win_cap] the members at those positions
     float* res_delta;    // [window] best delta of every pending step
     int32_t* res_mm;     // [window] its medoid slot
     float* cost_log;     // [1 + n_elems] addends of the running cost, in the reference's order
-    int32_t* state;      // [0] next draw  [1] done  [2] log length  [3] accepts  [4] arrivals  [5] cost bits  [6] error
-    int32_t n_elems, n_medoids, n_fixed, draws_len;
+    int32_t* state;      // [0] next draw  [1] done  [2] log length  [3] accepts  [4] arrivals  [5] cost bits  [6] error  [7] window buffer
+    int32_t n_elems, n_medoids, n_fixed, draws_len, win_cap;
 };
 hipError_t launch_subset_distances(const void* lcs, int elem_size, const int32_t* ids, const uint32_t* lens,
                                    const float* pow_f32, int kind, int n, float* D, hipStream_t stream);
-hipError_t launch_clarans_init(const ClaransArgs& a, hipStream_t stream);
+hipError_t launch_clarans_init(const ClaransArgs& a, int corrected, hipStream_t stream);
 hipError_t launch_clarans_rounds(const ClaransArgs& a, int corrected, bool first_of_search, int rounds,
                                  hipStream_t stream);
 

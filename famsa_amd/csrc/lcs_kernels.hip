@@ -133,7 +133,12 @@ __device__ __forceinline__ void store_result(const RowsArgs& a, int k, int c, ui
 {
     const int64_t row = a.ref_rows ? a.ref_rows[k] : (int64_t)k + a.row0;
     int64_t idx;
-    if (a.mode == MODE_TRIANGLE) { // rows/columns are POSITIONS in the caller's lists; only column < row
+    if (a.jobs) { // batched triangles: positions relative to the start of the ref's own id list
+        if (c >= row)
+            return;
+        const int64_t g0 = a.ref_col0[k], lr = row - g0;
+        idx = a.ref_out0[k] + lr * (lr - 1) / 2 + (c - g0);
+    } else if (a.mode == MODE_TRIANGLE) { // rows/columns are POSITIONS in the caller's lists; only column < row
         if (c >= row)
             return;
         idx = row * (row - 1) / 2 + c - a.out_offset;
@@ -167,6 +172,26 @@ __device__ __forceinline__ void block_coords(const RowsArgs& a, int& x, int& y)
     x = bid - a.tri_prefix[lo];
 }
 
+// The tile of this workgroup: refs [ref0, ref0 + nr) of the launch's ref list against the partner
+// positions [c0, c0 + 256) below `col_limit`.
+__device__ __forceinline__ void block_tile(const RowsArgs& a, int R, int& ref0, int& nr, int& c0, int& col_limit)
+{
+    if (a.jobs) {
+        const int4 j = a.jobs[blockIdx.x];
+        ref0 = j.x;
+        nr = j.y;
+        c0 = j.z;
+        col_limit = j.w;
+        return;
+    }
+    int bx, by;
+    block_coords(a, bx, by);
+    ref0 = by * R;
+    nr = min(R, a.n_refs - ref0);
+    c0 = bx * 256;
+    col_limit = a.n_cols;
+}
+
 // Triangle mode: a block whose columns all lie at or beyond its largest row has no work.
 __device__ __forceinline__ bool block_is_above_diagonal(const RowsArgs& a, int ref0, int nr, int c0)
 {
@@ -191,11 +216,8 @@ __global__ __launch_bounds__(256) void lcs_rows_kernel_quirk(RowsArgs a)
     constexpr int W = H / 2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int R = a.refs_per_block;
-    int bx, by;
-    block_coords(a, bx, by);
-    const int ref0 = by * R;
-    const int nr = min(R, a.n_refs - ref0);
-    const int c0 = bx * 256;
+    int ref0, nr, c0, col_limit;
+    block_tile(a, R, ref0, nr, c0, col_limit);
     if (block_is_above_diagonal(a, ref0, nr, c0))
         return;
     for (int r = 0; r < nr; ++r) {
@@ -205,7 +227,7 @@ __global__ __launch_bounds__(256) void lcs_rows_kernel_quirk(RowsArgs a)
     __syncthreads();
 
     const int c = c0 + tid;
-    const bool valid = c < a.n_cols;
+    const bool valid = c < col_limit;
     const int pid = a.col_ids ? a.col_ids[valid ? c : 0] : a.col_begin + (valid ? c : 0);
     const uint32_t len_p = valid ? a.lens[pid] : 0u;
     const uint8_t* pbase = a.tiles + a.tile_base[pid >> 6] + (uint64_t)(pid & 63) * 16;
@@ -348,11 +370,8 @@ __global__ __launch_bounds__(256) void lcs_rows_kernel_pipe(RowsArgs a)
     using P = Pipe<H, RG, LOOKAHEAD>;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int R = a.refs_per_block;
-    int bx, by;
-    block_coords(a, bx, by);
-    const int ref0 = by * R;
-    const int nr = min(R, a.n_refs - ref0);
-    const int c0 = bx * 256;
+    int ref0, nr, c0, col_limit;
+    block_tile(a, R, ref0, nr, c0, col_limit);
     if (block_is_above_diagonal(a, ref0, nr, c0))
         return;
     {
@@ -365,7 +384,7 @@ __global__ __launch_bounds__(256) void lcs_rows_kernel_pipe(RowsArgs a)
     __syncthreads();
 
     const int c = c0 + tid;
-    const bool valid = c < a.n_cols;
+    const bool valid = c < col_limit;
     const int pid = a.col_ids ? a.col_ids[valid ? c : 0] : a.col_begin + (valid ? c : 0);
     const uint32_t len_p = valid ? a.lens[pid] : 0u;
     const uint8_t* pbase = a.tiles + a.tile_base[pid >> 6] + (uint64_t)(pid & 63) * 16;

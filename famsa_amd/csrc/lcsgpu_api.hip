@@ -941,6 +941,166 @@ int lcsgpu_lcs_triangle_ids(lcsgpu_ctx* ctx, const int32_t* ids, int32_t n_ids, 
     return LCSGPU_OK;
 }
 
+int lcsgpu_lcs_triangles_batch(lcsgpu_ctx* ctx, const int32_t* ids, const int64_t* group_offsets, int32_t n_groups,
+                               void* out, int elem_size)
+{
+    if (!ctx) return fail(LCSGPU_E_INVALID, "NULL ctx");
+    if (ctx->n < 0) return fail(LCSGPU_E_STATE, "no sequence set uploaded");
+    if (n_groups < 0 || (n_groups > 0 && !group_offsets)) return fail(LCSGPU_E_INVALID, "bad group table");
+    if (elem_size != 2 && elem_size != 4) return fail(LCSGPU_E_INVALID, "elem_size must be 2 or 4");
+    if (elem_size == 2 && ctx->max_len > 65535)
+        return fail(LCSGPU_E_INVALID, "uint16 output needs all sequences <= 65535 residues");
+    if (n_groups == 0) return LCSGPU_OK;
+    if (group_offsets[0] != 0) return fail(LCSGPU_E_INVALID, "group_offsets[0] must be 0");
+    const int64_t n_total = group_offsets[n_groups];
+    if (n_total < 0 || n_total > 0x7fffffff) return fail(LCSGPU_E_INVALID, "bad total id count");
+    std::vector<int64_t> tri_base((size_t)n_groups + 1, 0);
+    bool any_long = false;
+    for (int32_t g = 0; g < n_groups; ++g) {
+        const int64_t m = group_offsets[g + 1] - group_offsets[g];
+        if (m < 0) return fail(LCSGPU_E_INVALID, "group_offsets not ascending");
+        tri_base[g + 1] = tri_base[g] + m * (m - 1) / 2;
+    }
+    const int64_t count = tri_base[n_groups];
+    if (count <= 0) return LCSGPU_OK;
+    if (!ids || !out) return fail(LCSGPU_E_INVALID, "NULL ids / out");
+    for (int64_t p = 0; p < n_total; ++p) {
+        if (ids[p] < 0 || ids[p] >= ctx->n) return fail(LCSGPU_E_INVALID, "id %d out of range", ids[p]);
+        any_long |= ctx->lens[ids[p]] > 2048;
+    }
+    LaneGuard guard(ctx, LaneGuard::ANY);
+    Lane& L = guard.lane();
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(L.d_out.reserve((size_t)count * elem_size));
+    if (any_long) { // the long-ref kernel keeps its 2-D grid: list by list
+        double ms = 0;
+        int launches = 0;
+        for (int32_t g = 0; g < n_groups; ++g) {
+            const int32_t m = (int32_t)(group_offsets[g + 1] - group_offsets[g]);
+            if (m < 2) continue;
+            const int32_t* gi = ids + group_offsets[g];
+            int rc = run_rows(ctx, L, lcsgpu::MODE_TRIANGLE, gi, 0, m, gi, 0, m - 1,
+                              (char*)L.d_out.p + (size_t)tri_base[g] * elem_size, 0, 0, elem_size, 0);
+            if (rc) return rc;
+            HIP_TRY(hipStreamSynchronize(L.stream));
+            finish_host_call(ctx, L);
+            ms += g_last.ms;
+            launches += g_last.launches;
+        }
+        HIP_TRY(hipMemcpy(out, L.d_out.p, (size_t)count * elem_size, hipMemcpyDeviceToHost));
+        g_last.ms = ms;
+        g_last.launches = launches;
+        return LCSGPU_OK;
+    }
+
+    // per instantiated kernel: its refs (in position order, so the refs of one list are adjacent) and its jobs
+    struct BatchBucket {
+        int bv;
+        bool quirk;
+        std::vector<int32_t> ref_id, ref_col0;
+        std::vector<int64_t> ref_row, ref_out0;
+        std::vector<int32_t> ref_group;
+        std::vector<int4> jobs;
+    };
+    std::vector<BatchBucket> buckets;
+    int index_of[160];
+    std::fill(index_of, index_of + 160, -1);
+    for (int32_t g = 0; g < n_groups; ++g)
+        for (int64_t p = group_offsets[g]; p < group_offsets[g + 1]; ++p) {
+            if (p == group_offsets[g]) continue; // the first member of a list has no partner
+            const int32_t id = ids[p];
+            const bool q = ctx->quirk[id] != 0;
+            const int bv = q ? lcsgpu::quirk_h_class(ctx->lens[id]) : lcsgpu::h_class(ctx->lens[id]);
+            const int key = bv * 2 + (q ? 1 : 0);
+            if (index_of[key] < 0) {
+                index_of[key] = (int)buckets.size();
+                buckets.push_back(BatchBucket{bv, q, {}, {}, {}, {}, {}, {}});
+            }
+            BatchBucket& b = buckets[index_of[key]];
+            b.ref_id.push_back(id);
+            b.ref_row.push_back(p);
+            b.ref_col0.push_back((int32_t)group_offsets[g]);
+            b.ref_out0.push_back(tri_base[g]);
+            b.ref_group.push_back(g);
+        }
+    size_t bytes = 0;
+    auto align16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
+    const size_t col_off = 0;
+    bytes += align16((size_t)n_total * 4);
+    std::vector<size_t> o_id(buckets.size()), o_row(buckets.size()), o_c0(buckets.size()), o_out(buckets.size()),
+        o_job(buckets.size());
+    for (size_t bi = 0; bi < buckets.size(); ++bi) {
+        BatchBucket& b = buckets[bi];
+        const int R = lcsgpu::refs_per_block(b.bv, b.quirk);
+        const size_t nr_all = b.ref_id.size();
+        for (size_t k0 = 0; k0 < nr_all;) {
+            size_t k1 = k0 + 1;
+            while (k1 < nr_all && k1 - k0 < (size_t)R && b.ref_group[k1] == b.ref_group[k0]) ++k1;
+            const int32_t g0 = b.ref_col0[k0];
+            const int32_t max_row = (int32_t)b.ref_row[k1 - 1]; // rows ascend inside a list
+            for (int32_t c0 = g0; c0 < max_row; c0 += 256)
+                b.jobs.push_back(make_int4((int)k0, (int)(k1 - k0), c0, max_row));
+            k0 = k1;
+        }
+        if (b.jobs.size() > 0x7fffffffu) return fail(LCSGPU_E_INVALID, "batch too large");
+        o_id[bi] = bytes; bytes += align16(nr_all * 4);
+        o_row[bi] = bytes; bytes += align16(nr_all * 8);
+        o_c0[bi] = bytes; bytes += align16(nr_all * 4);
+        o_out[bi] = bytes; bytes += align16(nr_all * 8);
+        o_job[bi] = bytes; bytes += align16(b.jobs.size() * sizeof(int4));
+    }
+    if (L.plan_in_flight) {
+        HIP_TRY(hipStreamSynchronize(L.stream));
+        L.plan_in_flight = false;
+    }
+    HIP_TRY(L.h_plan.reserve(bytes));
+    HIP_TRY(L.d_plan.reserve(bytes));
+    char* h = (char*)L.h_plan.p;
+    memcpy(h + col_off, ids, (size_t)n_total * 4);
+    for (size_t bi = 0; bi < buckets.size(); ++bi) {
+        const BatchBucket& b = buckets[bi];
+        memcpy(h + o_id[bi], b.ref_id.data(), b.ref_id.size() * 4);
+        memcpy(h + o_row[bi], b.ref_row.data(), b.ref_row.size() * 8);
+        memcpy(h + o_c0[bi], b.ref_col0.data(), b.ref_col0.size() * 4);
+        memcpy(h + o_out[bi], b.ref_out0.data(), b.ref_out0.size() * 8);
+        memcpy(h + o_job[bi], b.jobs.data(), b.jobs.size() * sizeof(int4));
+    }
+    HIP_TRY(hipMemcpyAsync(L.d_plan.p, h, bytes, hipMemcpyHostToDevice, L.stream));
+    L.plan_in_flight = true;
+    L.last_launches = 0;
+    HIP_TRY(hipEventRecord(L.ev_start, L.stream));
+    for (size_t bi = 0; bi < buckets.size(); ++bi) {
+        const BatchBucket& b = buckets[bi];
+        if (b.jobs.empty()) continue;
+        RowsArgs a{};
+        a.tiles = (const uint8_t*)ctx->d_tiles.p;
+        a.tile_base = (const uint64_t*)ctx->d_tile_base.p;
+        a.lens = (const uint32_t*)ctx->d_lens.p;
+        a.n_refs = (int32_t)b.ref_id.size();
+        char* d = (char*)L.d_plan.p;
+        a.ref_ids = (const int32_t*)(d + o_id[bi]);
+        a.ref_rows = (const int64_t*)(d + o_row[bi]);
+        a.ref_col0 = (const int32_t*)(d + o_c0[bi]);
+        a.ref_out0 = (const int64_t*)(d + o_out[bi]);
+        a.jobs = (const int4*)(d + o_job[bi]);
+        a.col_ids = (const int32_t*)(d + col_off);
+        a.n_cols = (int32_t)n_total;
+        a.out = L.d_out.p;
+        a.elem_size = elem_size;
+        a.mode = lcsgpu::MODE_TRIANGLE;
+        a.refs_per_block = lcsgpu::refs_per_block(b.bv, b.quirk);
+        HIP_TRY(lcsgpu::launch_rows(b.bv, b.quirk, a, (int)b.jobs.size(), 1, L.stream));
+        ++L.last_launches;
+    }
+    HIP_TRY(hipEventRecord(L.ev_stop, L.stream));
+    L.timing_valid = true;
+    HIP_TRY(hipMemcpyAsync(out, L.d_out.p, (size_t)count * elem_size, hipMemcpyDeviceToHost, L.stream));
+    HIP_TRY(hipEventRecord(L.ev_done, L.stream));
+    HIP_TRY(hipEventSynchronize(L.ev_done));
+    finish_host_call(ctx, L);
+    return LCSGPU_OK;
+}
+
 int lcsgpu_clarans(lcsgpu_ctx* ctx, const int32_t* ids, int32_t n_ids, int distance_kind, int32_t n_medoids,
                    int32_t n_fixed, float explore_fraction, int32_t num_local, int32_t* medoids_out)
 {
@@ -974,9 +1134,8 @@ int lcsgpu_clarans(lcsgpu_ctx* ctx, const int32_t* ids, int32_t n_ids, int dista
     auto a256 = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const size_t window = (size_t)std::max(corrected, 1);
     const size_t o_D = 0, o_DM = o_D + a256(pairs * 4), o_cand = o_DM + a256((size_t)n * k * 4),
-                 o_dn = o_cand + a256((size_t)n * 4), o_ds = o_dn + a256((size_t)n * 4), o_an = o_ds + a256((size_t)n * 4),
-                 o_as = o_an + a256((size_t)n * 4), o_rd = o_as + a256((size_t)n * 4), o_rm = o_rd + a256(window * 4),
-                 o_log = o_rm + a256(window * 4), o_state = o_log + a256((size_t)(n + 1) * 4), o_ids = o_state + 256,
+                 o_st = o_cand + a256((size_t)n * 4), o_rd = o_st + a256((size_t)n * 16), o_rm = o_rd + a256(window * 4),
+                 o_wxx = o_rm + a256(window * 4), o_wx = o_wxx + a256(window * 8), o_log = o_wx + a256(window * 8), o_state = o_log + a256((size_t)(n + 1) * 4), o_ids = o_state + 256,
                  total = o_ids + a256((size_t)n * 4);
     HIP_TRY(L.d_work.reserve(total));
     HIP_TRY(L.h_small.reserve(64));
@@ -993,14 +1152,14 @@ int lcsgpu_clarans(lcsgpu_ctx* ctx, const int32_t* ids, int32_t n_ids, int dista
     }
     lcsgpu::ClaransArgs a{};
     a.D = (const float*)(base + o_D);
-    a.DM = (float*)(base + o_DM);
+    a.DMt = (float*)(base + o_DM);
     a.cand = (int32_t*)(base + o_cand);
-    a.dn = (float*)(base + o_dn);
-    a.ds = (float*)(base + o_ds);
-    a.an = (int32_t*)(base + o_an);
-    a.as_ = (int32_t*)(base + o_as);
+    a.st = (float4*)(base + o_st);
     a.res_delta = (float*)(base + o_rd);
     a.res_mm = (int32_t*)(base + o_rm);
+    a.win_xx = (int32_t*)(base + o_wxx);
+    a.win_x = (int32_t*)(base + o_wx);
+    a.win_cap = (int32_t)window;
     a.cost_log = (float*)(base + o_log);
     a.state = (int32_t*)(base + o_state);
     a.n_elems = n;
@@ -1047,11 +1206,17 @@ int lcsgpu_clarans(lcsgpu_ctx* ctx, const int32_t* ids, int32_t n_ids, int dista
             }
         }
         HIP_TRY(hipMemcpyAsync(a.cand, cand.data(), (size_t)n * 4, hipMemcpyHostToDevice, L.stream));
-        HIP_TRY(lcsgpu::launch_clarans_init(a, L.stream));
+        if (diff) { // the init kernel already needs the first window's draws
+            int rc = extend_draws((size_t)p_host + (size_t)(batch + 1) * std::max(corrected, 1));
+            if (rc) return rc;
+        }
+        a.draws = (const int32_t*)L.d_draws.p;
+        a.draws_len = (int32_t)draws.size();
+        HIP_TRY(lcsgpu::launch_clarans_init(a, corrected, L.stream));
         bool first = true;
         for (;;) {
-            if (diff) {
-                int rc = extend_draws((size_t)p_host + (size_t)batch * std::max(corrected, 1));
+            if (diff) { // a round consumes at most `corrected` draws and prepares the window after it
+                int rc = extend_draws((size_t)p_host + (size_t)(batch + 1) * std::max(corrected, 1));
                 if (rc) return rc;
             }
             a.draws = (const int32_t*)L.d_draws.p;
@@ -1066,6 +1231,14 @@ int lcsgpu_clarans(lcsgpu_ctx* ctx, const int32_t* ids, int32_t n_ids, int dista
             p_host = h_state[0];
             if (h_state[1]) break;
         }
+#ifdef CLARANS_TRACE
+        {
+            unsigned long long tr[8];
+            HIP_TRY(hipMemcpy(tr, (char*)a.state + 64, sizeof tr, hipMemcpyDeviceToHost));
+            if (tr[7]) fprintf(stderr, "eval trace (x10 ns, avg over %llu): L1 %.0f gather %.0f sync %.0f walk %.0f sync %.0f reduce %.0f\n", tr[7],
+                    (double)tr[0] / tr[7], (double)tr[1] / tr[7], (double)tr[2] / tr[7], (double)tr[3] / tr[7], (double)tr[4] / tr[7], (double)tr[5] / tr[7]);
+        }
+#endif
         float cost;
         memcpy(&cost, &h_state[5], 4);
         HIP_TRY(hipMemcpy(cand.data(), a.cand, (size_t)n * 4, hipMemcpyDeviceToHost));

@@ -6,6 +6,7 @@
 // sequence), the sample triangle, and seeds x all rectangles (FastTree.cpp:309-324, 347, 385, 415).
 #include <algorithm>
 #include <limits>
+#include <memory>
 #include <numeric>
 #include <random>
 #include <stdexcept>
@@ -233,6 +234,12 @@ public:
         for (int i = 0; i < n_cols; ++i) c[i] = ids_[cols ? cols[i] : i];
         p_.rect(r.data(), n_refs, c.data(), n_cols, out);
     }
+    bool triangles_batch(const int* ids, const int64_t* offsets, int n_groups, LcsBuf& out) override
+    {
+        std::vector<int> g((size_t)offsets[n_groups]);
+        for (size_t i = 0; i < g.size(); ++i) g[i] = ids_[ids[i]];
+        return p_.triangles_batch(g.data(), offsets, n_groups, out);
+    }
     bool clarans(const int* ids, int n_ids, int kind, int n_medoids, int n_fixed, float fraction, int num_local,
                  int* medoids) override
     {
@@ -241,9 +248,28 @@ public:
         return p_.clarans(g.data(), n_ids, kind, n_medoids, n_fixed, fraction, num_local, medoids);
     }
 
-private:
+protected:
     LcsSource& p_;
     const std::vector<int>& ids_;
+};
+
+// A subset whose triangle has already been computed (as part of a batched request).
+class PrecomputedSubset : public SubsetSource {
+public:
+    PrecomputedSubset(LcsSource& parent, const std::vector<int>& ids, std::shared_ptr<const LcsBuf> all, size_t offset)
+        : SubsetSource(parent, ids), all_(std::move(all)), offset_(offset) {}
+    void triangle(int r0, int r1, LcsBuf& out) override
+    {
+        const size_t a = (size_t)r0 * (r0 > 0 ? r0 - 1 : 0) / 2, b = (size_t)r1 * (r1 > 0 ? r1 - 1 : 0) / 2;
+        out.resize(b > a ? b - a : 0, all_->wide);
+        for (size_t k = a; k < b; ++k) {
+            if (out.wide) out.v32[k - a] = all_->v32[offset_ + k]; else out.v16[k - a] = all_->v16[offset_ + k];
+        }
+    }
+
+private:
+    std::shared_ptr<const LcsBuf> all_;
+    size_t offset_;
 };
 
 // Sub-trees are independent, so every split at ANY depth hands its sub-trees to one shared pool
@@ -453,6 +479,25 @@ struct FastTree {
         return std::accumulate(dist_row.begin(), dist_row.end(), 0.0f);
     }
 
+    bool is_leaf(size_t n) const { return !(prm.use_clustering ? (int)n > prm.threshold : (int)n > prm.subtree_size); }
+
+    // the sub-tree of a subset that is not split further: the partial generator over its members
+    void leaf_tree(const std::vector<int>& ids, LcsSource& sub, tree_structure& tree, int previous_top)
+    {
+        const int n = (int)ids.size();
+        {
+            Scope t(g_phase.partial);
+            build_tree_partial(sub, partial, D, tree);
+        }
+        if (previous_top > n) {
+            for (int node = 0; node < n - 1; ++node) {
+                node_t& nd = tree[node];
+                nd.first = nd.first < n ? ids[nd.first] : nd.first + previous_top - n;
+                nd.second = nd.second < n ? ids[nd.second] : nd.second + previous_top - n;
+            }
+        }
+    }
+
     // FastTree::doStep, FastTree.cpp:56-266.  `ids` = global ids (sequence_no) of this subset.
     // parallel = true only at the top level, like the reference: the sub-trees of the first split
     // are built by worker threads (each with its own Transform tables; the GPU engine serialises
@@ -463,17 +508,7 @@ struct FastTree {
         const bool split = prm.use_clustering ? n > prm.threshold : n > prm.subtree_size;
         if (!split) {
             SubsetSource sub(src, ids);
-            {
-                Scope t(g_phase.partial);
-                build_tree_partial(sub, partial, D, tree);
-            }
-            if (previous_top > n) {
-                for (int node = 0; node < n - 1; ++node) {
-                    node_t& nd = tree[node];
-                    nd.first = nd.first < n ? ids[nd.first] : nd.first + previous_top - n;
-                    nd.second = nd.second < n ? ids[nd.second] : nd.second + previous_top - n;
-                }
-            }
+            leaf_tree(ids, sub, tree, previous_top);
             return;
         }
         float best_cost = std::numeric_limits<float>::max();
@@ -522,14 +557,63 @@ struct FastTree {
                 for (size_t i = 0; i < std::min<size_t>(6, sz.size()); ++i) fprintf(stderr, " %zu", sz[i]);
                 fprintf(stderr, "\n");
             }
-            // sub-trees only go through the pool when the split is big enough to amortise it
-            if (pool && tasks.size() > 1 && n >= 2 * std::max(prm.threshold, prm.subtree_size)) {
+            if (pool && !tasks.empty()) {
                 TaskPool::Group group;
-                for (size_t t = 0; t < tasks.size(); ++t)
-                    pool->submit(group, subgroups[tasks[t].k].size(), [this, t, &tasks, &subgroups, &locals] {
+                // the leaves' LCS triangles are requested in batches (one engine call each), the
+                // leaves of a batch then become tasks of their own; everything else is a task as it is
+                const size_t batch_pairs = (size_t)24 << 20;
+                std::vector<size_t> batch;
+                size_t batch_size = 0, batch_members = 0;
+                auto flush = [&] {
+                    if (batch.empty()) return;
+                    pool->submit(group, batch_members, [this, batch, &group, &tasks, &subgroups, &locals] {
+                        std::vector<int> ids;
+                        std::vector<int64_t> offs(1, 0);
+                        for (size_t t : batch) {
+                            const auto& g = subgroups[tasks[t].k];
+                            ids.insert(ids.end(), g.begin(), g.end());
+                            offs.push_back((int64_t)ids.size());
+                        }
+                        auto buf = std::make_shared<LcsBuf>();
+                        bool have;
+                        {
+                            Scope tm(g_phase.lcs);
+                            have = src.triangles_batch(ids.data(), offs.data(), (int)batch.size(), *buf);
+                        }
+                        size_t off = 0;
+                        for (size_t t : batch) {
+                            const size_t m = subgroups[tasks[t].k].size();
+                            pool->submit(group, m, [this, t, have, buf, off, &tasks, &subgroups, &locals] {
+                                FastTree<D> child{src, partial, prm, pool, {}};
+                                const auto& g = subgroups[tasks[t].k];
+                                if (have) {
+                                    PrecomputedSubset sub(src, g, buf, off);
+                                    child.leaf_tree(g, sub, locals[t], tasks[t].top);
+                                } else {
+                                    child.do_step(g, locals[t], tasks[t].top, false);
+                                }
+                            });
+                            off += m * (m - 1) / 2;
+                        }
+                    });
+                    batch.clear();
+                    batch_size = batch_members = 0;
+                };
+                for (size_t t = 0; t < tasks.size(); ++t) {
+                    const size_t m = subgroups[tasks[t].k].size();
+                    if (is_leaf(m) && partial != GT::MST_Prim) {
+                        batch.push_back(t);
+                        batch_size += m * (m - 1) / 2;
+                        batch_members += m;
+                        if (batch_size >= batch_pairs) flush();
+                        continue;
+                    }
+                    pool->submit(group, m, [this, t, &tasks, &subgroups, &locals] {
                         FastTree<D> child{src, partial, prm, pool, {}};
                         child.do_step(subgroups[tasks[t].k], locals[t], tasks[t].top, false);
                     });
+                }
+                flush();
                 pool->wait(group);
             } else {
                 for (size_t t = 0; t < tasks.size(); ++t)

@@ -40,10 +40,11 @@ GpuLcsSource::~GpuLcsSource()
 {
     if (getenv("FAMSA_GPU_PROFILE"))
         fprintf(stderr, "engine.rect: %ld calls %.3f thread-s %.3g pairs\nengine.triangle: %ld calls %.3f thread-s %.3g pairs\n"
-                        "engine.triangle_ids: %ld calls %.3f thread-s %.3g pairs\nengine.clarans: %ld calls %.3f thread-s %.3g pairs\n",
+                        "engine.triangle_ids: %ld calls %.3f thread-s %.3g pairs\nengine.clarans: %ld calls %.3f thread-s %.3g pairs\n"
+                        "engine.triangles_batch: %ld calls %.3f thread-s %.3g pairs\n",
                 st_rect_.calls, st_rect_.seconds, st_rect_.pairs, st_tri_.calls, st_tri_.seconds, st_tri_.pairs,
                 st_triids_.calls, st_triids_.seconds, st_triids_.pairs, st_clarans_.calls, st_clarans_.seconds,
-                st_clarans_.pairs);
+                st_clarans_.pairs, st_batch_.calls, st_batch_.seconds, st_batch_.pairs);
     if (ctx_) lcsgpu_destroy(ctx_);
 }
 
@@ -141,6 +142,22 @@ bool GpuLcsSource::nj_nodes(int distance_kind, std::vector<int32_t>& left, std::
     left.resize(m);
     right.resize(m);
     check(lcsgpu_nj(ctx_, distance_kind, left.data(), right.data()), "lcsgpu_nj");
+    add_kernel_ms();
+    return true;
+}
+
+bool GpuLcsSource::triangles_batch(const int* ids, const int64_t* offsets, int n_groups, LcsBuf& out)
+{
+    size_t count = 0;
+    for (int g = 0; g < n_groups; ++g) {
+        const size_t m = (size_t)(offsets[g + 1] - offsets[g]);
+        count += m * (m > 0 ? m - 1 : 0) / 2;
+    }
+    out.resize(count, wide());
+    if (count == 0) return true;
+    const double t0 = now_s();
+    check(lcsgpu_lcs_triangles_batch(ctx_, ids, offsets, n_groups, out.data(), out.elem_size()), "lcsgpu_lcs_triangles_batch");
+    note(st_batch_, now_s() - t0, (double)count);
     add_kernel_ms();
     return true;
 }

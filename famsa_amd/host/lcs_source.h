@@ -56,6 +56,9 @@ public:
     virtual bool upgma_nodes(int /*distance_kind*/, bool /*modified*/, std::vector<int32_t>& /*left*/,
                              std::vector<int32_t>& /*right*/) { return false; }
     virtual bool nj_nodes(int /*distance_kind*/, std::vector<int32_t>& /*left*/, std::vector<int32_t>& /*right*/) { return false; }
+    // The packed triangles of several id lists in one request: list g = ids[offsets[g] .. offsets[g+1]),
+    // its triangle at out[sum_{h<g} m_h(m_h-1)/2 ...].  False = not offered; ask list by list.
+    virtual bool triangles_batch(const int* /*ids*/, const int64_t* /*offsets*/, int /*n_groups*/, LcsBuf& /*out*/) { return false; }
     // CLARANS k-medoids over the sample `ids` computed by the source itself (device): medoids[k] =
     // member numbers 0..n_ids-1.  False = not offered for this shape; the caller runs the host search.
     virtual bool clarans(const int* /*ids*/, int /*n_ids*/, int /*distance_kind*/, int /*n_medoids*/, int /*n_fixed*/,
@@ -80,6 +83,7 @@ public:
     bool nj_nodes(int distance_kind, std::vector<int32_t>& left, std::vector<int32_t>& right) override;
     bool clarans(const int* ids, int n_ids, int distance_kind, int n_medoids, int n_fixed, float explore_fraction,
                  int num_local, int* medoids) override;
+    bool triangles_batch(const int* ids, const int64_t* offsets, int n_groups, LcsBuf& out) override;
     double kernel_ms_total() const { return kernel_ms_; }
     void add_kernel_ms();
 
@@ -91,7 +95,7 @@ private:
     double kernel_ms_ = 0;
     std::mutex mu_; // the tree builders may call from several threads
     // call statistics (printed at destruction when FAMSA_GPU_PROFILE is set)
-    struct CallStat { long calls = 0; double seconds = 0; double pairs = 0; } st_rect_, st_tri_, st_triids_, st_clarans_;
+    struct CallStat { long calls = 0; double seconds = 0; double pairs = 0; } st_rect_, st_tri_, st_triids_, st_clarans_, st_batch_;
     void note(CallStat& s, double sec, double pairs);
 };
 

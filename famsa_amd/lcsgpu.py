@@ -55,6 +55,7 @@ def load_library():
         "lcsgpu_mst_prim": (C.c_int, [vp, C.c_int, vp]),
         "lcsgpu_upgma": (C.c_int, [vp, C.c_int, C.c_int, vp, vp]),
         "lcsgpu_nj": (C.c_int, [vp, C.c_int, vp, vp]),
+        "lcsgpu_lcs_triangles_batch": (C.c_int, [vp, pi32, C.POINTER(C.c_int64), i32, vp, C.c_int]),
         "lcsgpu_clarans": (C.c_int, [vp, pi32, i32, C.c_int, i32, i32, C.c_float, i32, pi32]),
         "lcsgpu_sync": (C.c_int, [vp]),
         "lcsgpu_last_kernel_ms": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(i32)]),
@@ -167,6 +168,22 @@ class LcsGpu:
         self._check(self._lib.lcsgpu_lcs_triangle_ids(self._ctx, ptr, n, out.ctypes.data if out.size else None,
                                                       out.itemsize))
         return out
+
+    def lcs_triangles_batch(self, groups, dtype=np.uint16):
+        """Packed lower triangles of several id lists, one call; returns a list of 1-D arrays."""
+        sizes = [len(g) for g in groups]
+        offs = np.zeros(len(groups) + 1, dtype=np.int64)
+        np.cumsum(sizes, out=offs[1:])
+        ids = np.ascontiguousarray(np.concatenate([np.asarray(g, np.int32) for g in groups])
+                                   if offs[-1] else np.zeros(0, np.int32), dtype=np.int32)
+        tri = [m * (m - 1) // 2 for m in sizes]
+        base = np.zeros(len(groups) + 1, dtype=np.int64)
+        np.cumsum(tri, out=base[1:])
+        out = np.empty(max(int(base[-1]), 1), dtype=dtype)
+        self._check(self._lib.lcsgpu_lcs_triangles_batch(self._ctx, ids.ctypes.data_as(C.POINTER(C.c_int32)),
+                                                         offs.ctypes.data_as(C.POINTER(C.c_int64)), len(groups),
+                                                         out.ctypes.data, out.itemsize))
+        return [out[base[g]:base[g + 1]].copy() for g in range(len(groups))]
 
     def lcs_triangle_dev(self, row_begin, row_end, d_out_ptr, elem_size, sync=False):
         self._check(self._lib.lcsgpu_lcs_triangle_dev(self._ctx, row_begin, row_end, C.c_void_p(d_out_ptr),

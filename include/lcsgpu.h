@@ -190,6 +190,17 @@ int lcsgpu_upgma(lcsgpu_ctx* ctx, int distance_kind, int modified, int32_t* out_
  * NeighborJoining::computeTree. */
 int lcsgpu_nj(lcsgpu_ctx* ctx, int distance_kind, int32_t* out_left, int32_t* out_right);
 
+/* The lower triangles of several id lists in one call (the leaf sub-trees of one FastTree split):
+ * list g = ids[group_offsets[g] .. group_offsets[g+1]), m_g members; out receives the packed
+ * triangles one after the other, list g at element offset sum_{h<g} m_h(m_h-1)/2, inside it
+ * out[k*(k-1)/2 + c] = LCS(ref = list[k], partner = list[c]), c < k  (as lcsgpu_lcs_triangle_ids).
+ * out is HOST memory.  One kernel launch per word-count class for the whole batch instead of
+ * one call per list.
+ * Replaces: the calculateDistanceMatrix calls of the leaf generators that FastTree::doStep runs
+ * one by one on its sub-trees (tree/FastTree.cpp:82-103, 180-246). */
+int lcsgpu_lcs_triangles_batch(lcsgpu_ctx* ctx, const int32_t* ids, const int64_t* group_offsets, int32_t n_groups,
+                               void* out, int elem_size);
+
 /* CLARANS k-medoids over a sample of the uploaded set, on the device: LCS triangle over `ids`
  * (ref = ids[i], partner = ids[j], j < i) -> float distances (Transform<float>) -> `num_local`
  * local searches, each the reference's swap search with its two mt19937 streams, its float

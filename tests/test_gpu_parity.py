@@ -267,6 +267,53 @@ def test_triangle_over_id_lists(engine, oracle):
         assert (got == want).all(), m
 
 
+def _random_groups(rng, n, sizes):
+    return [rng.permutation(n)[:m].astype(np.int32) for m in sizes]
+
+
+def test_triangles_batch_vs_oracle(engine, oracle):
+    """The leaf matrices of one FastTree split in one call: every list's triangle, lists of 0 / 1 / 2
+    members, word-count classes mixed inside a list, orientation-sensitive members."""
+    rng = np.random.Generator(np.random.PCG64(23))
+    lens = [int(x) for x in rng.integers(1, 700, size=900)] + [64 * 3, 64 * 5, 64 * 2, 2048]
+    seqs = [rng.integers(0, 21, size=l).astype(np.uint8) for l in lens]
+    seqs[-4][64:128] = 3   # orientation-sensitive members
+    seqs[-3][128:256] = 9
+    seqs[-2][64:128] = 0
+    engine.upload_seqs(seqs)
+    codes, offsets = seqio.pack(seqs)
+    n = len(seqs)
+    groups = _random_groups(rng, n, [0, 1, 2, 3, 40, 257, 1, 300, 0, 77, 513, 5])
+    groups.append(np.array([n - 4, 5, n - 3, n - 2, 9, n - 1, n - 4], np.int32))  # quirk refs and a repeated id
+    groups.append(np.array(seqio.sort_order(seqs)[:350], np.int32))
+    for dtype in (np.uint16, np.uint32):
+        got = engine.lcs_triangles_batch(groups, dtype=dtype)
+        assert len(got) == len(groups)
+        for g, ids in enumerate(groups):
+            m = len(ids)
+            want = oracle.rect(codes, offsets, ids, ids)[np.tril_indices(m, -1)] if m > 1 else np.zeros(0)
+            assert got[g].shape == (m * (m - 1) // 2,)
+            assert (got[g] == want).all(), (g, m)
+        one_by_one = [engine.lcs_triangle_ids(ids, dtype=dtype) for ids in groups if len(ids) > 1]
+        assert all((a == b).all() for a, b in zip([x for x in got if len(x)], [x for x in one_by_one if len(x)]))
+
+
+def test_triangles_batch_with_long_members(engine, oracle):
+    """Lists containing members beyond 2048 residues take the list-by-list path; same values."""
+    rng = np.random.Generator(np.random.PCG64(29))
+    lens = [int(x) for x in rng.integers(20, 400, size=60)] + [2100, 2500, 3000]
+    seqs = [rng.integers(0, 20, size=l).astype(np.uint8) for l in lens]
+    engine.upload_seqs(seqs)
+    codes, offsets = seqio.pack(seqs)
+    n = len(seqs)
+    groups = [np.arange(n, dtype=np.int32)[::-1].copy(), np.array([n - 1, 3, n - 2], np.int32), np.array([4], np.int32)]
+    got = engine.lcs_triangles_batch(groups, dtype=np.uint32)
+    for g, ids in enumerate(groups):
+        m = len(ids)
+        want = oracle.rect(codes, offsets, ids, ids)[np.tril_indices(m, -1)] if m > 1 else np.zeros(0)
+        assert (got[g] == want).all(), g
+
+
 def test_concurrent_host_threads_share_one_context(engine, oracle):
     """The reference runs one CLCSBP per worker thread; here many threads share the engine and their
     host-memory calls run on separate lanes (streams).  Every thread must get its own results."""
