@@ -132,6 +132,11 @@ hipError_t launch_nj(const NjArgs& a, hipStream_t stream);
 hipError_t launch_float_distances(const void* lcs, int elem_size, const uint32_t* lens, const float* pow_f32, int kind,
                                   int n, float* D, hipStream_t stream);
 
+// ---- the uploaded set's device form (upload_kernels.hip) ----
+// tiles / quirk flags from the packed codes; flags[0] |= 1 if a symbol code >= 32 was met
+hipError_t launch_build_set(const uint8_t* codes, const uint64_t* offsets, const uint64_t* tile_base, int32_t n,
+                            uint8_t* tiles, uint8_t* quirk, int32_t* flags, hipStream_t stream);
+
 // ---- device-side CLARANS (clarans_kernels.hip) ----
 constexpr int CLARANS_MAX_MEDOIDS = 1024;
 struct ClaransArgs {

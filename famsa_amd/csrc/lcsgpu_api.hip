@@ -183,21 +183,6 @@ namespace {
 
 using lcsgpu::RowsArgs;
 
-// A ref is "quirk-capable" iff some word w >= 1 that lies fully inside the sequence holds
-// 64 copies of one valid residue: only then can tB == ~0 meet a carry-in (SURVEY note Q).
-bool is_quirk_capable(const uint8_t* s, uint32_t len)
-{
-    for (uint32_t w = 1; (w + 1) * 64 <= len; ++w) {
-        const uint8_t c = s[w * 64];
-        if (c >= 20) continue;
-        bool all = true;
-        for (uint32_t i = 1; i < 64 && all; ++i)
-            all = s[w * 64 + i] == c;
-        if (all) return true;
-    }
-    return false;
-}
-
 struct RefItem {
     int32_t id;
     int64_t row;
@@ -550,12 +535,9 @@ int lcsgpu_upload(lcsgpu_ctx* ctx, const uint8_t* codes, const uint64_t* offsets
         if (len > 0x7fffffffu) return fail(LCSGPU_E_INVALID, "sequence %d too long", i);
         lens[i] = (uint32_t)len;
         max_len = std::max(max_len, lens[i]);
-        const uint8_t* s = codes + offsets[i];
-        for (uint32_t k = 0; k < lens[i]; ++k)
-            if (s[k] >= 32) return fail(LCSGPU_E_INVALID, "symbol code %u out of range in sequence %d", s[k], i);
-        quirk[i] = is_quirk_capable(s, lens[i]) ? 1 : 0;
     }
-    // position-major tiles of 64 sequences; chunk = 16 residues; byte = code*8; pad = 22*8
+    // position-major tiles of 64 sequences; chunk = 16 residues; byte = code*8; pad = 22*8.
+    // The packed codes go to HBM as they are; tiles and orientation flags are built there.
     const int32_t n_tiles = (n + 63) / 64;
     std::vector<uint64_t> tile_base((size_t)n_tiles + 1, 0);
     for (int32_t t = 0; t < n_tiles; ++t) {
@@ -565,30 +547,38 @@ int lcsgpu_upload(lcsgpu_ctx* ctx, const uint8_t* codes, const uint64_t* offsets
         tile_base[t + 1] = tile_base[t] + chunks * 1024;
     }
     const size_t total = (size_t)tile_base[n_tiles];
-    PinBuf stage;
-    if (total) {
-        HIP_TRY(stage.reserve(total));
-        uint8_t* img = (uint8_t*)stage.p;
-        memset(img, 22 * 8, total);
-        for (int32_t s = 0; s < n; ++s) {
-            uint8_t* base = img + tile_base[s >> 6] + (size_t)(s & 63) * 16;
-            const uint8_t* src = codes + offsets[s];
-            for (uint32_t p = 0; p < lens[s]; ++p)
-                base[(size_t)(p >> 4) * 1024 + (p & 15)] = (uint8_t)(src[p] * 8);
-        }
-    }
+    const size_t raw_bytes = n ? (size_t)(offsets[n] - offsets[0]) : 0;
+    if (n && offsets[0] != 0) return fail(LCSGPU_E_INVALID, "offsets[0] must be 0");
     hipError_t e = hipSuccess;
     if ((e = ctx->d_tiles.reserve(std::max<size_t>(total, 16))) != hipSuccess ||
         (e = ctx->d_tile_base.reserve(((size_t)n_tiles + 1) * 8)) != hipSuccess ||
-        (e = ctx->d_lens.reserve(std::max<size_t>((size_t)n * 4, 16))) != hipSuccess) {
-        stage.release();
+        (e = ctx->d_lens.reserve(std::max<size_t>((size_t)n * 4, 16))) != hipSuccess)
         return fail(LCSGPU_E_NOMEM, "device allocation failed: %s", hipGetErrorString(e));
-    }
-    if (total) e = hipMemcpy(ctx->d_tiles.p, stage.p, total, hipMemcpyHostToDevice);
-    stage.release();
-    if (e != hipSuccess) return fail(LCSGPU_E_HIP, "tile upload failed: %s", hipGetErrorString(e));
     HIP_TRY(hipMemcpy(ctx->d_tile_base.p, tile_base.data(), ((size_t)n_tiles + 1) * 8, hipMemcpyHostToDevice));
     if (n) HIP_TRY(hipMemcpy(ctx->d_lens.p, lens.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+    if (n) {
+        DevBuf d_raw, d_off, d_quirk; // only needed while the tiles are built
+        struct Release {
+            DevBuf &a, &b, &c;
+            ~Release() { a.release(); b.release(); c.release(); }
+        } release{d_raw, d_off, d_quirk};
+        if ((e = d_raw.reserve(std::max<size_t>(raw_bytes, 16))) != hipSuccess ||
+            (e = d_off.reserve(((size_t)n + 1) * 8)) != hipSuccess || (e = d_quirk.reserve((size_t)n + 16)) != hipSuccess)
+            return fail(LCSGPU_E_NOMEM, "device allocation failed: %s", hipGetErrorString(e));
+        hipStream_t st = ctx->lanes[0].stream;
+        if (raw_bytes) HIP_TRY(hipMemcpyAsync(d_raw.p, codes, raw_bytes, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(d_off.p, offsets, ((size_t)n + 1) * 8, hipMemcpyHostToDevice, st));
+        int32_t* d_flags = (int32_t*)((char*)d_quirk.p + (((size_t)n + 3) & ~(size_t)3));
+        HIP_TRY(hipMemsetAsync(d_flags, 0, 4, st));
+        HIP_TRY(lcsgpu::launch_build_set((const uint8_t*)d_raw.p, (const uint64_t*)d_off.p,
+                                         (const uint64_t*)ctx->d_tile_base.p, n, (uint8_t*)ctx->d_tiles.p,
+                                         (uint8_t*)d_quirk.p, d_flags, st));
+        int32_t flags = 0;
+        HIP_TRY(hipMemcpyAsync(quirk.data(), d_quirk.p, (size_t)n, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(&flags, d_flags, 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (flags & 1) return fail(LCSGPU_E_INVALID, "symbol code out of range (>= 32) in the uploaded set");
+    }
     {
         // pow(indel, 0.75) for every possible indel, from the host's libm -- the entries of
         // Transform<double, indel075_div_lcs>::pp_pow075_rec (reference AbstractTreeGenerator.hpp:43-48)

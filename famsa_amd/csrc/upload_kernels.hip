@@ -1,0 +1,82 @@
+// upload_kernels.hip -- builds the device-resident form of an uploaded sequence set on the device:
+// the caller's packed codes (1 B/residue, lcsgpu_upload layout) are copied to HBM once and turned
+// there into the position-major 64-sequence tiles the LCS kernels stream (byte = code * 8, 16-byte
+// chunks, padding = code 22), together with the per-sequence orientation flags (SURVEY note Q).
+// On the host this transposition was a byte-wise scatter over the whole set (0.3 s per 10^6
+// sequences); here it is one pass at HBM speed.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "lcs_kernels.h"
+
+namespace lcsgpu {
+
+// one workgroup per tile; lane = sequence of the tile, the 4 waves stride over the 16-residue chunks
+__global__ __launch_bounds__(256) void tiles_fill_kernel(const uint8_t* __restrict__ codes,
+                                                         const uint64_t* __restrict__ offsets,
+                                                         const uint64_t* __restrict__ tile_base, int32_t n,
+                                                         uint8_t* __restrict__ tiles, int32_t* __restrict__ flags)
+{
+    const int tile = blockIdx.x, s = threadIdx.x & 63, stripe = threadIdx.x >> 6;
+    const int64_t seq = (int64_t)tile * 64 + s;
+    const uint64_t off = seq < n ? offsets[seq] : 0;
+    const uint32_t len = seq < n ? (uint32_t)(offsets[seq + 1] - off) : 0u;
+    const uint64_t base = tile_base[tile];
+    const int chunks = (int)((tile_base[tile + 1] - base) >> 10);
+    bool bad = false;
+    for (int c = stripe; c < chunks; c += 4) {
+        uint32_t w[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            uint32_t word = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const uint32_t p = (uint32_t)c * 16 + q * 4 + b;
+                uint32_t v = 22;
+                if (p < len) {
+                    v = codes[off + p];
+                    bad |= v >= 32;
+                }
+                word |= ((v * 8) & 0xFFu) << (8 * b);
+            }
+            w[q] = word;
+        }
+        *reinterpret_cast<uint4*>(tiles + base + (uint64_t)c * 1024 + (uint64_t)s * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    if (bad) atomicOr(flags, 1);
+}
+
+// A ref is orientation-sensitive iff some 64-bit word w >= 1 that lies fully inside the sequence
+// holds 64 copies of one valid residue (only then can tB == ~0 meet a carry-in).
+__global__ __launch_bounds__(256) void quirk_flags_kernel(const uint8_t* __restrict__ codes,
+                                                          const uint64_t* __restrict__ offsets, int32_t n,
+                                                          uint8_t* __restrict__ quirk)
+{
+    const int64_t seq = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (seq >= n) return;
+    const uint64_t off = offsets[seq];
+    const uint32_t len = (uint32_t)(offsets[seq + 1] - off);
+    bool q = false;
+    for (uint32_t w = 1; (w + 1) * 64 <= len && !q; ++w) {
+        const uint8_t* p = codes + off + (uint64_t)w * 64;
+        const uint8_t c = p[0];
+        if (c >= 20) continue;
+        bool all = true;
+        for (int i = 1; i < 64 && all; ++i) all = p[i] == c;
+        q = all;
+    }
+    quirk[seq] = q ? 1 : 0;
+}
+
+hipError_t launch_build_set(const uint8_t* codes, const uint64_t* offsets, const uint64_t* tile_base, int32_t n,
+                            uint8_t* tiles, uint8_t* quirk, int32_t* flags, hipStream_t stream)
+{
+    if (n <= 0) return hipSuccess;
+    const int n_tiles = (n + 63) / 64;
+    hipLaunchKernelGGL(tiles_fill_kernel, dim3(n_tiles), dim3(256), 0, stream, codes, offsets, tile_base, n, tiles, flags);
+    hipLaunchKernelGGL(quirk_flags_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, codes, offsets, n, quirk);
+    return hipGetLastError();
+}
+
+} // namespace lcsgpu

@@ -135,6 +135,29 @@ int famsa_host_dist_export_gpu(const char* fasta, int device, int distance, int 
     }
 }
 
+// The records of a FASTA file as the reader delivers them (tests): ids joined by '\n' into ids_buf,
+// codes and offsets as in SeqSet.  Returns the record count, or -1 (error / buffers too small).
+long famsa_host_records(const char* fasta, int n_threads, char* ids_buf, long ids_cap, uint8_t* codes_buf,
+                        long codes_cap, uint64_t* offsets, long cap)
+{
+    try {
+        SeqSet s = load_fasta(fasta, n_threads);
+        std::string joined;
+        for (const auto& id : s.ids) {
+            joined += id;
+            joined += '\n';
+        }
+        if ((long)s.size() + 1 > cap || (long)s.codes.size() > codes_cap || (long)joined.size() + 1 > ids_cap)
+            throw std::runtime_error("buffer too small");
+        memcpy(ids_buf, joined.c_str(), joined.size() + 1);
+        if (!s.codes.empty()) memcpy(codes_buf, s.codes.data(), s.codes.size());
+        for (size_t i = 0; i <= s.size(); ++i) offsets[i] = s.offsets[i];
+        return (long)s.size();
+    } catch (const std::exception& e) {
+        return fail(e);
+    }
+}
+
 int famsa_host_format_distance(double v, char* out) { return format_distance(v, out); }
 
 // The host CLARANS search over a caller-supplied float distance triangle (tests compare the device search with it).

@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <chrono>
 #include <fstream>
 #include <iostream>
 #include <stdexcept>
@@ -93,15 +94,7 @@ int main(int argc, char** argv)
         // -t <n>: host worker threads (0 = half of the hardware threads, reference core/params.cpp:285-291)
         int n_threads = 0;
         if (find_option(params, "-t", aux)) n_threads = std::stoi(aux);
-        if (n_threads <= 0) {
-            n_threads = std::max(1u, std::thread::hardware_concurrency() / 2);
-            // a container may grant fewer cores than the machine has (cgroup v2 cpu.max = "<quota> <period>")
-            std::ifstream cg("/sys/fs/cgroup/cpu.max");
-            std::string quota;
-            long period = 0;
-            if (cg >> quota >> period && quota != "max" && period > 0)
-                n_threads = std::max(1, std::min(n_threads, (int)((std::stol(quota) + period - 1) / period)));
-        }
+        if (n_threads <= 0) n_threads = default_host_threads(); // respects a container's cpu.max
         opt.fast.n_threads = n_threads;
         const bool very_verbose = find_switch(params, "-vv");
         const bool verbose = find_switch(params, "-v") || very_verbose;
@@ -121,21 +114,33 @@ int main(int argc, char** argv)
             throw std::runtime_error("famsa-gpu covers -gt_export and -dist_export; the alignment stage is not part of this engine");
 
         const std::string input = params[0], output = params[1];
-        SeqSet s = load_fasta(input);
+        const auto clock0 = std::chrono::steady_clock::now();
+        auto since = [](std::chrono::steady_clock::time_point a) {
+            return std::chrono::duration<double>(std::chrono::steady_clock::now() - a).count();
+        };
+        SeqSet s = load_fasta(input, n_threads);
         if (s.size() == 0) throw std::runtime_error("no sequences in " + input);
         Timings t;
+        t.load_s = since(clock0);
         if (export_dist) {
             dist_export_gpu(s, device, opt.dist, square, pid, output, &t);
         } else {
             const std::string nwk = guide_tree_newick_gpu(s, device, opt, &t);
+            const auto clock1 = std::chrono::steady_clock::now();
             std::ofstream f(output, std::ios::binary);
             if (!f.good()) throw std::runtime_error("cannot open " + output);
             f << nwk;
+            f.close();
+            t.store_s = since(clock1);
         }
         if (verbose) {
-            std::cerr << "time.sort=" << t.sort_s << "\n"
+            std::cerr << "time.load=" << t.load_s << "\n"
+                      << "time.sort=" << t.sort_s << "\n"
+                      << "time.gpu_init=" << t.init_s << "\n"
                       << "time.gpu_upload=" << t.upload_s << "\n"
                       << "time.tree_build=" << t.tree_s << "\n"
+                      << "time.newick=" << t.newick_s << "\n"
+                      << "time.store=" << t.store_s << "\n"
                       << "gpu.lcs_kernel_ms=" << t.kernel_ms << "\n";
         }
         return 0;

@@ -10,8 +10,9 @@ static double now_s()
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
-std::string guide_tree_newick(const SeqSet& s, const WorkSet& w, LcsSource& src, const TreeOptions& opt)
+std::string guide_tree_newick(const SeqSet& s, const WorkSet& w, LcsSource& src, const TreeOptions& opt, Timings* t)
 {
+    const double t0 = now_s();
     // names of the leaves = ids in sorted order (the reference reorders its sequence vector)
     std::vector<std::string> names(w.n_sorted());
     for (int k = 0; k < w.n_sorted(); ++k) names[k] = s.ids[w.sorted2input[k]];
@@ -28,8 +29,14 @@ std::string guide_tree_newick(const SeqSet& s, const WorkSet& w, LcsSource& src,
     } else {
         build_tree(src, opt.method, opt.dist, tree, 1);
     }
+    const double t1 = now_s();
     tree_from_unique(tree, w.sorted2unique);
-    return tree_to_newick(tree, names);
+    std::string nwk = tree_to_newick(tree, names);
+    if (t) {
+        t->tree_s = t1 - t0;
+        t->newick_s = now_s() - t1;
+    }
+    return nwk;
 }
 
 std::string guide_tree_newick_from_matrix(const SeqSet& s, const uint32_t* sq, const TreeOptions& opt)
@@ -52,22 +59,22 @@ std::string guide_tree_newick_from_matrix(const SeqSet& s, const uint32_t* sq, c
 std::string guide_tree_newick_gpu(const SeqSet& s, int device, const TreeOptions& opt, Timings* t)
 {
     double t0 = now_s();
-    WorkSet w = make_workset(s, opt.keep_duplicates);
+    WorkSet w = make_workset(s, opt.keep_duplicates, opt.fast.n_threads);
     std::vector<int> in_of(w.n_unique());
     for (int a = 0; a < w.n_unique(); ++a) in_of[a] = w.sorted2input[w.unique2sorted[a]];
     std::vector<uint8_t> codes;
     std::vector<uint64_t> offsets;
-    pack(s, in_of, codes, offsets);
+    pack(s, in_of, codes, offsets, opt.fast.n_threads);
     double t1 = now_s();
     GpuLcsSource src(device);
+    double t1b = now_s();
     src.upload(codes, offsets);
     double t2 = now_s();
-    std::string nwk = guide_tree_newick(s, w, src, opt);
-    double t3 = now_s();
+    std::string nwk = guide_tree_newick(s, w, src, opt, t);
     if (t) {
         t->sort_s = t1 - t0;
-        t->upload_s = t2 - t1;
-        t->tree_s = t3 - t2;
+        t->init_s = t1b - t1;
+        t->upload_s = t2 - t1b;
         t->kernel_ms = src.kernel_ms_total();
     }
     return nwk;
@@ -76,14 +83,9 @@ std::string guide_tree_newick_gpu(const SeqSet& s, int device, const TreeOptions
 void dist_export_gpu(const SeqSet& s, int device, Distance dist, bool square, bool pid, const std::string& path,
                      Timings* t)
 {
-    std::vector<int> all(s.size());
-    for (size_t i = 0; i < s.size(); ++i) all[i] = (int)i;
-    std::vector<uint8_t> codes;
-    std::vector<uint64_t> offsets;
-    pack(s, all, codes, offsets);
     double t1 = now_s();
     GpuLcsSource src(device);
-    src.upload(codes, offsets);
+    src.upload(s.codes, s.offsets); // input order, no sort, no dedup: the set as it was read
     double t2 = now_s();
     write_distance_csv(src, s.ids, dist, square, pid, path);
     double t3 = now_s();

@@ -11,7 +11,7 @@
 namespace famsa_host {
 
 struct Timings {
-    double sort_s = 0, upload_s = 0, tree_s = 0, kernel_ms = 0, store_s = 0;
+    double load_s = 0, sort_s = 0, init_s = 0, upload_s = 0, tree_s = 0, newick_s = 0, store_s = 0, kernel_ms = 0;
 };
 
 // Newick for the whole input (duplicates re-attached), LCS values from `src_of_unique`, whose
@@ -25,7 +25,8 @@ struct TreeOptions {
     FastTreeParams fast;
 };
 
-std::string guide_tree_newick(const SeqSet& s, const WorkSet& w, LcsSource& src_of_unique, const TreeOptions& opt);
+std::string guide_tree_newick(const SeqSet& s, const WorkSet& w, LcsSource& src_of_unique, const TreeOptions& opt,
+                              Timings* t = nullptr);
 
 std::string guide_tree_newick_from_matrix(const SeqSet& s, const uint32_t* square_input_order, const TreeOptions& opt);
 std::string guide_tree_newick_gpu(const SeqSet& s, int device, const TreeOptions& opt, Timings* t);

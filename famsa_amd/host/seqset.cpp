@@ -1,82 +1,244 @@
 #include "seqset.h"
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <algorithm>
+#include <cstring>
 #include <fstream>
 #include <numeric>
 #include <stdexcept>
+#include <thread>
 
 #include "../../include/lcsgpu.h"
 
 namespace famsa_host {
 
-static std::vector<uint8_t> encode(const std::string& residues)
+int default_host_threads()
 {
-    std::vector<uint8_t> out(residues.size() ? residues.size() : 1);
-    size_t n = 0;
-    if (lcsgpu_encode(residues.data(), residues.size(), out.data(), &n) != LCSGPU_OK)
-        throw std::runtime_error(std::string("lcsgpu_encode: ") + lcsgpu_last_error());
-    out.resize(n);
-    return out;
+    int n = std::max(1u, std::thread::hardware_concurrency() / 2);
+    // a container may grant fewer cores than the machine has (cgroup v2 cpu.max = "<quota> <period>")
+    std::ifstream cg("/sys/fs/cgroup/cpu.max");
+    std::string quota;
+    long period = 0;
+    if (cg >> quota >> period && quota != "max" && period > 0)
+        n = std::max(1, std::min(n, (int)((std::stol(quota) + period - 1) / period)));
+    return n;
 }
+
+namespace {
+
+// run fn(t) for t in [0, n_tasks) on up to n_threads threads (static split, one task per thread slot)
+template <class Fn>
+void parallel_for(int n_tasks, int n_threads, Fn fn)
+{
+    n_threads = std::max(1, std::min(n_threads, n_tasks));
+    if (n_threads == 1) {
+        for (int t = 0; t < n_tasks; ++t) fn(t);
+        return;
+    }
+    std::vector<std::thread> th;
+    std::vector<std::string> errors(n_threads);
+    for (int w = 0; w < n_threads; ++w)
+        th.emplace_back([&, w] {
+            try {
+                for (int t = w; t < n_tasks; t += n_threads) fn(t);
+            } catch (const std::exception& e) {
+                errors[w] = e.what();
+            }
+        });
+    for (auto& t : th) t.join();
+    for (const auto& e : errors)
+        if (!e.empty()) throw std::runtime_error(e);
+}
+
+void append_codes(std::vector<uint8_t>& out, const char* residues, size_t n)
+{
+    const size_t at = out.size();
+    out.resize(at + n);
+    size_t m = 0;
+    if (n && lcsgpu_encode(residues, n, out.data() + at, &m) != LCSGPU_OK)
+        throw std::runtime_error(std::string("lcsgpu_encode: ") + lcsgpu_last_error());
+    out.resize(at + m);
+}
+
+// The reader's state machine (reference core/io_service.h:99-124) over the lines of one piece of
+// the file.  A piece starts at a header line (or at the start of the file), so it starts with
+// the machine's clean state; only the first piece can see residue lines before any header.
+struct Piece {
+    std::vector<std::string> ids;
+    std::vector<uint8_t> codes;
+    std::vector<uint64_t> ends; // end offset of every record inside `codes`
+};
+
+void parse_piece(const char* p, const char* end, Piece& out)
+{
+    std::string id;
+    bool have_id = false;
+    size_t seq_begin = 0; // residues of the pending record start here in out.codes
+    while (p < end) {
+        const char* nl = (const char*)memchr(p, '\n', (size_t)(end - p));
+        const char* line_end = nl ? nl : end;
+        const char* next = nl ? nl + 1 : end;
+        while (line_end > p && (line_end[-1] == '\n' || line_end[-1] == '\r')) --line_end;
+        if (line_end > p) {
+            if (*p == '>') {
+                if (have_id && out.codes.size() > seq_begin) {
+                    out.ids.push_back(id);
+                    out.ends.push_back(out.codes.size());
+                    seq_begin = out.codes.size();
+                }
+                id.assign(p, line_end);
+                have_id = true;
+            } else {
+                append_codes(out.codes, p, (size_t)(line_end - p));
+            }
+        }
+        p = next;
+    }
+    if (have_id && out.codes.size() > seq_begin) {
+        out.ids.push_back(id);
+        out.ends.push_back(out.codes.size());
+        seq_begin = out.codes.size();
+    }
+    out.codes.resize(seq_begin); // residues that never got a record (no header at all)
+}
+
+// FAMSA's working order as a strict weak order on input indices; the index breaks ties, which
+// makes a plain sort give the stable sort's result
+struct OrderLess {
+    const SeqSet& s;
+    bool operator()(int a, int b) const
+    {
+        const uint32_t la = s.length(a), lb = s.length(b);
+        if (la != lb) return la > lb;
+        // the reference compares symbol_t = (signed) char; codes are < 32 so unsigned bytes agree
+        const int c = la ? memcmp(s.data(a), s.data(b), la) : 0;
+        if (c != 0) return c < 0;
+        return a < b;
+    }
+};
+
+} // namespace
 
 SeqSet from_records(const std::vector<std::string>& ids, const std::vector<std::string>& residues)
 {
     SeqSet s;
     s.ids = ids;
-    s.codes.reserve(ids.size());
-    for (const auto& r : residues) s.codes.push_back(encode(r));
+    s.offsets.assign(1, 0);
+    for (const auto& r : residues) {
+        append_codes(s.codes, r.data(), r.size());
+        s.offsets.push_back(s.codes.size());
+    }
     return s;
 }
 
-SeqSet load_fasta(const std::string& path)
+SeqSet load_fasta(const std::string& path, int n_threads)
 {
-    std::ifstream f(path, std::ios::binary);
-    if (!f.good()) throw std::runtime_error("Unable to open input file " + path);
-    std::vector<std::string> ids, seqs;
-    std::string line, id, seq;
-    while (std::getline(f, line)) {
-        while (!line.empty() && (line.back() == '\n' || line.back() == '\r')) line.pop_back();
-        if (line.empty()) continue;
-        if (line[0] == '>') {
-            if (!id.empty() && !seq.empty()) { // a record needs both an id and residues
-                ids.push_back(id);
-                seqs.push_back(seq);
-                seq.clear();
-            }
-            id = line;
-        } else {
-            seq += line;
+    if (n_threads <= 0) n_threads = default_host_threads();
+    const int fd = open(path.c_str(), O_RDONLY);
+    if (fd < 0) throw std::runtime_error("Unable to open input file " + path);
+    struct stat sb;
+    if (fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode)) {
+        close(fd);
+        throw std::runtime_error("Unable to open input file " + path);
+    }
+    const size_t size = (size_t)sb.st_size;
+    SeqSet s;
+    s.offsets.assign(1, 0);
+    if (size == 0) {
+        close(fd);
+        return s;
+    }
+    const char* buf = (const char*)mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (buf == MAP_FAILED) throw std::runtime_error("Unable to map input file " + path);
+    // pieces of ~equal size, each starting at a header line (a '>' right after a '\n')
+    const int n_pieces = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_threads * 4, size / (1 << 20)));
+    std::vector<size_t> start(n_pieces + 1, size);
+    start[0] = 0;
+    for (int k = 1; k < n_pieces; ++k) {
+        size_t at = std::max(start[k - 1], size / n_pieces * k);
+        const char* q = buf + at;
+        for (;;) {
+            q = (const char*)memchr(q, '\n', (size_t)(buf + size - q));
+            if (!q || q + 1 >= buf + size) { at = size; break; }
+            if (q[1] == '>') { at = (size_t)(q + 1 - buf); break; }
+            ++q;
         }
+        start[k] = at;
     }
-    if (!id.empty() && !seq.empty()) {
-        ids.push_back(id);
-        seqs.push_back(seq);
+    std::vector<Piece> pieces(n_pieces);
+    try {
+        parallel_for(n_pieces, n_threads, [&](int k) {
+            if (start[k] < start[k + 1]) parse_piece(buf + start[k], buf + start[k + 1], pieces[k]);
+        });
+    } catch (...) {
+        munmap((void*)buf, size);
+        throw;
     }
-    return from_records(ids, seqs);
+    munmap((void*)buf, size);
+    // stitch
+    std::vector<size_t> rec0(n_pieces + 1, 0), byte0(n_pieces + 1, 0);
+    for (int k = 0; k < n_pieces; ++k) {
+        rec0[k + 1] = rec0[k] + pieces[k].ids.size();
+        byte0[k + 1] = byte0[k] + pieces[k].codes.size();
+    }
+    s.ids.resize(rec0[n_pieces]);
+    s.offsets.resize(rec0[n_pieces] + 1);
+    s.codes.resize(byte0[n_pieces]);
+    parallel_for(n_pieces, n_threads, [&](int k) {
+        Piece& pc = pieces[k];
+        if (!pc.codes.empty()) memcpy(s.codes.data() + byte0[k], pc.codes.data(), pc.codes.size());
+        for (size_t r = 0; r < pc.ids.size(); ++r) {
+            s.ids[rec0[k] + r].swap(pc.ids[r]);
+            s.offsets[rec0[k] + r + 1] = byte0[k] + pc.ends[r];
+        }
+        Piece().codes.swap(pc.codes);
+    });
+    return s;
 }
 
-std::vector<int> famsa_order(const SeqSet& s)
+std::vector<int> famsa_order(const SeqSet& s, int n_threads)
 {
-    std::vector<int> order(s.size());
+    if (n_threads <= 0) n_threads = default_host_threads();
+    const int n = (int)s.size();
+    std::vector<int> order(n);
     std::iota(order.begin(), order.end(), 0);
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
-        const auto &x = s.codes[a], &y = s.codes[b];
-        if (x.size() != y.size()) return x.size() > y.size();
-        // the reference compares symbol_t = (signed) char; codes are < 32 so unsigned agrees
-        return std::lexicographical_compare(x.begin(), x.end(), y.begin(), y.end());
-    });
+    const OrderLess less{s};
+    // sorted runs in parallel, then rounds of pairwise merges
+    int runs = 1;
+    while (runs < n_threads && n / (runs * 2) >= 4096) runs *= 2;
+    std::vector<int> cut(runs + 1);
+    for (int r = 0; r <= runs; ++r) cut[r] = (int)((int64_t)n * r / runs);
+    parallel_for(runs, n_threads, [&](int r) { std::sort(order.begin() + cut[r], order.begin() + cut[r + 1], less); });
+    std::vector<int> tmp(runs > 1 ? n : 0);
+    for (int width = 1; width < runs; width *= 2) {
+        const int pairs = runs / (2 * width);
+        parallel_for(pairs, n_threads, [&](int q) {
+            const int a = cut[2 * width * q], m = cut[2 * width * q + width], b = cut[2 * width * (q + 1)];
+            std::merge(order.begin() + a, order.begin() + m, order.begin() + m, order.begin() + b, tmp.begin() + a, less);
+        });
+        order.swap(tmp);
+    }
     return order;
 }
 
-WorkSet make_workset(const SeqSet& s, bool keep_duplicates)
+WorkSet make_workset(const SeqSet& s, bool keep_duplicates, int n_threads)
 {
     WorkSet w;
-    w.sorted2input = famsa_order(s);
+    w.sorted2input = famsa_order(s, n_threads);
     const int n = (int)w.sorted2input.size();
     w.sorted2unique.resize(n);
     int cur = -1;
     for (int k = 0; k < n; ++k) {
-        const bool same = !keep_duplicates && k > 0 && s.codes[w.sorted2input[k]] == s.codes[w.sorted2input[k - 1]];
+        bool same = false;
+        if (!keep_duplicates && k > 0) {
+            const int a = w.sorted2input[k], b = w.sorted2input[k - 1];
+            same = s.length(a) == s.length(b) && (s.length(a) == 0 || memcmp(s.data(a), s.data(b), s.length(a)) == 0);
+        }
         if (!same) {
             ++cur;
             w.unique2sorted.push_back(k);
@@ -87,13 +249,18 @@ WorkSet make_workset(const SeqSet& s, bool keep_duplicates)
 }
 
 void pack(const SeqSet& s, const std::vector<int>& input_ids, std::vector<uint8_t>& codes,
-          std::vector<uint64_t>& offsets)
+          std::vector<uint64_t>& offsets, int n_threads)
 {
+    if (n_threads <= 0) n_threads = default_host_threads();
     offsets.assign(input_ids.size() + 1, 0);
-    for (size_t k = 0; k < input_ids.size(); ++k) offsets[k + 1] = offsets[k] + s.codes[input_ids[k]].size();
+    for (size_t k = 0; k < input_ids.size(); ++k) offsets[k + 1] = offsets[k] + s.length(input_ids[k]);
     codes.resize(offsets.back());
-    for (size_t k = 0; k < input_ids.size(); ++k)
-        std::copy(s.codes[input_ids[k]].begin(), s.codes[input_ids[k]].end(), codes.begin() + offsets[k]);
+    const int slices = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_threads, input_ids.size() / 4096));
+    parallel_for(slices, n_threads, [&](int t) {
+        const size_t k0 = input_ids.size() * t / slices, k1 = input_ids.size() * (t + 1) / slices;
+        for (size_t k = k0; k < k1; ++k)
+            if (s.length(input_ids[k])) memcpy(codes.data() + offsets[k], s.data(input_ids[k]), s.length(input_ids[k]));
+    });
 }
 
 } // namespace famsa_host

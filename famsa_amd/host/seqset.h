@@ -2,7 +2,10 @@
 // Mirrors the state FAMSA builds before its tree generators run: FASTA records
 // (reference core/io_service.h:84-127), symbol codes (core/sequence.cpp:22-80, done by
 // lcsgpu_encode), the length-descending sort (msa.cpp:245-279) and duplicate removal
-// (msa.cpp:338-356).  No padding is materialised: the GPU engine pads internally.
+// (msa.cpp:338-356).  The set is held packed -- one code buffer plus offsets, the layout
+// lcsgpu_upload takes -- and the reader, the sort and the gather run on all granted cores:
+// at a million sequences the serial forms cost more than the whole tree stage on the GPU.
+// No padding is materialised: the GPU engine pads internally.
 #pragma once
 #include <cstdint>
 #include <string>
@@ -11,20 +14,27 @@
 namespace famsa_host {
 
 struct SeqSet {
-    std::vector<std::string> ids;               // with the leading '>'
-    std::vector<std::vector<uint8_t>> codes;    // symbol codes, unpadded
+    std::vector<std::string> ids;     // with the leading '>'
+    std::vector<uint8_t> codes;       // symbol codes of all sequences, unpadded, input order
+    std::vector<uint64_t> offsets;    // [size() + 1]
     size_t size() const { return ids.size(); }
-    uint32_t length(size_t i) const { return (uint32_t)codes[i].size(); }
+    uint32_t length(size_t i) const { return (uint32_t)(offsets[i + 1] - offsets[i]); }
+    const uint8_t* data(size_t i) const { return codes.data() + offsets[i]; }
 };
 
+// Worker threads for the host-side stages: the hardware threads / 2 (reference core/params.cpp:285-291),
+// capped by the container's CPU quota (cgroup v2 cpu.max) when there is one.
+int default_host_threads();
+
 // FASTA reader with the reference's line handling; throws std::runtime_error on I/O errors.
-SeqSet load_fasta(const std::string& path);
+// n_threads <= 0: default_host_threads().
+SeqSet load_fasta(const std::string& path, int n_threads = 0);
 // Build from in-memory records (ids with '>', residue strings).
 SeqSet from_records(const std::vector<std::string>& ids, const std::vector<std::string>& residues);
 
 // Permutation `order` such that order[k] = input index of the k-th sequence in FAMSA's working
 // order: stable sort by length descending, then lexicographic over the symbol codes.
-std::vector<int> famsa_order(const SeqSet& s);
+std::vector<int> famsa_order(const SeqSet& s, int n_threads = 0);
 
 // Working set of the tree stage: the sorted sequences, duplicates collapsed.
 struct WorkSet {
@@ -34,10 +44,10 @@ struct WorkSet {
     int n_sorted() const { return (int)sorted2input.size(); }
     int n_unique() const { return (int)unique2sorted.size(); }
 };
-WorkSet make_workset(const SeqSet& s, bool keep_duplicates);
+WorkSet make_workset(const SeqSet& s, bool keep_duplicates, int n_threads = 0);
 
 // Concatenated codes + offsets (the lcsgpu_upload layout) of the given input indices, in order.
 void pack(const SeqSet& s, const std::vector<int>& input_ids, std::vector<uint8_t>& codes,
-          std::vector<uint64_t>& offsets);
+          std::vector<uint64_t>& offsets, int n_threads = 0);
 
 } // namespace famsa_host

@@ -28,6 +28,9 @@ class Host:
         lib.famsa_host_dist_export_gpu.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p]
         lib.famsa_host_workset.argtypes = [C.c_char_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
         lib.famsa_host_format_distance.argtypes = [C.c_double, C.c_char_p]
+        lib.famsa_host_records.restype = C.c_long
+        lib.famsa_host_records.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_long, C.c_void_p, C.c_long, C.c_void_p,
+                                           C.c_long]
         lib.famsa_host_clarans.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]
         self.lib = lib
 
@@ -91,3 +94,16 @@ class Host:
                                        out.ctypes.data) != 0:
             raise self._err()
         return out
+
+    def records(self, fasta, n_threads=0):
+        """(ids, [code arrays]) as the FASTA reader delivers them."""
+        size = os.path.getsize(fasta) + 16
+        ids = C.create_string_buffer(size)
+        codes = np.zeros(size, np.uint8)
+        offs = np.zeros(size // 2 + 2, np.uint64)
+        n = self.lib.famsa_host_records(fasta.encode(), n_threads, ids, size, codes.ctypes.data, size,
+                                        offs.ctypes.data, len(offs))
+        if n < 0:
+            raise self._err()
+        names = ids.value.decode("latin-1").split("\n")[:-1] if n else []
+        return names, [codes[int(offs[i]):int(offs[i + 1])].copy() for i in range(n)]

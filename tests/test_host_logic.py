@@ -181,3 +181,69 @@ def test_slink_equals_canonical_pointer_representation_of_the_mst(host, oracle, 
                 "hemopexin/hemopexin": "hemopexin/slink.dnd"}[name]
         m = square(oracle, f, symmetric_ok=(name != "adversarial_tree.fasta"))
         assert host.tree_from_matrix(f, m, "slink") == open(os.path.join(G, gold), "rb").read()
+
+
+def _reader_restatement(raw):
+    """The reference's loadFasta state machine (core/io_service.h:99-124), line by line."""
+    ids, seqs, ident, seq = [], [], "", ""
+    for line in raw.split(b"\n"):
+        line = line.decode("latin-1").rstrip("\r\n")
+        if not line:
+            continue
+        if line[0] == ">":
+            if ident and seq:
+                ids.append(ident)
+                seqs.append(seq)
+                seq = ""
+            ident = line
+        else:
+            seq += line
+    if ident and seq:
+        ids.append(ident)
+        seqs.append(seq)
+    return ids, seqs
+
+
+@pytest.mark.parametrize("variant", ["plain", "junk-first", "crlf", "no-final-newline", "only-junk"])
+def test_parallel_fasta_reader_matches_the_serial_semantics(host, oracle, tmp_path, variant):
+    """The reader splits the file at header lines and parses the pieces on several threads: same
+    records as the serial state machine (and as the reference's own loader), with headers that have
+    no residues, blank lines, multi-line and lower-case records, and residues before any header."""
+    rng = np.random.Generator(np.random.PCG64(41))
+    alpha = np.frombuffer(b"ARNDCQEGHILKMFPSTWYVBZX*acdxy-", dtype=np.uint8)
+    eol = b"\r\n" if variant == "crlf" else b"\n"
+    chunks = []
+    if variant in ("junk-first", "only-junk"):
+        chunks.append(b"MKV" + eol + b"LLA" + eol)
+    n = 0 if variant == "only-junk" else 9000
+    for i in range(n):
+        chunks.append(b">seq%d some description" % i + eol)
+        if i % 97 == 5:
+            continue  # a header without residues: the next header replaces it
+        length = int(rng.integers(1, 700))
+        res = alpha[rng.integers(0, len(alpha), size=length)].tobytes()
+        for a in range(0, length, 60):
+            chunks.append(res[a:a + 60] + eol)
+            if rng.random() < 0.01:
+                chunks.append(eol)
+    raw = b"".join(chunks)
+    if variant == "no-final-newline":
+        raw = raw.rstrip(b"\r\n")
+    path = str(tmp_path / "reader.fasta")
+    with open(path, "wb") as f:
+        f.write(raw)
+    want_ids, want_seqs = _reader_restatement(raw)
+    assert variant == "only-junk" or len(raw) > 3 << 20  # several pieces
+    for threads in (1, 7):
+        ids, codes = host.records(path, threads)
+        assert ids == want_ids
+        assert len(codes) == len(want_seqs)
+        for got, residues in zip(codes[:400] + codes[-400:], want_seqs[:400] + want_seqs[-400:]):
+            assert (got == oracle.encode(residues)).all()
+    if oracle_bind.have_ref() and variant != "only-junk":
+        ref = oracle_bind.Ref()
+        h = ref.open_fasta(path)
+        rc = ref.codes(h)
+        ref.close(h)
+        assert len(rc) == len(codes)
+        assert all((a == b).all() for a, b in zip(rc, codes))
