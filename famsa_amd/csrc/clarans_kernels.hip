@@ -25,6 +25,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cfloat>
+#include <algorithm>
 #include <climits>
 #include <cstdint>
 
@@ -44,7 +45,19 @@ __device__ __forceinline__ size_t tri_at(int i, int j)
 #else
 #define TR(i)
 #endif
-enum { ST_P = 0, ST_DONE = 1, ST_LOG_LEN = 2, ST_ROUNDS = 3, ST_ARRIVE = 4, ST_COST = 5, ST_ERR = 6, ST_WIN = 7 };
+enum { ST_P = 0, ST_DONE = 1, ST_LOG_LEN = 2, ST_ROUNDS = 3, ST_ARRIVE = 4, ST_COST = 5, ST_ERR = 6, ST_WIN = 7,
+       ST_OFF = 8, ST_STAGE = 9, ST_FIRST = 10 };
+
+// A window of pending steps is evaluated in stages of 16, 32, 64, 64, ... steps: most accepts come
+// within the first few steps, and the steps after the accepted one are wasted work that other
+// searches running at the same time have to queue behind.
+constexpr int STAGE_MAX = 64; // = the apply kernel's workgroup size: one result per lane
+__device__ __forceinline__ int window_size(int corrected, int first) { return first ? corrected : (corrected > 0 ? corrected - 1 : 0); }
+__device__ __forceinline__ int stage_size(int stage, int left)
+{
+    const int want = stage >= 2 ? STAGE_MAX : (16 << stage);
+    return left < want ? (left < 0 ? 0 : left) : want;
+}
 
 } // namespace
 
@@ -92,8 +105,9 @@ struct Nearest2 {
 // Start of one local search (Clustering.cpp:49-79): every non-medoid's distances to the medoid
 // slots (DMt[mm * n + pos]) and assignment, the addends of the initial cost in position order, and
 // the first window of pending steps (position and member of each).
-__global__ __launch_bounds__(256) void clarans_init_kernel(ClaransArgs a, int W)
+__global__ __launch_bounds__(256) void clarans_init_kernel(ClaransArgs a)
 {
+    const int W = a.corrected;
     const int pos = blockIdx.x * 256 + threadIdx.x;
     const int k = a.n_medoids, n = a.n_elems;
     const int p = a.state[ST_P];
@@ -104,6 +118,9 @@ __global__ __launch_bounds__(256) void clarans_init_kernel(ClaransArgs a, int W)
         a.state[ST_ARRIVE] = 0;
         a.state[ST_COST] = __float_as_int(0.0f);
         a.state[ST_WIN] = 0;
+        a.state[ST_OFF] = 0;
+        a.state[ST_STAGE] = 0;
+        a.state[ST_FIRST] = 1;
         if (p + W > a.draws_len) a.state[ST_ERR] = 1;
     }
     if (p + W <= a.draws_len)
@@ -139,12 +156,17 @@ __global__ __launch_bounds__(256) void clarans_init_kernel(ClaransArgs a, int W)
 // slots and then walks only those: skipped entries would add +0.0f, the identity.
 // Workgroup W adds the previous round's cost addends to the running cost, in order.
 template <int KPT>
-__global__ __launch_bounds__(512) void clarans_eval_kernel(ClaransArgs a, int W)
+__global__ __launch_bounds__(512) void clarans_eval_kernel(ClaransBatch batch)
 {
-    constexpr int CH = 2048, PER = CH / 512;
-    constexpr int SUB = 256;
-    __shared__ float4 s_e[CH];          // 32 KB
-    __shared__ float4 s_we[8][SUB];     // 32 KB: per wave, the entries of one sub-chunk that concern its slots
+    const ClaransArgs& a = batch.s[blockIdx.y];
+    const int corrected = a.corrected;
+    // 32 KB of LDS and 512 lanes per workgroup: four fit a CU, so the 65 x 16 workgroups of a full
+    // batch of searches are resident together
+    constexpr int CH = 2048, PER = CH / 512; // positions whose data a workgroup keeps in registers at a time
+    constexpr int HALF = CH / 2;             // ... and stages through LDS in two halves
+    constexpr int SUB = 128;
+    __shared__ float4 s_e[HALF];        // 16 KB
+    __shared__ float4 s_we[8][SUB];     // 16 KB: per wave, the entries of one sub-chunk that concern its slots
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int k = a.n_medoids, n = a.n_elems;
 #ifdef CLARANS_TRACE
@@ -154,8 +176,12 @@ __global__ __launch_bounds__(512) void clarans_eval_kernel(ClaransArgs a, int W)
     // level 1: state, this step, and the first chunk's per-position data
     const int4 st0 = *reinterpret_cast<const int4*>(a.state);
     const int4 st1 = *reinterpret_cast<const int4*>(a.state + 4);
+    const int4 st2 = *reinterpret_cast<const int4*>(a.state + 8);
     const int win = st1.w & 1;
-    const int bb = b < W ? b : 0;
+    const bool cost_wg = b == (int)gridDim.x - 1;
+    const int S = stage_size(st2.y, window_size(corrected, st2.z) - st2.x); // steps evaluated in this round
+    if (!cost_wg && b >= S) return;
+    const int bb = cost_wg ? 0 : st2.x + b; // index of this workgroup's step in the window
     const int xx = a.win_xx[win * a.win_cap + bb];
     const int x = a.win_x[win * a.win_cap + bb];
     int y_pre[PER];
@@ -169,7 +195,7 @@ __global__ __launch_bounds__(512) void clarans_eval_kernel(ClaransArgs a, int W)
     if (st0.y) return; // done
     TR(0);
     const uint64_t lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
-    if (b == W) {
+    if (cost_wg) {
         // running cost: c += addend for every logged addend, in order; zeros are the identity
         // (c starts at +0.0f and can never become -0.0f), so only the others are walked
         const int len = st0.z;
@@ -242,65 +268,73 @@ __global__ __launch_bounds__(512) void clarans_eval_kernel(ClaransArgs a, int W)
             }
             dxy[u] = (t < cnt && c0 + t != xx) ? a.D[tri_at(x, y_pre[u])] : 0.0f;
         }
+        float4 ent[PER];
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
             const int t = tid + 512 * u;
-            if (t < cnt) {
-                float4 e = make_float4(0.0f, 0.0f, __int_as_float(-1), 0.0f); // position xx: contributes nothing
-                if (c0 + t != xx) {
-                    const float dn = s_pre[u].x, ds = s_pre[u].y;
-                    const float m = ds < dxy[u] ? ds : dxy[u]; // std::min(dxy, ds)
-                    const float change = __fsub_rn(dxy[u], dn);
-                    e.x = __fsub_rn(m, dn);                     // goes to deltas[nearest(y)]
-                    e.y = change < 0.0f ? change : 0.0f;        // goes to every other slot when negative
-                    e.z = s_pre[u].z;
-                }
-                s_e[t] = e;
+            ent[u] = make_float4(0.0f, 0.0f, __int_as_float(-1), 0.0f); // position xx: contributes nothing
+            if (t < cnt && c0 + t != xx) {
+                const float dn = s_pre[u].x, ds = s_pre[u].y;
+                const float m = ds < dxy[u] ? ds : dxy[u]; // std::min(dxy, ds)
+                const float change = __fsub_rn(dxy[u], dn);
+                ent[u].x = __fsub_rn(m, dn);                     // goes to deltas[nearest(y)]
+                ent[u].y = change < 0.0f ? change : 0.0f;        // goes to every other slot when negative
+                ent[u].z = s_pre[u].z;
             }
         }
         TR(1);
-        __syncthreads();
-        TR(2);
-        for (int s0 = 0; s0 < cnt; s0 += SUB) {
-            float4 e[SUB / 64];
 #pragma unroll
-            for (int u = 0; u < SUB / 64; ++u) {
-                const int t = s0 + 64 * u + lane;
-                e[u] = t < cnt ? s_e[t] : make_float4(0.0f, 0.0f, __int_as_float(-1), 0.0f);
+        for (int h = 0; h < 2; ++h) {
+            const int hcnt = min(HALF, cnt - h * HALF);
+            if (hcnt <= 0) break;
+#pragma unroll
+            for (int u = 0; u < PER / 2; ++u) {
+                const int t = tid + 512 * u; // position inside this half
+                if (t < hcnt) s_e[t] = ent[h * (PER / 2) + u];
             }
-            int m = 0;
+            __syncthreads();
+            TR(2);
+            for (int s0 = 0; s0 < hcnt; s0 += SUB) {
+                float4 e[SUB / 64];
 #pragma unroll
-            for (int u = 0; u < SUB / 64; ++u) {
-                const int nn = __float_as_int(e[u].z);
-                const bool mine = e[u].y < 0.0f || (nn >= klo && nn < khi);
-                const uint64_t mask = __ballot(mine);
-                if (mine) s_we[wave][m + __popcll(mask & lt_mask)] = e[u];
-                m += __popcll(mask);
-            }
-            __builtin_amdgcn_wave_barrier(); // same wave: its LDS writes are performed before its later reads
-            int i = 0;
-            for (; i + 8 <= m; i += 8) {
-                float4 f[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) f[u] = s_we[wave][i + u];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int nn = __float_as_int(f[u].z);
-#pragma unroll
-                    for (int q = 0; q < KPT; ++q) acc[q] = __fadd_rn(acc[q], slot[q] == nn ? f[u].x : f[u].y);
+                for (int u = 0; u < SUB / 64; ++u) {
+                    const int t = s0 + 64 * u + lane;
+                    e[u] = t < hcnt ? s_e[t] : make_float4(0.0f, 0.0f, __int_as_float(-1), 0.0f);
                 }
-            }
-            for (; i < m; ++i) {
-                const float4 f = s_we[wave][i];
-                const int nn = __float_as_int(f.z);
+                int m = 0;
 #pragma unroll
-                for (int q = 0; q < KPT; ++q) acc[q] = __fadd_rn(acc[q], slot[q] == nn ? f.x : f.y);
+                for (int u = 0; u < SUB / 64; ++u) {
+                    const int nn = __float_as_int(e[u].z);
+                    const bool mine = e[u].y < 0.0f || (nn >= klo && nn < khi);
+                    const uint64_t mask = __ballot(mine);
+                    if (mine) s_we[wave][m + __popcll(mask & lt_mask)] = e[u];
+                    m += __popcll(mask);
+                }
+                __builtin_amdgcn_wave_barrier(); // same wave: its LDS writes are performed before its later reads
+                int i = 0;
+                for (; i + 8 <= m; i += 8) {
+                    float4 f[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) f[u] = s_we[wave][i + u];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int nn = __float_as_int(f[u].z);
+#pragma unroll
+                        for (int q = 0; q < KPT; ++q) acc[q] = __fadd_rn(acc[q], slot[q] == nn ? f[u].x : f[u].y);
+                    }
+                }
+                for (; i < m; ++i) {
+                    const float4 f = s_we[wave][i];
+                    const int nn = __float_as_int(f.z);
+#pragma unroll
+                    for (int q = 0; q < KPT; ++q) acc[q] = __fadd_rn(acc[q], slot[q] == nn ? f.x : f.y);
+                }
+                __builtin_amdgcn_wave_barrier();
             }
-            __builtin_amdgcn_wave_barrier();
+            TR(3);
+            __syncthreads();
+            TR(4);
         }
-        TR(3);
-        __syncthreads();
-        TR(4);
     }
     // std::min_element over slots [n_fixed, k): smallest value, earliest slot among equals
     float* s_v = reinterpret_cast<float*>(&s_we[0][0]);
@@ -340,18 +374,26 @@ __global__ __launch_bounds__(512) void clarans_eval_kernel(ClaransArgs a, int W)
 // rebuilds the position that receives the replaced medoid and prepares the next window of pending
 // steps.  The workgroup that arrives last commits the swap.
 constexpr int APPLY_MT = 128; // medoid slots staged per pass
-__global__ __launch_bounds__(64) void clarans_apply_kernel(ClaransArgs a, int W, int W_next)
+__global__ __launch_bounds__(64) void clarans_apply_kernel(ClaransBatch batch)
 {
+    const ClaransArgs& a = batch.s[blockIdx.y];
+    const int corrected = a.corrected;
     __shared__ int s_w;
     __shared__ int s_last;
     __shared__ float s_tile[APPLY_MT][64]; // 32 KB: [slot][lane]; the last workgroup uses it as one row
     int* st = a.state;
     const int tid = threadIdx.x;
     const int k = a.n_medoids, n = a.n_elems;
-    const bool last_wg = blockIdx.x == gridDim.x - 1;
+    const int n_wg = (n - k + 63) / 64 + 1; // this search's workgroups; the grid is sized for the largest search
+    if ((int)blockIdx.x >= n_wg) return;
+    const bool last_wg = (int)blockIdx.x == n_wg - 1;
     // level 1: everything whose address does not depend on the accepted step
     const int4 st0 = *reinterpret_cast<const int4*>(st);
     const int4 st1 = *reinterpret_cast<const int4*>(st + 4);
+    const int4 st2 = *reinterpret_cast<const int4*>(st + 8);
+    const int W = window_size(corrected, st2.z), off = st2.x;
+    const int S = stage_size(st2.y, W - off);
+    const int W_next = window_size(corrected, 0);
     const int yy = k + blockIdx.x * 64 + tid;
     const bool have = !last_wg && yy < n;
     const int y_mine = have ? a.cand[yy] : 0;
@@ -365,35 +407,29 @@ __global__ __launch_bounds__(64) void clarans_apply_kernel(ClaransArgs a, int W,
 #pragma unroll 16
         for (int mm = 0; mm < k0; ++mm) s_tile[mm][tid] = col[(size_t)mm * n];
     }
-    int w_mine = INT_MAX;
-    for (int w = tid; w < W; w += 64)
-        if (a.res_delta[w] < 0.0f) { w_mine = w; break; } // ascending per lane: its first
+    const float rd_mine = a.res_delta[tid]; // a stage has at most 64 steps: one per lane (the array holds >= 64)
     if (st0.y) return; // done
     if (tid == 0) s_w = INT_MAX;
     __syncthreads();
-    if (!st1.z && w_mine != INT_MAX) atomicMin(&s_w, w_mine);
+    if (!st1.z && tid < S && rd_mine < 0.0f) atomicMin(&s_w, tid);
     __syncthreads();
     const int w = s_w;
     const int p = st0.x;
     const int win = st1.w & 1;
-    if (w == INT_MAX) { // `corrected` steps without an accept: this local search is over
-        if (blockIdx.x == 0 && tid == 0) {
-            st[ST_P] = p + (st1.z ? 0 : W);
-            st[ST_LOG_LEN] = 0;
-            st[ST_DONE] = 1;
-        }
-        return;
-    }
+    const bool accept = w != INT_MAX;
+    const int j = off + (accept ? w : 0); // index of the accepted step in the window
     // level 2
-    const int xx = a.win_xx[win * a.win_cap + w];
-    const int x = a.win_x[win * a.win_cap + w]; // the new medoid
-    const int mm_new = a.res_mm[w];
+    const int xx = a.win_xx[win * a.win_cap + j];
+    const int x = a.win_x[win * a.win_cap + j]; // the new medoid
+    const int mm_new = accept ? a.res_mm[w] : 0;
     int m_old = 0;
-    if (last_wg) {
+    if (!accept) {
+        // no accept among this round's steps: the next round takes the next stage of the window
+    } else if (last_wg) {
         // level 3: the medoid that is replaced; from now on it sits at position xx
         m_old = a.cand[mm_new];
         // next window of pending steps, against the candidate order after this swap
-        const int p_new = p + w + 1;
+        const int p_new = p + j + 1;
         if (p_new + W_next > a.draws_len) {
             if (tid == 0) st[ST_ERR] = 1;
         } else {
@@ -449,7 +485,7 @@ __global__ __launch_bounds__(64) void clarans_apply_kernel(ClaransArgs a, int W,
             a.cost_log[0] = -old_dn;
             a.cost_log[1 + xx - k] = has1 ? v1 : FLT_MAX;
         }
-    } else if (have && yy != xx) {
+    } else if (accept && have && yy != xx) {
         const float d_new = a.D[tri_at(x, y_mine)]; // level 3
         a.DMt[(size_t)mm_new * n + yy] = d_new;
         const float dn_y = s.x, ds_y = s.y;
@@ -499,17 +535,31 @@ __global__ __launch_bounds__(64) void clarans_apply_kernel(ClaransArgs a, int W,
     }
     __threadfence();
     __syncthreads();
-    if (tid == 0) s_last = atomicAdd(&st[ST_ARRIVE], 1) == (int)gridDim.x - 1;
+    if (tid == 0) s_last = atomicAdd(&st[ST_ARRIVE], 1) == n_wg - 1;
     __syncthreads();
     if (s_last && tid == 0) {
-        const int mo = a.cand[mm_new];
-        a.cand[mm_new] = x;
-        a.cand[xx] = mo;
-        st[ST_P] = p + w + 1;
-        st[ST_LOG_LEN] = 1 + n - k;
-        st[ST_ROUNDS] = st0.w + 1;
         st[ST_ARRIVE] = 0;
-        st[ST_WIN] = 1 - win;
+        if (accept) {
+            const int mo = a.cand[mm_new];
+            a.cand[mm_new] = x;
+            a.cand[xx] = mo;
+            st[ST_P] = p + j + 1;
+            st[ST_LOG_LEN] = 1 + n - k;
+            st[ST_ROUNDS] = st0.w + 1;
+            st[ST_WIN] = 1 - win;
+            st[ST_OFF] = 0;
+            st[ST_STAGE] = 0;
+            st[ST_FIRST] = 0;
+        } else {
+            st[ST_LOG_LEN] = 0;
+            if (st1.z || off + S >= W) { // error, or `corrected` steps without an accept: this local search is over
+                st[ST_P] = p + (st1.z ? 0 : W);
+                st[ST_DONE] = 1;
+            } else {
+                st[ST_OFF] = off + S;
+                st[ST_STAGE] = st2.y + 1;
+            }
+        }
     }
 }
 
@@ -526,26 +576,29 @@ hipError_t launch_subset_distances(const void* lcs, int elem_size, const int32_t
     return hipGetLastError();
 }
 
-hipError_t launch_clarans_init(const ClaransArgs& a, int corrected, hipStream_t stream)
+hipError_t launch_clarans_init(const ClaransArgs& a, hipStream_t stream)
 {
-    hipLaunchKernelGGL(clarans_init_kernel, dim3((a.n_elems + 255) / 256), dim3(256), 0, stream, a, corrected);
+    hipLaunchKernelGGL(clarans_init_kernel, dim3((a.n_elems + 255) / 256), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 
-// `rounds` x (evaluate a window, apply); the first window of a local search has `corrected` steps,
-// the later ones corrected - 1 (the reference resets its step counter to 1 after an accept).
-hipError_t launch_clarans_rounds(const ClaransArgs& a, int corrected, bool first_of_search, int rounds,
-                                 hipStream_t stream)
+// `rounds` x (evaluate the next stage of every search's window, apply).  The first window of a local
+// search has `corrected` steps, the later ones corrected - 1 (the reference resets its step counter
+// to 1 after an accept).
+hipError_t launch_clarans_rounds(const ClaransBatch& b, int rounds, hipStream_t stream)
 {
-    const int kpt = ((a.n_medoids + 7) / 8 + 63) / 64; // slots per lane: 8 waves share the slots
-    const int apply_blocks = (a.n_elems - a.n_medoids + 63) / 64 + 1;
-    const int later = corrected > 0 ? corrected - 1 : 0;
+    int kpt = 1, apply_blocks = 1, steps = 0;
+    for (int i = 0; i < b.n; ++i) {
+        const ClaransArgs& a = b.s[i];
+        kpt = std::max(kpt, ((a.n_medoids + 7) / 8 + 63) / 64); // slots per lane: 8 waves share the slots
+        apply_blocks = std::max(apply_blocks, (a.n_elems - a.n_medoids + 63) / 64 + 1);
+        steps = std::max(steps, std::min(a.corrected, STAGE_MAX));
+    }
+    const dim3 grid(steps + 1, b.n), block(512); // a stage has at most STAGE_MAX steps; + the cost workgroup
     for (int r = 0; r < rounds; ++r) {
-        const int W = (first_of_search && r == 0) ? corrected : later;
-        const dim3 grid(W + 1), block(512);
-        if (kpt <= 1) hipLaunchKernelGGL(clarans_eval_kernel<1>, grid, block, 0, stream, a, W);
-        else hipLaunchKernelGGL(clarans_eval_kernel<2>, grid, block, 0, stream, a, W);
-        hipLaunchKernelGGL(clarans_apply_kernel, dim3(apply_blocks), dim3(64), 0, stream, a, W, later);
+        if (kpt <= 1) hipLaunchKernelGGL(clarans_eval_kernel<1>, grid, block, 0, stream, b);
+        else hipLaunchKernelGGL(clarans_eval_kernel<2>, grid, block, 0, stream, b);
+        hipLaunchKernelGGL(clarans_apply_kernel, dim3(apply_blocks, b.n), dim3(64), 0, stream, b);
     }
     return hipGetLastError();
 }

@@ -151,12 +151,21 @@ struct ClaransArgs {
     int32_t* res_mm;     // [window] its medoid slot
     float* cost_log;     // [1 + n_elems] addends of the running cost, in the reference's order
     int32_t* state;      // [0] next draw  [1] done  [2] log length  [3] accepts  [4] arrivals  [5] cost bits  [6] error  [7] window buffer
+                         // [8] steps of the window already evaluated  [9] stage  [10] no accept yet in this search
     int32_t n_elems, n_medoids, n_fixed, draws_len, win_cap;
+    int32_t corrected;   // steps without an accept that end a local search (Clustering.cpp:21-29)
+};
+// Searches that are advanced together, one grid row each: however many host threads are searching,
+// a round costs two launches (evaluate, apply) in total instead of two per search -- with one launch
+// pair per search the command processor, not the kernels, bounded the throughput beyond ~4 searches.
+constexpr int CLARANS_MAX_BATCH = 16;
+struct ClaransBatch {
+    ClaransArgs s[CLARANS_MAX_BATCH];
+    int32_t n;
 };
 hipError_t launch_subset_distances(const void* lcs, int elem_size, const int32_t* ids, const uint32_t* lens,
                                    const float* pow_f32, int kind, int n, float* D, hipStream_t stream);
-hipError_t launch_clarans_init(const ClaransArgs& a, int corrected, hipStream_t stream);
-hipError_t launch_clarans_rounds(const ClaransArgs& a, int corrected, bool first_of_search, int rounds,
-                                 hipStream_t stream);
+hipError_t launch_clarans_init(const ClaransArgs& a, hipStream_t stream);
+hipError_t launch_clarans_rounds(const ClaransBatch& b, int rounds, hipStream_t stream);
 
 } // namespace lcsgpu

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cmath>
@@ -106,6 +107,35 @@ struct Lane {
     bool busy = false;
 };
 
+
+// Local searches of several host threads advanced together (lcs_kernels.h, ClaransBatch): every
+// search joins with its device state ready; whichever owner finds no driver becomes the driver and
+// enqueues the rounds for ALL joined searches, looking at their done flags every `rounds_per_look`
+// rounds; a driver whose own search has finished hands the role to one of the remaining owners.
+struct ClaransJob {
+    lcsgpu::ClaransArgs a;
+    std::mt19937* gen_positions = nullptr; // the owner's position generator (Clustering.cpp:44)
+    std::vector<int32_t>* draws = nullptr; // its output so far, as accepted draws
+    DevBuf* d_draws = nullptr;
+    int32_t p_host = 0;
+    int32_t state[16] = {0};
+    bool done = false;
+    int rc = LCSGPU_OK;
+    std::string error;
+};
+struct ClaransBatcher {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<ClaransJob*> joined;
+    bool driver_present = false;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev = nullptr;
+    PinBuf h_states;
+    // LCSGPU_PROFILE: looks and seconds by number of searches in the batch
+    long prof_looks[lcsgpu::CLARANS_MAX_BATCH + 1] = {0};
+    double prof_seconds[lcsgpu::CLARANS_MAX_BATCH + 1] = {0};
+};
+
 struct lcsgpu_ctx {
     int device = 0;
     std::mutex mu; // guards the lane table
@@ -122,6 +152,7 @@ struct lcsgpu_ctx {
     // scratch of the lane-0 tree reducers
     DevBuf d_prim, d_qrows, d_qcols, d_dist;
     double total_kernel_ms = 0; // completed host-memory calls
+    ClaransBatcher clarans;
 };
 
 namespace {
@@ -400,6 +431,118 @@ void finish_host_call(lcsgpu_ctx* ctx, Lane& L)
     ctx->total_kernel_ms += f;
 }
 
+
+// det_uniform_int_distribution<int>(n_medoids, n_elems - 1) over the owner's generator
+// (deterministic_random.h:62-76), appended to the job's draws and copied to the device.
+int clarans_extend_draws(ClaransJob& j, size_t want, hipStream_t stream)
+{
+    std::vector<int32_t>& draws = *j.draws;
+    if (draws.size() < want) {
+        const uint32_t k = (uint32_t)j.a.n_medoids, diff = (uint32_t)(j.a.n_elems - j.a.n_medoids);
+        const uint32_t bad = 0xffffffffu / diff;
+        const size_t old = draws.size();
+        want = std::max(want, old * 2);
+        draws.reserve(want);
+        while (draws.size() < want) {
+            const uint32_t r = (*j.gen_positions)();
+            if (r / diff < bad) draws.push_back((int32_t)(r % diff + k));
+        }
+        const bool regrow = j.d_draws->cap < want * 4;
+        HIP_TRY(j.d_draws->reserve(want * 4));
+        const size_t from = regrow ? 0 : old;
+        HIP_TRY(hipMemcpyAsync((int32_t*)j.d_draws->p + from, draws.data() + from, (draws.size() - from) * 4,
+                               hipMemcpyHostToDevice, stream));
+    }
+    j.a.draws = (const int32_t*)j.d_draws->p;
+    j.a.draws_len = (int32_t)draws.size();
+    return LCSGPU_OK;
+}
+
+// One stint as the driver: rounds for everything joined, until nothing is left or `mine` is done.
+void clarans_drive(lcsgpu_ctx* ctx, ClaransJob* mine)
+{
+    ClaransBatcher& B = ctx->clarans;
+    const int rounds_per_look = 32;
+    for (;;) {
+        std::vector<ClaransJob*> now;
+        {
+            std::lock_guard<std::mutex> lk(B.mu);
+            for (ClaransJob* j : B.joined)
+                if ((int)now.size() < lcsgpu::CLARANS_MAX_BATCH) now.push_back(j);
+            if (now.empty() || mine->done) {
+                B.driver_present = false;
+                B.cv.notify_all();
+                return;
+            }
+        }
+        int rc = LCSGPU_OK;
+        const auto t_look = std::chrono::steady_clock::now();
+        lcsgpu::ClaransBatch batch{};
+        for (ClaransJob* j : now) {
+            if (rc == LCSGPU_OK && j->a.n_elems > j->a.n_medoids) // a round uses at most `corrected` draws and prepares the next window
+                rc = clarans_extend_draws(*j, (size_t)j->p_host + (size_t)(rounds_per_look + 1) * std::max(j->a.corrected, 1), B.stream);
+            batch.s[batch.n++] = j->a;
+        }
+        auto hip_ok = [&](hipError_t e, const char* what) {
+            if (e != hipSuccess && rc == LCSGPU_OK) rc = fail(LCSGPU_E_HIP, "%s failed: %s", what, hipGetErrorString(e));
+        };
+        if (rc == LCSGPU_OK) hip_ok(lcsgpu::launch_clarans_rounds(batch, rounds_per_look, B.stream), "CLARANS rounds");
+        int32_t* hs = (int32_t*)B.h_states.p;
+        for (size_t i = 0; i < now.size() && rc == LCSGPU_OK; ++i)
+            hip_ok(hipMemcpyAsync(hs + 16 * i, now[i]->a.state, 64, hipMemcpyDeviceToHost, B.stream), "state read-back");
+        if (rc == LCSGPU_OK) hip_ok(hipEventRecord(B.ev, B.stream), "hipEventRecord");
+        if (rc == LCSGPU_OK) hip_ok(hipEventSynchronize(B.ev), "hipEventSynchronize");
+        else (void)hipStreamSynchronize(B.stream);
+        {
+            std::lock_guard<std::mutex> lk(B.mu);
+            const std::string msg = rc == LCSGPU_OK ? std::string() : std::string(lcsgpu_last_error());
+            B.prof_looks[now.size()]++;
+            B.prof_seconds[now.size()] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_look).count();
+            for (size_t i = 0; i < now.size(); ++i) {
+                ClaransJob* j = now[i];
+                if (rc == LCSGPU_OK) {
+                    memcpy(j->state, hs + 16 * i, 64);
+                    j->p_host = j->state[0];
+                    if (j->state[6]) {
+                        j->rc = LCSGPU_E_STATE;
+                        j->error = "CLARANS: the device search ran out of pre-drawn steps";
+                    }
+                } else {
+                    j->rc = rc;
+                    j->error = msg;
+                }
+                if (j->rc != LCSGPU_OK || j->state[1]) {
+                    j->done = true;
+                    B.joined.erase(std::find(B.joined.begin(), B.joined.end(), j));
+                }
+            }
+            B.cv.notify_all();
+        }
+    }
+}
+
+// Join the batch with a search whose device state is initialised; returns when it has finished.
+int clarans_run_search(lcsgpu_ctx* ctx, ClaransJob& job)
+{
+    ClaransBatcher& B = ctx->clarans;
+    job.done = false;
+    std::unique_lock<std::mutex> lk(B.mu);
+    B.joined.push_back(&job);
+    while (!job.done) {
+        if (!B.driver_present) {
+            B.driver_present = true;
+            lk.unlock();
+            clarans_drive(ctx, &job);
+            lk.lock();
+        } else {
+            B.cv.wait(lk, [&] { return job.done || !B.driver_present; });
+        }
+    }
+    lk.unlock();
+    if (job.rc != LCSGPU_OK) return fail(job.rc, "%s", job.error.c_str());
+    return LCSGPU_OK;
+}
+
 void note_async_call(lcsgpu_ctx* ctx)
 {
     g_last.ctx = ctx;
@@ -458,6 +601,12 @@ int lcsgpu_create(int device_id, lcsgpu_ctx** out_ctx)
             lcsgpu_destroy(ctx);
             return fail(LCSGPU_E_HIP, "stream/event creation failed");
         }
+    if (hipStreamCreateWithFlags(&ctx->clarans.stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->clarans.ev, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess ||
+        ctx->clarans.h_states.reserve(lcsgpu::CLARANS_MAX_BATCH * 64) != hipSuccess) {
+        lcsgpu_destroy(ctx);
+        return fail(LCSGPU_E_HIP, "stream/event creation failed");
+    }
     *out_ctx = ctx;
     return LCSGPU_OK;
 }
@@ -480,6 +629,14 @@ int lcsgpu_destroy(lcsgpu_ctx* ctx)
         if (l.ev_done) (void)hipEventDestroy(l.ev_done);
         if (l.stream) (void)hipStreamDestroy(l.stream);
     }
+    if (getenv("LCSGPU_PROFILE"))
+        for (int i = 1; i <= lcsgpu::CLARANS_MAX_BATCH; ++i)
+            if (ctx->clarans.prof_looks[i])
+                fprintf(stderr, "clarans.batch[%d searches]: %ld looks of 32 rounds, %.3f s, %.1f us per round\n", i, ctx->clarans.prof_looks[i],
+                        ctx->clarans.prof_seconds[i], 1e6 * ctx->clarans.prof_seconds[i] / ctx->clarans.prof_looks[i] / 32);
+    if (ctx->clarans.stream) { (void)hipStreamSynchronize(ctx->clarans.stream); (void)hipStreamDestroy(ctx->clarans.stream); }
+    if (ctx->clarans.ev) (void)hipEventDestroy(ctx->clarans.ev);
+    ctx->clarans.h_states.release();
     ctx->d_tiles.release();
     ctx->d_tile_base.release();
     ctx->d_lens.release();
@@ -1124,8 +1281,8 @@ int lcsgpu_clarans(lcsgpu_ctx* ctx, const int32_t* ids, int32_t n_ids, int dista
     auto a256 = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const size_t window = (size_t)std::max(corrected, 1);
     const size_t o_D = 0, o_DM = o_D + a256(pairs * 4), o_cand = o_DM + a256((size_t)n * k * 4),
-                 o_st = o_cand + a256((size_t)n * 4), o_rd = o_st + a256((size_t)n * 16), o_rm = o_rd + a256(window * 4),
-                 o_wxx = o_rm + a256(window * 4), o_wx = o_wxx + a256(window * 8), o_log = o_wx + a256(window * 8), o_state = o_log + a256((size_t)(n + 1) * 4), o_ids = o_state + 256,
+                 o_st = o_cand + a256((size_t)n * 4), o_rd = o_st + a256((size_t)n * 16), o_rm = o_rd + a256(std::max<size_t>(window, 64) * 4),
+                 o_wxx = o_rm + a256(std::max<size_t>(window, 64) * 4), o_wx = o_wxx + a256(window * 8), o_log = o_wx + a256(window * 8), o_state = o_log + a256((size_t)(n + 1) * 4), o_ids = o_state + 256,
                  total = o_ids + a256((size_t)n * 4);
     HIP_TRY(L.d_work.reserve(total));
     HIP_TRY(L.h_small.reserve(64));
@@ -1156,34 +1313,19 @@ int lcsgpu_clarans(lcsgpu_ctx* ctx, const int32_t* ids, int32_t n_ids, int dista
     a.n_medoids = k;
     a.n_fixed = n_fixed;
 
+    a.corrected = corrected;
     // The two generators of Clustering.cpp:43-44.  Neither looks at the search state, so the host
     // runs them: gen_nodes shuffles the candidate order before every local search, gen_positions
     // yields the step positions, handed to the device as a growing array of draws.
     std::mt19937 gen_nodes, gen_positions;
     std::vector<int32_t> cand(n), draws;
     for (int32_t i = 0; i < n; ++i) cand[i] = i;
-    const uint32_t diff = (uint32_t)(n - k); // det_uniform_int_distribution<int>(n_medoids, n_elems - 1)
-    const uint32_t bad = diff ? 0xffffffffu / diff : 0;
-    auto extend_draws = [&](size_t want) -> int {
-        if (draws.size() >= want) return LCSGPU_OK;
-        const size_t old = draws.size();
-        want = std::max(want, old * 2);
-        draws.reserve(want);
-        while (draws.size() < want) {
-            const uint32_t r = gen_positions();
-            if (r / diff < bad) draws.push_back((int32_t)(r % diff) + k); // deterministic_random.h:62-76
-        }
-        const bool regrow = L.d_draws.cap < want * 4;
-        HIP_TRY(L.d_draws.reserve(want * 4));
-        const size_t from = regrow ? 0 : old;
-        HIP_TRY(hipMemcpyAsync((int32_t*)L.d_draws.p + from, draws.data() + from, (draws.size() - from) * 4,
-                               hipMemcpyHostToDevice, L.stream));
-        return LCSGPU_OK;
-    };
-    const int batch = 48; // rounds enqueued between two looks at the done flag
-    int32_t* h_state = (int32_t*)L.h_small.p;
+    ClaransJob job;
+    job.a = a;
+    job.gen_positions = &gen_positions;
+    job.draws = &draws;
+    job.d_draws = &L.d_draws;
     float best_cost = std::numeric_limits<float>::max();
-    int32_t p_host = 0;
     for (int iter = 0; iter < num_local; ++iter) {
         // partial_shuffle(candidate + n_fixed, candidate + n, candidate + n, gen_nodes), deterministic_random.h:113-127
         {
@@ -1196,41 +1338,18 @@ int lcsgpu_clarans(lcsgpu_ctx* ctx, const int32_t* ids, int32_t n_ids, int dista
             }
         }
         HIP_TRY(hipMemcpyAsync(a.cand, cand.data(), (size_t)n * 4, hipMemcpyHostToDevice, L.stream));
-        if (diff) { // the init kernel already needs the first window's draws
-            int rc = extend_draws((size_t)p_host + (size_t)(batch + 1) * std::max(corrected, 1));
+        if (n > k) { // the init kernel already needs the first window's draws
+            int rc = clarans_extend_draws(job, (size_t)job.p_host + (size_t)std::max(corrected, 1), L.stream);
             if (rc) return rc;
         }
-        a.draws = (const int32_t*)L.d_draws.p;
-        a.draws_len = (int32_t)draws.size();
-        HIP_TRY(lcsgpu::launch_clarans_init(a, corrected, L.stream));
-        bool first = true;
-        for (;;) {
-            if (diff) { // a round consumes at most `corrected` draws and prepares the window after it
-                int rc = extend_draws((size_t)p_host + (size_t)(batch + 1) * std::max(corrected, 1));
-                if (rc) return rc;
-            }
-            a.draws = (const int32_t*)L.d_draws.p;
-            a.draws_len = (int32_t)draws.size();
-            HIP_TRY(lcsgpu::launch_clarans_rounds(a, corrected, first, batch, L.stream));
-            first = false;
-            HIP_TRY(hipMemcpyAsync(h_state, a.state, 32, hipMemcpyDeviceToHost, L.stream));
-            HIP_TRY(hipEventRecord(L.ev_done, L.stream));
-            HIP_TRY(hipEventSynchronize(L.ev_done));
-            L.plan_in_flight = false;
-            if (h_state[6]) return fail(LCSGPU_E_STATE, "CLARANS: the device search ran out of pre-drawn steps");
-            p_host = h_state[0];
-            if (h_state[1]) break;
-        }
-#ifdef CLARANS_TRACE
-        {
-            unsigned long long tr[8];
-            HIP_TRY(hipMemcpy(tr, (char*)a.state + 64, sizeof tr, hipMemcpyDeviceToHost));
-            if (tr[7]) fprintf(stderr, "eval trace (x10 ns, avg over %llu): L1 %.0f gather %.0f sync %.0f walk %.0f sync %.0f reduce %.0f\n", tr[7],
-                    (double)tr[0] / tr[7], (double)tr[1] / tr[7], (double)tr[2] / tr[7], (double)tr[3] / tr[7], (double)tr[4] / tr[7], (double)tr[5] / tr[7]);
-        }
-#endif
+        HIP_TRY(lcsgpu::launch_clarans_init(job.a, L.stream));
+        HIP_TRY(hipEventRecord(L.ev_done, L.stream));
+        HIP_TRY(hipEventSynchronize(L.ev_done)); // the rounds run on the batch stream
+        L.plan_in_flight = false;
+        int rc = clarans_run_search(ctx, job);
+        if (rc) return rc;
         float cost;
-        memcpy(&cost, &h_state[5], 4);
+        memcpy(&cost, &job.state[5], 4);
         HIP_TRY(hipMemcpy(cand.data(), a.cand, (size_t)n * 4, hipMemcpyDeviceToHost));
         if (cost < best_cost) {
             best_cost = cost;
