@@ -48,6 +48,8 @@ struct RowsArgs {
 int h_class(uint32_t len);
 int quirk_h_class(uint32_t len);
 int refs_per_block(int h, bool quirk);
+// ... reduced for launches that would otherwise have too few workgroups to fill the chip
+int refs_per_block_for(int h, bool quirk, long n_refs, long col_blocks);
 hipError_t launch_rows(int h, bool quirk, const RowsArgs& a, int grid_x, int grid_y, hipStream_t stream);
 // refs longer than 2048 residues: needs grid_x*grid_y*n_chunks_max*512 bytes of carry scratch
 size_t long_carry_bytes(int grid_x, int grid_y, int n_chunks_max);

@@ -35,6 +35,8 @@
 // a segment at partner position p is parked in a per-lane bit stream in global memory and
 // re-enters word 0 of the next segment at the same position.
 #include <hip/hip_runtime.h>
+
+#include <algorithm>
 #include <stdint.h>
 
 #include "lcs_kernels.h"
@@ -611,6 +613,21 @@ int refs_per_block(int h, bool quirk)
     if (r > 32) r = 32;
     r = r / rg * rg;
     if (r < rg) r = rg;
+    return r;
+}
+
+// Small launches: a workgroup with the full complement of refs runs for hundreds of microseconds,
+// and a few hundred such workgroups leave most of the chip idle for that long.  Fewer refs per
+// workgroup (a multiple of the register group) give more, shorter workgroups; the full complement
+// is kept once the launch has enough of them anyway.
+int refs_per_block_for(int h, bool quirk, long n_refs, long col_blocks)
+{
+    const int full = refs_per_block(h, quirk);
+    if (h == 0) return full;
+    const int rg = quirk ? 1 : rg_of(h);
+    const long want = 2048; // workgroups
+    int r = full;
+    while (r > rg && ((n_refs + r - 1) / r) * col_blocks < want) r = std::max(rg, r / 2 / rg * rg);
     return r;
 }
 

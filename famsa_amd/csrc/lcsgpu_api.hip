@@ -288,12 +288,16 @@ int run_rows(lcsgpu_ctx* ctx, Lane& L, int mode, const int32_t* ref_ids, int32_t
     std::vector<size_t> row_off(buckets.size(), 0), id_off(buckets.size(), 0), pre_off(buckets.size(), 0);
     std::vector<char> is_contig(buckets.size(), 0);
     std::vector<std::vector<int32_t>> tri_prefix(buckets.size());
+    std::vector<int> refs_per_wg(buckets.size(), 0);
     for (size_t b = 0; b < buckets.size(); ++b) {
+        // triangle: about half of the column blocks of a ref tile lie below the diagonal
+        const long col_blocks = std::max<long>(1, ((long)n_cols + 255) / 256 / (mode == lcsgpu::MODE_TRIANGLE ? 2 : 1));
+        refs_per_wg[b] = lcsgpu::refs_per_block_for(buckets[b].bv, buckets[b].quirk, (long)buckets[b].items.size(), col_blocks);
         is_contig[b] = contiguous(buckets[b]);
         if (is_contig[b] && mode == lcsgpu::MODE_TRIANGLE && buckets[b].bv != 0) {
             // compact grid: only the workgroups at or below the diagonal, bottom row first
             const Bucket& bk = buckets[b];
-            const int R = lcsgpu::refs_per_block(bk.bv, bk.quirk);
+            const int R = refs_per_wg[b];
             const int nrefs = (int)bk.items.size();
             const int gy = (nrefs + R - 1) / R;
             std::vector<int32_t>& pre = tri_prefix[b];
@@ -366,7 +370,7 @@ int run_rows(lcsgpu_ctx* ctx, Lane& L, int mode, const int32_t* ref_ids, int32_t
         a.out_offset = out_offset;
         a.elem_size = elem_size;
         a.mode = mode;
-        a.refs_per_block = lcsgpu::refs_per_block(bk.bv, bk.quirk);
+        a.refs_per_block = refs_per_wg[b];
         int32_t use_cols = n_cols;
         if (mode == lcsgpu::MODE_TRIANGLE) { // columns at or beyond the largest row are never wanted
             int64_t max_row = 0;
@@ -1148,6 +1152,7 @@ int lcsgpu_lcs_triangles_batch(lcsgpu_ctx* ctx, const int32_t* ids, const int64_
         std::vector<int64_t> ref_row, ref_out0;
         std::vector<int32_t> ref_group;
         std::vector<int4> jobs;
+        int refs_per_wg = 0;
     };
     std::vector<BatchBucket> buckets;
     int index_of[160];
@@ -1161,7 +1166,7 @@ int lcsgpu_lcs_triangles_batch(lcsgpu_ctx* ctx, const int32_t* ids, const int64_
             const int key = bv * 2 + (q ? 1 : 0);
             if (index_of[key] < 0) {
                 index_of[key] = (int)buckets.size();
-                buckets.push_back(BatchBucket{bv, q, {}, {}, {}, {}, {}, {}});
+                buckets.push_back(BatchBucket{bv, q, {}, {}, {}, {}, {}, {}, 0});
             }
             BatchBucket& b = buckets[index_of[key]];
             b.ref_id.push_back(id);
@@ -1178,7 +1183,7 @@ int lcsgpu_lcs_triangles_batch(lcsgpu_ctx* ctx, const int32_t* ids, const int64_
         o_job(buckets.size());
     for (size_t bi = 0; bi < buckets.size(); ++bi) {
         BatchBucket& b = buckets[bi];
-        const int R = lcsgpu::refs_per_block(b.bv, b.quirk);
+        const int R = b.refs_per_wg = lcsgpu::refs_per_block_for(b.bv, b.quirk, (long)b.ref_id.size(), 1);
         const size_t nr_all = b.ref_id.size();
         for (size_t k0 = 0; k0 < nr_all;) {
             size_t k1 = k0 + 1;
@@ -1235,7 +1240,7 @@ int lcsgpu_lcs_triangles_batch(lcsgpu_ctx* ctx, const int32_t* ids, const int64_
         a.out = L.d_out.p;
         a.elem_size = elem_size;
         a.mode = lcsgpu::MODE_TRIANGLE;
-        a.refs_per_block = lcsgpu::refs_per_block(b.bv, b.quirk);
+        a.refs_per_block = b.refs_per_wg;
         HIP_TRY(lcsgpu::launch_rows(b.bv, b.quirk, a, (int)b.jobs.size(), 1, L.stream));
         ++L.last_launches;
     }
