@@ -43,11 +43,11 @@ def gpu(args, fasta):
     return time.time() - t0, float(kv["time.tree_build"]), open("/tmp/cmp_gpu.dnd", "rb").read()
 
 
-def case(name, fasta, gt, heuristic=0, cli_args=()):
-    t_ref, want = ref_tree(fasta, gt, heuristic)
+def case(name, fasta, gt, heuristic=0, cli_args=(), with_reference=True, limit=150):
+    t_ref, want = ref_tree(fasta, gt, heuristic, limit) if with_reference else (None, None)
     wall, tb, got = gpu(["-gt", gt, *cli_args], fasta)
     rec = {"case": name, "gt": gt, "identical_newick": (got == want) if want is not None else None,
-           "reference_tree_s": round(t_ref, 3) if t_ref else "> 150 (stopped)",
+           "reference_tree_s": round(t_ref, 3) if t_ref else ("> %d (stopped)" % limit if with_reference else "not run"),
            "gpu_tree_build_s": round(tb, 3), "gpu_cli_wall_s": round(wall, 3),
            "speedup_tree_stage": round(t_ref / tb, 1) if t_ref else None}
     print(rec, flush=True)
@@ -62,7 +62,13 @@ case("synthetic 10000 x 400 aa", "/tmp/cmp_10k.fasta", "upgma")
 case("synthetic 10000 x 400 aa", "/tmp/cmp_10k.fasta", "slink")
 case("hemopexin (4188 seqs, 21-210 aa)", os.path.join(ROOT, "tests", "golden", "hemopexin", "hemopexin"), "nj")
 case("hemopexin (4188 seqs, 21-210 aa)", os.path.join(ROOT, "tests", "golden", "hemopexin", "hemopexin"), "upgma")
-fam = "/tmp/family_200000_300.fasta"
-if os.path.exists(fam):
-    case("synthetic family 200000 x ~255 aa, -medoidtree", fam, "upgma", heuristic=2, cli_args=["-medoidtree"])
+codes, offsets = seqio.synth_uniform(100000, 400)
+seqio.to_fasta(codes, offsets, "/tmp/cmp_100k.fasta")
+for gt in ("sl", "slink", "upgma"):
+    case("synthetic 100000 x 400 aa", "/tmp/cmp_100k.fasta", gt, with_reference=False)
+for n, ref_limit in ((200000, 150), (1000000, 240), (3000000, 0)):
+    fam = "/tmp/family_%d_300.fasta" % n
+    if os.path.exists(fam):
+        case("synthetic family %d x ~255 aa, -medoidtree" % n, fam, "upgma", heuristic=2, cli_args=["-medoidtree"],
+             with_reference=ref_limit > 0, limit=ref_limit)
 json.dump(out, open(os.path.join(ROOT, "gpurun_out", "e2e_r01.json"), "w"), indent=1)
