@@ -134,6 +134,11 @@ hipError_t launch_nj(const NjArgs& a, hipStream_t stream);
 hipError_t launch_float_distances(const void* lcs, int elem_size, const uint32_t* lens, const float* pow_f32, int kind,
                                   int n, float* D, hipStream_t stream);
 
+// seed assignment over an LCS rectangle in HBM (tree_kernels.hip); dist / assign are read and updated
+hipError_t launch_assign_seeds(const void* lcs, int elem_size, int64_t ld, const int32_t* seed_ids, int32_t n_seeds,
+                               const int32_t* col_ids, int32_t n_cols, const uint32_t* lens, const float* pow_f32,
+                               int kind, int first_k, float* dist, int32_t* assign, hipStream_t stream);
+
 // ---- the uploaded set's device form (upload_kernels.hip) ----
 // tiles / quirk flags from the packed codes; flags[0] |= 1 if a symbol code >= 32 was met
 hipError_t launch_build_set(const uint8_t* codes, const uint64_t* offsets, const uint64_t* tile_base, int32_t n,

@@ -1253,6 +1253,57 @@ int lcsgpu_lcs_triangles_batch(lcsgpu_ctx* ctx, const int32_t* ids, const int64_
     return LCSGPU_OK;
 }
 
+int lcsgpu_assign_seeds(lcsgpu_ctx* ctx, const int32_t* seed_ids, int32_t n_seeds, const int32_t* col_ids,
+                        int32_t n_cols, int distance_kind, int32_t first_k, float* dist, int32_t* assign)
+{
+    if (!ctx) return fail(LCSGPU_E_INVALID, "NULL ctx");
+    if (ctx->n < 0) return fail(LCSGPU_E_STATE, "no sequence set uploaded");
+    if (distance_kind != LCSGPU_DIST_INDEL_DIV_LCS && distance_kind != LCSGPU_DIST_INDEL075_DIV_LCS)
+        return fail(LCSGPU_E_INVALID, "unknown distance kind %d", distance_kind);
+    if (n_seeds < 0 || n_cols < 0) return fail(LCSGPU_E_INVALID, "negative count");
+    if (n_seeds == 0 || n_cols == 0) return LCSGPU_OK;
+    if (!seed_ids || !col_ids || !dist || !assign) return fail(LCSGPU_E_INVALID, "NULL argument");
+    for (int32_t r = 0; r < n_seeds; ++r)
+        if (seed_ids[r] < 0 || seed_ids[r] >= ctx->n) return fail(LCSGPU_E_INVALID, "seed id %d out of range", seed_ids[r]);
+    LaneGuard guard(ctx, LaneGuard::ANY);
+    Lane& L = guard.lane();
+    HIP_TRY(hipSetDevice(ctx->device));
+    const int elem = ctx->max_len > 65535 ? 4 : 2;
+    // column chunks: the LCS rectangle of a chunk stays below 256 MB
+    const int32_t chunk = (int32_t)std::max<int64_t>(4096, std::min<int64_t>(n_cols, ((int64_t)256 << 20) / ((int64_t)n_seeds * elem)));
+    auto a256 = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t o_seeds = 0, o_cols = o_seeds + a256((size_t)n_seeds * 4), o_dist = o_cols + a256((size_t)chunk * 4),
+                 o_assign = o_dist + a256((size_t)chunk * 4), total = o_assign + a256((size_t)chunk * 4);
+    HIP_TRY(L.d_work.reserve(total));
+    HIP_TRY(L.d_out.reserve((size_t)n_seeds * chunk * elem));
+    char* base = (char*)L.d_work.p;
+    HIP_TRY(hipMemcpyAsync(base + o_seeds, seed_ids, (size_t)n_seeds * 4, hipMemcpyHostToDevice, L.stream));
+    double ms = 0;
+    int launches = 0;
+    for (int32_t c0 = 0; c0 < n_cols; c0 += chunk) {
+        const int32_t cn = std::min(chunk, n_cols - c0);
+        HIP_TRY(hipMemcpyAsync(base + o_cols, col_ids + c0, (size_t)cn * 4, hipMemcpyHostToDevice, L.stream));
+        HIP_TRY(hipMemcpyAsync(base + o_dist, dist + c0, (size_t)cn * 4, hipMemcpyHostToDevice, L.stream));
+        HIP_TRY(hipMemcpyAsync(base + o_assign, assign + c0, (size_t)cn * 4, hipMemcpyHostToDevice, L.stream));
+        int rc = run_rows(ctx, L, lcsgpu::MODE_RECT, seed_ids, 0, n_seeds, col_ids + c0, 0, cn, L.d_out.p, cn, 0, elem);
+        if (rc) return rc;
+        HIP_TRY(lcsgpu::launch_assign_seeds(L.d_out.p, elem, cn, (const int32_t*)(base + o_seeds), n_seeds,
+                                            (const int32_t*)(base + o_cols), cn, (const uint32_t*)ctx->d_lens.p,
+                                            (const float*)ctx->d_powf.p, distance_kind, first_k, (float*)(base + o_dist),
+                                            (int32_t*)(base + o_assign), L.stream));
+        HIP_TRY(hipMemcpyAsync(dist + c0, base + o_dist, (size_t)cn * 4, hipMemcpyDeviceToHost, L.stream));
+        HIP_TRY(hipMemcpyAsync(assign + c0, base + o_assign, (size_t)cn * 4, hipMemcpyDeviceToHost, L.stream));
+        HIP_TRY(hipEventRecord(L.ev_done, L.stream));
+        HIP_TRY(hipEventSynchronize(L.ev_done));
+        finish_host_call(ctx, L);
+        ms += g_last.ms;
+        launches += g_last.launches;
+    }
+    g_last.ms = ms;
+    g_last.launches = launches;
+    return LCSGPU_OK;
+}
+
 int lcsgpu_clarans(lcsgpu_ctx* ctx, const int32_t* ids, int32_t n_ids, int distance_kind, int32_t n_medoids,
                    int32_t n_fixed, float explore_fraction, int32_t num_local, int32_t* medoids_out)
 {

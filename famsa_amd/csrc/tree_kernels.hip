@@ -557,3 +557,54 @@ hipError_t launch_float_distances(const void* lcs, int elem_size, const uint32_t
 }
 
 } // namespace lcsgpu
+
+// =============================================================================================
+// Seed assignment of the FastTree recursion (FastTree::makeEvaluation, tree/FastTree.cpp:309-324):
+// for the seeds in order, d = Transform<float>(LCS(ref = seed, partner = column)); a column moves to a
+// seed only on a strictly smaller distance.  One lane per column over the LCS rectangle the engine has
+// just computed into HBM: 8 bytes per column leave the device instead of 2 bytes per pair.
+// =============================================================================================
+namespace lcsgpu {
+
+template <typename T>
+__global__ __launch_bounds__(256) void assign_seeds_kernel(const T* __restrict__ lcs, int64_t ld,
+                                                           const int32_t* __restrict__ seed_ids, int32_t n_seeds,
+                                                           const int32_t* __restrict__ col_ids, int32_t n_cols,
+                                                           const uint32_t* __restrict__ lens,
+                                                           const float* __restrict__ pow_f32, int kind, int first_k,
+                                                           float* __restrict__ dist, int32_t* __restrict__ assign)
+{
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= n_cols) return;
+    const uint32_t len_j = lens[col_ids[j]];
+    float best = dist[j];
+    int32_t who = assign[j];
+    for (int r = 0; r < n_seeds; ++r) {
+        const uint32_t l = lcs[(int64_t)r * ld + j];
+        const uint32_t indel = lens[seed_ids[r]] + len_j - 2u * l;
+        float d;
+        if (l == 0) d = 3.40282347e38f; // Transform<float>: (float) nextafter((double) FLT_MAX, 0) == FLT_MAX
+        else if (kind == 1) d = __fdiv_rn(pow_f32[indel], (float)l);
+        else d = __fdiv_rn((float)indel, (float)l);
+        if (d < best) { best = d; who = first_k + r; }
+    }
+    dist[j] = best;
+    assign[j] = who;
+}
+
+hipError_t launch_assign_seeds(const void* lcs, int elem_size, int64_t ld, const int32_t* seed_ids, int32_t n_seeds,
+                               const int32_t* col_ids, int32_t n_cols, const uint32_t* lens, const float* pow_f32,
+                               int kind, int first_k, float* dist, int32_t* assign, hipStream_t stream)
+{
+    if (n_cols <= 0 || n_seeds <= 0) return hipSuccess;
+    const dim3 grid((unsigned)((n_cols + 255) / 256));
+    if (elem_size == 2)
+        hipLaunchKernelGGL(assign_seeds_kernel<uint16_t>, grid, dim3(256), 0, stream, (const uint16_t*)lcs, ld, seed_ids,
+                           n_seeds, col_ids, n_cols, lens, pow_f32, kind, first_k, dist, assign);
+    else
+        hipLaunchKernelGGL(assign_seeds_kernel<uint32_t>, grid, dim3(256), 0, stream, (const uint32_t*)lcs, ld, seed_ids,
+                           n_seeds, col_ids, n_cols, lens, pow_f32, kind, first_k, dist, assign);
+    return hipGetLastError();
+}
+
+} // namespace lcsgpu

@@ -234,6 +234,14 @@ public:
         for (int i = 0; i < n_cols; ++i) c[i] = ids_[cols ? cols[i] : i];
         p_.rect(r.data(), n_refs, c.data(), n_cols, out);
     }
+    bool assign_seeds(const int* seeds, int n_seeds, const int* cols, int n_cols, int kind, int first_k, float* dist,
+                      int* assign) override
+    {
+        std::vector<int> sg(n_seeds), cg(n_cols);
+        for (int i = 0; i < n_seeds; ++i) sg[i] = ids_[seeds[i]];
+        for (int i = 0; i < n_cols; ++i) cg[i] = ids_[cols[i]];
+        return p_.assign_seeds(sg.data(), n_seeds, cg.data(), n_cols, kind, first_k, dist, assign);
+    }
     bool triangles_batch(const int* ids, const int64_t* offsets, int n_groups, LcsBuf& out) override
     {
         std::vector<int> g((size_t)offsets[n_groups]);
@@ -456,9 +464,14 @@ struct FastTree {
         // in increasing k, exactly as the reference's row-by-row sweep
         std::vector<int> refs(n_seeds - 1);
         for (int k = 1; k < n_seeds; ++k) refs[k - 1] = ids[seed_ids[k]];
+        bool on_device = false;
+        if (n_seeds > 1) { // the sweep inside the engine when it offers that: 8 bytes per column come back
+            Scope t(g_phase.assign);
+            on_device = src.assign_seeds(refs.data(), n_seeds - 1, ids.data(), n, (int)D, 1, dist_row.data(), assignments.data());
+        }
         const int chunk = 1 << 18;
         LcsBuf buf;
-        for (int c0 = 0; c0 < n && n_seeds > 1; c0 += chunk) {
+        for (int c0 = 0; c0 < n && n_seeds > 1 && !on_device; c0 += chunk) {
             const int c1 = std::min(n, c0 + chunk);
             {
                 Scope t(g_phase.lcs);

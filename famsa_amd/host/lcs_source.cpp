@@ -41,10 +41,11 @@ GpuLcsSource::~GpuLcsSource()
     if (getenv("FAMSA_GPU_PROFILE"))
         fprintf(stderr, "engine.rect: %ld calls %.3f thread-s %.3g pairs\nengine.triangle: %ld calls %.3f thread-s %.3g pairs\n"
                         "engine.triangle_ids: %ld calls %.3f thread-s %.3g pairs\nengine.clarans: %ld calls %.3f thread-s %.3g pairs\n"
-                        "engine.triangles_batch: %ld calls %.3f thread-s %.3g pairs\n",
+                        "engine.triangles_batch: %ld calls %.3f thread-s %.3g pairs\nengine.assign_seeds: %ld calls %.3f thread-s %.3g pairs\n",
                 st_rect_.calls, st_rect_.seconds, st_rect_.pairs, st_tri_.calls, st_tri_.seconds, st_tri_.pairs,
                 st_triids_.calls, st_triids_.seconds, st_triids_.pairs, st_clarans_.calls, st_clarans_.seconds,
-                st_clarans_.pairs, st_batch_.calls, st_batch_.seconds, st_batch_.pairs);
+                st_clarans_.pairs, st_batch_.calls, st_batch_.seconds, st_batch_.pairs, st_assign_.calls, st_assign_.seconds,
+                st_assign_.pairs);
     if (ctx_) lcsgpu_destroy(ctx_);
 }
 
@@ -158,6 +159,16 @@ bool GpuLcsSource::triangles_batch(const int* ids, const int64_t* offsets, int n
     const double t0 = now_s();
     check(lcsgpu_lcs_triangles_batch(ctx_, ids, offsets, n_groups, out.data(), out.elem_size()), "lcsgpu_lcs_triangles_batch");
     note(st_batch_, now_s() - t0, (double)count);
+    add_kernel_ms();
+    return true;
+}
+
+bool GpuLcsSource::assign_seeds(const int* seeds, int n_seeds, const int* cols, int n_cols, int distance_kind, int first_k,
+                                float* dist, int* assign)
+{
+    const double t0 = now_s();
+    check(lcsgpu_assign_seeds(ctx_, seeds, n_seeds, cols, n_cols, distance_kind, first_k, dist, assign), "lcsgpu_assign_seeds");
+    note(st_assign_, now_s() - t0, (double)n_seeds * n_cols);
     add_kernel_ms();
     return true;
 }

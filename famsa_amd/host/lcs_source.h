@@ -59,6 +59,10 @@ public:
     // The packed triangles of several id lists in one request: list g = ids[offsets[g] .. offsets[g+1]),
     // its triangle at out[sum_{h<g} m_h(m_h-1)/2 ...].  False = not offered; ask list by list.
     virtual bool triangles_batch(const int* /*ids*/, const int64_t* /*offsets*/, int /*n_groups*/, LcsBuf& /*out*/) { return false; }
+    // Seed assignment of one FastTree evaluation done by the source itself: for r in order, a column moves to
+    // seed first_k + r on a strictly smaller Transform<float> distance; dist / assign are updated in place.
+    virtual bool assign_seeds(const int* /*seeds*/, int /*n_seeds*/, const int* /*cols*/, int /*n_cols*/, int /*distance_kind*/,
+                              int /*first_k*/, float* /*dist*/, int* /*assign*/) { return false; }
     // CLARANS k-medoids over the sample `ids` computed by the source itself (device): medoids[k] =
     // member numbers 0..n_ids-1.  False = not offered for this shape; the caller runs the host search.
     virtual bool clarans(const int* /*ids*/, int /*n_ids*/, int /*distance_kind*/, int /*n_medoids*/, int /*n_fixed*/,
@@ -84,6 +88,8 @@ public:
     bool clarans(const int* ids, int n_ids, int distance_kind, int n_medoids, int n_fixed, float explore_fraction,
                  int num_local, int* medoids) override;
     bool triangles_batch(const int* ids, const int64_t* offsets, int n_groups, LcsBuf& out) override;
+    bool assign_seeds(const int* seeds, int n_seeds, const int* cols, int n_cols, int distance_kind, int first_k, float* dist,
+                      int* assign) override;
     double kernel_ms_total() const { return kernel_ms_; }
     void add_kernel_ms();
 
@@ -95,7 +101,7 @@ private:
     double kernel_ms_ = 0;
     std::mutex mu_; // the tree builders may call from several threads
     // call statistics (printed at destruction when FAMSA_GPU_PROFILE is set)
-    struct CallStat { long calls = 0; double seconds = 0; double pairs = 0; } st_rect_, st_tri_, st_triids_, st_clarans_, st_batch_;
+    struct CallStat { long calls = 0; double seconds = 0; double pairs = 0; } st_rect_, st_tri_, st_triids_, st_clarans_, st_batch_, st_assign_;
     void note(CallStat& s, double sec, double pairs);
 };
 

@@ -56,6 +56,7 @@ def load_library():
         "lcsgpu_upgma": (C.c_int, [vp, C.c_int, C.c_int, vp, vp]),
         "lcsgpu_nj": (C.c_int, [vp, C.c_int, vp, vp]),
         "lcsgpu_lcs_triangles_batch": (C.c_int, [vp, pi32, C.POINTER(C.c_int64), i32, vp, C.c_int]),
+        "lcsgpu_assign_seeds": (C.c_int, [vp, pi32, i32, pi32, i32, C.c_int, i32, vp, vp]),
         "lcsgpu_clarans": (C.c_int, [vp, pi32, i32, C.c_int, i32, i32, C.c_float, i32, pi32]),
         "lcsgpu_sync": (C.c_int, [vp]),
         "lcsgpu_last_kernel_ms": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(i32)]),
@@ -206,6 +207,14 @@ class LcsGpu:
         right = np.zeros(max(self.n - 1, 1), dtype=np.int32)
         self._check(self._lib.lcsgpu_upgma(self._ctx, kind, int(modified), left.ctypes.data, right.ctypes.data))
         return left[: max(self.n - 1, 0)], right[: max(self.n - 1, 0)]
+
+    def assign_seeds(self, seed_ids, col_ids, dist, assign, first_k=1, kind=1):
+        """Nearest-seed update of (dist, assign) over the columns, in place (float32 / int32 arrays)."""
+        s_arr, s_ptr = _ids(seed_ids)
+        c_arr, c_ptr = _ids(col_ids)
+        assert dist.dtype == np.float32 and assign.dtype == np.int32 and len(dist) == len(c_arr) == len(assign)
+        self._check(self._lib.lcsgpu_assign_seeds(self._ctx, s_ptr, len(s_arr), c_ptr, len(c_arr), kind, first_k,
+                                                  dist.ctypes.data, assign.ctypes.data))
 
     def clarans(self, ids, n_medoids, n_fixed=1, explore_fraction=0.1, num_local=2, kind=1):
         """CLARANS medoids (member numbers within `ids`) of the sample `ids`, computed on the device."""

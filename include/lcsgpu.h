@@ -201,6 +201,15 @@ int lcsgpu_nj(lcsgpu_ctx* ctx, int distance_kind, int32_t* out_left, int32_t* ou
 int lcsgpu_lcs_triangles_batch(lcsgpu_ctx* ctx, const int32_t* ids, const int64_t* group_offsets, int32_t n_groups,
                                void* out, int elem_size);
 
+/* Seed assignment of one FastTree evaluation: for r = 0 .. n_seeds-1 in order,
+ *   d = Transform<float>(LCS(ref = seed_ids[r], partner = col_ids[j]));  if (d < dist[j]) { dist[j] = d; assign[j] = first_k + r; }
+ * dist / assign (HOST, n_cols entries each) are read and updated: the caller initialises them with the
+ * distances to its seed 0 and zeros.  The LCS rectangle stays in HBM; 8 bytes per column come back.
+ * Replaces: the seeds x all calculateDistanceVector sweep of FastTree::makeEvaluation
+ * (tree/FastTree.cpp:309-324). */
+int lcsgpu_assign_seeds(lcsgpu_ctx* ctx, const int32_t* seed_ids, int32_t n_seeds, const int32_t* col_ids,
+                        int32_t n_cols, int distance_kind, int32_t first_k, float* dist, int32_t* assign);
+
 /* CLARANS k-medoids over a sample of the uploaded set, on the device: LCS triangle over `ids`
  * (ref = ids[i], partner = ids[j], j < i) -> float distances (Transform<float>) -> `num_local`
  * local searches, each the reference's swap search with its two mt19937 streams, its float

@@ -86,3 +86,31 @@ def test_device_clarans_rejects_bad_shapes(engine):
             engine.clarans(ids, args[0], args[1])
     with pytest.raises(famsa_amd.LcsGpuError):
         engine.clarans(np.array([0, 25], np.int32), 1, 0)
+
+
+@pytest.mark.parametrize("kind", [0, 1])
+def test_assign_seeds_matches_the_host_sweep(engine, oracle, kind):
+    """lcsgpu_assign_seeds against FastTree::makeEvaluation's sweep restated with the oracle's LCS and float
+    transform: seeds in order, strict '<', columns given as an id list, chunk borders, ties (short sequences)."""
+    rng = np.random.default_rng(77 + kind)
+    seqs = _family(rng, 500, 120, 0.3) + _short(rng, 300, 4, 9, 3)
+    engine.upload_seqs(seqs)
+    codes, offsets = seqio.pack(seqs)
+    n = len(seqs)
+    cols = rng.permutation(n)[:700].astype(np.int32)
+    seeds = rng.permutation(n)[:13].astype(np.int32)
+    lcs = oracle.rect(codes, offsets, seeds, cols)
+    fn = oracle.lib.oracle_dist_indel075_f32 if kind == 1 else oracle.lib.oracle_dist_indel_f32
+    lens = [len(s) for s in seqs]
+    first = np.array([fn(int(oracle.lcs(seqs[cols[0]], seqs[c])), lens[cols[0]], lens[c]) for c in cols], np.float32)
+    want_d, want_a = first.copy(), np.zeros(len(cols), np.int32)
+    for r, sid in enumerate(seeds):
+        for j, c in enumerate(cols):
+            d = np.float32(fn(int(lcs[r, j]), lens[sid], lens[c]))
+            if d < want_d[j]:
+                want_d[j] = d
+                want_a[j] = 1 + r
+    got_d, got_a = first.copy(), np.zeros(len(cols), np.int32)
+    engine.assign_seeds(seeds, cols, got_d, got_a, first_k=1, kind=kind)
+    assert (got_a == want_a).all()
+    assert (got_d.view(np.uint32) == want_d.view(np.uint32)).all()
