@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
@@ -152,7 +153,10 @@ struct lcsgpu_ctx {
     // scratch of the lane-0 tree reducers
     DevBuf d_prim, d_qrows, d_qcols, d_dist;
     double total_kernel_ms = 0; // completed host-memory calls
-    ClaransBatcher clarans;
+    // searches are spread over a few independent batches (each its own stream and driver): rounds of
+    // different batches overlap on the GPU, which hides part of a round's memory latency
+    std::vector<ClaransBatcher> clarans_groups;
+    std::atomic<unsigned> clarans_next{0};
 };
 
 namespace {
@@ -463,9 +467,8 @@ int clarans_extend_draws(ClaransJob& j, size_t want, hipStream_t stream)
 }
 
 // One stint as the driver: rounds for everything joined, until nothing is left or `mine` is done.
-void clarans_drive(lcsgpu_ctx* ctx, ClaransJob* mine)
+void clarans_drive(lcsgpu_ctx* ctx, ClaransBatcher& B, ClaransJob* mine)
 {
-    ClaransBatcher& B = ctx->clarans;
     const int rounds_per_look = 32;
     for (;;) {
         std::vector<ClaransJob*> now;
@@ -528,7 +531,7 @@ void clarans_drive(lcsgpu_ctx* ctx, ClaransJob* mine)
 // Join the batch with a search whose device state is initialised; returns when it has finished.
 int clarans_run_search(lcsgpu_ctx* ctx, ClaransJob& job)
 {
-    ClaransBatcher& B = ctx->clarans;
+    ClaransBatcher& B = ctx->clarans_groups[ctx->clarans_next++ % ctx->clarans_groups.size()];
     job.done = false;
     std::unique_lock<std::mutex> lk(B.mu);
     B.joined.push_back(&job);
@@ -536,7 +539,7 @@ int clarans_run_search(lcsgpu_ctx* ctx, ClaransJob& job)
         if (!B.driver_present) {
             B.driver_present = true;
             lk.unlock();
-            clarans_drive(ctx, &job);
+            clarans_drive(ctx, B, &job);
             lk.lock();
         } else {
             B.cv.wait(lk, [&] { return job.done || !B.driver_present; });
@@ -605,12 +608,16 @@ int lcsgpu_create(int device_id, lcsgpu_ctx** out_ctx)
             lcsgpu_destroy(ctx);
             return fail(LCSGPU_E_HIP, "stream/event creation failed");
         }
-    if (hipStreamCreateWithFlags(&ctx->clarans.stream, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&ctx->clarans.ev, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess ||
-        ctx->clarans.h_states.reserve(lcsgpu::CLARANS_MAX_BATCH * 64) != hipSuccess) {
-        lcsgpu_destroy(ctx);
-        return fail(LCSGPU_E_HIP, "stream/event creation failed");
-    }
+    int n_groups = 4; // 3 x 10^6-sequence MedoidTree, tree stage: 1 group 2.92 s, 2: 2.79 s, 4: 2.71 s, 8: 4.13 s
+    if (const char* e = getenv("LCSGPU_CLARANS_GROUPS")) n_groups = std::max(1, std::min(16, atoi(e)));
+    ctx->clarans_groups = std::vector<ClaransBatcher>(n_groups);
+    for (ClaransBatcher& B : ctx->clarans_groups)
+        if (hipStreamCreateWithFlags(&B.stream, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&B.ev, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess ||
+            B.h_states.reserve(lcsgpu::CLARANS_MAX_BATCH * 64) != hipSuccess) {
+            lcsgpu_destroy(ctx);
+            return fail(LCSGPU_E_HIP, "stream/event creation failed");
+        }
     *out_ctx = ctx;
     return LCSGPU_OK;
 }
@@ -633,14 +640,16 @@ int lcsgpu_destroy(lcsgpu_ctx* ctx)
         if (l.ev_done) (void)hipEventDestroy(l.ev_done);
         if (l.stream) (void)hipStreamDestroy(l.stream);
     }
-    if (getenv("LCSGPU_PROFILE"))
-        for (int i = 1; i <= lcsgpu::CLARANS_MAX_BATCH; ++i)
-            if (ctx->clarans.prof_looks[i])
-                fprintf(stderr, "clarans.batch[%d searches]: %ld looks of 32 rounds, %.3f s, %.1f us per round\n", i, ctx->clarans.prof_looks[i],
-                        ctx->clarans.prof_seconds[i], 1e6 * ctx->clarans.prof_seconds[i] / ctx->clarans.prof_looks[i] / 32);
-    if (ctx->clarans.stream) { (void)hipStreamSynchronize(ctx->clarans.stream); (void)hipStreamDestroy(ctx->clarans.stream); }
-    if (ctx->clarans.ev) (void)hipEventDestroy(ctx->clarans.ev);
-    ctx->clarans.h_states.release();
+    for (ClaransBatcher& B : ctx->clarans_groups) {
+        if (getenv("LCSGPU_PROFILE"))
+            for (int i = 1; i <= lcsgpu::CLARANS_MAX_BATCH; ++i)
+                if (B.prof_looks[i])
+                    fprintf(stderr, "clarans.batch[%d searches]: %ld looks of 32 rounds, %.3f s, %.1f us per round\n", i,
+                            B.prof_looks[i], B.prof_seconds[i], 1e6 * B.prof_seconds[i] / B.prof_looks[i] / 32);
+        if (B.stream) { (void)hipStreamSynchronize(B.stream); (void)hipStreamDestroy(B.stream); }
+        if (B.ev) (void)hipEventDestroy(B.ev);
+        B.h_states.release();
+    }
     ctx->d_tiles.release();
     ctx->d_tile_base.release();
     ctx->d_lens.release();

@@ -56,6 +56,11 @@ CASES = [
     ("one-medoid", "family", 40, 30, 1, 0, 0.1, 2, 1),
     ("tiny", "family", 8, 3, 2, 1, 0.1, 2, 1),
     ("single-member", "family", 8, 1, 1, 0, 0.1, 1, 1),
+    # few medoids: a candidate is closer than their medoid to a large part of the members;
+    # > 2048 non-medoids: a second pass over the positions
+    ("one-medoid-many-members", "family", 1300, 1200, 1, 0, 0.02, 2, 1),
+    ("three-medoids-two-passes", "family", 2600, 2500, 3, 1, 0.01, 2, 1),
+    ("many-samples", "family", 4400, 4300, 40, 1, 0.005, 1, 1),
 ]
 
 
