@@ -119,3 +119,36 @@ def test_assign_seeds_matches_the_host_sweep(engine, oracle, kind):
     engine.assign_seeds(seeds, cols, got_d, got_a, first_k=1, kind=kind)
     assert (got_a == want_a).all()
     assert (got_d.view(np.uint32) == want_d.view(np.uint32)).all()
+
+
+def test_concurrent_searches_share_the_batch(engine):
+    """Searches of several host threads are advanced together by whichever thread drives the batch:
+    every thread must get exactly what it gets when it searches alone (different shapes, so searches
+    join and leave the batch at different times and the driver role changes hands)."""
+    import threading
+    rng = np.random.default_rng(2024)
+    seqs = _family(rng, 2500, 160, 0.25)
+    engine.upload_seqs(seqs)
+    jobs = []
+    for t in range(12):
+        m = int(rng.integers(150, 1400))
+        ids = np.sort(rng.permutation(len(seqs))[:m]).astype(np.int32)
+        jobs.append((ids, int(rng.integers(2, 40)), int(rng.integers(0, 2)), float(rng.choice([0.05, 0.1, 0.3])),
+                     int(rng.integers(1, 4))))
+    alone = [engine.clarans(ids, k, fixed, frac, iters).tolist() for ids, k, fixed, frac, iters in jobs]
+    for attempt in range(2):
+        together = [None] * len(jobs)
+        errors = []
+
+        def work(i):
+            try:
+                ids, k, fixed, frac, iters = jobs[i]
+                together[i] = engine.clarans(ids, k, fixed, frac, iters).tolist()
+            except Exception as e:  # noqa: BLE001
+                errors.append(repr(e))
+
+        threads = [threading.Thread(target=work, args=(i,)) for i in range(len(jobs))]
+        [t.start() for t in threads]
+        [t.join() for t in threads]
+        assert not errors, errors
+        assert together == alone
