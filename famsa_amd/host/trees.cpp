@@ -1,3 +1,4 @@
+#include "seqset.h"
 #include "trees.h"
 
 #include <algorithm>
@@ -10,6 +11,7 @@
 #include <limits>
 #include <queue>
 #include <stdexcept>
+#include <thread>
 
 namespace famsa_host {
 
@@ -607,12 +609,16 @@ static void write_csv_d(LcsSource& src, const std::vector<std::string>& ids, boo
         for (const auto& id : ids) ofs << ',' << (id.c_str() + 1);
         ofs << std::endl;
     }
-    Transform<double, D> t_dist;
-    Transform<float, Distance::pairwise_identity> t_pid;
-    std::vector<char> line(10000 + (size_t)n * 100);
-    const int block = std::max(1, std::min(n, 2048));
+    // LCS rows come from the engine in blocks; the rows of a block are turned into text by all host
+    // threads (the reference formats inside its row workers, DistanceCalculator.cpp:28-82) and written in order
+    const int n_threads = std::max(1, default_host_threads());
+    const size_t value_text = 48; // upper bound of one formatted value: a saturated integer part has 20 digits
+    const size_t row_text = 64 + (size_t)n * value_text;
+    const int block = (int)std::max<size_t>(1, std::min<size_t>({(size_t)n, (size_t)2048, ((size_t)256 << 20) / row_text}));
     LcsBuf buf;
     std::vector<int> refs;
+    std::vector<std::vector<char>> text(n_threads);
+    std::vector<std::vector<size_t>> row_end(n_threads);
     for (int r0 = 0; r0 < n; r0 += block) {
         const int r1 = std::min(n, r0 + block);
         if (square) {
@@ -623,21 +629,44 @@ static void write_csv_d(LcsSource& src, const std::vector<std::string>& ids, boo
             src.triangle(r0, r1, buf);
         }
         const size_t off = (size_t)r0 * (r0 > 0 ? r0 - 1 : 0) / 2;
-        for (int i = r0; i < r1; ++i) {
-            char* p = line.data();
-            p += sprintf(p, "%s,", ids[i].c_str() + 1);
-            const int cols = square ? n : i;
-            const uint32_t len_i = src.length(i);
-            for (int j = 0; j < cols; ++j) {
-                const uint32_t l = square ? buf[(size_t)(i - r0) * n + j] : buf[(size_t)i * (i - 1) / 2 + j - off];
-                // the reference stores both kinds as float before printing (DistanceCalculator.cpp:44-76)
-                const float v = pid ? t_pid(l, len_i, src.length(j)) : (float)t_dist(l, len_i, src.length(j));
-                p += format_distance((double)v, p);
-                *p++ = ',';
+        // thread w formats the rows r0 + w, r0 + w + T, ... (triangle rows grow: interleaving balances them)
+        const int T = std::min(n_threads, r1 - r0);
+        auto format_rows = [&](int w) {
+            Transform<double, D> t_dist;
+            Transform<float, Distance::pairwise_identity> t_pid;
+            std::vector<char>& out = text[w];
+            std::vector<size_t>& ends = row_end[w];
+            ends.clear();
+            size_t need = 0;
+            for (int i = r0 + w; i < r1; i += T) need += 64 + ids[i].size() + (size_t)(square ? n : i) * value_text;
+            if (out.size() < need) out.resize(need);
+            char* p = out.data();
+            for (int i = r0 + w; i < r1; i += T) {
+                p += sprintf(p, "%s,", ids[i].c_str() + 1);
+                const int cols = square ? n : i;
+                const uint32_t len_i = src.length(i);
+                for (int j = 0; j < cols; ++j) {
+                    const uint32_t l = square ? buf[(size_t)(i - r0) * n + j] : buf[(size_t)i * (i - 1) / 2 + j - off];
+                    // the reference stores both kinds as float before printing (DistanceCalculator.cpp:44-76)
+                    const float v = pid ? t_pid(l, len_i, src.length(j)) : (float)t_dist(l, len_i, src.length(j));
+                    p += format_distance((double)v, p);
+                    *p++ = ',';
+                }
+                --p;
+                *p++ = '\n';
+                ends.push_back((size_t)(p - out.data()));
             }
-            --p;
-            *p++ = '\n';
-            ofs.write(line.data(), p - line.data());
+        };
+        std::vector<std::thread> workers;
+        for (int w = 1; w < T; ++w) workers.emplace_back(format_rows, w);
+        format_rows(0);
+        for (auto& t : workers) t.join();
+        std::vector<size_t> next(T, 0), begin(T, 0);
+        for (int i = r0; i < r1; ++i) {
+            const int w = (i - r0) % T;
+            const size_t e = row_end[w][next[w]++];
+            ofs.write(text[w].data() + begin[w], (std::streamsize)(e - begin[w]));
+            begin[w] = e;
         }
     }
 }

@@ -62,6 +62,46 @@ case("synthetic 10000 x 400 aa", "/tmp/cmp_10k.fasta", "upgma")
 case("synthetic 10000 x 400 aa", "/tmp/cmp_10k.fasta", "slink")
 case("hemopexin (4188 seqs, 21-210 aa)", os.path.join(ROOT, "tests", "golden", "hemopexin", "hemopexin"), "nj")
 case("hemopexin (4188 seqs, 21-210 aa)", os.path.join(ROOT, "tests", "golden", "hemopexin", "hemopexin"), "upgma")
+
+
+def _ref_dist_worker(fasta, path, q):
+    ref = oracle_bind.Ref()
+    h = ref.open_fasta(fasta)
+    t0 = time.time()
+    ref.dist_export(h, path, threads=threads)
+    q.put(time.time() - t0)
+
+
+def dist_case(name, fasta):
+    """-dist_export (lower triangle CSV): reference DistanceCalculator vs famsa-gpu, byte comparison."""
+    import hashlib
+    q = mp.Queue()
+    p = mp.Process(target=_ref_dist_worker, args=(fasta, "/tmp/cmp_ref.csv", q))
+    p.start()
+    t_ref = q.get(timeout=300)
+    p.join()
+    t0 = time.time()
+    r = subprocess.run([cli, "-v", "-dist_export", fasta, "/tmp/cmp_gpu.csv"], stderr=subprocess.PIPE, text=True)
+    wall = time.time() - t0
+    assert r.returncode == 0, r.stderr
+
+    def md5(path):
+        h = hashlib.md5()
+        with open(path, "rb") as f:
+            for blk in iter(lambda: f.read(1 << 24), b""):
+                h.update(blk)
+        return h.hexdigest()
+    rec = {"case": name, "mode": "-dist_export", "identical_csv": md5("/tmp/cmp_ref.csv") == md5("/tmp/cmp_gpu.csv"),
+           "csv_bytes": os.path.getsize("/tmp/cmp_gpu.csv"), "reference_s": round(t_ref, 3), "gpu_cli_wall_s": round(wall, 3),
+           "speedup": round(t_ref / wall, 1)}
+    print(rec, flush=True)
+    out["cases"].append(rec)
+    os.remove("/tmp/cmp_ref.csv")
+    os.remove("/tmp/cmp_gpu.csv")
+
+
+dist_case("hemopexin (4188 seqs)", os.path.join(ROOT, "tests", "golden", "hemopexin", "hemopexin"))
+dist_case("synthetic 10000 x 400 aa", "/tmp/cmp_10k.fasta")
 codes, offsets = seqio.synth_uniform(100000, 400)
 seqio.to_fasta(codes, offsets, "/tmp/cmp_100k.fasta")
 for gt in ("sl", "slink", "upgma"):
