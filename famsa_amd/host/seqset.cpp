@@ -4,6 +4,7 @@
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
+#include <zlib.h>
 
 #include <algorithm>
 #include <cstring>
@@ -106,6 +107,42 @@ void parse_piece(const char* p, const char* end, Piece& out)
     out.codes.resize(seq_begin); // residues that never got a record (no header at all)
 }
 
+// gzip input (the reference reads .gz transparently, core/io_service.h:95): all members of the file,
+// inflated into one buffer
+std::vector<char> gunzip(const unsigned char* in, size_t size, const std::string& path)
+{
+    std::vector<char> out;
+    out.resize(std::max<size_t>(size * 4, 1 << 16));
+    z_stream zs;
+    memset(&zs, 0, sizeof zs);
+    if (inflateInit2(&zs, 16 + MAX_WBITS) != Z_OK) throw std::runtime_error("zlib initialisation failed");
+    size_t in_pos = 0, out_pos = 0;
+    for (;;) {
+        if (out_pos == out.size()) out.resize(out.size() * 2);
+        const size_t in_now = std::min<size_t>(size - in_pos, 1u << 30), out_now = std::min<size_t>(out.size() - out_pos, 1u << 30);
+        zs.next_in = const_cast<unsigned char*>(in + in_pos);
+        zs.avail_in = (uInt)in_now;
+        zs.next_out = (unsigned char*)out.data() + out_pos;
+        zs.avail_out = (uInt)out_now;
+        const int rc = inflate(&zs, Z_NO_FLUSH);
+        in_pos += in_now - zs.avail_in;
+        out_pos += out_now - zs.avail_out;
+        if (rc == Z_STREAM_END) {
+            if (in_pos >= size) break;
+            if (inflateReset(&zs) != Z_OK) break; // next member
+        } else if (rc != Z_OK && rc != Z_BUF_ERROR) {
+            inflateEnd(&zs);
+            throw std::runtime_error("Unable to decompress input file " + path);
+        } else if (rc == Z_BUF_ERROR && zs.avail_in == 0 && in_pos >= size) {
+            inflateEnd(&zs);
+            throw std::runtime_error("Unexpected end of compressed input file " + path);
+        }
+    }
+    inflateEnd(&zs);
+    out.resize(out_pos);
+    return out;
+}
+
 // FAMSA's working order as a strict weak order on input indices; the index breaks ties, which
 // makes a plain sort give the stable sort's result
 struct OrderLess {
@@ -152,19 +189,33 @@ SeqSet load_fasta(const std::string& path, int n_threads)
         close(fd);
         return s;
     }
-    const char* buf = (const char*)mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+    const char* mapped = (const char*)mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
     close(fd);
-    if (buf == MAP_FAILED) throw std::runtime_error("Unable to map input file " + path);
+    if (mapped == MAP_FAILED) throw std::runtime_error("Unable to map input file " + path);
+    const size_t mapped_size = size;
+    std::vector<char> inflated;
+    const char* buf = mapped;
+    size_t size_now = size;
+    if (size >= 2 && (unsigned char)mapped[0] == 0x1f && (unsigned char)mapped[1] == 0x8b) {
+        try {
+            inflated = gunzip((const unsigned char*)mapped, size, path);
+        } catch (...) {
+            munmap((void*)mapped, mapped_size);
+            throw;
+        }
+        buf = inflated.data();
+        size_now = inflated.size();
+    }
     // pieces of ~equal size, each starting at a header line (a '>' right after a '\n')
-    const int n_pieces = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_threads * 4, size / (1 << 20)));
-    std::vector<size_t> start(n_pieces + 1, size);
+    const int n_pieces = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_threads * 4, size_now / (1 << 20)));
+    std::vector<size_t> start(n_pieces + 1, size_now);
     start[0] = 0;
     for (int k = 1; k < n_pieces; ++k) {
-        size_t at = std::max(start[k - 1], size / n_pieces * k);
+        size_t at = std::max(start[k - 1], size_now / n_pieces * k);
         const char* q = buf + at;
         for (;;) {
-            q = (const char*)memchr(q, '\n', (size_t)(buf + size - q));
-            if (!q || q + 1 >= buf + size) { at = size; break; }
+            q = (const char*)memchr(q, '\n', (size_t)(buf + size_now - q));
+            if (!q || q + 1 >= buf + size_now) { at = size_now; break; }
             if (q[1] == '>') { at = (size_t)(q + 1 - buf); break; }
             ++q;
         }
@@ -176,10 +227,10 @@ SeqSet load_fasta(const std::string& path, int n_threads)
             if (start[k] < start[k + 1]) parse_piece(buf + start[k], buf + start[k + 1], pieces[k]);
         });
     } catch (...) {
-        munmap((void*)buf, size);
+        munmap((void*)mapped, mapped_size);
         throw;
     }
-    munmap((void*)buf, size);
+    munmap((void*)mapped, mapped_size);
     // stitch
     std::vector<size_t> rec0(n_pieces + 1, 0), byte0(n_pieces + 1, 0);
     for (int k = 0; k < n_pieces; ++k) {

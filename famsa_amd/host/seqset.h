@@ -26,7 +26,8 @@ struct SeqSet {
 // capped by the container's CPU quota (cgroup v2 cpu.max) when there is one.
 int default_host_threads();
 
-// FASTA reader with the reference's line handling; throws std::runtime_error on I/O errors.
+// FASTA reader with the reference's line handling (plain text or gzip, told apart by the magic bytes);
+// throws std::runtime_error on I/O errors.
 // n_threads <= 0: default_host_threads().
 SeqSet load_fasta(const std::string& path, int n_threads = 0);
 // Build from in-memory records (ids with '>', residue strings).

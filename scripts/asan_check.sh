@@ -40,9 +40,9 @@ for name,f,cut in [('hemo','tests/golden/hemopexin/hemopexin',700),('adv','tests
     o.rect(codes,off,np.arange(n),np.arange(n)).astype(np.uint32).tofile(f'/tmp/asan/{name}.mat')
 PY
 cd $ROOT/famsa_amd/host && g++ -std=c++17 -O1 -g -fsanitize=address,undefined -fno-omit-frame-pointer -pthread -o $W/check $W/main.cpp \
-  seqset.cpp lcs_source.cpp trees.cpp fasttree.cpp pipeline.cpp capi.cpp -L.. -llcsgpu -Wl,-rpath,$ROOT/famsa_amd
+  seqset.cpp lcs_source.cpp trees.cpp fasttree.cpp pipeline.cpp capi.cpp -L.. -llcsgpu -lz -Wl,-rpath,$ROOT/famsa_amd
 for n in hemo adv dup; do FAMSA_HOST_THREADS=4 ASAN_OPTIONS=detect_leaks=0 $W/check $W/$n.fasta $W/$n.mat; done
 # ThreadSanitizer pass over the same driver (task pool of the FastTree recursion, parallel reader / sort)
 g++ -std=c++17 -O1 -g -fsanitize=thread -fno-omit-frame-pointer -pthread -o $W/check_tsan $W/main.cpp \
-  seqset.cpp lcs_source.cpp trees.cpp fasttree.cpp pipeline.cpp capi.cpp -L.. -llcsgpu -Wl,-rpath,$ROOT/famsa_amd
+  seqset.cpp lcs_source.cpp trees.cpp fasttree.cpp pipeline.cpp capi.cpp -L.. -llcsgpu -lz -Wl,-rpath,$ROOT/famsa_amd
 for n in hemo dup; do FAMSA_HOST_THREADS=6 $W/check_tsan $W/$n.fasta $W/$n.mat 2>&1 | grep -E "WARNING: ThreadSanitizer|asan ok" | sed 's/asan ok/tsan ok/'; done

@@ -98,11 +98,15 @@ class Host:
     def records(self, fasta, n_threads=0):
         """(ids, [code arrays]) as the FASTA reader delivers them."""
         size = os.path.getsize(fasta) + 16
-        ids = C.create_string_buffer(size)
-        codes = np.zeros(size, np.uint8)
-        offs = np.zeros(size // 2 + 2, np.uint64)
-        n = self.lib.famsa_host_records(fasta.encode(), n_threads, ids, size, codes.ctypes.data, size,
-                                        offs.ctypes.data, len(offs))
+        for attempt in range(4):  # a compressed file needs more room than its size on disk
+            ids = C.create_string_buffer(size)
+            codes = np.zeros(size, np.uint8)
+            offs = np.zeros(size // 2 + 2, np.uint64)
+            n = self.lib.famsa_host_records(fasta.encode(), n_threads, ids, size, codes.ctypes.data, size,
+                                            offs.ctypes.data, len(offs))
+            if n >= 0 or b"buffer too small" not in self.lib.famsa_host_last_error():
+                break
+            size *= 8
         if n < 0:
             raise self._err()
         names = ids.value.decode("latin-1").split("\n")[:-1] if n else []

@@ -247,3 +247,28 @@ def test_parallel_fasta_reader_matches_the_serial_semantics(host, oracle, tmp_pa
         ref.close(h)
         assert len(rc) == len(codes)
         assert all((a == b).all() for a, b in zip(rc, codes))
+
+
+def test_gzip_input_is_read_like_plain_text(host, tmp_path):
+    """A .gz input (one member, or several concatenated members as bgzip writes them) gives the same records."""
+    import gzip
+    rng = np.random.Generator(np.random.PCG64(43))
+    alpha = np.frombuffer(b"ARNDCQEGHILKMFPSTWYV", dtype=np.uint8)
+    parts = []
+    for i in range(6000):
+        parts.append(b">g%d\n" % i + alpha[rng.integers(0, 20, size=int(rng.integers(5, 600)))].tobytes() + b"\n")
+    raw = b"".join(parts)
+    plain, one, many = (str(tmp_path / n) for n in ("p.fasta", "one.fasta.gz", "many.fasta.gz"))
+    open(plain, "wb").write(raw)
+    open(one, "wb").write(gzip.compress(raw))
+    cut = [0, len(raw) // 3, 2 * len(raw) // 3 + 11, len(raw)]  # member borders inside records
+    open(many, "wb").write(b"".join(gzip.compress(raw[a:b]) for a, b in zip(cut, cut[1:])))
+    want_ids, want_codes = host.records(plain, 3)
+    for path in (one, many):
+        ids, codes = host.records(path, 3)
+        assert ids == want_ids
+        assert all((a == b).all() for a, b in zip(codes, want_codes)) and len(codes) == len(want_codes)
+    bad = str(tmp_path / "bad.fasta.gz")
+    open(bad, "wb").write(gzip.compress(raw)[: 5000])
+    with pytest.raises(RuntimeError):
+        host.records(bad, 2)
