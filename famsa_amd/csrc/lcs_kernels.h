@@ -1,4 +1,4 @@
-// lcs_kernels.h -- internal interface between the C-ABI layer (lcsgpu_api.hip) and the
+// lcs_kernels.h -- internal interface between the C-ABI layer (lcsgpu_api / _trees / _fasttree .hip) and the
 // gfx950 kernels (lcs_kernels.hip).  Not installed; the public boundary is include/lcsgpu.h.
 #pragma once
 #include <hip/hip_runtime.h>

@@ -1,0 +1,215 @@
+// lcsgpu_internal.h -- shared between the translation units of liblcsgpu.so (not installed):
+// the context, its lanes, error reporting, launch planning entry points.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <cmath>
+#include <condition_variable>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <mutex>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "../../include/lcsgpu.h"
+#include "lcs_kernels.h"
+
+namespace lcsgpu_impl {
+
+// thread-local error text of lcsgpu_last_error(); returns `code`
+int fail(int code, const char* fmt, ...);
+
+#define HIP_TRY(expr)                                                                           \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess)                                                                   \
+            return fail(LCSGPU_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),    \
+                        __FILE__, __LINE__);                                                    \
+    } while (0)
+
+// grow-only device / pinned-host buffers
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t n)
+    {
+        if (n <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = n + n / 4 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+struct PinBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t n)
+    {
+        if (n <= cap) return hipSuccess;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = n + n / 4 + 256;
+        hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release()
+    {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+} // namespace lcsgpu_impl
+
+// A lane = one HIP stream with its own staging / result buffers.  Host-memory calls (rect,
+// triangle, triangle over ids) take any free lane, so several host threads -- the reference runs
+// one CLCSBP per worker thread -- get their small LCS requests executed concurrently instead of
+// queueing behind one stream; device-memory calls and the tree reducers always use lane 0, whose
+// stream is the one lcsgpu_stream() hands out.
+struct Lane {
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    hipEvent_t ev_done = nullptr; // blocking-sync event: host-memory calls sleep on it instead of spinning
+    lcsgpu_impl::DevBuf d_plan, d_out, d_carry;
+    lcsgpu_impl::DevBuf d_work, d_draws; // CLARANS state and its pre-drawn step positions
+    lcsgpu_impl::PinBuf h_plan, h_small;
+    bool plan_in_flight = false;
+    int last_launches = 0;
+    bool timing_valid = false;
+    bool busy = false;
+};
+
+
+// Local searches of several host threads advanced together (lcs_kernels.h, ClaransBatch): every
+// search joins with its device state ready; whichever owner finds no driver becomes the driver and
+// enqueues the rounds for ALL joined searches, looking at their done flags every `rounds_per_look`
+// rounds; a driver whose own search has finished hands the role to one of the remaining owners.
+struct ClaransJob {
+    lcsgpu::ClaransArgs a;
+    std::mt19937* gen_positions = nullptr; // the owner's position generator (Clustering.cpp:44)
+    std::vector<int32_t>* draws = nullptr; // its output so far, as accepted draws
+    lcsgpu_impl::DevBuf* d_draws = nullptr;
+    int32_t p_host = 0;
+    int32_t state[16] = {0};
+    bool done = false;
+    int rc = LCSGPU_OK;
+    std::string error;
+};
+struct ClaransBatcher {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<ClaransJob*> joined;
+    bool driver_present = false;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev = nullptr;
+    lcsgpu_impl::PinBuf h_states;
+    // LCSGPU_PROFILE: looks and seconds by number of searches in the batch
+    long prof_looks[lcsgpu::CLARANS_MAX_BATCH + 1] = {0};
+    double prof_seconds[lcsgpu::CLARANS_MAX_BATCH + 1] = {0};
+};
+
+struct lcsgpu_ctx {
+    int device = 0;
+    std::mutex mu; // guards the lane table
+    std::condition_variable cv;
+    std::vector<Lane> lanes;
+
+    // uploaded set (read-only while any lane is busy)
+    int32_t n = -1;
+    uint32_t max_len = 0;
+    std::vector<uint32_t> lens;
+    std::vector<uint8_t> quirk; // ref needs the literal (V2 < V) carry rule
+    lcsgpu_impl::DevBuf d_tiles, d_tile_base, d_lens, d_pow, d_powf;
+
+    // scratch of the lane-0 tree reducers
+    lcsgpu_impl::DevBuf d_prim, d_qrows, d_qcols, d_dist;
+    double total_kernel_ms = 0; // completed host-memory calls
+    // searches are spread over a few independent batches (each its own stream and driver): rounds of
+    // different batches overlap on the GPU, which hides part of a round's memory latency
+    std::vector<ClaransBatcher> clarans_groups;
+    std::atomic<unsigned> clarans_next{0};
+};
+
+namespace lcsgpu_impl {
+
+struct LastCall { // timing of this thread's most recent call, for lcsgpu_last_kernel_ms
+    lcsgpu_ctx* ctx = nullptr;
+    bool pending_on_lane0 = false;
+    double ms = 0;
+    int launches = 0;
+};
+extern thread_local LastCall g_last;
+
+// RAII ownership of one lane (index 0 on request, else any free one) or of all lanes.
+class LaneGuard {
+public:
+    enum Which { ANY, LANE0, ALL };
+    LaneGuard(lcsgpu_ctx* ctx, Which which) : ctx_(ctx), which_(which)
+    {
+        std::unique_lock<std::mutex> lk(ctx->mu);
+        if (which == ALL) {
+            ctx->cv.wait(lk, [&] {
+                for (auto& l : ctx->lanes) if (l.busy) return false;
+                return true;
+            });
+            for (auto& l : ctx->lanes) l.busy = true;
+            idx_ = 0;
+        } else if (which == LANE0) {
+            ctx->cv.wait(lk, [&] { return !ctx->lanes[0].busy; });
+            ctx->lanes[0].busy = true;
+            idx_ = 0;
+        } else {
+            ctx->cv.wait(lk, [&] {
+                for (size_t i = ctx->lanes.size(); i-- > 0;) // prefer the higher lanes, keep lane 0 free
+                    if (!ctx->lanes[i].busy) { idx_ = (int)i; return true; }
+                return false;
+            });
+            ctx->lanes[idx_].busy = true;
+        }
+    }
+    ~LaneGuard()
+    {
+        {
+            std::lock_guard<std::mutex> lk(ctx_->mu);
+            if (which_ == ALL) for (auto& l : ctx_->lanes) l.busy = false;
+            else ctx_->lanes[idx_].busy = false;
+        }
+        ctx_->cv.notify_all();
+    }
+    Lane& lane() { return ctx_->lanes[idx_]; }
+
+private:
+    lcsgpu_ctx* ctx_;
+    Which which_;
+    int idx_ = 0;
+};
+
+// Core: plan + launch.  d_out is a device pointer.
+int run_rows(lcsgpu_ctx* ctx, Lane& L, int mode, const int32_t* ref_ids, int32_t ref_begin, int32_t n_refs,
+             const int32_t* col_ids, int32_t col_begin, int32_t n_cols, void* d_out, int64_t ld,
+             int64_t out_offset, int elem_size, int64_t first_row = 0);
+// After a host-memory call has been synchronised: account its kernel time.
+void finish_host_call(lcsgpu_ctx* ctx, Lane& L);
+// A *_dev call was queued on lane 0: its timing is read on demand.
+void note_async_call(lcsgpu_ctx* ctx);
+
+} // namespace lcsgpu_impl
