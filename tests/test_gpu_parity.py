@@ -369,3 +369,45 @@ def test_degenerate_set_sizes(engine, oracle):
     assert list(tri) == [oracle.lcs(b, a), 0, 0]
     e = engine.mst_prim(1)
     assert len(e) == 2 and {(int(x["from"]), int(x["to"])) for x in e} <= {(0, 1), (0, 2), (1, 2)}
+
+
+def test_sets_with_a_sequence_beyond_65535_residues(engine, oracle):
+    """One member longer than 65535 residues switches every result to 32-bit elements: the same calls,
+    the uint32 instantiations of the consumers (batched triangles, seed assignment, CLARANS distances)."""
+    import famsa_amd
+    rng = np.random.Generator(np.random.PCG64(31))
+    lens = [int(x) for x in rng.integers(30, 260, size=40)] + [66000]
+    seqs = [rng.integers(0, 20, size=l).astype(np.uint8) for l in lens]
+    seqs[-1][: lens[3]] = seqs[3]  # give the giant something in common with a short one
+    engine.upload_seqs(seqs)
+    codes, offsets = seqio.pack(seqs)
+    n = len(seqs)
+    ids = np.arange(n, dtype=np.int32)
+    want = oracle.rect(codes, offsets, ids, ids)
+    got = engine.lcs_rect(ids, ids, dtype=np.uint32)
+    assert (got == want).all()
+    assert want[n - 1, n - 1] == 66000
+    with pytest.raises(famsa_amd.LcsGpuError):
+        engine.lcs_rect(ids, ids, dtype=np.uint16)  # 16-bit results cannot hold this set's values
+    groups = [np.array([n - 1, 3, 7, 1], np.int32), np.arange(10, dtype=np.int32), np.array([5, n - 1], np.int32)]
+    tri = engine.lcs_triangles_batch(groups, dtype=np.uint32)
+    for g, gi in zip(tri, groups):
+        assert (g == want[np.ix_(gi, gi)][np.tril_indices(len(gi), -1)]).all()
+    # seed assignment and CLARANS read the same 32-bit rectangle / triangle on the device
+    seeds = np.array([n - 1, 4, 9], np.int32)
+    fn = oracle.lib.oracle_dist_indel075_f32
+    d0 = np.array([fn(int(want[0, c]), lens[0], lens[c]) for c in ids], np.float32)
+    wd, wa = d0.copy(), np.zeros(n, np.int32)
+    for r, s in enumerate(seeds):
+        for c in ids:
+            d = np.float32(fn(int(want[s, c]), lens[s], lens[c]))
+            if d < wd[c]:
+                wd[c], wa[c] = d, 1 + r
+    gd, ga = d0.copy(), np.zeros(n, np.int32)
+    engine.assign_seeds(seeds, ids, gd, ga)
+    assert (ga == wa).all() and (gd.view(np.uint32) == wd.view(np.uint32)).all()
+    import host_bind
+    sub = np.array([n - 1] + list(range(30)), np.int32)
+    lcs_tri = want[np.ix_(sub, sub)][np.tril_indices(len(sub), -1)]
+    dist = oracle.dist_triangle_f32(lcs_tri, np.array([lens[i] for i in sub], np.uint32), 1)
+    assert engine.clarans(sub, 4).tolist() == host_bind.Host().clarans(dist, len(sub), 4).tolist()
