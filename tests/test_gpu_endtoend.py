@@ -145,3 +145,21 @@ def test_device_upgma_on_tie_heavy_inputs(host, tmp_path, gt):
             want = host.tree_from_matrix(fasta, sq, gt, distance=dist)   # host algorithm over oracle LCS
             got = host.tree_gpu(fasta, gt, distance=dist)                # LCS + UPGMA on the device
             assert got == want, (seed, dist)
+
+
+@pytest.mark.parametrize("gt", ["sl", "slink", "upgma", "nj"])
+def test_trees_of_a_set_with_a_giant_sequence(host, oracle, tmp_path, gt):
+    """One member beyond 65535 residues: the device reducers run on 32-bit LCS values.  Expected tree =
+    the same host layer fed with the oracle's matrix (the CPU suite pins that path to the reference)."""
+    import numpy as np
+    rng = np.random.Generator(np.random.PCG64(37))
+    lens = [int(x) for x in rng.integers(40, 300, size=60)] + [66500]
+    seqs = [rng.integers(0, 20, size=l).astype(np.uint8) for l in lens]
+    for i in range(0, 60, 7):
+        seqs[-1][i * 300: i * 300 + lens[i]] = seqs[i]  # the giant shares pieces with some members
+    codes, offsets = seqio.pack(seqs)
+    fasta = str(tmp_path / "giant.fasta")
+    seqio.to_fasta(codes, offsets, fasta)
+    ids = np.arange(len(seqs), dtype=np.int32)
+    square = oracle.rect(codes, offsets, ids, ids)
+    assert host.tree_gpu(fasta, gt) == host.tree_from_matrix(fasta, square, gt)
