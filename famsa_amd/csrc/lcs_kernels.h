@@ -98,6 +98,27 @@ struct PrimArgs {
 };
 hipError_t launch_prim(const PrimArgs& a, int elem_size, hipStream_t stream);
 
+// ---- MST by Boruvka rounds over the triangle (mst_kernels.hip) ----
+struct BoruvkaArgs {
+    const void* tri;            // lower triangle of LCS lengths, ref = larger id
+    const uint32_t* lens;
+    const double* pow_table;
+    int32_t* comp;              // [n] component (= id of its root vertex) of every vertex
+    int32_t* comp_next;         // [n] ... after this round
+    int32_t* parent;            // [n] hooking forest over the component roots
+    unsigned long long* best_d; // [n] best edge of every vertex to another component: distance bits ...
+    unsigned long long* best_id; //     ... and ~pack(min id, max id)
+    unsigned long long* cb_d;   // [n] the same per component (indexed by root)
+    unsigned long long* cb_id;
+    unsigned long long* part_d; // [n_chunks][n] column-pass partials
+    unsigned long long* part_id;
+    MstEdge* edges;             // [n-1] in the order the rounds find them
+    int32_t* counters;          // [0] edges recorded
+    int32_t n, kind, n_chunks, rows_per_chunk;
+};
+hipError_t launch_boruvka_init(const BoruvkaArgs& a, hipStream_t stream);
+hipError_t launch_boruvka_round(const BoruvkaArgs& a, int elem_size, hipStream_t stream);
+
 // ---- device-side UPGMA (tree_kernels.hip) ----
 struct UpgmaArgs {
     float* D;             // float distance triangle (updated in place)

@@ -2,6 +2,8 @@
 // per-row minima: the LCS triangle stays in HBM, the kernels of tree_kernels.hip consume it there.
 #include "lcsgpu_internal.h"
 
+#include <queue>
+
 using namespace lcsgpu_impl;
 
 extern "C" {
@@ -63,6 +65,91 @@ int lcsgpu_mst_prim(lcsgpu_ctx* ctx, int distance_kind, lcsgpu_mst_edge* out_edg
         L.plan_in_flight = false;
         rc = run_rows(ctx, L, lcsgpu::MODE_RECT, nullptr, 0, n, qlist.data(), 0, nq, ctx->d_qcols.p, nq, 0, 4);
         if (rc) return rc;
+    }
+
+    if ((triangle_orientation || nq == 0) && !getenv("LCSGPU_MST_PRIM")) {
+        // distances do not depend on which endpoint is the ref: Boruvka rounds over the triangle, then
+        // Prim's insertion order from vertex 0 as a walk over the n-1 tree edges
+        auto a256 = [](size_t x) { return (x + 255) & ~(size_t)255; };
+        const int n_chunks = std::max(1, std::min(32, (n + 1023) / 1024));
+        const int rows_per_chunk = (n + n_chunks - 1) / n_chunks;
+        const size_t o_comp = 0, o_next = o_comp + a256((size_t)n * 4), o_par = o_next + a256((size_t)n * 4),
+                     o_bd = o_par + a256((size_t)n * 4), o_bi = o_bd + a256((size_t)n * 8), o_cd = o_bi + a256((size_t)n * 8),
+                     o_ci = o_cd + a256((size_t)n * 8), o_pd = o_ci + a256((size_t)n * 8),
+                     o_pi = o_pd + a256((size_t)n_chunks * n * 8), o_edges = o_pi + a256((size_t)n_chunks * n * 8),
+                     o_cnt = o_edges + a256((size_t)(n - 1) * sizeof(lcsgpu::MstEdge)), total = o_cnt + 256;
+        HIP_TRY(ctx->d_prim.reserve(total));
+        char* base = (char*)ctx->d_prim.p;
+        lcsgpu::BoruvkaArgs b{};
+        b.tri = L.d_out.p;
+        b.lens = (const uint32_t*)ctx->d_lens.p;
+        b.pow_table = (const double*)ctx->d_pow.p;
+        b.comp = (int32_t*)(base + o_comp);
+        b.comp_next = (int32_t*)(base + o_next);
+        b.parent = (int32_t*)(base + o_par);
+        b.best_d = (unsigned long long*)(base + o_bd);
+        b.best_id = (unsigned long long*)(base + o_bi);
+        b.cb_d = (unsigned long long*)(base + o_cd);
+        b.cb_id = (unsigned long long*)(base + o_ci);
+        b.part_d = (unsigned long long*)(base + o_pd);
+        b.part_id = (unsigned long long*)(base + o_pi);
+        b.edges = (lcsgpu::MstEdge*)(base + o_edges);
+        b.counters = (int32_t*)(base + o_cnt);
+        b.n = n;
+        b.kind = distance_kind;
+        b.n_chunks = n_chunks;
+        b.rows_per_chunk = rows_per_chunk;
+        HIP_TRY(lcsgpu::launch_boruvka_init(b, L.stream));
+        int32_t found = 0;
+        for (int round = 0; found < n - 1; ++round) {
+            if (round > 40) return fail(LCSGPU_E_STATE, "MST: the Boruvka rounds do not converge");
+            HIP_TRY(lcsgpu::launch_boruvka_round(b, elem, L.stream));
+            std::swap(b.comp, b.comp_next);
+            const int32_t before = found;
+            HIP_TRY(hipMemcpyAsync(&found, b.counters, 4, hipMemcpyDeviceToHost, L.stream));
+            HIP_TRY(hipStreamSynchronize(L.stream));
+            L.plan_in_flight = false;
+            if (found <= before) return fail(LCSGPU_E_STATE, "MST: a Boruvka round added no edge");
+        }
+        std::vector<lcsgpu::MstEdge> tree((size_t)n - 1);
+        HIP_TRY(hipMemcpy(tree.data(), b.edges, tree.size() * sizeof(lcsgpu::MstEdge), hipMemcpyDeviceToHost));
+        // Prim from vertex 0 over the tree, edges ordered like MSTPrim's keys: (d, ~pack(min, max))
+        std::vector<int32_t> head((size_t)n + 1, 0), adj((size_t)2 * (n - 1));
+        for (const auto& e : tree) { ++head[e.from + 1]; ++head[e.to + 1]; }
+        for (int32_t v = 0; v < n; ++v) head[v + 1] += head[v];
+        {
+            std::vector<int32_t> fill(head.begin(), head.end() - 1);
+            for (int32_t k = 0; k < n - 1; ++k) { adj[fill[tree[k].from]++] = k; adj[fill[tree[k].to]++] = k; }
+        }
+        struct Cand {
+            double d;
+            uint64_t id;
+            int32_t edge, to;
+            bool operator>(const Cand& o) const { return d > o.d || (d == o.d && id > o.id); }
+        };
+        std::priority_queue<Cand, std::vector<Cand>, std::greater<Cand>> heap;
+        std::vector<char> in_tree(n, 0);
+        auto visit = [&](int32_t v) {
+            in_tree[v] = 1;
+            for (int32_t k = head[v]; k < head[v + 1]; ++k) {
+                const lcsgpu::MstEdge& e = tree[adj[k]];
+                const int32_t w = e.from == v ? e.to : e.from;
+                if (!in_tree[w]) heap.push(Cand{e.dist, ~(((uint64_t)(uint32_t)e.from << 32) + (uint32_t)e.to), adj[k], w});
+            }
+        };
+        visit(0);
+        for (int32_t k = 0; k < n - 1; ++k) {
+            while (!heap.empty() && in_tree[heap.top().to]) heap.pop();
+            if (heap.empty()) return fail(LCSGPU_E_STATE, "MST: the edges found do not span the set");
+            const Cand c = heap.top();
+            heap.pop();
+            out_edges[k].from = tree[c.edge].from;
+            out_edges[k].to = tree[c.edge].to;
+            out_edges[k].dist = tree[c.edge].dist;
+            visit(c.to);
+        }
+        note_async_call(ctx);
+        return LCSGPU_OK;
     }
 
     const int blocks = (n + 255) / 256;

@@ -155,9 +155,11 @@ typedef struct lcsgpu_mst_edge {
     double dist;      /* Transform<double, kind> of the pair, ref = the endpoint that was in the tree */
 } lcsgpu_mst_edge;
 
-/* Prim's MST over the complete graph of the uploaded set, entirely on the device: the LCS
- * triangle is computed into HBM, then n-1 relaxation steps run over it (one launch per step).
- * out_edges (HOST, n-1 records) receives the edges in the order they are added, starting from
+/* Prim's MST over the complete graph of the uploaded set: the LCS triangle is computed into HBM and
+ * the tree is built there -- by Boruvka rounds over the triangle when distances do not depend on the
+ * ref / partner roles (the edge order below is strict and total, so the tree is unique whatever the
+ * algorithm), else by n-1 relaxation steps (one launch per step).
+ * out_edges (HOST, n-1 records) receives the edges in the order Prim adds them, starting from
  * vertex 0.  Semantics are those of MSTPrim::run_view (tree/MSTPrim.cpp:280-549): distance
  * d(cur, v) uses LCS(ref = cur, partner = v); keys are (d, ~((uint64)min(cur,v) << 32 | max(cur,v)))
  * compared lexicographically (mst_edge_t / dist_t, tree/MSTPrim.h:424-483), so the tree and the

@@ -411,3 +411,33 @@ def test_sets_with_a_sequence_beyond_65535_residues(engine, oracle):
     lcs_tri = want[np.ix_(sub, sub)][np.tril_indices(len(sub), -1)]
     dist = oracle.dist_triangle_f32(lcs_tri, np.array([lens[i] for i in sub], np.uint32), 1)
     assert engine.clarans(sub, 4).tolist() == host_bind.Host().clarans(dist, len(sub), 4).tolist()
+
+
+@pytest.mark.parametrize("shape", ["ties", "family", "tiny"])
+def test_boruvka_mst_equals_the_prim_kernel(engine, monkeypatch, shape):
+    """lcsgpu_mst_prim builds the tree by Boruvka rounds when distances are orientation free and orders the
+    edges by a Prim walk over the tree: same edges, same order, same distances as the step-by-step Prim
+    kernel (which the oracle's recurrence pins, test_device_prim_edges_vs_reference_recurrence)."""
+    rng = np.random.Generator(np.random.PCG64(53))
+    if shape == "ties":
+        seqs = [rng.integers(0, 3, size=int(rng.integers(3, 12))).astype(np.uint8) for _ in range(1500)]
+    elif shape == "family":
+        anc = rng.integers(0, 20, size=200, dtype=np.uint8)
+        seqs = []
+        for _ in range(3000):
+            s = anc.copy()
+            m = rng.random(200) < 0.2
+            s[m] = rng.integers(0, 20, size=int(m.sum()), dtype=np.uint8)
+            seqs.append(s[: int(rng.integers(120, 201))].copy())
+    else:
+        seqs = [rng.integers(0, 20, size=int(rng.integers(5, 40))).astype(np.uint8) for _ in range(3)]
+    engine.upload_seqs(seqs)
+    assert engine.orientation_flags().sum() == 0
+    for kind in (0, 1, 1 | 0x100):
+        monkeypatch.delenv("LCSGPU_MST_PRIM", raising=False)
+        fast = engine.mst_prim(kind)
+        monkeypatch.setenv("LCSGPU_MST_PRIM", "1")
+        slow = engine.mst_prim(kind)
+        monkeypatch.delenv("LCSGPU_MST_PRIM", raising=False)
+        assert (fast["from"] == slow["from"]).all() and (fast["to"] == slow["to"]).all()
+        assert (fast["dist"].view(np.uint64) == slow["dist"].view(np.uint64)).all()
