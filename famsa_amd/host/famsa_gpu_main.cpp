@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstring>
 #include <chrono>
+#include <cstdlib>
 #include <fstream>
 #include <iostream>
 #include <stdexcept>
@@ -118,14 +119,18 @@ int main(int argc, char** argv)
         auto since = [](std::chrono::steady_clock::time_point a) {
             return std::chrono::duration<double>(std::chrono::steady_clock::now() - a).count();
         };
+        // the engine wants one hardware queue per lane (lcsgpu_create sets this too, but the environment must not
+        // be modified once other threads run)
+        setenv("GPU_MAX_HW_QUEUES", getenv("LCSGPU_LANES") ? getenv("LCSGPU_LANES") : "16", 0);
+        EngineFuture engine = start_engine(device); // HIP initialisation runs while the input is read and sorted
         SeqSet s = load_fasta(input, n_threads);
         if (s.size() == 0) throw std::runtime_error("no sequences in " + input);
         Timings t;
         t.load_s = since(clock0);
         if (export_dist) {
-            dist_export_gpu(s, device, opt.dist, square, pid, output, &t);
+            dist_export_gpu(s, device, opt.dist, square, pid, output, &t, &engine);
         } else {
-            const std::string nwk = guide_tree_newick_gpu(s, device, opt, &t);
+            const std::string nwk = guide_tree_newick_gpu(s, device, opt, &t, &engine);
             const auto clock1 = std::chrono::steady_clock::now();
             std::ofstream f(output, std::ios::binary);
             if (!f.good()) throw std::runtime_error("cannot open " + output);

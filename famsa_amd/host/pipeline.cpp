@@ -56,8 +56,18 @@ std::string guide_tree_newick_from_matrix(const SeqSet& s, const uint32_t* sq, c
     return guide_tree_newick(s, w, src, opt);
 }
 
-std::string guide_tree_newick_gpu(const SeqSet& s, int device, const TreeOptions& opt, Timings* t)
+EngineFuture start_engine(int device)
 {
+    return std::async(std::launch::async, [device] { return std::make_unique<GpuLcsSource>(device); });
+}
+
+std::string guide_tree_newick_gpu(const SeqSet& s, int device, const TreeOptions& opt, Timings* t, EngineFuture* engine)
+{
+    EngineFuture own;
+    if (!engine) {
+        own = start_engine(device);
+        engine = &own;
+    }
     double t0 = now_s();
     WorkSet w = make_workset(s, opt.keep_duplicates, opt.fast.n_threads);
     std::vector<int> in_of(w.n_unique());
@@ -66,7 +76,8 @@ std::string guide_tree_newick_gpu(const SeqSet& s, int device, const TreeOptions
     std::vector<uint64_t> offsets;
     pack(s, in_of, codes, offsets, opt.fast.n_threads);
     double t1 = now_s();
-    GpuLcsSource src(device);
+    std::unique_ptr<GpuLcsSource> held = engine->get(); // waits only for what the sort did not cover
+    GpuLcsSource& src = *held;
     double t1b = now_s();
     src.upload(codes, offsets);
     double t2 = now_s();
@@ -81,10 +92,16 @@ std::string guide_tree_newick_gpu(const SeqSet& s, int device, const TreeOptions
 }
 
 void dist_export_gpu(const SeqSet& s, int device, Distance dist, bool square, bool pid, const std::string& path,
-                     Timings* t)
+                     Timings* t, EngineFuture* engine)
 {
+    EngineFuture own;
+    if (!engine) {
+        own = start_engine(device);
+        engine = &own;
+    }
     double t1 = now_s();
-    GpuLcsSource src(device);
+    std::unique_ptr<GpuLcsSource> held = engine->get();
+    GpuLcsSource& src = *held;
     src.upload(s.codes, s.offsets); // input order, no sort, no dedup: the set as it was read
     double t2 = now_s();
     write_distance_csv(src, s.ids, dist, square, pid, path);

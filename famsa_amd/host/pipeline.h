@@ -2,6 +2,8 @@
 // guide-tree generators: working order, duplicate removal, generator call, fromUnique, Newick;
 // and the -dist_export early branch (msa.cpp:518-526: input order, no sort, no dedup).
 #pragma once
+#include <future>
+#include <memory>
 #include <string>
 
 #include "lcs_source.h"
@@ -29,8 +31,13 @@ std::string guide_tree_newick(const SeqSet& s, const WorkSet& w, LcsSource& src_
                               Timings* t = nullptr);
 
 std::string guide_tree_newick_from_matrix(const SeqSet& s, const uint32_t* square_input_order, const TreeOptions& opt);
-std::string guide_tree_newick_gpu(const SeqSet& s, int device, const TreeOptions& opt, Timings* t);
+// The engine context takes ~0.2 s to create (HIP initialisation): a caller may start that early, on another
+// thread, and hand the future in; otherwise it is started here, next to the sort.
+using EngineFuture = std::future<std::unique_ptr<GpuLcsSource>>;
+EngineFuture start_engine(int device);
+std::string guide_tree_newick_gpu(const SeqSet& s, int device, const TreeOptions& opt, Timings* t,
+                                  EngineFuture* engine = nullptr);
 void dist_export_gpu(const SeqSet& s, int device, Distance dist, bool square, bool pid, const std::string& path,
-                     Timings* t);
+                     Timings* t, EngineFuture* engine = nullptr);
 
 } // namespace famsa_host
