@@ -125,9 +125,11 @@ struct UpgmaArgs {
     float* min_dist;      // [n]
     uint32_t* nearest;    // [n]
     uint32_t* node_index; // [n]
-    float* part_d;        // [n_blocks] per-workgroup minima of the last update
+    float* part_d;        // [2][n_blocks] per-workgroup minima of the new row, alternating between merges
     uint32_t* part_j;
-    uint32_t* sel;        // [0] Lmin, [1] Rmin, [2] error flag
+    float* bm_d;          // [n_blocks] first minimum of min_dist over each workgroup's 256 rows
+    uint32_t* bm_j;
+    uint32_t* sel;        // [2][4] (Lmin, Rmin) of the merges, alternating; [8] error flag
     int32_t* left;        // [n-1] children of the internal nodes
     int32_t* right;
     int32_t n;

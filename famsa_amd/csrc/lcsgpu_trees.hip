@@ -207,13 +207,16 @@ int lcsgpu_upgma(lcsgpu_ctx* ctx, int distance_kind, int modified, int32_t* out_
     const int blocks = (n + 255) / 256;
     auto a16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
     const size_t o_min = 0, o_near = o_min + a16((size_t)n * 4), o_node = o_near + a16((size_t)n * 4),
-                 o_pd = o_node + a16((size_t)n * 4), o_pj = o_pd + a16((size_t)blocks * 4),
-                 o_sel = o_pj + a16((size_t)blocks * 4), o_left = o_sel + 16, o_right = o_left + a16((size_t)n * 4),
+                 o_pd = o_node + a16((size_t)n * 4), o_pj = o_pd + a16((size_t)2 * blocks * 4),
+                 o_bd = o_pj + a16((size_t)2 * blocks * 4), o_bj = o_bd + a16((size_t)blocks * 4),
+                 o_sel = o_bj + a16((size_t)blocks * 4), o_left = o_sel + 48, o_right = o_left + a16((size_t)n * 4),
                  total = o_right + a16((size_t)n * 4);
     HIP_TRY(ctx->d_prim.reserve(total));
     char* base = (char*)ctx->d_prim.p;
-    HIP_TRY(hipMemsetAsync(base + o_sel, 0, 16, L.stream));
+    HIP_TRY(hipMemsetAsync(base + o_sel, 0, 48, L.stream));
     lcsgpu::UpgmaArgs a{};
+    a.bm_d = (float*)(base + o_bd);
+    a.bm_j = (uint32_t*)(base + o_bj);
     a.D = (float*)ctx->d_dist.p;
     a.min_dist = (float*)(base + o_min);
     a.nearest = (uint32_t*)(base + o_near);
@@ -227,13 +230,13 @@ int lcsgpu_upgma(lcsgpu_ctx* ctx, int distance_kind, int modified, int32_t* out_
     a.n_blocks = blocks;
     HIP_TRY(lcsgpu::launch_upgma(a, L.d_out.p, elem, (const uint32_t*)ctx->d_lens.p, (const float*)ctx->d_powf.p,
                                  distance_kind, modified != 0, L.stream));
-    uint32_t sel[4] = {0, 0, 0, 0};
+    uint32_t sel[12] = {0};
     HIP_TRY(hipMemcpyAsync(out_left, a.left, (size_t)(n - 1) * 4, hipMemcpyDeviceToHost, L.stream));
     HIP_TRY(hipMemcpyAsync(out_right, a.right, (size_t)(n - 1) * 4, hipMemcpyDeviceToHost, L.stream));
-    HIP_TRY(hipMemcpyAsync(sel, a.sel, 16, hipMemcpyDeviceToHost, L.stream));
+    HIP_TRY(hipMemcpyAsync(sel, a.sel, 48, hipMemcpyDeviceToHost, L.stream));
     HIP_TRY(hipStreamSynchronize(L.stream));
     L.plan_in_flight = false;
-    if (sel[2])
+    if (sel[8])
         return fail(LCSGPU_E_INVALID, "UPGMA: no finite nearest neighbour (a pair with LCS 0?) -- the reference's "
                                       "algorithm is undefined for this input");
     note_async_call(ctx);

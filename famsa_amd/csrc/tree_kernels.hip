@@ -171,11 +171,10 @@ hipError_t launch_prim(const PrimArgs& a, int elem_size, hipStream_t stream)
 // Device-side UPGMA over the resident triangle: the nearest-neighbour-array formulation the
 // reference took from MUSCLE (tree/UPGMA.cpp:114-295), kept operation for operation because its
 // tie rules (strict '<' in ascending scans => the smallest index wins) and its deliberately stale
-// row minima decide the topology.  n-1 sequential merges, two small launches per merge:
-//   upgma_select_kernel (1 workgroup): apply the previous merge's row statistics, then pick
-//                                      Lmin = argmin_j min_dist[j] (first minimum), Rmin = nearest[Lmin]
-//   upgma_update_kernel (n/256 workgroups): D[Lmin,j] = average(D[Lmin,j], D[Rmin,j]) for every
-//                                      active j, nearest-pointer rename, per-workgroup new minimum
+// row minima decide the topology.  n-1 sequential merges, one launch per merge (upgma_step_kernel):
+// apply the previous merge's row statistics, pick Lmin = argmin_j min_dist[j] (first minimum) and
+// Rmin = nearest[Lmin], then D[Lmin,j] = average(D[Lmin,j], D[Rmin,j]) for every active j with the
+// nearest-pointer rename and the per-workgroup minimum of the new row.
 // Distances are float, produced on the device from the LCS triangle with the reference's
 // Transform<float,...>: a host-built (float)pow(indel,0.75) table and IEEE float division.
 // =============================================================================================
@@ -242,55 +241,16 @@ __global__ __launch_bounds__(256) void upgma_init_kernel(UpgmaArgs a)
     }
 }
 
-__global__ __launch_bounds__(1024) void upgma_select_kernel(UpgmaArgs a, int it)
+// (value, index) minimum of a workgroup: smaller value, then smaller index; values >= UPGMA_BIG never win
+// against the (UPGMA_BIG, UPGMA_NONE) start ("dtDist < dtMinDist" from BIG_DIST in the reference)
+__device__ __forceinline__ void block_first_min(float& d, uint32_t& j, float* s_d, uint32_t* s_j)
 {
-    __shared__ float s_d[1024];
-    __shared__ uint32_t s_j[1024];
     const int tid = threadIdx.x;
-    // ---- finish merge it-1: statistics of the row that now holds the new cluster ----
-    if (it > 0) {
-        float bd = UPGMA_BIG;
-        uint32_t bj = UPGMA_NONE;
-        for (int b = tid; b < a.n_blocks; b += 1024) {
-            const float d = a.part_d[b];
-            const uint32_t j = a.part_j[b];
-            if (d < bd || (d == bd && j < bj)) { bd = d; bj = j; }
-        }
-        s_d[tid] = bd;
-        s_j[tid] = bj;
-        __syncthreads();
-        for (int s = 512; s > 0; s >>= 1) {
-            if (tid < s) {
-                const float d2 = s_d[tid + s];
-                const uint32_t j2 = s_j[tid + s];
-                if (d2 < s_d[tid] || (d2 == s_d[tid] && j2 < s_j[tid])) { s_d[tid] = d2; s_j[tid] = j2; }
-            }
-            __syncthreads();
-        }
-        if (tid == 0) {
-            const uint32_t L = a.sel[0], R = a.sel[1];
-            a.left[it - 1] = (int32_t)a.node_index[L];
-            a.right[it - 1] = (int32_t)a.node_index[R];
-            a.node_index[L] = (uint32_t)a.n + (uint32_t)(it - 1);
-            a.nearest[L] = s_j[0];
-            a.min_dist[L] = s_d[0];
-            a.node_index[R] = UPGMA_NONE;
-        }
-        __syncthreads();
-    }
-    if (it >= a.n - 1) return;
-    // ---- pick the closest pair: first strict minimum of min_dist over the active rows ----
-    float bd = UPGMA_BIG;
-    uint32_t bj = UPGMA_NONE;
-    for (int j = tid; j < a.n; j += 1024) {
-        if (a.node_index[j] == UPGMA_NONE) continue;
-        const float d = a.min_dist[j];
-        if (d < bd) { bd = d; bj = j; }
-    }
-    s_d[tid] = bd;
-    s_j[tid] = bj;
     __syncthreads();
-    for (int s = 512; s > 0; s >>= 1) {
+    s_d[tid] = d;
+    s_j[tid] = j;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
         if (tid < s) {
             const float d2 = s_d[tid + s];
             const uint32_t j2 = s_j[tid + s];
@@ -298,25 +258,121 @@ __global__ __launch_bounds__(1024) void upgma_select_kernel(UpgmaArgs a, int it)
         }
         __syncthreads();
     }
-    if (tid == 0) {
-        const uint32_t L = s_j[0];
-        a.sel[0] = L;
-        a.sel[1] = L == UPGMA_NONE ? UPGMA_NONE : a.nearest[L];
-        if (L == UPGMA_NONE || a.sel[1] == UPGMA_NONE) a.sel[2] = 1; // degenerate input (reference: UB)
-    }
+    d = s_d[0];
+    j = s_j[0];
 }
 
-template <bool MODIFIED>
-__global__ __launch_bounds__(256) void upgma_update_kernel(UpgmaArgs a)
+__device__ __forceinline__ void take_first_min(float d, uint32_t j, float& bd, uint32_t& bj)
+{
+    if (d < UPGMA_BIG && (d < bd || (d == bd && j < bj))) { bd = d; bj = j; }
+}
+
+// first minimum of min_dist over the 256 rows of every workgroup: the global pick then only looks at these
+__global__ __launch_bounds__(256) void upgma_block_min_kernel(UpgmaArgs a)
 {
     __shared__ float s_d[256];
     __shared__ uint32_t s_j[256];
-    const int tid = threadIdx.x;
-    const uint32_t L = a.sel[0], R = a.sel[1];
-    const uint32_t j = blockIdx.x * 256 + tid;
+    const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+    float d = UPGMA_BIG;
+    uint32_t bj = UPGMA_NONE;
+    if (j < (uint32_t)a.n) take_first_min(a.min_dist[j], j, d, bj);
+    block_first_min(d, bj, s_d, s_j);
+    if (threadIdx.x == 0) {
+        a.bm_d[blockIdx.x] = d;
+        a.bm_j[blockIdx.x] = bj;
+    }
+}
+
+// One launch = one merge of UPGMA::computeTree (tree/UPGMA.cpp:198-288).  The merges are strictly
+// sequential and the only synchronisation is the kernel boundary, so every workgroup redoes the small
+// serial part itself instead of waiting for a single-workgroup kernel:
+//   1. finish merge it-1: the new cluster's row minimum = first minimum of the per-workgroup minima the
+//      previous launch left (two buffers, alternating);
+//   2. pick this merge: first minimum of min_dist over the active rows = first minimum of the
+//      per-workgroup minima bm[], where the two workgroups that own the rows touched by merge it-1 are
+//      recomputed from their rows (with the not-yet-written changes of step 1 applied as patches);
+//   3. update its own 256 rows (new distances to the merged cluster, nearest-pointer rename).
+// Workgroup 0 does the bookkeeping writes of step 1; the owners write their bm[] entries; everything a
+// launch writes that the same launch reads elsewhere is overridden there by the same patch, so the
+// order in which workgroups run does not matter.
+template <bool MODIFIED>
+__global__ __launch_bounds__(256) void upgma_step_kernel(UpgmaArgs a, int it)
+{
+    __shared__ float s_d[256];
+    __shared__ uint32_t s_j[256];
+    const int tid = threadIdx.x, b = blockIdx.x, nb = a.n_blocks, n = a.n;
+    const uint32_t j = (uint32_t)b * 256 + tid;
+    const bool in = j < (uint32_t)n;
+    // requested first: nothing below depends on these addresses
+    const uint32_t my_node = in ? a.node_index[j] : UPGMA_NONE;
+    const uint32_t my_near = in ? a.nearest[j] : UPGMA_NONE;
+
+    // ---- 1. finish merge it-1 ----
+    uint32_t Lp = UPGMA_NONE, Rp = UPGMA_NONE, bLp = UPGMA_NONE, bRp = UPGMA_NONE;
+    float new_d = UPGMA_BIG;
+    uint32_t new_j = UPGMA_NONE;
+    if (it > 0) {
+        const uint32_t* selp = a.sel + 4 * ((it - 1) & 1);
+        Lp = selp[0];
+        Rp = selp[1];
+        bLp = Lp >> 8;
+        bRp = Rp >> 8;
+        const float* pd = a.part_d + (size_t)((it - 1) & 1) * nb;
+        const uint32_t* pj = a.part_j + (size_t)((it - 1) & 1) * nb;
+        for (int x = tid; x < nb; x += 256) take_first_min(pd[x], pj[x], new_d, new_j);
+        block_first_min(new_d, new_j, s_d, s_j);
+    }
+    // ---- 2. pick ----
+    float cd = UPGMA_BIG;
+    uint32_t cj = UPGMA_NONE;
+    for (int x = tid; x < nb; x += 256)
+        if ((uint32_t)x != bLp && (uint32_t)x != bRp) take_first_min(a.bm_d[x], a.bm_j[x], cd, cj);
+    float own_d = UPGMA_BIG; // the recomputed minimum of the touched workgroup this one owns (if any)
+    uint32_t own_j = UPGMA_NONE;
+    if (it > 0) {
+#pragma unroll
+        for (int which = 0; which < 2; ++which) {
+            const uint32_t blk = which == 0 ? bLp : bRp;
+            if (which == 1 && bRp == bLp) break;
+            const uint32_t r = blk * 256 + tid;
+            float d = UPGMA_BIG;
+            uint32_t rj = UPGMA_NONE;
+            if (r < (uint32_t)n && r != Rp && a.node_index[r] != UPGMA_NONE)
+                take_first_min(r == Lp ? new_d : a.min_dist[r], r, d, rj);
+            take_first_min(d, rj, cd, cj);
+            if (blk == (uint32_t)b) { own_d = d; own_j = rj; }
+        }
+    }
+    block_first_min(cd, cj, s_d, s_j);
+    const uint32_t L = cj;
+    if (it > 0 && ((uint32_t)b == bLp || (uint32_t)b == bRp)) {
+        block_first_min(own_d, own_j, s_d, s_j);
+        if (tid == 0) {
+            a.bm_d[b] = own_d;
+            a.bm_j[b] = own_j;
+        }
+    }
+    uint32_t R = UPGMA_NONE;
+    if (it < n - 1 && L != UPGMA_NONE) R = L == Lp ? new_j : a.nearest[L];
+    if (b == 0 && tid == 0) {
+        if (it > 0) {
+            a.left[it - 1] = (int32_t)a.node_index[Lp];
+            a.right[it - 1] = (int32_t)a.node_index[Rp];
+            a.node_index[Lp] = (uint32_t)n + (uint32_t)(it - 1);
+            a.node_index[Rp] = UPGMA_NONE;
+            a.min_dist[Lp] = new_d;
+        }
+        if (it < n - 1) {
+            a.sel[4 * (it & 1) + 0] = L;
+            a.sel[4 * (it & 1) + 1] = R;
+            if (L == UPGMA_NONE || R == UPGMA_NONE) a.sel[8] = 1; // degenerate input (reference: UB)
+        }
+    }
+    if (it >= n - 1) return; // the last launch only finishes merge n-2
+    // ---- 3. update my rows ----
     float nd = UPGMA_BIG;
     uint32_t nj = UPGMA_NONE;
-    if (L != UPGMA_NONE && R != UPGMA_NONE && j < (uint32_t)a.n && j != L && j != R && a.node_index[j] != UPGMA_NONE) {
+    if (L != UPGMA_NONE && R != UPGMA_NONE && in && my_node != UPGMA_NONE && j != Rp && j != L && j != R) {
         const size_t vL = tri_index(L, j), vR = tri_index(R, j);
         const float dL = a.D[vL], dR = a.D[vR];
         float v;
@@ -324,27 +380,17 @@ __global__ __launch_bounds__(256) void upgma_update_kernel(UpgmaArgs a)
             v = __fadd_rn(__fmul_rn(0.05f, __fadd_rn(dL, dR)), __fmul_rn(0.9f, fminf(dL, dR)));
         else
             v = __fmul_rn(__fadd_rn(dL, dR), 0.5f);
-        if (a.nearest[j] == R) a.nearest[j] = L;
+        uint32_t near_j = j == Lp ? new_j : my_near; // the row of the previous merge: its nearest is still in flight
+        if (near_j == R) near_j = L;
+        if (near_j != my_near) a.nearest[j] = near_j;
         a.D[vL] = v;
         nd = v;
         nj = j;
     }
-    s_d[tid] = nd;
-    s_j[tid] = nj;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if (tid < s) {
-            const float d2 = s_d[tid + s];
-            const uint32_t j2 = s_j[tid + s];
-            // "dtNewDist < dtNewMinDist" starting from BIG_DIST: values >= BIG never win
-            if (d2 < s_d[tid] || (d2 == s_d[tid] && j2 < s_j[tid])) { s_d[tid] = d2; s_j[tid] = j2; }
-        }
-        __syncthreads();
-    }
+    block_first_min(nd, nj, s_d, s_j);
     if (tid == 0) {
-        const bool ok = s_d[0] < UPGMA_BIG;
-        a.part_d[blockIdx.x] = ok ? s_d[0] : UPGMA_BIG;
-        a.part_j[blockIdx.x] = ok ? s_j[0] : UPGMA_NONE;
+        a.part_d[(size_t)(it & 1) * nb + b] = nd;
+        a.part_j[(size_t)(it & 1) * nb + b] = nj;
     }
 }
 
@@ -359,14 +405,12 @@ hipError_t launch_upgma(const UpgmaArgs& a, const void* lcs, int elem_size, cons
         hipLaunchKernelGGL(upgma_dist_kernel<uint32_t>, dim3(n - 1), dim3(256), 0, stream, (const uint32_t*)lcs, lens,
                            pow_f32, kind, n, a.D);
     hipLaunchKernelGGL(upgma_init_kernel, dim3(n), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(upgma_block_min_kernel, dim3(a.n_blocks), dim3(256), 0, stream, a);
     for (int it = 0; it < n; ++it) {
-        hipLaunchKernelGGL(upgma_select_kernel, dim3(1), dim3(1024), 0, stream, a, it);
-        if (it < n - 1) {
-            if (modified)
-                hipLaunchKernelGGL(upgma_update_kernel<true>, dim3(a.n_blocks), dim3(256), 0, stream, a);
-            else
-                hipLaunchKernelGGL(upgma_update_kernel<false>, dim3(a.n_blocks), dim3(256), 0, stream, a);
-        }
+        if (modified)
+            hipLaunchKernelGGL(upgma_step_kernel<true>, dim3(a.n_blocks), dim3(256), 0, stream, a, it);
+        else
+            hipLaunchKernelGGL(upgma_step_kernel<false>, dim3(a.n_blocks), dim3(256), 0, stream, a, it);
     }
     return hipGetLastError();
 }

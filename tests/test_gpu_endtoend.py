@@ -163,3 +163,29 @@ def test_trees_of_a_set_with_a_giant_sequence(host, oracle, tmp_path, gt):
     ids = np.arange(len(seqs), dtype=np.int32)
     square = oracle.rect(codes, offsets, ids, ids)
     assert host.tree_gpu(fasta, gt) == host.tree_from_matrix(fasta, square, gt)
+
+
+@pytest.mark.parametrize("gt", ["upgma", "upgma_modified"])
+@pytest.mark.parametrize("shape", ["ties", "family"])
+def test_device_upgma_on_tie_heavy_and_larger_sets(host, oracle, tmp_path, gt, shape):
+    """The one-launch-per-merge UPGMA against the host restatement (pinned to the reference by the CPU suite)
+    fed with the oracle's matrix: thousands of exact distance ties, several workgroups of rows, merges that
+    touch the same workgroup twice in a row."""
+    import numpy as np
+    rng = np.random.Generator(np.random.PCG64(61))
+    if shape == "ties":
+        seqs = [rng.integers(0, 3, size=int(rng.integers(8, 15))).astype(np.uint8) for _ in range(1300)]
+    else:
+        anc = rng.integers(0, 20, size=150, dtype=np.uint8)
+        seqs = []
+        for _ in range(1500):
+            s = anc.copy()
+            m = rng.random(150) < 0.2
+            s[m] = rng.integers(0, 20, size=int(m.sum()), dtype=np.uint8)
+            seqs.append(s[: int(rng.integers(90, 151))].copy())
+    codes, offsets = seqio.pack(seqs)
+    fasta = str(tmp_path / "u.fasta")
+    seqio.to_fasta(codes, offsets, fasta)
+    ids = np.arange(len(seqs), dtype=np.int32)
+    square = oracle.rect(codes, offsets, ids, ids)
+    assert host.tree_gpu(fasta, gt, keep_duplicates=True) == host.tree_from_matrix(fasta, square, gt, keep_duplicates=True)
