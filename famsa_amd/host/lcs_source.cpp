@@ -220,4 +220,25 @@ void MatrixLcsSource::rect(const int* refs, int n_refs, const int* cols, int n_c
         }
 }
 
+bool MatrixLcsSource::triangles_batch(const int* ids, const int64_t* offsets, int n_groups, LcsBuf& out)
+{
+    size_t count = 0;
+    for (int g = 0; g < n_groups; ++g) {
+        const size_t m = (size_t)(offsets[g + 1] - offsets[g]);
+        count += m * (m > 0 ? m - 1 : 0) / 2;
+    }
+    out.resize(count, wide());
+    size_t k = 0;
+    for (int g = 0; g < n_groups; ++g) {
+        const int* list = ids + offsets[g];
+        const int m = (int)(offsets[g + 1] - offsets[g]);
+        for (int i = 1; i < m; ++i)
+            for (int j = 0; j < i; ++j, ++k) {
+                const uint32_t v = m_[(size_t)list[i] * n_ + list[j]];
+                if (out.wide) out.v32[k] = v; else out.v16[k] = (uint16_t)v;
+            }
+    }
+    return true;
+}
+
 } // namespace famsa_host

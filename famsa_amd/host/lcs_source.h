@@ -115,6 +115,8 @@ public:
     bool wide() const override { return wide_; }
     void triangle(int r0, int r1, LcsBuf& out) override;
     void rect(const int* refs, int n_refs, const int* cols, int n_cols, LcsBuf& out) override;
+    // served from the matrix, so the batched-leaf path of the FastTree recursion runs without a GPU too
+    bool triangles_batch(const int* ids, const int64_t* offsets, int n_groups, LcsBuf& out) override;
 
 private:
     int n_;
