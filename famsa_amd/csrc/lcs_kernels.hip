@@ -427,10 +427,82 @@ __global__ __launch_bounds__(256) void lcs_rows_kernel_pipe(RowsArgs a)
 }
 
 // ---- refs longer than 2048 residues -------------------------------------------------------
-// Segments of SEGW = 32 words; X of one segment in 64 VGPRs; carries between segments go
-// through a per-lane stream of 16-bit words (one per 16-residue chunk) in global scratch:
-// carry[(slot*n_chunks + k)*256 + tid], read and rewritten in place by each segment.
+// The ref is cut into segments of at most SEGW = 32 words (X of one segment in 64 VGPRs) that are
+// processed one after another; the last segment of a ref uses the narrowest of the 8 / 16 / 24 /
+// 32-word passes that covers what is left, so a 3000-residue ref (47 words) costs 32 + 16 words
+// instead of 2 x 32.  Carries between segments go through a per-lane stream of 16-bit words (one
+// per 16-residue chunk) in global scratch: carry[(slot*n_chunks + k)*256 + tid], read and
+// rewritten in place by each segment.
 static constexpr int SEGW = 32;
+
+// one segment of W words of ref `rid`, starting at word `word0`, against this lane's partner
+template <bool QUIRK, int W>
+__device__ __forceinline__ uint32_t long_segment_pass(const RowsArgs& a, int rid, int word0, bool first, bool last,
+                                                      unsigned char* smem, const uint8_t* pbase, int my_chunks,
+                                                      int wave_chunks, uint16_t* my_carry, int wave, int lane)
+{
+    __syncthreads(); // previous segment's readers are done with the masks
+    build_mask_words(a, rid, word0, W, (lds_u64*)smem, wave, lane);
+    __syncthreads();
+    uint32_t res = 0;
+    if constexpr (!QUIRK) {
+        // the pipelined half-word step of the hot kernel
+        using P = Pipe<2 * W, 1, LCS_LOOKAHEAD>;
+        uint32_t X[1][2 * W];
+#pragma unroll
+        for (int j = 0; j < 2 * W; ++j)
+            X[0][j] = ~0u;
+        uint4 q = make_uint4(PAD4, PAD4, PAD4, PAD4);
+        if (0 < my_chunks)
+            q = *(const uint4*)pbase;
+        uint64_t ring[LCS_LOOKAHEAD];
+        P::prime((const lds_u8*)smem, q, ring);
+        for (int k = 0; k < wave_chunks; ++k) {
+            uint4 qn = make_uint4(PAD4, PAD4, PAD4, PAD4);
+            if (k + 1 < my_chunks)
+                qn = *(const uint4*)(pbase + (size_t)(k + 1) * 1024);
+            const uint32_t cw = first ? 0u : my_carry[(size_t)k * 256];
+            uint32_t cout = 0;
+            P::template chunk<true>((const lds_u8*)smem, q, qn, ring, X, cw, &cout);
+            if (!last)
+                my_carry[(size_t)k * 256] = (uint16_t)cout;
+            q = qn;
+        }
+#pragma unroll
+        for (int j = 0; j < 2 * W; ++j)
+            res += __popc(~X[0][j]);
+    } else {
+        uint32_t X[2 * W];
+#pragma unroll
+        for (int j = 0; j < 2 * W; ++j)
+            X[j] = ~0u;
+        for (int k = 0; k < wave_chunks; ++k) {
+            uint4 q = make_uint4(PAD4, PAD4, PAD4, PAD4);
+            if (k < my_chunks)
+                q = *(const uint4*)(pbase + (size_t)k * 1024);
+            const uint32_t cw = first ? 0u : my_carry[(size_t)k * 256];
+            uint32_t cout = 0;
+            const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                uint32_t d = w[i];
+#pragma unroll 1
+                for (int bb = 0; bb < 4; ++bb) {
+                    const int b = i * 4 + bb;
+                    const unsigned co = literal_step<W>((const lds_u8*)smem + (d & 0xFFu), X, (cw >> b) & 1u);
+                    cout |= co << b;
+                    d >>= 8;
+                }
+            }
+            if (!last)
+                my_carry[(size_t)k * 256] = (uint16_t)cout;
+        }
+#pragma unroll
+        for (int j = 0; j < 2 * W; ++j)
+            res += __popc(~X[j]);
+    }
+    return res;
+}
 
 template <bool QUIRK>
 __global__ __launch_bounds__(256) void lcs_long_kernel(RowsArgs a, uint16_t* carry, int n_chunks_max)
@@ -458,68 +530,19 @@ __global__ __launch_bounds__(256) void lcs_long_kernel(RowsArgs a, uint16_t* car
     for (int r = 0; r < nr; ++r) {
         const int rid = a.ref_ids ? a.ref_ids[ref0 + r] : a.ref_begin + ref0 + r;
         const int n_words = (int)((a.lens[rid] + 63) / 64);
-        const int n_seg = (n_words + SEGW - 1) / SEGW;
         uint32_t res = 0;
-        for (int seg = 0; seg < n_seg; ++seg) {
-            __syncthreads(); // previous segment's readers are done with the masks
-            build_mask_words(a, rid, seg * SEGW, SEGW, (lds_u64*)smem, wave, lane);
-            __syncthreads();
-            if constexpr (!QUIRK) {
-                // the pipelined half-word step of the hot kernel, one 64-half-word segment per pass
-                using P = Pipe<2 * SEGW, 1, LCS_LOOKAHEAD>;
-                uint32_t X[1][2 * SEGW];
-#pragma unroll
-                for (int j = 0; j < 2 * SEGW; ++j)
-                    X[0][j] = ~0u;
-                uint4 q = make_uint4(PAD4, PAD4, PAD4, PAD4);
-                if (0 < my_chunks)
-                    q = *(const uint4*)pbase;
-                uint64_t ring[LCS_LOOKAHEAD];
-                P::prime((const lds_u8*)smem, q, ring);
-                for (int k = 0; k < wave_chunks; ++k) {
-                    uint4 qn = make_uint4(PAD4, PAD4, PAD4, PAD4);
-                    if (k + 1 < my_chunks)
-                        qn = *(const uint4*)(pbase + (size_t)(k + 1) * 1024);
-                    const uint32_t cw = (seg > 0) ? my_carry[(size_t)k * 256] : 0u;
-                    uint32_t cout = 0;
-                    P::template chunk<true>((const lds_u8*)smem, q, qn, ring, X, cw, &cout);
-                    if (seg + 1 < n_seg)
-                        my_carry[(size_t)k * 256] = (uint16_t)cout;
-                    q = qn;
-                }
-#pragma unroll
-                for (int j = 0; j < 2 * SEGW; ++j)
-                    res += __popc(~X[0][j]);
-            } else {
-            uint32_t X[2 * SEGW];
-#pragma unroll
-            for (int j = 0; j < 2 * SEGW; ++j)
-                X[j] = ~0u;
-            for (int k = 0; k < wave_chunks; ++k) {
-                uint4 q = make_uint4(PAD4, PAD4, PAD4, PAD4);
-                if (k < my_chunks)
-                    q = *(const uint4*)(pbase + (size_t)k * 1024);
-                uint32_t cw = (seg > 0) ? my_carry[(size_t)k * 256] : 0u;
-                uint32_t cout = 0;
-                const uint32_t w[4] = {q.x, q.y, q.z, q.w};
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    uint32_t d = w[i];
-#pragma unroll 1
-                    for (int bb = 0; bb < 4; ++bb) {
-                        const int b = i * 4 + bb;
-                        const unsigned co = literal_step<SEGW>((const lds_u8*)smem + (d & 0xFFu), X, (cw >> b) & 1u);
-                        cout |= co << b;
-                        d >>= 8;
-                    }
-                }
-                if (seg + 1 < n_seg)
-                    my_carry[(size_t)k * 256] = (uint16_t)cout;
-            }
-#pragma unroll
-            for (int j = 0; j < 2 * SEGW; ++j)
-                res += __popc(~X[j]);
-            }
+        for (int word0 = 0; word0 < n_words;) {
+            const int left = n_words - word0;
+            const bool first = word0 == 0;
+#define LCS_LONG_PASS(W)                                                                                       \
+    res += long_segment_pass<QUIRK, W>(a, rid, word0, first, left <= W, smem, pbase, my_chunks, wave_chunks,  \
+                                       my_carry, wave, lane);                                                  \
+    word0 += W;
+            if (left > 24) { LCS_LONG_PASS(32) }
+            else if (left > 16) { LCS_LONG_PASS(24) }
+            else if (left > 8) { LCS_LONG_PASS(16) }
+            else { LCS_LONG_PASS(8) }
+#undef LCS_LONG_PASS
         }
         if (valid)
             store_result(a, ref0 + r, c, res);
