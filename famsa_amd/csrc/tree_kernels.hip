@@ -245,21 +245,27 @@ __global__ __launch_bounds__(256) void upgma_init_kernel(UpgmaArgs a)
 // against the (UPGMA_BIG, UPGMA_NONE) start ("dtDist < dtMinDist" from BIG_DIST in the reference)
 __device__ __forceinline__ void block_first_min(float& d, uint32_t& j, float* s_d, uint32_t* s_j)
 {
-    const int tid = threadIdx.x;
-    __syncthreads();
-    s_d[tid] = d;
-    s_j[tid] = j;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if (tid < s) {
-            const float d2 = s_d[tid + s];
-            const uint32_t j2 = s_j[tid + s];
-            if (d2 < s_d[tid] || (d2 == s_d[tid] && j2 < s_j[tid])) { s_d[tid] = d2; s_j[tid] = j2; }
-        }
-        __syncthreads();
+    // inside a wave by lane exchange, then the 4 wave results through LDS: two barriers per reduction
+    for (int off = 32; off > 0; off >>= 1) {
+        const float d2 = __shfl_xor(d, off);
+        const uint32_t j2 = __shfl_xor(j, off);
+        if (d2 < d || (d2 == d && j2 < j)) { d = d2; j = j2; }
     }
+    const int tid = threadIdx.x;
+    __syncthreads(); // the previous reduction's readers are done with s_d / s_j
+    if ((tid & 63) == 0) {
+        s_d[tid >> 6] = d;
+        s_j[tid >> 6] = j;
+    }
+    __syncthreads();
     d = s_d[0];
     j = s_j[0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+        const float d2 = s_d[w];
+        const uint32_t j2 = s_j[w];
+        if (d2 < d || (d2 == d && j2 < j)) { d = d2; j = j2; }
+    }
 }
 
 __device__ __forceinline__ void take_first_min(float d, uint32_t j, float& bd, uint32_t& bj)
