@@ -89,6 +89,7 @@ struct Lane {
     hipStream_t stream = nullptr;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     hipEvent_t ev_done = nullptr; // blocking-sync event: host-memory calls sleep on it instead of spinning
+    hipStream_t copy_stream = nullptr; // large host-buffer results leave in slices while the next slice is computed
     lcsgpu_impl::DevBuf d_plan, d_out, d_carry;
     lcsgpu_impl::DevBuf d_work, d_draws; // CLARANS state and its pre-drawn step positions
     lcsgpu_impl::PinBuf h_plan, h_small;

@@ -98,3 +98,22 @@ def test_device_reducers_produce_valid_trees(engine, big, which):
             used[c] += 1
     assert (used[: 2 * n - 2] == 1).all() and used[2 * n - 2] == 0
     engine.upload_seqs(big)
+
+
+def test_large_host_buffer_triangle_leaves_in_slices(engine):
+    """lcsgpu_lcs_triangle above 256 MB of results computes and copies row slices in a pipeline: same values
+    as the one-launch device-buffer form, for a full triangle and for a row block that starts mid-way."""
+    import torch
+    n = 17500
+    codes, offsets = seqio.synth_uniform(n, 96)
+    engine.upload(codes, offsets)
+    for r0, r1 in ((0, n), (6001, n - 17)):
+        count = r1 * (r1 - 1) // 2 - r0 * (r0 - 1) // 2
+        assert count * 2 >= 256 << 20
+        dev = torch.empty(count, dtype=torch.int16, device="cuda:0")
+        engine.lcs_triangle_dev(r0, r1, dev.data_ptr(), 2, sync=True)
+        want = dev.cpu().numpy().view(np.uint16)
+        got = engine.lcs_triangle(r0, r1)
+        assert got.shape == want.shape and (got == want).all()
+        ms, launches = engine.last_kernel_ms()
+        assert launches >= 8 and ms > 0
