@@ -1,113 +1,2 @@
-"""ctypes binding of famsa_amd/libfamsa_host.so (the C++ host layer above the C-ABI)."""
-import ctypes as C
-import os
-
-import numpy as np
-
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-HOST_SO = os.path.join(ROOT, "famsa_amd", "libfamsa_host.so")
-CLI = os.path.join(ROOT, "famsa_amd", "famsa-gpu")
-DIST = {"indel_div_lcs": 0, "indel075_div_lcs": 1}
-
-
-class Host:
-    def __init__(self):
-        import famsa_amd
-        famsa_amd.load_library()  # resolves liblcsgpu.so (and lets torch's HIP runtime load first)
-        lib = C.CDLL(HOST_SO)
-        lib.famsa_host_last_error.restype = C.c_char_p
-        lib.famsa_host_tree_from_matrix.restype = C.c_long
-        heur = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int]
-        lib.famsa_host_tree_from_matrix.argtypes = [C.c_char_p, C.c_void_p, C.c_char_p, C.c_int, C.c_int, *heur,
-                                                    C.c_char_p, C.c_long]
-        lib.famsa_host_dist_export_from_matrix.argtypes = [C.c_char_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
-                                                           C.c_char_p]
-        lib.famsa_host_tree_gpu.restype = C.c_long
-        lib.famsa_host_tree_gpu.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_int, *heur, C.c_char_p,
-                                            C.c_long]
-        lib.famsa_host_dist_export_gpu.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p]
-        lib.famsa_host_workset.argtypes = [C.c_char_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
-        lib.famsa_host_format_distance.argtypes = [C.c_double, C.c_char_p]
-        lib.famsa_host_records.restype = C.c_long
-        lib.famsa_host_records.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_long, C.c_void_p, C.c_long, C.c_void_p,
-                                           C.c_long]
-        lib.famsa_host_clarans.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]
-        self.lib = lib
-
-    def _err(self):
-        return RuntimeError(self.lib.famsa_host_last_error().decode())
-
-    HEUR = {None: 0, "parttree": 1, "medoidtree": 2}
-
-    def tree_from_matrix(self, fasta, square, method, distance="indel075_div_lcs", keep_duplicates=False,
-                         heuristic=None, subtree_size=0, sample_size=0, threshold=0, cluster_fraction=0.0,
-                         cluster_iters=0):
-        sq = np.ascontiguousarray(square, np.uint32)
-        buf = C.create_string_buffer(1 << 25)
-        n = self.lib.famsa_host_tree_from_matrix(fasta.encode(), sq.ctypes.data, method.encode(), DIST[distance],
-                                                 int(keep_duplicates), self.HEUR[heuristic], subtree_size,
-                                                 sample_size, threshold, cluster_fraction, cluster_iters, buf,
-                                                 len(buf))
-        if n < 0:
-            raise self._err()
-        return buf.raw[:n]
-
-    def dist_export_from_matrix(self, fasta, square, path, distance="indel075_div_lcs", square_matrix=False,
-                                pid=False):
-        sq = np.ascontiguousarray(square, np.uint32)
-        if self.lib.famsa_host_dist_export_from_matrix(fasta.encode(), sq.ctypes.data, DIST[distance],
-                                                       int(square_matrix), int(pid), path.encode()) != 0:
-            raise self._err()
-
-    def tree_gpu(self, fasta, method, distance="indel075_div_lcs", keep_duplicates=False, device=0, heuristic=None,
-                 subtree_size=0, sample_size=0, threshold=0, cluster_fraction=0.0, cluster_iters=0):
-        buf = C.create_string_buffer(1 << 25)
-        n = self.lib.famsa_host_tree_gpu(fasta.encode(), device, method.encode(), DIST[distance],
-                                         int(keep_duplicates), self.HEUR[heuristic], subtree_size, sample_size,
-                                         threshold, cluster_fraction, cluster_iters, buf, len(buf))
-        if n < 0:
-            raise self._err()
-        return buf.raw[:n]
-
-    def dist_export_gpu(self, fasta, path, distance="indel075_div_lcs", square_matrix=False, pid=False, device=0):
-        if self.lib.famsa_host_dist_export_gpu(fasta.encode(), device, DIST[distance], int(square_matrix), int(pid),
-                                               path.encode()) != 0:
-            raise self._err()
-
-    def workset(self, fasta, n, keep_duplicates=False):
-        a = np.zeros(n, np.int32)
-        b = np.zeros(n, np.int32)
-        u = self.lib.famsa_host_workset(fasta.encode(), int(keep_duplicates), a.ctypes.data, b.ctypes.data, n)
-        if u < 0:
-            raise self._err()
-        return u, a, b
-
-    def format_distance(self, v):
-        buf = C.create_string_buffer(64)
-        n = self.lib.famsa_host_format_distance(float(v), buf)
-        return buf.raw[:n].decode()
-
-    def clarans(self, triangle, n_elems, n_medoids, n_fixed=1, explore_fraction=0.1, num_local=2):
-        tri = np.ascontiguousarray(triangle, np.float32)
-        out = np.zeros(n_medoids, np.int32)
-        if self.lib.famsa_host_clarans(tri.ctypes.data, n_elems, n_medoids, n_fixed, explore_fraction, num_local,
-                                       out.ctypes.data) != 0:
-            raise self._err()
-        return out
-
-    def records(self, fasta, n_threads=0):
-        """(ids, [code arrays]) as the FASTA reader delivers them."""
-        size = os.path.getsize(fasta) + 16
-        for attempt in range(4):  # a compressed file needs more room than its size on disk
-            ids = C.create_string_buffer(size)
-            codes = np.zeros(size, np.uint8)
-            offs = np.zeros(size // 2 + 2, np.uint64)
-            n = self.lib.famsa_host_records(fasta.encode(), n_threads, ids, size, codes.ctypes.data, size,
-                                            offs.ctypes.data, len(offs))
-            if n >= 0 or b"buffer too small" not in self.lib.famsa_host_last_error():
-                break
-            size *= 8
-        if n < 0:
-            raise self._err()
-        names = ids.value.decode("latin-1").split("\n")[:-1] if n else []
-        return names, [codes[int(offs[i]):int(offs[i + 1])].copy() for i in range(n)]
+"""The ctypes binding of libfamsa_host.so lives in the package (famsa_amd/hostlib.py); the tests use it from here."""
+from famsa_amd.hostlib import CLI, DIST, HOST_SO, Host  # noqa: F401
