@@ -40,11 +40,6 @@ __device__ __forceinline__ size_t tri_at(int i, int j)
     return i >= j ? (size_t)j + (size_t)i * (i - 1) / 2 : (size_t)i + (size_t)j * (j - 1) / 2;
 }
 
-#ifdef CLARANS_TRACE
-#define TR(i) do { if (tid == 0 && b == 0) { const unsigned long long t_ = wall_clock64(); atomicAdd(&tr[i], t_ - t_prev); t_prev = t_; } } while (0)
-#else
-#define TR(i)
-#endif
 enum { ST_P = 0, ST_DONE = 1, ST_LOG_LEN = 2, ST_ROUNDS = 3, ST_ARRIVE = 4, ST_COST = 5, ST_ERR = 6, ST_WIN = 7,
        ST_OFF = 8, ST_STAGE = 9, ST_FIRST = 10 };
 
@@ -169,10 +164,6 @@ __global__ __launch_bounds__(512) void clarans_eval_kernel(ClaransBatch batch)
     __shared__ float4 s_we[8][SUB];     // 16 KB: per wave, the entries of one sub-chunk that concern its slots
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int k = a.n_medoids, n = a.n_elems;
-#ifdef CLARANS_TRACE
-    unsigned long long* tr = reinterpret_cast<unsigned long long*>(a.state + 16);
-    unsigned long long t_prev = wall_clock64();
-#endif
     // level 1: state, this step, and the first chunk's per-position data
     const int4 st0 = *reinterpret_cast<const int4*>(a.state);
     const int4 st1 = *reinterpret_cast<const int4*>(a.state + 4);
@@ -193,7 +184,6 @@ __global__ __launch_bounds__(512) void clarans_eval_kernel(ClaransBatch batch)
         s_pre[u] = yy < n ? a.st[yy] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     if (st0.y) return; // done
-    TR(0);
     const uint64_t lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
     if (cost_wg) {
         // running cost: c += addend for every logged addend, in order; zeros are the identity
@@ -282,7 +272,6 @@ __global__ __launch_bounds__(512) void clarans_eval_kernel(ClaransBatch batch)
                 ent[u].z = s_pre[u].z;
             }
         }
-        TR(1);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int hcnt = min(HALF, cnt - h * HALF);
@@ -293,7 +282,6 @@ __global__ __launch_bounds__(512) void clarans_eval_kernel(ClaransBatch batch)
                 if (t < hcnt) s_e[t] = ent[h * (PER / 2) + u];
             }
             __syncthreads();
-            TR(2);
             for (int s0 = 0; s0 < hcnt; s0 += SUB) {
                 float4 e[SUB / 64];
 #pragma unroll
@@ -331,9 +319,7 @@ __global__ __launch_bounds__(512) void clarans_eval_kernel(ClaransBatch batch)
                 }
                 __builtin_amdgcn_wave_barrier();
             }
-            TR(3);
             __syncthreads();
-            TR(4);
         }
     }
     // std::min_element over slots [n_fixed, k): smallest value, earliest slot among equals
@@ -363,10 +349,6 @@ __global__ __launch_bounds__(512) void clarans_eval_kernel(ClaransBatch batch)
         a.res_delta[b] = s_v[0];
         a.res_mm[b] = s_k[0];
     }
-    TR(5);
-#ifdef CLARANS_TRACE
-    if (tid == 0 && b == 0) atomicAdd(&tr[7], 1ull);
-#endif
 }
 
 // Accept the first improving step of the window (Clustering.cpp:124-238) or finish the search.
