@@ -544,16 +544,48 @@ __global__ __launch_bounds__(256) void nj_update_kernel(NjArgs a)
 
 __global__ __launch_bounds__(256) void nj_sum_kernel(NjArgs a, int iter)
 {
-    // ci.sum = sum of the new distances in ascending cluster order (NeighborJoining.cpp:88-108)
+    // ci.sum = sum of the new distances in ascending cluster order (NeighborJoining.cpp:88-108): a
+    // sequential float sum.  Clusters that take no part contribute +0.0f, the identity (the sum starts
+    // at +0.0f and cannot become -0.0f), so each wave first compacts the non-zero addends of its
+    // quarter of a chunk, in order, and one lane then walks the four compacted runs.
     __shared__ float buf[4096];
-    const int tid = threadIdx.x;
+    __shared__ float nz[4][1024];
+    __shared__ int cnt[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint64_t lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
     float s = 0.0f;
     for (int base = 0; base < a.n; base += 4096) {
         const int m = min(4096, a.n - base);
-        for (int t = tid; t < m; t += 256) buf[t] = a.tmp[base + t];
+        for (int t = tid; t < 4096; t += 256) buf[t] = t < m ? a.tmp[base + t] : 0.0f;
         __syncthreads();
-        if (tid == 0)
-            for (int t = 0; t < m; ++t) s = __fadd_rn(s, buf[t]);
+        int c = 0;
+        for (int t0 = wave * 1024; t0 < wave * 1024 + 1024; t0 += 256) {
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = buf[t0 + 64 * u + lane];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint64_t mask = __ballot(v[u] != 0.0f);
+                if (v[u] != 0.0f) nz[wave][c + __popcll(mask & lt_mask)] = v[u];
+                c += __popcll(mask);
+            }
+        }
+        if (lane == 0) cnt[wave] = c;
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 0; w < 4; ++w) {
+                const int k = cnt[w];
+                int t = 0;
+                for (; t + 8 <= k; t += 8) {
+                    float g[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) g[u] = nz[w][t + u];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) s = __fadd_rn(s, g[u]);
+                }
+                for (; t < k; ++t) s = __fadd_rn(s, nz[w][t]);
+            }
+        }
         __syncthreads();
     }
     if (tid == 0) {
