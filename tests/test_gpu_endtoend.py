@@ -189,3 +189,35 @@ def test_device_upgma_on_tie_heavy_and_larger_sets(host, oracle, tmp_path, gt, s
     ids = np.arange(len(seqs), dtype=np.int32)
     square = oracle.rect(codes, offsets, ids, ids)
     assert host.tree_gpu(fasta, gt, keep_duplicates=True) == host.tree_from_matrix(fasta, square, gt, keep_duplicates=True)
+
+
+@pytest.mark.skipif(not oracle_bind.have_ref(), reason="oracle/_ref not built (needs /root/reference)")
+@pytest.mark.parametrize("heur_id,heur", [(2, "medoidtree"), (1, "parttree")])
+def test_deep_recursion_against_the_reference_library(host, tmp_path, monkeypatch, heur_id, heur):
+    """A 6000-sequence family with small MedoidTree / PartTree parameters: three levels of recursion with device
+    CLARANS searches, seed assignments and batched leaf matrices at every split, eight host threads -- the
+    Newick must be the reference library's (its own generators, same parameters)."""
+    import numpy as np
+    rng = np.random.Generator(np.random.PCG64(71))
+    anc = rng.integers(0, 20, size=120, dtype=np.uint8)
+    seqs = []
+    for _ in range(6000):
+        s = anc.copy()
+        m = rng.random(120) < 0.3
+        s[m] = rng.integers(0, 20, size=int(m.sum()), dtype=np.uint8)
+        seqs.append(s[: int(rng.integers(70, 121))].copy())
+    codes, offsets = seqio.pack(seqs)
+    fasta = str(tmp_path / "deep.fasta")
+    seqio.to_fasta(codes, offsets, fasta)
+    monkeypatch.setenv("FAMSA_HOST_THREADS", "8")
+    ref = oracle_bind.Ref()
+    h = ref.open_fasta(fasta)
+    try:
+        for gt in ("upgma", "sl"):
+            want = ref.tree(h, gt, heuristic=heur_id, threads=8, subtree=12, sample=150, threshold=120,
+                            cluster_fraction=0.2, cluster_iters=2)
+            got = host.tree_gpu(fasta, gt, heuristic=heur, subtree_size=12, sample_size=150, threshold=120,
+                                cluster_fraction=0.2, cluster_iters=2)
+            assert got == want, (gt, heur)
+    finally:
+        ref.close(h)
