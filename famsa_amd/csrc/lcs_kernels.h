@@ -98,26 +98,38 @@ struct PrimArgs {
 };
 hipError_t launch_prim(const PrimArgs& a, int elem_size, hipStream_t stream);
 
-// ---- MST by Boruvka rounds over the triangle (mst_kernels.hip) ----
+// ---- MST by Boruvka rounds over row blocks of the triangle (mst_kernels.hip) ----
+// Edge key of MSTPrim's strict total order (reference tree/MSTPrim.h:424-483): distance bits (distances are
+// >= 0, so the bit patterns order like the values), then ~pack(min id, max id).  16 bytes = lcsgpu_mst_key,
+// the record of the per-round exchange between the GPUs of a node.
+struct MstKey {
+    unsigned long long d, id;
+};
 struct BoruvkaArgs {
-    const void* tri;            // lower triangle of LCS lengths, ref = larger id
+    const void* tri;            // rows [r0, r1) of the lower triangle of LCS lengths (ref = larger id):
+    int64_t off;                //   element (u, v), v < u, at tri[u(u-1)/2 + v - off], off = r0(r0-1)/2
+    int32_t r0, r1;
     const uint32_t* lens;
-    const double* pow_table;
-    int32_t* comp;              // [n] component (= id of its root vertex) of every vertex
+    const double* pow_table;    // pow(i, 0.75) from the host's libm (the reference's values)
+    int32_t* comp;              // [n] component (= id of its root vertex) of every vertex -- replicated on every GPU
     int32_t* comp_next;         // [n] ... after this round
     int32_t* parent;            // [n] hooking forest over the component roots
-    unsigned long long* best_d; // [n] best edge of every vertex to another component: distance bits ...
-    unsigned long long* best_id; //     ... and ~pack(min id, max id)
+    MstKey* row_best;           // [n] row-pass result (rows of this block only)
+    MstKey* part;               // [n_chunks][n] column-pass partials
+    MstKey* best;               // [n] this block's best edge per vertex = what a GPU contributes to the exchange
+    MstKey* vbest;              // [n] best edge per vertex over all blocks (after the exchange)
     unsigned long long* cb_d;   // [n] the same per component (indexed by root)
     unsigned long long* cb_id;
-    unsigned long long* part_d; // [n_chunks][n] column-pass partials
-    unsigned long long* part_id;
     MstEdge* edges;             // [n-1] in the order the rounds find them
     int32_t* counters;          // [0] edges recorded
     int32_t n, kind, n_chunks, rows_per_chunk;
 };
 hipError_t launch_boruvka_init(const BoruvkaArgs& a, hipStream_t stream);
-hipError_t launch_boruvka_round(const BoruvkaArgs& a, int elem_size, hipStream_t stream);
+// local half of a round: a.best[v] = best edge of v to another component among the pairs of this row block
+hipError_t launch_boruvka_best(const BoruvkaArgs& a, int elem_size, hipStream_t stream);
+// global half: `gathered` = n_parts x n keys (every block's a.best); per-component minima, hooking, relabel.
+// The caller swaps comp / comp_next afterwards and reads counters[0].
+hipError_t launch_boruvka_merge(const BoruvkaArgs& a, const MstKey* gathered, int n_parts, hipStream_t stream);
 
 // ---- device-side UPGMA (tree_kernels.hip) ----
 struct UpgmaArgs {

@@ -64,6 +64,23 @@ bool contiguous(const Bucket& b)
     return true;
 }
 
+int reserve_big(lcsgpu_ctx* ctx, DevBuf& buf, size_t bytes, const char* what)
+{
+    if (bytes <= buf.cap) return LCSGPU_OK;
+    if (hipSetDevice(ctx->device) != hipSuccess) return fail(LCSGPU_E_HIP, "hipSetDevice(%d) failed", ctx->device);
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && bytes > free_b + buf.cap)
+        return fail(LCSGPU_E_NOMEM, "%s needs %.1f GB of device memory, %.1f GB are free on device %d (of %.1f GB)", what,
+                    bytes / 1e9, (free_b + buf.cap) / 1e9, ctx->device, total_b / 1e9);
+    const hipError_t e = buf.reserve(bytes);
+    if (e != hipSuccess) {
+        (void)hipGetLastError(); // an allocation failure is not sticky
+        return fail(LCSGPU_E_NOMEM, "%s: allocating %.1f GB of device memory failed: %s", what, bytes / 1e9,
+                    hipGetErrorString(e));
+    }
+    return LCSGPU_OK;
+}
+
 // Core: plan + launch.  d_out is a device pointer.
 int run_rows(lcsgpu_ctx* ctx, Lane& L, int mode, const int32_t* ref_ids, int32_t ref_begin, int32_t n_refs,
              const int32_t* col_ids, int32_t col_begin, int32_t n_cols, void* d_out, int64_t ld,
@@ -355,6 +372,7 @@ int lcsgpu_destroy(lcsgpu_ctx* ctx)
     ctx->d_pow.release();
     ctx->d_powf.release();
     ctx->d_prim.release();
+    ctx->d_mst.release();
     ctx->d_qrows.release();
     ctx->d_qcols.release();
     ctx->d_dist.release();
@@ -367,19 +385,26 @@ int lcsgpu_encode(const char* residues, size_t n, uint8_t* codes, size_t* n_code
     if ((!residues && n) || !codes || !n_codes) return fail(LCSGPU_E_INVALID, "NULL argument");
     // The alphabet and the folding of characters above 'Z' of CSequence's constructor
     // (reference core/sequence.cpp:17,53-79); the lookup covers the terminator too.
-    static const char alphabet[25] = "ARNDCQEGHILKMFPSTWYVBZX*";
-    uint8_t lut[256];
-    for (int ch = 0; ch < 256; ++ch) {
-        char c = (char)ch;
-        if (c > 'Z') c = (char)(c - 32);
-        uint8_t code = 22;
-        for (int i = 0; i < 25; ++i)
-            if (alphabet[i] == c) {
-                code = (uint8_t)i;
-                break;
+    struct Lut {
+        uint8_t v[256];
+        Lut()
+        {
+            static const char alphabet[25] = "ARNDCQEGHILKMFPSTWYVBZX*";
+            for (int ch = 0; ch < 256; ++ch) {
+                char c = (char)ch;
+                if (c > 'Z') c = (char)(c - 32);
+                uint8_t code = 22;
+                for (int i = 0; i < 25; ++i)
+                    if (alphabet[i] == c) {
+                        code = (uint8_t)i;
+                        break;
+                    }
+                v[ch] = code;
             }
-        lut[ch] = code;
-    }
+        }
+    };
+    static const Lut table; // built once (the FASTA reader calls this per line)
+    const uint8_t* lut = table.v;
     size_t m = 0;
     for (size_t i = 0; i < n; ++i)
         if (residues[i] != '-') codes[m++] = lut[(unsigned char)residues[i]];
@@ -395,6 +420,7 @@ int lcsgpu_upload(lcsgpu_ctx* ctx, const uint8_t* codes, const uint64_t* offsets
     HIP_TRY(hipSetDevice(ctx->device));
     for (Lane& l : ctx->lanes) HIP_TRY(hipStreamSynchronize(l.stream));
     ctx->n = -1;
+    ctx->mst.active = false;
     std::vector<uint32_t> lens(n);
     std::vector<uint8_t> quirk(n);
     uint32_t max_len = 0;

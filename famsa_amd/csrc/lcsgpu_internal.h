@@ -44,7 +44,9 @@ struct DevBuf {
         if (p) (void)hipFree(p);
         p = nullptr;
         cap = 0;
-        size_t want = n + n / 4 + 256;
+        // 25% slack so that slowly growing requests do not reallocate every time -- but not on the
+        // multi-GB result triangles, where the slack alone could be what does not fit
+        size_t want = n + (n < ((size_t)256 << 20) ? n / 4 : 0) + 256;
         hipError_t e = hipMalloc(&p, want);
         if (e == hipSuccess) cap = want;
         return e;
@@ -143,6 +145,16 @@ struct lcsgpu_ctx {
 
     // scratch of the lane-0 tree reducers
     lcsgpu_impl::DevBuf d_prim, d_qrows, d_qcols, d_dist;
+    // sharded MST (lcsgpu_mst_shard_*): the replicated component state and this context's row block,
+    // alive from _begin to the next _begin / upload
+    lcsgpu_impl::DevBuf d_mst;
+    struct MstShard {
+        bool active = false;
+        lcsgpu::BoruvkaArgs b{};
+        int elem = 2;
+        int32_t found = 0; // MST edges recorded so far
+        int rounds = 0;
+    } mst;
     double total_kernel_ms = 0; // completed host-memory calls
     // searches are spread over a few independent batches (each its own stream and driver): rounds of
     // different batches overlap on the GPU, which hides part of a round's memory latency
@@ -203,6 +215,11 @@ private:
     Which which_;
     int idx_ = 0;
 };
+
+// Reserve a large device buffer, reporting LCSGPU_E_NOMEM (not a HIP error) when it cannot fit.
+int reserve_big(lcsgpu_ctx* ctx, DevBuf& buf, size_t bytes, const char* what);
+// The n-1 tree edges in the order Prim's algorithm adds them from vertex 0 (host; in place).
+int order_edges_like_prim(lcsgpu_mst_edge* edges, int32_t n);
 
 // Core: plan + launch.  d_out is a device pointer.
 int run_rows(lcsgpu_ctx* ctx, Lane& L, int mode, const int32_t* ref_ids, int32_t ref_begin, int32_t n_refs,

@@ -28,14 +28,288 @@ int lcsgpu_row_minima_dev(lcsgpu_ctx* ctx, const void* d_triangle, int elem_size
     return LCSGPU_OK;
 }
 
+} // extern "C"
+
+// ---- the sharded MST (Boruvka over row blocks): state set-up shared by the single-context and the
+// multi-context entry points.  The caller holds lane 0.
+static int shard_begin(lcsgpu_ctx* ctx, Lane& L, const void* d_tri, int elem, int32_t r0, int32_t r1, int kind)
+{
+    const int32_t n = ctx->n;
+    auto a256 = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const int32_t rows = r1 - r0;
+    const int n_chunks = std::max(1, std::min(32, (rows + 1023) / 1024));
+    const int rows_per_chunk = std::max(1, (rows + n_chunks - 1) / n_chunks);
+    const size_t key = sizeof(lcsgpu::MstKey);
+    const size_t o_comp = 0, o_next = o_comp + a256((size_t)n * 4), o_par = o_next + a256((size_t)n * 4),
+                 o_rb = o_par + a256((size_t)n * 4), o_best = o_rb + a256((size_t)n * key),
+                 o_vb = o_best + a256((size_t)n * key), o_cd = o_vb + a256((size_t)n * key),
+                 o_ci = o_cd + a256((size_t)n * 8), o_part = o_ci + a256((size_t)n * 8),
+                 o_edges = o_part + a256((size_t)n_chunks * n * key),
+                 o_cnt = o_edges + a256((size_t)std::max(n - 1, 1) * sizeof(lcsgpu::MstEdge)), total = o_cnt + 256;
+    int rc = reserve_big(ctx, ctx->d_mst, total, "the MST state");
+    if (rc) return rc;
+    char* base = (char*)ctx->d_mst.p;
+    lcsgpu::BoruvkaArgs b{};
+    b.tri = d_tri;
+    b.off = (int64_t)r0 * (r0 > 0 ? r0 - 1 : 0) / 2;
+    b.r0 = r0;
+    b.r1 = r1;
+    b.lens = (const uint32_t*)ctx->d_lens.p;
+    b.pow_table = (const double*)ctx->d_pow.p;
+    b.comp = (int32_t*)(base + o_comp);
+    b.comp_next = (int32_t*)(base + o_next);
+    b.parent = (int32_t*)(base + o_par);
+    b.row_best = (lcsgpu::MstKey*)(base + o_rb);
+    b.best = (lcsgpu::MstKey*)(base + o_best);
+    b.vbest = (lcsgpu::MstKey*)(base + o_vb);
+    b.cb_d = (unsigned long long*)(base + o_cd);
+    b.cb_id = (unsigned long long*)(base + o_ci);
+    b.part = (lcsgpu::MstKey*)(base + o_part);
+    b.edges = (lcsgpu::MstEdge*)(base + o_edges);
+    b.counters = (int32_t*)(base + o_cnt);
+    b.n = n;
+    b.kind = kind;
+    b.n_chunks = n_chunks;
+    b.rows_per_chunk = rows_per_chunk;
+    HIP_TRY(lcsgpu::launch_boruvka_init(b, L.stream));
+    ctx->mst.active = true;
+    ctx->mst.b = b;
+    ctx->mst.elem = elem;
+    ctx->mst.found = 0;
+    ctx->mst.rounds = 0;
+    return LCSGPU_OK;
+}
+
+// local half of a round into d_keys (NULL: the context's own buffer); optionally copied to the host
+static int shard_best(lcsgpu_ctx* ctx, Lane& L, void* d_keys, lcsgpu_mst_key* h_keys)
+{
+    lcsgpu::BoruvkaArgs b = ctx->mst.b;
+    if (d_keys) b.best = (lcsgpu::MstKey*)d_keys;
+    HIP_TRY(lcsgpu::launch_boruvka_best(b, ctx->mst.elem, L.stream));
+    if (h_keys) {
+        HIP_TRY(hipMemcpyAsync(h_keys, b.best, (size_t)b.n * sizeof(lcsgpu::MstKey), hipMemcpyDeviceToHost, L.stream));
+        HIP_TRY(hipStreamSynchronize(L.stream));
+        L.plan_in_flight = false;
+    }
+    return LCSGPU_OK;
+}
+
+// global half of a round over n_parts x n gathered keys (NULL: the context's own keys, one part)
+static int shard_merge(lcsgpu_ctx* ctx, Lane& L, const void* d_gathered, int32_t n_parts, int32_t* n_edges)
+{
+    lcsgpu::BoruvkaArgs& b = ctx->mst.b;
+    if (ctx->mst.rounds > 64) return fail(LCSGPU_E_STATE, "MST: the Boruvka rounds do not converge");
+    const lcsgpu::MstKey* g = d_gathered ? (const lcsgpu::MstKey*)d_gathered : b.best;
+    HIP_TRY(lcsgpu::launch_boruvka_merge(b, g, d_gathered ? n_parts : 1, L.stream));
+    std::swap(b.comp, b.comp_next);
+    ++ctx->mst.rounds;
+    int32_t found = 0;
+    HIP_TRY(hipMemcpyAsync(&found, b.counters, 4, hipMemcpyDeviceToHost, L.stream));
+    HIP_TRY(hipStreamSynchronize(L.stream));
+    L.plan_in_flight = false;
+    if (found > b.n - 1) return fail(LCSGPU_E_STATE, "MST: %d edges recorded for %d vertices", found, b.n);
+    if (found <= ctx->mst.found && found < b.n - 1)
+        return fail(LCSGPU_E_STATE, "MST: a Boruvka round added no edge (%d of %d)", found, b.n - 1);
+    ctx->mst.found = found;
+    if (n_edges) *n_edges = found;
+    return LCSGPU_OK;
+}
+
+static int shard_finish(lcsgpu_ctx* ctx, Lane& L, lcsgpu_mst_edge* out_edges)
+{
+    const lcsgpu::BoruvkaArgs& b = ctx->mst.b;
+    static_assert(sizeof(lcsgpu_mst_edge) == sizeof(lcsgpu::MstEdge), "edge layout");
+    if (ctx->mst.found != b.n - 1) return fail(LCSGPU_E_STATE, "MST: %d of %d edges found", ctx->mst.found, b.n - 1);
+    HIP_TRY(hipMemcpyAsync(out_edges, b.edges, (size_t)(b.n - 1) * sizeof(lcsgpu_mst_edge), hipMemcpyDeviceToHost, L.stream));
+    HIP_TRY(hipStreamSynchronize(L.stream));
+    L.plan_in_flight = false;
+    return order_edges_like_prim(out_edges, b.n);
+}
+
+namespace lcsgpu_impl {
+
+// Prim from vertex 0 over the n-1 tree edges, candidates ordered like MSTPrim's keys (d, ~pack(min, max))
+// (reference tree/MSTPrim.cpp:372-391): the order in which MSTPrim::run_view adds the edges.
+int order_edges_like_prim(lcsgpu_mst_edge* edges, int32_t n)
+{
+    if (n < 2) return LCSGPU_OK;
+    std::vector<lcsgpu_mst_edge> tree(edges, edges + (n - 1));
+    for (const auto& e : tree)
+        if (e.from < 0 || e.to < 0 || e.from >= n || e.to >= n || e.from >= e.to)
+            return fail(LCSGPU_E_INVALID, "MST: edge (%d, %d) is not a pair from < to of [0, %d)", e.from, e.to, n);
+    std::vector<int32_t> head((size_t)n + 1, 0), adj((size_t)2 * (n - 1));
+    for (const auto& e : tree) { ++head[e.from + 1]; ++head[e.to + 1]; }
+    for (int32_t v = 0; v < n; ++v) head[v + 1] += head[v];
+    {
+        std::vector<int32_t> fill(head.begin(), head.end() - 1);
+        for (int32_t k = 0; k < n - 1; ++k) { adj[fill[tree[k].from]++] = k; adj[fill[tree[k].to]++] = k; }
+    }
+    struct Cand {
+        double d;
+        uint64_t id;
+        int32_t edge, to;
+        bool operator>(const Cand& o) const { return d > o.d || (d == o.d && id > o.id); }
+    };
+    std::priority_queue<Cand, std::vector<Cand>, std::greater<Cand>> heap;
+    std::vector<char> in_tree(n, 0);
+    auto visit = [&](int32_t v) {
+        in_tree[v] = 1;
+        for (int32_t k = head[v]; k < head[v + 1]; ++k) {
+            const lcsgpu_mst_edge& e = tree[adj[k]];
+            const int32_t w = e.from == v ? e.to : e.from;
+            if (!in_tree[w]) heap.push(Cand{e.dist, ~(((uint64_t)(uint32_t)e.from << 32) + (uint32_t)e.to), adj[k], w});
+        }
+    };
+    visit(0);
+    for (int32_t k = 0; k < n - 1; ++k) {
+        while (!heap.empty() && in_tree[heap.top().to]) heap.pop();
+        if (heap.empty()) return fail(LCSGPU_E_STATE, "MST: the edges found do not span the set");
+        const Cand c = heap.top();
+        heap.pop();
+        edges[k] = tree[c.edge];
+        visit(c.to);
+    }
+    return LCSGPU_OK;
+}
+
+} // namespace lcsgpu_impl
+
+extern "C" {
+
+static bool valid_kind(int kind) { return kind == LCSGPU_DIST_INDEL_DIV_LCS || kind == LCSGPU_DIST_INDEL075_DIV_LCS; }
+
+int lcsgpu_mst_shard_begin(lcsgpu_ctx* ctx, const void* d_triangle, int elem_size, int32_t row_begin, int32_t row_end,
+                           int distance_kind)
+{
+    const bool triangle_orientation = (distance_kind & LCSGPU_MST_TRIANGLE_ORIENTATION) != 0;
+    distance_kind &= ~LCSGPU_MST_TRIANGLE_ORIENTATION;
+    if (!ctx) return fail(LCSGPU_E_INVALID, "NULL ctx");
+    if (ctx->n < 0) return fail(LCSGPU_E_STATE, "no sequence set uploaded");
+    if (!valid_kind(distance_kind)) return fail(LCSGPU_E_INVALID, "unknown distance kind %d", distance_kind);
+    if (row_begin < 0 || row_end < row_begin || row_end > ctx->n) return fail(LCSGPU_E_INVALID, "bad row range");
+    if (elem_size != 2 && elem_size != 4) return fail(LCSGPU_E_INVALID, "elem_size must be 2 or 4");
+    if (!d_triangle && (int64_t)row_end * (row_end - 1) / 2 - (int64_t)row_begin * (row_begin - 1) / 2 > 0)
+        return fail(LCSGPU_E_INVALID, "NULL device pointer");
+    if (!triangle_orientation)
+        for (int32_t i = 0; i < ctx->n; ++i)
+            if (ctx->quirk[i])
+                return fail(LCSGPU_E_UNSUPPORTED, "sequence %d is orientation sensitive: MSTPrim's distances depend on which "
+                                                  "endpoint is the ref, the triangle does not hold them (use lcsgpu_mst_prim)", i);
+    LaneGuard guard(ctx, LaneGuard::LANE0);
+    HIP_TRY(hipSetDevice(ctx->device));
+    return shard_begin(ctx, guard.lane(), d_triangle, elem_size, row_begin, row_end, distance_kind);
+}
+
+int lcsgpu_mst_shard_best(lcsgpu_ctx* ctx, void* d_keys, lcsgpu_mst_key* h_keys)
+{
+    if (!ctx) return fail(LCSGPU_E_INVALID, "NULL ctx");
+    if (!ctx->mst.active) return fail(LCSGPU_E_STATE, "lcsgpu_mst_shard_begin has not been called");
+    LaneGuard guard(ctx, LaneGuard::LANE0);
+    HIP_TRY(hipSetDevice(ctx->device));
+    return shard_best(ctx, guard.lane(), d_keys, h_keys);
+}
+
+int lcsgpu_mst_shard_merge(lcsgpu_ctx* ctx, const void* d_gathered, int32_t n_parts, int32_t* n_edges)
+{
+    if (!ctx) return fail(LCSGPU_E_INVALID, "NULL ctx");
+    if (!ctx->mst.active) return fail(LCSGPU_E_STATE, "lcsgpu_mst_shard_begin has not been called");
+    if (d_gathered && n_parts < 1) return fail(LCSGPU_E_INVALID, "n_parts < 1");
+    LaneGuard guard(ctx, LaneGuard::LANE0);
+    HIP_TRY(hipSetDevice(ctx->device));
+    return shard_merge(ctx, guard.lane(), d_gathered, n_parts, n_edges);
+}
+
+int lcsgpu_mst_shard_set_components(lcsgpu_ctx* ctx, const int32_t* comp)
+{
+    if (!ctx || !comp) return fail(LCSGPU_E_INVALID, "NULL argument");
+    if (!ctx->mst.active) return fail(LCSGPU_E_STATE, "lcsgpu_mst_shard_begin has not been called");
+    LaneGuard guard(ctx, LaneGuard::LANE0);
+    Lane& L = guard.lane();
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMemcpyAsync(ctx->mst.b.comp, comp, (size_t)ctx->n * 4, hipMemcpyHostToDevice, L.stream));
+    HIP_TRY(hipStreamSynchronize(L.stream));
+    return LCSGPU_OK;
+}
+
+int lcsgpu_mst_shard_finish(lcsgpu_ctx* ctx, lcsgpu_mst_edge* out_edges)
+{
+    if (!ctx) return fail(LCSGPU_E_INVALID, "NULL ctx");
+    if (!ctx->mst.active) return fail(LCSGPU_E_STATE, "lcsgpu_mst_shard_begin has not been called");
+    if (ctx->n < 2) return LCSGPU_OK;
+    if (!out_edges) return fail(LCSGPU_E_INVALID, "NULL out_edges");
+    LaneGuard guard(ctx, LaneGuard::LANE0);
+    HIP_TRY(hipSetDevice(ctx->device));
+    return shard_finish(ctx, guard.lane(), out_edges);
+}
+
+// Host form of the global half of a round (no GPU involved): the same fold / per-component minimum /
+// hooking / relabelling as launch_boruvka_merge, for exchanges that happen in host memory.
+int lcsgpu_mst_merge_host(const lcsgpu_mst_key* keys, int32_t n_parts, int32_t n, int32_t* comp, lcsgpu_mst_edge* edges,
+                          int32_t* n_edges)
+{
+    if (!keys || !comp || !edges || !n_edges || n_parts < 1 || n < 0) return fail(LCSGPU_E_INVALID, "bad argument");
+    const uint64_t NO_D = 0x7fefffffffffffffull, NO_ID = ~0ull;
+    auto less = [](uint64_t d1, uint64_t i1, uint64_t d2, uint64_t i2) { return d1 < d2 || (d1 == d2 && i1 < i2); };
+    std::vector<uint64_t> cb_d((size_t)n, NO_D), cb_id((size_t)n, NO_ID);
+    for (int32_t v = 0; v < n; ++v) {
+        uint64_t bd = NO_D, bi = NO_ID;
+        for (int32_t p = 0; p < n_parts; ++p) {
+            const lcsgpu_mst_key& k = keys[(size_t)p * n + v];
+            if (less(k.dist_bits, k.id, bd, bi)) { bd = k.dist_bits; bi = k.id; }
+        }
+        if (bi == NO_ID) continue;
+        const int32_t c = comp[v];
+        if (c < 0 || c >= n) return fail(LCSGPU_E_INVALID, "component label %d of vertex %d out of range", c, v);
+        if (less(bd, bi, cb_d[c], cb_id[c])) { cb_d[c] = bd; cb_id[c] = bi; }
+    }
+    std::vector<int32_t> parent((size_t)n);
+    for (int32_t c = 0; c < n; ++c) parent[c] = c;
+    int32_t found = *n_edges;
+    for (int32_t c = 0; c < n; ++c) {
+        if (comp[c] != c || cb_id[c] == NO_ID) continue;
+        const uint64_t packed = ~cb_id[c];
+        const int32_t x = (int32_t)(packed >> 32), y = (int32_t)(packed & 0xffffffffull);
+        if (x < 0 || y < 0 || x >= n || y >= n) return fail(LCSGPU_E_INVALID, "key of component %d names the pair (%d, %d)", c, x, y);
+        const int32_t other = comp[x] == c ? comp[y] : comp[x];
+        parent[c] = other;
+        const bool mutual = cb_id[other] == cb_id[c];
+        if (!mutual || c < other) {
+            if (found >= n - 1) return fail(LCSGPU_E_STATE, "MST: more than n-1 edges");
+            edges[found].from = x;
+            edges[found].to = y;
+            uint64_t bits = cb_d[c];
+            memcpy(&edges[found].dist, &bits, 8);
+            ++found;
+        }
+    }
+    for (int32_t c = 0; c < n; ++c) { // two components that chose each other: the smaller one becomes the root
+        if (comp[c] != c) continue;
+        const int32_t p = parent[c];
+        if (p != c && parent[p] == c && c < p) parent[c] = c;
+    }
+    for (int32_t v = 0; v < n; ++v) {
+        int32_t r = comp[v];
+        for (int32_t p = parent[r]; p != r; p = parent[r]) r = p;
+        cb_d[v] = (uint64_t)(uint32_t)r; // new labels, written back after every old one has been read
+    }
+    for (int32_t v = 0; v < n; ++v) comp[v] = (int32_t)cb_d[v];
+    *n_edges = found;
+    return LCSGPU_OK;
+}
+
+int lcsgpu_mst_order_edges(lcsgpu_mst_edge* edges, int32_t n)
+{
+    if (n >= 2 && !edges) return fail(LCSGPU_E_INVALID, "NULL edges");
+    return order_edges_like_prim(edges, n);
+}
+
 int lcsgpu_mst_prim(lcsgpu_ctx* ctx, int distance_kind, lcsgpu_mst_edge* out_edges)
 {
     const bool triangle_orientation = (distance_kind & LCSGPU_MST_TRIANGLE_ORIENTATION) != 0;
     distance_kind &= ~LCSGPU_MST_TRIANGLE_ORIENTATION;
     if (!ctx) return fail(LCSGPU_E_INVALID, "NULL ctx");
     if (ctx->n < 0) return fail(LCSGPU_E_STATE, "no sequence set uploaded");
-    if (distance_kind != LCSGPU_DIST_INDEL_DIV_LCS && distance_kind != LCSGPU_DIST_INDEL075_DIV_LCS)
-        return fail(LCSGPU_E_INVALID, "unknown distance kind %d", distance_kind);
+    if (!valid_kind(distance_kind)) return fail(LCSGPU_E_INVALID, "unknown distance kind %d", distance_kind);
     const int32_t n = ctx->n;
     if (n < 2) return LCSGPU_OK;
     if (!out_edges) return fail(LCSGPU_E_INVALID, "NULL out_edges");
@@ -44,8 +318,9 @@ int lcsgpu_mst_prim(lcsgpu_ctx* ctx, int distance_kind, lcsgpu_mst_edge* out_edg
     HIP_TRY(hipSetDevice(ctx->device));
     const int elem = ctx->max_len > 65535 ? 4 : 2;
     const size_t pairs = (size_t)n * (n - 1) / 2;
-    HIP_TRY(L.d_out.reserve(pairs * elem));
-    int rc = run_rows(ctx, L, lcsgpu::MODE_TRIANGLE, nullptr, 0, n, nullptr, 0, n - 1, L.d_out.p, 0, 0, elem);
+    int rc = reserve_big(ctx, L.d_out, pairs * elem, "the LCS triangle of the MST");
+    if (rc) return rc;
+    rc = run_rows(ctx, L, lcsgpu::MODE_TRIANGLE, nullptr, 0, n, nullptr, 0, n - 1, L.d_out.p, 0, 0, elem);
     if (rc) return rc;
 
     // orientation-sensitive sequences: their values in both roles, as side tables
@@ -68,86 +343,16 @@ int lcsgpu_mst_prim(lcsgpu_ctx* ctx, int distance_kind, lcsgpu_mst_edge* out_edg
     }
 
     if ((triangle_orientation || nq == 0) && !getenv("LCSGPU_MST_PRIM")) {
-        // distances do not depend on which endpoint is the ref: Boruvka rounds over the triangle, then
-        // Prim's insertion order from vertex 0 as a walk over the n-1 tree edges
-        auto a256 = [](size_t x) { return (x + 255) & ~(size_t)255; };
-        const int n_chunks = std::max(1, std::min(32, (n + 1023) / 1024));
-        const int rows_per_chunk = (n + n_chunks - 1) / n_chunks;
-        const size_t o_comp = 0, o_next = o_comp + a256((size_t)n * 4), o_par = o_next + a256((size_t)n * 4),
-                     o_bd = o_par + a256((size_t)n * 4), o_bi = o_bd + a256((size_t)n * 8), o_cd = o_bi + a256((size_t)n * 8),
-                     o_ci = o_cd + a256((size_t)n * 8), o_pd = o_ci + a256((size_t)n * 8),
-                     o_pi = o_pd + a256((size_t)n_chunks * n * 8), o_edges = o_pi + a256((size_t)n_chunks * n * 8),
-                     o_cnt = o_edges + a256((size_t)(n - 1) * sizeof(lcsgpu::MstEdge)), total = o_cnt + 256;
-        HIP_TRY(ctx->d_prim.reserve(total));
-        char* base = (char*)ctx->d_prim.p;
-        lcsgpu::BoruvkaArgs b{};
-        b.tri = L.d_out.p;
-        b.lens = (const uint32_t*)ctx->d_lens.p;
-        b.pow_table = (const double*)ctx->d_pow.p;
-        b.comp = (int32_t*)(base + o_comp);
-        b.comp_next = (int32_t*)(base + o_next);
-        b.parent = (int32_t*)(base + o_par);
-        b.best_d = (unsigned long long*)(base + o_bd);
-        b.best_id = (unsigned long long*)(base + o_bi);
-        b.cb_d = (unsigned long long*)(base + o_cd);
-        b.cb_id = (unsigned long long*)(base + o_ci);
-        b.part_d = (unsigned long long*)(base + o_pd);
-        b.part_id = (unsigned long long*)(base + o_pi);
-        b.edges = (lcsgpu::MstEdge*)(base + o_edges);
-        b.counters = (int32_t*)(base + o_cnt);
-        b.n = n;
-        b.kind = distance_kind;
-        b.n_chunks = n_chunks;
-        b.rows_per_chunk = rows_per_chunk;
-        HIP_TRY(lcsgpu::launch_boruvka_init(b, L.stream));
-        int32_t found = 0;
-        for (int round = 0; found < n - 1; ++round) {
-            if (round > 40) return fail(LCSGPU_E_STATE, "MST: the Boruvka rounds do not converge");
-            HIP_TRY(lcsgpu::launch_boruvka_round(b, elem, L.stream));
-            std::swap(b.comp, b.comp_next);
-            const int32_t before = found;
-            HIP_TRY(hipMemcpyAsync(&found, b.counters, 4, hipMemcpyDeviceToHost, L.stream));
-            HIP_TRY(hipStreamSynchronize(L.stream));
-            L.plan_in_flight = false;
-            if (found <= before) return fail(LCSGPU_E_STATE, "MST: a Boruvka round added no edge");
+        // distances do not depend on which endpoint is the ref: Boruvka rounds over the triangle (one
+        // block = all rows, no exchange), then Prim's insertion order as a walk over the n-1 tree edges
+        rc = shard_begin(ctx, L, L.d_out.p, elem, 0, n, distance_kind);
+        while (!rc && ctx->mst.found < n - 1) {
+            rc = shard_best(ctx, L, nullptr, nullptr);
+            if (!rc) rc = shard_merge(ctx, L, nullptr, 1, nullptr);
         }
-        std::vector<lcsgpu::MstEdge> tree((size_t)n - 1);
-        HIP_TRY(hipMemcpy(tree.data(), b.edges, tree.size() * sizeof(lcsgpu::MstEdge), hipMemcpyDeviceToHost));
-        // Prim from vertex 0 over the tree, edges ordered like MSTPrim's keys: (d, ~pack(min, max))
-        std::vector<int32_t> head((size_t)n + 1, 0), adj((size_t)2 * (n - 1));
-        for (const auto& e : tree) { ++head[e.from + 1]; ++head[e.to + 1]; }
-        for (int32_t v = 0; v < n; ++v) head[v + 1] += head[v];
-        {
-            std::vector<int32_t> fill(head.begin(), head.end() - 1);
-            for (int32_t k = 0; k < n - 1; ++k) { adj[fill[tree[k].from]++] = k; adj[fill[tree[k].to]++] = k; }
-        }
-        struct Cand {
-            double d;
-            uint64_t id;
-            int32_t edge, to;
-            bool operator>(const Cand& o) const { return d > o.d || (d == o.d && id > o.id); }
-        };
-        std::priority_queue<Cand, std::vector<Cand>, std::greater<Cand>> heap;
-        std::vector<char> in_tree(n, 0);
-        auto visit = [&](int32_t v) {
-            in_tree[v] = 1;
-            for (int32_t k = head[v]; k < head[v + 1]; ++k) {
-                const lcsgpu::MstEdge& e = tree[adj[k]];
-                const int32_t w = e.from == v ? e.to : e.from;
-                if (!in_tree[w]) heap.push(Cand{e.dist, ~(((uint64_t)(uint32_t)e.from << 32) + (uint32_t)e.to), adj[k], w});
-            }
-        };
-        visit(0);
-        for (int32_t k = 0; k < n - 1; ++k) {
-            while (!heap.empty() && in_tree[heap.top().to]) heap.pop();
-            if (heap.empty()) return fail(LCSGPU_E_STATE, "MST: the edges found do not span the set");
-            const Cand c = heap.top();
-            heap.pop();
-            out_edges[k].from = tree[c.edge].from;
-            out_edges[k].to = tree[c.edge].to;
-            out_edges[k].dist = tree[c.edge].dist;
-            visit(c.to);
-        }
+        if (!rc) rc = shard_finish(ctx, L, out_edges);
+        ctx->mst.active = false; // the triangle it points to belongs to this call
+        if (rc) return rc;
         note_async_call(ctx);
         return LCSGPU_OK;
     }
@@ -200,9 +405,10 @@ int lcsgpu_upgma(lcsgpu_ctx* ctx, int distance_kind, int modified, int32_t* out_
     HIP_TRY(hipSetDevice(ctx->device));
     const int elem = ctx->max_len > 65535 ? 4 : 2;
     const size_t pairs = (size_t)n * (n - 1) / 2;
-    HIP_TRY(L.d_out.reserve(pairs * elem));
-    HIP_TRY(ctx->d_dist.reserve(pairs * sizeof(float)));
-    int rc = run_rows(ctx, L, lcsgpu::MODE_TRIANGLE, nullptr, 0, n, nullptr, 0, n - 1, L.d_out.p, 0, 0, elem);
+    int rc = reserve_big(ctx, L.d_out, pairs * elem, "the LCS triangle");
+    if (!rc) rc = reserve_big(ctx, ctx->d_dist, pairs * sizeof(float), "the float distance triangle");
+    if (rc) return rc;
+    rc = run_rows(ctx, L, lcsgpu::MODE_TRIANGLE, nullptr, 0, n, nullptr, 0, n - 1, L.d_out.p, 0, 0, elem);
     if (rc) return rc;
     const int blocks = (n + 255) / 256;
     auto a16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
@@ -257,9 +463,10 @@ int lcsgpu_nj(lcsgpu_ctx* ctx, int distance_kind, int32_t* out_left, int32_t* ou
     HIP_TRY(hipSetDevice(ctx->device));
     const int elem = ctx->max_len > 65535 ? 4 : 2;
     const size_t pairs = (size_t)n * (n - 1) / 2;
-    HIP_TRY(L.d_out.reserve(pairs * elem));
-    HIP_TRY(ctx->d_dist.reserve(pairs * sizeof(float)));
-    int rc = run_rows(ctx, L, lcsgpu::MODE_TRIANGLE, nullptr, 0, n, nullptr, 0, n - 1, L.d_out.p, 0, 0, elem);
+    int rc = reserve_big(ctx, L.d_out, pairs * elem, "the LCS triangle");
+    if (!rc) rc = reserve_big(ctx, ctx->d_dist, pairs * sizeof(float), "the float distance triangle");
+    if (rc) return rc;
+    rc = run_rows(ctx, L, lcsgpu::MODE_TRIANGLE, nullptr, 0, n, nullptr, 0, n - 1, L.d_out.p, 0, 0, elem);
     if (rc) return rc;
     auto a16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
     const size_t o_sum = 0, o_tmp = o_sum + a16((size_t)n * 4), o_pq = o_tmp + a16((size_t)n * 4),

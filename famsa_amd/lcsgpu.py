@@ -53,6 +53,13 @@ def load_library():
         "lcsgpu_lcs_triangle_ids": (C.c_int, [vp, pi32, i32, vp, C.c_int]),
         "lcsgpu_row_minima_dev": (C.c_int, [vp, vp, C.c_int, i32, i32, C.c_int, vp, C.c_int]),
         "lcsgpu_mst_prim": (C.c_int, [vp, C.c_int, vp]),
+        "lcsgpu_mst_shard_begin": (C.c_int, [vp, vp, C.c_int, i32, i32, C.c_int]),
+        "lcsgpu_mst_shard_best": (C.c_int, [vp, vp, vp]),
+        "lcsgpu_mst_shard_merge": (C.c_int, [vp, vp, i32, pi32]),
+        "lcsgpu_mst_shard_finish": (C.c_int, [vp, vp]),
+        "lcsgpu_mst_merge_host": (C.c_int, [vp, i32, i32, vp, vp, pi32]),
+        "lcsgpu_mst_shard_set_components": (C.c_int, [vp, vp]),
+        "lcsgpu_mst_order_edges": (C.c_int, [vp, i32]),
         "lcsgpu_upgma": (C.c_int, [vp, C.c_int, C.c_int, vp, vp]),
         "lcsgpu_nj": (C.c_int, [vp, C.c_int, vp, vp]),
         "lcsgpu_lcs_triangles_batch": (C.c_int, [vp, pi32, C.POINTER(C.c_int64), i32, vp, C.c_int]),
@@ -69,6 +76,36 @@ def load_library():
         fn.argtypes = args
     _LIB = lib
     return lib
+
+
+MST_EDGE = np.dtype([("from", np.int32), ("to", np.int32), ("dist", np.float64)])  # lcsgpu_mst_edge
+MST_KEY = np.dtype([("dist_bits", np.uint64), ("id", np.uint64)])                  # lcsgpu_mst_key
+MST_TRIANGLE_ORIENTATION = 0x100
+
+
+def mst_merge_host(keys, comp, edges, n_edges):
+    """lcsgpu_mst_merge_host: keys [n_parts, n] MST_KEY (host), comp int32[n] and edges MST_EDGE[n-1]
+    updated in place; returns the new edge count.  Pure host code -- works without a GPU."""
+    lib = load_library()
+    keys = np.ascontiguousarray(keys, dtype=MST_KEY)
+    n_parts, n = keys.shape
+    assert comp.dtype == np.int32 and comp.flags.c_contiguous and len(comp) == n
+    assert edges.dtype == MST_EDGE and edges.flags.c_contiguous and len(edges) >= max(n - 1, 0)
+    cnt = C.c_int32(int(n_edges))
+    rc = lib.lcsgpu_mst_merge_host(keys.ctypes.data, n_parts, n, comp.ctypes.data, edges.ctypes.data, C.byref(cnt))
+    if rc:
+        raise LcsGpuError(f"lcsgpu error {rc}: {lib.lcsgpu_last_error().decode()}")
+    return cnt.value
+
+
+def mst_order_edges(edges, n):
+    """lcsgpu_mst_order_edges: in place, into Prim's insertion order from vertex 0.  Pure host code."""
+    lib = load_library()
+    assert edges.dtype == MST_EDGE and edges.flags.c_contiguous and len(edges) == max(n - 1, 0)
+    rc = lib.lcsgpu_mst_order_edges(edges.ctypes.data if len(edges) else None, n)
+    if rc:
+        raise LcsGpuError(f"lcsgpu error {rc}: {lib.lcsgpu_last_error().decode()}")
+    return edges
 
 
 def _ids(a):
@@ -196,9 +233,35 @@ class LcsGpu:
 
     def mst_prim(self, kind=1):
         """Edges of Prim's MST in insertion order: structured array (from, to, dist)."""
-        dt = np.dtype([("from", np.int32), ("to", np.int32), ("dist", np.float64)])
-        out = np.zeros(max(self.n - 1, 0), dtype=dt)
+        out = np.zeros(max(self.n - 1, 0), dtype=MST_EDGE)
         self._check(self._lib.lcsgpu_mst_prim(self._ctx, kind, out.ctypes.data if out.size else None))
+        return out
+
+    # ---- sharded MST (Boruvka over row blocks; one context per GPU) ----
+    def mst_shard_begin(self, d_tri_ptr, elem_size, row_begin, row_end, kind=1):
+        self._check(self._lib.lcsgpu_mst_shard_begin(self._ctx, C.c_void_p(d_tri_ptr), elem_size, row_begin, row_end, kind))
+
+    def mst_shard_best(self, d_keys_ptr=None, host=False):
+        """Local half of a round into device memory (d_keys_ptr) and/or a host array (returned when host=True)."""
+        h = np.zeros(self.n, dtype=MST_KEY) if host else None
+        self._check(self._lib.lcsgpu_mst_shard_best(self._ctx, C.c_void_p(d_keys_ptr) if d_keys_ptr else None,
+                                                    h.ctypes.data if host else None))
+        return h
+
+    def mst_shard_merge(self, d_gathered_ptr, n_parts):
+        cnt = C.c_int32(0)
+        self._check(self._lib.lcsgpu_mst_shard_merge(self._ctx, C.c_void_p(d_gathered_ptr) if d_gathered_ptr else None,
+                                                     n_parts, C.byref(cnt)))
+        return cnt.value
+
+    def mst_shard_set_components(self, comp):
+        comp = np.ascontiguousarray(comp, dtype=np.int32)
+        assert len(comp) == self.n
+        self._check(self._lib.lcsgpu_mst_shard_set_components(self._ctx, comp.ctypes.data))
+
+    def mst_shard_finish(self):
+        out = np.zeros(max(self.n - 1, 0), dtype=MST_EDGE)
+        self._check(self._lib.lcsgpu_mst_shard_finish(self._ctx, out.ctypes.data if out.size else None))
         return out
 
     def upgma(self, kind=1, modified=False):

@@ -97,3 +97,25 @@ def to_fasta(codes, offsets, path, prefix="s"):
             f.write(f">{prefix}{i}\n")
             f.write("".join(ALPHABET[c] for c in s))
             f.write("\n")
+
+
+def family_fasta(n, length, path, seed=1234):
+    """Large 'family' FASTA written in blocks (the C5 shape: one ancestor, 25 % substitutions, member
+    lengths uniform in [0.7*length, length]), ids s<i>.  Deterministic; used by the at-size tests, the
+    golden generator (oracle/make_golden_large.py) and the end-to-end timing scripts."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    anc = rng.integers(0, 20, size=length, dtype=np.uint8)
+    A = np.frombuffer(ALPHABET.encode(), dtype=np.uint8)
+    with open(path, "wb") as out:
+        B = 20000
+        for b0 in range(0, n, B):
+            m = min(B, n - b0)
+            S = np.tile(anc, (m, 1))
+            mut = rng.random((m, length)) < 0.25
+            S[mut] = rng.integers(0, 20, size=int(mut.sum()), dtype=np.uint8)
+            lens = rng.integers(int(length * 0.7), length + 1, size=m)
+            for i in range(m):
+                out.write(b">s%d\n" % (b0 + i))
+                out.write(A[S[i, : lens[i]]].tobytes())
+                out.write(b"\n")
+    return path

@@ -173,6 +173,55 @@ int lcsgpu_mst_prim(lcsgpu_ctx* ctx, int distance_kind, lcsgpu_mst_edge* out_edg
  * LCS(ref = the node just added).  The two differ only for orientation-sensitive sequences. */
 #define LCSGPU_MST_TRIANGLE_ORIENTATION 0x100
 
+/* ---- Single linkage over SEVERAL GPUs: the N x N pair space tiled by row block (one context / process per
+ * GPU, each holding the whole uploaded set and rows [row_begin, row_end) of the LCS triangle in its HBM),
+ * Boruvka rounds with ONE exchange per round.  The edge order of MSTPrim (tree/MSTPrim.cpp:493-509,
+ * tree/MSTPrim.h:424-483) is strict and total, so the minimum spanning tree is unique and this yields
+ * exactly the edges MSTPrim::run_view (tree/MSTPrim.cpp:356-533) finds; their insertion order from vertex 0
+ * (cpp:372-391), which the dendrogram needs (cpp:784-833), is a walk over the tree (lcsgpu_mst_order_edges).
+ *
+ * A round:  (1) every context: lcsgpu_mst_shard_best -> n keys of 16 bytes: per vertex, the best edge into
+ * another component among the pairs of the context's row block (round 0: the per-row minima, completed by
+ * the per-column minima);  (2) the caller exchanges the key arrays -- an all-gather of n x 16 B per GPU
+ * (RCCL over xGMI between processes: torch.distributed.all_gather_into_tensor in bench.py; host memory
+ * between the contexts of one process);  (3) every context: lcsgpu_mst_shard_merge over the n_parts x n
+ * gathered keys (device memory), or one lcsgpu_mst_merge_host over them in host memory followed by
+ * lcsgpu_mst_shard_set_components on every context.  Rounds repeat until n-1 edges are found (<= log2 n).
+ * The component labels are a pure function of the exchanged keys: every context derives the same ones.
+ *
+ * Not available (LCSGPU_E_UNSUPPORTED) when an uploaded sequence is orientation sensitive and MSTPrim's own
+ * orientation is asked for (no LCSGPU_MST_TRIANGLE_ORIENTATION): lcsgpu_mst_prim handles that on one GPU. */
+typedef struct lcsgpu_mst_key {
+    uint64_t dist_bits; /* bit pattern of the double distance (>= 0, so the bits order like the values); bits of DBL_MAX = none */
+    uint64_t id;        /* ~(((uint64_t)min(u,v) << 32) + max(u,v));  ~0 = none */
+} lcsgpu_mst_key;
+
+/* d_triangle: DEVICE memory holding rows [row_begin, row_end) as lcsgpu_lcs_triangle_dev wrote them; it must
+ * stay valid until the last lcsgpu_mst_shard_best.  Resets the component state (every vertex on its own).
+ * distance_kind may carry LCSGPU_MST_TRIANGLE_ORIENTATION. */
+int lcsgpu_mst_shard_begin(lcsgpu_ctx* ctx, const void* d_triangle, int elem_size, int32_t row_begin, int32_t row_end,
+                           int distance_kind);
+/* Local half of a round.  d_keys: DEVICE buffer of n lcsgpu_mst_key (NULL = a buffer of the context);
+ * h_keys: if not NULL, the keys are also copied to this HOST buffer and the call returns when they are
+ * there; otherwise the work is queued on the context's stream (lcsgpu_stream) and the call returns at once. */
+int lcsgpu_mst_shard_best(lcsgpu_ctx* ctx, void* d_keys, lcsgpu_mst_key* h_keys);
+/* Global half of a round on the device: d_gathered = n_parts x n keys (DEVICE; part p at d_gathered + p*n),
+ * every part's lcsgpu_mst_shard_best output of this round.  *n_edges (may be NULL) = tree edges found so far
+ * (the call waits for the round). */
+int lcsgpu_mst_shard_merge(lcsgpu_ctx* ctx, const void* d_gathered, int32_t n_parts, int32_t* n_edges);
+/* After the last round (n-1 edges): the edges in the order Prim's algorithm adds them from vertex 0, as
+ * lcsgpu_mst_prim returns them (HOST, n-1 records). */
+int lcsgpu_mst_shard_finish(lcsgpu_ctx* ctx, lcsgpu_mst_edge* out_edges);
+/* Host form of the global half -- no GPU, no context: keys = n_parts x n (HOST); comp[n] (in/out) the
+ * component label of every vertex (initially comp[v] = v); the round's new tree edges are appended to
+ * edges[*n_edges ...] and *n_edges is advanced.  Afterwards hand comp to every context: */
+int lcsgpu_mst_merge_host(const lcsgpu_mst_key* keys, int32_t n_parts, int32_t n, int32_t* comp, lcsgpu_mst_edge* edges,
+                          int32_t* n_edges);
+int lcsgpu_mst_shard_set_components(lcsgpu_ctx* ctx, const int32_t* comp);
+/* The n-1 edges of a spanning tree, in place, into Prim's insertion order from vertex 0 with MSTPrim's
+ * candidate order (tree/MSTPrim.cpp:372-391).  Host only. */
+int lcsgpu_mst_order_edges(lcsgpu_mst_edge* edges, int32_t n);
+
 /* UPGMA (or MAFFT-style "modified" UPGMA) over the uploaded set, entirely on the device: LCS
  * triangle -> float distances (Transform<float, kind>: host-built (float)pow(indel,0.75) table,
  * IEEE float division) -> n-1 merges with the nearest-neighbour-array algorithm of the reference,

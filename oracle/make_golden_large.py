@@ -1,0 +1,112 @@
+#!/usr/bin/env python3
+"""At-size fixtures (BASELINE configs C3, C4, C5) from the REFERENCE itself
+(oracle/_ref/libfamsa_ref.so = /root/reference sources built by oracle/Makefile).  Build container
+only; minutes of CPU.  Writes tests/golden/meta_large.json (sha256 values only -- the data is
+regenerated deterministically by famsa_amd/seqio.py on the GPU box).
+
+    python oracle/make_golden_large.py [c3] [c4] [c5]        (default: all)
+
+Model: the reference's own at-size regression, .github/workflows/self-hosted.yml:424-461."""
+import hashlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import oracle_bind  # noqa: E402
+from famsa_amd import seqio  # noqa: E402
+
+OUT = os.path.join(oracle_bind.GOLDEN, "meta_large.json")
+THREADS = len(os.sched_getaffinity(0))
+
+
+def sha(b):
+    return hashlib.sha256(b).hexdigest()
+
+
+def load():
+    return json.load(open(OUT)) if os.path.exists(OUT) else {}
+
+
+def save(meta):
+    json.dump(meta, open(OUT, "w"), indent=1, sort_keys=True)
+
+
+def c3(ref, meta):
+    n, L = 10000, 400
+    codes, offsets = seqio.synth_uniform(n, L)
+    path = "/tmp/golden_synth10k.fasta"
+    seqio.to_fasta(codes, offsets, path)
+    h = ref.open_fasta(path)
+    rec = {"n": n, "len": L, "codes_sha256": sha(codes.tobytes())}
+    t0 = time.time()
+    hh = hashlib.sha256()  # rows in order = the packed triangle, ref = row i, partner = column j < i
+    step = 500  # ref_lcs_rect copies the whole set per call: ask for many rows at a time
+    for i0 in range(0, n, step):
+        i1 = min(n, i0 + step)
+        m = ref.lcs_rect(h, np.arange(i0, i1), np.arange(i1 - 1), isa=2).astype(np.uint16)
+        for i in range(max(i0, 1), i1):
+            hh.update(m[i - i0, :i].tobytes())
+    rec["triangle_u16_sha256"] = hh.hexdigest()
+    print("c3 triangle %.0f s" % (time.time() - t0), flush=True)
+    for gt in ("sl", "slink", "upgma"):
+        t0 = time.time()
+        rec[f"{gt}_newick_sha256"] = sha(ref.tree(h, gt, threads=THREADS))
+        print("c3", gt, "%.0f s" % (time.time() - t0), flush=True)
+    ref.close(h)
+    meta["synth10k"] = rec
+    save(meta)
+
+
+def c4(ref, meta):
+    n, L = 100000, 400
+    codes, offsets = seqio.synth_uniform(n, L)
+    path = "/tmp/golden_synth100k.fasta"
+    seqio.to_fasta(codes, offsets, path)
+    h = ref.open_fasta(path)
+    rec = meta.get("synth100k", {"n": n, "len": L, "codes_sha256": sha(codes.tobytes())})
+    for gt in ("sl",):
+        t0 = time.time()
+        rec[f"{gt}_newick_sha256"] = sha(ref.tree(h, gt, threads=THREADS))
+        rec[f"{gt}_reference_seconds_{THREADS}_threads"] = round(time.time() - t0, 1)
+        print("c4", gt, "%.0f s" % (time.time() - t0), flush=True)
+        meta["synth100k"] = rec
+        save(meta)
+    ref.close(h)
+
+
+def c5(ref, meta):
+    for n in (200000, 1000000):
+        path = f"/tmp/golden_family_{n}_300.fasta"
+        seqio.family_fasta(n, 300, path)
+        fh = hashlib.sha256()
+        with open(path, "rb") as f:
+            for blk in iter(lambda: f.read(1 << 24), b""):
+                fh.update(blk)
+        h = ref.open_fasta(path)
+        t0 = time.time()
+        nw = ref.tree(h, "upgma", heuristic=2, threads=THREADS)  # -medoidtree -gt upgma, default parameters
+        rec = {"n": n, "len": 300, "fasta_sha256": fh.hexdigest(), "medoid_upgma_newick_sha256": sha(nw),
+               "newick_bytes": len(nw), f"reference_seconds_{THREADS}_threads": round(time.time() - t0, 1)}
+        print("c5", n, "%.0f s" % (time.time() - t0), flush=True)
+        ref.close(h)
+        meta[f"family{n}"] = rec
+        save(meta)
+
+
+def main():
+    which = sys.argv[1:] or ["c3", "c5", "c4"]
+    ref = oracle_bind.Ref()
+    meta = load()
+    for w in which:
+        {"c3": c3, "c4": c4, "c5": c5}[w](ref, meta)
+    print(json.dumps(load(), indent=1))
+
+
+if __name__ == "__main__":
+    main()
