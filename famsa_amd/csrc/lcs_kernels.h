@@ -110,7 +110,8 @@ struct BoruvkaArgs {
     int64_t off;                //   element (u, v), v < u, at tri[u(u-1)/2 + v - off], off = r0(r0-1)/2
     int32_t r0, r1;
     const uint32_t* lens;
-    const double* pow_table;    // pow(i, 0.75) from the host's libm (the reference's values)
+    const double* pow_table;    // pow(i, 0.75), i < pow_n, from the host's libm (the reference's values)
+    int32_t pow_n, pow_in_lds;  // staged in LDS by the passes when it fits
     int32_t* comp;              // [n] component (= id of its root vertex) of every vertex -- replicated on every GPU
     int32_t* comp_next;         // [n] ... after this round
     int32_t* parent;            // [n] hooking forest over the component roots

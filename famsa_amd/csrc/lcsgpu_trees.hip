@@ -37,7 +37,12 @@ static int shard_begin(lcsgpu_ctx* ctx, Lane& L, const void* d_tri, int elem, in
     const int32_t n = ctx->n;
     auto a256 = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const int32_t rows = r1 - r0;
-    const int n_chunks = std::max(1, std::min(32, (rows + 1023) / 1024));
+    // Row chunks of the column pass: long streams per lane (a lane's threshold matures after its first ~100
+    // rows; until then most of its candidates go the exact way), yet enough workgroups to fill the chip
+    // (n = 100 000, MST stage per step: 3 chunks 76 ms, 6: 65, 12: 58, 24: 58, 48: 60)
+    const int col_blocks = std::max(1, (r1 + 255) / 256);
+    int n_chunks = std::max(1, std::min({32, (4096 + col_blocks - 1) / col_blocks, (rows + 2047) / 2048}));
+    if (const char* e = getenv("LCSGPU_MST_CHUNKS")) n_chunks = std::max(1, std::min(64, atoi(e))); // measurement aid
     const int rows_per_chunk = std::max(1, (rows + n_chunks - 1) / n_chunks);
     const size_t key = sizeof(lcsgpu::MstKey);
     const size_t o_comp = 0, o_next = o_comp + a256((size_t)n * 4), o_par = o_next + a256((size_t)n * 4),
@@ -56,6 +61,8 @@ static int shard_begin(lcsgpu_ctx* ctx, Lane& L, const void* d_tri, int elem, in
     b.r1 = r1;
     b.lens = (const uint32_t*)ctx->d_lens.p;
     b.pow_table = (const double*)ctx->d_pow.p;
+    b.pow_n = (int32_t)std::min<uint64_t>((uint64_t)2 * ctx->max_len + 1, 0x7fffffff);
+    b.pow_in_lds = (kind == 1 && (size_t)b.pow_n * sizeof(double) <= 48 * 1024) ? 1 : 0;
     b.comp = (int32_t*)(base + o_comp);
     b.comp_next = (int32_t*)(base + o_next);
     b.parent = (int32_t*)(base + o_par);

@@ -43,9 +43,14 @@ int fail(const std::exception& e)
     g_error = e.what();
     return -1;
 }
+// -1 is the error code of every entry point; a result that does not fit returns -(bytes needed) - 1 <= -2
+// (bytes needed = size + 1 for the terminator) and says so in the error text
 long give(const std::string& s, char* out, long cap)
 {
-    if ((long)s.size() + 1 > cap) return -(long)s.size() - 1;
+    if ((long)s.size() + 1 > cap) {
+        g_error = "buffer too small: need " + std::to_string(s.size() + 1) + " bytes";
+        return -(long)(s.size() + 1) - 1;
+    }
     memcpy(out, s.c_str(), s.size() + 1);
     return (long)s.size();
 }

@@ -78,7 +78,16 @@ void parse_piece(const char* p, const char* end, Piece& out)
 {
     std::string id;
     bool have_id = false;
+    // the reference tests the RAW residue text of the pending record (io_service.h:108,122): a record
+    // whose lines hold only gaps is kept, as a sequence of length 0
+    bool have_residues = false;
     size_t seq_begin = 0; // residues of the pending record start here in out.codes
+    auto emit = [&] {
+        out.ids.push_back(id);
+        out.ends.push_back(out.codes.size());
+        seq_begin = out.codes.size();
+        have_residues = false;
+    };
     while (p < end) {
         const char* nl = (const char*)memchr(p, '\n', (size_t)(end - p));
         const char* line_end = nl ? nl : end;
@@ -86,24 +95,17 @@ void parse_piece(const char* p, const char* end, Piece& out)
         while (line_end > p && (line_end[-1] == '\n' || line_end[-1] == '\r')) --line_end;
         if (line_end > p) {
             if (*p == '>') {
-                if (have_id && out.codes.size() > seq_begin) {
-                    out.ids.push_back(id);
-                    out.ends.push_back(out.codes.size());
-                    seq_begin = out.codes.size();
-                }
+                if (have_id && have_residues) emit();
                 id.assign(p, line_end);
                 have_id = true;
             } else {
                 append_codes(out.codes, p, (size_t)(line_end - p));
+                have_residues = true;
             }
         }
         p = next;
     }
-    if (have_id && out.codes.size() > seq_begin) {
-        out.ids.push_back(id);
-        out.ends.push_back(out.codes.size());
-        seq_begin = out.codes.size();
-    }
+    if (have_id && have_residues) emit();
     out.codes.resize(seq_begin); // residues that never got a record (no header at all)
 }
 

@@ -42,18 +42,25 @@ class Host:
 
     HEUR = {None: 0, "parttree": 1, "medoidtree": 2}
 
+    def _text(self, call, cap=1 << 25):
+        """Run a text-returning entry point; -1 = error, <= -2 = the buffer must hold -(n + 1) bytes: retry."""
+        for _ in range(2):
+            buf = C.create_string_buffer(cap)
+            n = call(buf)
+            if n >= 0:
+                return buf.raw[:n]
+            if n == -1:
+                raise self._err()
+            cap = -(n + 1)
+        raise self._err()
+
     def tree_from_matrix(self, fasta, square, method, distance="indel075_div_lcs", keep_duplicates=False,
                          heuristic=None, subtree_size=0, sample_size=0, threshold=0, cluster_fraction=0.0,
                          cluster_iters=0):
         sq = np.ascontiguousarray(square, np.uint32)
-        buf = C.create_string_buffer(1 << 25)
-        n = self.lib.famsa_host_tree_from_matrix(fasta.encode(), sq.ctypes.data, method.encode(), DIST[distance],
-                                                 int(keep_duplicates), self.HEUR[heuristic], subtree_size,
-                                                 sample_size, threshold, cluster_fraction, cluster_iters, buf,
-                                                 len(buf))
-        if n < 0:
-            raise self._err()
-        return buf.raw[:n]
+        return self._text(lambda buf: self.lib.famsa_host_tree_from_matrix(
+            fasta.encode(), sq.ctypes.data, method.encode(), DIST[distance], int(keep_duplicates), self.HEUR[heuristic],
+            subtree_size, sample_size, threshold, cluster_fraction, cluster_iters, buf, len(buf)))
 
     def dist_export_from_matrix(self, fasta, square, path, distance="indel075_div_lcs", square_matrix=False,
                                 pid=False):
@@ -64,13 +71,9 @@ class Host:
 
     def tree_gpu(self, fasta, method, distance="indel075_div_lcs", keep_duplicates=False, device=0, heuristic=None,
                  subtree_size=0, sample_size=0, threshold=0, cluster_fraction=0.0, cluster_iters=0):
-        buf = C.create_string_buffer(1 << 25)
-        n = self.lib.famsa_host_tree_gpu(fasta.encode(), device, method.encode(), DIST[distance],
-                                         int(keep_duplicates), self.HEUR[heuristic], subtree_size, sample_size,
-                                         threshold, cluster_fraction, cluster_iters, buf, len(buf))
-        if n < 0:
-            raise self._err()
-        return buf.raw[:n]
+        return self._text(lambda buf: self.lib.famsa_host_tree_gpu(
+            fasta.encode(), device, method.encode(), DIST[distance], int(keep_duplicates), self.HEUR[heuristic],
+            subtree_size, sample_size, threshold, cluster_fraction, cluster_iters, buf, len(buf)))
 
     def dist_export_gpu(self, fasta, path, distance="indel075_div_lcs", square_matrix=False, pid=False, device=0):
         if self.lib.famsa_host_dist_export_gpu(fasta.encode(), device, DIST[distance], int(square_matrix), int(pid),

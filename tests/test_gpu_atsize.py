@@ -1,0 +1,157 @@
+"""BASELINE configs at their size on the GPU, against sha256 values produced once by the REFERENCE itself
+(oracle/make_golden_large.py -> tests/golden/meta_large.json; the inputs are regenerated here by the same
+deterministic generators).  Model: the reference's own at-size regression, .github/workflows/self-hosted.yml:424-461.
+
+  C3  synthetic 10 000 x 400 aa: the u16 LCS triangle and the sl / slink / upgma Newick
+  C4  synthetic 100 000 x 400 aa: -gt sl Newick (one GPU; the 2-context row-block form too), sampled oracle check
+  C5  'family' sets of 200 000 and 1 000 000 sequences: -medoidtree -gt upgma Newick
+      (3 000 000: FAMSA_TEST_HUGE=1 -- device CLARANS + 16 threads against host CLARANS + 1 thread)
+"""
+import hashlib
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import famsa_amd
+from famsa_amd import seqio
+from famsa_amd.hostlib import CLI
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+META = json.load(open(os.path.join(ROOT, "tests", "golden", "meta_large.json")))
+
+
+def sha(b):
+    return hashlib.sha256(b).hexdigest()
+
+
+def file_sha(path):
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 24), b""):
+            h.update(blk)
+    return h.hexdigest()
+
+
+def cli(*args, env=None):
+    e = dict(os.environ)
+    e.update(env or {})
+    p = subprocess.run([CLI, *args], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=e)
+    assert p.returncode == 0, p.stderr[-2000:]
+    return p
+
+
+@pytest.fixture(scope="module")
+def synth10k(tmp_path_factory):
+    codes, offsets = seqio.synth_uniform(10000, 400)
+    assert sha(codes.tobytes()) == META["synth10k"]["codes_sha256"]
+    path = str(tmp_path_factory.mktemp("c3") / "synth10k.fasta")
+    seqio.to_fasta(codes, offsets, path)
+    return codes, offsets, path
+
+
+@pytest.fixture(scope="module")
+def synth100k(tmp_path_factory):
+    codes, offsets = seqio.synth_uniform(100000, 400)
+    assert sha(codes.tobytes()) == META["synth100k"]["codes_sha256"]
+    path = str(tmp_path_factory.mktemp("c4") / "synth100k.fasta")
+    seqio.to_fasta(codes, offsets, path)
+    return codes, offsets, path
+
+
+def test_c3_triangle(engine, synth10k):
+    codes, offsets, _ = synth10k
+    engine.upload(codes, offsets)  # fixed length, generator order: the reference's rows are the same sequences
+    assert sha(engine.lcs_triangle().tobytes()) == META["synth10k"]["triangle_u16_sha256"]
+
+
+@pytest.mark.parametrize("gt", ["sl", "slink", "upgma"])
+def test_c3_trees(synth10k, gt):
+    got = famsa_amd.guide_tree(synth10k[2], gt)
+    assert sha(got) == META["synth10k"][f"{gt}_newick_sha256"]
+
+
+def test_c4_single_linkage_tree(synth100k, tmp_path):
+    out = str(tmp_path / "sl.dnd")
+    cli("-gt", "sl", "-gt_export", synth100k[2], out)
+    assert file_sha(out) == META["synth100k"]["sl_newick_sha256"]
+
+
+def test_c4_row_block_contexts_tree_and_sampled_triangle(oracle, synth100k):
+    """C4's shape on one GPU: two contexts holding the two row blocks of the 100 000-sequence triangle (5 GB
+    each), Boruvka rounds with the key exchange in device memory; 6000 sampled pairs against the oracle; the
+    edges must be the single-context MST's (whose Newick the test above pins to the reference)."""
+    import torch
+    from famsa_amd.rowblock import row_cuts, pairs_in_rows, edge_list_sha256
+    codes, offsets, _ = synth100k
+    n = 100000
+    cuts = row_cuts(n, 2)
+    engs, tris = [], []
+    for p in range(2):
+        e = famsa_amd.LcsGpu(0)
+        e.upload(codes, offsets)
+        t = torch.empty(pairs_in_rows(cuts[p], cuts[p + 1]), dtype=torch.int16, device="cuda:0")
+        e.lcs_triangle_dev(cuts[p], cuts[p + 1], t.data_ptr(), 2, sync=True)
+        engs.append(e)
+        tris.append(t)
+    try:
+        rng = np.random.Generator(np.random.PCG64(4))
+        o = offsets.astype(np.int64)
+        for p in range(2):
+            r0, r1 = cuts[p], cuts[p + 1]
+            rows = rng.integers(max(r0, 1), r1, size=3000)
+            cols = (rng.random(3000) * rows).astype(np.int64)
+            idx = rows * (rows - 1) // 2 + cols - r0 * (r0 - 1) // 2
+            got = tris[p][torch.from_numpy(idx).cuda()].cpu().numpy().astype(np.int64) & 0xFFFF
+            for k in range(3000):
+                i, j = int(rows[k]), int(cols[k])
+                assert got[k] == oracle.lcs(codes[o[i]:o[i + 1]], codes[o[j]:o[j + 1]]), (i, j)
+        for p, e in enumerate(engs):
+            e.mst_shard_begin(tris[p].data_ptr(), 2, cuts[p], cuts[p + 1], 1)
+        keys = [torch.zeros(2 * n, dtype=torch.int64, device="cuda:0") for _ in engs]
+        found = 0
+        while found < n - 1:
+            for e, k in zip(engs, keys):
+                e.mst_shard_best(k.data_ptr())
+            for e in engs:
+                e.sync()
+            gathered = torch.cat(keys)
+            torch.cuda.synchronize()
+            found = [e.mst_shard_merge(gathered.data_ptr(), 2) for e in engs][0]
+        sharded = [e.mst_shard_finish() for e in engs]
+        del tris, keys, gathered
+        torch.cuda.empty_cache()
+        single = engs[0].mst_prim(1)
+        assert edge_list_sha256(sharded[0]) == edge_list_sha256(sharded[1]) == edge_list_sha256(single)
+    finally:
+        for e in engs:
+            e.close()
+
+
+@pytest.mark.parametrize("n", [200000, 1000000])
+def test_c5_medoid_tree(tmp_path, n):
+    rec = META[f"family{n}"]
+    path = str(tmp_path / f"family_{n}.fasta")
+    seqio.family_fasta(n, rec["len"], path)
+    assert file_sha(path) == rec["fasta_sha256"]
+    out = str(tmp_path / "medoid.dnd")
+    cli("-medoidtree", "-gt", "upgma", "-gt_export", path, out)
+    assert os.path.getsize(out) == rec["newick_bytes"]
+    assert file_sha(out) == rec["medoid_upgma_newick_sha256"]
+
+
+@pytest.mark.skipif(not os.environ.get("FAMSA_TEST_HUGE"), reason="3 000 000 sequences: minutes; set FAMSA_TEST_HUGE=1")
+def test_c5_three_million(tmp_path):
+    """No reference run exists at this size (it would take ~6 min on 8 cores per run): the default path
+    (device CLARANS, all granted host threads, batched leaves) against the plainest one this engine has
+    (host CLARANS, one host thread) -- the two share only the LCS kernels."""
+    path = str(tmp_path / "family_3m.fasta")
+    seqio.family_fasta(3000000, 300, path)
+    a, b = str(tmp_path / "a.dnd"), str(tmp_path / "b.dnd")
+    cli("-medoidtree", "-gt", "upgma", "-gt_export", path, a)
+    cli("-medoidtree", "-gt", "upgma", "-t", "1", "-gt_export", path, b, env={"FAMSA_CLARANS_HOST": "1"})
+    assert file_sha(a) == file_sha(b)
+    open(os.path.join(ROOT, "gpurun_out", "c5_3m_newick_sha256.txt"), "w").write(file_sha(a) + "\n")

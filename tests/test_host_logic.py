@@ -220,6 +220,9 @@ def test_parallel_fasta_reader_matches_the_serial_semantics(host, oracle, tmp_pa
         chunks.append(b">seq%d some description" % i + eol)
         if i % 97 == 5:
             continue  # a header without residues: the next header replaces it
+        if i % 101 == 7:
+            chunks.append(b"--" + eol + b"-" + eol)  # residue lines of gaps only: kept, as a sequence of length 0
+            continue
         length = int(rng.integers(1, 700))
         res = alpha[rng.integers(0, len(alpha), size=length)].tobytes()
         for a in range(0, length, 60):
