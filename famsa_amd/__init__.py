@@ -5,6 +5,6 @@ The product is the C-ABI shared library ``liblcsgpu.so`` (``include/lcsgpu.h``; 
 thin ctypes binding used by the tests and ``bench.py`` (``LcsGpu`` = the C-ABI, ``guide_tree`` /
 ``dist_export`` = the host layer); it never computes an LCS itself and raises if the HIP library is missing.
 """
-from .lcsgpu import LcsGpu, LcsGpuError, load_library, library_path  # noqa: F401
+from .lcsgpu import LcsGpu, LcsGpuGroup, LcsGpuError, load_library, library_path  # noqa: F401
 from . import seqio  # noqa: F401
 from .hostlib import guide_tree, dist_export  # noqa: F401,E402

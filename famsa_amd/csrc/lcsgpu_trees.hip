@@ -2,6 +2,7 @@
 // per-row minima: the LCS triangle stays in HBM, the kernels of tree_kernels.hip consume it there.
 #include "lcsgpu_internal.h"
 
+#include <memory>
 #include <queue>
 
 using namespace lcsgpu_impl;
@@ -398,24 +399,119 @@ int lcsgpu_mst_prim(lcsgpu_ctx* ctx, int distance_kind, lcsgpu_mst_edge* out_edg
     return LCSGPU_OK;
 }
 
-int lcsgpu_upgma(lcsgpu_ctx* ctx, int distance_kind, int modified, int32_t* out_left, int32_t* out_right)
+} // extern "C"
+
+// ---- several contexts (one per GPU) working on ONE problem ------------------------------------------
+namespace {
+
+// lane 0 of every context, taken in address order (two multi-context calls cannot deadlock each other)
+struct MultiGuard {
+    std::vector<std::unique_ptr<LaneGuard>> guards; // index = position in the caller's context list
+    std::vector<Lane*> lanes;
+    MultiGuard(lcsgpu_ctx* const* ctxs, int n)
+    {
+        std::vector<int> order(n);
+        for (int i = 0; i < n; ++i) order[i] = i;
+        std::sort(order.begin(), order.end(), [&](int a, int b) { return ctxs[a] < ctxs[b]; });
+        guards.resize(n);
+        lanes.resize(n);
+        for (int i : order) {
+            guards[i].reset(new LaneGuard(ctxs[i], LaneGuard::LANE0));
+            lanes[i] = &guards[i]->lane();
+        }
+    }
+};
+
+int check_multi(lcsgpu_ctx* const* ctxs, int32_t n_ctx)
 {
-    if (!ctx) return fail(LCSGPU_E_INVALID, "NULL ctx");
-    if (ctx->n < 0) return fail(LCSGPU_E_STATE, "no sequence set uploaded");
-    if (distance_kind != LCSGPU_DIST_INDEL_DIV_LCS && distance_kind != LCSGPU_DIST_INDEL075_DIV_LCS)
-        return fail(LCSGPU_E_INVALID, "unknown distance kind %d", distance_kind);
-    const int32_t n = ctx->n;
-    if (n < 2) return LCSGPU_OK;
-    if (!out_left || !out_right) return fail(LCSGPU_E_INVALID, "NULL output");
-    LaneGuard guard(ctx, LaneGuard::LANE0);
-    Lane& L = guard.lane();
-    HIP_TRY(hipSetDevice(ctx->device));
-    const int elem = ctx->max_len > 65535 ? 4 : 2;
-    const size_t pairs = (size_t)n * (n - 1) / 2;
-    int rc = reserve_big(ctx, L.d_out, pairs * elem, "the LCS triangle");
-    if (!rc) rc = reserve_big(ctx, ctx->d_dist, pairs * sizeof(float), "the float distance triangle");
+    if (!ctxs || n_ctx < 1) return fail(LCSGPU_E_INVALID, "no contexts");
+    for (int k = 0; k < n_ctx; ++k) {
+        if (!ctxs[k]) return fail(LCSGPU_E_INVALID, "NULL ctx");
+        if (ctxs[k]->n < 0) return fail(LCSGPU_E_STATE, "no sequence set uploaded");
+        for (int j = 0; j < k; ++j)
+            if (ctxs[j] == ctxs[k]) return fail(LCSGPU_E_INVALID, "the same context twice");
+        if (ctxs[k]->n != ctxs[0]->n || ctxs[k]->lens != ctxs[0]->lens)
+            return fail(LCSGPU_E_STATE, "context %d holds a different sequence set than context 0", k);
+    }
+    return LCSGPU_OK;
+}
+
+// row-block boundaries with (nearly) equal pair counts over rows [r0, r1): row i holds i pairs
+std::vector<int32_t> equal_pair_cuts(int32_t r0, int32_t r1, int parts)
+{
+    std::vector<int32_t> cut(parts + 1, r1);
+    cut[0] = r0;
+    const double p0 = (double)r0 * (r0 - 1) / 2, p1 = (double)r1 * (r1 - 1) / 2;
+    for (int k = 1; k < parts; ++k) {
+        const double target = p0 + (p1 - p0) * k / parts; // pairs below the cut
+        const int32_t r = (int32_t)std::floor(0.5 + std::sqrt(0.25 + 2.0 * std::max(0.0, target)));
+        cut[k] = std::min(r1, std::max(cut[k - 1], r));
+    }
+    return cut;
+}
+
+int64_t tri_offset(int64_t r) { return r * (r - 1) / 2; }
+
+// The whole LCS triangle of the uploaded set into lane 0's result buffer of ctxs[0]: row blocks of equal
+// pair counts, one per context, each computed on its own GPU at the same time; the blocks of the other
+// contexts travel into place over xGMI (hipMemcpyPeerAsync on the producer's stream) -- the "all-gather of
+// u16 row blocks" of a matrix consumer that lives on one device.  No host thread per GPU is
+// needed: every launch and copy is asynchronous.
+int whole_triangle(lcsgpu_ctx* const* ctxs, int32_t n_ctx, MultiGuard& g, int elem)
+{
+    lcsgpu_ctx* c0 = ctxs[0];
+    Lane& L0 = *g.lanes[0];
+    const int32_t n = c0->n;
+    int rc = reserve_big(c0, L0.d_out, (size_t)tri_offset(n) * elem, "the LCS triangle");
     if (rc) return rc;
-    rc = run_rows(ctx, L, lcsgpu::MODE_TRIANGLE, nullptr, 0, n, nullptr, 0, n - 1, L.d_out.p, 0, 0, elem);
+    const std::vector<int32_t> cut = equal_pair_cuts(0, n, n_ctx);
+    std::vector<hipEvent_t> landed(n_ctx, nullptr);
+    struct Events {
+        std::vector<hipEvent_t>& v;
+        ~Events() { for (hipEvent_t e : v) if (e) (void)hipEventDestroy(e); }
+    } events{landed};
+    for (int k = 0; k < n_ctx; ++k) {
+        const int32_t r0 = cut[k], r1 = cut[k + 1];
+        if (r1 <= r0) continue;
+        Lane& L = *g.lanes[k];
+        void* dst = L0.d_out.p;
+        int64_t off = 0;
+        if (k > 0) {
+            off = tri_offset(r0);
+            rc = reserve_big(ctxs[k], L.d_out, (size_t)(tri_offset(r1) - off) * elem, "a row block of the LCS triangle");
+            if (rc) return rc;
+            dst = L.d_out.p;
+        }
+        rc = run_rows(ctxs[k], L, lcsgpu::MODE_TRIANGLE, nullptr, r0, r1 - r0, nullptr, 0, std::max(0, r1 - 1), dst, 0, off, elem, r0);
+        if (rc) return rc;
+        if (k > 0) {
+            const size_t bytes = (size_t)(tri_offset(r1) - off) * elem;
+            char* place = (char*)L0.d_out.p + (size_t)off * elem;
+            HIP_TRY(hipSetDevice(ctxs[k]->device));
+            if (ctxs[k]->device == c0->device)
+                HIP_TRY(hipMemcpyAsync(place, L.d_out.p, bytes, hipMemcpyDeviceToDevice, L.stream));
+            else
+                HIP_TRY(hipMemcpyPeerAsync(place, c0->device, L.d_out.p, ctxs[k]->device, bytes, L.stream));
+            HIP_TRY(hipEventCreateWithFlags(&landed[k], hipEventDisableTiming));
+            HIP_TRY(hipEventRecord(landed[k], L.stream));
+        }
+    }
+    HIP_TRY(hipSetDevice(c0->device));
+    for (int k = 1; k < n_ctx; ++k)
+        if (landed[k]) HIP_TRY(hipStreamWaitEvent(L0.stream, landed[k], 0));
+    for (int k = 1; k < n_ctx; ++k) { // the staging buffers of the plans and the events must outlive the work
+        if (!landed[k]) continue;
+        HIP_TRY(hipEventSynchronize(landed[k]));
+        g.lanes[k]->plan_in_flight = false;
+    }
+    return LCSGPU_OK;
+}
+
+int upgma_reduce(lcsgpu_ctx* ctx, Lane& L, int elem, int distance_kind, int modified, int32_t* out_left, int32_t* out_right)
+{
+    const int32_t n = ctx->n;
+    HIP_TRY(hipSetDevice(ctx->device));
+    int rc = reserve_big(ctx, ctx->d_dist, (size_t)tri_offset(n) * sizeof(float), "the float distance triangle");
     if (rc) return rc;
     const int blocks = (n + 255) / 256;
     auto a16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
@@ -456,24 +552,11 @@ int lcsgpu_upgma(lcsgpu_ctx* ctx, int distance_kind, int modified, int32_t* out_
     return LCSGPU_OK;
 }
 
-int lcsgpu_nj(lcsgpu_ctx* ctx, int distance_kind, int32_t* out_left, int32_t* out_right)
+int nj_reduce(lcsgpu_ctx* ctx, Lane& L, int elem, int distance_kind, int32_t* out_left, int32_t* out_right)
 {
-    if (!ctx) return fail(LCSGPU_E_INVALID, "NULL ctx");
-    if (ctx->n < 0) return fail(LCSGPU_E_STATE, "no sequence set uploaded");
-    if (distance_kind != LCSGPU_DIST_INDEL_DIV_LCS && distance_kind != LCSGPU_DIST_INDEL075_DIV_LCS)
-        return fail(LCSGPU_E_INVALID, "unknown distance kind %d", distance_kind);
     const int32_t n = ctx->n;
-    if (n < 2) return LCSGPU_OK;
-    if (!out_left || !out_right) return fail(LCSGPU_E_INVALID, "NULL output");
-    LaneGuard guard(ctx, LaneGuard::LANE0);
-    Lane& L = guard.lane();
     HIP_TRY(hipSetDevice(ctx->device));
-    const int elem = ctx->max_len > 65535 ? 4 : 2;
-    const size_t pairs = (size_t)n * (n - 1) / 2;
-    int rc = reserve_big(ctx, L.d_out, pairs * elem, "the LCS triangle");
-    if (!rc) rc = reserve_big(ctx, ctx->d_dist, pairs * sizeof(float), "the float distance triangle");
-    if (rc) return rc;
-    rc = run_rows(ctx, L, lcsgpu::MODE_TRIANGLE, nullptr, 0, n, nullptr, 0, n - 1, L.d_out.p, 0, 0, elem);
+    int rc = reserve_big(ctx, ctx->d_dist, (size_t)tri_offset(n) * sizeof(float), "the float distance triangle");
     if (rc) return rc;
     auto a16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
     const size_t o_sum = 0, o_tmp = o_sum + a16((size_t)n * 4), o_pq = o_tmp + a16((size_t)n * 4),
@@ -508,6 +591,163 @@ int lcsgpu_nj(lcsgpu_ctx* ctx, int distance_kind, int32_t* out_left, int32_t* ou
     if (sel[2])
         return fail(LCSGPU_E_INVALID, "NJ: no finite q (a pair with LCS 0?) -- the reference's result is degenerate "
                                       "for this input");
+    return LCSGPU_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int lcsgpu_multi_upgma(lcsgpu_ctx* const* ctxs, int32_t n_ctx, int distance_kind, int modified, int32_t* out_left,
+                       int32_t* out_right)
+{
+    int rc = check_multi(ctxs, n_ctx);
+    if (rc) return rc;
+    if (!valid_kind(distance_kind)) return fail(LCSGPU_E_INVALID, "unknown distance kind %d", distance_kind);
+    const int32_t n = ctxs[0]->n;
+    if (n < 2) return LCSGPU_OK;
+    if (!out_left || !out_right) return fail(LCSGPU_E_INVALID, "NULL output");
+    MultiGuard g(ctxs, n_ctx);
+    const int elem = ctxs[0]->max_len > 65535 ? 4 : 2;
+    rc = whole_triangle(ctxs, n_ctx, g, elem);
+    if (rc) return rc;
+    return upgma_reduce(ctxs[0], *g.lanes[0], elem, distance_kind, modified, out_left, out_right);
+}
+
+int lcsgpu_upgma(lcsgpu_ctx* ctx, int distance_kind, int modified, int32_t* out_left, int32_t* out_right)
+{
+    return lcsgpu_multi_upgma(&ctx, 1, distance_kind, modified, out_left, out_right);
+}
+
+int lcsgpu_multi_nj(lcsgpu_ctx* const* ctxs, int32_t n_ctx, int distance_kind, int32_t* out_left, int32_t* out_right)
+{
+    int rc = check_multi(ctxs, n_ctx);
+    if (rc) return rc;
+    if (!valid_kind(distance_kind)) return fail(LCSGPU_E_INVALID, "unknown distance kind %d", distance_kind);
+    const int32_t n = ctxs[0]->n;
+    if (n < 2) return LCSGPU_OK;
+    if (!out_left || !out_right) return fail(LCSGPU_E_INVALID, "NULL output");
+    MultiGuard g(ctxs, n_ctx);
+    const int elem = ctxs[0]->max_len > 65535 ? 4 : 2;
+    rc = whole_triangle(ctxs, n_ctx, g, elem);
+    if (rc) return rc;
+    return nj_reduce(ctxs[0], *g.lanes[0], elem, distance_kind, out_left, out_right);
+}
+
+int lcsgpu_nj(lcsgpu_ctx* ctx, int distance_kind, int32_t* out_left, int32_t* out_right)
+{
+    return lcsgpu_multi_nj(&ctx, 1, distance_kind, out_left, out_right);
+}
+
+// Single linkage over several GPUs inside one process: every context computes its row block and the local half
+// of each Boruvka round on its own GPU (all asynchronous, so the GPUs work at the same time); the keys meet in
+// host memory, the global half runs once on the host (lcsgpu_mst_merge_host) and the labels go back.
+int lcsgpu_multi_mst_prim(lcsgpu_ctx* const* ctxs, int32_t n_ctx, int distance_kind, lcsgpu_mst_edge* out_edges)
+{
+    int rc = check_multi(ctxs, n_ctx);
+    if (rc) return rc;
+    if (n_ctx == 1) return lcsgpu_mst_prim(ctxs[0], distance_kind, out_edges);
+    const bool triangle_orientation = (distance_kind & LCSGPU_MST_TRIANGLE_ORIENTATION) != 0;
+    const int kind = distance_kind & ~LCSGPU_MST_TRIANGLE_ORIENTATION;
+    if (!valid_kind(kind)) return fail(LCSGPU_E_INVALID, "unknown distance kind %d", kind);
+    const int32_t n = ctxs[0]->n;
+    if (n < 2) return LCSGPU_OK;
+    if (!out_edges) return fail(LCSGPU_E_INVALID, "NULL out_edges");
+    if (!triangle_orientation)
+        for (int32_t i = 0; i < n; ++i)
+            if (ctxs[0]->quirk[i])
+                return fail(LCSGPU_E_UNSUPPORTED, "sequence %d is orientation sensitive: MSTPrim's distances depend on which "
+                                                  "endpoint is the ref (use lcsgpu_mst_prim on one context)", i);
+    MultiGuard g(ctxs, n_ctx);
+    const int elem = ctxs[0]->max_len > 65535 ? 4 : 2;
+    const std::vector<int32_t> cut = equal_pair_cuts(0, n, n_ctx);
+    for (int k = 0; k < n_ctx; ++k) {
+        Lane& L = *g.lanes[k];
+        const int32_t r0 = cut[k], r1 = cut[k + 1];
+        const int64_t off = tri_offset(r0);
+        rc = reserve_big(ctxs[k], L.d_out, (size_t)std::max<int64_t>(tri_offset(r1) - off, 1) * elem, "a row block of the LCS triangle");
+        if (rc) return rc;
+        if (r1 > r0) {
+            rc = run_rows(ctxs[k], L, lcsgpu::MODE_TRIANGLE, nullptr, r0, r1 - r0, nullptr, 0, std::max(0, r1 - 1), L.d_out.p, 0, off, elem, r0);
+            if (rc) return rc;
+        }
+        HIP_TRY(hipSetDevice(ctxs[k]->device));
+        rc = shard_begin(ctxs[k], L, L.d_out.p, elem, r0, r1, kind);
+        if (rc) return rc;
+    }
+    std::vector<lcsgpu_mst_key> keys((size_t)n_ctx * n);
+    std::vector<int32_t> comp(n);
+    for (int32_t v = 0; v < n; ++v) comp[v] = v;
+    int32_t found = 0;
+    for (int round = 0; found < n - 1; ++round) {
+        if (round > 64) return fail(LCSGPU_E_STATE, "MST: the Boruvka rounds do not converge");
+        for (int k = 0; k < n_ctx; ++k) { // queue the local halves everywhere, then collect
+            HIP_TRY(hipSetDevice(ctxs[k]->device));
+            rc = shard_best(ctxs[k], *g.lanes[k], nullptr, nullptr);
+            if (rc) return rc;
+            HIP_TRY(hipMemcpyAsync(keys.data() + (size_t)k * n, ctxs[k]->mst.b.best, (size_t)n * sizeof(lcsgpu_mst_key),
+                                   hipMemcpyDeviceToHost, g.lanes[k]->stream));
+        }
+        for (int k = 0; k < n_ctx; ++k) {
+            HIP_TRY(hipSetDevice(ctxs[k]->device));
+            HIP_TRY(hipStreamSynchronize(g.lanes[k]->stream));
+            g.lanes[k]->plan_in_flight = false;
+        }
+        const int32_t before = found;
+        rc = lcsgpu_mst_merge_host(keys.data(), n_ctx, n, comp.data(), out_edges, &found);
+        if (rc) return rc;
+        if (found <= before) return fail(LCSGPU_E_STATE, "MST: a Boruvka round added no edge (%d of %d)", found, n - 1);
+        if (found < n - 1)
+            for (int k = 0; k < n_ctx; ++k) {
+                HIP_TRY(hipSetDevice(ctxs[k]->device));
+                HIP_TRY(hipMemcpyAsync(ctxs[k]->mst.b.comp, comp.data(), (size_t)n * 4, hipMemcpyHostToDevice, g.lanes[k]->stream));
+            }
+    }
+    for (int k = 0; k < n_ctx; ++k) {
+        HIP_TRY(hipSetDevice(ctxs[k]->device));
+        HIP_TRY(hipStreamSynchronize(g.lanes[k]->stream));
+        ctxs[k]->mst.active = false; // the triangle block belongs to this call
+        note_async_call(ctxs[k]);
+    }
+    return order_edges_like_prim(out_edges, n);
+}
+
+// Rows [row_begin, row_end) of the lower triangle into HOST memory, the rows split into blocks of equal pair
+// counts, one per context.
+int lcsgpu_multi_lcs_triangle(lcsgpu_ctx* const* ctxs, int32_t n_ctx, int32_t row_begin, int32_t row_end, void* out, int elem_size)
+{
+    int rc = check_multi(ctxs, n_ctx);
+    if (rc) return rc;
+    if (row_begin < 0 || row_end < row_begin || row_end > ctxs[0]->n) return fail(LCSGPU_E_INVALID, "bad row range");
+    if (elem_size != 2 && elem_size != 4) return fail(LCSGPU_E_INVALID, "elem_size must be 2 or 4");
+    const int64_t base = tri_offset(row_begin), count = tri_offset(row_end) - base;
+    if (count <= 0) return LCSGPU_OK;
+    if (!out) return fail(LCSGPU_E_INVALID, "NULL out");
+    if (n_ctx == 1 || count < (1 << 20)) return lcsgpu_lcs_triangle(ctxs[0], row_begin, row_end, out, elem_size);
+    const std::vector<int32_t> cut = equal_pair_cuts(row_begin, row_end, n_ctx);
+    MultiGuard g(ctxs, n_ctx);
+    for (int k = 0; k < n_ctx; ++k) {
+        const int32_t r0 = cut[k], r1 = cut[k + 1];
+        if (r1 <= r0) continue;
+        Lane& L = *g.lanes[k];
+        const int64_t off = tri_offset(r0);
+        const size_t bytes = (size_t)(tri_offset(r1) - off) * elem_size;
+        rc = reserve_big(ctxs[k], L.d_out, bytes, "a row block of the LCS triangle");
+        if (rc) return rc;
+        rc = run_rows(ctxs[k], L, lcsgpu::MODE_TRIANGLE, nullptr, r0, r1 - r0, nullptr, 0, std::max(0, r1 - 1), L.d_out.p, 0, off, elem_size, r0);
+        if (rc) return rc;
+    }
+    for (int k = 0; k < n_ctx; ++k) { // every GPU is computing by now; collect in order
+        const int32_t r0 = cut[k], r1 = cut[k + 1];
+        if (r1 <= r0) continue;
+        Lane& L = *g.lanes[k];
+        const int64_t off = tri_offset(r0);
+        HIP_TRY(hipSetDevice(ctxs[k]->device));
+        HIP_TRY(hipMemcpyAsync((char*)out + (size_t)(off - base) * elem_size, L.d_out.p, (size_t)(tri_offset(r1) - off) * elem_size,
+                               hipMemcpyDeviceToHost, L.stream));
+        HIP_TRY(hipStreamSynchronize(L.stream));
+        finish_host_call(ctxs[k], L);
+    }
     return LCSGPU_OK;
 }
 

@@ -5,7 +5,8 @@
 //   -gt_export                               write the guide tree in Newick format and stop
 //   -dist_export [-pid] [-square_matrix]     write the distance (or identity) matrix as CSV
 //   -dist <indel_div_lcs|indel075_div_lcs>   distance measure (default indel075_div_lcs)
-//   -keep-duplicates, -t <n>, -v / -vv, -gpu <id>
+//   -keep-duplicates, -t <n>, -v / -vv, -gpu <id[,id...]> | -gpus <n>   (several GPUs: the pair space is tiled
+//                                              by row blocks, FastTree batches are split between the devices)
 //   -medoidtree | -parttree [-medoid_threshold n -subtree_size n -sample_size n -cluster_fraction f -cluster_iters n]
 // Everything downstream of the guide tree (profile alignment, refinement, gz I/O)
 // is outside this engine's scope and is refused with an error, not silently ignored.
@@ -57,7 +58,8 @@ void usage()
                  "  -keep-duplicates      keep duplicated sequences during tree construction\n"
                  "  -medoidtree | -parttree   MedoidTree / PartTree heuristic (with -medoid_threshold, -subtree_size,\n"
                  "                        -sample_size, -cluster_fraction, -cluster_iters as in FAMSA)\n"
-                 "  -gpu <id>             HIP device (default 0)\n"
+                 "  -gpu <id[,id...]>     HIP device(s) (default 0); -gpus <n> = devices 0..n-1.  With several devices\n"
+                 "                        the all-pairs work is tiled by row blocks over them\n"
                  "  -t <n>, -v, -vv       accepted for compatibility / verbosity\n";
 }
 
@@ -73,7 +75,7 @@ int main(int argc, char** argv)
         }
         std::string aux;
         TreeOptions opt;
-        int device = 0;
+        std::vector<int> devices{0};
         if (find_option(params, "-gt", aux)) {
             if (aux == "import") throw std::runtime_error("-gt import needs the alignment stage, which is outside this tool");
             opt.method = gt_from_string(aux);
@@ -91,7 +93,19 @@ int main(int argc, char** argv)
         if (find_option(params, "-sample_size", aux)) opt.fast.sample_size = std::stoi(aux);
         if (find_option(params, "-cluster_fraction", aux)) opt.fast.cluster_fraction = std::stof(aux);
         if (find_option(params, "-cluster_iters", aux)) opt.fast.cluster_iters = std::stoi(aux);
-        if (find_option(params, "-gpu", aux)) device = std::stoi(aux);
+        if (find_option(params, "-gpu", aux)) {
+            devices.clear();
+            for (size_t at = 0; at <= aux.size();) {
+                const size_t comma = std::min(aux.find(',', at), aux.size());
+                devices.push_back(std::stoi(aux.substr(at, comma - at)));
+                at = comma + 1;
+            }
+        }
+        if (find_option(params, "-gpus", aux)) {
+            devices.clear();
+            for (int d = 0; d < std::stoi(aux); ++d) devices.push_back(d);
+            if (devices.empty()) throw std::runtime_error("-gpus needs a positive count");
+        }
         // -t <n>: host worker threads (0 = half of the hardware threads, reference core/params.cpp:285-291)
         int n_threads = 0;
         if (find_option(params, "-t", aux)) n_threads = std::stoi(aux);
@@ -122,7 +136,8 @@ int main(int argc, char** argv)
         // the engine wants one hardware queue per lane (lcsgpu_create sets this too, but the environment must not
         // be modified once other threads run)
         setenv("GPU_MAX_HW_QUEUES", getenv("LCSGPU_LANES") ? getenv("LCSGPU_LANES") : "16", 0);
-        EngineFuture engine = start_engine(device); // HIP initialisation runs while the input is read and sorted
+        EngineFuture engine = start_engine(devices); // HIP initialisation runs while the input is read and sorted
+        const int device = devices[0];
         SeqSet s = load_fasta(input, n_threads);
         if (s.size() == 0) throw std::runtime_error("no sequences in " + input);
         Timings t;

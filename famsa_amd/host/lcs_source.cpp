@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <stdexcept>
+#include <thread>
 
 #include "../../include/lcsgpu.h"
 
@@ -31,9 +32,23 @@ void LcsSource::triangle_ids(const int* ids, int n_ids, LcsBuf& out)
         }
 }
 
-GpuLcsSource::GpuLcsSource(int device)
+GpuLcsSource::GpuLcsSource(int device) : GpuLcsSource(std::vector<int>{device}) {}
+
+GpuLcsSource::GpuLcsSource(const std::vector<int>& devices)
 {
-    check(lcsgpu_create(device, &ctx_), "lcsgpu_create");
+    if (devices.empty()) throw std::runtime_error("no GPU device given");
+    for (int d : devices) {
+        lcsgpu_ctx* c = nullptr;
+        const int rc = lcsgpu_create(d, &c);
+        if (rc != LCSGPU_OK) {
+            const std::string why = lcsgpu_last_error();
+            for (lcsgpu_ctx* x : ctxs_) lcsgpu_destroy(x);
+            ctxs_.clear();
+            throw std::runtime_error("lcsgpu_create failed (" + std::to_string(rc) + "): " + why);
+        }
+        ctxs_.push_back(c);
+    }
+    ctx_ = ctxs_[0];
 }
 
 GpuLcsSource::~GpuLcsSource()
@@ -46,7 +61,13 @@ GpuLcsSource::~GpuLcsSource()
                 st_triids_.calls, st_triids_.seconds, st_triids_.pairs, st_clarans_.calls, st_clarans_.seconds,
                 st_clarans_.pairs, st_batch_.calls, st_batch_.seconds, st_batch_.pairs, st_assign_.calls, st_assign_.seconds,
                 st_assign_.pairs);
-    if (ctx_) lcsgpu_destroy(ctx_);
+    for (lcsgpu_ctx* c : ctxs_) lcsgpu_destroy(c);
+}
+
+lcsgpu_ctx* GpuLcsSource::pick()
+{
+    if (ctxs_.size() == 1) return ctx_;
+    return ctxs_[next_.fetch_add(1, std::memory_order_relaxed) % ctxs_.size()];
 }
 
 void GpuLcsSource::note(CallStat& s, double sec, double pairs)
@@ -65,10 +86,33 @@ void GpuLcsSource::check(int rc, const char* what)
         throw std::runtime_error(std::string(what) + " failed (" + std::to_string(rc) + "): " + lcsgpu_last_error());
 }
 
+// run fn(k) for k = 0 .. parts-1 on their own threads (part 0 on the caller's); the first error is rethrown
+template <typename F>
+static void on_each_device(int parts, F fn)
+{
+    std::vector<std::string> errors(parts);
+    std::vector<std::thread> th;
+    auto guarded = [&](int k) {
+        try {
+            fn(k);
+        } catch (const std::exception& e) {
+            errors[k] = e.what();
+        }
+    };
+    for (int k = 1; k < parts; ++k) th.emplace_back(guarded, k);
+    guarded(0);
+    for (auto& t : th) t.join();
+    for (const auto& e : errors)
+        if (!e.empty()) throw std::runtime_error(e);
+}
+
 void GpuLcsSource::upload(const std::vector<uint8_t>& codes, const std::vector<uint64_t>& offsets)
 {
     const int32_t n = (int32_t)offsets.size() - 1;
-    check(lcsgpu_upload(ctx_, codes.data(), offsets.data(), n), "lcsgpu_upload");
+    on_each_device((int)ctxs_.size(), [&](int k) {
+        const int rc = lcsgpu_upload(ctxs_[k], codes.data(), offsets.data(), n);
+        if (rc != LCSGPU_OK) throw std::runtime_error(std::string("lcsgpu_upload failed (") + std::to_string(rc) + "): " + lcsgpu_last_error());
+    });
     lens_.resize(n);
     for (int i = 0; i < n; ++i) lens_[i] = (uint32_t)(offsets[i + 1] - offsets[i]);
     wide_ = LcsSource::wide();
@@ -78,11 +122,11 @@ void GpuLcsSource::upload(const std::vector<uint8_t>& codes, const std::vector<u
     sensitive_ = nq > 0;
 }
 
-void GpuLcsSource::add_kernel_ms()
+void GpuLcsSource::add_kernel_ms(lcsgpu_ctx* ctx)
 {
     double ms = 0;
     int32_t nl = 0;
-    if (lcsgpu_last_kernel_ms(ctx_, &ms, &nl) != LCSGPU_OK) return; // this thread's last call
+    if (lcsgpu_last_kernel_ms(ctx, &ms, &nl) != LCSGPU_OK) return; // this thread's last call on that context
     std::lock_guard<std::mutex> lk(mu_);
     kernel_ms_ += ms;
 }
@@ -92,19 +136,25 @@ void GpuLcsSource::triangle(int r0, int r1, LcsBuf& out)
     const size_t count = (size_t)r1 * (r1 - 1) / 2 - (size_t)r0 * (r0 > 0 ? r0 - 1 : 0) / 2;
     out.resize(count, wide());
     const double t0 = now_s();
-    check(lcsgpu_lcs_triangle(ctx_, r0, r1, out.data(), out.elem_size()), "lcsgpu_lcs_triangle");
+    if (ctxs_.size() > 1) {
+        check(lcsgpu_multi_lcs_triangle(ctxs_.data(), (int32_t)ctxs_.size(), r0, r1, out.data(), out.elem_size()),
+              "lcsgpu_multi_lcs_triangle");
+    } else {
+        check(lcsgpu_lcs_triangle(ctx_, r0, r1, out.data(), out.elem_size()), "lcsgpu_lcs_triangle");
+    }
     note(st_tri_, now_s() - t0, (double)count);
-    add_kernel_ms();
+    add_kernel_ms(ctx_);
 }
 
 void GpuLcsSource::rect(const int* refs, int n_refs, const int* cols, int n_cols, LcsBuf& out)
 {
     out.resize((size_t)n_refs * n_cols, wide());
     const double t0 = now_s();
-    check(lcsgpu_lcs_rect(ctx_, refs, 0, n_refs, cols, 0, n_cols, out.data(), n_cols, out.elem_size()),
+    lcsgpu_ctx* c = pick();
+    check(lcsgpu_lcs_rect(c, refs, 0, n_refs, cols, 0, n_cols, out.data(), n_cols, out.elem_size()),
           "lcsgpu_lcs_rect");
     note(st_rect_, now_s() - t0, (double)n_refs * n_cols);
-    add_kernel_ms();
+    add_kernel_ms(c);
 }
 
 void GpuLcsSource::triangle_ids(const int* ids, int n_ids, LcsBuf& out)
@@ -112,9 +162,10 @@ void GpuLcsSource::triangle_ids(const int* ids, int n_ids, LcsBuf& out)
     out.resize(n_ids > 1 ? (size_t)n_ids * (n_ids - 1) / 2 : 0, wide());
     if (n_ids < 2) return;
     const double t0 = now_s();
-    check(lcsgpu_lcs_triangle_ids(ctx_, ids, n_ids, out.data(), out.elem_size()), "lcsgpu_lcs_triangle_ids");
+    lcsgpu_ctx* c = pick();
+    check(lcsgpu_lcs_triangle_ids(c, ids, n_ids, out.data(), out.elem_size()), "lcsgpu_lcs_triangle_ids");
     note(st_triids_, now_s() - t0, (double)n_ids * (n_ids - 1) / 2);
-    add_kernel_ms();
+    add_kernel_ms(c);
 }
 
 bool GpuLcsSource::prim_edges(int distance_kind, std::vector<MstEdge>& edges, bool triangle_orientation)
@@ -122,8 +173,17 @@ bool GpuLcsSource::prim_edges(int distance_kind, std::vector<MstEdge>& edges, bo
     static_assert(sizeof(MstEdge) == sizeof(lcsgpu_mst_edge), "edge layout");
     edges.resize(n() > 0 ? n() - 1 : 0);
     const int flags = triangle_orientation ? LCSGPU_MST_TRIANGLE_ORIENTATION : 0;
-    check(lcsgpu_mst_prim(ctx_, distance_kind | flags, (lcsgpu_mst_edge*)edges.data()), "lcsgpu_mst_prim");
-    add_kernel_ms();
+    int rc = LCSGPU_E_UNSUPPORTED;
+    if (ctxs_.size() > 1)
+        rc = lcsgpu_multi_mst_prim(ctxs_.data(), (int32_t)ctxs_.size(), distance_kind | flags, (lcsgpu_mst_edge*)edges.data());
+    if (rc == LCSGPU_E_UNSUPPORTED) // one GPU, or an orientation-sensitive set in MSTPrim's orientation
+        rc = lcsgpu_mst_prim(ctx_, distance_kind | flags, (lcsgpu_mst_edge*)edges.data());
+    if (rc == LCSGPU_E_NOMEM) { // the triangle does not fit the HBM of the devices given: the caller's row-blocked host form applies
+        fprintf(stderr, "[famsa-gpu] %s -- continuing with the host reduction over row blocks\n", lcsgpu_last_error());
+        return false;
+    }
+    check(rc, "lcsgpu_mst_prim");
+    add_kernel_ms(ctx_);
     return true;
 }
 
@@ -132,8 +192,9 @@ bool GpuLcsSource::upgma_nodes(int distance_kind, bool modified, std::vector<int
     const int m = n() > 0 ? n() - 1 : 0;
     left.resize(m);
     right.resize(m);
-    check(lcsgpu_upgma(ctx_, distance_kind, modified ? 1 : 0, left.data(), right.data()), "lcsgpu_upgma");
-    add_kernel_ms();
+    check(lcsgpu_multi_upgma(ctxs_.data(), (int32_t)ctxs_.size(), distance_kind, modified ? 1 : 0, left.data(), right.data()),
+          "lcsgpu_upgma");
+    add_kernel_ms(ctx_);
     return true;
 }
 
@@ -142,24 +203,49 @@ bool GpuLcsSource::nj_nodes(int distance_kind, std::vector<int32_t>& left, std::
     const int m = n() > 0 ? n() - 1 : 0;
     left.resize(m);
     right.resize(m);
-    check(lcsgpu_nj(ctx_, distance_kind, left.data(), right.data()), "lcsgpu_nj");
-    add_kernel_ms();
+    check(lcsgpu_multi_nj(ctxs_.data(), (int32_t)ctxs_.size(), distance_kind, left.data(), right.data()), "lcsgpu_nj");
+    add_kernel_ms(ctx_);
     return true;
 }
 
 bool GpuLcsSource::triangles_batch(const int* ids, const int64_t* offsets, int n_groups, LcsBuf& out)
 {
-    size_t count = 0;
+    std::vector<size_t> start((size_t)n_groups + 1, 0); // output position of every list
     for (int g = 0; g < n_groups; ++g) {
         const size_t m = (size_t)(offsets[g + 1] - offsets[g]);
-        count += m * (m > 0 ? m - 1 : 0) / 2;
+        start[g + 1] = start[g] + m * (m > 0 ? m - 1 : 0) / 2;
     }
+    const size_t count = start[n_groups];
     out.resize(count, wide());
     if (count == 0) return true;
     const double t0 = now_s();
-    check(lcsgpu_lcs_triangles_batch(ctx_, ids, offsets, n_groups, out.data(), out.elem_size()), "lcsgpu_lcs_triangles_batch");
+    const int parts = (int)std::min<size_t>(ctxs_.size(), (size_t)n_groups);
+    if (parts <= 1 || count < (1u << 16)) {
+        lcsgpu_ctx* c = pick();
+        check(lcsgpu_lcs_triangles_batch(c, ids, offsets, n_groups, out.data(), out.elem_size()), "lcsgpu_lcs_triangles_batch");
+        add_kernel_ms(c);
+    } else {
+        // consecutive lists per device, cut where the running pair count passes k/parts of the total
+        std::vector<int> cut(parts + 1, n_groups);
+        cut[0] = 0;
+        for (int k = 1; k < parts; ++k) {
+            const size_t target = count / parts * k;
+            int g = cut[k - 1];
+            while (g < n_groups && start[g] < target) ++g;
+            cut[k] = g;
+        }
+        on_each_device(parts, [&](int k) {
+            const int g0 = cut[k], g1 = cut[k + 1];
+            if (g1 <= g0) return;
+            std::vector<int64_t> rel((size_t)(g1 - g0) + 1);
+            for (int g = g0; g <= g1; ++g) rel[g - g0] = offsets[g] - offsets[g0];
+            const int rc = lcsgpu_lcs_triangles_batch(ctxs_[k], ids + offsets[g0], rel.data(), g1 - g0,
+                                                      (char*)out.data() + start[g0] * out.elem_size(), out.elem_size());
+            if (rc != LCSGPU_OK) throw std::runtime_error(std::string("lcsgpu_lcs_triangles_batch failed: ") + lcsgpu_last_error());
+            add_kernel_ms(ctxs_[k]);
+        });
+    }
     note(st_batch_, now_s() - t0, (double)count);
-    add_kernel_ms();
     return true;
 }
 
@@ -167,9 +253,21 @@ bool GpuLcsSource::assign_seeds(const int* seeds, int n_seeds, const int* cols, 
                                 float* dist, int* assign)
 {
     const double t0 = now_s();
-    check(lcsgpu_assign_seeds(ctx_, seeds, n_seeds, cols, n_cols, distance_kind, first_k, dist, assign), "lcsgpu_assign_seeds");
+    const int parts = (int)std::min<size_t>(ctxs_.size(), (size_t)std::max(1, n_cols / 4096));
+    if (parts <= 1) {
+        lcsgpu_ctx* c = pick();
+        check(lcsgpu_assign_seeds(c, seeds, n_seeds, cols, n_cols, distance_kind, first_k, dist, assign), "lcsgpu_assign_seeds");
+        add_kernel_ms(c);
+    } else { // every column is independent of the others: the columns are split between the devices
+        on_each_device(parts, [&](int k) {
+            const int c0 = (int)((int64_t)n_cols * k / parts), c1 = (int)((int64_t)n_cols * (k + 1) / parts);
+            if (c1 <= c0) return;
+            const int rc = lcsgpu_assign_seeds(ctxs_[k], seeds, n_seeds, cols + c0, c1 - c0, distance_kind, first_k, dist + c0, assign + c0);
+            if (rc != LCSGPU_OK) throw std::runtime_error(std::string("lcsgpu_assign_seeds failed: ") + lcsgpu_last_error());
+            add_kernel_ms(ctxs_[k]);
+        });
+    }
     note(st_assign_, now_s() - t0, (double)n_seeds * n_cols);
-    add_kernel_ms();
     return true;
 }
 
@@ -179,11 +277,12 @@ bool GpuLcsSource::clarans(const int* ids, int n_ids, int distance_kind, int n_m
     static const bool host_search = getenv("FAMSA_CLARANS_HOST") != nullptr; // A/B aid: keep the search on the host
     if (host_search) return false;
     const double t0 = now_s();
-    const int rc = lcsgpu_clarans(ctx_, ids, n_ids, distance_kind, n_medoids, n_fixed, explore_fraction, num_local, medoids);
+    lcsgpu_ctx* c = pick();
+    const int rc = lcsgpu_clarans(c, ids, n_ids, distance_kind, n_medoids, n_fixed, explore_fraction, num_local, medoids);
     if (rc == LCSGPU_E_UNSUPPORTED) return false;
     check(rc, "lcsgpu_clarans");
     note(st_clarans_, now_s() - t0, (double)n_ids * (n_ids - 1) / 2);
-    add_kernel_ms();
+    add_kernel_ms(c);
     return true;
 }
 

@@ -3,6 +3,7 @@
 // serves a caller-supplied matrix so the host logic can be exercised without a GPU (tests feed
 // it the oracle's matrix).  There is no CPU LCS implementation on this side of the boundary.
 #pragma once
+#include <atomic>
 #include <cstdint>
 #include <memory>
 #include <mutex>
@@ -70,10 +71,15 @@ public:
 };
 
 // The MI355X engine.  Throws std::runtime_error if the library reports an error (no fallback).
+// With several devices (one context each, all holding the uploaded set) the whole-set requests are tiled by
+// row blocks over the GPUs (lcsgpu_multi_*), the batched requests of the FastTree recursion are split between
+// them (leaf matrices by pair count, seed assignment by columns) and the small per-thread requests go round robin.
 class GpuLcsSource : public LcsSource {
 public:
     explicit GpuLcsSource(int device);
+    explicit GpuLcsSource(const std::vector<int>& devices);
     ~GpuLcsSource() override;
+    int n_devices() const { return (int)ctxs_.size(); }
     void upload(const std::vector<uint8_t>& codes, const std::vector<uint64_t>& offsets);
     int n() const override { return (int)lens_.size(); }
     uint32_t length(int i) const override { return lens_[i]; }
@@ -91,11 +97,14 @@ public:
     bool assign_seeds(const int* seeds, int n_seeds, const int* cols, int n_cols, int distance_kind, int first_k, float* dist,
                       int* assign) override;
     double kernel_ms_total() const { return kernel_ms_; }
-    void add_kernel_ms();
+    void add_kernel_ms(lcsgpu_ctx* ctx);
 
 private:
     void check(int rc, const char* what);
-    lcsgpu_ctx* ctx_ = nullptr;
+    lcsgpu_ctx* pick(); // the context for a small request: round robin over the devices
+    std::vector<lcsgpu_ctx*> ctxs_;
+    lcsgpu_ctx* ctx_ = nullptr; // = ctxs_[0]
+    std::atomic<unsigned> next_{0};
     std::vector<uint32_t> lens_;
     bool sensitive_ = false, wide_ = false;
     double kernel_ms_ = 0;

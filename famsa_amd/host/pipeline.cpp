@@ -56,9 +56,11 @@ std::string guide_tree_newick_from_matrix(const SeqSet& s, const uint32_t* sq, c
     return guide_tree_newick(s, w, src, opt);
 }
 
-EngineFuture start_engine(int device)
+EngineFuture start_engine(int device) { return start_engine(std::vector<int>{device}); }
+
+EngineFuture start_engine(const std::vector<int>& devices)
 {
-    return std::async(std::launch::async, [device] { return std::make_unique<GpuLcsSource>(device); });
+    return std::async(std::launch::async, [devices] { return std::make_unique<GpuLcsSource>(devices); });
 }
 
 std::string guide_tree_newick_gpu(const SeqSet& s, int device, const TreeOptions& opt, Timings* t, EngineFuture* engine)

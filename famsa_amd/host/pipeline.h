@@ -35,6 +35,7 @@ std::string guide_tree_newick_from_matrix(const SeqSet& s, const uint32_t* squar
 // thread, and hand the future in; otherwise it is started here, next to the sort.
 using EngineFuture = std::future<std::unique_ptr<GpuLcsSource>>;
 EngineFuture start_engine(int device);
+EngineFuture start_engine(const std::vector<int>& devices); // one context per entry (entries may repeat)
 std::string guide_tree_newick_gpu(const SeqSet& s, int device, const TreeOptions& opt, Timings* t,
                                   EngineFuture* engine = nullptr);
 void dist_export_gpu(const SeqSet& s, int device, Distance dist, bool square, bool pid, const std::string& path,

@@ -60,6 +60,10 @@ def load_library():
         "lcsgpu_mst_merge_host": (C.c_int, [vp, i32, i32, vp, vp, pi32]),
         "lcsgpu_mst_shard_set_components": (C.c_int, [vp, vp]),
         "lcsgpu_mst_order_edges": (C.c_int, [vp, i32]),
+        "lcsgpu_multi_lcs_triangle": (C.c_int, [vp, i32, i32, i32, vp, C.c_int]),
+        "lcsgpu_multi_upgma": (C.c_int, [vp, i32, C.c_int, C.c_int, vp, vp]),
+        "lcsgpu_multi_nj": (C.c_int, [vp, i32, C.c_int, vp, vp]),
+        "lcsgpu_multi_mst_prim": (C.c_int, [vp, i32, C.c_int, vp]),
         "lcsgpu_upgma": (C.c_int, [vp, C.c_int, C.c_int, vp, vp]),
         "lcsgpu_nj": (C.c_int, [vp, C.c_int, vp, vp]),
         "lcsgpu_lcs_triangles_batch": (C.c_int, [vp, pi32, C.POINTER(C.c_int64), i32, vp, C.c_int]),
@@ -271,6 +275,13 @@ class LcsGpu:
         self._check(self._lib.lcsgpu_upgma(self._ctx, kind, int(modified), left.ctypes.data, right.ctypes.data))
         return left[: max(self.n - 1, 0)], right[: max(self.n - 1, 0)]
 
+    def nj(self, kind=1):
+        """Children (left, right) of internal nodes n..2n-2 of the neighbour-joining tree."""
+        left = np.zeros(max(self.n - 1, 1), dtype=np.int32)
+        right = np.zeros(max(self.n - 1, 1), dtype=np.int32)
+        self._check(self._lib.lcsgpu_nj(self._ctx, kind, left.ctypes.data, right.ctypes.data))
+        return left[: max(self.n - 1, 0)], right[: max(self.n - 1, 0)]
+
     def assign_seeds(self, seed_ids, col_ids, dist, assign, first_k=1, kind=1):
         """Nearest-seed update of (dist, assign) over the columns, in place (float32 / int32 arrays)."""
         s_arr, s_ptr = _ids(seed_ids)
@@ -302,3 +313,56 @@ class LcsGpu:
             return None, None, int(x[0]), int(x[1])
         arr, ptr = _ids(x)
         return arr, ptr, 0, len(arr)
+
+
+class LcsGpuGroup:
+    """Several contexts (one per GPU; on a 1-GPU box several on the same device) holding the same set:
+    the lcsgpu_multi_* calls of include/lcsgpu.h."""
+
+    def __init__(self, devices):
+        self.engs = [LcsGpu(d) for d in devices]
+        self._lib = self.engs[0]._lib
+        self._arr = (C.c_void_p * len(self.engs))(*[e._ctx for e in self.engs])
+        self.n = 0
+
+    def _check(self, rc):
+        self.engs[0]._check(rc)
+
+    def close(self):
+        for e in self.engs:
+            e.close()
+
+    def upload_seqs(self, seqs):
+        for e in self.engs:
+            e.upload_seqs(seqs)
+        self.n = self.engs[0].n
+
+    def upload(self, codes, offsets):
+        for e in self.engs:
+            e.upload(codes, offsets)
+        self.n = self.engs[0].n
+
+    def lcs_triangle(self, row_begin=0, row_end=None, dtype=np.uint16):
+        row_end = self.n if row_end is None else row_end
+        count = row_end * (row_end - 1) // 2 - row_begin * (row_begin - 1) // 2
+        out = np.empty(max(count, 0), dtype=dtype)
+        self._check(self._lib.lcsgpu_multi_lcs_triangle(self._arr, len(self.engs), row_begin, row_end,
+                                                        out.ctypes.data if out.size else None, out.itemsize))
+        return out
+
+    def mst_prim(self, kind=1):
+        out = np.zeros(max(self.n - 1, 0), dtype=MST_EDGE)
+        self._check(self._lib.lcsgpu_multi_mst_prim(self._arr, len(self.engs), kind, out.ctypes.data if out.size else None))
+        return out
+
+    def upgma(self, kind=1, modified=False):
+        left = np.zeros(max(self.n - 1, 1), dtype=np.int32)
+        right = np.zeros(max(self.n - 1, 1), dtype=np.int32)
+        self._check(self._lib.lcsgpu_multi_upgma(self._arr, len(self.engs), kind, int(modified), left.ctypes.data, right.ctypes.data))
+        return left[: max(self.n - 1, 0)], right[: max(self.n - 1, 0)]
+
+    def nj(self, kind=1):
+        left = np.zeros(max(self.n - 1, 1), dtype=np.int32)
+        right = np.zeros(max(self.n - 1, 1), dtype=np.int32)
+        self._check(self._lib.lcsgpu_multi_nj(self._arr, len(self.engs), kind, left.ctypes.data, right.ctypes.data))
+        return left[: max(self.n - 1, 0)], right[: max(self.n - 1, 0)]

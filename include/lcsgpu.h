@@ -15,7 +15,8 @@
  * internal lanes (HIP streams); device-memory calls, the tree reducers and lcsgpu_sync use one
  * fixed stream (lcsgpu_stream) in call order; lcsgpu_upload waits for everything and is
  * exclusive.  Different contexts are independent -- the multi-GPU model is one process (or one
- * context) per GPU.
+ * context) per GPU; the lcsgpu_multi_* calls and the lcsgpu_mst_shard_* protocol let several contexts work
+ * on one problem.
  *
  * Symbol codes are the reference's: index in "ARNDCQEGHILKMFPSTWYVBZX*"
  * (core/sequence.cpp:17), 22 = unknown; only codes < 20 ever match
@@ -240,6 +241,26 @@ int lcsgpu_upgma(lcsgpu_ctx* ctx, int distance_kind, int modified, int32_t* out_
  * Replaces: calculateDistanceMatrix (single-threaded in the reference, NeighborJoining.cpp:16) +
  * NeighborJoining::computeTree. */
 int lcsgpu_nj(lcsgpu_ctx* ctx, int distance_kind, int32_t* out_left, int32_t* out_right);
+
+/* ---- Several contexts (one per GPU of a node) on ONE problem, driven from one host thread --------------
+ * SURVEY 8(b) sketched lcsgpu_create(dev_ids, n_dev); the boundary keeps one context per GPU (the reference's
+ * one-CLCSBP-per-worker convention) and adds calls that take a LIST of contexts.  Every context of the list
+ * must hold the same uploaded set (lcsgpu_upload on each); contexts may also share a device.  The pair space
+ * is tiled by row blocks of equal pair counts, block k on ctxs[k]; all GPUs compute at the same time.
+ *
+ * lcsgpu_multi_lcs_triangle: as lcsgpu_lcs_triangle, HOST output -- the row producers of UPGMA::computeDistances
+ *   (tree/UPGMA.cpp:75-109) / DistanceCalculator::run (tree/DistanceCalculator.cpp:28-82), one block per GPU.
+ * lcsgpu_multi_upgma / lcsgpu_multi_nj: as lcsgpu_upgma / lcsgpu_nj; the row blocks of the other GPUs are copied
+ *   into ctxs[0]'s HBM over xGMI (device-to-device), where the sequential merges run.
+ * lcsgpu_multi_mst_prim: as lcsgpu_mst_prim, by the sharded Boruvka rounds above with the keys exchanged through
+ *   host memory (lcsgpu_mst_merge_host); LCSGPU_E_UNSUPPORTED for orientation-sensitive sets in MSTPrim's own
+ *   orientation (run lcsgpu_mst_prim on one context then). */
+int lcsgpu_multi_lcs_triangle(lcsgpu_ctx* const* ctxs, int32_t n_ctx, int32_t row_begin, int32_t row_end, void* out,
+                              int elem_size);
+int lcsgpu_multi_upgma(lcsgpu_ctx* const* ctxs, int32_t n_ctx, int distance_kind, int modified, int32_t* out_left,
+                       int32_t* out_right);
+int lcsgpu_multi_nj(lcsgpu_ctx* const* ctxs, int32_t n_ctx, int distance_kind, int32_t* out_left, int32_t* out_right);
+int lcsgpu_multi_mst_prim(lcsgpu_ctx* const* ctxs, int32_t n_ctx, int distance_kind, lcsgpu_mst_edge* out_edges);
 
 /* The lower triangles of several id lists in one call (the leaf sub-trees of one FastTree split):
  * list g = ids[group_offsets[g] .. group_offsets[g+1]), m_g members; out receives the packed
