@@ -291,6 +291,42 @@ long ref_tree_newick(void* h, int gt, int distance, int heuristic, int subtree_s
     }
 }
 
+// The same orchestration with a generator the CALLER builds (oracle/adapter_check.cpp: the reference's
+// generators with their distance stage bound to the GPU engine).  Returns length, -(needed) - 1, or -1.
+long ref_tree_newick_with(void* h, int keep_dups, AbstractTreeGenerator* (*make)(void* user), void* user, char* out, long cap)
+{
+    try {
+        const RefSet& rs = *(RefSet*)h;
+        std::vector<CSequence> sequences = clone(rs);
+        GuideTree tree;
+        sort_and_extend(sequences);
+        std::vector<CSequence*> mapped(sequences.size());
+        std::transform(sequences.begin(), sequences.end(), mapped.begin(), [](CSequence& s) { return &s; });
+        std::vector<int> original2mapped(sequences.size());
+        std::iota(original2mapped.begin(), original2mapped.end(), 0);
+        if (!keep_dups)
+            remove_duplicates(mapped, original2mapped);
+        std::string description;
+        if (mapped.size() > 1) {
+            for (int i = 0; i < (int)mapped.size(); ++i)
+                mapped[i]->sequence_no = i;
+            std::unique_ptr<AbstractTreeGenerator> gen(make(user));
+            (*gen)(mapped, tree.raw());
+            for (auto& s : sequences)
+                s.DataResize(s.length, UNKNOWN_SYMBOL);
+            tree.fromUnique(original2mapped);
+            NewickParser nw(false);
+            nw.store(sequences, tree.raw(), description);
+        }
+        if ((long)description.size() + 1 > cap)
+            return -(long)description.size() - 2;
+        memcpy(out, description.c_str(), description.size() + 1);
+        return (long)description.size();
+    } catch (...) {
+        return -1;
+    }
+}
+
 // `famsa -dist_export [-pid] [-square_matrix]`: ComputeMSA's early branch, msa.cpp:518-526.
 int ref_dist_export(void* h, int distance, int square, int pid, int n_threads, int isa, const char* out_path)
 {
