@@ -187,6 +187,7 @@ def main():
     keys = torch.zeros(2 * n, dtype=torch.int64, device=dev)          # this rank's lcsgpu_mst_key records
     gathered = torch.zeros(world * 2 * n, dtype=torch.int64, device=dev) if world > 1 else keys
     ext = torch.cuda.ExternalStream(eng._lib.lcsgpu_stream(eng._ctx), device=dev)
+    torch.cuda.synchronize()  # torch zero-fills on ITS stream; the engine writes these buffers on its own
 
     if world == 1:
         def all_gather(g, k):

@@ -64,6 +64,28 @@ bool contiguous(const Bucket& b)
     return true;
 }
 
+bool create_lane(lcsgpu_ctx* ctx, Lane& l)
+{
+    if (hipSetDevice(ctx->device) != hipSuccess) return false;
+    const bool ok = hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking) == hipSuccess &&
+                    hipStreamCreateWithFlags(&l.copy_stream, hipStreamNonBlocking) == hipSuccess &&
+                    hipEventCreate(&l.ev_start) == hipSuccess && hipEventCreate(&l.ev_stop) == hipSuccess &&
+                    hipEventCreateWithFlags(&l.ev_done, hipEventBlockingSync | hipEventDisableTiming) == hipSuccess;
+    if (!ok) (void)hipGetLastError();
+    return ok;
+}
+
+int ensure_batcher(lcsgpu_ctx* ctx, ClaransBatcher& B)
+{
+    std::lock_guard<std::mutex> lk(B.mu);
+    if (B.stream) return LCSGPU_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamCreateWithFlags(&B.stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&B.ev, hipEventBlockingSync | hipEventDisableTiming));
+    HIP_TRY(B.h_states.reserve(lcsgpu::CLARANS_MAX_BATCH * 64));
+    return LCSGPU_OK;
+}
+
 int reserve_big(lcsgpu_ctx* ctx, DevBuf& buf, size_t bytes, const char* what)
 {
     if (bytes <= buf.cap) return LCSGPU_OK;
@@ -315,24 +337,15 @@ int lcsgpu_create(int device_id, lcsgpu_ctx** out_ctx)
     if (!ctx) return fail(LCSGPU_E_NOMEM, "out of host memory");
     ctx->device = device_id;
     ctx->lanes.resize(n_lanes);
-    for (Lane& l : ctx->lanes)
-        if (hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking) != hipSuccess ||
-            hipStreamCreateWithFlags(&l.copy_stream, hipStreamNonBlocking) != hipSuccess ||
-            hipEventCreate(&l.ev_start) != hipSuccess || hipEventCreate(&l.ev_stop) != hipSuccess ||
-            hipEventCreateWithFlags(&l.ev_done, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess) {
-            lcsgpu_destroy(ctx);
-            return fail(LCSGPU_E_HIP, "stream/event creation failed");
-        }
+    // lane 0 now; the others (and the streams of the CLARANS batches) when first needed -- see Lane::created
+    if (!create_lane(ctx, ctx->lanes[0])) {
+        lcsgpu_destroy(ctx);
+        return fail(LCSGPU_E_HIP, "stream/event creation failed");
+    }
+    ctx->lanes[0].created = true;
     int n_groups = 4; // 3 x 10^6-sequence MedoidTree, tree stage: 1 group 2.92 s, 2: 2.79 s, 4: 2.71 s, 8: 4.13 s
     if (const char* e = getenv("LCSGPU_CLARANS_GROUPS")) n_groups = std::max(1, std::min(16, atoi(e)));
     ctx->clarans_groups = std::vector<ClaransBatcher>(n_groups);
-    for (ClaransBatcher& B : ctx->clarans_groups)
-        if (hipStreamCreateWithFlags(&B.stream, hipStreamNonBlocking) != hipSuccess ||
-            hipEventCreateWithFlags(&B.ev, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess ||
-            B.h_states.reserve(lcsgpu::CLARANS_MAX_BATCH * 64) != hipSuccess) {
-            lcsgpu_destroy(ctx);
-            return fail(LCSGPU_E_HIP, "stream/event creation failed");
-        }
     *out_ctx = ctx;
     return LCSGPU_OK;
 }
@@ -418,7 +431,8 @@ int lcsgpu_upload(lcsgpu_ctx* ctx, const uint8_t* codes, const uint64_t* offsets
         return fail(LCSGPU_E_INVALID, "bad argument");
     LaneGuard guard(ctx, LaneGuard::ALL); // nothing may run while the set is replaced
     HIP_TRY(hipSetDevice(ctx->device));
-    for (Lane& l : ctx->lanes) HIP_TRY(hipStreamSynchronize(l.stream));
+    for (Lane& l : ctx->lanes)
+        if (l.created) HIP_TRY(hipStreamSynchronize(l.stream));
     ctx->n = -1;
     ctx->mst.active = false;
     std::vector<uint32_t> lens(n);

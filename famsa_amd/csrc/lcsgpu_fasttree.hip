@@ -100,6 +100,7 @@ void clarans_drive(lcsgpu_ctx* ctx, ClaransBatcher& B, ClaransJob* mine)
 int clarans_run_search(lcsgpu_ctx* ctx, ClaransJob& job)
 {
     ClaransBatcher& B = ctx->clarans_groups[ctx->clarans_next++ % ctx->clarans_groups.size()];
+    if (int rc = ensure_batcher(ctx, B)) return rc;
     job.done = false;
     std::unique_lock<std::mutex> lk(B.mu);
     B.joined.push_back(&job);

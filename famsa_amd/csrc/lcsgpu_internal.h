@@ -99,6 +99,10 @@ struct Lane {
     int last_launches = 0;
     bool timing_valid = false;
     bool busy = false;
+    // Lanes are created when first needed: a stream pair, its events and (with one hardware queue per lane)
+    // its queue cost ~20 ms each -- 0.25 s for all 16 at start-up, most of what a small input paid in total.
+    bool created = false;
+    bool unusable = false; // creation failed: never offered again
 };
 
 
@@ -172,6 +176,11 @@ struct LastCall { // timing of this thread's most recent call, for lcsgpu_last_k
 };
 extern thread_local LastCall g_last;
 
+// streams / events of one lane (lcsgpu_api.hip); false on failure
+bool create_lane(lcsgpu_ctx* ctx, Lane& l);
+// stream / event / pinned state block of a CLARANS batch, on first use
+int ensure_batcher(lcsgpu_ctx* ctx, ClaransBatcher& B);
+
 // RAII ownership of one lane (index 0 on request, else any free one) or of all lanes.
 class LaneGuard {
 public:
@@ -191,12 +200,42 @@ public:
             ctx->lanes[0].busy = true;
             idx_ = 0;
         } else {
-            ctx->cv.wait(lk, [&] {
-                for (size_t i = ctx->lanes.size(); i-- > 0;) // prefer the higher lanes, keep lane 0 free
-                    if (!ctx->lanes[i].busy) { idx_ = (int)i; return true; }
-                return false;
-            });
-            ctx->lanes[idx_].busy = true;
+            // a created free lane other than lane 0 (device-memory calls and the tree reducers queue there);
+            // else a lane that does not exist yet -- unless lane 0 is free and nothing else has been needed
+            // so far (a single-threaded caller never pays for a second lane); else lane 0; else wait
+            for (;;) {
+                int pick = -1, fresh = -1;
+                bool others = false;
+                for (size_t i = 1; i < ctx->lanes.size(); ++i) {
+                    const Lane& l = ctx->lanes[i];
+                    if (l.unusable) continue;
+                    if (l.created) others = true;
+                    if (l.created && !l.busy && pick < 0) pick = (int)i;
+                    if (!l.created && !l.busy && fresh < 0) fresh = (int)i;
+                }
+                if (pick < 0 && !ctx->lanes[0].busy && (!others || fresh < 0)) pick = 0;
+                if (pick < 0 && fresh >= 0 && (others || ctx->lanes[0].busy)) {
+                    Lane& l = ctx->lanes[fresh];
+                    l.busy = true; // reserved while it is being created, outside the lock
+                    lk.unlock();
+                    const bool ok = create_lane(ctx, l);
+                    lk.lock();
+                    if (ok) {
+                        l.created = true;
+                        idx_ = fresh;
+                        break;
+                    }
+                    l.unusable = true;
+                    l.busy = false;
+                    continue;
+                }
+                if (pick >= 0) {
+                    ctx->lanes[pick].busy = true;
+                    idx_ = pick;
+                    break;
+                }
+                ctx->cv.wait(lk);
+            }
         }
     }
     ~LaneGuard()

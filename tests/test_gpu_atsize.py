@@ -112,6 +112,7 @@ def test_c4_row_block_contexts_tree_and_sampled_triangle(oracle, synth100k):
         for p, e in enumerate(engs):
             e.mst_shard_begin(tris[p].data_ptr(), 2, cuts[p], cuts[p + 1], 1)
         keys = [torch.zeros(2 * n, dtype=torch.int64, device="cuda:0") for _ in engs]
+        torch.cuda.synchronize()  # torch fills them on ITS stream; the engines write them on theirs
         found = 0
         while found < n - 1:
             for e, k in zip(engs, keys):

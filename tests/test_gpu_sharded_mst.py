@@ -66,6 +66,7 @@ class Shards:
         torch = self.torch
         self.begin(kind)
         keys = [torch.zeros(2 * self.n, dtype=torch.int64, device="cuda:0") for _ in self.engs]
+        torch.cuda.synchronize()  # torch fills them on ITS stream; the engines write them on theirs
         found, rounds = 0, 0
         while found < self.n - 1:
             assert rounds < 40
