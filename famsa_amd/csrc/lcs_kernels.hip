@@ -307,15 +307,20 @@ struct Pipe {
 
     // CARRY (long refs, one segment of the bit-vector per pass): bit b of `cw` enters word 0 at
     // residue b, the carry leaving the last word is collected in bit b of `cout`.
-    template <bool CARRY = false>
+    // NPOS < 16: the partner's LAST chunk, of which only the first NPOS residues can be real for any lane of
+    // the wave (the rest is padding, a no-op step each): the tail of a 100-residue partner costs 4 positions
+    // instead of 16 (-11% of its steps).
+    template <bool CARRY = false, int NPOS = 16>
     static __device__ __forceinline__ void chunk(const lds_u8* grp, const uint4& q, const uint4& qn,
                                                  uint64_t (&ring)[LOOKAHEAD], uint32_t (&X)[RG][H], uint32_t cw = 0,
                                                  uint32_t* cout_p = nullptr)
     {
         static_assert(!CARRY || RG == 1, "carry streams are per (ref, partner)");
+        static_assert(NPOS == 16 || !CARRY, "partial chunks exist in the register-resident kernel only");
+        static_assert((NPOS * PER_POS) % LOOKAHEAD == 0, "ring phase");
         uint32_t cout = 0;
 #pragma unroll
-        for (int b = 0; b < 16; ++b) {
+        for (int b = 0; b < NPOS; ++b) {
 #pragma unroll
             for (int r = 0; r < RG; ++r) {
                 unsigned cin = 0;
@@ -328,7 +333,8 @@ struct Pipe {
                 for (int j = 0; j < W; ++j) {
                     const int t = (b * RG + r) * W + j;
                     const uint64_t nn = ring[t % LOOKAHEAD];
-                    ring[t % LOOKAHEAD] = gather(grp, q, qn, t + LOOKAHEAD);
+                    if (NPOS == 16 || t + LOOKAHEAD < NPOS * PER_POS) // nothing follows a partial chunk
+                        ring[t % LOOKAHEAD] = gather(grp, q, qn, t + LOOKAHEAD);
                     LCS_PIN();
                     const uint32_t n0 = (uint32_t)nn, n1 = (uint32_t)(nn >> 32);
                     unsigned co;
@@ -392,6 +398,9 @@ __global__ __launch_bounds__(256) void lcs_rows_kernel_pipe(RowsArgs a)
     const uint8_t* pbase = a.tiles + a.tile_base[pid >> 6] + (uint64_t)(pid & 63) * 16;
     const int my_chunks = (int)((len_p + 15) >> 4);
     const int wave_chunks = wave_max(my_chunks);
+    // residues of the wave's last chunk that are real for some lane, in quads of 4
+    const int my_tail = my_chunks == wave_chunks ? (int)(((len_p - 1) & 15) >> 2) + 1 : 0;
+    const int tail_quads = wave_max(my_tail);
 
     for (int g = 0; g < nr; g += RG) {
         uint32_t X[RG][H];
@@ -406,12 +415,27 @@ __global__ __launch_bounds__(256) void lcs_rows_kernel_pipe(RowsArgs a)
             q = *(const uint4*)pbase;
         uint64_t ring[LOOKAHEAD];
         P::prime(grp, q, ring);
-        for (int k = 0; k < wave_chunks; ++k) {
+        // Short refs (H <= 8, up to 256 residues -- where a partner's padded tail is a visible share of its
+        // steps): the last chunk runs as many 4-residue quads as the longest partner of the wave needs.
+        // Longer refs keep one chunk body: four more copies of it cost the 13-half-word kernel a quarter of
+        // its rate (registers / instruction cache), measured 555 -> 421 Tcell/s at 400 aa.
+        constexpr bool PARTIAL_TAIL = H <= 8;
+        const int full_chunks = PARTIAL_TAIL ? wave_chunks - 1 : wave_chunks;
+        for (int k = 0; k < full_chunks; ++k) {
             uint4 qn = make_uint4(PAD4, PAD4, PAD4, PAD4);
             if (k + 1 < my_chunks)
                 qn = *(const uint4*)(pbase + (size_t)(k + 1) * 1024);
             P::chunk(grp, q, qn, ring, X);
             q = qn;
+        }
+        if constexpr (PARTIAL_TAIL) {
+            if (wave_chunks > 0) {
+                const uint4 pad = make_uint4(PAD4, PAD4, PAD4, PAD4);
+                if (tail_quads == 1) P::template chunk<false, 4>(grp, q, pad, ring, X);
+                else if (tail_quads == 2) P::template chunk<false, 8>(grp, q, pad, ring, X);
+                else if (tail_quads == 3) P::template chunk<false, 12>(grp, q, pad, ring, X);
+                else P::chunk(grp, q, pad, ring, X);
+            }
         }
 #pragma unroll
         for (int r = 0; r < RG; ++r) {

@@ -321,10 +321,14 @@ int lcsgpu_create(int device_id, lcsgpu_ctx** out_ctx)
         snprintf(buf, sizeof buf, "%d", n_lanes);
         setenv("GPU_MAX_HW_QUEUES", buf, 0);
     }
+    const bool profile = getenv("LCSGPU_PROFILE") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = now();
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n <= 0)
         return fail(LCSGPU_E_NODEVICE, "no HIP device available (%s)", hipGetErrorString(e));
+    const double t1 = now();
     if (device_id < 0 || device_id >= n)
         return fail(LCSGPU_E_INVALID, "device %d not in [0,%d)", device_id, n);
     hipDeviceProp_t prop;
@@ -332,6 +336,7 @@ int lcsgpu_create(int device_id, lcsgpu_ctx** out_ctx)
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(LCSGPU_E_NODEVICE, "device %d is %s; this library is built for gfx950 only", device_id,
                     prop.gcnArchName);
+    const double t2 = now();
     HIP_TRY(hipSetDevice(device_id));
     lcsgpu_ctx* ctx = new (std::nothrow) lcsgpu_ctx;
     if (!ctx) return fail(LCSGPU_E_NOMEM, "out of host memory");
@@ -343,6 +348,9 @@ int lcsgpu_create(int device_id, lcsgpu_ctx** out_ctx)
         return fail(LCSGPU_E_HIP, "stream/event creation failed");
     }
     ctx->lanes[0].created = true;
+    if (profile)
+        fprintf(stderr, "lcsgpu_create: HIP runtime start (hipGetDeviceCount) %.3f s, device properties %.3f s, context + first lane %.3f s\n",
+                t1 - t0, t2 - t1, now() - t2);
     int n_groups = 4; // 3 x 10^6-sequence MedoidTree, tree stage: 1 group 2.92 s, 2: 2.79 s, 4: 2.71 s, 8: 4.13 s
     if (const char* e = getenv("LCSGPU_CLARANS_GROUPS")) n_groups = std::max(1, std::min(16, atoi(e)));
     ctx->clarans_groups = std::vector<ClaransBatcher>(n_groups);

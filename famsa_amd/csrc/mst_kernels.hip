@@ -455,6 +455,7 @@ __global__ __launch_bounds__(256) void boruvka_hook_kernel(BoruvkaArgs a)
     const bool mutual = a.cb_id[other] == id;
     if (!mutual || c < other) {
         const int at = atomicAdd(&a.counters[0], 1);
+        if (at >= a.n - 1) return; // cannot happen with consistent keys; the host reports the count
         a.edges[at].from = x;
         a.edges[at].to = y;
         a.edges[at].dist = __longlong_as_double((long long)a.cb_d[c]);

@@ -1,6 +1,7 @@
 #include "pipeline.h"
 
 #include <chrono>
+#include <cstdlib>
 #include <stdexcept>
 
 namespace famsa_host {
@@ -56,6 +57,8 @@ std::string guide_tree_newick_from_matrix(const SeqSet& s, const uint32_t* sq, c
     return guide_tree_newick(s, w, src, opt);
 }
 
+bool g_abandon_engine_at_return = false;
+
 EngineFuture start_engine(int device) { return start_engine(std::vector<int>{device}); }
 
 EngineFuture start_engine(const std::vector<int>& devices)
@@ -90,6 +93,7 @@ std::string guide_tree_newick_gpu(const SeqSet& s, int device, const TreeOptions
         t->upload_s = t2 - t1b;
         t->kernel_ms = src.kernel_ms_total();
     }
+    if (g_abandon_engine_at_return && !getenv("FAMSA_GPU_PROFILE")) (void)held.release();
     return nwk;
 }
 
@@ -113,6 +117,7 @@ void dist_export_gpu(const SeqSet& s, int device, Distance dist, bool square, bo
         t->tree_s = t3 - t2;
         t->kernel_ms = src.kernel_ms_total();
     }
+    if (g_abandon_engine_at_return && !getenv("FAMSA_GPU_PROFILE")) (void)held.release();
 }
 
 } // namespace famsa_host

@@ -34,6 +34,9 @@ std::string guide_tree_newick_from_matrix(const SeqSet& s, const uint32_t* squar
 // The engine context takes ~0.2 s to create (HIP initialisation): a caller may start that early, on another
 // thread, and hand the future in; otherwise it is started here, next to the sort.
 using EngineFuture = std::future<std::unique_ptr<GpuLcsSource>>;
+// A command-line tool that ends right after the call may skip the engine's teardown (~tens of ms of stream /
+// buffer destruction that the operating system does anyway): set before calling the *_gpu functions.
+extern bool g_abandon_engine_at_return;
 EngineFuture start_engine(int device);
 EngineFuture start_engine(const std::vector<int>& devices); // one context per entry (entries may repeat)
 std::string guide_tree_newick_gpu(const SeqSet& s, int device, const TreeOptions& opt, Timings* t,
