@@ -1,15 +1,16 @@
 // lcs_kernels.hip -- hand-written gfx950 (CDNA4) kernels for FAMSA's bit-parallel LCS.
 //
 // One lane = one PARTNER sequence (the streamed side), one workgroup = 4 waves = 256
-// partners x R REF sequences (the bit-mask side).  The refs' complemented occurrence masks
-// nM[ref][word][code] live in LDS; every lane keeps the bit-vector X of RG refs at a time
+// partners x R REF sequences (the bit-mask side).  The refs' occurrence masks
+// M[ref][word][code] live in LDS; every lane keeps the bit-vector X of RG refs at a time
 // in VGPRs (H x RG registers, H = number of 32-bit half-words = ceil(len_ref/32)) and walks
 // its partner's residues.  Per 64-bit word-step the lane does one conflict-free ds_read_b64
 // gather (address = residue code x 8 inside a 256-byte row, so the 20 residue codes hit 20
 // distinct bank pairs) and six VALU ops, three per 32-bit half:
-//     tB = V & ~nM       v_bitop3_b32      (nM = ~M, so this is V & M)
+//     tB = V & M         v_and_b32         (a 2-source VOP2: 2.2 cycles; the 3-source form costs 2.6)
 //     V2 = V + tB + c    v_add(c)_co_u32   -- one carry chain through all half-words
-//     X  = V2 | (V & nM) v_bitop3_b32
+//     X  = V2 | (V & ~M) v_bitop3_b32      (three VGPR sources: 2.6 cycles if they sit in three different
+//                                           register banks, 4.3 if not -- csrc/recolor_vgprs.py sees to that)
 // which is the recurrence of CLCSBP_Classic_Impl (reference lcs/lcsbp_classic.h:51-58,
 // 67-98) restated for 32-bit lanes.  Working in half-words saves the dead upper half of the
 // last 64-bit word (400 aa: 13 half-words instead of 14).  No MFMA: this is integer/bit work,
@@ -49,13 +50,9 @@ typedef __attribute__((address_space(3))) uint32_t lds_u32;
 
 static constexpr uint32_t PAD4 = 0xB0B0B0B0u; // four bytes of 22*8
 
-__device__ __forceinline__ uint32_t andn(uint32_t v, uint32_t n)
+__device__ __forceinline__ uint32_t or_andn(uint32_t s, uint32_t v, uint32_t m)
 {
-    return __builtin_amdgcn_bitop3_b32(v, n, 0u, 0x30); // v & ~n
-}
-__device__ __forceinline__ uint32_t or_and(uint32_t s, uint32_t v, uint32_t n)
-{
-    return __builtin_amdgcn_bitop3_b32(s, v, n, 0xF8); // s | (v & n)
+    return __builtin_amdgcn_bitop3_b32(s, v, m, 0xF4); // s | (v & ~m): table index = 4 s + 2 v + m
 }
 
 // Mask read for the last, half-used word of an odd half-word count: only the low 32 bits are
@@ -82,12 +79,12 @@ __device__ __forceinline__ unsigned literal_step(const lds_u8* row, uint32_t (&X
     uint64_t cin = cin_bit;
 #pragma unroll
     for (int j = 0; j < W; ++j) {
-        const uint64_t nn = *(const lds_u64*)(row + j * 256);
+        const uint64_t mm = *(const lds_u64*)(row + j * 256);
         const uint64_t V = ((uint64_t)X[2 * j + 1] << 32) | X[2 * j];
-        const uint64_t tB = V & ~nn;
+        const uint64_t tB = V & mm;
         const uint64_t V2 = V + tB + cin;
         cin = (V2 < V) ? 1u : 0u;
-        const uint64_t Xn = V2 | (V & nn);
+        const uint64_t Xn = V2 | (V & ~mm);
         X[2 * j] = (uint32_t)Xn;
         X[2 * j + 1] = (uint32_t)(Xn >> 32);
     }
@@ -104,8 +101,8 @@ __device__ __forceinline__ int wave_max(int v)
     return v;
 }
 
-// Complemented occurrence masks of `count` 64-bit words of ref `rid`, starting at word
-// `word0`, into LDS rows dst[(w)*32 + c] = ~M[c][word0 + w]; M as CSequence::ComputeBitMasks
+// Occurrence masks of `count` 64-bit words of ref `rid`, starting at word
+// `word0`, into LDS rows dst[(w)*32 + c] = M[c][word0 + w]; M as CSequence::ComputeBitMasks
 // builds it (reference core/sequence.cpp:190-201: bits only for codes < 20).  rid < 0 fills
 // "no match".  Called by all 4 waves of the workgroup; item = one word, one wave per item.
 __device__ __forceinline__ void build_mask_words(const RowsArgs& a, int rid, int word0, int count, lds_u64* dst,
@@ -127,7 +124,7 @@ __device__ __forceinline__ void build_mask_words(const RowsArgs& a, int rid, int
                 mine = b;
         }
         if (lane < 32)
-            dst[w * 32 + lane] = ~mine;
+            dst[w * 32 + lane] = mine;
     }
 }
 
@@ -332,29 +329,29 @@ struct Pipe {
 #pragma unroll
                 for (int j = 0; j < W; ++j) {
                     const int t = (b * RG + r) * W + j;
-                    const uint64_t nn = ring[t % LOOKAHEAD];
+                    const uint64_t mm = ring[t % LOOKAHEAD];
                     if (NPOS == 16 || t + LOOKAHEAD < NPOS * PER_POS) // nothing follows a partial chunk
                         ring[t % LOOKAHEAD] = gather(grp, q, qn, t + LOOKAHEAD);
                     LCS_PIN();
-                    const uint32_t n0 = (uint32_t)nn, n1 = (uint32_t)(nn >> 32);
+                    const uint32_t m0 = (uint32_t)mm, m1 = (uint32_t)(mm >> 32);
                     unsigned co;
                     {
                         const uint32_t V = X[r][2 * j];
-                        const uint32_t tb = andn(V, n0);
+                        const uint32_t tb = V & m0;
                         LCS_PIN();
                         const uint32_t s = __builtin_addc(V, tb, cin, &co);
                         LCS_PIN();
-                        X[r][2 * j] = or_and(s, V, n0);
+                        X[r][2 * j] = or_andn(s, V, m0);
                         cin = co;
                         LCS_PIN();
                     }
                     if (2 * j + 1 < H) {
                         const uint32_t V = X[r][2 * j + 1];
-                        const uint32_t tb = andn(V, n1);
+                        const uint32_t tb = V & m1;
                         LCS_PIN();
                         const uint32_t s = __builtin_addc(V, tb, cin, &co);
                         LCS_PIN();
-                        X[r][2 * j + 1] = or_and(s, V, n1);
+                        X[r][2 * j + 1] = or_andn(s, V, m1);
                         cin = co;
                         LCS_PIN();
                     }
