@@ -358,6 +358,30 @@ int lcsgpu_create(int device_id, lcsgpu_ctx** out_ctx)
     return LCSGPU_OK;
 }
 
+int lcsgpu_reserve_lanes(lcsgpu_ctx* ctx, int32_t n_threads)
+{
+    if (!ctx) return fail(LCSGPU_E_INVALID, "NULL ctx");
+    for (size_t i = 1; i < ctx->lanes.size() && (int32_t)i <= n_threads; ++i) {
+        Lane& l = ctx->lanes[i];
+        {
+            std::lock_guard<std::mutex> lk(ctx->mu);
+            if (l.created || l.unusable || l.busy) continue;
+            l.busy = true; // reserved while it is being created
+        }
+        const bool ok = create_lane(ctx, l);
+        {
+            std::lock_guard<std::mutex> lk(ctx->mu);
+            l.created = ok;
+            l.unusable = !ok;
+            l.busy = false;
+        }
+        ctx->cv.notify_all();
+    }
+    for (ClaransBatcher& B : ctx->clarans_groups)
+        if (int rc = ensure_batcher(ctx, B)) return rc;
+    return LCSGPU_OK;
+}
+
 int lcsgpu_destroy(lcsgpu_ctx* ctx)
 {
     if (!ctx) return LCSGPU_OK;

@@ -123,7 +123,7 @@ static int shard_merge(lcsgpu_ctx* ctx, Lane& L, const void* d_gathered, int32_t
     return LCSGPU_OK;
 }
 
-static int shard_finish(lcsgpu_ctx* ctx, Lane& L, lcsgpu_mst_edge* out_edges)
+static int shard_finish(lcsgpu_ctx* ctx, Lane& L, lcsgpu_mst_edge* out_edges, bool order = true)
 {
     const lcsgpu::BoruvkaArgs& b = ctx->mst.b;
     static_assert(sizeof(lcsgpu_mst_edge) == sizeof(lcsgpu::MstEdge), "edge layout");
@@ -131,7 +131,7 @@ static int shard_finish(lcsgpu_ctx* ctx, Lane& L, lcsgpu_mst_edge* out_edges)
     HIP_TRY(hipMemcpyAsync(out_edges, b.edges, (size_t)(b.n - 1) * sizeof(lcsgpu_mst_edge), hipMemcpyDeviceToHost, L.stream));
     HIP_TRY(hipStreamSynchronize(L.stream));
     L.plan_in_flight = false;
-    return order_edges_like_prim(out_edges, b.n);
+    return order ? order_edges_like_prim(out_edges, b.n) : LCSGPU_OK;
 }
 
 namespace lcsgpu_impl {
@@ -248,6 +248,17 @@ int lcsgpu_mst_shard_finish(lcsgpu_ctx* ctx, lcsgpu_mst_edge* out_edges)
     LaneGuard guard(ctx, LaneGuard::LANE0);
     HIP_TRY(hipSetDevice(ctx->device));
     return shard_finish(ctx, guard.lane(), out_edges);
+}
+
+int lcsgpu_mst_shard_edges(lcsgpu_ctx* ctx, lcsgpu_mst_edge* out_edges)
+{
+    if (!ctx) return fail(LCSGPU_E_INVALID, "NULL ctx");
+    if (!ctx->mst.active) return fail(LCSGPU_E_STATE, "lcsgpu_mst_shard_begin has not been called");
+    if (ctx->n < 2) return LCSGPU_OK;
+    if (!out_edges) return fail(LCSGPU_E_INVALID, "NULL out_edges");
+    LaneGuard guard(ctx, LaneGuard::LANE0);
+    HIP_TRY(hipSetDevice(ctx->device));
+    return shard_finish(ctx, guard.lane(), out_edges, false);
 }
 
 // Host form of the global half of a round (no GPU involved): the same fold / per-component minimum /

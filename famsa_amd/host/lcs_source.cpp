@@ -64,6 +64,12 @@ GpuLcsSource::~GpuLcsSource()
     for (lcsgpu_ctx* c : ctxs_) lcsgpu_destroy(c);
 }
 
+void GpuLcsSource::expect_threads(int n_threads)
+{
+    const int per_ctx = (n_threads + (int)ctxs_.size() - 1) / (int)ctxs_.size();
+    for (lcsgpu_ctx* c : ctxs_) check(lcsgpu_reserve_lanes(c, per_ctx), "lcsgpu_reserve_lanes");
+}
+
 lcsgpu_ctx* GpuLcsSource::pick()
 {
     if (ctxs_.size() == 1) return ctx_;

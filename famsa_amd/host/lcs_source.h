@@ -80,6 +80,8 @@ public:
     explicit GpuLcsSource(const std::vector<int>& devices);
     ~GpuLcsSource() override;
     int n_devices() const { return (int)ctxs_.size(); }
+    // the FastTree recursion calls from `n_threads` host threads: have the engine's lanes ready (lcsgpu_reserve_lanes)
+    void expect_threads(int n_threads);
     void upload(const std::vector<uint8_t>& codes, const std::vector<uint64_t>& offsets);
     int n() const override { return (int)lens_.size(); }
     uint32_t length(int i) const override { return lens_[i]; }

@@ -61,9 +61,13 @@ bool g_abandon_engine_at_return = false;
 
 EngineFuture start_engine(int device) { return start_engine(std::vector<int>{device}); }
 
-EngineFuture start_engine(const std::vector<int>& devices)
+EngineFuture start_engine(const std::vector<int>& devices, int expect_threads)
 {
-    return std::async(std::launch::async, [devices] { return std::make_unique<GpuLcsSource>(devices); });
+    return std::async(std::launch::async, [devices, expect_threads] {
+        auto src = std::make_unique<GpuLcsSource>(devices);
+        if (expect_threads > 1) src->expect_threads(expect_threads);
+        return src;
+    });
 }
 
 std::string guide_tree_newick_gpu(const SeqSet& s, int device, const TreeOptions& opt, Timings* t, EngineFuture* engine)

@@ -38,7 +38,7 @@ using EngineFuture = std::future<std::unique_ptr<GpuLcsSource>>;
 // buffer destruction that the operating system does anyway): set before calling the *_gpu functions.
 extern bool g_abandon_engine_at_return;
 EngineFuture start_engine(int device);
-EngineFuture start_engine(const std::vector<int>& devices); // one context per entry (entries may repeat)
+EngineFuture start_engine(const std::vector<int>& devices, int expect_threads = 0); // one context per entry (entries may repeat)
 std::string guide_tree_newick_gpu(const SeqSet& s, int device, const TreeOptions& opt, Timings* t,
                                   EngineFuture* engine = nullptr);
 void dist_export_gpu(const SeqSet& s, int device, Distance dist, bool square, bool pid, const std::string& path,

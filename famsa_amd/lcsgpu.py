@@ -41,6 +41,7 @@ def load_library():
         "lcsgpu_device_count": (C.c_int, []),
         "lcsgpu_create": (C.c_int, [C.c_int, C.POINTER(vp)]),
         "lcsgpu_destroy": (C.c_int, [vp]),
+        "lcsgpu_reserve_lanes": (C.c_int, [vp, i32]),
         "lcsgpu_encode": (C.c_int, [C.c_char_p, sz, vp, C.POINTER(sz)]),
         "lcsgpu_upload": (C.c_int, [vp, vp, vp, i32]),
         "lcsgpu_count": (i32, [vp]),
@@ -57,6 +58,7 @@ def load_library():
         "lcsgpu_mst_shard_best": (C.c_int, [vp, vp, vp]),
         "lcsgpu_mst_shard_merge": (C.c_int, [vp, vp, i32, pi32]),
         "lcsgpu_mst_shard_finish": (C.c_int, [vp, vp]),
+        "lcsgpu_mst_shard_edges": (C.c_int, [vp, vp]),
         "lcsgpu_mst_merge_host": (C.c_int, [vp, i32, i32, vp, vp, pi32]),
         "lcsgpu_mst_shard_set_components": (C.c_int, [vp, vp]),
         "lcsgpu_mst_order_edges": (C.c_int, [vp, i32]),
@@ -263,9 +265,12 @@ class LcsGpu:
         assert len(comp) == self.n
         self._check(self._lib.lcsgpu_mst_shard_set_components(self._ctx, comp.ctypes.data))
 
-    def mst_shard_finish(self):
+    def mst_shard_finish(self, ordered=True):
+        """The n-1 tree edges: in Prim's insertion order, or (ordered=False) as the rounds found them --
+        mst_order_edges() then orders them, e.g. while the GPU already works on the next problem."""
         out = np.zeros(max(self.n - 1, 0), dtype=MST_EDGE)
-        self._check(self._lib.lcsgpu_mst_shard_finish(self._ctx, out.ctypes.data if out.size else None))
+        fn = self._lib.lcsgpu_mst_shard_finish if ordered else self._lib.lcsgpu_mst_shard_edges
+        self._check(fn(self._ctx, out.ctypes.data if out.size else None))
         return out
 
     def upgma(self, kind=1, modified=False):

@@ -56,7 +56,7 @@ def assemble_row_minima(gathered, cuts):
 
 # ---- the sharded single-linkage reduction: Boruvka rounds with one all-gather per round ----------
 
-def sharded_mst_device(eng, d_tri_ptr, elem_size, r0, r1, kind, keys, gathered, all_gather, max_rounds=64):
+def sharded_mst_device(eng, d_tri_ptr, elem_size, r0, r1, kind, keys, gathered, all_gather, max_rounds=64, ordered=True):
     """Device flow (bench.py over RCCL; the multi-context GPU test): `eng` holds rows [r0, r1) at
     d_tri_ptr.  keys: device int64 tensor [2n] (this rank's lcsgpu_mst_key records), gathered: device
     int64 tensor [world * 2n]; all_gather(gathered, keys) must order itself after the engine's stream
@@ -72,7 +72,7 @@ def sharded_mst_device(eng, d_tri_ptr, elem_size, r0, r1, kind, keys, gathered, 
         all_gather(gathered, keys)
         found = eng.mst_shard_merge(gathered.data_ptr(), world)
         rounds += 1
-    return eng.mst_shard_finish(), rounds
+    return eng.mst_shard_finish(ordered), rounds
 
 
 def sharded_mst_host(n, local_best, exchange, set_components, max_rounds=64):

@@ -58,6 +58,10 @@ int lcsgpu_device_count(void);
  * Replaces: CLCSBP::CLCSBP(instruction_set_t) (lcs/lcsbp.cpp:24-45), one per worker. */
 int lcsgpu_create(int device_id, lcsgpu_ctx** out_ctx);
 int lcsgpu_destroy(lcsgpu_ctx* ctx);
+/* Optional: a context creates the stream pairs of its internal lanes when a call first needs them (~20 ms each;
+ * a single-threaded caller never needs a second one).  A caller that is about to issue host-memory calls from
+ * `n_threads` threads (the FastTree recursion) can have that many created now -- e.g. while it still reads its input. */
+int lcsgpu_reserve_lanes(lcsgpu_ctx* ctx, int32_t n_threads);
 
 /* Residue characters -> symbol codes, gaps ('-') dropped.
  * Replaces: the encoding loop of CSequence::CSequence (core/sequence.cpp:53-79).
@@ -213,6 +217,9 @@ int lcsgpu_mst_shard_merge(lcsgpu_ctx* ctx, const void* d_gathered, int32_t n_pa
 /* After the last round (n-1 edges): the edges in the order Prim's algorithm adds them from vertex 0, as
  * lcsgpu_mst_prim returns them (HOST, n-1 records). */
 int lcsgpu_mst_shard_finish(lcsgpu_ctx* ctx, lcsgpu_mst_edge* out_edges);
+/* The same n-1 edges in the order the rounds found them (any order): for a caller that overlaps the ordering
+ * (lcsgpu_mst_order_edges, O(n log n) on the host, ~10 ms at n = 100 000) with the GPU work of its next problem. */
+int lcsgpu_mst_shard_edges(lcsgpu_ctx* ctx, lcsgpu_mst_edge* out_edges);
 /* Host form of the global half -- no GPU, no context: keys = n_parts x n (HOST); comp[n] (in/out) the
  * component label of every vertex (initially comp[v] = v); the round's new tree edges are appended to
  * edges[*n_edges ...] and *n_edges is advanced.  Afterwards hand comp to every context: */

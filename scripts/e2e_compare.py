@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Tree-stage wall time: famsa-gpu vs the reference's own generators (oracle/_ref) on the same box.
-Writes a JSON summary (copied to profiles/e2e_r01.json).  Dev/measurement tool: the oracle is the baseline."""
+Writes a JSON summary gpurun_out/e2e_<tag>.json (tag = argv[1], copied to profiles/).  Dev/measurement tool: the oracle is the baseline."""
 import json, os, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -10,6 +10,9 @@ from famsa_amd import seqio
 cli = os.path.join(ROOT, "famsa_amd", "famsa-gpu")
 import multiprocessing as mp
 threads = min(32, len(os.sched_getaffinity(0)))  # the reference's published setup; its spin barriers degrade beyond
+TAG = sys.argv[1] if len(sys.argv) > 1 else "rXX"
+OUT = os.path.join(ROOT, "gpurun_out", f"e2e_{TAG}.json")
+os.makedirs(os.path.dirname(OUT), exist_ok=True)
 out = {"host_threads": threads, "cases": []}
 
 
@@ -52,7 +55,7 @@ def case(name, fasta, gt, heuristic=0, cli_args=(), with_reference=True, limit=1
            "speedup_tree_stage": round(t_ref / tb, 1) if t_ref else None}
     print(rec, flush=True)
     out["cases"].append(rec)
-    json.dump(out, open(os.path.join(ROOT, "gpurun_out", "e2e_r01.json"), "w"), indent=1)
+    json.dump(out, open(OUT, "w"), indent=1)
 
 
 codes, offsets = seqio.synth_uniform(10000, 400)
@@ -108,7 +111,9 @@ for gt in ("sl", "slink", "upgma"):
     case("synthetic 100000 x 400 aa", "/tmp/cmp_100k.fasta", gt, with_reference=False)
 for n, ref_limit in ((200000, 150), (1000000, 240), (3000000, 0)):
     fam = "/tmp/family_%d_300.fasta" % n
+    if not os.path.exists(fam):
+        seqio.family_fasta(n, 300, fam)
     if os.path.exists(fam):
         case("synthetic family %d x ~255 aa, -medoidtree" % n, fam, "upgma", heuristic=2, cli_args=["-medoidtree"],
              with_reference=ref_limit > 0, limit=ref_limit)
-json.dump(out, open(os.path.join(ROOT, "gpurun_out", "e2e_r01.json"), "w"), indent=1)
+json.dump(out, open(OUT, "w"), indent=1)
