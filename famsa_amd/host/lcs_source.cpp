@@ -177,6 +177,7 @@ void GpuLcsSource::triangle_ids(const int* ids, int n_ids, LcsBuf& out)
 bool GpuLcsSource::prim_edges(int distance_kind, std::vector<MstEdge>& edges, bool triangle_orientation)
 {
     static_assert(sizeof(MstEdge) == sizeof(lcsgpu_mst_edge), "edge layout");
+    if (getenv("FAMSA_NO_DEVICE_MST")) return false; // test aid: what happens when the triangle does not fit the HBM
     edges.resize(n() > 0 ? n() - 1 : 0);
     const int flags = triangle_orientation ? LCSGPU_MST_TRIANGLE_ORIENTATION : 0;
     int rc = LCSGPU_E_UNSUPPORTED;

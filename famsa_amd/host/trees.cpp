@@ -89,10 +89,18 @@ void mst_prim(LcsSource& src, tree_structure& tree)
             if (prim_order[e.from] == n) prim_order[e.from] = next_order++; else prim_order[e.to] = next_order++;
         }
     } else {
-        LcsBuf buf;
+        // The source did not build the tree itself (no GPU reducer, or the triangle does not fit its memory).
+        // Small sets: all values up front.  Large sets: O(n) memory like the reference -- one ref against the
+        // unprocessed vertices per step, exactly MSTPrim::run_view's calculateDistanceRangeSV call
+        // (tree/MSTPrim.cpp:478); each step is one engine call, so this is a last resort, not a fast path.
+        const bool sensitive = src.orientation_sensitive();
+        const double values = sensitive ? (double)n * n : (double)n * (n - 1) / 2;
+        const bool streaming = values * (src.wide() ? 4 : 2) > 16e9 || getenv("FAMSA_PRIM_STREAMING") != nullptr;
+        LcsBuf buf, rowbuf;
         PrimLcs lcs;
         lcs.n = n;
-        if (src.orientation_sensitive()) {
+        if (streaming) {
+        } else if (sensitive) {
             // ref = the node just added, partner = the candidate (reference MSTPrim.cpp:478-485): the
             // triangle's fixed orientation is not enough, take both orientations
             std::vector<int> all(n);
@@ -111,10 +119,11 @@ void mst_prim(LcsSource& src, tree_structure& tree)
         int cur = 0;
         while (!alive.empty()) {
             const uint32_t len_cur = src.length(cur);
+            if (streaming) src.rect(&cur, 1, alive.data(), (int)alive.size(), rowbuf); // LCS(ref = cur, partner = alive[p])
             size_t best_pos = 0;
             for (size_t p = 0; p < alive.size(); ++p) {
                 const int v = alive[p];
-                const double d = transform(lcs(cur, v), len_cur, src.length(v));
+                const double d = transform(streaming ? rowbuf[p] : lcs(cur, v), len_cur, src.length(v));
                 if (d <= key[v].d) {
                     const Key s{d, ~pack_ids(cur, v)};
                     if (s < key[v]) key[v] = s;

@@ -221,3 +221,19 @@ def test_deep_recursion_against_the_reference_library(host, tmp_path, monkeypatc
             assert got == want, (gt, heur)
     finally:
         ref.close(h)
+
+
+@pytest.mark.parametrize("case,gold", [("adeno_fiber/adeno_fiber", "adeno_fiber/{gt}.dnd"),
+                                       ("adversarial_tree.fasta", "adversarial_tree_{gt}.dnd"),
+                                       ("hemopexin/hemopexin", "hemopexin/{gt}.dnd")])
+@pytest.mark.parametrize("gt", ["sl", "slink"])
+def test_single_linkage_without_the_resident_triangle(tmp_path, case, gold, gt):
+    """What a set too large for the HBM gets (lcsgpu_mst_prim answers LCSGPU_E_NOMEM): -gt sl by Prim steps that ask
+    the engine for one row of the unprocessed vertices each (O(n) memory, MSTPrim::run_view's own structure,
+    reference tree/MSTPrim.cpp:356-533), -gt slink by the row-blocked SLINK loop.  Forced here on small inputs."""
+    out = str(tmp_path / "t.dnd")
+    env = dict(os.environ, FAMSA_NO_DEVICE_MST="1", FAMSA_PRIM_STREAMING="1")
+    p = subprocess.run([host_bind.CLI, "-gt", gt, "-gt_export", os.path.join(G, case), out], stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, env=env)
+    assert p.returncode == 0, p.stderr
+    assert open(out, "rb").read() == open(os.path.join(G, gold.format(gt=gt)), "rb").read()
