@@ -31,7 +31,7 @@
 // exactly what the reference's `continue` (lcsbp_classic.h:82) / padded SIMD lanes do.
 //
 // Refs longer than 2048 residues (the reference's LoopCalculate case, lcsbp_classic.cpp:83)
-// go through lcs_long_kernel: the ref is cut into segments of 32 words that are processed one
+// go through lcs_long_kernel: the ref is cut into segments of 24 words that are processed one
 // after another with the same register-resident step; the carry that leaves the last word of
 // a segment at partner position p is parked in a per-lane bit stream in global memory and
 // re-enters word 0 of the next segment at the same position.
@@ -448,13 +448,13 @@ __global__ __launch_bounds__(256) void lcs_rows_kernel_pipe(RowsArgs a)
 }
 
 // ---- refs longer than 2048 residues -------------------------------------------------------
-// The ref is cut into segments of at most SEGW = 32 words (X of one segment in 64 VGPRs) that are
-// processed one after another; the last segment of a ref uses the narrowest of the 8 / 16 / 24 /
-// 32-word passes that covers what is left, so a 3000-residue ref (47 words) costs 32 + 16 words
-// instead of 2 x 32.  Carries between segments go through a per-lane stream of 16-bit words (one
+// The ref is cut into segments of at most SEGW = 24 words (X of one segment in 48 VGPRs) that are
+// processed one after another; the last segment of a ref uses the narrowest of the 8 / 16 / 24-word
+// passes that covers what is left, so a 3000-residue ref (47 words) costs 24 + 24 words, a 2100-residue
+// one (33 words) 24 + 16.  Carries between segments go through a per-lane stream of 16-bit words (one
 // per 16-residue chunk) in global scratch: carry[(slot*n_chunks + k)*256 + tid], read and
 // rewritten in place by each segment.
-static constexpr int SEGW = 32;
+static constexpr int SEGW = 24; // 32-word passes made hipcc keep two copies of X (212 VGPRs in that loop, 2 waves per SIMD); 24: 106
 
 // one segment of W words of ref `rid`, starting at word `word0`, against this lane's partner
 template <bool QUIRK, int W>
@@ -525,6 +525,7 @@ __device__ __forceinline__ uint32_t long_segment_pass(const RowsArgs& a, int rid
     return res;
 }
 
+// (capping the registers at 128 for 4 waves per SIMD spills 58 dwords and is slower: 3000 aa 310 -> 276 Tcell/s)
 template <bool QUIRK>
 __global__ __launch_bounds__(256) void lcs_long_kernel(RowsArgs a, uint16_t* carry, int n_chunks_max)
 {
@@ -559,8 +560,7 @@ __global__ __launch_bounds__(256) void lcs_long_kernel(RowsArgs a, uint16_t* car
     res += long_segment_pass<QUIRK, W>(a, rid, word0, first, left <= W, smem, pbase, my_chunks, wave_chunks,  \
                                        my_carry, wave, lane);                                                  \
     word0 += W;
-            if (left > 24) { LCS_LONG_PASS(32) }
-            else if (left > 16) { LCS_LONG_PASS(24) }
+            if (left > 16) { LCS_LONG_PASS(24) }
             else if (left > 8) { LCS_LONG_PASS(16) }
             else { LCS_LONG_PASS(8) }
 #undef LCS_LONG_PASS
