@@ -13,6 +13,10 @@ struct RowsArgs {
     const uint8_t* tiles;      // position-major residue store, bytes = code*8
     const uint64_t* tile_base; // byte offset of each 64-sequence tile
     const uint32_t* lens;      // length per sequence
+    // occurrence masks of every sequence, built once at upload: row (mask_base[i] + w) = the 32 x u64 masks
+    // M[code][w] of sequence i's 64-residue word w (codes >= 20 never match: zero); words beyond a sequence: none
+    const uint64_t* masks;
+    const uint64_t* mask_base; // [n + 1] first row of each sequence
     // refs (bit-mask side): ids ref_ids[k] or ref_begin + k, k < n_refs
     const int32_t* ref_ids;
     const int64_t* ref_rows; // output row of ref k (else row0 + k)
@@ -178,7 +182,8 @@ hipError_t launch_assign_seeds(const void* lcs, int elem_size, int64_t ld, const
 // ---- the uploaded set's device form (upload_kernels.hip) ----
 // tiles / quirk flags from the packed codes; flags[0] |= 1 if a symbol code >= 32 was met
 hipError_t launch_build_set(const uint8_t* codes, const uint64_t* offsets, const uint64_t* tile_base, int32_t n,
-                            uint8_t* tiles, uint8_t* quirk, int32_t* flags, hipStream_t stream);
+                            uint8_t* tiles, uint8_t* quirk, int32_t* flags, const uint64_t* mask_base, uint64_t* masks,
+                            hipStream_t stream);
 
 // ---- device-side CLARANS (clarans_kernels.hip) ----
 constexpr int CLARANS_MAX_MEDOIDS = 1024;

@@ -101,30 +101,42 @@ __device__ __forceinline__ int wave_max(int v)
     return v;
 }
 
-// Occurrence masks of `count` 64-bit words of ref `rid`, starting at word
-// `word0`, into LDS rows dst[(w)*32 + c] = M[c][word0 + w]; M as CSequence::ComputeBitMasks
-// builds it (reference core/sequence.cpp:190-201: bits only for codes < 20).  rid < 0 fills
-// "no match".  Called by all 4 waves of the workgroup; item = one word, one wave per item.
+// Occurrence masks of `count` 64-bit words of ref `rid`, starting at word `word0`, into LDS rows
+// dst[w * 32 + c] = M[c][word0 + w]; M as CSequence::ComputeBitMasks builds it (reference core/sequence.cpp:190-201:
+// bits only for codes < 20) -- built once per upload (upload_kernels.hip, masks_fill_kernel) and copied here.
+// rid < 0 or a word beyond the ref fills "no match".  Called by all 256 threads of the workgroup.
 __device__ __forceinline__ void build_mask_words(const RowsArgs& a, int rid, int word0, int count, lds_u64* dst,
                                                  int wave, int lane)
 {
-    for (int w = wave; w < count; w += 4) {
-        uint32_t code8 = 0xFFu;
-        if (rid >= 0) {
-            const uint32_t len = a.lens[rid];
-            const uint32_t p = (uint32_t)(word0 + w) * 64 + lane;
-            if (p < len)
-                code8 = a.tiles[a.tile_base[rid >> 6] + ((uint64_t)(p >> 4) * 64 + (rid & 63)) * 16 + (p & 15)];
+    const int tid = wave * 64 + lane;
+    uint64_t base = 0;
+    int have = 0; // words the ref holds from word0 on
+    if (rid >= 0) {
+        base = a.mask_base[rid];
+        have = (int)(a.mask_base[rid + 1] - base) - word0;
+    }
+    for (int idx = tid; idx < count * 32; idx += 256) {
+        const int w = idx >> 5;
+        dst[idx] = w < have ? a.masks[(base + (uint64_t)(word0 + w)) * 32 + (idx & 31)] : 0ull;
+    }
+}
+
+// The masks of a whole ref tile (nr_pad refs x W words) in one flat sweep: every thread copies its share of the
+// nr_pad * W * 32 mask words, so the loads of different refs overlap instead of queueing ref after ref.
+template <int W>
+__device__ __forceinline__ void fill_tile_masks(const RowsArgs& a, int ref0, int nr, int nr_pad, lds_u64* dst, int tid)
+{
+    const int total = nr_pad * (W * 32);
+#pragma unroll 4
+    for (int idx = tid; idx < total; idx += 256) {
+        const int r = idx / (W * 32), rem = idx - r * (W * 32), w = rem >> 5;
+        uint64_t m = 0;
+        if (r < nr) {
+            const int rid = a.ref_ids ? a.ref_ids[ref0 + r] : a.ref_begin + ref0 + r;
+            const uint64_t base = a.mask_base[rid];
+            if ((uint64_t)w < a.mask_base[rid + 1] - base) m = a.masks[(base + (uint64_t)w) * 32 + (rem & 31)];
         }
-        uint64_t mine = 0;
-#pragma unroll
-        for (int c = 0; c < 20; ++c) {
-            const uint64_t b = __ballot(code8 == (uint32_t)(c * 8));
-            if (lane == c)
-                mine = b;
-        }
-        if (lane < 32)
-            dst[w * 32 + lane] = mine;
+        dst[idx] = m;
     }
 }
 
@@ -379,13 +391,7 @@ __global__ __launch_bounds__(256) void lcs_rows_kernel_pipe(RowsArgs a)
     block_tile(a, R, ref0, nr, c0, col_limit);
     if (block_is_above_diagonal(a, ref0, nr, c0))
         return;
-    {
-        const int nr_pad = (nr + RG - 1) / RG * RG;
-        for (int r = 0; r < nr_pad; ++r) {
-            const int rid = r < nr ? (a.ref_ids ? a.ref_ids[ref0 + r] : a.ref_begin + ref0 + r) : -1;
-            build_mask_words(a, rid, 0, W, (lds_u64*)smem + r * W * 32, wave, lane);
-        }
-    }
+    fill_tile_masks<W>(a, ref0, nr, (nr + RG - 1) / RG * RG, (lds_u64*)smem, tid);
     __syncthreads();
 
     const int c = c0 + tid;

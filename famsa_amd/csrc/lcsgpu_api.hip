@@ -199,6 +199,8 @@ int run_rows(lcsgpu_ctx* ctx, Lane& L, int mode, const int32_t* ref_ids, int32_t
         a.tiles = (const uint8_t*)ctx->d_tiles.p;
         a.tile_base = (const uint64_t*)ctx->d_tile_base.p;
         a.lens = (const uint32_t*)ctx->d_lens.p;
+        a.masks = (const uint64_t*)ctx->d_masks.p;
+        a.mask_base = (const uint64_t*)ctx->d_mask_base.p;
         a.n_refs = (int32_t)bk.items.size();
         if (is_contig[b]) {
             a.ref_ids = nullptr;
@@ -414,6 +416,8 @@ int lcsgpu_destroy(lcsgpu_ctx* ctx)
     ctx->d_tiles.release();
     ctx->d_tile_base.release();
     ctx->d_lens.release();
+    ctx->d_masks.release();
+    ctx->d_mask_base.release();
     ctx->d_pow.release();
     ctx->d_powf.release();
     ctx->d_prim.release();
@@ -487,14 +491,19 @@ int lcsgpu_upload(lcsgpu_ctx* ctx, const uint8_t* codes, const uint64_t* offsets
         const uint64_t chunks = std::max<uint64_t>(1, (tmax + 15) / 16);
         tile_base[t + 1] = tile_base[t] + chunks * 1024;
     }
+    std::vector<uint64_t> mask_base((size_t)n + 1, 0); // rows of 32 x u64 per 64-residue word
+    for (int32_t i = 0; i < n; ++i) mask_base[i + 1] = mask_base[i] + (lens[i] + 63) / 64;
     const size_t total = (size_t)tile_base[n_tiles];
     const size_t raw_bytes = n ? (size_t)(offsets[n] - offsets[0]) : 0;
     if (n && offsets[0] != 0) return fail(LCSGPU_E_INVALID, "offsets[0] must be 0");
     hipError_t e = hipSuccess;
     if ((e = ctx->d_tiles.reserve(std::max<size_t>(total, 16))) != hipSuccess ||
         (e = ctx->d_tile_base.reserve(((size_t)n_tiles + 1) * 8)) != hipSuccess ||
-        (e = ctx->d_lens.reserve(std::max<size_t>((size_t)n * 4, 16))) != hipSuccess)
+        (e = ctx->d_lens.reserve(std::max<size_t>((size_t)n * 4, 16))) != hipSuccess ||
+        (e = ctx->d_mask_base.reserve(((size_t)n + 1) * 8)) != hipSuccess ||
+        (e = ctx->d_masks.reserve(std::max<size_t>((size_t)mask_base[n] * 256, 256))) != hipSuccess)
         return fail(LCSGPU_E_NOMEM, "device allocation failed: %s", hipGetErrorString(e));
+    HIP_TRY(hipMemcpy(ctx->d_mask_base.p, mask_base.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(ctx->d_tile_base.p, tile_base.data(), ((size_t)n_tiles + 1) * 8, hipMemcpyHostToDevice));
     if (n) HIP_TRY(hipMemcpy(ctx->d_lens.p, lens.data(), (size_t)n * 4, hipMemcpyHostToDevice));
     if (n) {
@@ -513,7 +522,8 @@ int lcsgpu_upload(lcsgpu_ctx* ctx, const uint8_t* codes, const uint64_t* offsets
         HIP_TRY(hipMemsetAsync(d_flags, 0, 4, st));
         HIP_TRY(lcsgpu::launch_build_set((const uint8_t*)d_raw.p, (const uint64_t*)d_off.p,
                                          (const uint64_t*)ctx->d_tile_base.p, n, (uint8_t*)ctx->d_tiles.p,
-                                         (uint8_t*)d_quirk.p, d_flags, st));
+                                         (uint8_t*)d_quirk.p, d_flags, (const uint64_t*)ctx->d_mask_base.p,
+                                         (uint64_t*)ctx->d_masks.p, st));
         int32_t flags = 0;
         HIP_TRY(hipMemcpyAsync(quirk.data(), d_quirk.p, (size_t)n, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipMemcpyAsync(&flags, d_flags, 4, hipMemcpyDeviceToHost, st));

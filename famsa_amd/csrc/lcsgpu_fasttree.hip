@@ -259,6 +259,8 @@ int lcsgpu_lcs_triangles_batch(lcsgpu_ctx* ctx, const int32_t* ids, const int64_
         a.tiles = (const uint8_t*)ctx->d_tiles.p;
         a.tile_base = (const uint64_t*)ctx->d_tile_base.p;
         a.lens = (const uint32_t*)ctx->d_lens.p;
+        a.masks = (const uint64_t*)ctx->d_masks.p;
+        a.mask_base = (const uint64_t*)ctx->d_mask_base.p;
         a.n_refs = (int32_t)b.ref_id.size();
         char* d = (char*)L.d_plan.p;
         a.ref_ids = (const int32_t*)(d + o_id[bi]);

@@ -145,7 +145,7 @@ struct lcsgpu_ctx {
     uint32_t max_len = 0;
     std::vector<uint32_t> lens;
     std::vector<uint8_t> quirk; // ref needs the literal (V2 < V) carry rule
-    lcsgpu_impl::DevBuf d_tiles, d_tile_base, d_lens, d_pow, d_powf;
+    lcsgpu_impl::DevBuf d_tiles, d_tile_base, d_lens, d_pow, d_powf, d_masks, d_mask_base;
 
     // scratch of the lane-0 tree reducers
     lcsgpu_impl::DevBuf d_prim, d_qrows, d_qcols, d_dist;

@@ -69,13 +69,43 @@ __global__ __launch_bounds__(256) void quirk_flags_kernel(const uint8_t* __restr
     quirk[seq] = q ? 1 : 0;
 }
 
+// The occurrence masks of every sequence (CSequence::ComputeBitMasks, reference core/sequence.cpp:190-201: bits
+// only for codes < 20), once per upload: one wave per 64-residue word, 20 ballots, lane c keeps code c's mask.
+// The LCS kernels copy the rows of their refs into LDS instead of rebuilding them per workgroup (that was 3 % of
+// the hot kernel's instructions at 400 aa and 11 % at 100 aa).  4 bytes per residue of HBM.
+__global__ __launch_bounds__(256) void masks_fill_kernel(const uint8_t* __restrict__ codes,
+                                                         const uint64_t* __restrict__ offsets,
+                                                         const uint64_t* __restrict__ mask_base, int32_t n,
+                                                         uint64_t* __restrict__ masks)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t seq = blockIdx.x;
+    const uint64_t off = offsets[seq];
+    const uint32_t len = (uint32_t)(offsets[seq + 1] - off);
+    const uint64_t row0 = mask_base[seq];
+    const int words = (int)(mask_base[seq + 1] - row0);
+    for (int w = wave; w < words; w += 4) {
+        const uint32_t p = (uint32_t)w * 64 + lane;
+        const uint32_t code = p < len ? codes[off + p] : 0xFFu;
+        uint64_t mine = 0;
+#pragma unroll
+        for (int c = 0; c < 20; ++c) {
+            const uint64_t b = __ballot(code == (uint32_t)c);
+            if (lane == c) mine = b;
+        }
+        if (lane < 32) masks[(row0 + w) * 32 + lane] = mine;
+    }
+}
+
 hipError_t launch_build_set(const uint8_t* codes, const uint64_t* offsets, const uint64_t* tile_base, int32_t n,
-                            uint8_t* tiles, uint8_t* quirk, int32_t* flags, hipStream_t stream)
+                            uint8_t* tiles, uint8_t* quirk, int32_t* flags, const uint64_t* mask_base, uint64_t* masks,
+                            hipStream_t stream)
 {
     if (n <= 0) return hipSuccess;
     const int n_tiles = (n + 63) / 64;
     hipLaunchKernelGGL(tiles_fill_kernel, dim3(n_tiles), dim3(256), 0, stream, codes, offsets, tile_base, n, tiles, flags);
     hipLaunchKernelGGL(quirk_flags_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, codes, offsets, n, quirk);
+    hipLaunchKernelGGL(masks_fill_kernel, dim3(n), dim3(256), 0, stream, codes, offsets, mask_base, n, masks);
     return hipGetLastError();
 }
 
