@@ -4,7 +4,7 @@
 cd "$(dirname "$0")/.."
 H=tests/golden/hemopexin/hemopexin
 A=tests/golden/adeno_fiber/adeno_fiber
-run() { local t0=$(date +%s.%N); "$@" 2>&1 | tr "\n" " "; local t1=$(date +%s.%N); echo " WALL=$(echo "$t1 - $t0" | bc)"; }
+run() { local t0=$(date +%s%N); "$@" 2>&1 | tr "\n" " "; local t1=$(date +%s%N); echo " WALL_ms=$(( (t1 - t0) / 1000000 ))"; }
 echo "== hemopexin -dist_export"; for i in 1 2 3; do run famsa_amd/famsa-gpu -v -dist_export $H /tmp/o.csv; done
 echo "== hemopexin -gt upgma"; for i in 1 2 3; do run famsa_amd/famsa-gpu -v -gt upgma -gt_export $H /tmp/o.dnd; done
 echo "== hemopexin -gt sl"; for i in 1 2; do run famsa_amd/famsa-gpu -v -gt sl -gt_export $H /tmp/o.dnd; done
