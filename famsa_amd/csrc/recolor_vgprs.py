@@ -406,6 +406,20 @@ def recolor_function(lines, name, rng):
     return best, (n, c0, trail[1], best_c, nv0, used)
 
 
+def _job(job):
+    name, body = job
+    best = None
+    for seed in (12345, 777, 4242):  # fixed seeds: the build is reproducible; the greedy search profits from a few tries
+        out, st = recolor_function(body, name, random.Random(seed))
+        if st is None:
+            return out, st
+        if best is None or st[3] < best[1][3]:
+            best = (out, st)
+        if st[3] * 50 <= st[0]:
+            break
+    return best
+
+
 def main():
     argv = sys.argv[1:]
     only, report, files = None, False, []
@@ -422,22 +436,44 @@ def main():
             i += 1
     src, dst = files
     lines = open(src).read().split("\n")
-    rng = random.Random(12345)
-    out, i, stats = [], 0, []
+    # cut the file into plain stretches and kernel bodies; the bodies are independent jobs
+    pieces, i = [], 0  # ("text", [lines]) | ("kernel", name, [lines])
+    plain = []
     while i < len(lines):
         m = KERNEL_LABEL.match(lines[i])
         if not m or (only and not only.search(m.group(1))):
-            out.append(lines[i])
+            plain.append(lines[i])
             i += 1
             continue
         j = i
         while j < len(lines) and "s_endpgm" not in lines[j]:
             j += 1
-        body, st = recolor_function(lines[i:j + 1], m.group(1), rng)
-        out.extend(body)
-        if st:
-            stats.append((m.group(1), st))
+        if plain:
+            pieces.append(("text", plain))
+            plain = []
+        pieces.append(("kernel", m.group(1), lines[i:j + 1]))
         i = j + 1
+    if plain:
+        pieces.append(("text", plain))
+    jobs = [(p[1], p[2]) for p in pieces if p[0] == "kernel"]
+    import multiprocessing as mp
+    import os
+    workers = max(1, min(len(jobs), len(os.sched_getaffinity(0)), 16))
+    if workers > 1:
+        with mp.Pool(workers) as pool:
+            results = pool.map(_job, jobs, chunksize=1)
+    else:
+        results = [_job(j) for j in jobs]
+    out, stats, k = [], [], 0
+    for p in pieces:
+        if p[0] == "text":
+            out.extend(p[1])
+        else:
+            body, st = results[k]
+            k += 1
+            out.extend(body)
+            if st:
+                stats.append((p[1], st))
     # the kernel descriptors and the metadata of the kernels whose register count grew
     grew = {name: st[5] for name, st in stats if st[5] > st[4]}
     if grew:
