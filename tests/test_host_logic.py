@@ -82,6 +82,18 @@ def test_adversarial_trees_with_carry_quirk(host, oracle, gt):
     assert got == open(os.path.join(G, f"adversarial_tree_{gt}.dnd"), "rb").read()
 
 
+@pytest.mark.parametrize("name,gold", [("adeno_fiber/adeno_fiber", "adeno_fiber/sl.dnd"),
+                                       ("adversarial_tree.fasta", "adversarial_tree_sl.dnd")])
+def test_prim_with_one_row_per_step(host, oracle, monkeypatch, name, gold):
+    """-gt sl when the triangle is not held anywhere: every Prim step asks the source for the row of the node just
+    added against the unprocessed vertices (MSTPrim::run_view's own shape, reference tree/MSTPrim.cpp:356-533) --
+    O(n) memory; the orientation-sensitive set shows that ref = the node just added is honoured."""
+    monkeypatch.setenv("FAMSA_PRIM_STREAMING", "1")
+    f = os.path.join(G, name)
+    m = square(oracle, f, symmetric_ok=(name != "adversarial_tree.fasta"))
+    assert host.tree_from_matrix(f, m, "sl") == open(os.path.join(G, gold), "rb").read()
+
+
 def test_adversarial_csv_zero_lcs(host, oracle, tmp_path):
     f = os.path.join(G, "adversarial.fasta")
     m = square(oracle, f, symmetric_ok=False)
