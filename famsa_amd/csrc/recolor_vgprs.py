@@ -22,7 +22,7 @@ What.  Registers are only names.  Two renamings that cannot change what a kernel
 The register count and everything else in the kernel descriptor stay what they were.  Exactness is not a
 matter of trust: the GPU parity suite compares every instantiation with the oracle bit for bit.
 
-usage: recolor_vgprs.py in.s out.s [--only REGEX] [--report]
+usage: recolor_vgprs.py in.s out.s [--only REGEX] [--report] [--map map.json]
 """
 import random
 import re
@@ -341,7 +341,7 @@ def permute_function(lines, name, rng):
     for ln in lines:
         code, comment = split_code_comment(ln)
         out.append(ln if code.lstrip().startswith(".") else VTOK.sub(sub, code) + comment)
-    return out, (len(tri), start, best, nv)
+    return out, (len(tri), start, best, nv, mapping)
 
 
 def count_conflicts(lines):
@@ -388,22 +388,26 @@ def recolor_function(lines, name, rng):
     # that leave the local pass room, the local pass then re-seats the temporaries around them
     best, best_c, trail = lines, c0, [c0]
     cur = lines
+    perm = {r: r for r in range(nv)}  # compiler's register number -> present number, for values the local pass leaves alone
+    best_perm = dict(perm)
     for _ in range(4):
         cur = local_pass(cur)
         trail.append(count_conflicts(cur)[1])
         if trail[-1] < best_c:
-            best, best_c = cur, trail[-1]
-        cur, _ = permute_function(cur, name, rng)
+            best, best_c, best_perm = cur, trail[-1], dict(perm)
+        cur, pst = permute_function(cur, name, rng)
+        if pst:
+            perm = {r: pst[4].get(v, v) for r, v in perm.items()}
         trail.append(count_conflicts(cur)[1])
         if trail[-1] < best_c:
-            best, best_c = cur, trail[-1]
+            best, best_c, best_perm = cur, trail[-1], dict(perm)
         if len(trail) >= 5 and trail[-1] >= trail[-3]:
             break
     used = 0
     for ln in best:
         for m in VTOK.finditer(split_code_comment(ln)[0]):
             used = max(used, int(m.group(1)) + 1 if m.group(1) is not None else int(m.group(3)) + 1)
-    return best, (n, c0, trail[1], best_c, nv0, used)
+    return best, (n, c0, trail[1], best_c, nv0, used, best_perm)
 
 
 def _job(job):
@@ -422,7 +426,7 @@ def _job(job):
 
 def main():
     argv = sys.argv[1:]
-    only, report, files = None, False, []
+    only, report, files, map_file = None, False, [], None
     i = 0
     while i < len(argv):
         if argv[i] == "--only":
@@ -431,6 +435,9 @@ def main():
         elif argv[i] == "--report":
             report = True
             i += 1
+        elif argv[i] == "--map":
+            map_file = argv[i + 1]
+            i += 2
         else:
             files.append(argv[i])
             i += 1
@@ -504,11 +511,14 @@ def main():
                 cur_kernel = None
             out.append(ln)
     open(dst, "w").write("\n".join(out))
+    if map_file:  # for tests: where the global renaming put each of the compiler's registers
+        import json
+        json.dump({name: {str(k): v for k, v in st[6].items()} for name, st in stats}, open(map_file, "w"))
     if report:
         t = [sum(s[k] for _, s in stats) for k in range(4)]
         print(f"recolor_vgprs: {len(stats)} kernels, {t[0]} three-source v_bitop3_b32; with a shared bank: {t[1]} as compiled "
               f"-> {t[2]} after the local pass -> {t[3]} after the permutation", file=sys.stderr)
-        for name, (n, a, b, c, nv0, nv1) in stats:
+        for name, (n, a, b, c, nv0, nv1, _) in stats:
             if "Li13ELi4E" in name or c * 20 > n:
                 print(f"  {name}: {n} ops, shared bank {a} -> {b} -> {c} ({nv0} -> {nv1} VGPRs)", file=sys.stderr)
 
