@@ -313,14 +313,16 @@ int lcsgpu_create(int device_id, lcsgpu_ctx** out_ctx)
     if (!out_ctx) return fail(LCSGPU_E_INVALID, "out_ctx is NULL");
     *out_ctx = nullptr;
     int n_lanes = 16;
-    if (const char* e = getenv("LCSGPU_LANES")) n_lanes = std::max(1, std::min(64, atoi(e)));
-    // One hardware queue per lane, so that the lanes' small kernels really overlap: the runtime's
+    if (const char* e = getenv("LCSGPU_LANES")) n_lanes = std::max(1, std::min(MAX_LANES, atoi(e)));
+    // One hardware queue per lane up to 16, so that the lanes' small kernels really overlap: the runtime's
     // default of 4 queues makes 16 streams share them and serialises their launches (1 M-sequence
-    // MedoidTree: 4.7 s -> 2.6 s of tree stage).  Read by the HIP runtime when it initialises, i.e.
-    // effective if this is the process's first HIP call; an explicit setting by the user wins.
+    // MedoidTree: 4.7 s -> 2.6 s of tree stage).  More than 16 queues cost more than they give (3 x 10^6-sequence
+    // MedoidTree, tree stage: 16 queues 2.6 s, 24: 3.0 s, 32: 3.5 s, 64: 7.2 s), further lanes share the 16.  Read by
+    // the HIP runtime when it initialises, i.e. effective if this is the process's first HIP call; an explicit
+    // setting by the user wins.
     {
         char buf[16];
-        snprintf(buf, sizeof buf, "%d", n_lanes);
+        snprintf(buf, sizeof buf, "%d", std::min(n_lanes, 16));
         setenv("GPU_MAX_HW_QUEUES", buf, 0);
     }
     const bool profile = getenv("LCSGPU_PROFILE") != nullptr;
@@ -343,7 +345,8 @@ int lcsgpu_create(int device_id, lcsgpu_ctx** out_ctx)
     lcsgpu_ctx* ctx = new (std::nothrow) lcsgpu_ctx;
     if (!ctx) return fail(LCSGPU_E_NOMEM, "out of host memory");
     ctx->device = device_id;
-    ctx->lanes.resize(n_lanes);
+    ctx->lanes.resize(MAX_LANES);
+    ctx->lane_limit = n_lanes;
     // lane 0 now; the others (and the streams of the CLARANS batches) when first needed -- see Lane::created
     if (!create_lane(ctx, ctx->lanes[0])) {
         lcsgpu_destroy(ctx);
@@ -363,7 +366,12 @@ int lcsgpu_create(int device_id, lcsgpu_ctx** out_ctx)
 int lcsgpu_reserve_lanes(lcsgpu_ctx* ctx, int32_t n_threads)
 {
     if (!ctx) return fail(LCSGPU_E_INVALID, "NULL ctx");
-    for (size_t i = 1; i < ctx->lanes.size() && (int32_t)i <= n_threads; ++i) {
+    {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        ctx->lane_limit = std::max(ctx->lane_limit, std::min<int>(MAX_LANES, n_threads + 1));
+    }
+    // the first 16 now, the others when a call first needs them (created by the calling threads, in parallel)
+    for (size_t i = 1; i < (size_t)ctx->lane_limit && (int32_t)i <= std::min(n_threads, 16); ++i) {
         Lane& l = ctx->lanes[i];
         {
             std::lock_guard<std::mutex> lk(ctx->mu);

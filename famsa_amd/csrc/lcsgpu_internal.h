@@ -87,6 +87,7 @@ struct PinBuf {
 // one CLCSBP per worker thread -- get their small LCS requests executed concurrently instead of
 // queueing behind one stream; device-memory calls and the tree reducers always use lane 0, whose
 // stream is the one lcsgpu_stream() hands out.
+constexpr int MAX_LANES = 64;
 struct Lane {
     hipStream_t stream = nullptr;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
@@ -138,7 +139,8 @@ struct lcsgpu_ctx {
     int device = 0;
     std::mutex mu; // guards the lane table
     std::condition_variable cv;
-    std::vector<Lane> lanes;
+    std::vector<Lane> lanes;  // MAX_LANES slots; a slot costs nothing until its lane is created
+    int lane_limit = 16;      // lanes [0, lane_limit) are handed out (lcsgpu_reserve_lanes raises it)
 
     // uploaded set (read-only while any lane is busy)
     int32_t n = -1;
@@ -206,7 +208,7 @@ public:
             for (;;) {
                 int pick = -1, fresh = -1;
                 bool others = false;
-                for (size_t i = 1; i < ctx->lanes.size(); ++i) {
+                for (size_t i = 1; i < (size_t)ctx->lane_limit; ++i) {
                     const Lane& l = ctx->lanes[i];
                     if (l.unusable) continue;
                     if (l.created) others = true;

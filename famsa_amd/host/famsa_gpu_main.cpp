@@ -139,7 +139,7 @@ int main(int argc, char** argv)
         setenv("GPU_MAX_HW_QUEUES", getenv("LCSGPU_LANES") ? getenv("LCSGPU_LANES") : "16", 0);
         g_abandon_engine_at_return = getenv("FAMSA_GPU_CLEAN_EXIT") == nullptr;
         // HIP initialisation runs while the input is read and sorted; the heuristics' worker threads get their lanes now
-        EngineFuture engine = start_engine(devices, opt.heuristic != 0 ? n_threads : 0);
+        EngineFuture engine = start_engine(devices, opt.heuristic != 0 ? fasttree_pool_threads(n_threads) : 0);
         const int device = devices[0];
         SeqSet s = load_fasta(input, n_threads);
         if (s.size() == 0) throw std::runtime_error("no sequences in " + input);

@@ -46,6 +46,8 @@ public:
     virtual void triangle_ids(const int* ids, int n_ids, LcsBuf& out);
     // values need 32 bits (some sequence longer than 65535 residues); sources cache this
     virtual bool wide() const;
+    // a hint: requests will come from this many host threads at once (the FastTree pool)
+    virtual void expect_threads(int /*n_threads*/) {}
     // Prim's MST computed by the source itself (the GPU engine does it on the device): n-1 edges
     // (from < to, distance) in the order they are added from vertex 0.  Returns false if the
     // source cannot (then the caller runs Prim on the host over triangle()/rect()).
@@ -81,7 +83,7 @@ public:
     ~GpuLcsSource() override;
     int n_devices() const { return (int)ctxs_.size(); }
     // the FastTree recursion calls from `n_threads` host threads: have the engine's lanes ready (lcsgpu_reserve_lanes)
-    void expect_threads(int n_threads);
+    void expect_threads(int n_threads) override;
     void upload(const std::vector<uint8_t>& codes, const std::vector<uint64_t>& offsets);
     int n() const override { return (int)lens_.size(); }
     uint32_t length(int i) const override { return lens_[i]; }

@@ -41,8 +41,10 @@ struct FastTreeParams { // CParams::medoid, reference core/params.h:88-97
     int threshold = 2000;
     float cluster_fraction = 0.1f;
     int cluster_iters = 2;
-    int n_threads = 1; // worker threads for the sub-trees of the top-level split
+    int n_threads = 1; // host cores the recursion may keep busy
 };
+// threads of the recursion's task pool for `n_cpu` cores: the ones waiting for the GPU cost no core
+inline int fasttree_pool_threads(int n_cpu) { return n_cpu > 1 ? 2 * n_cpu : 1; }
 void build_tree_fast(LcsSource& src, GT partial, Distance dist, const FastTreeParams& p, tree_structure& tree);
 // the host form of the CLARANS search (used when the LcsSource does not run it itself)
 void clarans_host(const float* distances, int n_elems, int n_medoids, int n_fixed, float explore_fraction, int num_local,
