@@ -80,7 +80,13 @@ int ensure_batcher(lcsgpu_ctx* ctx, ClaransBatcher& B)
     std::lock_guard<std::mutex> lk(B.mu);
     if (B.stream) return LCSGPU_OK;
     HIP_TRY(hipSetDevice(ctx->device));
-    HIP_TRY(hipStreamCreateWithFlags(&B.stream, hipStreamNonBlocking));
+    // the rounds are chains of small dependent kernels next to the lanes' LCS launches, which fill the chip for
+    // hundreds of microseconds each: their workgroups go first when slots free up
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = greatest = 0;
+    if (getenv("LCSGPU_CLARANS_NO_PRIORITY")) greatest = least = 0;
+    if (greatest != least) HIP_TRY(hipStreamCreateWithPriority(&B.stream, hipStreamNonBlocking, greatest));
+    else HIP_TRY(hipStreamCreateWithFlags(&B.stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&B.ev, hipEventBlockingSync | hipEventDisableTiming));
     HIP_TRY(B.h_states.reserve(lcsgpu::CLARANS_MAX_BATCH * 64));
     return LCSGPU_OK;

@@ -26,9 +26,7 @@ run() { # label, env...
     echo "$label rep=$rep rc=$rc wall_ms=$(( (t1 - t0) / 1000000 )) sha=$(sha256sum /tmp/sweep.dnd | cut -c1-16) $(grep -E 'tree|clarans|partial|lcs_calls|assign' /tmp/sweep.err | tr '\n' ' ')" >> $OUT
   done
 }
-run "defaults" X=1
-run "pool=16" FAMSA_GPU_POOL_THREADS=16
-run "pool=48" FAMSA_GPU_POOL_THREADS=48
-run "defaults groups=2" LCSGPU_CLARANS_GROUPS=2
-run "defaults groups=8" LCSGPU_CLARANS_GROUPS=8
+run "defaults (priority streams)" X=1
+run "no priority" LCSGPU_CLARANS_NO_PRIORITY=1
+run "defaults (priority streams) again" X=1
 cat $OUT
