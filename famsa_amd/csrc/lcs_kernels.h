@@ -144,9 +144,11 @@ struct UpgmaArgs {
     uint32_t* node_index; // [n]
     float* part_d;        // [2][n_blocks] per-workgroup minima of the new row, alternating between merges
     uint32_t* part_j;
-    float* bm_d;          // [n_blocks] first minimum of min_dist over each workgroup's 256 rows
-    uint32_t* bm_j;
-    uint32_t* sel;        // [2][4] (Lmin, Rmin) of the merges, alternating; [8] error flag
+    float* bm_d;          // [n_blocks] first minimum of min_dist over each workgroup's 256 rows,
+    uint32_t* bm_j;       //            its row
+    uint32_t* bm_near;    //            and that row's nearest
+    uint32_t* sel;        // 64 words: (Lmin, Rmin) of the merges, error flag, the touched workgroups' other minima
+                          // (tree_kernels.hip, UPGMA_SEL_EXCL)
     int32_t* left;        // [n-1] children of the internal nodes
     int32_t* right;
     int32_t n;

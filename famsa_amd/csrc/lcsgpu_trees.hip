@@ -529,14 +529,15 @@ int upgma_reduce(lcsgpu_ctx* ctx, Lane& L, int elem, int distance_kind, int modi
     const size_t o_min = 0, o_near = o_min + a16((size_t)n * 4), o_node = o_near + a16((size_t)n * 4),
                  o_pd = o_node + a16((size_t)n * 4), o_pj = o_pd + a16((size_t)2 * blocks * 4),
                  o_bd = o_pj + a16((size_t)2 * blocks * 4), o_bj = o_bd + a16((size_t)blocks * 4),
-                 o_sel = o_bj + a16((size_t)blocks * 4), o_left = o_sel + 48, o_right = o_left + a16((size_t)n * 4),
-                 total = o_right + a16((size_t)n * 4);
+                 o_bn = o_bj + a16((size_t)blocks * 4), o_sel = o_bn + a16((size_t)blocks * 4), o_left = o_sel + 256,
+                 o_right = o_left + a16((size_t)n * 4), total = o_right + a16((size_t)n * 4);
     HIP_TRY(ctx->d_prim.reserve(total));
     char* base = (char*)ctx->d_prim.p;
-    HIP_TRY(hipMemsetAsync(base + o_sel, 0, 48, L.stream));
+    HIP_TRY(hipMemsetAsync(base + o_sel, 0, 256, L.stream));
     lcsgpu::UpgmaArgs a{};
     a.bm_d = (float*)(base + o_bd);
     a.bm_j = (uint32_t*)(base + o_bj);
+    a.bm_near = (uint32_t*)(base + o_bn);
     a.D = (float*)ctx->d_dist.p;
     a.min_dist = (float*)(base + o_min);
     a.nearest = (uint32_t*)(base + o_near);

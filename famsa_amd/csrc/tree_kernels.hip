@@ -273,7 +273,8 @@ __device__ __forceinline__ void take_first_min(float d, uint32_t j, float& bd, u
     if (d < UPGMA_BIG && (d < bd || (d == bd && j < bj))) { bd = d; bj = j; }
 }
 
-// first minimum of min_dist over the 256 rows of every workgroup: the global pick then only looks at these
+// first minimum of min_dist over the 256 rows of every workgroup (and that row's nearest): the global pick then only
+// looks at these
 __global__ __launch_bounds__(256) void upgma_block_min_kernel(UpgmaArgs a)
 {
     __shared__ float s_d[256];
@@ -286,8 +287,30 @@ __global__ __launch_bounds__(256) void upgma_block_min_kernel(UpgmaArgs a)
     if (threadIdx.x == 0) {
         a.bm_d[blockIdx.x] = d;
         a.bm_j[blockIdx.x] = bj;
+        a.bm_near[blockIdx.x] = bj != UPGMA_NONE ? a.nearest[bj] : UPGMA_NONE;
     }
 }
+
+// (value, index, nearest-of-index) candidates of the pick
+__device__ __forceinline__ void take_first_min3(float d, uint32_t j, uint32_t nr, float& bd, uint32_t& bj, uint32_t& bn)
+{
+    if (d < UPGMA_BIG && (d < bd || (d == bd && j < bj))) { bd = d; bj = j; bn = nr; }
+}
+// block_first_min that also hands every thread the third field of the winner
+__device__ __forceinline__ void block_first_min3(float& d, uint32_t& j, uint32_t& nr, float* s_d, uint32_t* s_j, uint32_t* s_n)
+{
+    const uint32_t mine_j = j, mine_n = nr;
+    block_first_min(d, j, s_d, s_j);
+    // (a barrier lies between every reader of *s_n below and the next call's write: block_first_min starts with one)
+    if (j != UPGMA_NONE && mine_j == j) *s_n = mine_n; // all holders of the winner hold the same record
+    __syncthreads();
+    nr = j != UPGMA_NONE ? *s_n : UPGMA_NONE;
+}
+
+// words of UpgmaArgs::sel: [4p + 0..1] = (Lmin, Rmin) of the merges of parity p; [8] = error flag;
+// [16 + 4(2p + w) + 0..2] = (min_dist bits, row, its nearest) of the first minimum over the rows of the workgroup
+// that owns Lmin (w = 0) / Rmin (w = 1) of the merge of parity p, WITHOUT the rows Lmin and Rmin themselves
+constexpr int UPGMA_SEL_EXCL = 16;
 
 // One launch = one merge of UPGMA::computeTree (tree/UPGMA.cpp:198-288).  The merges are strictly
 // sequential and the only synchronisation is the kernel boundary, so every workgroup redoes the small
@@ -296,89 +319,109 @@ __global__ __launch_bounds__(256) void upgma_block_min_kernel(UpgmaArgs a)
 //      previous launch left (two buffers, alternating);
 //   2. pick this merge: first minimum of min_dist over the active rows = first minimum of the
 //      per-workgroup minima bm[], where the two workgroups that own the rows touched by merge it-1 are
-//      recomputed from their rows (with the not-yet-written changes of step 1 applied as patches);
-//   3. update its own 256 rows (new distances to the merged cluster, nearest-pointer rename).
+//      replaced by the minima over their other rows which their owners left in sel[] (computed while merge it-1
+//      was applied), completed by the merged row itself;
+//   3. update its own 256 rows (new distances to the merged cluster, nearest-pointer rename), and, as the owner of
+//      Lmin's / Rmin's rows, leave the minimum over the other rows for the next launch.
+// A kernel boundary leaves nothing in the caches, so what a launch costs is its chain of DEPENDENT loads (~1.5-2 us
+// each): every address of steps 1-2 is known before the launch (one level: bm[] carries each minimum's nearest, so
+// Rmin needs no look-up), the only dependent level is the two distance rows of step 3.  (Round 1's form had four:
+// the selection, the touched workgroups' rows, nearest[Lmin], the distance rows -- 11 us per merge.)
 // Workgroup 0 does the bookkeeping writes of step 1; the owners write their bm[] entries; everything a
-// launch writes that the same launch reads elsewhere is overridden there by the same patch, so the
-// order in which workgroups run does not matter.
+// launch writes that the same launch reads elsewhere is either unused there or overridden by the same patch, so
+// the order in which workgroups run does not matter.
 template <bool MODIFIED>
 __global__ __launch_bounds__(256) void upgma_step_kernel(UpgmaArgs a, int it)
 {
     __shared__ float s_d[256];
     __shared__ uint32_t s_j[256];
+    __shared__ uint32_t s_n;
     const int tid = threadIdx.x, b = blockIdx.x, nb = a.n_blocks, n = a.n;
     const uint32_t j = (uint32_t)b * 256 + tid;
     const bool in = j < (uint32_t)n;
-    // requested first: nothing below depends on these addresses
+    const int pp = (it - 1) & 1, pc = it & 1;
+    // ---- the one level of loads whose addresses are known before the launch ----
     const uint32_t my_node = in ? a.node_index[j] : UPGMA_NONE;
     const uint32_t my_near = in ? a.nearest[j] : UPGMA_NONE;
-
-    // ---- 1. finish merge it-1 ----
-    uint32_t Lp = UPGMA_NONE, Rp = UPGMA_NONE, bLp = UPGMA_NONE, bRp = UPGMA_NONE;
+    const float my_min = in ? a.min_dist[j] : UPGMA_BIG;
+    const uint32_t own_bm_j = a.bm_j[b];
+    uint32_t Lp = UPGMA_NONE, Rp = UPGMA_NONE;
+    float eLd = UPGMA_BIG, eRd = UPGMA_BIG;
+    uint32_t eLj = UPGMA_NONE, eRj = UPGMA_NONE, eLn = UPGMA_NONE, eRn = UPGMA_NONE;
     float new_d = UPGMA_BIG;
     uint32_t new_j = UPGMA_NONE;
     if (it > 0) {
-        const uint32_t* selp = a.sel + 4 * ((it - 1) & 1);
-        Lp = selp[0];
-        Rp = selp[1];
-        bLp = Lp >> 8;
-        bRp = Rp >> 8;
-        const float* pd = a.part_d + (size_t)((it - 1) & 1) * nb;
-        const uint32_t* pj = a.part_j + (size_t)((it - 1) & 1) * nb;
+        Lp = a.sel[4 * pp + 0];
+        Rp = a.sel[4 * pp + 1];
+        const uint32_t* e = a.sel + UPGMA_SEL_EXCL + 8 * pp;
+        eLd = __uint_as_float(e[0]); eLj = e[1]; eLn = e[2];
+        eRd = __uint_as_float(e[4]); eRj = e[5]; eRn = e[6];
+        const float* pd = a.part_d + (size_t)pp * nb;
+        const uint32_t* pj = a.part_j + (size_t)pp * nb;
         for (int x = tid; x < nb; x += 256) take_first_min(pd[x], pj[x], new_d, new_j);
-        block_first_min(new_d, new_j, s_d, s_j);
     }
-    // ---- 2. pick ----
     float cd = UPGMA_BIG;
-    uint32_t cj = UPGMA_NONE;
-    for (int x = tid; x < nb; x += 256)
-        if ((uint32_t)x != bLp && (uint32_t)x != bRp) take_first_min(a.bm_d[x], a.bm_j[x], cd, cj);
-    float own_d = UPGMA_BIG; // the recomputed minimum of the touched workgroup this one owns (if any)
-    uint32_t own_j = UPGMA_NONE;
+    uint32_t cj = UPGMA_NONE, cn = UPGMA_NONE;
+    {
+        const uint32_t bLp = Lp >> 8, bRp = Rp >> 8; // UPGMA_NONE >> 8 is no workgroup
+        for (int x = tid; x < nb; x += 256) {
+            const float d = a.bm_d[x];
+            const uint32_t dj = a.bm_j[x], dn = a.bm_near[x]; // loaded whatever x is: no load waits for Lp
+            if ((uint32_t)x != bLp && (uint32_t)x != bRp) take_first_min3(d, dj, dn, cd, cj, cn);
+        }
+    }
+    uint32_t nodeLp = UPGMA_NONE, nodeRp = UPGMA_NONE;
+    if (it > 0 && b == 0 && tid == 0) { // in flight during the reductions below
+        nodeLp = a.node_index[Lp];
+        nodeRp = a.node_index[Rp];
+    }
+    // ---- 1. finish merge it-1 ----
+    if (it > 0) block_first_min(new_d, new_j, s_d, s_j);
+    // ---- 2. pick ----
+    const uint32_t bLp = Lp >> 8, bRp = Rp >> 8;
+    float tLd = UPGMA_BIG, tRd = UPGMA_BIG; // the minima of the two touched workgroups as they are now
+    uint32_t tLj = UPGMA_NONE, tRj = UPGMA_NONE, tLn = UPGMA_NONE, tRn = UPGMA_NONE;
     if (it > 0) {
-#pragma unroll
-        for (int which = 0; which < 2; ++which) {
-            const uint32_t blk = which == 0 ? bLp : bRp;
-            if (which == 1 && bRp == bLp) break;
-            const uint32_t r = blk * 256 + tid;
-            float d = UPGMA_BIG;
-            uint32_t rj = UPGMA_NONE;
-            if (r < (uint32_t)n && r != Rp && a.node_index[r] != UPGMA_NONE)
-                take_first_min(r == Lp ? new_d : a.min_dist[r], r, d, rj);
-            take_first_min(d, rj, cd, cj);
-            if (blk == (uint32_t)b) { own_d = d; own_j = rj; }
-        }
+        take_first_min3(eLd, eLj, eLn, tLd, tLj, tLn);
+        take_first_min3(new_d, Lp, new_j, tLd, tLj, tLn); // the merged row: its minimum and nearest are still in flight
+        if (bRp != bLp) take_first_min3(eRd, eRj, eRn, tRd, tRj, tRn);
+        take_first_min3(tLd, tLj, tLn, cd, cj, cn);
+        take_first_min3(tRd, tRj, tRn, cd, cj, cn);
     }
-    block_first_min(cd, cj, s_d, s_j);
+    block_first_min3(cd, cj, cn, s_d, s_j, &s_n);
     const uint32_t L = cj;
-    if (it > 0 && ((uint32_t)b == bLp || (uint32_t)b == bRp)) {
-        block_first_min(own_d, own_j, s_d, s_j);
-        if (tid == 0) {
-            a.bm_d[b] = own_d;
-            a.bm_j[b] = own_j;
-        }
-    }
     uint32_t R = UPGMA_NONE;
-    if (it < n - 1 && L != UPGMA_NONE) R = L == Lp ? new_j : a.nearest[L];
+    if (it < n - 1 && L != UPGMA_NONE) R = cn;
     if (b == 0 && tid == 0) {
         if (it > 0) {
-            a.left[it - 1] = (int32_t)a.node_index[Lp];
-            a.right[it - 1] = (int32_t)a.node_index[Rp];
+            a.left[it - 1] = (int32_t)nodeLp;
+            a.right[it - 1] = (int32_t)nodeRp;
             a.node_index[Lp] = (uint32_t)n + (uint32_t)(it - 1);
             a.node_index[Rp] = UPGMA_NONE;
             a.min_dist[Lp] = new_d;
         }
         if (it < n - 1) {
-            a.sel[4 * (it & 1) + 0] = L;
-            a.sel[4 * (it & 1) + 1] = R;
+            a.sel[4 * pc + 0] = L;
+            a.sel[4 * pc + 1] = R;
             if (L == UPGMA_NONE || R == UPGMA_NONE) a.sel[8] = 1; // degenerate input (reference: UB)
         }
+    }
+    const bool touched = it > 0 && ((uint32_t)b == bLp || (uint32_t)b == bRp);
+    if (touched && tid == 0) { // this workgroup's minimum changed with merge it-1
+        const bool isL = (uint32_t)b == bLp;
+        uint32_t nr = isL ? tLn : tRn;
+        if (nr == R && R != UPGMA_NONE) nr = L; // ... and this merge renames
+        a.bm_d[b] = isL ? tLd : tRd;
+        a.bm_j[b] = isL ? tLj : tRj;
+        a.bm_near[b] = nr;
     }
     if (it >= n - 1) return; // the last launch only finishes merge n-2
     // ---- 3. update my rows ----
     float nd = UPGMA_BIG;
     uint32_t nj = UPGMA_NONE;
-    if (L != UPGMA_NONE && R != UPGMA_NONE && in && my_node != UPGMA_NONE && j != Rp && j != L && j != R) {
+    const bool row_ok = L != UPGMA_NONE && R != UPGMA_NONE && in && my_node != UPGMA_NONE && j != Rp && j != L && j != R;
+    uint32_t near_j = UPGMA_NONE;
+    if (row_ok) {
         const size_t vL = tri_index(L, j), vR = tri_index(R, j);
         const float dL = a.D[vL], dR = a.D[vR];
         float v;
@@ -386,17 +429,34 @@ __global__ __launch_bounds__(256) void upgma_step_kernel(UpgmaArgs a, int it)
             v = __fadd_rn(__fmul_rn(0.05f, __fadd_rn(dL, dR)), __fmul_rn(0.9f, fminf(dL, dR)));
         else
             v = __fmul_rn(__fadd_rn(dL, dR), 0.5f);
-        uint32_t near_j = j == Lp ? new_j : my_near; // the row of the previous merge: its nearest is still in flight
+        near_j = j == Lp ? new_j : my_near; // the row of the previous merge: its nearest is still in flight
         if (near_j == R) near_j = L;
-        if (near_j != my_near) a.nearest[j] = near_j;
+        if (near_j != my_near) {
+            a.nearest[j] = near_j;
+            if (!touched && j == own_bm_j) a.bm_near[b] = near_j;
+        }
         a.D[vL] = v;
         nd = v;
         nj = j;
     }
     block_first_min(nd, nj, s_d, s_j);
     if (tid == 0) {
-        a.part_d[(size_t)(it & 1) * nb + b] = nd;
-        a.part_j[(size_t)(it & 1) * nb + b] = nj;
+        a.part_d[(size_t)pc * nb + b] = nd;
+        a.part_j[(size_t)pc * nb + b] = nj;
+    }
+    // the owners of Lmin's and Rmin's rows: the minimum over their OTHER rows, for the next launch's pick
+    const uint32_t bL = L >> 8, bR = R >> 8;
+    if (L != UPGMA_NONE && R != UPGMA_NONE && ((uint32_t)b == bL || (uint32_t)b == bR)) {
+        float ed = UPGMA_BIG;
+        uint32_t ej = UPGMA_NONE, en = UPGMA_NONE;
+        if (row_ok) take_first_min3(j == Lp ? new_d : my_min, j, near_j, ed, ej, en);
+        block_first_min3(ed, ej, en, s_d, s_j, &s_n);
+        if (tid == 0) {
+            uint32_t* e = a.sel + UPGMA_SEL_EXCL + 8 * pc + ((uint32_t)b == bL ? 0 : 4);
+            e[0] = __float_as_uint(ed);
+            e[1] = ej;
+            e[2] = en;
+        }
     }
 }
 

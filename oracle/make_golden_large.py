@@ -63,14 +63,14 @@ def c3(ref, meta):
     save(meta)
 
 
-def c4(ref, meta):
+def c4(ref, meta, gts=("sl",)):
     n, L = 100000, 400
     codes, offsets = seqio.synth_uniform(n, L)
     path = "/tmp/golden_synth100k.fasta"
     seqio.to_fasta(codes, offsets, path)
     h = ref.open_fasta(path)
     rec = meta.get("synth100k", {"n": n, "len": L, "codes_sha256": sha(codes.tobytes())})
-    for gt in ("sl",):
+    for gt in gts:
         t0 = time.time()
         rec[f"{gt}_newick_sha256"] = sha(ref.tree(h, gt, threads=THREADS))
         rec[f"{gt}_reference_seconds_{THREADS}_threads"] = round(time.time() - t0, 1)
@@ -104,7 +104,7 @@ def main():
     ref = oracle_bind.Ref()
     meta = load()
     for w in which:
-        {"c3": c3, "c4": c4, "c5": c5}[w](ref, meta)
+        {"c3": c3, "c4": c4, "c5": c5, "c4upgma": lambda r, m: c4(r, m, ("upgma", "upgma_modified"))}[w](ref, meta)
     print(json.dumps(load(), indent=1))
 
 
