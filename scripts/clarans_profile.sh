@@ -20,3 +20,5 @@ FAMSA_GPU_CLEAN_EXIT=1 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/cpro
 tail -3 /tmp/cprof.log
 python $ROOT/scripts/rocpd_summary.py $(find /tmp/cprof -name "*.db") > $ROOT/gpurun_out/clarans_kernel_stats.txt
 python $ROOT/scripts/rocpd_timeline.py $(find /tmp/cprof -name "*.db") clarans >> $ROOT/gpurun_out/clarans_kernel_stats.txt 2>&1
+python $ROOT/scripts/rocpd_timeline.py $(find /tmp/cprof -name "*.db") lcs_rows >> $ROOT/gpurun_out/clarans_kernel_stats.txt 2>&1
+python $ROOT/scripts/rocpd_timeline.py $(find /tmp/cprof -name "*.db") lcsgpu >> $ROOT/gpurun_out/clarans_kernel_stats.txt 2>&1

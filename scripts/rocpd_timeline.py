@@ -55,6 +55,7 @@ for t, dlt in ev:
         hist[cur_n] += t - last
     cur_n += dlt; last = t
 tot = sum(hist.values())
+print("span %.1f ms, at least one in flight %.1f ms" % (tot / 1e6, (tot - hist.get(0, 0)) / 1e6))
 print("in flight (share of the span):", " ".join(f"{k}:{100*v/tot:.1f}%" for k, v in sorted(hist.items())))
 # per stream: gap between the end of one dispatch and the start of the next
 if c_q:
