@@ -3,7 +3,8 @@
 deterministic generators).  Model: the reference's own at-size regression, .github/workflows/self-hosted.yml:424-461.
 
   C3  synthetic 10 000 x 400 aa: the u16 LCS triangle and the sl / slink / upgma Newick
-  C4  synthetic 100 000 x 400 aa: -gt sl Newick (one GPU; the 2-context row-block form too), sampled oracle check
+  C4  synthetic 100 000 x 400 aa: -gt sl Newick (one GPU; the 2-context row-block form too), sampled oracle check;
+      -gt upgma / upgma_modified Newick
   C5  'family' sets of 200 000 and 1 000 000 sequences: -medoidtree -gt upgma Newick
       (3 000 000: FAMSA_TEST_HUGE=1 -- device CLARANS + 16 threads against host CLARANS + 1 thread)
 """
@@ -78,6 +79,18 @@ def test_c4_single_linkage_tree(synth100k, tmp_path):
     out = str(tmp_path / "sl.dnd")
     cli("-gt", "sl", "-gt_export", synth100k[2], out)
     assert file_sha(out) == META["synth100k"]["sl_newick_sha256"]
+
+
+@pytest.mark.parametrize("gt", ["upgma", "upgma_modified"])
+def test_c4_upgma_trees(synth100k, tmp_path, gt):
+    """100 000 merges on the device (one launch each) over the 20 GB float triangle: the per-workgroup minima are
+    two per thread at this size (391 workgroups), which no smaller case reaches."""
+    key = f"{gt}_newick_sha256"
+    if key not in META["synth100k"]:
+        pytest.skip("no reference value (oracle/make_golden_large.py c4upgma)")
+    out = str(tmp_path / f"{gt}.dnd")
+    cli("-gt", gt, "-gt_export", synth100k[2], out)
+    assert file_sha(out) == META["synth100k"][key]
 
 
 def test_c4_row_block_contexts_tree_and_sampled_triangle(oracle, synth100k):
