@@ -59,8 +59,10 @@ int lcsgpu_device_count(void);
 int lcsgpu_create(int device_id, lcsgpu_ctx** out_ctx);
 int lcsgpu_destroy(lcsgpu_ctx* ctx);
 /* Optional: a context creates the stream pairs of its internal lanes when a call first needs them (~20 ms each;
- * a single-threaded caller never needs a second one).  A caller that is about to issue host-memory calls from
- * `n_threads` threads (the FastTree recursion) can have that many created now -- e.g. while it still reads its input. */
+ * a single-threaded caller never needs a second one) and hands out at most 16 of them at a time.  A caller that is
+ * about to issue host-memory calls from `n_threads` threads (the FastTree recursion) raises that limit to n_threads
+ * (at most 64; lanes beyond 16 share the 16 hardware queues) and has the first 16 created now -- e.g. while it still
+ * reads its input. */
 int lcsgpu_reserve_lanes(lcsgpu_ctx* ctx, int32_t n_threads);
 
 /* Residue characters -> symbol codes, gaps ('-') dropped.
