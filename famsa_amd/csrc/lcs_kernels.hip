@@ -31,7 +31,7 @@
 // exactly what the reference's `continue` (lcsbp_classic.h:82) / padded SIMD lanes do.
 //
 // Refs longer than 2048 residues (the reference's LoopCalculate case, lcsbp_classic.cpp:83)
-// go through lcs_long_kernel: the ref is cut into segments of 24 words that are processed one
+// go through lcs_long_kernel: the ref is cut into segments of 16 words that are processed one
 // after another with the same register-resident step; the carry that leaves the last word of
 // a segment at partner position p is parked in a per-lane bit stream in global memory and
 // re-enters word 0 of the next segment at the same position.
@@ -454,13 +454,19 @@ __global__ __launch_bounds__(256) void lcs_rows_kernel_pipe(RowsArgs a)
 }
 
 // ---- refs longer than 2048 residues -------------------------------------------------------
-// The ref is cut into segments of at most SEGW = 24 words (X of one segment in 48 VGPRs) that are
-// processed one after another; the last segment of a ref uses the narrowest of the 8 / 16 / 24-word
-// passes that covers what is left, so a 3000-residue ref (47 words) costs 24 + 24 words, a 2100-residue
-// one (33 words) 24 + 16.  Carries between segments go through a per-lane stream of 16-bit words (one
+// The ref is cut into segments of at most SEGW words (X of one segment in 2 x SEGW VGPRs) that are
+// processed one after another; the last segment of a ref uses the narrowest of the 8 / 16-word
+// passes that covers what is left, so a 3000-residue ref (47 words) costs 16 + 16 + 16 words, a 2100-residue
+// one (33 words) 16 + 16 + 8.  Carries between segments go through a per-lane stream of 16-bit words (one
 // per 16-residue chunk) in global scratch: carry[(slot*n_chunks + k)*256 + tid], read and
 // rewritten in place by each segment.
-static constexpr int SEGW = 24; // 32-word passes made hipcc keep two copies of X (212 VGPRs in that loop, 2 waves per SIMD); 24: 106
+// Segment width, measured with the single-block chunk loop below (6000 sequences of 2100 / 3000 / 4200 / 6000
+// residues, Tcell/s): 16 words (88 VGPRs, 5 waves per SIMD) 363 / 433 / 387 / 417, 24 words (108 VGPRs, 4 waves)
+// 364 / 427 / 384 / 412, 32 words (124 VGPRs) 361 / 428 / 382 / 415 -- the narrowest is kept.
+#ifndef LCS_SEGW
+#define LCS_SEGW 16
+#endif
+static constexpr int SEGW = LCS_SEGW;
 
 // one segment of W words of ref `rid`, starting at word `word0`, against this lane's partner
 template <bool QUIRK, int W>
@@ -484,16 +490,23 @@ __device__ __forceinline__ uint32_t long_segment_pass(const RowsArgs& a, int rid
             q = *(const uint4*)pbase;
         uint64_t ring[LCS_LOOKAHEAD];
         P::prime((const lds_u8*)smem, q, ring);
+        // The chunk body must stay ONE basic block up to the loop latch: with a conditional carry store behind it
+        // the compiler sank the last residue's 2W X updates past the branch and kept their 3 x 2W operands alive
+        // over the whole body (24 words: 187 VGPRs, 2 waves per SIMD).  So the carry word is stored always (the
+        // last segment's is never read) and the next chunk's incoming word is requested a chunk ahead, like qn.
+        uint32_t cw = (!first && 0 < wave_chunks) ? my_carry[0] : 0u;
         for (int k = 0; k < wave_chunks; ++k) {
             uint4 qn = make_uint4(PAD4, PAD4, PAD4, PAD4);
             if (k + 1 < my_chunks)
                 qn = *(const uint4*)(pbase + (size_t)(k + 1) * 1024);
-            const uint32_t cw = first ? 0u : my_carry[(size_t)k * 256];
+            uint32_t cwn = 0;
+            if (!first && k + 1 < wave_chunks)
+                cwn = my_carry[(size_t)(k + 1) * 256];
             uint32_t cout = 0;
             P::template chunk<true>((const lds_u8*)smem, q, qn, ring, X, cw, &cout);
-            if (!last)
-                my_carry[(size_t)k * 256] = (uint16_t)cout;
+            my_carry[(size_t)k * 256] = (uint16_t)cout;
             q = qn;
+            cw = cwn;
         }
 #pragma unroll
         for (int j = 0; j < 2 * W; ++j)
@@ -531,7 +544,6 @@ __device__ __forceinline__ uint32_t long_segment_pass(const RowsArgs& a, int rid
     return res;
 }
 
-// (capping the registers at 128 for 4 waves per SIMD spills 58 dwords and is slower: 3000 aa 310 -> 276 Tcell/s)
 template <bool QUIRK>
 __global__ __launch_bounds__(256) void lcs_long_kernel(RowsArgs a, uint16_t* carry, int n_chunks_max)
 {
@@ -566,7 +578,8 @@ __global__ __launch_bounds__(256) void lcs_long_kernel(RowsArgs a, uint16_t* car
     res += long_segment_pass<QUIRK, W>(a, rid, word0, first, left <= W, smem, pbase, my_chunks, wave_chunks,  \
                                        my_carry, wave, lane);                                                  \
     word0 += W;
-            if (left > 16) { LCS_LONG_PASS(24) }
+            if (SEGW >= 32 && left > 24) { LCS_LONG_PASS(32) }
+            else if (SEGW >= 24 && left > 16) { LCS_LONG_PASS(24) }
             else if (left > 8) { LCS_LONG_PASS(16) }
             else { LCS_LONG_PASS(8) }
 #undef LCS_LONG_PASS

@@ -38,6 +38,7 @@ class Lane:
         self.v = dict(vgpr)
         self.vcc = 0
         self.carry = {}  # SGPR pairs written by VALU carries / compares
+        self.stores = []  # (address, data) of global stores, in program order
 
     def val(self, tok):
         tok = tok.strip()
@@ -118,6 +119,20 @@ def run_block(lines, lane):
             off = int(re.search(r"offset:(\d+)", mods).group(1)) if "offset:" in mods else 0
             x = mix((v(ops[1]) + off) & M32)
             (lane.set64 if op == "ds_read_b64" else lane.set)(ops[0], x)
+        elif op in ("global_load_ushort", "global_load_dword", "global_load_dwordx4") and ops[2] == "off":
+            # memory is a function of the address (the long-ref kernel's carry stream / residue chunks)
+            off = int(re.search(r"offset:(-?\d+)", mods).group(1)) if "offset:" in mods else 0
+            x = mix((lane.val64(ops[1]) + off) & 0xFFFFFFFFFFFFFFFF)
+            if op == "global_load_dwordx4":
+                m = re.fullmatch(r"v\[(\d+):(\d+)\]", ops[0])
+                for i, r in enumerate(range(int(m.group(1)), int(m.group(2)) + 1)):
+                    lane.v[r] = mix(x + i) & M32
+            else:
+                lane.set(ops[0], x & (0xFFFF if op.endswith("ushort") else M32))
+        elif op in ("global_store_short", "global_store_dword") and ops[2] == "off":
+            off = int(re.search(r"offset:(-?\d+)", mods).group(1)) if "offset:" in mods else 0
+            lane.stores.append(((lane.val64(ops[0]) + off) & 0xFFFFFFFFFFFFFFFF,
+                                v(ops[1]) & (0xFFFF if op.endswith("short") else M32)))
         elif op == "v_add_u32_sdwa":
             sel = re.search(r"src1_sel:BYTE_(\d)", mods)
             assert sel and "src0_sel:DWORD" in mods and "dst_sel:DWORD" in mods, code
@@ -215,6 +230,7 @@ def test_loop_bodies_compute_the_same(recolored, kernel):
             bad = [r for r in sorted(named) if old_lane.v[r] != new_lane.v[perm[r]]]
             assert not bad, (kernel, n3, bad[:10])
             assert old_lane.vcc == new_lane.vcc
+            assert old_lane.stores == new_lane.stores
         checked += 1
     assert checked >= 1
 
