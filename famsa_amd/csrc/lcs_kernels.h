@@ -120,6 +120,9 @@ struct BoruvkaArgs {
     int32_t* comp_next;         // [n] ... after this round
     int32_t* parent;            // [n] hooking forest over the component roots
     MstKey* row_best;           // [n] row-pass result (rows of this block only)
+    uint2* row_aux;             // [n] (LCS, length of the other endpoint) of row_best: seeds the column pass's filter
+    const uint32_t* minlen16;   // [ceil(n/16)]   shortest sequence of every aligned block of 16 vertices
+    const uint32_t* minlen1024; // [ceil(n/1024)] ... of 1024 vertices (the passes' integer pre-filter)
     MstKey* part;               // [n_chunks][n] column-pass partials
     MstKey* best;               // [n] this block's best edge per vertex = what a GPU contributes to the exchange
     MstKey* vbest;              // [n] best edge per vertex over all blocks (after the exchange)

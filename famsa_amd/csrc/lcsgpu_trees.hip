@@ -51,7 +51,9 @@ static int shard_begin(lcsgpu_ctx* ctx, Lane& L, const void* d_tri, int elem, in
                  o_vb = o_best + a256((size_t)n * key), o_cd = o_vb + a256((size_t)n * key),
                  o_ci = o_cd + a256((size_t)n * 8), o_part = o_ci + a256((size_t)n * 8),
                  o_edges = o_part + a256((size_t)n_chunks * n * key),
-                 o_cnt = o_edges + a256((size_t)std::max(n - 1, 1) * sizeof(lcsgpu::MstEdge)), total = o_cnt + 256;
+                 o_cnt = o_edges + a256((size_t)std::max(n - 1, 1) * sizeof(lcsgpu::MstEdge)), o_aux = o_cnt + 256,
+                 o_m16 = o_aux + a256((size_t)n * 8), o_m1k = o_m16 + a256(((size_t)n + 15) / 16 * 4),
+                 total = o_m1k + a256(((size_t)n + 1023) / 1024 * 4);
     int rc = reserve_big(ctx, ctx->d_mst, total, "the MST state");
     if (rc) return rc;
     char* base = (char*)ctx->d_mst.p;
@@ -75,6 +77,9 @@ static int shard_begin(lcsgpu_ctx* ctx, Lane& L, const void* d_tri, int elem, in
     b.part = (lcsgpu::MstKey*)(base + o_part);
     b.edges = (lcsgpu::MstEdge*)(base + o_edges);
     b.counters = (int32_t*)(base + o_cnt);
+    b.row_aux = (uint2*)(base + o_aux);
+    b.minlen16 = (const uint32_t*)(base + o_m16);
+    b.minlen1024 = (const uint32_t*)(base + o_m1k);
     b.n = n;
     b.kind = kind;
     b.n_chunks = n_chunks;

@@ -20,10 +20,10 @@
 // The component labels are a pure function of the exchanged keys, so every GPU derives the same ones.
 //
 // Distances: Transform<double, kind> (reference tree/AbstractTreeGenerator.hpp:28-82) exactly -- host-built
-// pow table + IEEE f64 division -- but only for candidates that can win: a multiplication-only float test
-// (certainly_worse) against a per-lane threshold kept just above the lane's current exact best proves most
-// candidates larger than the best, and the table look-up, the f64 division and the 128-bit compare are
-// skipped for them.  History of the two passes at n = 100 000 (10 GB of u16 each) is in DESIGN.md.
+// pow table + IEEE f64 division -- but only for candidates that can win: one integer comparison of the LCS
+// length against a threshold derived from the current best edge (l_threshold below) proves most candidates
+// worse than the best, and component labels, lengths, the table look-up, the f64 division and the 128-bit
+// compare are skipped for them.  History of the two passes at n = 100 000 (10 GB of u16 each) is in DESIGN.md.
 //
 // Valid when d(u, v) does not depend on which endpoint is the ref: always for the triangle's own
 // orientation (what SLINK sees), and for MSTPrim's orientation when no uploaded sequence is orientation
@@ -53,17 +53,15 @@ __device__ __forceinline__ unsigned long long pack_ids(uint32_t a, uint32_t b) /
     return a < b ? ((unsigned long long)a << 32) + b : ((unsigned long long)b << 32) + a;
 }
 
-// a lane's running best: exact key, the (l, indel) it came from, and the float threshold that admits every
-// candidate able to beat it (KIND 1: the threshold lives in the d^4 domain, see certainly_worse)
+// a lane's running best: exact key, the (l, indel) it came from (ties on both are settled on the ids alone) and the
+// length of the edge's other endpoint (what the integer pre-filter needs besides l)
 struct Best {
     unsigned long long d = NO_D, id = NO_ID;
-    uint32_t l = ~0u, indel = ~0u;
-    float thr = __builtin_inff();
+    uint32_t l = ~0u, indel = ~0u, len_o = 0;
 };
 
 // pow(i, 0.75) for the exact path: from LDS when the table fits -- the exact path then touches no global
-// memory, so it never waits for the triangle loads in flight (and the compiler's s_waitcnt vmcnt bookkeeping
-// of those loads stays exact) -- else from HBM
+// memory for it -- else from HBM
 template <bool IN_LDS>
 struct PowTable {
     const double* p;
@@ -78,33 +76,29 @@ __device__ __forceinline__ PowTable<IN_LDS> stage_pow_table(const BoruvkaArgs& a
     return PowTable<IN_LDS>{smem};
 }
 
-// Pre-filter, multiplications only.  KIND 1: d = indel^0.75 / l, and d > t  <=>  indel^3 > t^4 l^4; KIND 0:
-// d = indel / l > t  <=>  indel > t l.  `thr` holds (best d x (1 + 2^-14))^4 resp. best d x (1 + 2^-14), the
-// five float roundings stay below 2^-21, so "greater" is certain.  l == 0 or an infinite threshold give
-// NaN / inf on the right-hand side: not "greater", the exact path decides.  `excluded` (same component)
-// counts as worse than anything.
-template <int KIND>
-__device__ __forceinline__ bool may_win(float thr, uint32_t l, uint32_t indel, bool excluded)
+// The pre-filter: ONE integer comparison of the LCS length.  For a fixed vertex v, d(l, S) = f(S - 2l) / l with
+// S = len_v + len_other is decreasing in l and increasing in S, and along a level line d = const the slope
+// dl/dS = 0.75 l / (1.5 l + indel)  (indel^0.75 / l)  resp.  l / S  (indel / l)  never exceeds 1/2.  So with a best
+// edge (l_b, len_b) in hand, a candidate whose other endpoint is at least `minlen` long can reach the best's
+// distance only with  l >= l_b - max(0, len_b - minlen) / 2;  every l at least one below that bound is worse by
+// a factor >= 1 + 1/65535, far beyond the roundings of the table and the division, so dropping
+//     l < l_b - ceil(max(0, len_b - minlen) / 2)
+// drops no candidate that could win or tie.  minlen = the shortest sequence of the batch (minlen16 / minlen1024,
+// built once per tree), so the bulk of a pass costs a max-reduction and a compare per batch; component labels,
+// lengths, the table look-up, the f64 division and the 128-bit key compare are touched by the survivors only.
+__device__ __forceinline__ uint32_t l_threshold(uint32_t l_b, uint32_t len_b, uint32_t minlen)
 {
-    const float x = (float)indel, lf = (float)l;
-    float lhs, rhs;
-    if (KIND == 1) {
-        const float l2 = lf * lf;
-        lhs = (x * x) * x;
-        rhs = thr * (l2 * l2);
-    } else {
-        lhs = x;
-        rhs = thr * lf;
-    }
-    lhs = excluded ? __builtin_inff() : lhs;
-    return !(lhs > rhs);
+    if (l_b == ~0u) return 0; // no best yet: everything goes the exact way
+    const uint32_t slack = len_b > minlen ? (len_b - minlen + 1) >> 1 : 0;
+    return l_b > slack ? l_b - slack : 0;
 }
 
 // The exact comparison: Transform<double, KIND> (hpp:28-82) and MSTPrim's key order.  A candidate with the
 // best's own (l, indel) has the best's distance bit for bit: only the ids decide, no division.  Returns true
-// if the threshold changed.
+// if the best's (l, length) changed.
 template <int KIND, typename PW>
-__device__ __forceinline__ bool exact_update(const PW& pw, Best& b, uint32_t l, uint32_t indel, uint32_t lo, uint32_t hi)
+__device__ __forceinline__ bool exact_update(const PW& pw, Best& b, uint32_t l, uint32_t indel, uint32_t lo, uint32_t hi,
+                                             uint32_t len_other)
 {
     const unsigned long long id = ~(((unsigned long long)lo << 32) + hi);
     if (l == b.l && indel == b.indel) {
@@ -121,32 +115,18 @@ __device__ __forceinline__ bool exact_update(const PW& pw, Best& b, uint32_t l, 
     b.id = id;
     b.l = l;
     b.indel = indel;
-    const float t = __double2float_ru(d) * 1.00006104f; // x (1 + 2^-14), stays >= d (1 + 2^-15)
-    if (KIND == 1) {
-        const float t2 = t * t;
-        float t4 = t2 * t2;
-        if (t4 < 1e-30f && t != 0.0f) t4 = __builtin_inff(); // no float headroom left: everything goes the exact way
-        b.thr = t4;
-    } else {
-        b.thr = t;
-    }
+    b.len_o = len_other;
     return true;
 }
 
-// smallest value over the wave, for non-negative floats (their bit patterns order like the values)
-__device__ __forceinline__ float wave_min_nonneg(float f)
+// smallest key of the wave, in every lane
+__device__ __forceinline__ void wave_min_key(unsigned long long& d, unsigned long long& id)
 {
-    uint32_t x = __float_as_uint(f);
-    uint32_t y;
-    y = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0xB1, 0xF, 0xF, false);  x = y < x ? y : x; // quad_perm [1,0,3,2]
-    y = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x4E, 0xF, 0xF, false);  x = y < x ? y : x; // quad_perm [2,3,0,1]
-    y = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x141, 0xF, 0xF, false); x = y < x ? y : x; // row_half_mirror
-    y = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x140, 0xF, 0xF, false); x = y < x ? y : x; // row_mirror
-    uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)x, 0);
-    y = (uint32_t)__builtin_amdgcn_readlane((int)x, 16); r = y < r ? y : r;
-    y = (uint32_t)__builtin_amdgcn_readlane((int)x, 32); r = y < r ? y : r;
-    y = (uint32_t)__builtin_amdgcn_readlane((int)x, 48); r = y < r ? y : r;
-    return __uint_as_float(r);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long d2 = __shfl_xor(d, o, 64), i2 = __shfl_xor(id, o, 64);
+        if (key_less(d2, i2, d, id)) { d = d2; id = i2; }
+    }
 }
 
 } // namespace
@@ -156,147 +136,113 @@ __global__ __launch_bounds__(256) void boruvka_init_kernel(BoruvkaArgs a)
     const int v = blockIdx.x * 256 + threadIdx.x;
     if (v < a.n) a.comp[v] = v;
     if (v == 0) a.counters[0] = 0; // edges recorded so far
+    // shortest sequence per aligned block of 16 / 1024 vertices (the passes' pre-filter)
+    if (v < (a.n + 15) / 16) {
+        uint32_t m = ~0u;
+        for (int i = 16 * v; i < min(a.n, 16 * v + 16); ++i) m = min(m, a.lens[i]);
+        const_cast<uint32_t*>(a.minlen16)[v] = m;
+    }
+    if (v < (a.n + 1023) / 1024) {
+        uint32_t m = ~0u;
+        for (int i = 1024 * v; i < min(a.n, 1024 * v + 1024); ++i) m = min(m, a.lens[i]);
+        const_cast<uint32_t*>(a.minlen1024)[v] = m;
+    }
 }
 
-// What bounds the two passes (PMC, n = 50 000): not HBM -- the CU's single SCALAR unit (80% busy: per-element
-// index arithmetic, mask combining, branches and scalar-load addresses of 4 SIMDs' waves) and the exact path
-// (a wave takes it when ANY lane has a candidate that may win: 30-70% of the elements while every lane keeps
-// its own young threshold).  Hence: (1) the bulk of each pass runs without range tests, on batches whose
-// per-row data come in wide scalar loads, with ONE branch per group of four elements; (2) ties with the
-// current best are settled on the ids alone; (3) the row pass, where all lanes of a wave work for the same
-// vertex, shares the threshold across the wave after every update; the column pass gives each lane a long
-// stream (few row chunks) so thresholds mature early; (4) two batches of loads are in flight per lane, all of
-// them unconditional (clamped indices), so the loop bodies are straight-line code with exact s_waitcnt counts.
+// The two passes stream the block's triangle once each (2 B per pair) and are meant to be bound by that stream:
+// per batch of 16 elements a lane does 15 max + 1 compare against the integer threshold above; only batches with a
+// survivor look at component labels and lengths (gathers) and at the exact key.  (History: the float pre-filter of
+// the first version cost ~14 VALU per element plus per-element scalar work -- the CU's scalar unit was 80% busy --
+// and read comp[] / lens[] for every column: row pass 2.85 ms, column pass 3.8 ms per 10 GB at n = 100 000.)
 constexpr int COLS_PER_WG = 256; // columns of one workgroup of the column pass
-constexpr int ROWS_PER_WG = 4;   // rows of one workgroup of the row pass: they share the per-column loads
+constexpr int ROWS_PER_WG = 4;   // rows of one workgroup of the row pass: one per wave
 typedef int int4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 
-// the smallest key of the workgroup -> returned in thread 0 (all 256 threads call it)
-__device__ __forceinline__ MstKey block_min_key(unsigned long long d, unsigned long long id, MstKey* s_wave /* [4] */)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const unsigned long long d2 = __shfl_xor(d, o, 64), i2 = __shfl_xor(id, o, 64);
-        if (key_less(d2, i2, d, id)) { d = d2; id = i2; }
-    }
-    __syncthreads(); // s_wave may still be read by the previous call
-    if ((threadIdx.x & 63) == 0) s_wave[threadIdx.x >> 6] = MstKey{d, id};
-    __syncthreads();
-    MstKey k = s_wave[0];
-#pragma unroll
-    for (int w = 1; w < 4; ++w)
-        if (key_less(s_wave[w].d, s_wave[w].id, k.d, k.id)) k = s_wave[w];
-    return k;
-}
-
-// best edge of the vertices v = r0 + ROWS_PER_WG * blockIdx.x + r among u < v (row v of the triangle), to
-// another component; lanes stride over the columns.
+// best edge of the vertex v (one WAVE per row, the block's longest rows first) among u < v (row v of the triangle)
+// to another component; lanes stride over the columns, 16 x 64 columns per batch, two batches of loads in flight.
+// All lanes work for the same vertex, so the filter's threshold is the wave's: after every update the best of the
+// wave is found and its (l, length) broadcast.
 template <typename T, int KIND, bool POW_LDS>
 __global__ __launch_bounds__(256) void boruvka_row_kernel(BoruvkaArgs a)
 {
-    __shared__ MstKey s_wave[4];
     extern __shared__ double s_pow[];
-    constexpr int R = ROWS_PER_WG, UNR = 4;
-    const int tid = threadIdx.x;
+    constexpr int UNR = 16, STEP = 64 * UNR;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const PowTable<POW_LDS> pw = stage_pow_table<POW_LDS>(a, s_pow);
-    const int vb = a.r0 + blockIdx.x * R;
-    const int nr = min(R, a.r1 - vb);
-    const int vmax = vb + nr - 1; // the longest row of the tile
-    if (vmax < 1) { // row 0 alone: nothing below it
-        if (tid == 0) a.row_best[vb] = MstKey{NO_D, NO_ID};
+    const int v = a.r1 - 1 - (blockIdx.x * ROWS_PER_WG + wave);
+    if (v < a.r0) return;
+    if (v < 1) { // row 0: nothing below it
+        if (lane == 0) {
+            a.row_best[v] = MstKey{NO_D, NO_ID};
+            a.row_aux[v] = make_uint2(~0u, 0u);
+        }
         return;
     }
-    int v[R], cv[R], last[R];
-    uint32_t len_v[R];
-    const T* row[R];
-    Best b[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const int vr = r < nr ? vb + r : vmax;
-        cv[r] = a.comp[vr];
-        len_v[r] = a.lens[vr];
-        const int vp = vr >= 1 ? vr : vmax;        // the row the loads go to (row 0 has no elements)
-        row[r] = (const T*)a.tri + ((int64_t)vp * (vp - 1) / 2 - a.off);
-        last[r] = vp - 1;                            // its last valid column
-        v[r] = r < nr ? vr : 0;                      // columns u < v[r] count (0: none)
-        if (r >= nr) b[r].thr = -1.0f;               // a missing row: every candidate is "certainly worse"
-    }
-    T l[2][R][UNR];
-    int cu[2][UNR];
-    uint32_t lu[2][UNR];
+    const int cv = a.comp[v];
+    const uint32_t len_v = a.lens[v];
+    const T* row = (const T*)a.tri + ((int64_t)v * (v - 1) / 2 - a.off);
+    const int last = v - 1;
+    Best b;
+    uint32_t wl = ~0u, wlen = 0; // (l, length) of the wave's best edge so far
+    T l[2][UNR];
     auto request = [&](int ub, int s) {
 #pragma unroll
-        for (int k = 0; k < UNR; ++k) {
-            const int u = ub + 256 * k;
-            const int uc = min(u, vmax);
-            cu[s][k] = a.comp[uc];
-            lu[s][k] = a.lens[uc];
-#pragma unroll
-            for (int r = 0; r < R; ++r) l[s][r][k] = row[r][min(u, last[r])];
-        }
+        for (int k = 0; k < UNR; ++k) l[s][k] = row[min(ub + lane + 64 * k, last)];
     };
-    // BULK = true: every column of the batch lies below every row of the tile (u < vb): no range tests
-    auto evaluate = [&](int ub, int s, auto bulk) {
-        constexpr bool BULK = decltype(bulk)::value;
+    auto evaluate = [&](int ub, int s) {
+        const uint32_t thr = l_threshold(wl, wlen, a.minlen1024[ub >> 10]);
+        uint32_t m = l[s][0];
+#pragma unroll
+        for (int k = 1; k < UNR; ++k) m = max(m, (uint32_t)l[s][k]);
+        if (__builtin_amdgcn_ballot_w64(m >= thr) == 0) return;
         bool changed = false;
 #pragma unroll
         for (int k = 0; k < UNR; ++k) {
-            const int u = ub + 256 * k;
-            bool pass[R];
-            uint32_t indel[R];
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const uint32_t lv = l[s][r][k];
-                indel[r] = len_v[r] + lu[s][k] - 2u * lv;
-                pass[r] = may_win<KIND>(b[r].thr, lv, indel[r], cu[s][k] == cv[r] || (!BULK && u >= v[r]));
-            }
-            bool any = false;
-#pragma unroll
-            for (int r = 0; r < R; ++r) any |= pass[r];
-            if (any) {
-#pragma unroll
-                for (int r = 0; r < R; ++r)
-                    if (pass[r] && r < nr && u < v[r] && cu[s][k] != cv[r])
-                        changed |= exact_update<KIND>(pw, b[r], l[s][r][k], indel[r], (uint32_t)u, (uint32_t)v[r]);
+            const int u = ub + lane + 64 * k;
+            const uint32_t lv = l[s][k];
+            if (lv >= thr && u < v) {
+                if (a.comp[u] != cv) {
+                    const uint32_t lu = a.lens[u];
+                    changed |= exact_update<KIND>(pw, b, lv, len_v + lu - 2u * lv, (uint32_t)u, (uint32_t)v, lu);
+                }
             }
         }
-        // all lanes of the wave work for the same vertices: a threshold one lane has reached holds for all
         if (__builtin_amdgcn_ballot_w64(changed) != 0) {
-#pragma unroll
-            for (int r = 0; r < R; ++r)
-                if (r < nr) b[r].thr = wave_min_nonneg(b[r].thr);
+            unsigned long long d = b.d, id = b.id;
+            wave_min_key(d, id);
+            const unsigned long long who = __builtin_amdgcn_ballot_w64(b.d == d && b.id == id);
+            const int src = __ffsll((long long)who) - 1;
+            wl = (uint32_t)__builtin_amdgcn_readlane((int)b.l, src);
+            wlen = (uint32_t)__builtin_amdgcn_readlane((int)b.len_o, src);
         }
     };
-    constexpr int STEP = 256 * UNR;
-    // batches [ub, ub + STEP) with ub + STEP <= vb lie entirely below the tile's rows; processed in pairs
-    int ub = tid;
-    const int n_pairs = vb / (2 * STEP);
-    request(ub, 0);
-    for (int it = 0; it < n_pairs; ++it, ub += 2 * STEP) {
-        request(ub + STEP, 1);
-        evaluate(ub, 0, std::true_type{});
+    request(0, 0);
+    for (int ub = 0; ub < v; ub += 2 * STEP) {
+        request(ub + STEP, 1); // past the row's end: clamped, never evaluated
+        evaluate(ub, 0);
         request(ub + 2 * STEP, 0);
-        evaluate(ub + STEP, 1, std::true_type{});
+        if (ub + STEP < v) evaluate(ub + STEP, 1);
     }
-    for (; ub < vmax; ub += 2 * STEP) { // the rest, with range tests (l[0] holds the batch at ub)
-        request(ub + STEP, 1);
-        evaluate(ub, 0, std::false_type{});
-        request(ub + 2 * STEP, 0);
-        evaluate(ub + STEP, 1, std::false_type{});
-    }
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const MstKey k = block_min_key(b[r].d, b[r].id, s_wave);
-        if (tid == 0 && r < nr) a.row_best[vb + r] = k;
+    unsigned long long d = b.d, id = b.id;
+    wave_min_key(d, id);
+    const unsigned long long who = __builtin_amdgcn_ballot_w64(b.d == d && b.id == id);
+    const int src = __ffsll((long long)who) - 1;
+    const uint32_t bl = (uint32_t)__builtin_amdgcn_readlane((int)b.l, src);
+    const uint32_t blen = (uint32_t)__builtin_amdgcn_readlane((int)b.len_o, src);
+    if (lane == 0) {
+        a.row_best[v] = MstKey{d, id};
+        a.row_aux[v] = make_uint2(bl, blen);
     }
 }
 
 // best edge of vertex v (lane = column) among the rows u > v of one row chunk of the block -> part[chunk][v].
-// The row index is uniform across the workgroup: comp[u] / lens[u] are scalar loads, 16 rows per load.
+// The row index is uniform across the workgroup: what the survivors need of comp[u] / lens[u] are scalar loads.
+// A lane of the block's own rows starts from the row pass's result for its vertex (the row pass runs first):
+// only candidates that beat it matter, and its threshold is mature from the first batch on.
 template <typename T, int KIND, bool POW_LDS>
 __global__ __launch_bounds__(256) void boruvka_col_kernel(BoruvkaArgs a)
 {
-    constexpr int UNR = 16, GRP = 4; // rows per batch (two batches in flight); elements per branch
+    constexpr int UNR = 16; // rows per batch (two batches in flight)
     const int c0 = blockIdx.x * COLS_PER_WG;
     const int v = c0 + threadIdx.x;
     const int chunk = blockIdx.y;
@@ -309,6 +255,17 @@ __global__ __launch_bounds__(256) void boruvka_col_kernel(BoruvkaArgs a)
     const int cv = a.comp[v];
     const uint32_t len_v = a.lens[v];
     const T* tri = (const T*)a.tri - a.off;
+    if (v >= a.r0 && v < a.r1) {
+        const MstKey k = a.row_best[v];
+        if (k.id != NO_ID) {
+            const uint2 aux = a.row_aux[v];
+            b.d = k.d;
+            b.id = k.id;
+            b.l = aux.x;
+            b.len_o = aux.y;
+            b.indel = len_v + aux.y - 2u * aux.x;
+        }
+    }
 
     // rows [ua, ub): one by one, with the range test (the diagonal block and the chunk's last rows)
     auto plain_rows = [&](int ua, int ub) {
@@ -316,8 +273,9 @@ __global__ __launch_bounds__(256) void boruvka_col_kernel(BoruvkaArgs a)
             const int cu = a.comp[u];
             const uint32_t len_u = a.lens[u];
             if (u > v && cu != cv) {
-                const uint32_t lv = tri[(int64_t)u * (u - 1) / 2 + v], indel = len_u + len_v - 2u * lv;
-                if (may_win<KIND>(b.thr, lv, indel, false)) exact_update<KIND>(pw, b, lv, indel, (uint32_t)v, (uint32_t)u);
+                const uint32_t lv = tri[(int64_t)u * (u - 1) / 2 + v];
+                if (lv >= l_threshold(b.l, b.len_o, len_u))
+                    exact_update<KIND>(pw, b, lv, len_u + len_v - 2u * lv, (uint32_t)v, (uint32_t)u, len_u);
             }
         }
     };
@@ -326,41 +284,36 @@ __global__ __launch_bounds__(256) void boruvka_col_kernel(BoruvkaArgs a)
     plain_rows(first, bulk0);
 
     T l[2][UNR];
+    // rows ub .. ub + UNR - 1 (all < u1): ONE 64-bit row base per batch (scalar), then 32-bit offsets that grow by the
+    // row length -- the per-row 64-bit u(u-1)/2 cost ~15 scalar instructions each, and the CU's one scalar unit,
+    // shared by the waves of all four SIMDs, was what the pass waited for
     auto request = [&](int ub, int s) {
+        const char* base = (const char*)(tri + (int64_t)ub * (ub - 1) / 2);
+        uint32_t off = (uint32_t)sizeof(T) * (uint32_t)v;
 #pragma unroll
         for (int k = 0; k < UNR; ++k) {
-            const int64_t us = min(ub + k, u1 - 1); // > v here
-            l[s][k] = tri[us * (us - 1) / 2 + v];
+            l[s][k] = *(const T*)(base + off);
+            off += (uint32_t)sizeof(T) * (uint32_t)(ub + k);
         }
     };
-    auto evaluate = [&](int ub, int s) { // a full batch of the bulk: rows ub .. ub + UNR - 1 < u1, all below... above every lane's column
-        int cu[UNR];
-        uint32_t len_u[UNR];
+    auto evaluate = [&](int ub, int s) { // a full batch of the bulk: rows ub .. ub + UNR - 1 < u1, all below every lane's column
+        const uint32_t mb = min(a.minlen16[ub >> 4], a.minlen16[(ub + UNR - 1) >> 4]);
+        uint32_t thr = l_threshold(b.l, b.len_o, mb);
+        uint32_t m = l[s][0];
 #pragma unroll
-        for (int q = 0; q < UNR / 4; ++q) {
-            const int4_a4 c = *(const int4_a4*)(a.comp + ub + 4 * q);
-            const int4_a4 n = *(const int4_a4*)(a.lens + ub + 4 * q);
-            cu[4 * q] = c.x; cu[4 * q + 1] = c.y; cu[4 * q + 2] = c.z; cu[4 * q + 3] = c.w;
-            len_u[4 * q] = (uint32_t)n.x; len_u[4 * q + 1] = (uint32_t)n.y; len_u[4 * q + 2] = (uint32_t)n.z; len_u[4 * q + 3] = (uint32_t)n.w;
-        }
+        for (int k = 1; k < UNR; ++k) m = max(m, (uint32_t)l[s][k]);
+        if (m >= thr) {
 #pragma unroll
-        for (int g = 0; g < UNR; g += GRP) {
-            bool pass[GRP];
-            uint32_t indel[GRP];
-#pragma unroll
-            for (int j = 0; j < GRP; ++j) {
-                const uint32_t lv = l[s][g + j];
-                indel[j] = len_u[g + j] + len_v - 2u * lv;
-                pass[j] = may_win<KIND>(b.thr, lv, indel[j], cu[g + j] == cv);
-            }
-            bool any = false;
-#pragma unroll
-            for (int j = 0; j < GRP; ++j) any |= pass[j];
-            if (any) {
-#pragma unroll
-                for (int j = 0; j < GRP; ++j)
-                    if (pass[j] && cu[g + j] != cv)
-                        exact_update<KIND>(pw, b, l[s][g + j], indel[j], (uint32_t)v, (uint32_t)(ub + g + j));
+            for (int k = 0; k < UNR; ++k) {
+                const uint32_t lv = l[s][k];
+                if (lv >= thr) {
+                    const int u = ub + k;
+                    if (a.comp[u] != cv) {
+                        const uint32_t len_u = a.lens[u];
+                        if (exact_update<KIND>(pw, b, lv, len_u + len_v - 2u * lv, (uint32_t)v, (uint32_t)u, len_u))
+                            thr = l_threshold(b.l, b.len_o, mb);
+                    }
+                }
             }
         }
     };
@@ -371,7 +324,7 @@ __global__ __launch_bounds__(256) void boruvka_col_kernel(BoruvkaArgs a)
         for (int it = 0; it < n_pairs; ++it, ub += 2 * UNR) {
             request(ub + UNR, 1);
             evaluate(ub, 0);
-            request(ub + 2 * UNR, 0); // past the last pair: clamped rows, never evaluated
+            if (it + 1 < n_pairs) request(ub + 2 * UNR, 0);
             evaluate(ub + UNR, 1);
         }
     }
