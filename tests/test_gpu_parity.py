@@ -413,7 +413,7 @@ def test_sets_with_a_sequence_beyond_65535_residues(engine, oracle):
     assert engine.clarans(sub, 4).tolist() == host_bind.Host().clarans(dist, len(sub), 4).tolist()
 
 
-@pytest.mark.parametrize("shape", ["ties", "family", "tiny"])
+@pytest.mark.parametrize("shape", ["ties", "family", "tiny", "prefixes", "prefixes-sorted", "family-sorted", "two-lengths"])
 def test_boruvka_mst_equals_the_prim_kernel(engine, monkeypatch, shape):
     """lcsgpu_mst_prim builds the tree by Boruvka rounds when distances are orientation free and orders the
     edges by a Prim walk over the tree: same edges, same order, same distances as the step-by-step Prim
@@ -429,6 +429,27 @@ def test_boruvka_mst_equals_the_prim_kernel(engine, monkeypatch, shape):
             m = rng.random(200) < 0.2
             s[m] = rng.integers(0, 20, size=int(m.sum()), dtype=np.uint8)
             seqs.append(s[: int(rng.integers(120, 201))].copy())
+    elif shape.startswith("prefixes"):
+        # prefixes of one ancestor: LCS = the shorter length, so equal distances come from many different
+        # (LCS, lengths) combinations and near-equal ones from neighbouring ones -- what the passes' integer
+        # pre-filter (mst_kernels.hip, l_threshold) must not cut; unsorted = wide length spread inside a batch
+        anc = rng.integers(0, 20, size=420, dtype=np.uint8)
+        seqs = [anc[: int(l)].copy() for l in rng.integers(40, 421, size=2600)]
+        if shape.endswith("sorted"):
+            seqs.sort(key=lambda q: -len(q))
+    elif shape == "family-sorted":
+        anc = rng.integers(0, 20, size=300, dtype=np.uint8)
+        seqs = []
+        for _ in range(2600):
+            q = anc.copy()
+            m = rng.random(300) < 0.05
+            q[m] = rng.integers(0, 20, size=int(m.sum()), dtype=np.uint8)
+            seqs.append(q[: int(rng.integers(200, 301))].copy())
+        seqs.sort(key=lambda q: -len(q))
+    elif shape == "two-lengths":
+        # blocks of long sequences interleaved with short ones: the block minima of the filter are far below
+        # the best edge's length in every batch
+        seqs = [rng.integers(0, 4, size=(300 if (i // 7) % 2 else 30)).astype(np.uint8) for i in range(2100)]
     else:
         seqs = [rng.integers(0, 20, size=int(rng.integers(5, 40))).astype(np.uint8) for _ in range(3)]
     engine.upload_seqs(seqs)
