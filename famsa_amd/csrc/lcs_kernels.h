@@ -67,9 +67,10 @@ struct RowMin {
 };
 
 // per-row minima over a triangle slice (see lcsgpu_row_minima_dev in include/lcsgpu.h)
+// (mst_kernels.hip; minlen1024 = shortest sequence per aligned block of 1024 vertices, built at upload)
 hipError_t launch_row_minima(const void* tri, int elem_size, int32_t row_begin, int32_t row_end,
-                             const uint32_t* lens, const double* pow_table, int kind, RowMin* out,
-                             hipStream_t stream);
+                             const uint32_t* lens, const uint32_t* minlen1024, const double* pow_table, int kind,
+                             RowMin* out, hipStream_t stream);
 
 
 // ---- device-side Prim (tree_kernels.hip) ----
@@ -122,7 +123,7 @@ struct BoruvkaArgs {
     MstKey* row_best;           // [n] row-pass result (rows of this block only)
     uint2* row_aux;             // [n] (LCS, length of the other endpoint) of row_best: seeds the column pass's filter
     const uint32_t* minlen16;   // [ceil(n/16)]   shortest sequence of every aligned block of 16 vertices
-    const uint32_t* minlen1024; // [ceil(n/1024)] ... of 1024 vertices (the passes' integer pre-filter)
+    const uint32_t* minlen1024; // [ceil(n/1024)] ... of 1024 vertices (the passes' integer pre-filter; built at upload)
     MstKey* part;               // [n_chunks][n] column-pass partials
     MstKey* best;               // [n] this block's best edge per vertex = what a GPU contributes to the exchange
     MstKey* vbest;              // [n] best edge per vertex over all blocks (after the exchange)

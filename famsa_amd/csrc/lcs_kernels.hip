@@ -589,59 +589,6 @@ __global__ __launch_bounds__(256) void lcs_long_kernel(RowsArgs a, uint16_t* car
     }
 }
 
-// ---- per-row minima over a triangle slice ----------------------------------------------
-// One workgroup per row i: key(i,j) = (d, ~pack(j,i)) as MSTPrim orders edges (reference
-// tree/MSTPrim.cpp:493-509): smaller d first, then the larger j.  HBM-bound: reads the row's
-// LCS values once, coalesced.
-template <typename T>
-__global__ __launch_bounds__(256) void row_minima_kernel(const T* __restrict__ tri, int32_t row_begin,
-                                                         const uint32_t* __restrict__ lens,
-                                                         const double* __restrict__ pow_table, int kind,
-                                                         RowMin* __restrict__ out)
-{
-    const int64_t i = (int64_t)row_begin + blockIdx.x;
-    const int64_t off = (int64_t)row_begin * (row_begin - 1) / 2;
-    const T* row = tri + (i * (i - 1) / 2 - off);
-    const uint32_t len_i = lens[i];
-    double best = 1.7976931348623157e308; // DBL_MAX: an empty row stays here
-    int64_t best_j = -1;
-    for (int64_t j = threadIdx.x; j < i; j += 256) {
-        const uint32_t l = row[j];
-        const uint32_t indel = len_i + lens[j] - 2u * l;
-        double d;
-        if (l == 0)
-            d = 1.7976931348623155e308; // nextafter(DBL_MAX, 0)
-        else if (kind == 1)
-            d = pow_table[indel] / (double)l;
-        else
-            d = (double)indel / (double)l;
-        if (d < best || (d == best && j > best_j)) {
-            best = d;
-            best_j = j;
-        }
-    }
-    __shared__ double s_d[256];
-    __shared__ int64_t s_j[256];
-    s_d[threadIdx.x] = best;
-    s_j[threadIdx.x] = best_j;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) {
-            const double d2 = s_d[threadIdx.x + s];
-            const int64_t j2 = s_j[threadIdx.x + s];
-            if (d2 < s_d[threadIdx.x] || (d2 == s_d[threadIdx.x] && j2 > s_j[threadIdx.x])) {
-                s_d[threadIdx.x] = d2;
-                s_j[threadIdx.x] = j2;
-            }
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        out[blockIdx.x].dist = s_d[0];
-        out[blockIdx.x].index = s_j[0];
-    }
-}
-
 // ---- host-side dispatch ---------------------------------------------------------------
 
 int h_class(uint32_t len)
@@ -747,21 +694,6 @@ hipError_t launch_long(bool quirk, const RowsArgs& a, int grid_x, int grid_y, vo
         hipLaunchKernelGGL(lcs_long_kernel<true>, grid, dim3(256), lds, stream, a, (uint16_t*)carry, n_chunks_max);
     else
         hipLaunchKernelGGL(lcs_long_kernel<false>, grid, dim3(256), lds, stream, a, (uint16_t*)carry, n_chunks_max);
-    return hipGetLastError();
-}
-
-hipError_t launch_row_minima(const void* tri, int elem_size, int32_t row_begin, int32_t row_end,
-                             const uint32_t* lens, const double* pow_table, int kind, RowMin* out,
-                             hipStream_t stream)
-{
-    const int rows = row_end - row_begin;
-    if (rows <= 0) return hipSuccess;
-    if (elem_size == 2)
-        hipLaunchKernelGGL(row_minima_kernel<uint16_t>, dim3(rows), dim3(256), 0, stream, (const uint16_t*)tri,
-                           row_begin, lens, pow_table, kind, out);
-    else
-        hipLaunchKernelGGL(row_minima_kernel<uint32_t>, dim3(rows), dim3(256), 0, stream, (const uint32_t*)tri,
-                           row_begin, lens, pow_table, kind, out);
     return hipGetLastError();
 }
 

@@ -430,6 +430,7 @@ int lcsgpu_destroy(lcsgpu_ctx* ctx)
     ctx->d_tiles.release();
     ctx->d_tile_base.release();
     ctx->d_lens.release();
+    ctx->d_minlen.release();
     ctx->d_masks.release();
     ctx->d_mask_base.release();
     ctx->d_pow.release();
@@ -520,6 +521,16 @@ int lcsgpu_upload(lcsgpu_ctx* ctx, const uint8_t* codes, const uint64_t* offsets
     HIP_TRY(hipMemcpy(ctx->d_mask_base.p, mask_base.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(ctx->d_tile_base.p, tile_base.data(), ((size_t)n_tiles + 1) * 8, hipMemcpyHostToDevice));
     if (n) HIP_TRY(hipMemcpy(ctx->d_lens.p, lens.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+    {   // block minima of the lengths: the integer pre-filter of the per-row minima / MST passes (mst_kernels.hip)
+        const size_t n16 = ((size_t)n + 15) / 16, n1k = ((size_t)n + 1023) / 1024;
+        std::vector<uint32_t> ml(n16 + n1k + 1, ~0u);
+        for (int32_t i = 0; i < n; ++i) {
+            ml[(size_t)i / 16] = std::min(ml[(size_t)i / 16], lens[i]);
+            ml[n16 + (size_t)i / 1024] = std::min(ml[n16 + (size_t)i / 1024], lens[i]);
+        }
+        HIP_TRY(ctx->d_minlen.reserve(ml.size() * 4));
+        HIP_TRY(hipMemcpy(ctx->d_minlen.p, ml.data(), ml.size() * 4, hipMemcpyHostToDevice));
+    }
     if (n) {
         DevBuf d_raw, d_off, d_quirk; // only needed while the tiles are built
         struct Release {

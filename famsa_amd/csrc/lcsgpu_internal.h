@@ -148,6 +148,9 @@ struct lcsgpu_ctx {
     std::vector<uint32_t> lens;
     std::vector<uint8_t> quirk; // ref needs the literal (V2 < V) carry rule
     lcsgpu_impl::DevBuf d_tiles, d_tile_base, d_lens, d_pow, d_powf, d_masks, d_mask_base;
+    lcsgpu_impl::DevBuf d_minlen; // shortest sequence per aligned block of 16 vertices [ceil(n/16)], then of 1024 [ceil(n/1024)]
+    const uint32_t* minlen16() const { return (const uint32_t*)d_minlen.p; }
+    const uint32_t* minlen1024() const { return (const uint32_t*)d_minlen.p + ((size_t)(n > 0 ? n : 0) + 15) / 16; }
 
     // scratch of the lane-0 tree reducers
     lcsgpu_impl::DevBuf d_prim, d_qrows, d_qcols, d_dist;

@@ -24,7 +24,8 @@ int lcsgpu_row_minima_dev(lcsgpu_ctx* ctx, const void* d_triangle, int elem_size
     Lane& L = guard.lane();
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(lcsgpu::launch_row_minima(d_triangle, elem_size, row_begin, row_end, (const uint32_t*)ctx->d_lens.p,
-                                      (const double*)ctx->d_pow.p, distance_kind, (lcsgpu::RowMin*)d_out, L.stream));
+                                      ctx->minlen1024(), (const double*)ctx->d_pow.p, distance_kind,
+                                      (lcsgpu::RowMin*)d_out, L.stream));
     if (sync) HIP_TRY(hipStreamSynchronize(L.stream));
     return LCSGPU_OK;
 }
@@ -52,8 +53,7 @@ static int shard_begin(lcsgpu_ctx* ctx, Lane& L, const void* d_tri, int elem, in
                  o_ci = o_cd + a256((size_t)n * 8), o_part = o_ci + a256((size_t)n * 8),
                  o_edges = o_part + a256((size_t)n_chunks * n * key),
                  o_cnt = o_edges + a256((size_t)std::max(n - 1, 1) * sizeof(lcsgpu::MstEdge)), o_aux = o_cnt + 256,
-                 o_m16 = o_aux + a256((size_t)n * 8), o_m1k = o_m16 + a256(((size_t)n + 15) / 16 * 4),
-                 total = o_m1k + a256(((size_t)n + 1023) / 1024 * 4);
+                 total = o_aux + a256((size_t)n * 8);
     int rc = reserve_big(ctx, ctx->d_mst, total, "the MST state");
     if (rc) return rc;
     char* base = (char*)ctx->d_mst.p;
@@ -78,8 +78,8 @@ static int shard_begin(lcsgpu_ctx* ctx, Lane& L, const void* d_tri, int elem, in
     b.edges = (lcsgpu::MstEdge*)(base + o_edges);
     b.counters = (int32_t*)(base + o_cnt);
     b.row_aux = (uint2*)(base + o_aux);
-    b.minlen16 = (const uint32_t*)(base + o_m16);
-    b.minlen1024 = (const uint32_t*)(base + o_m1k);
+    b.minlen16 = ctx->minlen16();
+    b.minlen1024 = ctx->minlen1024();
     b.n = n;
     b.kind = kind;
     b.n_chunks = n_chunks;

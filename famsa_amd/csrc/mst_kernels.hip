@@ -136,17 +136,6 @@ __global__ __launch_bounds__(256) void boruvka_init_kernel(BoruvkaArgs a)
     const int v = blockIdx.x * 256 + threadIdx.x;
     if (v < a.n) a.comp[v] = v;
     if (v == 0) a.counters[0] = 0; // edges recorded so far
-    // shortest sequence per aligned block of 16 / 1024 vertices (the passes' pre-filter)
-    if (v < (a.n + 15) / 16) {
-        uint32_t m = ~0u;
-        for (int i = 16 * v; i < min(a.n, 16 * v + 16); ++i) m = min(m, a.lens[i]);
-        const_cast<uint32_t*>(a.minlen16)[v] = m;
-    }
-    if (v < (a.n + 1023) / 1024) {
-        uint32_t m = ~0u;
-        for (int i = 1024 * v; i < min(a.n, 1024 * v + 1024); ++i) m = min(m, a.lens[i]);
-        const_cast<uint32_t*>(a.minlen1024)[v] = m;
-    }
 }
 
 // The two passes stream the block's triangle once each (2 B per pair) and are meant to be bound by that stream:
@@ -330,6 +319,100 @@ __global__ __launch_bounds__(256) void boruvka_col_kernel(BoruvkaArgs a)
     }
     plain_rows(ub, u1);
     a.part[(size_t)chunk * a.n + v] = MstKey{b.d, b.id};
+}
+
+// ---- per-row minima over a triangle slice (lcsgpu_row_minima_dev) -----------------------------------------
+// Row i's nearest neighbour among j < i with MSTPrim's edge order (reference tree/MSTPrim.cpp:493-509: smaller d,
+// then the larger j) = the row pass above without component labels: one wave per row, the integer pre-filter,
+// the exact f64 key for survivors only.  HBM-bound: reads the slice once (round 1 computed the f64 distance of
+// every pair: 11.7 ms per 10 GB).
+template <typename T, int KIND>
+__global__ __launch_bounds__(256) void row_minima_kernel(const T* __restrict__ tri, int32_t row_begin, int32_t row_end,
+                                                         const uint32_t* __restrict__ lens,
+                                                         const uint32_t* __restrict__ minlen1024,
+                                                         const double* __restrict__ pow_table, RowMin* __restrict__ out)
+{
+    constexpr int UNR = 16, STEP = 64 * UNR;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const PowTable<false> pw{pow_table};
+    const int v = row_end - 1 - (blockIdx.x * ROWS_PER_WG + wave); // the slice's longest rows first
+    if (v < row_begin) return;
+    RowMin* o = out + (v - row_begin);
+    if (v < 1) {
+        if (lane == 0) {
+            o->dist = 1.7976931348623157e308; // DBL_MAX: an empty row
+            o->index = -1;
+        }
+        return;
+    }
+    const uint32_t len_v = lens[v];
+    const int64_t off = (int64_t)row_begin * (row_begin - 1) / 2;
+    const T* row = tri + ((int64_t)v * (v - 1) / 2 - off);
+    const int last = v - 1;
+    Best b;
+    uint32_t wl = ~0u, wlen = 0;
+    T l[2][UNR];
+    auto request = [&](int ub, int s) {
+#pragma unroll
+        for (int k = 0; k < UNR; ++k) l[s][k] = row[min(ub + lane + 64 * k, last)];
+    };
+    auto evaluate = [&](int ub, int s) {
+        const uint32_t thr = l_threshold(wl, wlen, minlen1024[ub >> 10]);
+        uint32_t m = l[s][0];
+#pragma unroll
+        for (int k = 1; k < UNR; ++k) m = max(m, (uint32_t)l[s][k]);
+        if (__builtin_amdgcn_ballot_w64(m >= thr) == 0) return;
+        bool changed = false;
+#pragma unroll
+        for (int k = 0; k < UNR; ++k) {
+            const int u = ub + lane + 64 * k;
+            const uint32_t lv = l[s][k];
+            if (lv >= thr && u < v) {
+                const uint32_t lu = lens[u];
+                changed |= exact_update<KIND>(pw, b, lv, len_v + lu - 2u * lv, (uint32_t)u, (uint32_t)v, lu);
+            }
+        }
+        if (__builtin_amdgcn_ballot_w64(changed) != 0) {
+            unsigned long long d = b.d, id = b.id;
+            wave_min_key(d, id);
+            const unsigned long long who = __builtin_amdgcn_ballot_w64(b.d == d && b.id == id);
+            const int src = __ffsll((long long)who) - 1;
+            wl = (uint32_t)__builtin_amdgcn_readlane((int)b.l, src);
+            wlen = (uint32_t)__builtin_amdgcn_readlane((int)b.len_o, src);
+        }
+    };
+    request(0, 0);
+    for (int ub = 0; ub < v; ub += 2 * STEP) {
+        request(ub + STEP, 1);
+        evaluate(ub, 0);
+        request(ub + 2 * STEP, 0);
+        if (ub + STEP < v) evaluate(ub + STEP, 1);
+    }
+    unsigned long long d = b.d, id = b.id;
+    wave_min_key(d, id);
+    if (lane == 0) {
+        o->dist = __longlong_as_double((long long)d);
+        o->index = (int64_t)((~id) >> 32); // id = ~pack(j, i), j < i
+    }
+}
+
+hipError_t launch_row_minima(const void* tri, int elem_size, int32_t row_begin, int32_t row_end, const uint32_t* lens,
+                             const uint32_t* minlen1024, const double* pow_table, int kind, RowMin* out,
+                             hipStream_t stream)
+{
+    const int rows = row_end - row_begin;
+    if (rows <= 0) return hipSuccess;
+    const dim3 grid((unsigned)((rows + ROWS_PER_WG - 1) / ROWS_PER_WG)), block(256);
+#define ROW_MIN(T, K)                                                                                        \
+    hipLaunchKernelGGL((row_minima_kernel<T, K>), grid, block, 0, stream, (const T*)tri, row_begin, row_end, \
+                       lens, minlen1024, pow_table, out)
+    if (elem_size == 2) {
+        if (kind == 1) ROW_MIN(uint16_t, 1); else ROW_MIN(uint16_t, 0);
+    } else {
+        if (kind == 1) ROW_MIN(uint32_t, 1); else ROW_MIN(uint32_t, 0);
+    }
+#undef ROW_MIN
+    return hipGetLastError();
 }
 
 // this block's best edge per vertex: its row part (rows of the block) and the column partials that exist
