@@ -39,12 +39,12 @@ static int shard_begin(lcsgpu_ctx* ctx, Lane& L, const void* d_tri, int elem, in
     const int32_t n = ctx->n;
     auto a256 = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const int32_t rows = r1 - r0;
-    // Row chunks of the column pass: long streams per lane (a lane's threshold matures after its first ~100
-    // rows; until then most of its candidates go the exact way), yet enough workgroups to fill the chip
-    // (n = 100 000, MST stage per step: 3 chunks 76 ms, 6: 65, 12: 58, 24: 58, 48: 60)
-    const int col_blocks = std::max(1, (r1 + 255) / 256);
-    int n_chunks = std::max(1, std::min({32, (4096 + col_blocks - 1) / col_blocks, (rows + 2047) / 2048}));
-    if (const char* e = getenv("LCSGPU_MST_CHUNKS")) n_chunks = std::max(1, std::min(64, atoi(e))); // measurement aid
+    // Row chunks of the column pass.  Its lanes start from the row pass's result, so short streams cost no
+    // threshold warm-up any more, and short chunks keep the workgroups that run at the same time on neighbouring
+    // rows (the DRAM pages they share): n = 100 000, column passes of one tree: 2 chunks 21.2 ms, 8: 18.2, 16: 16.6,
+    // 32: 15.4, 64: 14.1, 128: 13.7 (+0.5 fold), 256: 13.7 (+0.9), 512: 14.2 (+1.8) -> about 1024 rows per chunk
+    int n_chunks = std::max(1, std::min(96, (rows + 1023) / 1024));
+    if (const char* e = getenv("LCSGPU_MST_CHUNKS")) n_chunks = std::max(1, std::min(1024, atoi(e))); // measurement aid
     const int rows_per_chunk = std::max(1, (rows + n_chunks - 1) / n_chunks);
     const size_t key = sizeof(lcsgpu::MstKey);
     const size_t o_comp = 0, o_next = o_comp + a256((size_t)n * 4), o_par = o_next + a256((size_t)n * 4),
