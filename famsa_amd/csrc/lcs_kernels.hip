@@ -38,6 +38,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <stdint.h>
 
 #include "lcs_kernels.h"
@@ -644,7 +645,8 @@ int refs_per_block_for(int h, bool quirk, long n_refs, long col_blocks)
 template <int H, int RG, bool QUIRK>
 static hipError_t launch_one(const RowsArgs& a, dim3 grid, hipStream_t stream)
 {
-    const size_t lds = (size_t)a.refs_per_block * ((H + 1) / 2) * 256;
+    static const size_t lds_pad = getenv("LCSGPU_LDS_PAD") ? (size_t)atoi(getenv("LCSGPU_LDS_PAD")) : 0; // measurement aid: fewer workgroups per CU
+    const size_t lds = (size_t)a.refs_per_block * ((H + 1) / 2) * 256 + lds_pad;
     if constexpr (QUIRK)
         hipLaunchKernelGGL((lcs_rows_kernel_quirk<H>), grid, dim3(256), lds, stream, a);
     else
