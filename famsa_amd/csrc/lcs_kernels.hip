@@ -92,6 +92,10 @@ __device__ __forceinline__ unsigned literal_step(const lds_u8* row, uint32_t (&X
     return (unsigned)cin;
 }
 
+// The maximum over the wave, as a value the compiler KNOWS to be wave-uniform (readfirstlane -> SGPR).  Without
+// that, loops and branches on it are compiled as divergent control flow: exec-masked regions whose live-out
+// vectors (the whole X array) must be kept for the "inactive" lanes in a second set of registers and copied at the
+// join -- the kernels with a partial last chunk held 3 x H x RG extra VGPRs that way.
 __device__ __forceinline__ int wave_max(int v)
 {
 #pragma unroll
@@ -99,7 +103,7 @@ __device__ __forceinline__ int wave_max(int v)
         int t = __shfl_xor(v, o, 64);
         v = t > v ? t : v;
     }
-    return v;
+    return __builtin_amdgcn_readfirstlane(v);
 }
 
 // Occurrence masks of `count` 64-bit words of ref `rid`, starting at word `word0`, into LDS rows
@@ -320,7 +324,9 @@ struct Pipe {
     // NPOS < 16: the partner's LAST chunk, of which only the first NPOS residues can be real for any lane of
     // the wave (the rest is padding, a no-op step each): the tail of a 100-residue partner costs 4 positions
     // instead of 16 (-11% of its steps).
-    template <bool CARRY = false, int NPOS = 16>
+    // AHEAD (with NPOS < 16): the body is one turn of a loop over groups of NPOS residues of the same chunk -- the
+    // gathers run ahead into the residues that follow (the caller shifts q by NPOS bytes after every turn).
+    template <bool CARRY = false, int NPOS = 16, bool AHEAD = false>
     static __device__ __forceinline__ void chunk(const lds_u8* grp, const uint4& q, const uint4& qn,
                                                  uint64_t (&ring)[LOOKAHEAD], uint32_t (&X)[RG][H], uint32_t cw = 0,
                                                  uint32_t* cout_p = nullptr)
@@ -343,7 +349,7 @@ struct Pipe {
                 for (int j = 0; j < W; ++j) {
                     const int t = (b * RG + r) * W + j;
                     const uint64_t mm = ring[t % LOOKAHEAD];
-                    if (NPOS == 16 || t + LOOKAHEAD < NPOS * PER_POS) // nothing follows a partial chunk
+                    if (NPOS == 16 || AHEAD || t + LOOKAHEAD < NPOS * PER_POS) // nothing follows a partial chunk
                         ring[t % LOOKAHEAD] = gather(grp, q, qn, t + LOOKAHEAD);
                     LCS_PIN();
                     const uint32_t m0 = (uint32_t)mm, m1 = (uint32_t)(mm >> 32);
@@ -419,12 +425,12 @@ __global__ __launch_bounds__(256) void lcs_rows_kernel_pipe(RowsArgs a)
             q = *(const uint4*)pbase;
         uint64_t ring[LOOKAHEAD];
         P::prime(grp, q, ring);
-        // Short refs (H <= 8, up to 256 residues -- where a partner's padded tail is a visible share of its
-        // steps): the last chunk runs as many 4-residue quads as the longest partner of the wave needs.
-        // Longer refs keep one chunk body: four more copies of it cost the 13-half-word kernel a quarter of
-        // its rate (registers / instruction cache), measured 555 -> 421 Tcell/s at 400 aa.
-        constexpr bool PARTIAL_TAIL = H <= 8;
-        const int full_chunks = PARTIAL_TAIL ? wave_chunks - 1 : wave_chunks;
+        // The last chunk of the wave's longest partner runs as a loop over 4-residue quads, as many as that partner
+        // needs: a 100-residue partner pays 100 steps, not 112.  One extra body of 4 residues per kernel; X stays in
+        // the registers of the main loop.  (The first form -- three more copies of the body for 4 / 8 / 12 residues
+        // behind a branch -- made the compiler keep a second set of X registers for them and copy at the join: 121
+        // VGPRs for 8 half-words, 171 for 13, which is why only H <= 8 had it.)
+        const int full_chunks = wave_chunks - 1;
         for (int k = 0; k < full_chunks; ++k) {
             uint4 qn = make_uint4(PAD4, PAD4, PAD4, PAD4);
             if (k + 1 < my_chunks)
@@ -432,14 +438,12 @@ __global__ __launch_bounds__(256) void lcs_rows_kernel_pipe(RowsArgs a)
             P::chunk(grp, q, qn, ring, X);
             q = qn;
         }
-        if constexpr (PARTIAL_TAIL) {
-            if (wave_chunks > 0) {
-                const uint4 pad = make_uint4(PAD4, PAD4, PAD4, PAD4);
-                if (tail_quads == 1) P::template chunk<false, 4>(grp, q, pad, ring, X);
-                else if (tail_quads == 2) P::template chunk<false, 8>(grp, q, pad, ring, X);
-                else if (tail_quads == 3) P::template chunk<false, 12>(grp, q, pad, ring, X);
-                else P::chunk(grp, q, pad, ring, X);
-            }
+        for (int i = 0; i < tail_quads; ++i) {
+            P::template chunk<false, 4, true>(grp, q, q, ring, X);
+            q.x = q.y;
+            q.y = q.z;
+            q.z = q.w;
+            q.w = PAD4;
         }
 #pragma unroll
         for (int r = 0; r < RG; ++r) {

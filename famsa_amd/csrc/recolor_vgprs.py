@@ -72,7 +72,8 @@ def parse_instr(code):
 
 
 def relocate_block(lines, nv, stats, nv_used=None):
-    """Local pass over one straight-line block.  Returns the new lines (or the old ones if anything unusual is seen)."""
+    """Local pass over one straight-line block.  nv_used: the set of registers the function names anywhere (a register
+    outside it holds nothing).  Returns the new lines (or the old ones if anything unusual is seen)."""
     instrs = []  # (line index, opcode, operands)
     for li, ln in enumerate(lines):
         code, _ = split_code_comment(ln)
@@ -143,7 +144,7 @@ def relocate_block(lines, nv, stats, nv_used=None):
             op_val[(k, oi)] = (v, 0)
     end = len(instrs)
     for r, (v, _) in cur.items():  # whatever sits in a register at the end may be live after the block
-        if v.d < 0 and nv_used is not None and r >= nv_used:
+        if v.d < 0 and nv_used is not None and r not in nv_used:
             v.u = -1  # a register the function never names: nothing lives there
             continue
         v.fixed = True
@@ -370,18 +371,27 @@ def recolor_function(lines, name, rng):
     while nv + 8 <= 256 and min(8, 512 // (nv + 8)) == waves:
         nv += 8
     def local_pass(src):
+        # the registers the function names NOW (after an earlier turn's renamings the free seats above the compiler's
+        # count may hold values that only pass through a block: those are not free there)
+        named = set()
+        for ln in src:
+            for m in VTOK.finditer(split_code_comment(ln)[0]):
+                if m.group(1) is not None:
+                    named.add(int(m.group(1)))
+                else:
+                    named.update(range(int(m.group(2)), int(m.group(3)) + 1))
         out, blk, st = [], [], {}
         for ln in src:
             code = split_code_comment(ln)[0]
             if LABEL.match(code.strip()) and blk:
-                out.extend(relocate_block(blk, nv, st, nv0))
+                out.extend(relocate_block(blk, nv, st, named))
                 blk = []
             blk.append(ln)
             if BLOCK_END.match(code):
-                out.extend(relocate_block(blk, nv, st, nv0))
+                out.extend(relocate_block(blk, nv, st, named))
                 blk = []
         if blk:
-            out.extend(relocate_block(blk, nv, st, nv0))
+            out.extend(relocate_block(blk, nv, st, named))
         return out
 
     # alternate the two renamings while the count falls: the permutation moves the loop-carried registers to banks

@@ -103,3 +103,9 @@ if len(sys.argv) > 3:  # block name: list the registers that are live through it
                 if any(r in regs(o) for o in ops):
                     sites.append((ln, code))
         print(f"v{r}:", "; ".join(f"{ln}:{c}" for ln, c in sites[:4]), "..." if len(sites) > 4 else "")
+if len(sys.argv) > 4:  # register number: blocks where it is read before being written (upward exposed), and its successors chain
+    r = int(sys.argv[4])
+    for i, (n, ins) in enumerate(blocks):
+        if r in use_b[i]:
+            ln = next(l for l, (opc, ops), c in ins if any((not o.is_def) and r in regs(o) for o in ops))
+            print("upward-exposed use of v%d in block %s (line %d), live_in there: %s" % (r, n, ln, r in live_in[i]))

@@ -191,21 +191,35 @@ def body(lines, name):
     return lines[i:j + 1]
 
 
+def _all_kernels():
+    """every kernel the build renames (Makefile: --only 'lcs_rows_kernel_pipe|lcs_long_kernel')"""
+    if not os.path.exists(DEV_S):
+        return list(KERNELS)
+    names = re.findall(r"^(_ZN6lcsgpu\w*(?:lcs_rows_kernel_pipe|lcs_long_kernel)\w*):", open(DEV_S).read(), re.M)
+    return sorted(set(names) | set(KERNELS))
+
+
+ALL_KERNELS = _all_kernels()
+
+
 @pytest.fixture(scope="module")
 def recolored(tmp_path_factory):
     if not os.path.exists(DEV_S):
         pytest.skip("famsa_amd/csrc/_obj/lcs_kernels.dev.s is made by the build (make -C famsa_amd/csrc)")
     d = tmp_path_factory.mktemp("recolor")
     out, mp = str(d / "rec.s"), str(d / "map.json")
-    only = "|".join(re.escape(k) for k in KERNELS)
+    only = "|".join(re.escape(k) for k in ALL_KERNELS)
     subprocess.check_call([sys.executable, os.path.join(CSRC, "recolor_vgprs.py"), DEV_S, out, "--only", only, "--map", mp],
                           stdout=subprocess.DEVNULL)
     return open(DEV_S).read().split("\n"), open(out).read().split("\n"), json.load(open(mp))
 
 
-@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("kernel", ALL_KERNELS)
 def test_loop_bodies_compute_the_same(recolored, kernel):
     old_all, new_all, maps = recolored
+    if kernel not in maps:
+        assert kernel not in KERNELS
+        pytest.skip("no three-source instruction in this kernel: the pass leaves it alone")
     perm = {int(k): v for k, v in maps[kernel].items()}
     assert sorted(perm.values()) == sorted(perm)  # a permutation of the register file the kernel owns
     old_blocks, new_blocks = blocks_of(body(old_all, kernel)), blocks_of(body(new_all, kernel))
@@ -220,7 +234,7 @@ def test_loop_bodies_compute_the_same(recolored, kernel):
         assert [l.split()[0] for l in ob if l.strip()] == [l.split()[0] for l in nb if l.strip()]  # same instructions, same order
         if n3 < 32:
             continue
-        for trial in range(3):
+        for trial in range(3 if kernel in KERNELS else 1):  # every instantiation once, the listed ones three times
             rng = random.Random(1000 * trial + n3)
             init = {r: rng.getrandbits(32) for r in perm}
             old_lane = Lane(init)
