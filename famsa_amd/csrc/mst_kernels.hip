@@ -156,7 +156,8 @@ __global__ __launch_bounds__(256) void boruvka_row_kernel(BoruvkaArgs a)
 {
     extern __shared__ double s_pow[];
     constexpr int UNR = 16, STEP = 64 * UNR;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // wave-uniform, and known to be: the row, its base and the loop bounds stay in SGPRs
     const PowTable<POW_LDS> pw = stage_pow_table<POW_LDS>(a, s_pow);
     const int v = a.r1 - 1 - (blockIdx.x * ROWS_PER_WG + wave);
     if (v < a.r0) return;
@@ -333,7 +334,8 @@ __global__ __launch_bounds__(256) void row_minima_kernel(const T* __restrict__ t
                                                          const double* __restrict__ pow_table, RowMin* __restrict__ out)
 {
     constexpr int UNR = 16, STEP = 64 * UNR;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // wave-uniform, and known to be: the row, its base and the loop bounds stay in SGPRs
     const PowTable<false> pw{pow_table};
     const int v = row_end - 1 - (blockIdx.x * ROWS_PER_WG + wave); // the slice's longest rows first
     if (v < row_begin) return;
