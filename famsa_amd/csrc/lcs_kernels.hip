@@ -617,7 +617,10 @@ int quirk_h_class(uint32_t len)
     return 0;
 }
 
-static int rg_of(int h) { return h <= 16 ? 4 : (h <= 32 ? 2 : 1); }
+#ifndef LCS_RG13
+#define LCS_RG13 4 // measurement aid: refs advanced together in the 13-half-word (400 aa) instantiation
+#endif
+static int rg_of(int h) { return h == 13 ? LCS_RG13 : h <= 16 ? 4 : (h <= 32 ? 2 : 1); }
 
 int refs_per_block(int h, bool quirk)
 {
@@ -674,7 +677,7 @@ hipError_t launch_rows(int h, bool quirk, const RowsArgs& a, int grid_x, int gri
 #define LCS_CASE(B, G) case B: return launch_one<B, G, false>(a, grid, stream);
         LCS_CASE(1, 4) LCS_CASE(2, 4) LCS_CASE(3, 4) LCS_CASE(4, 4) LCS_CASE(5, 4) LCS_CASE(6, 4)
         LCS_CASE(7, 4) LCS_CASE(8, 4) LCS_CASE(9, 4) LCS_CASE(10, 4) LCS_CASE(11, 4) LCS_CASE(12, 4)
-        LCS_CASE(13, 4) LCS_CASE(14, 4) LCS_CASE(15, 4) LCS_CASE(16, 4)
+        LCS_CASE(13, LCS_RG13) LCS_CASE(14, 4) LCS_CASE(15, 4) LCS_CASE(16, 4)
         LCS_CASE(17, 2) LCS_CASE(18, 2) LCS_CASE(19, 2) LCS_CASE(20, 2) LCS_CASE(21, 2) LCS_CASE(22, 2)
         LCS_CASE(23, 2) LCS_CASE(24, 2) LCS_CASE(25, 2) LCS_CASE(26, 2) LCS_CASE(27, 2) LCS_CASE(28, 2)
         LCS_CASE(29, 2) LCS_CASE(30, 2) LCS_CASE(31, 2) LCS_CASE(32, 2)
