@@ -386,6 +386,9 @@ struct Pipe {
     }
 };
 
+// (The instantiations with X = 64 registers -- 16 x 4, 32 x 2, 64 x 1 half-words x refs -- hold 105 VGPRs = 4 waves per
+// SIMD; asked for 5 through the launch bounds the compiler fits 96 with three dwords spilled outside the loop bodies,
+// and nothing is gained: 448 / 512 / 1024 / 2048 aa 615 / 616 / 615 / 611 Tcell/s with 4 waves, 619 / 611 / 613 / 606 with 5.)
 template <int H, int RG, int LOOKAHEAD>
 __global__ __launch_bounds__(256) void lcs_rows_kernel_pipe(RowsArgs a)
 {
