@@ -174,8 +174,13 @@ __device__ __forceinline__ void store_result(const RowsArgs& a, int k, int c, ui
 __device__ __forceinline__ void block_coords(const RowsArgs& a, int& x, int& y)
 {
     if (!a.tri_prefix) {
-        x = blockIdx.x;
-        y = blockIdx.y;
+        // 2-D grid: workgroups go to the 8 XCDs round robin by their linear id.  With the column block as the fast
+        // index and a column count that is a multiple of 8, an XCD would own whole COLUMNS -- and in triangle mode the
+        // first columns hold all the work (4000 long sequences, 16 column blocks: XCD 0 had 744 workgroups below the
+        // diagonal, XCD 7 had 296; the long-ref kernel ran with half of the CUs idle).  So the ref tile is the fast index.
+        const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x;
+        y = (int)(lin % gridDim.y);
+        x = (int)(lin / gridDim.y);
         return;
     }
     const int bid = blockIdx.x;

@@ -15,9 +15,8 @@ for L, n in ((3000, 4000), (2048, 5000)):
     ms, nl = eng.last_kernel_ms(); print(L, ms)
     eng.close()
 P
-for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES" \
-           "GRBM_GUI_ACTIVE SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM" \
-           "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_INSTS_SMEM SQ_WAIT_INST_VMEM"; do
+for set in "SQ_LEVEL_WAVES SQ_BUSY_CU_CYCLES SQ_IFETCH SQ_IFETCH_LEVEL SQ_INSTS_BRANCH SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_VMEM SQ_CYCLES" \
+           "SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_LDS_CMD_FIFO_FULL SQ_LDS_DATA_FIFO_FULL SQ_INSTS SQ_THREAD_CYCLES_VALU SQ_INST_CYCLES_VMEM_RD SQ_WAVES_LT_64"; do
   rm -rf /tmp/prof_l; ROOT=$ROOT rocprofv3 --kernel-trace --pmc $set -d /tmp/prof_l -o run -- python /tmp/long_one.py > /dev/null 2>&1
   python $ROOT/scripts/rocpd_summary.py $(find /tmp/prof_l -name "*.db") | grep -E "lcs_long_kernel|lcs_rows_kernel_pipe<64" 
 done
