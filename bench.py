@@ -147,6 +147,9 @@ def main():
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--emulate-ranks-on-one-gpu", action="store_true",
                     help="functional test of the N>1 path on a 1-GPU box: all ranks use cuda:0, gloo exchange")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="with one rank: initialise the nccl (RCCL) backend anyway and run the real "
+                         "all_gather_into_tensor + stream hand-off every Boruvka round, as the N>1 path does")
     args = ap.parse_args()
 
     import torch
@@ -164,9 +167,11 @@ def main():
     emulate = args.emulate_ranks_on_one_gpu
     if emulate:
         local_rank = 0
-    if world > 1:
+    collective = world > 1 or args.force_collective  # the exchange runs as a real collective
+    if collective:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         if emulate:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
@@ -185,11 +190,11 @@ def main():
     total_pairs = n * (n - 1) // 2
     tri = torch.empty(max(my_pairs, 1), dtype=torch.int16, device=dev)
     keys = torch.zeros(2 * n, dtype=torch.int64, device=dev)          # this rank's lcsgpu_mst_key records
-    gathered = torch.zeros(world * 2 * n, dtype=torch.int64, device=dev) if world > 1 else keys
+    gathered = torch.zeros(world * 2 * n, dtype=torch.int64, device=dev) if collective else keys
     ext = torch.cuda.ExternalStream(eng._lib.lcsgpu_stream(eng._ctx), device=dev)
     torch.cuda.synchronize()  # torch zero-fills on ITS stream; the engine writes these buffers on its own
 
-    if world == 1:
+    if not collective:
         def all_gather(g, k):
             pass                                   # one block: its keys are the gathered keys
     elif not emulate:
@@ -230,7 +235,7 @@ def main():
     def fence():
         eng.sync()
         torch.cuda.synchronize()
-        if world > 1:
+        if collective:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -246,7 +251,7 @@ def main():
     finish_previous()
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if collective:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if emulate else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -256,7 +261,7 @@ def main():
     sampled, bad = (0, 0) if args.no_parity else sampled_parity(eng, tri, r0, r1, codes, offsets)
     edges = last["edges"]
     edges_hash = edge_list_sha256(edges)
-    if world > 1:
+    if collective:
         rec = [None] * world
         dist.all_gather_object(rec, (edges_hash, sampled, bad))
         assert len({h for h, _, _ in rec}) == 1, "ranks disagree on the tree"
@@ -291,7 +296,8 @@ def main():
                 "workload": f"synthetic {n} proteins x {L} aa (uniform over 20 residues), full all-pairs LCS "
                             f"lower triangle -> uint16 in HBM -> single-linkage MST (n-1 edges, Prim's order) on the host",
                 "n_seqs": n, "seq_len": L, "pairs": total_pairs,
-                "parallelism": f"rowblock{world}" + ("+allgather(n x 16 B best-edge keys per Boruvka round)" if world > 1 else ""),
+                "parallelism": f"rowblock{world}" + ("+allgather(n x 16 B best-edge keys per Boruvka round)" if collective else ""),
+                "exchange": ("gloo (host memory)" if emulate else "nccl = RCCL (device memory)") if collective else "none (one block)",
             },
             "pairs_per_s": total_pairs * args.steps / elapsed,
             "mst": {"n_edges": int(len(edges)), "rounds": int(last["rounds"]), "edges_sha256": edges_hash,
@@ -327,7 +333,7 @@ def main():
                 cb = {"error": repr(e)}
             out["cpu_baseline"] = cb
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if collective:
         dist.destroy_process_group()
 
 

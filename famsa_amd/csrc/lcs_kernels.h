@@ -48,6 +48,7 @@ struct RowsArgs {
     const int64_t* ref_out0;
 };
 
+const char* recolor_state(); // "on" | "off" | "failed": see csrc/Makefile, RECOLOR
 // instantiated half-word (32-bit) counts: exact 1..32, even 34..64; 0 = the long-sequence path
 int h_class(uint32_t len);
 int quirk_h_class(uint32_t len);
@@ -130,7 +131,7 @@ struct BoruvkaArgs {
     unsigned long long* cb_d;   // [n] the same per component (indexed by root)
     unsigned long long* cb_id;
     MstEdge* edges;             // [n-1] in the order the rounds find them
-    int32_t* counters;          // [0] edges recorded
+    int32_t* counters;          // [0] edges recorded  [1] inconsistent keys seen by the global half
     int32_t n, kind, n_chunks, rows_per_chunk;
 };
 hipError_t launch_boruvka_init(const BoruvkaArgs& a, hipStream_t stream);

@@ -604,6 +604,13 @@ __global__ __launch_bounds__(256) void lcs_long_kernel(RowsArgs a, uint16_t* car
 
 // ---- host-side dispatch ---------------------------------------------------------------
 
+// how this translation unit's device code was built (csrc/Makefile): "on" = the register-renaming pass ran and its
+// equivalence check passed, "off" = RECOLOR=0, "failed" = the pass or the check failed and the kernels are as compiled
+#ifndef LCSGPU_RECOLOR_STATE
+#define LCSGPU_RECOLOR_STATE "off"
+#endif
+const char* recolor_state() { return LCSGPU_RECOLOR_STATE; }
+
 int h_class(uint32_t len)
 {
     // half-word counts that have their own instantiation; others round up (extra half-words

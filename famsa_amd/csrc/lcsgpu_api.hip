@@ -304,7 +304,11 @@ using namespace lcsgpu_impl;
 extern "C" {
 
 
-const char* lcsgpu_version(void) { return "lcsgpu 0.1 gfx950"; }
+const char* lcsgpu_version(void)
+{
+    static const std::string v = std::string("lcsgpu 0.3 gfx950 recolor=") + lcsgpu::recolor_state();
+    return v.c_str();
+}
 const char* lcsgpu_last_error(void) { return g_err.c_str(); }
 
 int lcsgpu_device_count(void)
@@ -372,12 +376,14 @@ int lcsgpu_create(int device_id, lcsgpu_ctx** out_ctx)
 int lcsgpu_reserve_lanes(lcsgpu_ctx* ctx, int32_t n_threads)
 {
     if (!ctx) return fail(LCSGPU_E_INVALID, "NULL ctx");
+    int limit;
     {
         std::lock_guard<std::mutex> lk(ctx->mu);
         ctx->lane_limit = std::max(ctx->lane_limit, std::min<int>(MAX_LANES, n_threads + 1));
+        limit = ctx->lane_limit; // other threads may raise it meanwhile: this call works with what it saw under the lock
     }
     // the first 16 now, the others when a call first needs them (created by the calling threads, in parallel)
-    for (size_t i = 1; i < (size_t)ctx->lane_limit && (int32_t)i <= std::min(n_threads, 16); ++i) {
+    for (size_t i = 1; i < (size_t)limit && (int32_t)i <= std::min(n_threads, 16); ++i) {
         Lane& l = ctx->lanes[i];
         {
             std::lock_guard<std::mutex> lk(ctx->mu);
@@ -437,6 +443,7 @@ int lcsgpu_destroy(lcsgpu_ctx* ctx)
     ctx->d_powf.release();
     ctx->d_prim.release();
     ctx->d_mst.release();
+    ctx->d_gather.release();
     ctx->d_qrows.release();
     ctx->d_qcols.release();
     ctx->d_dist.release();

@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <map>
 #include <mutex>
 #include <random>
 #include <string>
@@ -157,6 +158,7 @@ struct lcsgpu_ctx {
     // sharded MST (lcsgpu_mst_shard_*): the replicated component state and this context's row block,
     // alive from _begin to the next _begin / upload
     lcsgpu_impl::DevBuf d_mst;
+    lcsgpu_impl::DevBuf d_gather; // lcsgpu_multi_mst_prim: 2 x n_ctx x n keys, the slots the contexts push their keys into
     struct MstShard {
         bool active = false;
         lcsgpu::BoruvkaArgs b{};
@@ -232,6 +234,7 @@ public:
                     }
                     l.unusable = true;
                     l.busy = false;
+                    ctx->cv.notify_all(); // a LaneGuard(ALL) waiter counts busy lanes: this one just stopped being busy
                     continue;
                 }
                 if (pick >= 0) {

@@ -107,8 +107,9 @@ static int shard_best(lcsgpu_ctx* ctx, Lane& L, void* d_keys, lcsgpu_mst_key* h_
     return LCSGPU_OK;
 }
 
-// global half of a round over n_parts x n gathered keys (NULL: the context's own keys, one part)
-static int shard_merge(lcsgpu_ctx* ctx, Lane& L, const void* d_gathered, int32_t n_parts, int32_t* n_edges)
+// global half of a round over n_parts x n gathered keys (NULL: the context's own keys, one part): queued on the
+// lane's stream, no host synchronisation
+static int shard_merge_async(lcsgpu_ctx* ctx, Lane& L, const void* d_gathered, int32_t n_parts)
 {
     lcsgpu::BoruvkaArgs& b = ctx->mst.b;
     if (ctx->mst.rounds > 64) return fail(LCSGPU_E_STATE, "MST: the Boruvka rounds do not converge");
@@ -116,16 +117,32 @@ static int shard_merge(lcsgpu_ctx* ctx, Lane& L, const void* d_gathered, int32_t
     HIP_TRY(lcsgpu::launch_boruvka_merge(b, g, d_gathered ? n_parts : 1, L.stream));
     std::swap(b.comp, b.comp_next);
     ++ctx->mst.rounds;
-    int32_t found = 0;
-    HIP_TRY(hipMemcpyAsync(&found, b.counters, 4, hipMemcpyDeviceToHost, L.stream));
+    return LCSGPU_OK;
+}
+
+// the number of tree edges recorded so far, once the queued rounds have run (one host synchronisation); the
+// merge kernels report a relabelling walk that did not end (inconsistent keys) through counters[1]
+static int shard_count(lcsgpu_ctx* ctx, Lane& L, int32_t* n_edges)
+{
+    lcsgpu::BoruvkaArgs& b = ctx->mst.b;
+    int32_t c[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(c, b.counters, 8, hipMemcpyDeviceToHost, L.stream));
     HIP_TRY(hipStreamSynchronize(L.stream));
     L.plan_in_flight = false;
+    const int32_t found = c[0];
+    if (c[1]) return fail(LCSGPU_E_STATE, "MST: inconsistent keys (a hooking cycle among the components; were the keys gathered from different rounds?)");
     if (found > b.n - 1) return fail(LCSGPU_E_STATE, "MST: %d edges recorded for %d vertices", found, b.n);
     if (found <= ctx->mst.found && found < b.n - 1)
         return fail(LCSGPU_E_STATE, "MST: a Boruvka round added no edge (%d of %d)", found, b.n - 1);
     ctx->mst.found = found;
     if (n_edges) *n_edges = found;
     return LCSGPU_OK;
+}
+
+static int shard_merge(lcsgpu_ctx* ctx, Lane& L, const void* d_gathered, int32_t n_parts, int32_t* n_edges)
+{
+    int rc = shard_merge_async(ctx, L, d_gathered, n_parts);
+    return rc ? rc : shard_count(ctx, L, n_edges);
 }
 
 static int shard_finish(lcsgpu_ctx* ctx, Lane& L, lcsgpu_mst_edge* out_edges, bool order = true)
@@ -294,6 +311,9 @@ int lcsgpu_mst_merge_host(const lcsgpu_mst_key* keys, int32_t n_parts, int32_t n
         const uint64_t packed = ~cb_id[c];
         const int32_t x = (int32_t)(packed >> 32), y = (int32_t)(packed & 0xffffffffull);
         if (x < 0 || y < 0 || x >= n || y >= n) return fail(LCSGPU_E_INVALID, "key of component %d names the pair (%d, %d)", c, x, y);
+        if ((comp[x] == c) == (comp[y] == c))
+            return fail(LCSGPU_E_STATE, "MST: the key of component %d names the pair (%d, %d), which does not leave it "
+                                        "(keys gathered from different rounds?)", c, x, y);
         const int32_t other = comp[x] == c ? comp[y] : comp[x];
         parent[c] = other;
         const bool mutual = cb_id[other] == cb_id[c];
@@ -312,8 +332,11 @@ int lcsgpu_mst_merge_host(const lcsgpu_mst_key* keys, int32_t n_parts, int32_t n
         if (p != c && parent[p] == c && c < p) parent[c] = c;
     }
     for (int32_t v = 0; v < n; ++v) {
-        int32_t r = comp[v];
-        for (int32_t p = parent[r]; p != r; p = parent[r]) r = p;
+        int32_t r = comp[v], steps = 0;
+        for (int32_t p = parent[r]; p != r; p = parent[r]) {
+            r = p;
+            if (++steps > n) return fail(LCSGPU_E_STATE, "MST: inconsistent keys (a hooking cycle among the components)");
+        }
         cb_d[v] = (uint64_t)(uint32_t)r; // new labels, written back after every old one has been read
     }
     for (int32_t v = 0; v < n; ++v) comp[v] = (int32_t)cb_d[v];
@@ -468,9 +491,83 @@ std::vector<int32_t> equal_pair_cuts(int32_t r0, int32_t r1, int parts)
 
 int64_t tri_offset(int64_t r) { return r * (r - 1) / 2; }
 
+// ---- device-to-device transport between the contexts of one process ---------------------------------------
+// Peer access is a property of an ordered device pair and has to be switched on once per process; without it
+// hipMemcpyPeerAsync still works but is staged through host memory by the runtime, i.e. PCIe both ways instead
+// of one xGMI hop (7 links x ~153 GB/s per GPU).  When the devices cannot address each other at all the copy goes
+// through a pinned host buffer here, in 64 MB pieces (two PCIe crossings, ~25 GB/s: the 8.75 GB a GPU receives for
+// lcsgpu_multi_upgma at 100 000 sequences then take ~0.35 s instead of ~0.06 s).
+//   LCSGPU_FORCE_PEER_COPY=1     same-device contexts take the hipMemcpyPeerAsync branch too (so a 1-GPU box runs it)
+//   LCSGPU_FORCE_HOST_STAGING=1  every copy between contexts takes the pinned-host path (the no-peer-access fallback)
+std::mutex g_peer_mu;
+std::vector<std::pair<std::pair<int, int>, bool>> g_peer; // (accessing device, owner of the memory) -> usable
+
+bool env_flag(const char* name)
+{
+    const char* e = getenv(name);
+    return e && *e && *e != '0';
+}
+
+// may kernels / copy engines of device `from` address memory of device `to`?  Switches it on at first use.
+bool peer_access(int from, int to)
+{
+    if (from == to) return true;
+    std::lock_guard<std::mutex> lk(g_peer_mu);
+    for (const auto& e : g_peer)
+        if (e.first.first == from && e.first.second == to) return e.second;
+    int can = 0;
+    bool ok = hipDeviceCanAccessPeer(&can, from, to) == hipSuccess && can;
+    if (ok) {
+        int cur = 0;
+        (void)hipGetDevice(&cur);
+        ok = hipSetDevice(from) == hipSuccess;
+        if (ok) {
+            const hipError_t e = hipDeviceEnablePeerAccess(to, 0);
+            ok = e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled;
+        }
+        (void)hipGetLastError();
+        (void)hipSetDevice(cur);
+    } else
+        (void)hipGetLastError();
+    g_peer.push_back({{from, to}, ok});
+    return ok;
+}
+
+// `bytes` from src (device memory of src_ctx) to dst (device memory of dst_ctx), ordered on `stream` (a stream of
+// src_ctx's device: the producer pushes).  Returns with the copy queued -- or, on the staging path, done.
+int copy_between(lcsgpu_ctx* dst_ctx, void* dst, lcsgpu_ctx* src_ctx, const void* src, size_t bytes, hipStream_t stream)
+{
+    if (!bytes) return LCSGPU_OK;
+    const int sd = src_ctx->device, dd = dst_ctx->device;
+    HIP_TRY(hipSetDevice(sd));
+    if (env_flag("LCSGPU_FORCE_HOST_STAGING") || (sd != dd && !(peer_access(sd, dd) && peer_access(dd, sd)))) {
+        static std::mutex mu; // one staging buffer per process: this path is the exception, not the design
+        static PinBuf stage;
+        std::lock_guard<std::mutex> lk(mu);
+        const size_t piece = (size_t)64 << 20;
+        HIP_TRY(stage.reserve(std::min(bytes, piece)));
+        for (size_t at = 0; at < bytes; at += piece) {
+            const size_t m = std::min(piece, bytes - at);
+            HIP_TRY(hipSetDevice(sd));
+            HIP_TRY(hipMemcpyAsync(stage.p, (const char*)src + at, m, hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipStreamSynchronize(stream));
+            HIP_TRY(hipSetDevice(dd));
+            HIP_TRY(hipMemcpy((char*)dst + at, stage.p, m, hipMemcpyHostToDevice));
+        }
+        HIP_TRY(hipSetDevice(sd));
+        return LCSGPU_OK;
+    }
+    if (sd == dd && !env_flag("LCSGPU_FORCE_PEER_COPY"))
+        HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, stream));
+    else
+        HIP_TRY(hipMemcpyPeerAsync(dst, dd, src, sd, bytes, stream));
+    return LCSGPU_OK;
+}
+
 // The whole LCS triangle of the uploaded set into lane 0's result buffer of ctxs[0]: row blocks of equal
 // pair counts, one per context, each computed on its own GPU at the same time; the blocks of the other
-// contexts travel into place over xGMI (hipMemcpyPeerAsync on the producer's stream) -- the "all-gather of
+// contexts travel into place over xGMI (copy_between: hipMemcpyPeerAsync on the producer's stream, peer access
+// switched on for the pair) -- the "all-gather of
 // u16 row blocks" of a matrix consumer that lives on one device.  No host thread per GPU is
 // needed: every launch and copy is asynchronous.
 int whole_triangle(lcsgpu_ctx* const* ctxs, int32_t n_ctx, MultiGuard& g, int elem)
@@ -503,11 +600,9 @@ int whole_triangle(lcsgpu_ctx* const* ctxs, int32_t n_ctx, MultiGuard& g, int el
         if (k > 0) {
             const size_t bytes = (size_t)(tri_offset(r1) - off) * elem;
             char* place = (char*)L0.d_out.p + (size_t)off * elem;
+            rc = copy_between(c0, place, ctxs[k], L.d_out.p, bytes, L.stream); // xGMI with peer access (see copy_between)
+            if (rc) return rc;
             HIP_TRY(hipSetDevice(ctxs[k]->device));
-            if (ctxs[k]->device == c0->device)
-                HIP_TRY(hipMemcpyAsync(place, L.d_out.p, bytes, hipMemcpyDeviceToDevice, L.stream));
-            else
-                HIP_TRY(hipMemcpyPeerAsync(place, c0->device, L.d_out.p, ctxs[k]->device, bytes, L.stream));
             HIP_TRY(hipEventCreateWithFlags(&landed[k], hipEventDisableTiming));
             HIP_TRY(hipEventRecord(landed[k], L.stream));
         }
@@ -657,8 +752,15 @@ int lcsgpu_nj(lcsgpu_ctx* ctx, int distance_kind, int32_t* out_left, int32_t* ou
 }
 
 // Single linkage over several GPUs inside one process: every context computes its row block and the local half
-// of each Boruvka round on its own GPU (all asynchronous, so the GPUs work at the same time); the keys meet in
-// host memory, the global half runs once on the host (lcsgpu_mst_merge_host) and the labels go back.
+// of each Boruvka round on its own GPU (all asynchronous, so the GPUs work at the same time).  The exchange stays
+// in device memory: context k pushes its n keys (16 B each) into slot k of EVERY context's gathered buffer -- the
+// all-gather of include/lcsgpu.h's protocol, written as N x (N-1) peer copies of n x 16 B on the producers' streams
+// (xGMI; 1.6 MB each at n = 100 000) -- every context waits for the N pushes on its own stream (events, no host
+// involvement) and runs the same global half (lcsgpu_mst_shard_merge's kernels), so the component labels stay
+// replicated without being sent.  The host synchronises ONCE per round, for the edge count that ends the loop.
+// The gathered buffers alternate between two halves by round parity: a producer's push of round r+2 is ordered
+// after its own merge of round r+1, which waited for every context's push of round r+1, which in turn follows that
+// context's merge of round r in stream order -- so no half is overwritten while a merge still reads it.
 int lcsgpu_multi_mst_prim(lcsgpu_ctx* const* ctxs, int32_t n_ctx, int distance_kind, lcsgpu_mst_edge* out_edges)
 {
     int rc = check_multi(ctxs, n_ctx);
@@ -676,8 +778,31 @@ int lcsgpu_multi_mst_prim(lcsgpu_ctx* const* ctxs, int32_t n_ctx, int distance_k
                 return fail(LCSGPU_E_UNSUPPORTED, "sequence %d is orientation sensitive: MSTPrim's distances depend on which "
                                                   "endpoint is the ref (use lcsgpu_mst_prim on one context)", i);
     MultiGuard g(ctxs, n_ctx);
+    // Whatever way this call ends, nothing of it may still run when its events are destroyed and the lanes are handed
+    // back, and no context may be left pointing at a triangle block that the next call reuses.
+    std::vector<hipEvent_t> pushed((size_t)2 * n_ctx, nullptr);
+    struct Cleanup {
+        lcsgpu_ctx* const* ctxs;
+        int32_t n_ctx;
+        MultiGuard& g;
+        std::vector<hipEvent_t>& ev;
+        ~Cleanup()
+        {
+            for (int k = 0; k < n_ctx; ++k) {
+                (void)hipSetDevice(ctxs[k]->device);
+                (void)hipStreamSynchronize(g.lanes[k]->stream);
+                g.lanes[k]->plan_in_flight = false;
+                ctxs[k]->mst.active = false;
+            }
+            for (hipEvent_t e : ev)
+                if (e) (void)hipEventDestroy(e);
+            (void)hipGetLastError();
+        }
+    } cleanup{ctxs, n_ctx, g, pushed};
+
     const int elem = ctxs[0]->max_len > 65535 ? 4 : 2;
     const std::vector<int32_t> cut = equal_pair_cuts(0, n, n_ctx);
+    const size_t key_bytes = (size_t)n * sizeof(lcsgpu_mst_key);
     for (int k = 0; k < n_ctx; ++k) {
         Lane& L = *g.lanes[k];
         const int32_t r0 = cut[k], r1 = cut[k + 1];
@@ -691,42 +816,44 @@ int lcsgpu_multi_mst_prim(lcsgpu_ctx* const* ctxs, int32_t n_ctx, int distance_k
         HIP_TRY(hipSetDevice(ctxs[k]->device));
         rc = shard_begin(ctxs[k], L, L.d_out.p, elem, r0, r1, kind);
         if (rc) return rc;
+        HIP_TRY(ctxs[k]->d_gather.reserve(2 * (size_t)n_ctx * key_bytes));
+        for (int h = 0; h < 2; ++h) HIP_TRY(hipEventCreateWithFlags(&pushed[(size_t)h * n_ctx + k], hipEventDisableTiming));
     }
-    std::vector<lcsgpu_mst_key> keys((size_t)n_ctx * n);
-    std::vector<int32_t> comp(n);
-    for (int32_t v = 0; v < n; ++v) comp[v] = v;
     int32_t found = 0;
     for (int round = 0; found < n - 1; ++round) {
         if (round > 64) return fail(LCSGPU_E_STATE, "MST: the Boruvka rounds do not converge");
-        for (int k = 0; k < n_ctx; ++k) { // queue the local halves everywhere, then collect
+        const int half = round & 1;
+        for (int k = 0; k < n_ctx; ++k) { // local halves everywhere, each followed by its pushes
             HIP_TRY(hipSetDevice(ctxs[k]->device));
-            rc = shard_best(ctxs[k], *g.lanes[k], nullptr, nullptr);
+            char* own = (char*)ctxs[k]->d_gather.p + ((size_t)half * n_ctx + k) * key_bytes;
+            rc = shard_best(ctxs[k], *g.lanes[k], own, nullptr); // straight into its own slot
             if (rc) return rc;
-            HIP_TRY(hipMemcpyAsync(keys.data() + (size_t)k * n, ctxs[k]->mst.b.best, (size_t)n * sizeof(lcsgpu_mst_key),
-                                   hipMemcpyDeviceToHost, g.lanes[k]->stream));
-        }
-        for (int k = 0; k < n_ctx; ++k) {
-            HIP_TRY(hipSetDevice(ctxs[k]->device));
-            HIP_TRY(hipStreamSynchronize(g.lanes[k]->stream));
-            g.lanes[k]->plan_in_flight = false;
-        }
-        const int32_t before = found;
-        rc = lcsgpu_mst_merge_host(keys.data(), n_ctx, n, comp.data(), out_edges, &found);
-        if (rc) return rc;
-        if (found <= before) return fail(LCSGPU_E_STATE, "MST: a Boruvka round added no edge (%d of %d)", found, n - 1);
-        if (found < n - 1)
-            for (int k = 0; k < n_ctx; ++k) {
-                HIP_TRY(hipSetDevice(ctxs[k]->device));
-                HIP_TRY(hipMemcpyAsync(ctxs[k]->mst.b.comp, comp.data(), (size_t)n * 4, hipMemcpyHostToDevice, g.lanes[k]->stream));
+            for (int j = 0; j < n_ctx; ++j) {
+                if (j == k) continue;
+                char* slot = (char*)ctxs[j]->d_gather.p + ((size_t)half * n_ctx + k) * key_bytes;
+                rc = copy_between(ctxs[j], slot, ctxs[k], own, key_bytes, g.lanes[k]->stream);
+                if (rc) return rc;
             }
+            HIP_TRY(hipSetDevice(ctxs[k]->device));
+            HIP_TRY(hipEventRecord(pushed[(size_t)half * n_ctx + k], g.lanes[k]->stream));
+        }
+        for (int j = 0; j < n_ctx; ++j) { // global halves: each context over all N slots, once they have landed
+            HIP_TRY(hipSetDevice(ctxs[j]->device));
+            for (int k = 0; k < n_ctx; ++k)
+                if (k != j) HIP_TRY(hipStreamWaitEvent(g.lanes[j]->stream, pushed[(size_t)half * n_ctx + k], 0));
+            rc = shard_merge_async(ctxs[j], *g.lanes[j], (char*)ctxs[j]->d_gather.p + (size_t)half * n_ctx * key_bytes, n_ctx);
+            if (rc) return rc;
+        }
+        HIP_TRY(hipSetDevice(ctxs[0]->device));
+        rc = shard_count(ctxs[0], *g.lanes[0], &found); // the round's one host synchronisation
+        if (rc) return rc;
+        for (int k = 1; k < n_ctx; ++k) ctxs[k]->mst.found = found; // same keys, same kernels: same count everywhere
     }
-    for (int k = 0; k < n_ctx; ++k) {
-        HIP_TRY(hipSetDevice(ctxs[k]->device));
-        HIP_TRY(hipStreamSynchronize(g.lanes[k]->stream));
-        ctxs[k]->mst.active = false; // the triangle block belongs to this call
-        note_async_call(ctxs[k]);
-    }
-    return order_edges_like_prim(out_edges, n);
+    HIP_TRY(hipSetDevice(ctxs[0]->device));
+    rc = shard_finish(ctxs[0], *g.lanes[0], out_edges); // context 0's copy of the edge list, in Prim's order
+    if (rc) return rc;
+    for (int k = 0; k < n_ctx; ++k) note_async_call(ctxs[k]);
+    return LCSGPU_OK;
 }
 
 // Rows [row_begin, row_end) of the lower triangle into HOST memory, the rows split into blocks of equal pair

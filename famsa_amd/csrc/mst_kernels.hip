@@ -135,7 +135,10 @@ __global__ __launch_bounds__(256) void boruvka_init_kernel(BoruvkaArgs a)
 {
     const int v = blockIdx.x * 256 + threadIdx.x;
     if (v < a.n) a.comp[v] = v;
-    if (v == 0) a.counters[0] = 0; // edges recorded so far
+    if (v == 0) {
+        a.counters[0] = 0; // edges recorded so far
+        a.counters[1] = 0; // set by the global half when the gathered keys are inconsistent
+    }
 }
 
 // The two passes stream the block's triangle once each (2 B per pair) and are meant to be bound by that stream:
@@ -486,7 +489,15 @@ __global__ __launch_bounds__(256) void boruvka_hook_kernel(BoruvkaArgs a)
     if (id == NO_ID) return; // the last component
     const unsigned long long packed = ~id;
     const int x = (int)(packed >> 32), y = (int)(packed & 0xffffffffull);
+    if ((unsigned)x >= (unsigned)a.n || (unsigned)y >= (unsigned)a.n) { // keys are caller-supplied (exchanged between ranks)
+        a.counters[1] = 1;
+        return;
+    }
     const int cx = a.comp[x], cy = a.comp[y];
+    if ((cx == c) == (cy == c)) { // the edge must leave component c: both ends inside or both outside = keys of another round
+        a.counters[1] = 1;
+        return;
+    }
     const int other = cx == c ? cy : cx;
     a.parent[c] = other;
     // the edge is recorded once: by its only chooser, or by the smaller of two components that chose each other
@@ -513,8 +524,16 @@ __global__ __launch_bounds__(256) void boruvka_relabel_kernel(BoruvkaArgs a)
 {
     const int v = blockIdx.x * 256 + threadIdx.x;
     if (v >= a.n) return;
-    int r = a.comp[v];
-    for (int p = a.parent[r]; p != r; p = a.parent[r]) r = p;
+    // consistent keys give a forest (2-cycles were cut above): the walk ends at a root within n steps.  Stale or mixed
+    // keys can form a longer hooking cycle: bounded, reported through counters[1] (LCSGPU_E_STATE on the host side)
+    int r = a.comp[v], steps = 0;
+    for (int p = a.parent[r]; p != r; p = a.parent[r]) {
+        r = p;
+        if (++steps > a.n) {
+            a.counters[1] = 1;
+            break;
+        }
+    }
     a.comp_next[v] = r;
 }
 

@@ -33,6 +33,33 @@ KERNEL_LABEL = re.compile(r"^(_ZN6lcsgpu\w+):\s*(;.*)?$")
 NO_VGPR_DEF = ("v_cmp", "v_cmpx", "ds_write", "ds_store", "global_store", "buffer_store", "flat_store", "v_readlane",
                "v_readfirstlane", "s_", "global_atomic", "ds_add", "ds_min", "ds_max", "v_nop", "buffer_wbl2", "buffer_inv")
 BLOCK_END = re.compile(r"\s+(s_cbranch|s_branch|s_endpgm|s_setpc|s_swappc)")
+# The LOCAL pass only touches blocks made of instructions it understands completely -- one destination that is the
+# first operand and is written whole, every other VGPR token a plain source, no static hazard that depends on WHICH
+# register an operand is (none of these forms has one on gfx950: the LDS / global results are guarded by counters,
+# the carries by the order of the instructions, and neither changes) -- which is exactly the instruction set of the
+# build's equivalence check (recolor_check.py executes such a block before and after the pass).  Anything else
+# (tied or partial destinations: v_fmac / v_mac / v_dot*, *_d16[_hi] loads, v_permlane*_swap, DPP, op_sel or an SDWA
+# dst_sel, trans ops, MFMA, inline assembly with text) leaves the block as the compiler wrote it.
+ALLOWED_VALU = {
+    "v_and_b32_e32", "v_or_b32_e32", "v_xor_b32_e32", "v_add_co_u32_e32", "v_addc_co_u32_e32", "v_add_co_u32_e64",
+    "v_addc_co_u32_e64", "v_bitop3_b32", "v_add_u32_sdwa", "v_mov_b32_e32", "v_add_u32_e32", "v_sub_u32_e32",
+    "v_lshlrev_b32_e32", "v_lshrrev_b32_e32", "v_lshl_or_b32", "v_lshl_add_u32", "v_and_or_b32", "v_bfe_u32",
+    "v_lshl_add_u64", "v_cndmask_b32_e32",
+}
+ALLOWED_MEM = {"ds_read_b64", "ds_read_b32", "global_load_ushort", "global_load_dword", "global_load_dwordx4",
+               "global_store_short", "global_store_dword"}
+ALLOWED_CMP = re.compile(r"v_cmp_(eq|ne|lt|gt|le|ge)_[ui]32_e32$")
+# The GLOBAL pass renames registers through a whole function: that is a bijection of names and safe for every
+# instruction that names its registers in its text -- not for relative addressing or the accumulation file
+NO_PERMUTE = ("v_movrel", "s_set_gpr_idx", "v_accvgpr", "v_mfma", "s_setreg", "scratch_", "buffer_load", "buffer_store")
+
+
+def understood(op, line):
+    if op.startswith("s_"):
+        return True
+    if op == "v_add_u32_sdwa":
+        return "dst_sel:DWORD" in line and "src0_sel:DWORD" in line and "dst_unused" in line and "UNUSED_PAD" in line
+    return op in ALLOWED_VALU or op in ALLOWED_MEM or bool(ALLOWED_CMP.match(op))
 LABEL = re.compile(r"^[.\w$]+:")
 
 
@@ -94,12 +121,11 @@ def relocate_block(lines, nv, stats, nv_used=None):
             lo = max(lo, k + 1)
         else:
             hi = min(hi, k)
-    for _, op, _ in instrs[lo:hi]:
-        if "dpp" in op or op.startswith(("v_movrel", "s_set_gpr_idx", "v_swap", "v_writelane", "v_accvgpr", "v_mfma")):
-            return lines  # partial-register writes and the like: leave such a block alone
-    for li, op, _ in instrs[lo:hi]:
-        if "UNUSED_PRESERVE" in lines[li] or "op_sel" in lines[li]:
-            return lines
+    for li, op, _ in instrs:
+        if not understood(op, lines[li]) or "op_sel" in lines[li] or "dpp" in lines[li]:
+            stats["skipped_blocks"] = stats.get("skipped_blocks", 0) + 1
+            stats.setdefault("skipped_ops", set()).add(op)
+            return lines  # an instruction outside the allow-list: leave the block as the compiler wrote it
 
     # value numbering over the whole block
     class Val:
@@ -359,6 +385,11 @@ def recolor_function(lines, name, rng):
     n, c0 = count_conflicts(lines)
     if n == 0:
         return lines, None
+    for ln in lines:
+        code = split_code_comment(ln)[0].strip()
+        if code and code.split()[0].startswith(NO_PERMUTE):
+            print(f"recolor_vgprs: {name}: '{code.split()[0]}' found -- kernel left as compiled", file=sys.stderr)
+            return lines, None
     nv0 = 0
     for ln in lines:
         for m in VTOK.finditer(split_code_comment(ln)[0]):

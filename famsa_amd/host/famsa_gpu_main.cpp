@@ -136,7 +136,11 @@ int main(int argc, char** argv)
         };
         // the engine wants one hardware queue per lane (lcsgpu_create sets this too, but the environment must not
         // be modified once other threads run)
-        setenv("GPU_MAX_HW_QUEUES", getenv("LCSGPU_LANES") ? getenv("LCSGPU_LANES") : "16", 0);
+        // -- capped at 16 like the library's own setting: more hardware queues cost more than they give
+        {
+            const int lanes = getenv("LCSGPU_LANES") ? atoi(getenv("LCSGPU_LANES")) : 16;
+            setenv("GPU_MAX_HW_QUEUES", std::to_string(std::max(1, std::min(lanes, 16))).c_str(), 0);
+        }
         g_abandon_engine_at_return = getenv("FAMSA_GPU_CLEAN_EXIT") == nullptr;
         // HIP initialisation runs while the input is read and sorted; the heuristics' worker threads get their lanes now
         EngineFuture engine = start_engine(devices, opt.heuristic != 0 ? fasttree_pool_threads(n_threads) : 0);
@@ -154,6 +158,7 @@ int main(int argc, char** argv)
             if (!f.good()) throw std::runtime_error("cannot open " + output);
             f << nwk;
             f.close();
+            if (f.fail()) throw std::runtime_error("writing " + output + " failed (disk full?)"); // before the fast exit below reports success
             t.store_s = since(clock1);
         }
         if (verbose) {

@@ -677,7 +677,10 @@ static void write_csv_d(LcsSource& src, const std::vector<std::string>& ids, boo
             ofs.write(text[w].data() + begin[w], (std::streamsize)(e - begin[w]));
             begin[w] = e;
         }
+        if (ofs.fail()) throw std::runtime_error("writing " + path + " failed (disk full?)");
     }
+    ofs.close();
+    if (ofs.fail()) throw std::runtime_error("writing " + path + " failed (disk full?)");
 }
 
 void write_distance_csv(LcsSource& src, const std::vector<std::string>& ids, Distance dist, bool square, bool pid,

@@ -47,7 +47,10 @@ extern "C" {
 
 typedef struct lcsgpu_ctx lcsgpu_ctx;
 
-/* Library / build information: "lcsgpu <version> gfx950". */
+/* Library / build information: "lcsgpu <version> gfx950 recolor=<on|off|failed>" -- the last field says how the hot
+ * kernels were built: with the register-bank renaming pass and its equivalence check passed ("on"), without the pass
+ * on request ("off", make RECOLOR=0), or as compiled because the pass or its check failed ("failed": results are the
+ * same, the LCS kernels ~5 % slower). */
 const char* lcsgpu_version(void);
 const char* lcsgpu_last_error(void);
 
@@ -261,9 +264,15 @@ int lcsgpu_nj(lcsgpu_ctx* ctx, int distance_kind, int32_t* out_left, int32_t* ou
  *   (tree/UPGMA.cpp:75-109) / DistanceCalculator::run (tree/DistanceCalculator.cpp:28-82), one block per GPU.
  * lcsgpu_multi_upgma / lcsgpu_multi_nj: as lcsgpu_upgma / lcsgpu_nj; the row blocks of the other GPUs are copied
  *   into ctxs[0]'s HBM over xGMI (device-to-device), where the sequential merges run.
- * lcsgpu_multi_mst_prim: as lcsgpu_mst_prim, by the sharded Boruvka rounds above with the keys exchanged through
- *   host memory (lcsgpu_mst_merge_host); LCSGPU_E_UNSUPPORTED for orientation-sensitive sets in MSTPrim's own
- *   orientation (run lcsgpu_mst_prim on one context then). */
+ * lcsgpu_multi_mst_prim: as lcsgpu_mst_prim, by the sharded Boruvka rounds above with the exchange in DEVICE memory:
+ *   per round every context pushes its n keys (16 B each) into its slot of every other context's gathered buffer
+ *   (peer copies over xGMI on the producer's stream = the all-gather), every context runs the same global half on
+ *   its own GPU, and the host synchronises once (the edge count).  LCSGPU_E_UNSUPPORTED for orientation-sensitive
+ *   sets in MSTPrim's own orientation (run lcsgpu_mst_prim on one context then).
+ * Device-to-device copies between contexts switch peer access on for the device pair at first use; where the
+ * devices cannot address each other the copy is staged through pinned host memory (slower, same result).  Test
+ * switches (environment): LCSGPU_FORCE_PEER_COPY=1 makes same-device contexts take the peer-copy branch,
+ * LCSGPU_FORCE_HOST_STAGING=1 makes every inter-context copy take the host-staging branch. */
 int lcsgpu_multi_lcs_triangle(lcsgpu_ctx* const* ctxs, int32_t n_ctx, int32_t row_begin, int32_t row_end, void* out,
                               int elem_size);
 int lcsgpu_multi_upgma(lcsgpu_ctx* const* ctxs, int32_t n_ctx, int distance_kind, int modified, int32_t* out_left,

@@ -4,7 +4,10 @@
 only; minutes of CPU.  Writes tests/golden/meta_large.json (sha256 values only -- the data is
 regenerated deterministically by famsa_amd/seqio.py on the GPU box).
 
-    python oracle/make_golden_large.py [c3] [c4] [c5]        (default: all)
+    python oracle/make_golden_large.py [c3] [c4] [c5] [c5huge] [c4upgma]      (default: c3 c5 c4)
+
+c5huge = the 3 000 000-sequence family set (BASELINE config C5's size); c4upgma = -gt upgma / upgma_modified at
+100 000 x 400 aa (the reference holds the 20 GB float triangle in host memory).
 
 Model: the reference's own at-size regression, .github/workflows/self-hosted.yml:424-461."""
 import hashlib
@@ -80,8 +83,8 @@ def c4(ref, meta, gts=("sl",)):
     ref.close(h)
 
 
-def c5(ref, meta):
-    for n in (200000, 1000000):
+def c5(ref, meta, sizes=(200000, 1000000)):
+    for n in sizes:
         path = f"/tmp/golden_family_{n}_300.fasta"
         seqio.family_fasta(n, 300, path)
         fh = hashlib.sha256()
@@ -90,7 +93,7 @@ def c5(ref, meta):
                 fh.update(blk)
         h = ref.open_fasta(path)
         t0 = time.time()
-        nw = ref.tree(h, "upgma", heuristic=2, threads=THREADS)  # -medoidtree -gt upgma, default parameters
+        nw = ref.tree(h, "upgma", heuristic=2, threads=THREADS, cap=max(1 << 25, 24 * n))  # -medoidtree -gt upgma, default parameters
         rec = {"n": n, "len": 300, "fasta_sha256": fh.hexdigest(), "medoid_upgma_newick_sha256": sha(nw),
                "newick_bytes": len(nw), f"reference_seconds_{THREADS}_threads": round(time.time() - t0, 1)}
         print("c5", n, "%.0f s" % (time.time() - t0), flush=True)
@@ -104,7 +107,8 @@ def main():
     ref = oracle_bind.Ref()
     meta = load()
     for w in which:
-        {"c3": c3, "c4": c4, "c5": c5, "c4upgma": lambda r, m: c4(r, m, ("upgma", "upgma_modified"))}[w](ref, meta)
+        {"c3": c3, "c4": c4, "c5": c5, "c5huge": lambda r, m: c5(r, m, (3000000,)),
+         "c4upgma": lambda r, m: c4(r, m, ("upgma", "upgma_modified"))}[w](ref, meta)
     print(json.dumps(load(), indent=1))
 
 

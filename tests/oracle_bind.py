@@ -149,8 +149,8 @@ class Ref:
         return out
 
     def tree(self, h, gt, distance=1, heuristic=0, subtree=0, sample=0, threshold=0, cluster_fraction=0.0,
-             cluster_iters=0, keep_dups=0, threads=4, isa=2):
-        buf = C.create_string_buffer(1 << 25)
+             cluster_iters=0, keep_dups=0, threads=4, isa=2, cap=1 << 25):
+        buf = C.create_string_buffer(cap)
         n = self.lib.ref_tree_newick(h, self.GT[gt], distance, heuristic, subtree, sample, threshold,
                                      cluster_fraction, cluster_iters, keep_dups, threads, isa, buf, len(buf))
         assert n >= 0, n

@@ -6,7 +6,7 @@ deterministic generators).  Model: the reference's own at-size regression, .gith
   C4  synthetic 100 000 x 400 aa: -gt sl Newick (one GPU; the 2-context row-block form too), sampled oracle check;
       -gt upgma / upgma_modified Newick
   C5  'family' sets of 200 000 and 1 000 000 sequences: -medoidtree -gt upgma Newick
-      (3 000 000: FAMSA_TEST_HUGE=1 -- device CLARANS + 16 threads against host CLARANS + 1 thread)
+      and of 3 000 000 sequences (the C5 shape at its size); FAMSA_TEST_HUGE=1 adds the host-CLARANS / 1-thread run
 """
 import hashlib
 import json
@@ -157,15 +157,20 @@ def test_c5_medoid_tree(tmp_path, n):
     assert file_sha(out) == rec["medoid_upgma_newick_sha256"]
 
 
-@pytest.mark.skipif(not os.environ.get("FAMSA_TEST_HUGE"), reason="3 000 000 sequences: minutes; set FAMSA_TEST_HUGE=1")
 def test_c5_three_million(tmp_path):
-    """No reference run exists at this size (it would take ~6 min on 8 cores per run): the default path
-    (device CLARANS, all granted host threads, batched leaves) against the plainest one this engine has
-    (host CLARANS, one host thread) -- the two share only the LCS kernels."""
+    """BASELINE config C5 at its size: -medoidtree -gt upgma over 3 000 000 sequences, against the sha256 of the
+    REFERENCE's own run (oracle/make_golden_large.py c5huge: 444 s on the build container's 8 cores).  With
+    FAMSA_TEST_HUGE=1 additionally: the plainest path this engine has (host CLARANS, one host thread) must give the
+    same file -- the two paths share only the LCS kernels."""
+    rec = META["family3000000"]
     path = str(tmp_path / "family_3m.fasta")
-    seqio.family_fasta(3000000, 300, path)
-    a, b = str(tmp_path / "a.dnd"), str(tmp_path / "b.dnd")
+    seqio.family_fasta(rec["n"], rec["len"], path)
+    assert file_sha(path) == rec["fasta_sha256"]
+    a = str(tmp_path / "a.dnd")
     cli("-medoidtree", "-gt", "upgma", "-gt_export", path, a)
-    cli("-medoidtree", "-gt", "upgma", "-t", "1", "-gt_export", path, b, env={"FAMSA_CLARANS_HOST": "1"})
-    assert file_sha(a) == file_sha(b)
-    open(os.path.join(ROOT, "gpurun_out", "c5_3m_newick_sha256.txt"), "w").write(file_sha(a) + "\n")
+    assert os.path.getsize(a) == rec["newick_bytes"]
+    assert file_sha(a) == rec["medoid_upgma_newick_sha256"]
+    if os.environ.get("FAMSA_TEST_HUGE"):
+        b = str(tmp_path / "b.dnd")
+        cli("-medoidtree", "-gt", "upgma", "-t", "1", "-gt_export", path, b, env={"FAMSA_CLARANS_HOST": "1"})
+        assert file_sha(b) == rec["medoid_upgma_newick_sha256"]
