@@ -6,7 +6,8 @@
 // batch-distance seam -- AbstractTreeGenerator::calculateDistanceMatrix / calculateDistanceVector
 // (reference src/tree/AbstractTreeGenerator.hpp:130-182, 378-398; same template parameters and argument
 // meaning, the CLCSBP& scratch argument replaced by the engine context) -- on top of liblcsgpu.so; the
-// distances come out of the reference's own Transform functors (hpp:28-82).  GpuUPGMA / GpuNJ derive from the
+// distances come out of the reference's own Transform functors (hpp:28-82).  GpuMSTPrim feeds the reference's own
+// MSTPrim<D>::mst_to_dendogram (MSTPrim.cpp:784-833) with the edges of lcsgpu_mst_prim.  GpuUPGMA / GpuNJ derive from the
 // reference's generators and override only the distance stage (UPGMA<D>::run, UPGMA.cpp:39-51;
 // NeighborJoining<D>::run, NeighborJoining.cpp:10-23); the trees are built by the reference's own
 // UPGMA<D>::computeTree (UPGMA.cpp:114-295) and NeighborJoining<D>::computeTree (NeighborJoining.cpp:33-118),
@@ -17,9 +18,33 @@
 #include "tree/NeighborJoining.h"
 #include "tree/UPGMA.h"
 
+#include "tree/IPartialGenerator.h"
+#include "lcs/lcsbp.h"
+
+#include <algorithm>
+#include <array>
+#include <condition_variable>
+#include <functional>
+#include <iterator>
+#include <limits>
+#include <list>
+#include <math.h>
+#include <mutex>
+#include <queue>
+#include <stack>
 #include <stdexcept>
 #include <string>
+#include <tuple>
+#include <utility>
 #include <vector>
+// MSTPrim keeps its MST -> dendrogram step (mst_to_dendogram, tree/MSTPrim.cpp:784-833) and the edge record it takes
+// private (members of a `class` without an access specifier); a maintainer would call it from inside the class.
+// This test binding reaches it from a subclass instead: for this one header `class` reads `struct`, which changes
+// the default access and nothing else (layout and mangled names are the same; every header it includes has been
+// included above and is guarded).
+#define class struct
+#include "tree/MSTPrim.h"
+#undef class
 
 #include "../include/lcsgpu.h"
 
@@ -120,6 +145,51 @@ private:
     GpuDistanceProvider gpu_;
 };
 
+// `-gt sl`, the reference's default (tree/TreeDefs.h:91), in its batched form: the whole of MSTPrim::run_view's
+// distance work and key bookkeeping (tree/MSTPrim.cpp:356-533) is one lcsgpu_mst_prim call -- the LCS triangle and
+// the MST are built in HBM -- and the reference's own mst_to_dendogram turns the n-1 edges, which arrive in the
+// order Prim's algorithm adds them, into the tree.  mst_edges / v_prim_orders are filled exactly as run_view
+// fills them (cpp:383-391: edge k gets prim order k, weight -d; the endpoint that is new gets the next order).
+template <Distance D>
+class GpuMSTPrim : public MSTPrim<D> {
+public:
+    explicit GpuMSTPrim(int device) : MSTPrim<D>(1, instruction_set_t::none), device_(device) {}
+    void run(std::vector<CSequence*>& sequences, tree_structure& tree) override
+    {
+        const int n = (int)sequences.size();
+        lcsgpu_ctx* ctx = nullptr;
+        if (lcsgpu_create(device_, &ctx) != LCSGPU_OK) throw std::runtime_error(lcsgpu_last_error());
+        struct Close {
+            lcsgpu_ctx* c;
+            ~Close() { lcsgpu_destroy(c); }
+        } close{ctx};
+        std::vector<uint64_t> offsets((size_t)n + 1, 0);
+        for (int i = 0; i < n; ++i) offsets[i + 1] = offsets[i] + sequences[i]->length;
+        std::vector<uint8_t> codes(offsets[n] ? offsets[n] : 1);
+        for (int i = 0; i < n; ++i)
+            for (uint32_t p = 0; p < sequences[i]->length; ++p) codes[offsets[i] + p] = (uint8_t)sequences[i]->data[p];
+        if (lcsgpu_upload(ctx, codes.data(), offsets.data(), n) != LCSGPU_OK) throw std::runtime_error(lcsgpu_last_error());
+        std::vector<lcsgpu_mst_edge> edges((size_t)std::max(n - 1, 1));
+        const int kind = D == Distance::indel_div_lcs ? LCSGPU_DIST_INDEL_DIV_LCS : LCSGPU_DIST_INDEL075_DIV_LCS;
+        if (lcsgpu_mst_prim(ctx, kind, edges.data()) != LCSGPU_OK) throw std::runtime_error(lcsgpu_last_error());
+
+        std::vector<typename MSTPrim<D>::mst_edge_t> mst_edges;
+        mst_edges.reserve(n);
+        std::vector<int> v_prim_orders(n, n);
+        int cur_prim_order = 0;
+        v_prim_orders[0] = cur_prim_order++;
+        for (int k = 0; k + 1 < n; ++k) {
+            mst_edges.emplace_back(edges[k].from, edges[k].to, cur_prim_order, -edges[k].dist);
+            if (v_prim_orders[edges[k].from] == n) v_prim_orders[edges[k].from] = cur_prim_order++;
+            else v_prim_orders[edges[k].to] = cur_prim_order++;
+        }
+        this->mst_to_dendogram(mst_edges, v_prim_orders, tree);
+    }
+
+private:
+    int device_;
+};
+
 struct Request {
     int gt, distance, device;
 };
@@ -128,7 +198,10 @@ AbstractTreeGenerator* make_generator(void* user)
 {
     const Request& r = *(const Request*)user;
     const bool d0 = r.distance == 0;
-    switch (r.gt) { // ids as in ref_harness.cpp: 2 upgma, 3 nj, 4 upgma_modified
+    switch (r.gt) { // ids as in ref_harness.cpp: 0 sl (MSTPrim), 2 upgma, 3 nj, 4 upgma_modified
+    case 0:
+        return d0 ? (AbstractTreeGenerator*)new GpuMSTPrim<Distance::indel_div_lcs>(r.device)
+                  : (AbstractTreeGenerator*)new GpuMSTPrim<Distance::indel075_div_lcs>(r.device);
     case 2:
     case 4:
         return d0 ? (AbstractTreeGenerator*)new GpuUPGMA<Distance::indel_div_lcs>(r.gt == 4, r.device)
@@ -136,13 +209,14 @@ AbstractTreeGenerator* make_generator(void* user)
     case 3:
         return d0 ? (AbstractTreeGenerator*)new GpuNJ<Distance::indel_div_lcs>(r.device)
                   : (AbstractTreeGenerator*)new GpuNJ<Distance::indel075_div_lcs>(r.device);
-    default: throw std::runtime_error("the adapter check covers upgma, upgma_modified and nj");
+    default: throw std::runtime_error("this binding covers sl, upgma, upgma_modified and nj; slink, -dist_export and the "
+                                      "heuristics run through the dispatcher seam (gpu_lcsbp.cpp)");
     }
 }
 
 } // namespace
 
-// Newick text of `famsa -gt <upgma|upgma_modified|nj> -gt_export`: the reference's generators over GPU distances.
+// Newick text of `famsa -gt <sl|upgma|upgma_modified|nj> -gt_export`: the reference's generators over the GPU engine.
 extern "C" long adapter_tree_newick(void* ref_handle, int gt, int distance, int keep_dups, int device, char* out, long cap)
 {
     Request r{gt, distance, device};

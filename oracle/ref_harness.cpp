@@ -36,6 +36,16 @@
 
 namespace {
 
+// Called with the working set right before a generator runs -- the place of AbstractTreeGenerator::operator()
+// (reference tree/AbstractTreeGenerator.cpp:25-32).  Unset in libfamsa_ref.so (the CPU reference); set by
+// gpu_lcsbp.cpp in libfamsa_gpuref.so, whose CLCSBP is served by the GPU engine and needs the set uploaded.
+void (*g_pre_run)(CSequence* const* seqs, int n, void* user) = nullptr;
+void* g_pre_run_user = nullptr;
+void pre_run(std::vector<CSequence*>& working_set)
+{
+    if (g_pre_run) g_pre_run(working_set.data(), (int)working_set.size(), g_pre_run_user);
+}
+
 struct RefSet {
     std::vector<std::string> ids, residues; // input order, as read
     std::vector<CSequence> seqs;            // encoded once by the reference's CSequence ctor
@@ -190,6 +200,7 @@ std::string run_tree(const RefSet& rs, int gt, int heuristic, const MedoidParams
                                            mp.subtree_size, mp.sample_size, mp.num_evaluations, mp.threshold,
                                            clustering);
     }
+    pre_run(mapped);
     (*gen)(mapped, tree.raw());
     for (auto& s : sequences) // shrinkSequences, msa.cpp:320-335
         s.DataResize(s.length, UNKNOWN_SYMBOL);
@@ -203,6 +214,12 @@ std::string run_tree(const RefSet& rs, int gt, int heuristic, const MedoidParams
 } // namespace
 
 extern "C" {
+
+void ref_set_pre_run_hook(void (*hook)(CSequence* const* seqs, int n, void* user), void* user)
+{
+    g_pre_run = hook;
+    g_pre_run_user = user;
+}
 
 void* ref_open_fasta(const char* path)
 {
@@ -248,6 +265,11 @@ int ref_lcs_rect(void* h, const int* ref_ids, int n_refs, const int* col_ids, in
     extend(seqs);
     for (int i = 0; i < (int)seqs.size(); ++i)
         seqs[i].sequence_no = i;
+    {
+        std::vector<CSequence*> all(seqs.size());
+        std::transform(seqs.begin(), seqs.end(), all.begin(), [](CSequence& s) { return &s; });
+        pre_run(all);
+    }
     CLCSBP lcsbp(isa_of(isa));
     uint32_t lens[8];
     for (int r = 0; r < n_refs; ++r) {
@@ -311,6 +333,7 @@ long ref_tree_newick_with(void* h, int keep_dups, AbstractTreeGenerator* (*make)
             for (int i = 0; i < (int)mapped.size(); ++i)
                 mapped[i]->sequence_no = i;
             std::unique_ptr<AbstractTreeGenerator> gen(make(user));
+            pre_run(mapped);
             (*gen)(mapped, tree.raw());
             for (auto& s : sequences)
                 s.DataResize(s.length, UNKNOWN_SYMBOL);
@@ -341,6 +364,9 @@ int ref_dist_export(void* h, int distance, int square, int pid, int n_threads, i
             gen = std::make_shared<DistanceCalculator<Distance::indel_div_lcs>>(n_threads, isa_of(isa), out_path, square != 0, pid != 0);
         else
             gen = std::make_shared<DistanceCalculator<Distance::indel075_div_lcs>>(n_threads, isa_of(isa), out_path, square != 0, pid != 0);
+        for (int i = 0; i < (int)mapped.size(); ++i)
+            mapped[i]->sequence_no = i; // input order (the CSequence constructor already numbered them so)
+        pre_run(mapped);
         (*gen)(mapped, tree);
         return 0;
     } catch (...) {

@@ -10,6 +10,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_SO = os.path.join(ROOT, "oracle", "liblcs_oracle.so")
 REF_SO = os.path.join(ROOT, "oracle", "_ref", "libfamsa_ref.so")
+# the reference's generators with class CLCSBP implemented over liblcsgpu.so (oracle/gpu_lcsbp.cpp): same entry points
+GPUREF_SO = os.path.join(ROOT, "oracle", "_ref", "libfamsa_gpuref.so")
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
@@ -96,11 +98,12 @@ def have_ref():
 
 
 class Ref:
-    """The reference's own code (oracle/_ref/libfamsa_ref.so)."""
+    """The reference's own code (oracle/_ref/libfamsa_ref.so); with so=GPUREF_SO the same driver and generators
+    with the LCS dispatcher served by the GPU engine (GPU tests only)."""
     GT = {"sl": 0, "slink": 1, "upgma": 2, "nj": 3, "upgma_modified": 4}
 
-    def __init__(self):
-        lib = C.CDLL(REF_SO)
+    def __init__(self, so=REF_SO):
+        lib = C.CDLL(so)
         vp, i = C.c_void_p, C.c_int
         lib.ref_open_fasta.restype = vp
         lib.ref_open_fasta.argtypes = [C.c_char_p]

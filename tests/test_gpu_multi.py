@@ -72,6 +72,28 @@ def test_group_calls_equal_single_context(engine, name, devices):
         grp.close()
 
 
+@pytest.mark.parametrize("switch", ["LCSGPU_FORCE_PEER_COPY", "LCSGPU_FORCE_HOST_STAGING"])
+def test_group_calls_over_the_other_transports(engine, monkeypatch, switch):
+    """Contexts on ONE device copy with hipMemcpyAsync; these switches make the same calls take the branches two
+    devices take: hipMemcpyPeerAsync (with peer access: xGMI) resp. the pinned-host staging used when two devices
+    cannot address each other -- the row-block gather of lcsgpu_multi_upgma and the per-round key pushes of
+    lcsgpu_multi_mst_prim."""
+    monkeypatch.setenv(switch, "1")
+    seqs = _sets()["family"]
+    engine.upload_seqs(seqs)
+    grp = famsa_amd.LcsGpuGroup([0, 0, 0])
+    try:
+        grp.upload_seqs(seqs)
+        a, b = grp.mst_prim(1), engine.mst_prim(1)
+        assert (a["from"] == b["from"]).all() and (a["to"] == b["to"]).all()
+        assert (a["dist"].view(np.uint64) == b["dist"].view(np.uint64)).all()
+        gl, gr = grp.upgma(1, False)
+        sl, sr = engine.upgma(1, False)
+        assert (gl == sl).all() and (gr == sr).all()
+    finally:
+        grp.close()
+
+
 def test_group_refuses_what_it_cannot_do(engine):
     seqs = [np.zeros(192, np.uint8)] + _sets()["family"][:300]  # a carry-quirk (orientation-sensitive) sequence
     grp = famsa_amd.LcsGpuGroup([0, 0])

@@ -214,3 +214,16 @@ def test_bench_step_ends_in_the_same_tree_for_every_rank_count():
     assert one["mst"]["n_edges"] == 5999 and two["n_gpus"] == 2 and three["n_gpus"] == 3
     assert one["parity"]["sampled_pairs"] > 0 and one["parity"]["mismatches"] == 0
     assert two["parity"]["mismatches"] == 0
+
+
+def test_bench_with_the_real_collective_on_one_rank():
+    """bench.py --force-collective: one rank, but the exchange of every Boruvka round is the N > 1 path's own --
+    torch.distributed initialised with the nccl (= RCCL) backend, all_gather_into_tensor on device tensors, the
+    hand-off between the engine's stream and torch's -- so RCCL initialisation and the stream ordering run on an
+    MI355X in every GPU test run, not for the first time on an 8-GPU node.  Same tree as without it."""
+    args = ["--steps", "2", "--warmup", "1", "--n-seqs", "6000", "--seq-len", "120", "--no-cpu-baseline"]
+    plain = _bench(args, 1)
+    forced = _bench(args + ["--force-collective"], 1)
+    assert forced["config"]["exchange"].startswith("nccl") and plain["config"]["exchange"].startswith("none")
+    assert forced["mst"]["edges_sha256"] == plain["mst"]["edges_sha256"]
+    assert forced["mst"]["rounds"] == plain["mst"]["rounds"] and forced["parity"]["mismatches"] == 0
