@@ -332,6 +332,11 @@ def main():
             except Exception as e:  # the baseline is a report, never a reason to lose the GPU number
                 cb = {"error": repr(e)}
             out["cpu_baseline"] = cb
+        try:  # RCCL writes its version banner through C stdio: out with it before the one JSON line, not after
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
         print(json.dumps(out), flush=True)
     if collective:
         dist.destroy_process_group()

@@ -123,7 +123,7 @@ def test_reference_generators_at_the_dispatcher_seam(gpuref, case, gt, gold):
     ("sl", {}, "medoid-sl.dnd"),
     ("upgma", {}, "medoid-upgma.dnd"),
     ("nj", {}, "medoid-nj.dnd"),
-    ("slink", dict(subtree=10, sample=100, cluster_fraction=0.2, cluster_iters=1), "medoid-slink-params.dnd"),
+    ("slink", dict(subtree=10, sample=100, threshold=100, cluster_fraction=0.2, cluster_iters=1), "medoid-slink-params.dnd"),
 ])
 def test_reference_medoid_tree_at_the_dispatcher_seam(gpuref, gt, params, gold):
     """FastTree::doStep / makeEvaluation / clusterSeeds + CLARANS + the partial generators (reference object code):
