@@ -8,6 +8,23 @@ namespace lcsgpu {
 
 enum { MODE_RECT = 0, MODE_TRIANGLE = 1 };
 
+// The local half of a Boruvka round FUSED into the LCS launch (triangle mode over contiguous rows / columns):
+// besides (or instead of) storing LCS(row, column), a workgroup folds its 256 columns x R rows into every vertex's
+// best edge to another component -- nothing but n x 8 B leaves the kernel per side.  A vertex's best edge is kept as
+// ONE 64-bit record (l : 16 | length of the other endpoint : 16 | other endpoint : 32), from which MSTPrim's 128-bit
+// key (distance bits, ~pack(ids); reference tree/MSTPrim.h:424-483) is a pure function -- so the global fold is a
+// 64-bit compare-and-swap loop with an exact comparator (Transform<double>'s division on both records), and the
+// same record is the hint for the integer pre-filter (mst_kernels.hip: l_threshold).  ~0 = none.
+struct FuseArgs {
+    unsigned long long* row_rec; // [n] best edge of v among u < v (its row)
+    unsigned long long* col_rec; // [n] ... among u > v (its column)
+    const int32_t* comp;         // [n] component labels; NULL = every vertex on its own (round 0)
+    const double* pow_table;     // pow(i, 0.75) from the host's libm
+    int32_t kind;                // LCSGPU_DIST_*
+    int32_t on;
+};
+constexpr size_t FUSE_LDS_BYTES = 256 * 8 + 4 * 32 * 8; // per-column records + per-(wave, row) records
+
 struct RowsArgs {
     // the uploaded sequence set (device)
     const uint8_t* tiles;      // position-major residue store, bytes = code*8
@@ -46,15 +63,17 @@ struct RowsArgs {
     const int4* jobs;
     const int32_t* ref_col0;
     const int64_t* ref_out0;
+    FuseArgs fuse; // fuse.on: MODE_TRIANGLE, contiguous columns, row == ref id; `out` may then be NULL (nothing stored)
 };
 
-const char* recolor_state(); // "on" | "off" | "failed": see csrc/Makefile, RECOLOR
+const char* recolor_state();       // "on" | "off" | "failed": see csrc/Makefile, RECOLOR (the plain LCS kernels)
+const char* recolor_state_fused(); // ... the translation unit of the fused instantiations
 // instantiated half-word (32-bit) counts: exact 1..32, even 34..64; 0 = the long-sequence path
 int h_class(uint32_t len);
 int quirk_h_class(uint32_t len);
-int refs_per_block(int h, bool quirk);
+int refs_per_block(int h, bool quirk, bool fused = false);
 // ... reduced for launches that would otherwise have too few workgroups to fill the chip
-int refs_per_block_for(int h, bool quirk, long n_refs, long col_blocks);
+int refs_per_block_for(int h, bool quirk, long n_refs, long col_blocks, bool fused = false);
 hipError_t launch_rows(int h, bool quirk, const RowsArgs& a, int grid_x, int grid_y, hipStream_t stream);
 // refs longer than 2048 residues: needs grid_x*grid_y*n_chunks_max*512 bytes of carry scratch
 size_t long_carry_bytes(int grid_x, int grid_y, int n_chunks_max);
@@ -133,8 +152,14 @@ struct BoruvkaArgs {
     MstEdge* edges;             // [n-1] in the order the rounds find them
     int32_t* counters;          // [0] edges recorded  [1] inconsistent keys seen by the global half
     int32_t n, kind, n_chunks, rows_per_chunk;
+    unsigned long long* fuse_row; // [n] the records of a local half done by the LCS launch itself (FuseArgs)
+    unsigned long long* fuse_col; // [n]
 };
 hipError_t launch_boruvka_init(const BoruvkaArgs& a, hipStream_t stream);
+// local half by the LCS launch (run_rows with FuseArgs over the block's rows): reset the records before it,
+// turn them into a.best afterwards
+hipError_t launch_boruvka_fuse_reset(const BoruvkaArgs& a, hipStream_t stream);
+hipError_t launch_boruvka_fuse_fold(const BoruvkaArgs& a, hipStream_t stream);
 // local half of a round: a.best[v] = best edge of v to another component among the pairs of this row block
 hipError_t launch_boruvka_best(const BoruvkaArgs& a, int elem_size, hipStream_t stream);
 // global half: `gathered` = n_parts x n keys (every block's a.best); per-component minima, hooking, relabel.

@@ -167,6 +167,165 @@ __device__ __forceinline__ void store_result(const RowsArgs& a, int k, int c, ui
         ((uint32_t*)a.out)[idx] = res;
 }
 
+// bytes of mask rows in LDS ahead of the fused launch's records
+__device__ __forceinline__ lds_u64* fuse_lds(unsigned char* smem, int refs_per_block, int W)
+{
+    return (lds_u64*)(smem + (size_t)refs_per_block * W * 256);
+}
+
+// ---- the local half of a Boruvka round fused into the LCS launch (FuseArgs, lcs_kernels.h) ------------------------
+typedef unsigned long long fuse_rec;
+static constexpr fuse_rec FUSE_NONE = ~0ull;
+__device__ __forceinline__ fuse_rec fuse_pack(uint32_t l, uint32_t len, uint32_t u)
+{
+    return ((fuse_rec)l << 48) | ((fuse_rec)(len & 0xFFFFu) << 32) | u;
+}
+__device__ __forceinline__ uint32_t fuse_l(fuse_rec r) { return (uint32_t)(r >> 48); }
+__device__ __forceinline__ uint32_t fuse_len(fuse_rec r) { return (uint32_t)(r >> 32) & 0xFFFFu; }
+__device__ __forceinline__ uint32_t fuse_u(fuse_rec r) { return (uint32_t)r; }
+
+// Transform<double, kind> (reference tree/AbstractTreeGenerator.hpp:28-82): host-built pow table + IEEE division
+__device__ __forceinline__ double fuse_dist(const FuseArgs& f, uint32_t l, uint32_t indel)
+{
+    if (l == 0) return 1.7976931348623155e308; // nextafter(DBL_MAX, 0), hpp:61,73
+    return f.kind == 1 ? f.pow_table[indel] / (double)l : (double)indel / (double)l;
+}
+
+// Is record A a better edge for the vertex v (length len_v) than record B?  MSTPrim's order (tree/MSTPrim.cpp:493-509):
+// smaller distance, then the LARGER packed id pair -- for a fixed v and one side (all u < v, or all u > v) that is the
+// larger u.  Equal (l, length) give the same distance bit for bit: no division then.
+__device__ __forceinline__ bool fuse_better(const FuseArgs& f, fuse_rec A, fuse_rec B, uint32_t len_v)
+{
+    if (A == FUSE_NONE) return false;
+    if (B == FUSE_NONE) return true;
+    const uint32_t la = fuse_l(A), lb = fuse_l(B), na = fuse_len(A), nb = fuse_len(B);
+    if (la == lb && na == nb) return fuse_u(A) > fuse_u(B);
+    const double da = fuse_dist(f, la, len_v + na - 2u * la), db = fuse_dist(f, lb, len_v + nb - 2u * lb);
+    if (da != db) return da < db;
+    return fuse_u(A) > fuse_u(B);
+}
+
+// The integer pre-filter (mst_kernels.hip, l_threshold): with the edge `rec` in hand, a candidate whose other endpoint
+// is len_c long can reach its distance only with l >= this.
+__device__ __forceinline__ uint32_t fuse_thr(fuse_rec rec, uint32_t len_c)
+{
+    if (rec == FUSE_NONE) return 0;
+    const uint32_t l_b = fuse_l(rec), len_b = fuse_len(rec);
+    const uint32_t slack = len_b > len_c ? (len_b - len_c + 1) >> 1 : 0;
+    return l_b > slack ? l_b - slack : 0;
+}
+
+__device__ __forceinline__ void fuse_global_update(const FuseArgs& f, fuse_rec* slot, fuse_rec mine, uint32_t len_v)
+{
+    if (mine == FUSE_NONE) return;
+    fuse_rec cur = __atomic_load_n(slot, __ATOMIC_RELAXED);
+    while (cur != mine && fuse_better(f, mine, cur, len_v)) {
+        const fuse_rec prev = atomicCAS(slot, cur, mine);
+        if (prev == cur) break;
+        cur = prev;
+    }
+}
+
+// LDS of a fused launch, behind the masks: f_col[256] -- the best edge of this workgroup's column vertices, each
+// owned by its lane -- and f_row[4][32] -- the best edge of its row vertices as seen by each wave.  Both start
+// from the global records (hints: whatever other workgroups have folded so far) and are folded back at the end.
+__device__ __forceinline__ void fuse_init(const RowsArgs& a, lds_u64* f_col, lds_u64* f_row, int ref0, int nr, int c, bool valid,
+                                          int tid)
+{
+    f_col[tid] = valid ? a.fuse.col_rec[a.col_begin + c] : FUSE_NONE;
+    if (tid < 128) {
+        const int i = tid & 31;
+        fuse_rec h = FUSE_NONE;
+        if (i < nr) h = a.fuse.row_rec[a.ref_ids ? a.ref_ids[ref0 + i] : a.ref_begin + ref0 + i];
+        f_row[tid] = h;
+    }
+}
+
+// NR results of this lane (refs kl0 .. kl0 + cnt - 1 of the workgroup's tile against column c).  The bulk costs two
+// integer thresholds and a compare per result; the exact comparison (component labels, the f64 division, a wave
+// reduction for the row side) runs only when some lane's LCS length reaches a threshold.
+template <int NR>
+__device__ __forceinline__ void fuse_group(const RowsArgs& a, lds_u64* f_col, lds_u64* f_row, int ref0, int kl0, int cnt, int c_in,
+                                           int col_limit, const uint32_t (&res)[NR], int tid_in)
+{
+    // Everything here that does not depend on the ref group -- the column's id, its length, its LDS slot -- would be
+    // hoisted out of the workgroup's loop over ref groups by the compiler and then stay in VGPRs through the hot loop
+    // (+17 registers: 5 -> 4 waves per SIMD at 13 half-words).  The two lane indices are made opaque here, so all of
+    // it is recomputed per group, after the loop: a dozen instructions against ~60 000.
+    int c = c_in, tid = tid_in;
+    asm volatile("" : "+v"(c), "+v"(tid));
+    const FuseArgs& f = a.fuse;
+    const bool valid = c < col_limit;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pid = a.col_begin + c;
+    const uint32_t len_c = valid ? a.lens[pid] : 0u;
+    fuse_rec crec = f_col[tid];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        if (r >= cnt) break;
+        const int rid = a.ref_ids ? a.ref_ids[ref0 + kl0 + r] : a.ref_begin + ref0 + kl0 + r;
+        const uint32_t len_r = a.lens[rid];
+        const fuse_rec rrec = f_row[wave * 32 + kl0 + r];
+        const uint32_t l = res[r];
+        const bool pass = valid && pid < rid && (l >= fuse_thr(rrec, len_c) || l >= fuse_thr(crec, len_r));
+        if (__builtin_amdgcn_ballot_w64(pass) == 0) continue;
+        bool cand = pass;
+        if (f.comp && cand) cand = f.comp[pid] != f.comp[rid];
+        if (__builtin_amdgcn_ballot_w64(cand) == 0) continue;
+        fuse_rec mine = 0;
+        unsigned long long dbits = 0;
+        if (cand) {
+            const fuse_rec as_col = fuse_pack(l, len_r, (uint32_t)rid); // the column vertex's view of the edge
+            if (fuse_better(f, as_col, crec, len_c)) crec = as_col;
+            mine = fuse_pack(l, len_c, (uint32_t)pid);                  // the row vertex's view
+            dbits = (unsigned long long)__double_as_longlong(fuse_dist(f, l, len_r + len_c - 2u * l));
+        }
+        // the wave's best candidate for the row vertex -- smaller d (distances are >= 0: their bits order like the
+        // values), then larger u -- by a walk over the candidate lanes in SGPRs (few lanes get here; a shuffle
+        // butterfly would keep six lane-index registers alive through the hot loop)
+        unsigned long long todo = __builtin_amdgcn_ballot_w64(cand);
+        unsigned long long bd = 0;
+        fuse_rec bm = FUSE_NONE;
+        while (todo) {
+            const int src = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            const unsigned long long d2 = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(dbits >> 32), src) << 32) |
+                                          (uint32_t)__builtin_amdgcn_readlane((int)dbits, src);
+            const fuse_rec m2 = ((fuse_rec)(uint32_t)__builtin_amdgcn_readlane((int)(mine >> 32), src) << 32) |
+                                (uint32_t)__builtin_amdgcn_readlane((int)mine, src);
+            if (bm == FUSE_NONE || d2 < bd || (d2 == bd && fuse_u(m2) > fuse_u(bm))) {
+                bd = d2;
+                bm = m2;
+            }
+        }
+        mine = bm;
+        if ((tid & 63) == 0 && fuse_better(f, mine, rrec, len_r)) f_row[wave * 32 + kl0 + r] = mine;
+    }
+    f_col[tid] = crec;
+}
+
+// after the workgroup's last result (and a barrier): fold the records back into the global ones
+__device__ __forceinline__ void fuse_flush(const RowsArgs& a, const lds_u64* f_col, const lds_u64* f_row, int ref0, int nr, int c,
+                                           bool valid, int tid)
+{
+    const FuseArgs& f = a.fuse;
+    if (tid < nr) {
+        const int rid = a.ref_ids ? a.ref_ids[ref0 + tid] : a.ref_begin + ref0 + tid;
+        const uint32_t len_r = a.lens[rid];
+        fuse_rec best = f_row[tid];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+            const fuse_rec o = f_row[w * 32 + tid];
+            if (o != best && fuse_better(f, o, best, len_r)) best = o;
+        }
+        fuse_global_update(f, &f.row_rec[rid], best, len_r);
+    }
+    if (valid) {
+        const int pid = a.col_begin + c;
+        fuse_global_update(f, &f.col_rec[pid], f_col[tid], a.lens[pid]);
+    }
+}
+
 // Workgroup -> (column block x, ref tile y).  In the compact triangle grid the rows are walked
 // from the bottom (most column blocks) to the top, so the chip fills at once and the workgroups
 // above the diagonal -- half of a 2-D grid, and nearly all of its first rows -- are never launched
@@ -229,7 +388,7 @@ __device__ __forceinline__ bool block_is_above_diagonal(const RowsArgs& a, int r
 // Orientation-sensitive refs (SURVEY note Q): one ref at a time, whole 64-bit words, literal rule.
 // Rare by construction (a ref needs an aligned 64-residue homopolymer), so this kernel is written
 // for exactness, not speed.
-template <int H>
+template <int H, bool FUSE>
 __global__ __launch_bounds__(256) void lcs_rows_kernel_quirk(RowsArgs a)
 {
     static_assert(H % 2 == 0, "quirk instantiations use whole 64-bit words");
@@ -245,10 +404,13 @@ __global__ __launch_bounds__(256) void lcs_rows_kernel_quirk(RowsArgs a)
         const int rid = a.ref_ids ? a.ref_ids[ref0 + r] : a.ref_begin + ref0 + r;
         build_mask_words(a, rid, 0, W, (lds_u64*)smem + r * W * 32, wave, lane);
     }
-    __syncthreads();
-
     const int c = c0 + tid;
     const bool valid = c < col_limit;
+    [[maybe_unused]] lds_u64* f_col = fuse_lds(smem, R, W);
+    [[maybe_unused]] lds_u64* f_row = f_col + 256;
+    if constexpr (FUSE) fuse_init(a, f_col, f_row, ref0, nr, c, valid, tid);
+    __syncthreads();
+
     const int pid = a.col_ids ? a.col_ids[valid ? c : 0] : a.col_begin + (valid ? c : 0);
     const uint32_t len_p = valid ? a.lens[pid] : 0u;
     const uint8_t* pbase = a.tiles + a.tile_base[pid >> 6] + (uint64_t)(pid & 63) * 16;
@@ -270,13 +432,16 @@ __global__ __launch_bounds__(256) void lcs_rows_kernel_quirk(RowsArgs a)
             for (int b = 0; b < 16; ++b)
                 literal_step<W>(masks + ((w[b >> 2] >> (8 * (b & 3))) & 0xFFu), X, 0u);
         }
-        if (!valid)
-            continue;
-        uint32_t res = 0; // number of zero bits (reference lcsbp_classic.h:60-65)
+        uint32_t res[1] = {0}; // number of zero bits (reference lcsbp_classic.h:60-65)
 #pragma unroll
         for (int j = 0; j < H; ++j)
-            res += __popc(~X[j]);
-        store_result(a, ref0 + r, c, res);
+            res[0] += __popc(~X[j]);
+        if (valid && (!FUSE || a.out)) store_result(a, ref0 + r, c, res[0]);
+        if constexpr (FUSE) fuse_group<1>(a, f_col, f_row, ref0, r, 1, c, col_limit, res, tid);
+    }
+    if constexpr (FUSE) {
+        __syncthreads();
+        fuse_flush(a, f_col, f_row, ref0, nr, c, valid, tid);
     }
 }
 
@@ -394,7 +559,10 @@ struct Pipe {
 // (The instantiations with X = 64 registers -- 16 x 4, 32 x 2, 64 x 1 half-words x refs -- hold 105 VGPRs = 4 waves per
 // SIMD; asked for 5 through the launch bounds the compiler fits 96 with three dwords spilled outside the loop bodies,
 // and nothing is gained: 448 / 512 / 1024 / 2048 aa 615 / 616 / 615 / 611 Tcell/s with 4 waves, 619 / 611 / 613 / 606 with 5.)
-template <int H, int RG, int LOOKAHEAD>
+// FUSE: the instantiations that also fold their results into the per-vertex best-edge records (FuseArgs); a separate
+// set of kernels (built as its own translation unit, LCS_FUSED_TU) so that the plain ones keep their registers: the
+// fold costs the 13-half-word kernel 5 VGPRs (90 -> 95, still 5 waves per SIMD), the 14-half-word one its fifth wave.
+template <int H, int RG, int LOOKAHEAD, bool FUSE>
 __global__ __launch_bounds__(256) void lcs_rows_kernel_pipe(RowsArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -407,10 +575,13 @@ __global__ __launch_bounds__(256) void lcs_rows_kernel_pipe(RowsArgs a)
     if (block_is_above_diagonal(a, ref0, nr, c0))
         return;
     fill_tile_masks<W>(a, ref0, nr, (nr + RG - 1) / RG * RG, (lds_u64*)smem, tid);
-    __syncthreads();
-
     const int c = c0 + tid;
     const bool valid = c < col_limit;
+    [[maybe_unused]] lds_u64* f_col = fuse_lds(smem, R, W);
+    [[maybe_unused]] lds_u64* f_row = f_col + 256;
+    if constexpr (FUSE) fuse_init(a, f_col, f_row, ref0, nr, c, valid, tid);
+    __syncthreads();
+
     const int pid = a.col_ids ? a.col_ids[valid ? c : 0] : a.col_begin + (valid ? c : 0);
     const uint32_t len_p = valid ? a.lens[pid] : 0u;
     const uint8_t* pbase = a.tiles + a.tile_base[pid >> 6] + (uint64_t)(pid & 63) * 16;
@@ -453,16 +624,24 @@ __global__ __launch_bounds__(256) void lcs_rows_kernel_pipe(RowsArgs a)
             q.z = q.w;
             q.w = PAD4;
         }
+        uint32_t res[RG];
 #pragma unroll
         for (int r = 0; r < RG; ++r) {
-            if (g + r >= nr || !valid)
-                continue;
-            uint32_t res = 0;
+            res[r] = 0;
 #pragma unroll
             for (int j = 0; j < H; ++j)
-                res += __popc(~X[r][j]);
-            store_result(a, ref0 + g + r, c, res);
+                res[r] += __popc(~X[r][j]);
         }
+        if (!FUSE || a.out) {
+#pragma unroll
+            for (int r = 0; r < RG; ++r)
+                if (g + r < nr && valid) store_result(a, ref0 + g + r, c, res[r]);
+        }
+        if constexpr (FUSE) fuse_group<RG>(a, f_col, f_row, ref0, g, min(RG, nr - g), c, col_limit, res, tid);
+    }
+    if constexpr (FUSE) {
+        __syncthreads();
+        fuse_flush(a, f_col, f_row, ref0, nr, c, valid, tid);
     }
 }
 
@@ -557,7 +736,7 @@ __device__ __forceinline__ uint32_t long_segment_pass(const RowsArgs& a, int rid
     return res;
 }
 
-template <bool QUIRK>
+template <bool QUIRK, bool FUSE>
 __global__ __launch_bounds__(256) void lcs_long_kernel(RowsArgs a, uint16_t* carry, int n_chunks_max)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[]; // SEGW x 256 bytes
@@ -573,6 +752,9 @@ __global__ __launch_bounds__(256) void lcs_long_kernel(RowsArgs a, uint16_t* car
 
     const int c = c0 + tid;
     const bool valid = c < a.n_cols;
+    [[maybe_unused]] lds_u64* f_col = (lds_u64*)(smem + (size_t)SEGW * 256);
+    [[maybe_unused]] lds_u64* f_row = f_col + 256;
+    if constexpr (FUSE) fuse_init(a, f_col, f_row, ref0, nr, c, valid, tid); // the first segment pass starts with a barrier
     const int pid = a.col_ids ? a.col_ids[valid ? c : 0] : a.col_begin + (valid ? c : 0);
     const uint32_t len_p = valid ? a.lens[pid] : 0u;
     const uint8_t* pbase = a.tiles + a.tile_base[pid >> 6] + (uint64_t)(pid & 63) * 16;
@@ -597,8 +779,15 @@ __global__ __launch_bounds__(256) void lcs_long_kernel(RowsArgs a, uint16_t* car
             else { LCS_LONG_PASS(8) }
 #undef LCS_LONG_PASS
         }
-        if (valid)
-            store_result(a, ref0 + r, c, res);
+        if (valid && (!FUSE || a.out)) store_result(a, ref0 + r, c, res);
+        if constexpr (FUSE) {
+            const uint32_t one[1] = {res};
+            fuse_group<1>(a, f_col, f_row, ref0, r, 1, c, a.n_cols, one, tid);
+        }
+    }
+    if constexpr (FUSE) {
+        __syncthreads();
+        fuse_flush(a, f_col, f_row, ref0, nr, c, valid, tid);
     }
 }
 
@@ -609,6 +798,7 @@ __global__ __launch_bounds__(256) void lcs_long_kernel(RowsArgs a, uint16_t* car
 #ifndef LCSGPU_RECOLOR_STATE
 #define LCSGPU_RECOLOR_STATE "off"
 #endif
+#ifndef LCS_FUSED_TU
 const char* recolor_state() { return LCSGPU_RECOLOR_STATE; }
 
 int h_class(uint32_t len)
@@ -632,17 +822,20 @@ int quirk_h_class(uint32_t len)
     return 0;
 }
 
+#endif // !LCS_FUSED_TU
 #ifndef LCS_RG13
 #define LCS_RG13 4 // measurement aid: refs advanced together in the 13-half-word (400 aa) instantiation
 #endif
+#ifndef LCS_FUSED_TU
 static int rg_of(int h) { return h == 13 ? LCS_RG13 : h <= 16 ? 4 : (h <= 32 ? 2 : 1); }
 
-int refs_per_block(int h, bool quirk)
+int refs_per_block(int h, bool quirk, bool fused)
 {
     if (h == 0) return 8; // long path: refs are processed one after another
     const int rg = quirk ? 1 : rg_of(h);
     const int w = (h + 1) / 2;
-    int r = (32 * 1024) / (w * 256);
+    // 32 KB of LDS per workgroup = 5 workgroups per CU; a fused launch keeps its records (3 KB) inside that budget
+    int r = (int)((32 * 1024 - (fused ? FUSE_LDS_BYTES : 0)) / (size_t)(w * 256));
     if (r > 32) r = 32;
     r = r / rg * rg;
     if (r < rg) r = rg;
@@ -653,9 +846,9 @@ int refs_per_block(int h, bool quirk)
 // and a few hundred such workgroups leave most of the chip idle for that long.  Fewer refs per
 // workgroup (a multiple of the register group) give more, shorter workgroups; the full complement
 // is kept once the launch has enough of them anyway.
-int refs_per_block_for(int h, bool quirk, long n_refs, long col_blocks)
+int refs_per_block_for(int h, bool quirk, long n_refs, long col_blocks, bool fused)
 {
-    const int full = refs_per_block(h, quirk);
+    const int full = refs_per_block(h, quirk, fused);
     if (h == 0) return full;
     const int rg = quirk ? 1 : rg_of(h);
     const long want = 2048; // workgroups
@@ -663,33 +856,35 @@ int refs_per_block_for(int h, bool quirk, long n_refs, long col_blocks)
     while (r > rg && ((n_refs + r - 1) / r) * col_blocks < want) r = std::max(rg, r / 2 / rg * rg);
     return r;
 }
+#endif // !LCS_FUSED_TU
 
-template <int H, int RG, bool QUIRK>
+template <int H, int RG, bool QUIRK, bool FUSE>
 static hipError_t launch_one(const RowsArgs& a, dim3 grid, hipStream_t stream)
 {
     static const size_t lds_pad = getenv("LCSGPU_LDS_PAD") ? (size_t)atoi(getenv("LCSGPU_LDS_PAD")) : 0; // measurement aid: fewer workgroups per CU
-    const size_t lds = (size_t)a.refs_per_block * ((H + 1) / 2) * 256 + lds_pad;
+    const size_t lds = (size_t)a.refs_per_block * ((H + 1) / 2) * 256 + (FUSE ? FUSE_LDS_BYTES : 0) + lds_pad;
     if constexpr (QUIRK)
-        hipLaunchKernelGGL((lcs_rows_kernel_quirk<H>), grid, dim3(256), lds, stream, a);
+        hipLaunchKernelGGL((lcs_rows_kernel_quirk<H, FUSE>), grid, dim3(256), lds, stream, a);
     else
-        hipLaunchKernelGGL((lcs_rows_kernel_pipe<H, RG, LCS_LOOKAHEAD>), grid, dim3(256), lds, stream, a);
+        hipLaunchKernelGGL((lcs_rows_kernel_pipe<H, RG, LCS_LOOKAHEAD, FUSE>), grid, dim3(256), lds, stream, a);
     return hipGetLastError();
 }
 
-hipError_t launch_rows(int h, bool quirk, const RowsArgs& a, int grid_x, int grid_y, hipStream_t stream)
+template <bool FUSE>
+static hipError_t launch_rows_t(int h, bool quirk, const RowsArgs& a, int grid_x, int grid_y, hipStream_t stream)
 {
     const dim3 grid((unsigned)grid_x, (unsigned)grid_y);
     if (quirk) {
         switch (h) {
-        case 8: return launch_one<8, 1, true>(a, grid, stream);
-        case 16: return launch_one<16, 1, true>(a, grid, stream);
-        case 32: return launch_one<32, 1, true>(a, grid, stream);
-        case 64: return launch_one<64, 1, true>(a, grid, stream);
+        case 8: return launch_one<8, 1, true, FUSE>(a, grid, stream);
+        case 16: return launch_one<16, 1, true, FUSE>(a, grid, stream);
+        case 32: return launch_one<32, 1, true, FUSE>(a, grid, stream);
+        case 64: return launch_one<64, 1, true, FUSE>(a, grid, stream);
         default: return hipErrorInvalidValue;
         }
     }
     switch (h) {
-#define LCS_CASE(B, G) case B: return launch_one<B, G, false>(a, grid, stream);
+#define LCS_CASE(B, G) case B: return launch_one<B, G, false, FUSE>(a, grid, stream);
         LCS_CASE(1, 4) LCS_CASE(2, 4) LCS_CASE(3, 4) LCS_CASE(4, 4) LCS_CASE(5, 4) LCS_CASE(6, 4)
         LCS_CASE(7, 4) LCS_CASE(8, 4) LCS_CASE(9, 4) LCS_CASE(10, 4) LCS_CASE(11, 4) LCS_CASE(12, 4)
         LCS_CASE(13, LCS_RG13) LCS_CASE(14, 4) LCS_CASE(15, 4) LCS_CASE(16, 4)
@@ -704,6 +899,43 @@ hipError_t launch_rows(int h, bool quirk, const RowsArgs& a, int grid_x, int gri
     }
 }
 
+template <bool FUSE>
+static hipError_t launch_long_t(bool quirk, const RowsArgs& a, int grid_x, int grid_y, void* carry, int n_chunks_max,
+                                hipStream_t stream)
+{
+    const dim3 grid((unsigned)grid_x, (unsigned)grid_y);
+    const size_t lds = (size_t)SEGW * 256 + (FUSE ? FUSE_LDS_BYTES : 0);
+    if (quirk)
+        hipLaunchKernelGGL((lcs_long_kernel<true, FUSE>), grid, dim3(256), lds, stream, a, (uint16_t*)carry, n_chunks_max);
+    else
+        hipLaunchKernelGGL((lcs_long_kernel<false, FUSE>), grid, dim3(256), lds, stream, a, (uint16_t*)carry, n_chunks_max);
+    return hipGetLastError();
+}
+
+// This source is compiled twice (csrc/Makefile): as the plain translation unit -- every kernel without the fold, the
+// host-side planning helpers -- and, with LCS_FUSED_TU, as the unit that holds the FUSE instantiations only.  Two
+// units compile (and get their register pass) side by side.
+#ifdef LCS_FUSED_TU
+const char* recolor_state_fused() { return LCSGPU_RECOLOR_STATE; }
+hipError_t launch_rows_fused(int h, bool quirk, const RowsArgs& a, int grid_x, int grid_y, hipStream_t stream)
+{
+    return launch_rows_t<true>(h, quirk, a, grid_x, grid_y, stream);
+}
+hipError_t launch_long_fused(bool quirk, const RowsArgs& a, int grid_x, int grid_y, void* carry, int n_chunks_max,
+                             hipStream_t stream)
+{
+    return launch_long_t<true>(quirk, a, grid_x, grid_y, carry, n_chunks_max, stream);
+}
+#else
+hipError_t launch_rows_fused(int h, bool quirk, const RowsArgs& a, int grid_x, int grid_y, hipStream_t stream);
+hipError_t launch_long_fused(bool quirk, const RowsArgs& a, int grid_x, int grid_y, void* carry, int n_chunks_max,
+                             hipStream_t stream);
+hipError_t launch_rows(int h, bool quirk, const RowsArgs& a, int grid_x, int grid_y, hipStream_t stream)
+{
+    if (a.fuse.on) return launch_rows_fused(h, quirk, a, grid_x, grid_y, stream);
+    return launch_rows_t<false>(h, quirk, a, grid_x, grid_y, stream);
+}
+
 size_t long_carry_bytes(int grid_x, int grid_y, int n_chunks_max)
 {
     return (size_t)grid_x * grid_y * (size_t)n_chunks_max * 256 * sizeof(uint16_t);
@@ -712,13 +944,9 @@ size_t long_carry_bytes(int grid_x, int grid_y, int n_chunks_max)
 hipError_t launch_long(bool quirk, const RowsArgs& a, int grid_x, int grid_y, void* carry, int n_chunks_max,
                        hipStream_t stream)
 {
-    const dim3 grid((unsigned)grid_x, (unsigned)grid_y);
-    const size_t lds = (size_t)SEGW * 256;
-    if (quirk)
-        hipLaunchKernelGGL(lcs_long_kernel<true>, grid, dim3(256), lds, stream, a, (uint16_t*)carry, n_chunks_max);
-    else
-        hipLaunchKernelGGL(lcs_long_kernel<false>, grid, dim3(256), lds, stream, a, (uint16_t*)carry, n_chunks_max);
-    return hipGetLastError();
+    if (a.fuse.on) return launch_long_fused(quirk, a, grid_x, grid_y, carry, n_chunks_max, stream);
+    return launch_long_t<false>(quirk, a, grid_x, grid_y, carry, n_chunks_max, stream);
 }
+#endif
 
 } // namespace lcsgpu

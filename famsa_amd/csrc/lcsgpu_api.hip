@@ -97,7 +97,10 @@ int reserve_big(lcsgpu_ctx* ctx, DevBuf& buf, size_t bytes, const char* what)
     if (bytes <= buf.cap) return LCSGPU_OK;
     if (hipSetDevice(ctx->device) != hipSuccess) return fail(LCSGPU_E_HIP, "hipSetDevice(%d) failed", ctx->device);
     size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && bytes > free_b + buf.cap)
+    const bool known = hipMemGetInfo(&free_b, &total_b) == hipSuccess;
+    if (const char* e = getenv("LCSGPU_FAKE_HBM_GB")) // tests: behave as if only this much device memory were free
+        free_b = std::min(free_b, (size_t)(atof(e) * 1e9));
+    if (known && bytes > free_b + buf.cap)
         return fail(LCSGPU_E_NOMEM, "%s needs %.1f GB of device memory, %.1f GB are free on device %d (of %.1f GB)", what,
                     bytes / 1e9, (free_b + buf.cap) / 1e9, ctx->device, total_b / 1e9);
     const hipError_t e = buf.reserve(bytes);
@@ -112,16 +115,22 @@ int reserve_big(lcsgpu_ctx* ctx, DevBuf& buf, size_t bytes, const char* what)
 // Core: plan + launch.  d_out is a device pointer.
 int run_rows(lcsgpu_ctx* ctx, Lane& L, int mode, const int32_t* ref_ids, int32_t ref_begin, int32_t n_refs,
              const int32_t* col_ids, int32_t col_begin, int32_t n_cols, void* d_out, int64_t ld,
-             int64_t out_offset, int elem_size, int64_t first_row)
+             int64_t out_offset, int elem_size, int64_t first_row, const lcsgpu::FuseArgs* fuse)
 {
     if (ctx->n < 0) return fail(LCSGPU_E_STATE, "no sequence set uploaded");
     if (elem_size != 2 && elem_size != 4) return fail(LCSGPU_E_INVALID, "elem_size must be 2 or 4");
+    if (fuse) {
+        if (mode != lcsgpu::MODE_TRIANGLE || ref_ids || col_ids || first_row != ref_begin)
+            return fail(LCSGPU_E_INVALID, "a fused launch covers contiguous rows of the triangle");
+        if (ctx->max_len > 65535) return fail(LCSGPU_E_UNSUPPORTED, "fused records hold 16-bit lengths");
+    }
     if (elem_size == 2 && ctx->max_len > 65535)
         return fail(LCSGPU_E_INVALID, "uint16 output needs all sequences <= 65535 residues");
     if (n_refs < 0 || n_cols < 0) return fail(LCSGPU_E_INVALID, "negative count");
     L.last_launches = 0;
     L.timing_valid = false;
     if (n_refs == 0 || n_cols == 0) return LCSGPU_OK;
+    if (!fuse && !d_out) return fail(LCSGPU_E_INVALID, "NULL output");
     if (!col_ids && (col_begin < 0 || (int64_t)col_begin + n_cols > ctx->n))
         return fail(LCSGPU_E_INVALID, "column range out of bounds");
     if (col_ids)
@@ -145,7 +154,7 @@ int run_rows(lcsgpu_ctx* ctx, Lane& L, int mode, const int32_t* ref_ids, int32_t
     for (size_t b = 0; b < buckets.size(); ++b) {
         // triangle: about half of the column blocks of a ref tile lie below the diagonal
         const long col_blocks = std::max<long>(1, ((long)n_cols + 255) / 256 / (mode == lcsgpu::MODE_TRIANGLE ? 2 : 1));
-        refs_per_wg[b] = lcsgpu::refs_per_block_for(buckets[b].bv, buckets[b].quirk, (long)buckets[b].items.size(), col_blocks);
+        refs_per_wg[b] = lcsgpu::refs_per_block_for(buckets[b].bv, buckets[b].quirk, (long)buckets[b].items.size(), col_blocks, fuse != nullptr);
         is_contig[b] = contiguous(buckets[b]);
         if (is_contig[b] && mode == lcsgpu::MODE_TRIANGLE && buckets[b].bv != 0) {
             // compact grid: only the workgroups at or below the diagonal, bottom row first
@@ -225,6 +234,10 @@ int run_rows(lcsgpu_ctx* ctx, Lane& L, int mode, const int32_t* ref_ids, int32_t
         a.out_offset = out_offset;
         a.elem_size = elem_size;
         a.mode = mode;
+        if (fuse) {
+            a.fuse = *fuse;
+            a.fuse.on = 1;
+        }
         a.refs_per_block = refs_per_wg[b];
         int32_t use_cols = n_cols;
         if (mode == lcsgpu::MODE_TRIANGLE) { // columns at or beyond the largest row are never wanted
@@ -306,7 +319,9 @@ extern "C" {
 
 const char* lcsgpu_version(void)
 {
-    static const std::string v = std::string("lcsgpu 0.3 gfx950 recolor=") + lcsgpu::recolor_state();
+    // both LCS translation units went through the register pass and its check, or the string says what did not
+    static const std::string a = lcsgpu::recolor_state(), b = lcsgpu::recolor_state_fused();
+    static const std::string v = std::string("lcsgpu 0.3 gfx950 recolor=") + (a == b ? a : (a == "failed" || b == "failed") ? "failed" : "off");
     return v.c_str();
 }
 const char* lcsgpu_last_error(void) { return g_err.c_str(); }

@@ -165,6 +165,10 @@ struct lcsgpu_ctx {
         int elem = 2;
         int32_t found = 0; // MST edges recorded so far
         int rounds = 0;
+        // how the local half of a round is done: by passes over the block's resident triangle (b.tri), or -- b.tri ==
+        // NULL -- by recomputing the block's LCS values with the fold fused into the launch (O(n) memory);
+        // fused_ready: the launch that filled b.tri has already done round 0's local half
+        bool fused_ready = false;
     } mst;
     double total_kernel_ms = 0; // completed host-memory calls
     // searches are spread over a few independent batches (each its own stream and driver): rounds of
@@ -269,9 +273,11 @@ int reserve_big(lcsgpu_ctx* ctx, DevBuf& buf, size_t bytes, const char* what);
 int order_edges_like_prim(lcsgpu_mst_edge* edges, int32_t n);
 
 // Core: plan + launch.  d_out is a device pointer.
+// fuse != NULL (triangle mode, contiguous rows and columns): the launches also fold their results into the
+// per-vertex best-edge records (lcs_kernels.h, FuseArgs); d_out may then be NULL (nothing is stored).
 int run_rows(lcsgpu_ctx* ctx, Lane& L, int mode, const int32_t* ref_ids, int32_t ref_begin, int32_t n_refs,
              const int32_t* col_ids, int32_t col_begin, int32_t n_cols, void* d_out, int64_t ld,
-             int64_t out_offset, int elem_size, int64_t first_row = 0);
+             int64_t out_offset, int elem_size, int64_t first_row = 0, const lcsgpu::FuseArgs* fuse = nullptr);
 // After a host-memory call has been synchronised: account its kernel time.
 void finish_host_call(lcsgpu_ctx* ctx, Lane& L);
 // A *_dev call was queued on lane 0: its timing is read on demand.

@@ -34,7 +34,24 @@ int lcsgpu_row_minima_dev(lcsgpu_ctx* ctx, const void* d_triangle, int elem_size
 
 // ---- the sharded MST (Boruvka over row blocks): state set-up shared by the single-context and the
 // multi-context entry points.  The caller holds lane 0.
-static int shard_begin(lcsgpu_ctx* ctx, Lane& L, const void* d_tri, int elem, int32_t r0, int32_t r1, int kind)
+// the block's LCS values with the local half of a Boruvka round folded into the launch (lcs_kernels.h, FuseArgs):
+// stored to d_out as well, or -- d_out NULL -- only folded
+static int fused_rows(lcsgpu_ctx* ctx, Lane& L, const lcsgpu::BoruvkaArgs& b, void* d_out, int elem, bool with_labels)
+{
+    HIP_TRY(lcsgpu::launch_boruvka_fuse_reset(b, L.stream));
+    lcsgpu::FuseArgs f{};
+    f.row_rec = b.fuse_row;
+    f.col_rec = b.fuse_col;
+    f.comp = with_labels ? b.comp : nullptr; // round 0: every vertex is its own component
+    f.pow_table = b.pow_table;
+    f.kind = b.kind;
+    return run_rows(ctx, L, lcsgpu::MODE_TRIANGLE, nullptr, b.r0, b.r1 - b.r0, nullptr, 0, std::max(0, b.r1 - 1), d_out, 0, b.off,
+                    elem, b.r0, &f);
+}
+
+// d_tri: the block's triangle in device memory, or NULL = none is kept (every round recomputes the block's LCS
+// values, O(n) memory).  compute: d_tri is to be FILLED here, by a launch that does round 0's local half as well.
+static int shard_begin(lcsgpu_ctx* ctx, Lane& L, void* d_tri, int elem, int32_t r0, int32_t r1, int kind, bool compute = false)
 {
     const int32_t n = ctx->n;
     auto a256 = [](size_t x) { return (x + 255) & ~(size_t)255; };
@@ -45,7 +62,8 @@ static int shard_begin(lcsgpu_ctx* ctx, Lane& L, const void* d_tri, int elem, in
     // 32: 15.4, 64: 14.1, 128: 13.7 (+0.5 fold), 256: 13.7 (+0.9), 512: 14.2 (+1.8) -> about 1024 rows per chunk
     int n_chunks = std::max(1, std::min(96, (rows + 1023) / 1024));
     if (const char* e = getenv("LCSGPU_MST_CHUNKS")) n_chunks = std::max(1, std::min(1024, atoi(e))); // measurement aid
-    const int rows_per_chunk = std::max(1, (rows + n_chunks - 1) / n_chunks);
+    if (!d_tri) n_chunks = 0; // no passes, no partials
+    const int rows_per_chunk = std::max(1, (rows + std::max(n_chunks, 1) - 1) / std::max(n_chunks, 1));
     const size_t key = sizeof(lcsgpu::MstKey);
     const size_t o_comp = 0, o_next = o_comp + a256((size_t)n * 4), o_par = o_next + a256((size_t)n * 4),
                  o_rb = o_par + a256((size_t)n * 4), o_best = o_rb + a256((size_t)n * key),
@@ -53,7 +71,8 @@ static int shard_begin(lcsgpu_ctx* ctx, Lane& L, const void* d_tri, int elem, in
                  o_ci = o_cd + a256((size_t)n * 8), o_part = o_ci + a256((size_t)n * 8),
                  o_edges = o_part + a256((size_t)n_chunks * n * key),
                  o_cnt = o_edges + a256((size_t)std::max(n - 1, 1) * sizeof(lcsgpu::MstEdge)), o_aux = o_cnt + 256,
-                 total = o_aux + a256((size_t)n * 8);
+                 o_frow = o_aux + a256((size_t)n * 8), o_fcol = o_frow + a256((size_t)n * 8),
+                 total = o_fcol + a256((size_t)n * 8);
     int rc = reserve_big(ctx, ctx->d_mst, total, "the MST state");
     if (rc) return rc;
     char* base = (char*)ctx->d_mst.p;
@@ -78,6 +97,8 @@ static int shard_begin(lcsgpu_ctx* ctx, Lane& L, const void* d_tri, int elem, in
     b.edges = (lcsgpu::MstEdge*)(base + o_edges);
     b.counters = (int32_t*)(base + o_cnt);
     b.row_aux = (uint2*)(base + o_aux);
+    b.fuse_row = (unsigned long long*)(base + o_frow);
+    b.fuse_col = (unsigned long long*)(base + o_fcol);
     b.minlen16 = ctx->minlen16();
     b.minlen1024 = ctx->minlen1024();
     b.n = n;
@@ -90,6 +111,15 @@ static int shard_begin(lcsgpu_ctx* ctx, Lane& L, const void* d_tri, int elem, in
     ctx->mst.elem = elem;
     ctx->mst.found = 0;
     ctx->mst.rounds = 0;
+    ctx->mst.fused_ready = false;
+    if (d_tri && compute) {
+        rc = fused_rows(ctx, L, b, d_tri, elem, false);
+        if (rc) {
+            ctx->mst.active = false;
+            return rc;
+        }
+        ctx->mst.fused_ready = true;
+    }
     return LCSGPU_OK;
 }
 
@@ -98,7 +128,14 @@ static int shard_best(lcsgpu_ctx* ctx, Lane& L, void* d_keys, lcsgpu_mst_key* h_
 {
     lcsgpu::BoruvkaArgs b = ctx->mst.b;
     if (d_keys) b.best = (lcsgpu::MstKey*)d_keys;
-    HIP_TRY(lcsgpu::launch_boruvka_best(b, ctx->mst.elem, L.stream));
+    if (!b.tri) { // nothing resident: this round's LCS values are computed now, the fold fused into the launch
+        int rc = fused_rows(ctx, L, b, nullptr, ctx->mst.elem, ctx->mst.rounds > 0);
+        if (rc) return rc;
+        HIP_TRY(lcsgpu::launch_boruvka_fuse_fold(b, L.stream));
+    } else if (ctx->mst.fused_ready && ctx->mst.rounds == 0) {
+        HIP_TRY(lcsgpu::launch_boruvka_fuse_fold(b, L.stream)); // the launch that filled the triangle did round 0
+    } else
+        HIP_TRY(lcsgpu::launch_boruvka_best(b, ctx->mst.elem, L.stream));
     if (h_keys) {
         HIP_TRY(hipMemcpyAsync(h_keys, b.best, (size_t)b.n * sizeof(lcsgpu::MstKey), hipMemcpyDeviceToHost, L.stream));
         HIP_TRY(hipStreamSynchronize(L.stream));
@@ -208,18 +245,22 @@ extern "C" {
 
 static bool valid_kind(int kind) { return kind == LCSGPU_DIST_INDEL_DIV_LCS || kind == LCSGPU_DIST_INDEL075_DIV_LCS; }
 
-int lcsgpu_mst_shard_begin(lcsgpu_ctx* ctx, const void* d_triangle, int elem_size, int32_t row_begin, int32_t row_end,
+int lcsgpu_mst_shard_begin(lcsgpu_ctx* ctx, void* d_triangle, int elem_size, int32_t row_begin, int32_t row_end,
                            int distance_kind)
 {
     const bool triangle_orientation = (distance_kind & LCSGPU_MST_TRIANGLE_ORIENTATION) != 0;
-    distance_kind &= ~LCSGPU_MST_TRIANGLE_ORIENTATION;
+    const bool compute = (distance_kind & LCSGPU_MST_COMPUTE) != 0;
+    distance_kind &= ~(LCSGPU_MST_TRIANGLE_ORIENTATION | LCSGPU_MST_COMPUTE);
     if (!ctx) return fail(LCSGPU_E_INVALID, "NULL ctx");
     if (ctx->n < 0) return fail(LCSGPU_E_STATE, "no sequence set uploaded");
     if (!valid_kind(distance_kind)) return fail(LCSGPU_E_INVALID, "unknown distance kind %d", distance_kind);
     if (row_begin < 0 || row_end < row_begin || row_end > ctx->n) return fail(LCSGPU_E_INVALID, "bad row range");
     if (elem_size != 2 && elem_size != 4) return fail(LCSGPU_E_INVALID, "elem_size must be 2 or 4");
-    if (!d_triangle && (int64_t)row_end * (row_end - 1) / 2 - (int64_t)row_begin * (row_begin - 1) / 2 > 0)
-        return fail(LCSGPU_E_INVALID, "NULL device pointer");
+    if (!d_triangle && !compute && (int64_t)row_end * (row_end - 1) / 2 - (int64_t)row_begin * (row_begin - 1) / 2 > 0)
+        return fail(LCSGPU_E_INVALID, "NULL device pointer (pass LCSGPU_MST_COMPUTE to run without a resident triangle)");
+    if (compute && ctx->max_len > 65535)
+        return fail(LCSGPU_E_UNSUPPORTED, "LCSGPU_MST_COMPUTE needs all sequences <= 65535 residues");
+    if (compute && elem_size != 2 && d_triangle) return fail(LCSGPU_E_INVALID, "LCSGPU_MST_COMPUTE fills a uint16 triangle");
     if (!triangle_orientation)
         for (int32_t i = 0; i < ctx->n; ++i)
             if (ctx->quirk[i])
@@ -227,7 +268,9 @@ int lcsgpu_mst_shard_begin(lcsgpu_ctx* ctx, const void* d_triangle, int elem_siz
                                                   "endpoint is the ref, the triangle does not hold them (use lcsgpu_mst_prim)", i);
     LaneGuard guard(ctx, LaneGuard::LANE0);
     HIP_TRY(hipSetDevice(ctx->device));
-    return shard_begin(ctx, guard.lane(), d_triangle, elem_size, row_begin, row_end, distance_kind);
+    int rc = shard_begin(ctx, guard.lane(), d_triangle, elem_size, row_begin, row_end, distance_kind, compute);
+    if (!rc && compute && d_triangle) note_async_call(ctx); // lcsgpu_last_kernel_ms: the fused LCS launch
+    return rc;
 }
 
 int lcsgpu_mst_shard_best(lcsgpu_ctx* ctx, void* d_keys, lcsgpu_mst_key* h_keys)
@@ -365,34 +408,34 @@ int lcsgpu_mst_prim(lcsgpu_ctx* ctx, int distance_kind, lcsgpu_mst_edge* out_edg
     HIP_TRY(hipSetDevice(ctx->device));
     const int elem = ctx->max_len > 65535 ? 4 : 2;
     const size_t pairs = (size_t)n * (n - 1) / 2;
-    int rc = reserve_big(ctx, L.d_out, pairs * elem, "the LCS triangle of the MST");
-    if (rc) return rc;
-    rc = run_rows(ctx, L, lcsgpu::MODE_TRIANGLE, nullptr, 0, n, nullptr, 0, n - 1, L.d_out.p, 0, 0, elem);
-    if (rc) return rc;
-
-    // orientation-sensitive sequences: their values in both roles, as side tables
-    std::vector<int32_t> qindex(n, -1), qlist;
-    for (int32_t i = 0; i < n && !triangle_orientation; ++i)
-        if (ctx->quirk[i]) {
-            qindex[i] = (int32_t)qlist.size();
-            qlist.push_back(i);
-        }
-    const int32_t nq = (int32_t)qlist.size();
-    if (nq) {
-        HIP_TRY(ctx->d_qrows.reserve((size_t)nq * n * 4));
-        HIP_TRY(ctx->d_qcols.reserve((size_t)nq * n * 4));
-        rc = run_rows(ctx, L, lcsgpu::MODE_RECT, qlist.data(), 0, nq, nullptr, 0, n, ctx->d_qrows.p, n, 0, 4);
-        if (rc) return rc;
-        HIP_TRY(hipStreamSynchronize(L.stream)); // the staging buffer of the plan is reused by the next call
-        L.plan_in_flight = false;
-        rc = run_rows(ctx, L, lcsgpu::MODE_RECT, nullptr, 0, n, qlist.data(), 0, nq, ctx->d_qcols.p, nq, 0, 4);
-        if (rc) return rc;
-    }
+    int32_t nq = 0;
+    for (int32_t i = 0; i < n && !triangle_orientation; ++i) nq += ctx->quirk[i] ? 1 : 0;
+    int rc;
 
     if ((triangle_orientation || nq == 0) && !getenv("LCSGPU_MST_PRIM")) {
-        // distances do not depend on which endpoint is the ref: Boruvka rounds over the triangle (one
-        // block = all rows, no exchange), then Prim's insertion order as a walk over the n-1 tree edges
-        rc = shard_begin(ctx, L, L.d_out.p, elem, 0, n, distance_kind);
+        // Distances do not depend on which endpoint is the ref: Boruvka rounds (one block = all rows, no exchange),
+        // then Prim's insertion order as a walk over the n-1 tree edges.  Where the rounds get their LCS values from:
+        //   fused     (default) the triangle is computed into HBM by a launch that does round 0's local half as well
+        //             (nothing but keys to read back for it); rounds >= 1 stream the resident triangle
+        //   recompute (when the triangle does not fit -- n > ~530 000 on 288 GB -- or on request) no triangle:
+        //             every round recomputes the LCS values with the fold fused into the launch; O(n) memory
+        //   passes    (on request; sets with a sequence beyond 65535 residues) plain launch, then passes for every round
+        // LCSGPU_MST_MODE=fused|recompute|passes overrides the choice (tests, measurements).
+        enum { AUTO, FUSED, RECOMPUTE, PASSES } mode = AUTO;
+        if (const char* e = getenv("LCSGPU_MST_MODE"))
+            mode = !strcmp(e, "fused") ? FUSED : !strcmp(e, "recompute") ? RECOMPUTE : !strcmp(e, "passes") ? PASSES : AUTO;
+        if (elem != 2) mode = PASSES;
+        bool resident = mode != RECOMPUTE;
+        if (resident) {
+            rc = reserve_big(ctx, L.d_out, pairs * elem, "the LCS triangle of the MST");
+            if (rc == LCSGPU_E_NOMEM && mode == AUTO) resident = false; // no room for 2 B per pair: O(n) memory instead
+            else if (rc) return rc;
+        }
+        if (resident && mode == PASSES) {
+            rc = run_rows(ctx, L, lcsgpu::MODE_TRIANGLE, nullptr, 0, n, nullptr, 0, n - 1, L.d_out.p, 0, 0, elem);
+            if (!rc) rc = shard_begin(ctx, L, L.d_out.p, elem, 0, n, distance_kind);
+        } else
+            rc = shard_begin(ctx, L, resident ? L.d_out.p : nullptr, elem, 0, n, distance_kind, true);
         while (!rc && ctx->mst.found < n - 1) {
             rc = shard_best(ctx, L, nullptr, nullptr);
             if (!rc) rc = shard_merge(ctx, L, nullptr, 1, nullptr);
@@ -402,6 +445,30 @@ int lcsgpu_mst_prim(lcsgpu_ctx* ctx, int distance_kind, lcsgpu_mst_edge* out_edg
         if (rc) return rc;
         note_async_call(ctx);
         return LCSGPU_OK;
+    }
+
+    // MSTPrim's own orientation with orientation-sensitive sequences in the set: the step-by-step kernel over the
+    // resident triangle, the sensitive sequences' values in both roles as side tables
+    rc = reserve_big(ctx, L.d_out, pairs * elem, "the LCS triangle of the MST");
+    if (rc) return rc;
+    rc = run_rows(ctx, L, lcsgpu::MODE_TRIANGLE, nullptr, 0, n, nullptr, 0, n - 1, L.d_out.p, 0, 0, elem);
+    if (rc) return rc;
+    std::vector<int32_t> qindex(n, -1), qlist;
+    for (int32_t i = 0; i < n && !triangle_orientation; ++i)
+        if (ctx->quirk[i]) {
+            qindex[i] = (int32_t)qlist.size();
+            qlist.push_back(i);
+        }
+    nq = (int32_t)qlist.size();
+    if (nq) {
+        HIP_TRY(ctx->d_qrows.reserve((size_t)nq * n * 4));
+        HIP_TRY(ctx->d_qcols.reserve((size_t)nq * n * 4));
+        rc = run_rows(ctx, L, lcsgpu::MODE_RECT, qlist.data(), 0, nq, nullptr, 0, n, ctx->d_qrows.p, n, 0, 4);
+        if (rc) return rc;
+        HIP_TRY(hipStreamSynchronize(L.stream)); // the staging buffer of the plan is reused by the next call
+        L.plan_in_flight = false;
+        rc = run_rows(ctx, L, lcsgpu::MODE_RECT, nullptr, 0, n, qlist.data(), 0, nq, ctx->d_qcols.p, nq, 0, 4);
+        if (rc) return rc;
     }
 
     const int blocks = (n + 255) / 256;
@@ -807,14 +874,24 @@ int lcsgpu_multi_mst_prim(lcsgpu_ctx* const* ctxs, int32_t n_ctx, int distance_k
         Lane& L = *g.lanes[k];
         const int32_t r0 = cut[k], r1 = cut[k + 1];
         const int64_t off = tri_offset(r0);
-        rc = reserve_big(ctxs[k], L.d_out, (size_t)std::max<int64_t>(tri_offset(r1) - off, 1) * elem, "a row block of the LCS triangle");
-        if (rc) return rc;
-        if (r1 > r0) {
-            rc = run_rows(ctxs[k], L, lcsgpu::MODE_TRIANGLE, nullptr, r0, r1 - r0, nullptr, 0, std::max(0, r1 - 1), L.d_out.p, 0, off, elem, r0);
-            if (rc) return rc;
+        // the block's triangle stays in this GPU's HBM when it fits (filled by a launch that does round 0's local half
+        // as well); else nothing is kept and every round recomputes the block (lcsgpu_mst_shard_begin, LCSGPU_MST_COMPUTE)
+        bool resident = !(getenv("LCSGPU_MST_MODE") && !strcmp(getenv("LCSGPU_MST_MODE"), "recompute") && elem == 2);
+        if (resident) {
+            rc = reserve_big(ctxs[k], L.d_out, (size_t)std::max<int64_t>(tri_offset(r1) - off, 1) * elem, "a row block of the LCS triangle");
+            if (rc == LCSGPU_E_NOMEM && elem == 2) resident = false;
+            else if (rc) return rc;
         }
         HIP_TRY(hipSetDevice(ctxs[k]->device));
-        rc = shard_begin(ctxs[k], L, L.d_out.p, elem, r0, r1, kind);
+        if (elem == 2)
+            rc = shard_begin(ctxs[k], L, resident ? L.d_out.p : nullptr, elem, r0, r1, kind, true);
+        else {
+            if (r1 > r0) {
+                rc = run_rows(ctxs[k], L, lcsgpu::MODE_TRIANGLE, nullptr, r0, r1 - r0, nullptr, 0, std::max(0, r1 - 1), L.d_out.p, 0, off, elem, r0);
+                if (rc) return rc;
+            }
+            rc = shard_begin(ctxs[k], L, L.d_out.p, elem, r0, r1, kind);
+        }
         if (rc) return rc;
         HIP_TRY(ctxs[k]->d_gather.reserve(2 * (size_t)n_ctx * key_bytes));
         for (int h = 0; h < 2; ++h) HIP_TRY(hipEventCreateWithFlags(&pushed[(size_t)h * n_ctx + k], hipEventDisableTiming));

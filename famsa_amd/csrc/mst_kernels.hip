@@ -441,6 +441,37 @@ __global__ __launch_bounds__(256) void boruvka_fold_kernel(BoruvkaArgs a)
     a.best[v] = MstKey{bd, bi};
 }
 
+// ---- the local half done by the LCS launch itself (lcs_kernels.hip, FuseArgs): reset / conversion of the records ----
+__global__ __launch_bounds__(256) void boruvka_fuse_reset_kernel(BoruvkaArgs a)
+{
+    const int v = blockIdx.x * 256 + threadIdx.x;
+    if (v >= a.n) return;
+    a.fuse_row[v] = ~0ull;
+    a.fuse_col[v] = ~0ull;
+}
+
+// (l, length of the other endpoint, other endpoint) -> MSTPrim's key, with the arithmetic of exact_update above
+__device__ __forceinline__ MstKey fuse_key(const BoruvkaArgs& a, unsigned long long rec, int v)
+{
+    if (rec == ~0ull) return MstKey{NO_D, NO_ID};
+    const uint32_t l = (uint32_t)(rec >> 48), u = (uint32_t)rec;
+    const uint32_t indel = a.lens[v] + a.lens[u] - 2u * l;
+    double d;
+    if (l == 0) d = 1.7976931348623155e308;
+    else if (a.kind == 1) d = a.pow_table[indel] / (double)l;
+    else d = (double)indel / (double)l;
+    const uint32_t lo = u < (uint32_t)v ? u : (uint32_t)v, hi = u < (uint32_t)v ? (uint32_t)v : u;
+    return MstKey{(unsigned long long)__double_as_longlong(d), ~(((unsigned long long)lo << 32) + hi)};
+}
+
+__global__ __launch_bounds__(256) void boruvka_fuse_fold_kernel(BoruvkaArgs a)
+{
+    const int v = blockIdx.x * 256 + threadIdx.x;
+    if (v >= a.n) return;
+    const MstKey r = fuse_key(a, a.fuse_row[v], v), c = fuse_key(a, a.fuse_col[v], v);
+    a.best[v] = key_less(c.d, c.id, r.d, r.id) ? c : r;
+}
+
 __global__ __launch_bounds__(256) void boruvka_reset_kernel(BoruvkaArgs a)
 {
     const int v = blockIdx.x * 256 + threadIdx.x;
@@ -563,6 +594,18 @@ hipError_t launch_boruvka_best(const BoruvkaArgs& a, int elem_size, hipStream_t 
 #undef MST_PASSES
     }
     hipLaunchKernelGGL(boruvka_fold_kernel, per_vertex, threads, 0, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_boruvka_fuse_reset(const BoruvkaArgs& a, hipStream_t stream)
+{
+    hipLaunchKernelGGL(boruvka_fuse_reset_kernel, dim3((a.n + 255) / 256), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_boruvka_fuse_fold(const BoruvkaArgs& a, hipStream_t stream)
+{
+    hipLaunchKernelGGL(boruvka_fuse_fold_kernel, dim3((a.n + 255) / 256), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 

@@ -87,6 +87,7 @@ def load_library():
 MST_EDGE = np.dtype([("from", np.int32), ("to", np.int32), ("dist", np.float64)])  # lcsgpu_mst_edge
 MST_KEY = np.dtype([("dist_bits", np.uint64), ("id", np.uint64)])                  # lcsgpu_mst_key
 MST_TRIANGLE_ORIENTATION = 0x100
+MST_COMPUTE = 0x200  # lcsgpu_mst_shard_begin: the LCS launch itself does the local half (see include/lcsgpu.h)
 
 
 def mst_merge_host(keys, comp, edges, n_edges):
@@ -245,7 +246,10 @@ class LcsGpu:
 
     # ---- sharded MST (Boruvka over row blocks; one context per GPU) ----
     def mst_shard_begin(self, d_tri_ptr, elem_size, row_begin, row_end, kind=1):
-        self._check(self._lib.lcsgpu_mst_shard_begin(self._ctx, C.c_void_p(d_tri_ptr), elem_size, row_begin, row_end, kind))
+        """kind may carry MST_TRIANGLE_ORIENTATION and MST_COMPUTE (d_tri_ptr is then an output, or None = no
+        triangle is kept and every round recomputes the block)."""
+        self._check(self._lib.lcsgpu_mst_shard_begin(self._ctx, C.c_void_p(d_tri_ptr) if d_tri_ptr else None, elem_size,
+                                                     row_begin, row_end, kind))
 
     def mst_shard_best(self, d_keys_ptr=None, host=False):
         """Local half of a round into device memory (d_keys_ptr) and/or a host array (returned when host=True)."""

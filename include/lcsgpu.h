@@ -208,8 +208,23 @@ typedef struct lcsgpu_mst_key {
 
 /* d_triangle: DEVICE memory holding rows [row_begin, row_end) as lcsgpu_lcs_triangle_dev wrote them; it must
  * stay valid until the last lcsgpu_mst_shard_best.  Resets the component state (every vertex on its own).
- * distance_kind may carry LCSGPU_MST_TRIANGLE_ORIENTATION. */
-int lcsgpu_mst_shard_begin(lcsgpu_ctx* ctx, const void* d_triangle, int elem_size, int32_t row_begin, int32_t row_end,
+ * distance_kind may carry LCSGPU_MST_TRIANGLE_ORIENTATION and LCSGPU_MST_COMPUTE.
+ *
+ * LCSGPU_MST_COMPUTE -- the local half of a round FUSED into the LCS launch: the workgroup that holds LCS(row, 256
+ * columns) in registers folds it into every vertex's best edge into another component before (or instead of)
+ * storing it -- an integer pre-filter on the LCS length, the exact key (Transform<double> + MSTPrim's id order) for
+ * survivors only, per-vertex 64-bit records updated by compare-and-swap -- so nothing but n x 16 B of keys leaves
+ * the launch: "each GPU reduces its row block to per-row minima, then the ranks all-gather them".
+ *   d_triangle != NULL: it is an OUTPUT (uint16, elem_size 2): this call computes rows [row_begin, row_end) into it as
+ *     lcsgpu_lcs_triangle_dev would (lcsgpu_last_kernel_ms times that launch) AND round 0's local half in the same
+ *     launch; later rounds read the resident triangle.
+ *   d_triangle == NULL: NO triangle is kept: every lcsgpu_mst_shard_best recomputes the block's LCS values with the
+ *     fold fused in.  O(n) device memory like the reference's MSTPrim (tree/MSTPrim.cpp:450-512), at the price of
+ *     one LCS pass per round (<= log2 n rounds; 7 at n = 100 000) -- what lifts the n <= ~530 000 limit of a
+ *     2-byte-per-pair triangle in 288 GB.
+ * Needs every sequence <= 65535 residues (LCSGPU_E_UNSUPPORTED otherwise). */
+#define LCSGPU_MST_COMPUTE 0x200
+int lcsgpu_mst_shard_begin(lcsgpu_ctx* ctx, void* d_triangle, int elem_size, int32_t row_begin, int32_t row_end,
                            int distance_kind);
 /* Local half of a round.  d_keys: DEVICE buffer of n lcsgpu_mst_key (NULL = a buffer of the context);
  * h_keys: if not NULL, the keys are also copied to this HOST buffer and the call returns when they are

@@ -1,0 +1,177 @@
+"""The local half of a Boruvka round FUSED into the LCS launch (include/lcsgpu.h, LCSGPU_MST_COMPUTE;
+lcs_kernels.hip, FuseArgs): the workgroup that holds LCS(row, 256 columns) in registers folds it into every vertex's
+best edge before (or instead of) storing it.  Three ways to the same tree, which must agree bit for bit --
+  passes     the triangle in HBM, every round by the streaming passes (round 2's form),
+  fused      the triangle in HBM, round 0 done by the launch that fills it,
+  recompute  NO triangle (O(n) memory, what lifts the n <= ~530 000 limit): every round recomputes the LCS values --
+on the shapes that stress the record / filter logic: ties everywhere, variable lengths over several half-word
+classes, orientation-sensitive refs (the quirk kernels) in the triangle orientation, refs beyond 2048 residues (the
+long kernel), empty sequences, LCS-0 pairs, row-block shards."""
+import hashlib
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import famsa_amd
+from famsa_amd import seqio
+from famsa_amd.hostlib import CLI
+from famsa_amd.lcsgpu import MST_COMPUTE, MST_TRIANGLE_ORIENTATION
+from famsa_amd.rowblock import row_cuts, pairs_in_rows
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+META_LARGE = json.load(open(os.path.join(G, "meta_large.json")))
+
+
+def same(a, b):
+    return (a["from"] == b["from"]).all() and (a["to"] == b["to"]).all() and \
+        (a["dist"].view(np.uint64) == b["dist"].view(np.uint64)).all()
+
+
+def _sets():
+    rng = np.random.Generator(np.random.PCG64(17))
+    out = {}
+    out["ties"] = [rng.integers(0, 3, size=int(rng.integers(4, 14))).astype(np.uint8) for _ in range(1500)]
+    out["family"] = seqio.synth_family(3000, 150, seed=5)
+    # several half-word classes in one set (lengths 20 .. 700), working order (length descending) and shuffled
+    mixed = [rng.integers(0, 20, size=int(l)).astype(np.uint8) for l in rng.integers(20, 700, size=1200)]
+    out["mixed_sorted"] = [mixed[i] for i in seqio.sort_order(mixed)]
+    out["mixed_shuffled"] = mixed
+    # orientation-sensitive refs (an aligned 64-residue homopolymer word at word index >= 1), empty and all-X sequences
+    quirk = [np.zeros(192, np.uint8), np.full(130, 3, np.uint8), np.zeros(0, np.uint8), np.full(9, 22, np.uint8)]
+    quirk += [np.concatenate([rng.integers(0, 20, size=64), np.full(64, 7), rng.integers(0, 20, size=int(k))]).astype(np.uint8)
+              for k in rng.integers(0, 90, size=40)]
+    out["quirk"] = quirk + seqio.synth_family(500, 120, seed=9)
+    # refs beyond 2048 residues next to short ones
+    out["long"] = [rng.integers(0, 20, size=int(l)).astype(np.uint8) for l in [2100, 3000, 2500, 2049, 4200] * 4] + \
+        seqio.synth_family(300, 200, seed=2)
+    return out
+
+
+@pytest.mark.parametrize("name", ["ties", "family", "mixed_sorted", "mixed_shuffled", "quirk", "long"])
+def test_three_ways_to_the_same_tree(engine, monkeypatch, name):
+    seqs = _sets()[name]
+    engine.upload_seqs(seqs)
+    kinds = [1 | MST_TRIANGLE_ORIENTATION, 0 | MST_TRIANGLE_ORIENTATION]
+    if name not in ("quirk",):
+        kinds.append(1)  # MSTPrim's own orientation (no orientation-sensitive sequence in these sets)
+    for kind in kinds:
+        monkeypatch.setenv("LCSGPU_MST_MODE", "passes")
+        want = engine.mst_prim(kind)
+        for mode in ("fused", "recompute"):
+            monkeypatch.setenv("LCSGPU_MST_MODE", mode)
+            got = engine.mst_prim(kind)
+            assert same(got, want), (name, kind, mode)
+    monkeypatch.delenv("LCSGPU_MST_MODE")
+    assert same(engine.mst_prim(kinds[0]), engine.mst_prim(kinds[0]))
+
+
+def test_no_room_for_the_triangle_means_recompute(engine, monkeypatch):
+    """The automatic choice: when 2 B per pair do not fit the free device memory, lcsgpu_mst_prim keeps no triangle."""
+    seqs = _sets()["family"]
+    engine.upload_seqs(seqs)
+    want = engine.mst_prim(1)
+    probe = famsa_amd.LcsGpu(0)  # a fresh context: no result buffer of an earlier call that would already fit
+    try:
+        probe.upload_seqs(seqs)
+        monkeypatch.setenv("LCSGPU_FAKE_HBM_GB", "0.001")  # 1 MB "free": the 9 MB triangle does not fit
+        assert same(probe.mst_prim(1), want)
+        with pytest.raises(famsa_amd.LcsGpuError, match="device memory"):
+            probe.upgma(1)  # the matrix consumers do need their triangle: a clean LCSGPU_E_NOMEM
+    finally:
+        probe.close()
+
+
+@pytest.mark.parametrize("parts", [2, 3])
+@pytest.mark.parametrize("resident", [True, False])
+def test_row_block_shards_with_the_fold_in_the_launch(engine, parts, resident):
+    """lcsgpu_mst_shard_begin with LCSGPU_MST_COMPUTE: `parts` contexts over disjoint row blocks -- the triangle of a
+    block filled by the fused launch (resident) or never stored (recompute) -- keys exchanged in device memory."""
+    import torch
+    seqs = _sets()["mixed_sorted"]
+    engine.upload_seqs(seqs)
+    want = engine.mst_prim(1)
+    n = len(seqs)
+    cuts = row_cuts(n, parts)
+    engs, tris = [], []
+    try:
+        for p in range(parts):
+            e = famsa_amd.LcsGpu(0)
+            e.upload_seqs(seqs)
+            t = torch.empty(max(pairs_in_rows(cuts[p], cuts[p + 1]), 1), dtype=torch.int16, device="cuda:0") if resident else None
+            engs.append(e)
+            tris.append(t)
+        torch.cuda.synchronize()
+        for p, e in enumerate(engs):
+            e.mst_shard_begin(tris[p].data_ptr() if resident else None, 2, cuts[p], cuts[p + 1], 1 | MST_COMPUTE)
+        keys = [torch.zeros(2 * n, dtype=torch.int64, device="cuda:0") for _ in engs]
+        torch.cuda.synchronize()
+        found, rounds = 0, 0
+        while found < n - 1:
+            assert rounds < 40
+            for e, k in zip(engs, keys):
+                e.mst_shard_best(k.data_ptr())
+            for e in engs:
+                e.sync()
+            gathered = torch.cat(keys)
+            torch.cuda.synchronize()
+            found = [e.mst_shard_merge(gathered.data_ptr(), parts) for e in engs][0]
+            rounds += 1
+        for e in engs:
+            assert same(e.mst_shard_finish(), want)
+        if resident:  # the fused launch stored the block's triangle as lcsgpu_lcs_triangle_dev does
+            for p in range(parts):
+                got = tris[p].cpu().numpy().view(np.uint16)[: pairs_in_rows(cuts[p], cuts[p + 1])]
+                assert (got == engine.lcs_triangle(cuts[p], cuts[p + 1])).all()
+    finally:
+        for e in engs:
+            e.close()
+
+
+def test_group_call_without_triangles(engine, monkeypatch):
+    """lcsgpu_multi_mst_prim with every context in recompute mode (what N GPUs do beyond ~1.5 M sequences)."""
+    seqs = _sets()["family"]
+    engine.upload_seqs(seqs)
+    want = engine.mst_prim(1)
+    grp = famsa_amd.LcsGpuGroup([0, 0, 0])
+    try:
+        grp.upload_seqs(seqs)
+        monkeypatch.setenv("LCSGPU_MST_MODE", "recompute")
+        assert same(grp.mst_prim(1), want)
+    finally:
+        grp.close()
+
+
+def _cli(*args, env=None):
+    e = dict(os.environ)
+    e.update(env or {})
+    p = subprocess.run([CLI, *args], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=e)
+    assert p.returncode == 0, p.stderr[-2000:]
+    return p
+
+
+@pytest.mark.parametrize("mode", ["fused", "recompute"])
+@pytest.mark.parametrize("gt", ["sl", "slink"])
+@pytest.mark.parametrize("case", ["adeno_fiber/adeno_fiber", "hemopexin/hemopexin", "adversarial_tree.fasta"])
+def test_cli_goldens_in_both_modes(tmp_path, case, gt, mode):
+    gold = {"adeno_fiber/adeno_fiber": f"adeno_fiber/{gt}.dnd", "adversarial_tree.fasta": f"adversarial_tree_{gt}.dnd",
+            "hemopexin/hemopexin": f"hemopexin/{gt}.dnd"}[case]
+    out = str(tmp_path / "t.dnd")
+    _cli("-gt", gt, "-gt_export", os.path.join(G, case), out, env={"LCSGPU_MST_MODE": mode})
+    assert open(out, "rb").read() == open(os.path.join(G, gold), "rb").read()
+
+
+def test_c4_without_a_triangle(tmp_path):
+    """BASELINE config C4 (100 000 x 400 aa) with O(n) device memory: 7 rounds, each a full LCS pass with the fold
+    fused in, nothing stored; the Newick must be the reference's (tests/golden/meta_large.json)."""
+    codes, offsets = seqio.synth_uniform(100000, 400)
+    path = str(tmp_path / "synth100k.fasta")
+    seqio.to_fasta(codes, offsets, path)
+    out = str(tmp_path / "sl.dnd")
+    p = _cli("-v", "-gt", "sl", "-gt_export", path, out, env={"LCSGPU_MST_MODE": "recompute"})
+    h = hashlib.sha256(open(out, "rb").read()).hexdigest()
+    assert h == META_LARGE["synth100k"]["sl_newick_sha256"], p.stderr

@@ -15,15 +15,16 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "famsa_amd", "csrc")
 DEV_S = os.path.join(CSRC, "_obj", "lcs_kernels.dev.s")
+DEV_S_FUSED = os.path.join(CSRC, "_obj", "lcs_kernels_fused.dev.s")  # the second translation unit: FUSE instantiations
 sys.path.insert(0, CSRC)
 
 import recolor_check as RC  # the interpreter lives with the build: it is a build step (csrc/Makefile)
 
-KERNELS = ["_ZN6lcsgpu20lcs_rows_kernel_pipeILi13ELi4ELi4EEEvNS_8RowsArgsE",   # the bench kernel (400 aa)
-           "_ZN6lcsgpu20lcs_rows_kernel_pipeILi4ELi4ELi4EEEvNS_8RowsArgsE",    # short refs: partial last chunk
-           "_ZN6lcsgpu20lcs_rows_kernel_pipeILi25ELi2ELi4EEEvNS_8RowsArgsE",
-           "_ZN6lcsgpu20lcs_rows_kernel_pipeILi40ELi1ELi4EEEvNS_8RowsArgsE",
-           "_ZN6lcsgpu15lcs_long_kernelILb0EEEvNS_8RowsArgsEPti"]
+KERNELS = ["_ZN6lcsgpu20lcs_rows_kernel_pipeILi13ELi4ELi4ELb0EEEvNS_8RowsArgsE",   # the bench kernel (400 aa)
+           "_ZN6lcsgpu20lcs_rows_kernel_pipeILi4ELi4ELi4ELb0EEEvNS_8RowsArgsE",    # short refs: partial last chunk
+           "_ZN6lcsgpu20lcs_rows_kernel_pipeILi25ELi2ELi4ELb0EEEvNS_8RowsArgsE",
+           "_ZN6lcsgpu20lcs_rows_kernel_pipeILi40ELi1ELi4ELb0EEEvNS_8RowsArgsE",
+           "_ZN6lcsgpu15lcs_long_kernelILb0ELb0EEEvNS_8RowsArgsEPti"]
 
 
 def _all_kernels():
@@ -59,6 +60,22 @@ def test_loop_bodies_compute_the_same(recolored, kernel):
     checked, err = RC.check_kernel(old_all, new_all, kernel, perm, trials=3 if kernel in KERNELS else 1)
     assert err is None, (kernel, err)
     assert checked >= 1
+
+
+def test_fused_unit_loop_bodies_compute_the_same(tmp_path):
+    """The same check for the translation unit of the fused instantiations (the build runs it on all of them;
+    here: the 13- and 4-half-word kernels and the long-ref kernel)."""
+    if not os.path.exists(DEV_S_FUSED):
+        pytest.skip("famsa_amd/csrc/_obj/lcs_kernels_fused.dev.s is made by the build (make -C famsa_amd/csrc)")
+    out, mp = str(tmp_path / "rec.s"), str(tmp_path / "map.json")
+    only = "lcs_rows_kernel_pipeILi13ELi4|lcs_rows_kernel_pipeILi4ELi4|lcs_long_kernelILb0"
+    subprocess.check_call([sys.executable, os.path.join(CSRC, "recolor_vgprs.py"), DEV_S_FUSED, out, "--only", only, "--map", mp],
+                          stdout=subprocess.DEVNULL)
+    old_all, new_all, maps = open(DEV_S_FUSED).read().split("\n"), open(out).read().split("\n"), json.load(open(mp))
+    assert len(maps) == 3 and RC.renaming_only(old_all, new_all) is None
+    for kernel, m in maps.items():
+        checked, err = RC.check_kernel(old_all, new_all, kernel, {int(k): v for k, v in m.items()})
+        assert err is None and checked >= 1, (kernel, err)
 
 
 def test_pass_is_a_renaming_only(recolored):
@@ -103,7 +120,7 @@ def test_build_fails_closed(tmp_path):
     obj = str(tmp_path / "obj")
     os.makedirs(obj)
     shutil.copy(DEV_S, os.path.join(obj, "lcs_kernels.dev.s"))
-    final, state = os.path.join(obj, "lcs_kernels.final.s"), os.path.join(obj, "recolor.state")
+    final, state = os.path.join(obj, "lcs_kernels.final.s"), os.path.join(obj, "lcs_kernels.recolor.state")
     dev_text = open(DEV_S).read()
 
     p = _make(obj, "RECOLOR=0", final)
