@@ -147,6 +147,11 @@ def main():
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--emulate-ranks-on-one-gpu", action="store_true",
                     help="functional test of the N>1 path on a 1-GPU box: all ranks use cuda:0, gloo exchange")
+    ap.add_argument("--mst-mode", choices=["fused", "passes"], default="passes",
+                    help="passes (default): plain LCS launch, every Boruvka round streams the resident triangle; "
+                         "fused: the LCS launch does round 0's local half on the values it holds in registers "
+                         "(lcsgpu_mst_shard_begin, LCSGPU_MST_COMPUTE) -- measured slower by 16 ms per step at 100 000 x "
+                         "400 aa (the fold's registers cost the launch more than the saved passes), kept for A/B runs")
     ap.add_argument("--force-collective", action="store_true",
                     help="with one rank: initialise the nccl (RCCL) backend anyway and run the real "
                          "all_gather_into_tensor + stream hand-off every Boruvka round, as the N>1 path does")
@@ -156,6 +161,7 @@ def main():
     import famsa_amd
     from famsa_amd import seqio
     from famsa_amd.rowblock import row_cuts, pairs_in_rows, sharded_mst_device, edge_list_sha256
+    from famsa_amd.lcsgpu import MST_COMPUTE
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -222,13 +228,19 @@ def main():
         if "unordered" in last:
             last["edges"] = mst_order_edges(last.pop("unordered"), n)
 
+    fused = args.mst_mode == "fused"
+
     def step():
-        eng.lcs_triangle_dev(r0, r1, tri.data_ptr(), 2)
+        if fused:  # one launch: LCS values -> uint16 triangle in HBM + every vertex's best edge (round 0's local half)
+            eng.mst_shard_begin(tri.data_ptr(), 2, r0, r1, 1 | MST_COMPUTE)
+        else:
+            eng.lcs_triangle_dev(r0, r1, tri.data_ptr(), 2)
         finish_previous()
         ms, _ = eng.last_kernel_ms()  # HIP events on the engine's stream, around the LCS launch (waits for it)
         kernel_ms.append(ms)
         t0 = time.perf_counter()
-        edges, rounds = sharded_mst_device(eng, tri.data_ptr(), 2, r0, r1, 1, keys, gathered, all_gather, ordered=False)
+        edges, rounds = sharded_mst_device(eng, tri.data_ptr(), 2, r0, r1, 1, keys, gathered, all_gather, ordered=False,
+                                           begun=fused)
         mst_ms.append((time.perf_counter() - t0) * 1e3)
         last["unordered"], last["rounds"] = edges, rounds
 
@@ -300,7 +312,7 @@ def main():
                 "exchange": ("gloo (host memory)" if emulate else "nccl = RCCL (device memory)") if collective else "none (one block)",
             },
             "pairs_per_s": total_pairs * args.steps / elapsed,
-            "mst": {"n_edges": int(len(edges)), "rounds": int(last["rounds"]), "edges_sha256": edges_hash,
+            "mst": {"mode": args.mst_mode, "n_edges": int(len(edges)), "rounds": int(last["rounds"]), "edges_sha256": edges_hash,
                     "ms_per_step": float(np.mean(mst_ms)), "exchange_bytes_per_rank_per_round": 16 * n},
             "parity": {"sampled_pairs": int(sampled), "mismatches": int(bad),
                        "checker": "oracle/lcs_oracle.c on a sample of the triangle the last timed step left in HBM"},
@@ -311,7 +323,7 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": None,  # HBM-side bytes come from the separate PMC passes under profiles/, not from this run
-                "kernel": f"lcsgpu::lcs_rows_kernel_pipe<{H}, {4 if H <= 16 else 2 if H <= 32 else 1}, 4>",
+                "kernel": f"lcsgpu::lcs_rows_kernel_pipe<{H}, {4 if H <= 16 else 2 if H <= 32 else 1}, 4, {'true' if fused else 'false'}>",
                 "kernel_ms": k_ms,
                 "algorithmic_bytes_per_pair": L + ALGO_BYTES_PER_PAIR_EXTRA,
                 "pairs_per_launch": my_pairs,

@@ -92,6 +92,17 @@ int ensure_batcher(lcsgpu_ctx* ctx, ClaransBatcher& B)
     return LCSGPU_OK;
 }
 
+// free device memory as reserve_big sees it (LCSGPU_FAKE_HBM_GB included)
+int device_free_bytes(lcsgpu_ctx* ctx, size_t* out)
+{
+    if (hipSetDevice(ctx->device) != hipSuccess) return fail(LCSGPU_E_HIP, "hipSetDevice(%d) failed", ctx->device);
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    if (const char* e = getenv("LCSGPU_FAKE_HBM_GB")) free_b = std::min(free_b, (size_t)(atof(e) * 1e9));
+    *out = free_b;
+    return LCSGPU_OK;
+}
+
 int reserve_big(lcsgpu_ctx* ctx, DevBuf& buf, size_t bytes, const char* what)
 {
     if (bytes <= buf.cap) return LCSGPU_OK;

@@ -269,6 +269,7 @@ private:
 
 // Reserve a large device buffer, reporting LCSGPU_E_NOMEM (not a HIP error) when it cannot fit.
 int reserve_big(lcsgpu_ctx* ctx, DevBuf& buf, size_t bytes, const char* what);
+int device_free_bytes(lcsgpu_ctx* ctx, size_t* out); // as reserve_big sees it (LCSGPU_FAKE_HBM_GB included)
 // The n-1 tree edges in the order Prim's algorithm adds them from vertex 0 (host; in place).
 int order_edges_like_prim(lcsgpu_mst_edge* edges, int32_t n);
 

@@ -7,6 +7,8 @@
 
 using namespace lcsgpu_impl;
 
+static int64_t tri_offset(int64_t r) { return r * (r - 1) / 2; }
+
 extern "C" {
 
 int lcsgpu_row_minima_dev(lcsgpu_ctx* ctx, const void* d_triangle, int elem_size, int32_t row_begin,
@@ -415,30 +417,74 @@ int lcsgpu_mst_prim(lcsgpu_ctx* ctx, int distance_kind, lcsgpu_mst_edge* out_edg
     if ((triangle_orientation || nq == 0) && !getenv("LCSGPU_MST_PRIM")) {
         // Distances do not depend on which endpoint is the ref: Boruvka rounds (one block = all rows, no exchange),
         // then Prim's insertion order as a walk over the n-1 tree edges.  Where the rounds get their LCS values from:
-        //   fused     (default) the triangle is computed into HBM by a launch that does round 0's local half as well
-        //             (nothing but keys to read back for it); rounds >= 1 stream the resident triangle
-        //   recompute (when the triangle does not fit -- n > ~530 000 on 288 GB -- or on request) no triangle:
-        //             every round recomputes the LCS values with the fold fused into the launch; O(n) memory
-        //   passes    (on request; sets with a sequence beyond 65535 residues) plain launch, then passes for every round
-        // LCSGPU_MST_MODE=fused|recompute|passes overrides the choice (tests, measurements).
+        //   passes    (default while the triangle fits) the triangle is computed into HBM, every round streams it
+        //   recompute (when it does not fit -- n > ~530 000 on 288 GB -- or on request) no triangle: every round
+        //             recomputes the LCS values with the fold fused into the launch; O(n) device memory
+        //   fused     (on request) the triangle is computed by a launch that does round 0's local half as well.
+        //             Measured at 100 000 x 400 aa: the fold's 5 extra registers leave the 13-half-word kernel's
+        //             register pass no free seat (174 instead of 28 of its 1040 three-source ops keep a shared bank)
+        //             -- LCS launch 1318 -> 1338 ms for 4 ms of passes saved -- so it is not the default.
+        // LCSGPU_MST_MODE=passes|fused|recompute overrides the choice (tests, measurements).
         enum { AUTO, FUSED, RECOMPUTE, PASSES } mode = AUTO;
         if (const char* e = getenv("LCSGPU_MST_MODE"))
             mode = !strcmp(e, "fused") ? FUSED : !strcmp(e, "recompute") ? RECOMPUTE : !strcmp(e, "passes") ? PASSES : AUTO;
         if (elem != 2) mode = PASSES;
-        bool resident = mode != RECOMPUTE;
-        if (resident) {
+        // rows [0, r_fit) of the triangle are kept in HBM, rows [r_fit, n) are recomputed every round
+        int32_t r_fit = mode == RECOMPUTE ? 0 : n;
+        if (r_fit == n) {
             rc = reserve_big(ctx, L.d_out, pairs * elem, "the LCS triangle of the MST");
-            if (rc == LCSGPU_E_NOMEM && mode == AUTO) resident = false; // no room for 2 B per pair: O(n) memory instead
-            else if (rc) return rc;
+            if (rc == LCSGPU_E_NOMEM && mode == AUTO) {
+                // No room for 2 B per pair.  Keep the rows that do fit -- every round then recomputes only the rest
+                // (at 600 000 sequences on 288 GB: the last 80 000 rows, a quarter of the pairs) -- or, when that would
+                // be less than a quarter of the rows, nothing at all.
+                size_t free_b = 0;
+                if (int rc2 = device_free_bytes(ctx, &free_b)) return rc2;
+                free_b += L.d_out.cap;
+                const size_t keep_free = (size_t)n * 256 + std::min<size_t>((size_t)1 << 30, free_b / 16); // MST state, plans, slack
+                const double usable = free_b > keep_free ? (double)(free_b - keep_free) : 0.0;
+                r_fit = (int32_t)std::min<double>(n, std::floor(0.5 + std::sqrt(0.25 + 2.0 * usable / elem)));
+                if (r_fit < n / 4) r_fit = 0;
+                while (r_fit > 0 && reserve_big(ctx, L.d_out, (size_t)tri_offset(r_fit) * elem, "the resident rows of the LCS triangle"))
+                    r_fit = r_fit * 15 / 16 < n / 4 ? 0 : r_fit * 15 / 16;
+            } else if (rc)
+                return rc;
         }
-        if (resident && mode == PASSES) {
+        if (r_fit == n && mode != FUSED) {
             rc = run_rows(ctx, L, lcsgpu::MODE_TRIANGLE, nullptr, 0, n, nullptr, 0, n - 1, L.d_out.p, 0, 0, elem);
             if (!rc) rc = shard_begin(ctx, L, L.d_out.p, elem, 0, n, distance_kind);
-        } else
-            rc = shard_begin(ctx, L, resident ? L.d_out.p : nullptr, elem, 0, n, distance_kind, true);
+        } else if (r_fit == n || r_fit == 0)
+            rc = shard_begin(ctx, L, r_fit ? L.d_out.p : nullptr, elem, 0, n, distance_kind, true);
+        else {
+            rc = run_rows(ctx, L, lcsgpu::MODE_TRIANGLE, nullptr, 0, r_fit, nullptr, 0, r_fit - 1, L.d_out.p, 0, 0, elem);
+            if (!rc) rc = shard_begin(ctx, L, L.d_out.p, elem, 0, r_fit, distance_kind);
+            if (!rc) HIP_TRY(ctx->d_gather.reserve(2 * (size_t)n * sizeof(lcsgpu_mst_key)));
+        }
+        const bool hybrid = r_fit > 0 && r_fit < n;
+        if (getenv("LCSGPU_PROFILE"))
+            fprintf(stderr, "lcsgpu_mst_prim: n = %d, rows [0, %d) of the triangle resident (%.2f GB), rows [%d, %d) recomputed per round%s\n",
+                    n, r_fit, (double)tri_offset(r_fit) * elem / 1e9, r_fit, n,
+                    r_fit == n ? (mode == FUSED ? " -- round 0 fused into the launch" : "") : r_fit == 0 ? " -- no triangle" : " -- hybrid");
         while (!rc && ctx->mst.found < n - 1) {
-            rc = shard_best(ctx, L, nullptr, nullptr);
-            if (!rc) rc = shard_merge(ctx, L, nullptr, 1, nullptr);
+            if (!hybrid) {
+                rc = shard_best(ctx, L, nullptr, nullptr);
+                if (!rc) rc = shard_merge(ctx, L, nullptr, 1, nullptr);
+                continue;
+            }
+            // two row blocks on one GPU: [0, r_fit) by passes over its resident triangle, [r_fit, n) by a launch with the
+            // fold fused in; their keys meet like two ranks' keys (part 0, part 1 of the gathered buffer)
+            lcsgpu::MstKey* gathered = (lcsgpu::MstKey*)ctx->d_gather.p;
+            rc = shard_best(ctx, L, gathered, nullptr);
+            if (rc) break;
+            lcsgpu::BoruvkaArgs rest = ctx->mst.b; // the component state is shared; the block and where its keys go differ
+            rest.tri = nullptr;
+            rest.r0 = r_fit;
+            rest.r1 = n;
+            rest.off = tri_offset(r_fit);
+            rest.best = gathered + n;
+            rc = fused_rows(ctx, L, rest, nullptr, elem, ctx->mst.rounds > 0);
+            if (rc) break;
+            HIP_TRY(lcsgpu::launch_boruvka_fuse_fold(rest, L.stream));
+            rc = shard_merge(ctx, L, gathered, 2, nullptr);
         }
         if (!rc) rc = shard_finish(ctx, L, out_edges);
         ctx->mst.active = false; // the triangle it points to belongs to this call
@@ -555,8 +601,6 @@ std::vector<int32_t> equal_pair_cuts(int32_t r0, int32_t r1, int parts)
     }
     return cut;
 }
-
-int64_t tri_offset(int64_t r) { return r * (r - 1) / 2; }
 
 // ---- device-to-device transport between the contexts of one process ---------------------------------------
 // Peer access is a property of an ordered device pair and has to be switched on once per process; without it
@@ -874,16 +918,18 @@ int lcsgpu_multi_mst_prim(lcsgpu_ctx* const* ctxs, int32_t n_ctx, int distance_k
         Lane& L = *g.lanes[k];
         const int32_t r0 = cut[k], r1 = cut[k + 1];
         const int64_t off = tri_offset(r0);
-        // the block's triangle stays in this GPU's HBM when it fits (filled by a launch that does round 0's local half
-        // as well); else nothing is kept and every round recomputes the block (lcsgpu_mst_shard_begin, LCSGPU_MST_COMPUTE)
-        bool resident = !(getenv("LCSGPU_MST_MODE") && !strcmp(getenv("LCSGPU_MST_MODE"), "recompute") && elem == 2);
+        // the block's triangle stays in this GPU's HBM when it fits; else nothing is kept and every round recomputes the
+        // block with the fold fused into the launch (lcsgpu_mst_shard_begin, LCSGPU_MST_COMPUTE); LCSGPU_MST_MODE as above
+        const char* mode = getenv("LCSGPU_MST_MODE");
+        const bool want_fused = mode && !strcmp(mode, "fused") && elem == 2;
+        bool resident = !(mode && !strcmp(mode, "recompute") && elem == 2);
         if (resident) {
             rc = reserve_big(ctxs[k], L.d_out, (size_t)std::max<int64_t>(tri_offset(r1) - off, 1) * elem, "a row block of the LCS triangle");
             if (rc == LCSGPU_E_NOMEM && elem == 2) resident = false;
             else if (rc) return rc;
         }
         HIP_TRY(hipSetDevice(ctxs[k]->device));
-        if (elem == 2)
+        if (!resident || want_fused)
             rc = shard_begin(ctxs[k], L, resident ? L.d_out.p : nullptr, elem, r0, r1, kind, true);
         else {
             if (r1 > r0) {

@@ -56,14 +56,18 @@ def assemble_row_minima(gathered, cuts):
 
 # ---- the sharded single-linkage reduction: Boruvka rounds with one all-gather per round ----------
 
-def sharded_mst_device(eng, d_tri_ptr, elem_size, r0, r1, kind, keys, gathered, all_gather, max_rounds=64, ordered=True):
+def sharded_mst_device(eng, d_tri_ptr, elem_size, r0, r1, kind, keys, gathered, all_gather, max_rounds=64, ordered=True,
+                       begun=False):
     """Device flow (bench.py over RCCL; the multi-context GPU test): `eng` holds rows [r0, r1) at
     d_tri_ptr.  keys: device int64 tensor [2n] (this rank's lcsgpu_mst_key records), gathered: device
     int64 tensor [world * 2n]; all_gather(gathered, keys) must order itself after the engine's stream
-    and the next engine call after it.  Returns (edges in Prim's insertion order, rounds)."""
+    and the next engine call after it.  begun: the caller has already called mst_shard_begin (e.g. with
+    MST_COMPUTE, which fills d_tri_ptr and does round 0's local half in the same launch).
+    Returns (edges in Prim's insertion order, rounds)."""
     n = eng.n
     world = gathered.numel() // max(keys.numel(), 1)
-    eng.mst_shard_begin(d_tri_ptr, elem_size, r0, r1, kind)
+    if not begun:
+        eng.mst_shard_begin(d_tri_ptr, elem_size, r0, r1, kind)
     found, rounds = 0, 0
     while found < n - 1:
         if rounds >= max_rounds:

@@ -86,6 +86,28 @@ def test_no_room_for_the_triangle_means_recompute(engine, monkeypatch):
         probe.close()
 
 
+def test_part_of_the_triangle_resident(engine, monkeypatch, capfd):
+    """Between "fits" and "nothing fits": the rows that fit stay in HBM (passes), the rest is recomputed per round
+    (fused launch); the two blocks' keys are merged like two ranks' keys."""
+    seqs = _sets()["mixed_sorted"] + _sets()["family"]
+    seqs = [seqs[i] for i in seqio.sort_order(seqs)]
+    engine.upload_seqs(seqs)
+    n = len(seqs)
+    want = engine.mst_prim(1 | MST_TRIANGLE_ORIENTATION)
+    probe = famsa_amd.LcsGpu(0)
+    try:
+        probe.upload_seqs(seqs)
+        monkeypatch.setenv("LCSGPU_PROFILE", "1")
+        monkeypatch.setenv("LCSGPU_FAKE_HBM_GB", "%.6f" % (0.6 * n * (n - 1) / 1e9))  # room for ~60 % of the 2 B x pairs
+        capfd.readouterr()
+        got = probe.mst_prim(1 | MST_TRIANGLE_ORIENTATION)
+        err = capfd.readouterr().err
+        assert "hybrid" in err, err
+        assert same(got, want)
+    finally:
+        probe.close()
+
+
 @pytest.mark.parametrize("parts", [2, 3])
 @pytest.mark.parametrize("resident", [True, False])
 def test_row_block_shards_with_the_fold_in_the_launch(engine, parts, resident):
