@@ -66,6 +66,22 @@ def c3(ref, meta):
     save(meta)
 
 
+def c3more(ref, meta):
+    """-gt nj (O(n^3) on one thread in the reference: minutes) and upgma_modified at 10 000 x 400 aa."""
+    n, L = 10000, 400
+    codes, offsets = seqio.synth_uniform(n, L)
+    path = "/tmp/golden_synth10k.fasta"
+    seqio.to_fasta(codes, offsets, path)
+    h = ref.open_fasta(path)
+    rec = meta["synth10k"]
+    for gt in ("upgma_modified", "nj"):
+        t0 = time.time()
+        rec[f"{gt}_newick_sha256"] = sha(ref.tree(h, gt, threads=THREADS))
+        print("c3", gt, "%.0f s" % (time.time() - t0), flush=True)
+        save(meta)
+    ref.close(h)
+
+
 def c4(ref, meta, gts=("sl",)):
     n, L = 100000, 400
     codes, offsets = seqio.synth_uniform(n, L)
@@ -107,7 +123,7 @@ def main():
     ref = oracle_bind.Ref()
     meta = load()
     for w in which:
-        {"c3": c3, "c4": c4, "c5": c5, "c5huge": lambda r, m: c5(r, m, (3000000,)),
+        {"c3": c3, "c3more": c3more, "c4": c4, "c5": c5, "c5huge": lambda r, m: c5(r, m, (3000000,)),
          "c4upgma": lambda r, m: c4(r, m, ("upgma", "upgma_modified"))}[w](ref, meta)
     print(json.dumps(load(), indent=1))
 
