@@ -440,7 +440,8 @@ int lcsgpu_mst_prim(lcsgpu_ctx* ctx, int distance_kind, lcsgpu_mst_edge* out_edg
                 size_t free_b = 0;
                 if (int rc2 = device_free_bytes(ctx, &free_b)) return rc2;
                 free_b += L.d_out.cap;
-                const size_t keep_free = (size_t)n * 256 + std::min<size_t>((size_t)1 << 30, free_b / 16); // MST state, plans, slack
+                // what else must fit: the MST state (n x ~200 B and the column pass's partials, 96 chunks x n x 16 B), plans, slack
+                const size_t keep_free = (size_t)n * (256 + 96 * 16) + std::min<size_t>((size_t)2 << 30, free_b / 16);
                 const double usable = free_b > keep_free ? (double)(free_b - keep_free) : 0.0;
                 r_fit = (int32_t)std::min<double>(n, std::floor(0.5 + std::sqrt(0.25 + 2.0 * usable / elem)));
                 if (r_fit < n / 4) r_fit = 0;
