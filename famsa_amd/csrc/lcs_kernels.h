@@ -168,7 +168,9 @@ hipError_t launch_boruvka_merge(const BoruvkaArgs& a, const MstKey* gathered, in
 
 // ---- device-side UPGMA (tree_kernels.hip) ----
 struct UpgmaArgs {
-    float* D;             // float distance triangle (updated in place)
+    float* D;             // float distances (updated in place): the packed lower triangle, or -- square -- the full
+                          // symmetric n x n matrix, in which both rows a merge reads are contiguous
+    int32_t square;
     float* min_dist;      // [n]
     uint32_t* nearest;    // [n]
     uint32_t* node_index; // [n]

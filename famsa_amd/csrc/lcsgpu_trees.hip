@@ -734,7 +734,17 @@ int upgma_reduce(lcsgpu_ctx* ctx, Lane& L, int elem, int distance_kind, int modi
 {
     const int32_t n = ctx->n;
     HIP_TRY(hipSetDevice(ctx->device));
-    int rc = reserve_big(ctx, ctx->d_dist, (size_t)tri_offset(n) * sizeof(float), "the float distance triangle");
+    // The distances as a full symmetric matrix when 4 B x n^2 fit (n <= ~190 000 next to the LCS triangle on 288 GB):
+    // both rows a merge reads are then contiguous (tree_kernels.hip).  Else the packed triangle.  LCSGPU_UPGMA_LAYOUT=
+    // triangle|square forces one (tests, measurements).
+    bool square = (size_t)n * n * sizeof(float) <= ((size_t)200 << 30);
+    if (const char* e = getenv("LCSGPU_UPGMA_LAYOUT")) square = !strcmp(e, "square");
+    int rc = LCSGPU_E_NOMEM;
+    if (square) rc = reserve_big(ctx, ctx->d_dist, (size_t)n * n * sizeof(float), "the float distance matrix");
+    if (rc == LCSGPU_E_NOMEM) {
+        square = false;
+        rc = reserve_big(ctx, ctx->d_dist, (size_t)tri_offset(n) * sizeof(float), "the float distance triangle");
+    }
     if (rc) return rc;
     const int blocks = (n + 255) / 256;
     auto a16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
@@ -751,6 +761,7 @@ int upgma_reduce(lcsgpu_ctx* ctx, Lane& L, int elem, int distance_kind, int modi
     a.bm_j = (uint32_t*)(base + o_bj);
     a.bm_near = (uint32_t*)(base + o_bn);
     a.D = (float*)ctx->d_dist.p;
+    a.square = square ? 1 : 0;
     a.min_dist = (float*)(base + o_min);
     a.nearest = (uint32_t*)(base + o_near);
     a.node_index = (uint32_t*)(base + o_node);

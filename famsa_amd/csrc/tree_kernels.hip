@@ -210,7 +210,60 @@ __global__ __launch_bounds__(256) void upgma_dist_kernel(const T* __restrict__ l
     }
 }
 
+// The same distances as a full symmetric matrix D[i*n + j] = D[j*n + i]: a merge then reads two contiguous rows
+// (in the packed triangle the part j > Lmin of "row" Lmin is a column walk, one 32-byte sector per element, on the
+// merge's dependent path).  One workgroup per 32 x 32 tile at or below the diagonal: the tile is written as it
+// is read (rows i, coalesced along j) and, through LDS, transposed (rows j, coalesced along i).
+template <typename T>
+__global__ __launch_bounds__(256) void upgma_dist_square_kernel(const T* __restrict__ lcs, const uint32_t* __restrict__ lens,
+                                                                const float* __restrict__ pow_f32, int kind, int n,
+                                                                float* __restrict__ D)
+{
+    __shared__ float tile[32][33];
+    // tile (ti, tj), tj <= ti, from the linear workgroup id
+    const long long b = blockIdx.x;
+    int ti = (int)((sqrt(8.0 * (double)b + 1.0) - 1.0) * 0.5);
+    while ((long long)(ti + 1) * (ti + 2) / 2 <= b) ++ti;
+    while ((long long)ti * (ti + 1) / 2 > b) --ti;
+    const int tj = (int)(b - (long long)ti * (ti + 1) / 2);
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5; // ty = 0..7
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i = ti * 32 + ty + 8 * r, j = tj * 32 + tx;
+        float d = 0.0f;
+        if (i < n && j < i) {
+            const uint32_t l = lcs[(size_t)i * (i - 1) / 2 + j];
+            const uint32_t indel = lens[i] + lens[j] - 2u * l;
+            if (l == 0)
+                d = 3.40282347e38f; // (float) nextafter((double) FLT_MAX, 0) rounds back to FLT_MAX
+            else if (kind == 1)
+                d = __fdiv_rn(pow_f32[indel], (float)l);
+            else
+                d = __fdiv_rn((float)indel, (float)l);
+            D[(size_t)i * n + j] = d;
+        }
+        tile[ty + 8 * r][tx] = d;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int j = tj * 32 + ty + 8 * r, i = ti * 32 + tx; // element (j, i) of the upper half = tile[i][j]
+        if (i < n && j < i) D[(size_t)j * n + i] = tile[tx][ty + 8 * r];
+    }
+    if (ti == tj && threadIdx.x < 32) { // the diagonal is never read; keep it defined
+        const int i = ti * 32 + threadIdx.x;
+        if (i < n) D[(size_t)i * n + i] = 0.0f;
+    }
+}
+
+template <bool SQUARE>
+__device__ __forceinline__ size_t upgma_index(const UpgmaArgs& a, uint64_t row, uint64_t col)
+{
+    return SQUARE ? (size_t)(row * (uint64_t)a.n + col) : tri_index(row, col);
+}
+
 // initial row minima over the FULL row of x (columns y != x), first strict minimum in ascending y
+template <bool SQUARE>
 __global__ __launch_bounds__(256) void upgma_init_kernel(UpgmaArgs a)
 {
     __shared__ float s_d[256];
@@ -220,7 +273,7 @@ __global__ __launch_bounds__(256) void upgma_init_kernel(UpgmaArgs a)
     uint32_t bj = UPGMA_NONE;
     for (int y = tid; y < a.n; y += 256) {
         if (y == x) continue;
-        const float d = a.D[tri_index(x, y)];
+        const float d = a.D[upgma_index<SQUARE>(a, x, y)];
         if (d < best) { best = d; bj = y; } // ascending y within the thread
     }
     s_d[tid] = best;
@@ -330,7 +383,7 @@ constexpr int UPGMA_SEL_EXCL = 16;
 // Workgroup 0 does the bookkeeping writes of step 1; the owners write their bm[] entries; everything a
 // launch writes that the same launch reads elsewhere is either unused there or overridden by the same patch, so
 // the order in which workgroups run does not matter.
-template <bool MODIFIED>
+template <bool MODIFIED, bool SQUARE>
 __global__ __launch_bounds__(256) void upgma_step_kernel(UpgmaArgs a, int it)
 {
     __shared__ float s_d[256];
@@ -422,7 +475,7 @@ __global__ __launch_bounds__(256) void upgma_step_kernel(UpgmaArgs a, int it)
     const bool row_ok = L != UPGMA_NONE && R != UPGMA_NONE && in && my_node != UPGMA_NONE && j != Rp && j != L && j != R;
     uint32_t near_j = UPGMA_NONE;
     if (row_ok) {
-        const size_t vL = tri_index(L, j), vR = tri_index(R, j);
+        const size_t vL = upgma_index<SQUARE>(a, L, j), vR = upgma_index<SQUARE>(a, R, j);
         const float dL = a.D[vL], dR = a.D[vR];
         float v;
         if (MODIFIED) // 0.05f * (x + y) + 0.9f * min(x, y), no contraction (reference UPGMA.cpp:32-34)
@@ -436,6 +489,7 @@ __global__ __launch_bounds__(256) void upgma_step_kernel(UpgmaArgs a, int it)
             if (!touched && j == own_bm_j) a.bm_near[b] = near_j;
         }
         a.D[vL] = v;
+        if (SQUARE) a.D[(size_t)j * (size_t)n + L] = v; // the mirror: a strided store, off the dependent path
         nd = v;
         nj = j;
     }
@@ -464,19 +518,30 @@ hipError_t launch_upgma(const UpgmaArgs& a, const void* lcs, int elem_size, cons
                         const float* pow_f32, int kind, bool modified, hipStream_t stream)
 {
     const int n = a.n;
-    if (elem_size == 2)
-        hipLaunchKernelGGL(upgma_dist_kernel<uint16_t>, dim3(n - 1), dim3(256), 0, stream, (const uint16_t*)lcs, lens,
-                           pow_f32, kind, n, a.D);
-    else
-        hipLaunchKernelGGL(upgma_dist_kernel<uint32_t>, dim3(n - 1), dim3(256), 0, stream, (const uint32_t*)lcs, lens,
-                           pow_f32, kind, n, a.D);
-    hipLaunchKernelGGL(upgma_init_kernel, dim3(n), dim3(256), 0, stream, a);
+    if (a.square) {
+        const long long t = (n + 31) / 32, tiles = t * (t + 1) / 2;
+        if (elem_size == 2)
+            hipLaunchKernelGGL(upgma_dist_square_kernel<uint16_t>, dim3((unsigned)tiles), dim3(256), 0, stream, (const uint16_t*)lcs,
+                               lens, pow_f32, kind, n, a.D);
+        else
+            hipLaunchKernelGGL(upgma_dist_square_kernel<uint32_t>, dim3((unsigned)tiles), dim3(256), 0, stream, (const uint32_t*)lcs,
+                               lens, pow_f32, kind, n, a.D);
+        hipLaunchKernelGGL(upgma_init_kernel<true>, dim3(n), dim3(256), 0, stream, a);
+    } else {
+        if (elem_size == 2)
+            hipLaunchKernelGGL(upgma_dist_kernel<uint16_t>, dim3(n - 1), dim3(256), 0, stream, (const uint16_t*)lcs, lens,
+                               pow_f32, kind, n, a.D);
+        else
+            hipLaunchKernelGGL(upgma_dist_kernel<uint32_t>, dim3(n - 1), dim3(256), 0, stream, (const uint32_t*)lcs, lens,
+                               pow_f32, kind, n, a.D);
+        hipLaunchKernelGGL(upgma_init_kernel<false>, dim3(n), dim3(256), 0, stream, a);
+    }
     hipLaunchKernelGGL(upgma_block_min_kernel, dim3(a.n_blocks), dim3(256), 0, stream, a);
     for (int it = 0; it < n; ++it) {
-        if (modified)
-            hipLaunchKernelGGL(upgma_step_kernel<true>, dim3(a.n_blocks), dim3(256), 0, stream, a, it);
-        else
-            hipLaunchKernelGGL(upgma_step_kernel<false>, dim3(a.n_blocks), dim3(256), 0, stream, a, it);
+#define UPGMA_STEP(M, S) hipLaunchKernelGGL((upgma_step_kernel<M, S>), dim3(a.n_blocks), dim3(256), 0, stream, a, it)
+        if (modified) { if (a.square) UPGMA_STEP(true, true); else UPGMA_STEP(true, false); }
+        else { if (a.square) UPGMA_STEP(false, true); else UPGMA_STEP(false, false); }
+#undef UPGMA_STEP
     }
     return hipGetLastError();
 }

@@ -81,16 +81,14 @@ def test_c4_single_linkage_tree(synth100k, tmp_path):
     assert file_sha(out) == META["synth100k"]["sl_newick_sha256"]
 
 
-@pytest.mark.parametrize("gt", ["upgma", "upgma_modified"])
-def test_c4_upgma_trees(synth100k, tmp_path, gt):
-    """100 000 merges on the device (one launch each) over the 20 GB float triangle: the per-workgroup minima are
-    two per thread at this size (391 workgroups), which no smaller case reaches."""
-    key = f"{gt}_newick_sha256"
-    if key not in META["synth100k"]:
-        pytest.skip("no reference value (oracle/make_golden_large.py c4upgma)")
+@pytest.mark.parametrize("gt,layout", [("upgma", "square"), ("upgma_modified", "square"), ("upgma", "triangle")])
+def test_c4_upgma_trees(synth100k, tmp_path, gt, layout):
+    """100 000 merges on the device (one launch each) over the float distances -- the 40 GB symmetric matrix (default)
+    or the 20 GB packed triangle: the per-workgroup minima are two per thread at this size (391 workgroups), which no
+    smaller case reaches.  Against the sha256 of the REFERENCE's own runs (oracle/make_golden_large.py c4upgma)."""
     out = str(tmp_path / f"{gt}.dnd")
-    cli("-gt", gt, "-gt_export", synth100k[2], out)
-    assert file_sha(out) == META["synth100k"][key]
+    cli("-gt", gt, "-gt_export", synth100k[2], out, env={"LCSGPU_UPGMA_LAYOUT": layout})
+    assert file_sha(out) == META["synth100k"][f"{gt}_newick_sha256"]
 
 
 def test_c4_row_block_contexts_tree_and_sampled_triangle(oracle, synth100k):
