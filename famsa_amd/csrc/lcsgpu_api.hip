@@ -219,8 +219,34 @@ int run_rows(lcsgpu_ctx* ctx, Lane& L, int mode, const int32_t* ref_ids, int32_t
     }
 
     HIP_TRY(hipEventRecord(L.ev_start, L.stream));
+    // several buckets: their launches go to the lane's side streams (see Lane::aux); the long-ref kernel shares the
+    // lane's carry scratch between its launches and stays on the main stream
+    bool spread = buckets.size() > 1 && !getenv("LCSGPU_NO_SPREAD");
+    if (spread && !L.aux_tried) {
+        L.aux_tried = true;
+        bool ok = hipEventCreateWithFlags(&L.fork, hipEventDisableTiming) == hipSuccess;
+        for (int k = 0; k < Lane::N_AUX && ok; ++k)
+            ok = hipStreamCreateWithFlags(&L.aux[k], hipStreamNonBlocking) == hipSuccess &&
+                 hipEventCreateWithFlags(&L.aux_done[k], hipEventDisableTiming) == hipSuccess;
+        if (!ok) (void)hipGetLastError();
+        L.aux_ok = ok;
+    }
+    spread = spread && L.aux_ok;
+    bool aux_used[Lane::N_AUX] = {false, false, false};
+    if (spread) HIP_TRY(hipEventRecord(L.fork, L.stream)); // behind the plan's copy
+    int next_side = 0;
+    const int rc_launch = [&]() -> int {
     for (size_t b = 0; b < buckets.size(); ++b) {
         const Bucket& bk = buckets[b];
+        hipStream_t st = L.stream;
+        if (spread && bk.bv != 0 && b > 0) {
+            const int k = next_side++ % Lane::N_AUX;
+            if (!aux_used[k]) {
+                HIP_TRY(hipStreamWaitEvent(L.aux[k], L.fork, 0));
+                aux_used[k] = true;
+            }
+            st = L.aux[k];
+        }
         RowsArgs a{};
         a.tiles = (const uint8_t*)ctx->d_tiles.p;
         a.tile_base = (const uint64_t*)ctx->d_tile_base.p;
@@ -264,12 +290,12 @@ int run_rows(lcsgpu_ctx* ctx, Lane& L, int mode, const int32_t* ref_ids, int32_t
             a.tri_rows = (int32_t)tri_prefix[b].size() - 1;
             const int total = tri_prefix[b].back();
             if (total > 0) {
-                HIP_TRY(lcsgpu::launch_rows(bk.bv, bk.quirk, a, total, 1, L.stream));
+                HIP_TRY(lcsgpu::launch_rows(bk.bv, bk.quirk, a, total, 1, st));
                 ++L.last_launches;
             }
         } else if (bk.bv != 0) {
             if (gy > 65535) return fail(LCSGPU_E_INVALID, "too many ref tiles in one call (%d)", gy);
-            HIP_TRY(lcsgpu::launch_rows(bk.bv, bk.quirk, a, gx, gy, L.stream));
+            HIP_TRY(lcsgpu::launch_rows(bk.bv, bk.quirk, a, gx, gy, st));
             ++L.last_launches;
         } else {
             // long refs: slices of ref blocks so the carry scratch stays bounded
@@ -295,6 +321,14 @@ int run_rows(lcsgpu_ctx* ctx, Lane& L, int mode, const int32_t* ref_ids, int32_t
             }
         }
     }
+    return LCSGPU_OK;
+    }();
+    for (int k = 0; k < Lane::N_AUX; ++k)
+        if (aux_used[k]) { // join: whatever follows on the lane's stream sees every bucket's results
+            HIP_TRY(hipEventRecord(L.aux_done[k], L.aux[k]));
+            HIP_TRY(hipStreamWaitEvent(L.stream, L.aux_done[k], 0));
+        }
+    if (rc_launch) return rc_launch; // (joined above: nothing of this call runs unordered behind the lane's stream)
     HIP_TRY(hipEventRecord(L.ev_stop, L.stream));
     L.timing_valid = true;
     return LCSGPU_OK;
@@ -447,6 +481,11 @@ int lcsgpu_destroy(lcsgpu_ctx* ctx)
         if (l.ev_stop) (void)hipEventDestroy(l.ev_stop);
         if (l.ev_done) (void)hipEventDestroy(l.ev_done);
         if (l.copy_stream) (void)hipStreamDestroy(l.copy_stream);
+        for (int k = 0; k < Lane::N_AUX; ++k) {
+            if (l.aux[k]) { (void)hipStreamSynchronize(l.aux[k]); (void)hipStreamDestroy(l.aux[k]); }
+            if (l.aux_done[k]) (void)hipEventDestroy(l.aux_done[k]);
+        }
+        if (l.fork) (void)hipEventDestroy(l.fork);
         if (l.stream) (void)hipStreamDestroy(l.stream);
     }
     for (ClaransBatcher& B : ctx->clarans_groups) {
