@@ -190,6 +190,25 @@ hipError_t launch_upgma(const UpgmaArgs& a, const void* lcs, int elem_size, cons
                         const float* pow_f32, int kind, bool modified, hipStream_t stream);
 
 
+// ---- leaf sub-trees of the FastTree recursion: UPGMA, one workgroup per leaf (tree_kernels.hip) ----
+constexpr int LEAF_MAX = 2048; // members of a leaf (the reference's default threshold is 2000)
+struct LeafArgs {
+    const void* lcs;              // the batch's packed uint16 LCS triangles, list after list
+    const int32_t* ids;           // the concatenated id lists
+    const int64_t* group_offsets; // [n_groups + 1] into ids
+    const int64_t* tri_base;      // [n_groups] first pair of each list's triangle
+    const int64_t* node_base;     // [n_groups] first internal node of each list (sum of m_h - 1 over the lists before it)
+    const int32_t* order;         // [n_groups] lists by size, descending: workgroup b builds list order[b]
+    const uint32_t* lens;
+    const float* pow_f32;
+    int32_t kind;
+    float* D;                     // scratch: the float triangles, laid out like lcs
+    int32_t* left;                // children of the internal nodes, local ids (leaves 0..m-1, internal m..2m-2)
+    int32_t* right;
+    int32_t* err;                 // [0] set when a leaf has no finite nearest neighbour
+};
+hipError_t launch_leaf_upgma(const LeafArgs& a, int n_groups, bool modified, hipStream_t stream);
+
 // ---- device-side neighbour joining (tree_kernels.hip) ----
 struct NjArgs {
     float* D;         // float distance triangle (updated in place)

@@ -123,8 +123,14 @@ int clarans_run_search(lcsgpu_ctx* ctx, ClaransJob& job)
 
 extern "C" {
 
-int lcsgpu_lcs_triangles_batch(lcsgpu_ctx* ctx, const int32_t* ids, const int64_t* group_offsets, int32_t n_groups,
-                               void* out, int elem_size)
+} // extern "C"
+
+// The packed LCS triangles of several id lists into lane L's result buffer (device memory), list g at pair offset
+// tri_base[g]: validation, planning and the launches of lcsgpu_lcs_triangles_batch, shared with the batched leaf
+// reducers, which consume the triangles where they are.  *count = pairs in total (0: nothing to do).  On return the
+// launches are queued on L.stream (or, with a ref beyond 2048 residues in the batch, already finished).
+static int batch_triangles_to_device(lcsgpu_ctx* ctx, Lane& L, const int32_t* ids, const int64_t* group_offsets, int32_t n_groups,
+                                     int elem_size, std::vector<int64_t>& tri_base, int64_t* count_out, bool* had_long)
 {
     if (!ctx) return fail(LCSGPU_E_INVALID, "NULL ctx");
     if (ctx->n < 0) return fail(LCSGPU_E_STATE, "no sequence set uploaded");
@@ -132,11 +138,13 @@ int lcsgpu_lcs_triangles_batch(lcsgpu_ctx* ctx, const int32_t* ids, const int64_
     if (elem_size != 2 && elem_size != 4) return fail(LCSGPU_E_INVALID, "elem_size must be 2 or 4");
     if (elem_size == 2 && ctx->max_len > 65535)
         return fail(LCSGPU_E_INVALID, "uint16 output needs all sequences <= 65535 residues");
+    *count_out = 0;
+    *had_long = false;
     if (n_groups == 0) return LCSGPU_OK;
     if (group_offsets[0] != 0) return fail(LCSGPU_E_INVALID, "group_offsets[0] must be 0");
     const int64_t n_total = group_offsets[n_groups];
     if (n_total < 0 || n_total > 0x7fffffff) return fail(LCSGPU_E_INVALID, "bad total id count");
-    std::vector<int64_t> tri_base((size_t)n_groups + 1, 0);
+    tri_base.assign((size_t)n_groups + 1, 0);
     bool any_long = false;
     for (int32_t g = 0; g < n_groups; ++g) {
         const int64_t m = group_offsets[g + 1] - group_offsets[g];
@@ -145,13 +153,13 @@ int lcsgpu_lcs_triangles_batch(lcsgpu_ctx* ctx, const int32_t* ids, const int64_
     }
     const int64_t count = tri_base[n_groups];
     if (count <= 0) return LCSGPU_OK;
-    if (!ids || !out) return fail(LCSGPU_E_INVALID, "NULL ids / out");
+    if (!ids) return fail(LCSGPU_E_INVALID, "NULL ids");
     for (int64_t p = 0; p < n_total; ++p) {
         if (ids[p] < 0 || ids[p] >= ctx->n) return fail(LCSGPU_E_INVALID, "id %d out of range", ids[p]);
         any_long |= ctx->lens[ids[p]] > 2048;
     }
-    LaneGuard guard(ctx, LaneGuard::ANY);
-    Lane& L = guard.lane();
+    *count_out = count;
+    *had_long = any_long;
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(L.d_out.reserve((size_t)count * elem_size));
     if (any_long) { // the long-ref kernel keeps its 2-D grid: list by list
@@ -169,7 +177,6 @@ int lcsgpu_lcs_triangles_batch(lcsgpu_ctx* ctx, const int32_t* ids, const int64_
             ms += g_last.ms;
             launches += g_last.launches;
         }
-        HIP_TRY(hipMemcpy(out, L.d_out.p, (size_t)count * elem_size, hipMemcpyDeviceToHost));
         g_last.ms = ms;
         g_last.launches = launches;
         return LCSGPU_OK;
@@ -279,12 +286,118 @@ int lcsgpu_lcs_triangles_batch(lcsgpu_ctx* ctx, const int32_t* ids, const int64_
     }
     HIP_TRY(hipEventRecord(L.ev_stop, L.stream));
     L.timing_valid = true;
+    return LCSGPU_OK;
+}
+
+extern "C" {
+
+int lcsgpu_lcs_triangles_batch(lcsgpu_ctx* ctx, const int32_t* ids, const int64_t* group_offsets, int32_t n_groups,
+                               void* out, int elem_size)
+{
+    if (!ctx) return fail(LCSGPU_E_INVALID, "NULL ctx");
+    LaneGuard guard(ctx, LaneGuard::ANY);
+    Lane& L = guard.lane();
+    std::vector<int64_t> tri_base;
+    int64_t count = 0;
+    bool had_long = false;
+    int rc = batch_triangles_to_device(ctx, L, ids, group_offsets, n_groups, elem_size, tri_base, &count, &had_long);
+    if (rc || count <= 0) return rc;
+    if (!out) return fail(LCSGPU_E_INVALID, "NULL out");
+    if (had_long) { // every list was synchronised already; the timing is in g_last
+        HIP_TRY(hipMemcpy(out, L.d_out.p, (size_t)count * elem_size, hipMemcpyDeviceToHost));
+        return LCSGPU_OK;
+    }
     HIP_TRY(hipMemcpyAsync(out, L.d_out.p, (size_t)count * elem_size, hipMemcpyDeviceToHost, L.stream));
     HIP_TRY(hipEventRecord(L.ev_done, L.stream));
     HIP_TRY(hipEventSynchronize(L.ev_done));
     finish_host_call(ctx, L);
     return LCSGPU_OK;
 }
+
+// UPGMA sub-trees of several id lists in one call: the lists' LCS triangles are computed as by
+// lcsgpu_lcs_triangles_batch, stay in HBM, and one workgroup per list builds its tree there (tree_kernels.hip,
+// leaf_upgma_kernel); only the trees come back.
+int lcsgpu_leaf_upgma_batch(lcsgpu_ctx* ctx, const int32_t* ids, const int64_t* group_offsets, int32_t n_groups,
+                            int distance_kind, int modified, int32_t* out_left, int32_t* out_right)
+{
+    if (!ctx) return fail(LCSGPU_E_INVALID, "NULL ctx");
+    if (ctx->n < 0) return fail(LCSGPU_E_STATE, "no sequence set uploaded");
+    if (distance_kind != LCSGPU_DIST_INDEL_DIV_LCS && distance_kind != LCSGPU_DIST_INDEL075_DIV_LCS)
+        return fail(LCSGPU_E_INVALID, "unknown distance kind %d", distance_kind);
+    if (n_groups < 0 || (n_groups > 0 && !group_offsets)) return fail(LCSGPU_E_INVALID, "bad group table");
+    if (n_groups == 0) return LCSGPU_OK;
+    if (ctx->max_len > 65535) return fail(LCSGPU_E_UNSUPPORTED, "the leaf reducer reads uint16 LCS values");
+    std::vector<int64_t> node_base((size_t)n_groups, 0);
+    std::vector<int32_t> order((size_t)n_groups);
+    int64_t nodes = 0;
+    for (int32_t g = 0; g < n_groups; ++g) {
+        const int64_t m = group_offsets[g + 1] - group_offsets[g];
+        if (m < 0) return fail(LCSGPU_E_INVALID, "group_offsets not ascending");
+        if (m > lcsgpu::LEAF_MAX)
+            return fail(LCSGPU_E_UNSUPPORTED, "list %d has %lld members; the leaf reducer takes up to %d", g, (long long)m, lcsgpu::LEAF_MAX);
+        node_base[g] = nodes;
+        nodes += std::max<int64_t>(m - 1, 0);
+        order[g] = g;
+    }
+    if (nodes == 0) return LCSGPU_OK;
+    if (!out_left || !out_right) return fail(LCSGPU_E_INVALID, "NULL output");
+    std::sort(order.begin(), order.end(), [&](int32_t x, int32_t y) {
+        return group_offsets[x + 1] - group_offsets[x] > group_offsets[y + 1] - group_offsets[y];
+    });
+    LaneGuard guard(ctx, LaneGuard::ANY);
+    Lane& L = guard.lane();
+    std::vector<int64_t> tri_base;
+    int64_t count = 0;
+    bool had_long = false;
+    int rc = batch_triangles_to_device(ctx, L, ids, group_offsets, n_groups, 2, tri_base, &count, &had_long);
+    if (rc) return rc;
+    if (count <= 0) return LCSGPU_OK; // (cannot happen with nodes > 0)
+    // tables + scratch of the reducer: [ids][group_offsets][tri_base][node_base][order][err][left][right] ... [D]
+    auto a16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
+    const int64_t n_total = group_offsets[n_groups];
+    const size_t o_ids = 0, o_go = o_ids + a16((size_t)n_total * 4), o_tb = o_go + a16(((size_t)n_groups + 1) * 8),
+                 o_nb = o_tb + a16((size_t)n_groups * 8), o_ord = o_nb + a16((size_t)n_groups * 8),
+                 o_err = o_ord + a16((size_t)n_groups * 4), o_left = o_err + 16, o_right = o_left + a16((size_t)nodes * 4),
+                 o_D = o_right + a16((size_t)nodes * 4), total = o_D + (size_t)count * sizeof(float);
+    HIP_TRY(L.d_work.reserve(total));
+    HIP_TRY(L.h_small.reserve(o_left));
+    char* h = (char*)L.h_small.p;
+    memset(h + o_err, 0, 16);
+    memcpy(h + o_ids, ids, (size_t)n_total * 4);
+    memcpy(h + o_go, group_offsets, ((size_t)n_groups + 1) * 8);
+    memcpy(h + o_tb, tri_base.data(), (size_t)n_groups * 8);
+    memcpy(h + o_nb, node_base.data(), (size_t)n_groups * 8);
+    memcpy(h + o_ord, order.data(), (size_t)n_groups * 4);
+    char* d = (char*)L.d_work.p;
+    HIP_TRY(hipMemcpyAsync(d, h, o_left, hipMemcpyHostToDevice, L.stream));
+    lcsgpu::LeafArgs a{};
+    a.lcs = L.d_out.p;
+    a.ids = (const int32_t*)(d + o_ids);
+    a.group_offsets = (const int64_t*)(d + o_go);
+    a.tri_base = (const int64_t*)(d + o_tb);
+    a.node_base = (const int64_t*)(d + o_nb);
+    a.order = (const int32_t*)(d + o_ord);
+    a.lens = (const uint32_t*)ctx->d_lens.p;
+    a.pow_f32 = (const float*)ctx->d_powf.p;
+    a.kind = distance_kind;
+    a.D = (float*)(d + o_D);
+    a.left = (int32_t*)(d + o_left);
+    a.right = (int32_t*)(d + o_right);
+    a.err = (int32_t*)(d + o_err);
+    HIP_TRY(lcsgpu::launch_leaf_upgma(a, n_groups, modified != 0, L.stream));
+    int32_t err = 0;
+    HIP_TRY(hipMemcpyAsync(out_left, a.left, (size_t)nodes * 4, hipMemcpyDeviceToHost, L.stream));
+    HIP_TRY(hipMemcpyAsync(out_right, a.right, (size_t)nodes * 4, hipMemcpyDeviceToHost, L.stream));
+    HIP_TRY(hipMemcpyAsync(&err, a.err, 4, hipMemcpyDeviceToHost, L.stream));
+    HIP_TRY(hipEventRecord(L.ev_done, L.stream));
+    HIP_TRY(hipEventSynchronize(L.ev_done)); // sleeps; worker threads must not burn a core per pending call
+    if (!had_long) finish_host_call(ctx, L);
+    if (err)
+        return fail(LCSGPU_E_INVALID, "UPGMA: a list with no finite nearest neighbour (a pair with LCS 0?) -- the reference's "
+                                      "algorithm is undefined for this input");
+    return LCSGPU_OK;
+}
+
 
 int lcsgpu_assign_seeds(lcsgpu_ctx* ctx, const int32_t* seed_ids, int32_t n_seeds, const int32_t* col_ids,
                         int32_t n_cols, int distance_kind, int32_t first_k, float* dist, int32_t* assign)

@@ -549,6 +549,131 @@ hipError_t launch_upgma(const UpgmaArgs& a, const void* lcs, int elem_size, cons
 } // namespace lcsgpu
 
 // =============================================================================================
+// Leaf sub-trees of the FastTree recursion (UPGMA<D>::runPartial, reference tree/UPGMA.cpp:55-70: the distance
+// matrix of <= 2000 sequences + computeTree): ONE WORKGROUP PER LEAF, all leaves of a batch in one launch.  The
+// leaf's float triangle (<= 8 MB) sits in global scratch and stays in the XCD's L2; the row statistics
+// (min_dist, nearest, node_index: UPGMA.cpp:137-152) live in LDS; the m-1 merges are a loop inside the kernel with
+// workgroup barriers only -- no launch per merge, no device-wide synchronisation.  The arithmetic and every tie
+// rule are those of the whole-set kernels above (first strict minimum in ascending index, stale row minima,
+// (x+y)*0.5f resp. 0.05f*(x+y)+0.9f*min(x,y) without contraction).
+// =============================================================================================
+namespace lcsgpu {
+
+template <bool MODIFIED>
+__global__ __launch_bounds__(256) void leaf_upgma_kernel(LeafArgs a)
+{
+    __shared__ float s_min[LEAF_MAX];
+    __shared__ uint32_t s_near[LEAF_MAX];
+    __shared__ uint32_t s_node[LEAF_MAX];
+    __shared__ uint32_t s_len[LEAF_MAX];
+    __shared__ float s_d[4];
+    __shared__ uint32_t s_j[4];
+    const int tid = threadIdx.x;
+    const int g = a.order[blockIdx.x]; // largest leaves first
+    const int m = (int)(a.group_offsets[g + 1] - a.group_offsets[g]);
+    if (m < 2) return;
+    const int32_t* ids = a.ids + a.group_offsets[g];
+    const uint16_t* lcs = (const uint16_t*)a.lcs + a.tri_base[g];
+    float* D = a.D + a.tri_base[g];
+    int32_t* left = a.left + a.node_base[g];
+    int32_t* right = a.right + a.node_base[g];
+    for (int i = tid; i < m; i += 256) {
+        s_len[i] = a.lens[ids[i]];
+        s_node[i] = (uint32_t)i;
+    }
+    __syncthreads();
+    // distances (Transform<float, kind>) and the initial row minima in one sweep over the rows, in the reference's
+    // visiting order (UPGMA.cpp:182-199): vertex x sees y < x when row x is processed, then y > x row by row.
+    // Thread t owns the columns t, t + 256, ...: their running minima stay in its registers.
+    constexpr int Q = LEAF_MAX / 256;
+    float cmin[Q];
+    uint32_t carg[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) { cmin[q] = UPGMA_BIG; carg[q] = UPGMA_NONE; }
+    for (int i = 1; i < m; ++i) {
+        const size_t row = (size_t)i * (i - 1) / 2;
+        const uint32_t len_i = s_len[i];
+        float bd = UPGMA_BIG;
+        uint32_t bj = UPGMA_NONE;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const int j = tid + 256 * q;
+            if (j < i) {
+                const uint32_t l = lcs[row + j];
+                const uint32_t indel = len_i + s_len[j] - 2u * l;
+                float d;
+                if (l == 0) d = 3.40282347e38f;
+                else if (a.kind == 1) d = __fdiv_rn(a.pow_f32[indel], (float)l);
+                else d = __fdiv_rn((float)indel, (float)l);
+                D[row + j] = d;
+                if (d < bd) { bd = d; bj = (uint32_t)j; }                 // row i: ascending j inside the thread
+                if (d < cmin[q]) { cmin[q] = d; carg[q] = (uint32_t)i; }  // column j: ascending i over the sweep
+            }
+        }
+        block_first_min(bd, bj, s_d, s_j);
+        if ((i & 255) == tid && bd < UPGMA_BIG) { // the owner of vertex i: its row part comes before any column part
+#pragma unroll
+            for (int q = 0; q < Q; ++q)
+                if (q == (i >> 8)) { cmin[q] = bd; carg[q] = bj; }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        const int j = tid + 256 * q;
+        if (j < m) { s_min[j] = cmin[q]; s_near[j] = carg[q]; }
+    }
+    __syncthreads();
+    for (int it = 0; it < m - 1; ++it) {
+        // Lmin = first minimum of min_dist over the active rows, Rmin = its nearest (UPGMA.cpp:203-219)
+        float pd = UPGMA_BIG;
+        uint32_t pj = UPGMA_NONE;
+        for (int j = tid; j < m; j += 256)
+            if (s_node[j] != UPGMA_NONE) take_first_min(s_min[j], (uint32_t)j, pd, pj);
+        block_first_min(pd, pj, s_d, s_j);
+        const uint32_t L = pj;
+        const uint32_t R = L != UPGMA_NONE ? s_near[L] : UPGMA_NONE;
+        if (L == UPGMA_NONE || R == UPGMA_NONE || R >= (uint32_t)m) { // degenerate input (the reference: undefined)
+            if (tid == 0) a.err[0] = 1;
+            return;
+        }
+        // distances to the new cluster, which takes row Lmin (UPGMA.cpp:221-250)
+        float nd = UPGMA_BIG;
+        uint32_t nj = UPGMA_NONE;
+        for (int j = tid; j < m; j += 256) {
+            if ((uint32_t)j == L || (uint32_t)j == R || s_node[j] == UPGMA_NONE) continue;
+            const size_t vL = tri_index(L, j), vR = tri_index(R, j);
+            const float dL = D[vL], dR = D[vR];
+            float v;
+            if (MODIFIED) v = __fadd_rn(__fmul_rn(0.05f, __fadd_rn(dL, dR)), __fmul_rn(0.9f, fminf(dL, dR)));
+            else v = __fmul_rn(__fadd_rn(dL, dR), 0.5f);
+            if (s_near[j] == R) s_near[j] = L;
+            D[vL] = v;
+            if (v < nd) { nd = v; nj = (uint32_t)j; }
+        }
+        block_first_min(nd, nj, s_d, s_j); // (its barriers also order this merge's D / LDS writes before the next reads)
+        if (tid == 0) {
+            left[it] = (int32_t)s_node[L];
+            right[it] = (int32_t)s_node[R];
+            s_node[L] = (uint32_t)(m + it);
+            s_near[L] = nj;
+            s_min[L] = nd;
+            s_node[R] = UPGMA_NONE;
+        }
+        __syncthreads();
+    }
+}
+
+hipError_t launch_leaf_upgma(const LeafArgs& a, int n_groups, bool modified, hipStream_t stream)
+{
+    if (n_groups <= 0) return hipSuccess;
+    if (modified) hipLaunchKernelGGL(leaf_upgma_kernel<true>, dim3(n_groups), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(leaf_upgma_kernel<false>, dim3(n_groups), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
+} // namespace lcsgpu
+
+// =============================================================================================
 // Device-side neighbour joining, operation for operation the reference's
 // NeighborJoining::computeTree (tree/NeighborJoining.cpp:33-118): float arithmetic with its
 // exact association and summation ORDER (the sums of distances are accumulated sequentially in

@@ -289,6 +289,13 @@ public:
         for (size_t i = 0; i < g.size(); ++i) g[i] = ids_[ids[i]];
         return p_.triangles_batch(g.data(), offsets, n_groups, out);
     }
+    bool leaf_upgma_batch(const int* ids, const int64_t* offsets, int n_groups, int kind, bool modified,
+                          std::vector<int32_t>& left, std::vector<int32_t>& right) override
+    {
+        std::vector<int> g((size_t)offsets[n_groups]);
+        for (size_t i = 0; i < g.size(); ++i) g[i] = ids_[ids[i]];
+        return p_.leaf_upgma_batch(g.data(), offsets, n_groups, kind, modified, left, right);
+    }
     bool clarans(const int* ids, int n_ids, int kind, int n_medoids, int n_fixed, float fraction, int num_local,
                  int* medoids) override
     {
@@ -643,6 +650,32 @@ struct FastTree {
                             const auto& g = subgroups[tasks[t].k];
                             ids.insert(ids.end(), g.begin(), g.end());
                             offs.push_back((int64_t)ids.size());
+                        }
+                        if (partial == GT::UPGMA || partial == GT::UPGMA_modified) {
+                            // the leaves' trees come from the source itself: their LCS triangles never leave the device
+                            std::vector<int32_t> left, right;
+                            bool built;
+                            {
+                                Scope tm(g_phase.lcs);
+                                OffCpu w;
+                                built = src.leaf_upgma_batch(ids.data(), offs.data(), (int)batch.size(), (int)D,
+                                                             partial == GT::UPGMA_modified, left, right);
+                            }
+                            if (built) {
+                                size_t node0 = 0;
+                                for (size_t t : batch) {
+                                    const auto& g = subgroups[tasks[t].k];
+                                    const int m = (int)g.size(), top = tasks[t].top;
+                                    tree_structure& out = locals[t];
+                                    out.resize((size_t)std::max(m - 1, 0));
+                                    for (int node = 0; node < m - 1; ++node) { // local ids -> ids of the whole tree (leaf_tree)
+                                        const int a = left[node0 + node], b = right[node0 + node];
+                                        out[node] = top > m ? node_t(a < m ? g[a] : a + top - m, b < m ? g[b] : b + top - m) : node_t(a, b);
+                                    }
+                                    node0 += (size_t)std::max(m - 1, 0);
+                                }
+                                return;
+                            }
                         }
                         auto buf = std::make_shared<LcsBuf>();
                         bool have;

@@ -1,5 +1,7 @@
 #include "lcs_source.h"
 
+#include <mutex>
+
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
@@ -253,6 +255,59 @@ bool GpuLcsSource::triangles_batch(const int* ids, const int64_t* offsets, int n
         });
     }
     note(st_batch_, now_s() - t0, (double)count);
+    return true;
+}
+
+bool GpuLcsSource::leaf_upgma_batch(const int* ids, const int64_t* offsets, int n_groups, int distance_kind, bool modified,
+                                    std::vector<int32_t>& left, std::vector<int32_t>& right)
+{
+    if (getenv("FAMSA_LEAF_HOST")) return false; // test aid: the leaf trees on the host, as before round 3
+    std::vector<size_t> node0((size_t)n_groups + 1, 0), pairs0((size_t)n_groups + 1, 0);
+    for (int g = 0; g < n_groups; ++g) {
+        const size_t m = (size_t)(offsets[g + 1] - offsets[g]);
+        node0[g + 1] = node0[g] + (m > 0 ? m - 1 : 0);
+        pairs0[g + 1] = pairs0[g] + m * (m > 0 ? m - 1 : 0) / 2;
+    }
+    left.assign(node0[n_groups], 0);
+    right.assign(node0[n_groups], 0);
+    if (node0[n_groups] == 0) return true;
+    const double t0 = now_s();
+    const int parts = (int)std::min<size_t>(ctxs_.size(), (size_t)n_groups);
+    bool unsupported = false;
+    if (parts <= 1 || pairs0[n_groups] < (1u << 16)) {
+        lcsgpu_ctx* c = pick();
+        const int rc = lcsgpu_leaf_upgma_batch(c, ids, offsets, n_groups, distance_kind, modified ? 1 : 0, left.data(), right.data());
+        if (rc == LCSGPU_E_UNSUPPORTED) return false;
+        check(rc, "lcsgpu_leaf_upgma_batch");
+        add_kernel_ms(c);
+    } else { // consecutive lists per device, cut by pair count
+        std::vector<int> cut(parts + 1, n_groups);
+        cut[0] = 0;
+        for (int k = 1; k < parts; ++k) {
+            const size_t target = pairs0[n_groups] / parts * k;
+            int g = cut[k - 1];
+            while (g < n_groups && pairs0[g] < target) ++g;
+            cut[k] = g;
+        }
+        std::mutex mu;
+        on_each_device(parts, [&](int k) {
+            const int g0 = cut[k], g1 = cut[k + 1];
+            if (g1 <= g0) return;
+            std::vector<int64_t> rel((size_t)(g1 - g0) + 1);
+            for (int g = g0; g <= g1; ++g) rel[g - g0] = offsets[g] - offsets[g0];
+            const int rc = lcsgpu_leaf_upgma_batch(ctxs_[k], ids + offsets[g0], rel.data(), g1 - g0, distance_kind, modified ? 1 : 0,
+                                                   left.data() + node0[g0], right.data() + node0[g0]);
+            if (rc == LCSGPU_E_UNSUPPORTED) {
+                std::lock_guard<std::mutex> lk(mu);
+                unsupported = true;
+                return;
+            }
+            if (rc != LCSGPU_OK) throw std::runtime_error(std::string("lcsgpu_leaf_upgma_batch failed: ") + lcsgpu_last_error());
+            add_kernel_ms(ctxs_[k]);
+        });
+    }
+    if (unsupported) return false;
+    note(st_batch_, now_s() - t0, (double)pairs0[n_groups]);
     return true;
 }
 
