@@ -261,7 +261,11 @@ bool GpuLcsSource::triangles_batch(const int* ids, const int64_t* offsets, int n
 bool GpuLcsSource::leaf_upgma_batch(const int* ids, const int64_t* offsets, int n_groups, int distance_kind, bool modified,
                                     std::vector<int32_t>& left, std::vector<int32_t>& right)
 {
-    if (getenv("FAMSA_LEAF_HOST")) return false; // test aid: the leaf trees on the host, as before round 3
+    // Opt-in (FAMSA_LEAF_DEVICE=1).  Measured at 3 000 000 sequences (profiles/c5_leaf_r03.txt): the host spends 6.2
+    // thread-seconds less on leaf trees, but a batch call grows from 3 to 25 ms (a 2000-member leaf is 2000 dependent
+    // merges of ~3 us inside its workgroup) and the CLARANS rounds that share the chip with those long-running
+    // workgroups slow down by 40 % -- tree stage 2.22 -> 2.5-3.0 s.  So the leaves stay on the host's cores by default.
+    if (!getenv("FAMSA_LEAF_DEVICE")) return false;
     std::vector<size_t> node0((size_t)n_groups + 1, 0), pairs0((size_t)n_groups + 1, 0);
     for (int g = 0; g < n_groups; ++g) {
         const size_t m = (size_t)(offsets[g + 1] - offsets[g]);

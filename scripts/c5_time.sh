@@ -1,6 +1,6 @@
 #!/bin/bash
 # dev tool (GPU box): -medoidtree -gt upgma tree stage at 1 000 000 and 3 000 000 family sequences, leaves on the device
-# (default) and on the host (FAMSA_LEAF_HOST=1) -> gpurun_out/c5_time.txt
+# (FAMSA_LEAF_DEVICE=1) and on the host (default) -> gpurun_out/c5_time.txt
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
 python - <<'PY'
@@ -16,11 +16,11 @@ PY
 for n in 1000000 3000000; do
   for leaf in device host; do
     for rep in 1 2; do
-      if [ $leaf = host ]; then export FAMSA_LEAF_HOST=1; else unset FAMSA_LEAF_HOST; fi
+      if [ $leaf = device ]; then export FAMSA_LEAF_DEVICE=1; else unset FAMSA_LEAF_DEVICE; fi
       FAMSA_GPU_PROFILE=1 timeout 300 famsa_amd/famsa-gpu -v -medoidtree -gt upgma -gt_export /tmp/fam_$n.fasta /tmp/fam_$n.dnd 2> /tmp/c5.err
       echo "n=$n leaves=$leaf rc=$? $(grep -E 'time.tree_build|fasttree.partial_trees|fasttree.clarans|fasttree.lcs_calls' /tmp/c5.err | tr '\n' ' ') sha=$(sha256sum /tmp/fam_$n.dnd | cut -c1-16)" >> gpurun_out/c5_time.txt
     done
   done
 done
-unset FAMSA_LEAF_HOST
+unset FAMSA_LEAF_DEVICE
 cat gpurun_out/c5_time.txt
