@@ -2,7 +2,7 @@
 (oracle/make_golden_large.py -> tests/golden/meta_large.json; the inputs are regenerated here by the same
 deterministic generators).  Model: the reference's own at-size regression, .github/workflows/self-hosted.yml:424-461.
 
-  C3  synthetic 10 000 x 400 aa: the u16 LCS triangle and the sl / slink / upgma Newick
+  C3  synthetic 10 000 x 400 aa: the u16 LCS triangle and the sl / slink / upgma / upgma_modified / nj Newick
   C4  synthetic 100 000 x 400 aa: -gt sl Newick (one GPU; the 2-context row-block form too), sampled oracle check;
       -gt upgma / upgma_modified Newick
   C5  'family' sets of 200 000 and 1 000 000 sequences: -medoidtree -gt upgma Newick
@@ -69,8 +69,10 @@ def test_c3_triangle(engine, synth10k):
     assert sha(engine.lcs_triangle().tobytes()) == META["synth10k"]["triangle_u16_sha256"]
 
 
-@pytest.mark.parametrize("gt", ["sl", "slink", "upgma"])
+@pytest.mark.parametrize("gt", ["sl", "slink", "upgma", "upgma_modified", "nj"])
 def test_c3_trees(synth10k, gt):
+    """(upgma_modified and nj were added in round 3 together with -ffp-contract=off: both reducers have a
+    multiply-add the compiler used to fuse.)"""
     got = famsa_amd.guide_tree(synth10k[2], gt)
     assert sha(got) == META["synth10k"][f"{gt}_newick_sha256"]
 
