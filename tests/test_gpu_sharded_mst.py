@@ -176,6 +176,7 @@ def test_row_minima_of_a_row_block(engine, oracle):
             tri = torch.empty(max(pairs_in_rows(r0, r1), 1), dtype=torch.int16, device="cuda:0")
             engine.lcs_triangle_dev(r0, r1, tri.data_ptr(), 2)
             out = torch.zeros((r1 - r0, 2), dtype=torch.float64, device="cuda:0")
+            torch.cuda.synchronize()  # torch fills on ITS stream; the engine writes `out` on its own
             engine.row_minima_dev(tri.data_ptr(), 2, r0, r1, kind, out.data_ptr(), sync=True)
             d = out[:, 0].cpu().numpy()
             j = out[:, 1].cpu().numpy().view(np.int64)
