@@ -110,6 +110,22 @@ def cpu_baseline(n, length, target_s=12.0):
     }
 
 
+def pmc_traffic(n, length, world, my_pairs, total_pairs):
+    """(2 x FETCH_SIZE + WRITE_SIZE) x 1024 of the hot kernel's launch, from profiles/pmc_r*.json (the newest round)."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "pmc_r*.json"))):
+        try:
+            d = json.load(open(path))
+        except Exception:
+            continue
+        if d.get("n_seqs") == n and d.get("seq_len") == length and "traffic_bytes" in d:
+            best = d
+    if best is None or world != 1 or my_pairs != total_pairs:
+        return None
+    return best["traffic_bytes"]
+
+
 def sampled_parity(eng, tri, r0, r1, codes, offsets, n_samples=6000, seed=11):
     """Compare a sample of the rank's triangle in HBM (what the timed steps produced) with the oracle."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -322,7 +338,10 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,  # HBM-side bytes come from the separate PMC passes under profiles/, not from this run
+                # HBM-side bytes per launch: not measurable in this run (PMC passes are separate rocprofv3 runs of this very
+                # command, scripts/profile_round.sh); taken from the committed summary of those passes when it is for this
+                # workload, else null
+                "traffic": pmc_traffic(n, L, world, my_pairs, total_pairs),
                 "kernel": f"lcsgpu::lcs_rows_kernel_pipe<{H}, {4 if H <= 16 else 2 if H <= 32 else 1}, 4, {'true' if fused else 'false'}>",
                 "kernel_ms": k_ms,
                 "algorithmic_bytes_per_pair": L + ALGO_BYTES_PER_PAIR_EXTRA,

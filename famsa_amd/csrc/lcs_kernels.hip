@@ -568,7 +568,7 @@ __global__ __launch_bounds__(256) void lcs_rows_kernel_pipe(RowsArgs a)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int W = (H + 1) / 2;
     using P = Pipe<H, RG, LOOKAHEAD>;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x;
     const int R = a.refs_per_block;
     int ref0, nr, c0, col_limit;
     block_tile(a, R, ref0, nr, c0, col_limit);

@@ -32,7 +32,7 @@ out = {"_comment": "per launch of the hot kernel, default bench workload (n=1000
                    "(rocprof summary next to this file). traffic_bytes = (2*FETCH_SIZE + WRITE_SIZE) KiB * 1024: FETCH_SIZE doubled per the "
                    "gfx950 correction of MI355X_MICROARCH.md", "n_seqs": 100000, "seq_len": 400, "n_gpus": 1}
 for line in txt.splitlines():
-    m = re.match(r"\s+lcsgpu::lcs_rows_kernel_pipe<13, 4, 4>\S*\s+(\w+)\s+n=(\d+)\s+sum=(\d+)\s+mean=([\d.]+)", line)
+    m = re.match(r"\s+lcsgpu::lcs_rows_kernel_pipe<13, 4, 4[^>]*>\S*\s+(\w+)\s+n=(\d+)\s+sum=(\d+)\s+mean=([\d.]+)", line)
     if m:
         out[m.group(1)] = float(m.group(4))
     m = re.match(r"\s+lcsgpu::(boruvka_\w+_kernel)<[^>]*>\S*\s+(FETCH_SIZE|WRITE_SIZE|GRBM_GUI_ACTIVE|SQ_INSTS_VALU|SQ_INSTS_SALU)\s+n=(\d+)\s+sum=(\d+)\s+mean=([\d.]+)", line)
