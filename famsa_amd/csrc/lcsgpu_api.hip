@@ -221,7 +221,9 @@ int run_rows(lcsgpu_ctx* ctx, Lane& L, int mode, const int32_t* ref_ids, int32_t
     HIP_TRY(hipEventRecord(L.ev_start, L.stream));
     // several buckets: their launches go to the lane's side streams (see Lane::aux); the long-ref kernel shares the
     // lane's carry scratch between its launches and stays on the main stream
-    bool spread = buckets.size() > 1 && !getenv("LCSGPU_NO_SPREAD");
+    // -- once the lane has seen a few such calls: creating the side streams costs ~30 ms, which a one-shot run (the CLI
+    // on a small input: 0.3 s in all) would pay for a gain of 0.02 ms
+    bool spread = buckets.size() > 1 && !getenv("LCSGPU_NO_SPREAD") && ++L.multi_bucket_calls > 8;
     if (spread && !L.aux_tried) {
         L.aux_tried = true;
         bool ok = hipEventCreateWithFlags(&L.fork, hipEventDisableTiming) == hipSuccess;

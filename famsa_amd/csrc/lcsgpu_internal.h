@@ -103,6 +103,7 @@ struct Lane {
     hipEvent_t aux_done[N_AUX] = {nullptr, nullptr, nullptr};
     hipEvent_t fork = nullptr;
     bool aux_ok = false, aux_tried = false;
+    int multi_bucket_calls = 0;
     lcsgpu_impl::DevBuf d_plan, d_out, d_carry;
     lcsgpu_impl::DevBuf d_work, d_draws; // CLARANS state and its pre-drawn step positions
     lcsgpu_impl::PinBuf h_plan, h_small;
