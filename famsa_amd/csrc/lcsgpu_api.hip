@@ -221,9 +221,10 @@ int run_rows(lcsgpu_ctx* ctx, Lane& L, int mode, const int32_t* ref_ids, int32_t
     HIP_TRY(hipEventRecord(L.ev_start, L.stream));
     // several buckets: their launches go to the lane's side streams (see Lane::aux); the long-ref kernel shares the
     // lane's carry scratch between its launches and stays on the main stream
-    // -- once the lane has seen a few such calls: creating the side streams costs ~30 ms, which a one-shot run (the CLI
-    // on a small input: 0.3 s in all) would pay for a gain of 0.02 ms
-    bool spread = buckets.size() > 1 && !getenv("LCSGPU_NO_SPREAD") && ++L.multi_bucket_calls > 8;
+    // -- opt-in (LCSGPU_SPREAD=1): measured on hemopexin's 4 launches the overlap is worth 0.02 of 0.26 ms, while creating
+    // the side streams costs a lane ~30 ms once (a one-shot CLI run on a small input is 0.3 s in all)
+    static const bool spread_on = getenv("LCSGPU_SPREAD") != nullptr;
+    bool spread = spread_on && buckets.size() > 1;
     if (spread && !L.aux_tried) {
         L.aux_tried = true;
         bool ok = hipEventCreateWithFlags(&L.fork, hipEventDisableTiming) == hipSuccess;

@@ -97,13 +97,12 @@ struct Lane {
     // A call whose refs fall into several half-word classes is several launches; on one stream they run one after
     // the other, each a few hundred workgroups that leave most of the chip idle (hemopexin: 7 launches, 3.3 ms).
     // They are independent (different refs), so they are spread over these side streams, forked from and joined
-    // back into `stream` by events.  Created when a call first has more than one bucket.
+    // back into `stream` by events.  Opt-in (LCSGPU_SPREAD=1): see run_rows.
     static constexpr int N_AUX = 3;
     hipStream_t aux[N_AUX] = {nullptr, nullptr, nullptr};
     hipEvent_t aux_done[N_AUX] = {nullptr, nullptr, nullptr};
     hipEvent_t fork = nullptr;
     bool aux_ok = false, aux_tried = false;
-    int multi_bucket_calls = 0;
     lcsgpu_impl::DevBuf d_plan, d_out, d_carry;
     lcsgpu_impl::DevBuf d_work, d_draws; // CLARANS state and its pre-drawn step positions
     lcsgpu_impl::PinBuf h_plan, h_small;
