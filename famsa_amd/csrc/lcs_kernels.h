@@ -185,7 +185,19 @@ struct UpgmaArgs {
     int32_t* right;
     int32_t n;
     int32_t n_blocks;
+    uint32_t* chain_ctl;   // 64 words, zeroed: [0] tickets of the merge chain's workgroups, [32] its barrier counter
+    uint32_t* chain_slots; // [2][UPGMA_CHAIN_MAX_WG][8] the workgroups' partial minima of a merge, alternating by parity
 };
+// distances + initial row minima; then EITHER the n launches of the merge steps ...
+hipError_t launch_upgma_prologue(const UpgmaArgs& a, const void* lcs, int elem_size, const uint32_t* lens, const float* pow_f32,
+                                 int kind, hipStream_t stream);
+hipError_t launch_upgma_steps(const UpgmaArgs& a, bool modified, hipStream_t stream);
+// ... OR all merges inside one kernel whose workgroups run on ONE XCD (square layout only; tree_kernels.hip).  a.sel[9]
+// afterwards: 1 = done, 2 = the workgroups could not be assembled (nothing was touched: run the steps), 3 = lost on the way
+constexpr int UPGMA_CHAIN_MAX_WG = 32;
+constexpr int UPGMA_CHAIN_THREADS = 1024;
+constexpr int UPGMA_CHAIN_ROWS = 8; // rows per thread at most
+hipError_t launch_upgma_chain(const UpgmaArgs& a, bool modified, int n_workgroups, hipStream_t stream);
 hipError_t launch_upgma(const UpgmaArgs& a, const void* lcs, int elem_size, const uint32_t* lens,
                         const float* pow_f32, int kind, bool modified, hipStream_t stream);
 

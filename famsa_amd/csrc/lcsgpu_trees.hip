@@ -751,11 +751,12 @@ int upgma_reduce(lcsgpu_ctx* ctx, Lane& L, int elem, int distance_kind, int modi
     const size_t o_min = 0, o_near = o_min + a16((size_t)n * 4), o_node = o_near + a16((size_t)n * 4),
                  o_pd = o_node + a16((size_t)n * 4), o_pj = o_pd + a16((size_t)2 * blocks * 4),
                  o_bd = o_pj + a16((size_t)2 * blocks * 4), o_bj = o_bd + a16((size_t)blocks * 4),
-                 o_bn = o_bj + a16((size_t)blocks * 4), o_sel = o_bn + a16((size_t)blocks * 4), o_left = o_sel + 256,
+                 o_bn = o_bj + a16((size_t)blocks * 4), o_sel = o_bn + a16((size_t)blocks * 4), o_ctl = o_sel + 256,
+                 o_slots = o_ctl + 256, o_left = o_slots + (size_t)2 * lcsgpu::UPGMA_CHAIN_MAX_WG * 8 * 4,
                  o_right = o_left + a16((size_t)n * 4), total = o_right + a16((size_t)n * 4);
     HIP_TRY(ctx->d_prim.reserve(total));
     char* base = (char*)ctx->d_prim.p;
-    HIP_TRY(hipMemsetAsync(base + o_sel, 0, 256, L.stream));
+    HIP_TRY(hipMemsetAsync(base + o_sel, 0, o_left - o_sel, L.stream)); // flags, the chain's tickets / barrier counter / slots
     lcsgpu::UpgmaArgs a{};
     a.bm_d = (float*)(base + o_bd);
     a.bm_j = (uint32_t*)(base + o_bj);
@@ -768,13 +769,35 @@ int upgma_reduce(lcsgpu_ctx* ctx, Lane& L, int elem, int distance_kind, int modi
     a.part_d = (float*)(base + o_pd);
     a.part_j = (uint32_t*)(base + o_pj);
     a.sel = (uint32_t*)(base + o_sel);
+    a.chain_ctl = (uint32_t*)(base + o_ctl);
+    a.chain_slots = (uint32_t*)(base + o_slots);
     a.left = (int32_t*)(base + o_left);
     a.right = (int32_t*)(base + o_right);
     a.n = n;
     a.n_blocks = blocks;
-    HIP_TRY(lcsgpu::launch_upgma(a, L.d_out.p, elem, (const uint32_t*)ctx->d_lens.p, (const float*)ctx->d_powf.p,
-                                 distance_kind, modified != 0, L.stream));
+    HIP_TRY(lcsgpu::launch_upgma_prologue(a, L.d_out.p, elem, (const uint32_t*)ctx->d_lens.p, (const float*)ctx->d_powf.p,
+                                          distance_kind, L.stream));
+    // The n-1 merges: inside ONE kernel whose workgroups all run on one XCD and synchronise through its L2
+    // (tree_kernels.hip, upgma_chain_kernel) when the distances are the symmetric matrix; else -- or if that kernel could
+    // not assemble its workgroups, in which case it has touched nothing -- one launch per merge.
     uint32_t sel[12] = {0};
+    bool merged = false;
+    int wg = std::max(4, std::min<int>(lcsgpu::UPGMA_CHAIN_MAX_WG, (n + 4 * lcsgpu::UPGMA_CHAIN_THREADS - 1) / (4 * lcsgpu::UPGMA_CHAIN_THREADS)));
+    if (const char* e = getenv("LCSGPU_UPGMA_CHAIN_WG")) wg = std::max(1, std::min<int>(lcsgpu::UPGMA_CHAIN_MAX_WG, atoi(e)));
+    const bool chain_fits = (int64_t)wg * lcsgpu::UPGMA_CHAIN_THREADS * lcsgpu::UPGMA_CHAIN_ROWS >= n;
+    const char* chain_env = getenv("LCSGPU_UPGMA_CHAIN"); // "0" = always one launch per merge
+    if (square && chain_fits && n >= 64 && !(chain_env && !strcmp(chain_env, "0"))) {
+        HIP_TRY(lcsgpu::launch_upgma_chain(a, modified != 0, wg, L.stream));
+        HIP_TRY(hipMemcpyAsync(sel, a.sel, 48, hipMemcpyDeviceToHost, L.stream));
+        HIP_TRY(hipStreamSynchronize(L.stream));
+        if (sel[9] == 1) merged = true;
+        else if (sel[9] == 2) {
+            if (getenv("LCSGPU_PROFILE")) fprintf(stderr, "lcsgpu_upgma: the one-XCD merge kernel could not assemble %d workgroups; one launch per merge\n", wg);
+            HIP_TRY(hipMemsetAsync(base + o_sel, 0, 256, L.stream));
+        } else
+            return fail(LCSGPU_E_HIP, "UPGMA: the merge kernel lost its workgroups on the way (status %u)", sel[9]);
+    }
+    if (!merged) HIP_TRY(lcsgpu::launch_upgma_steps(a, modified != 0, L.stream));
     HIP_TRY(hipMemcpyAsync(out_left, a.left, (size_t)(n - 1) * 4, hipMemcpyDeviceToHost, L.stream));
     HIP_TRY(hipMemcpyAsync(out_right, a.right, (size_t)(n - 1) * 4, hipMemcpyDeviceToHost, L.stream));
     HIP_TRY(hipMemcpyAsync(sel, a.sel, 48, hipMemcpyDeviceToHost, L.stream));

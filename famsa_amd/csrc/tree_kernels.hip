@@ -514,8 +514,200 @@ __global__ __launch_bounds__(256) void upgma_step_kernel(UpgmaArgs a, int it)
     }
 }
 
-hipError_t launch_upgma(const UpgmaArgs& a, const void* lcs, int elem_size, const uint32_t* lens,
-                        const float* pow_f32, int kind, bool modified, hipStream_t stream)
+// ---- all merges in ONE kernel whose workgroups run on ONE XCD ----------------------------------------------------
+// One launch per merge costs ~9 us (a dependent launch, a level of loads, four block reductions, the two rows); a
+// device-wide barrier inside a persistent kernel costs more still (ubench_gridbar.hip: 20 us with 391 workgroups) because
+// ordinary device memory is only made coherent between the eight XCDs' L2 caches by writing back and invalidating them.
+// Workgroups on the SAME XCD share one L2 (scripts/ubench_xcd.hip: 16 workgroups, barrier + read-back 1.8 us per step,
+// not one stale read in 20 000 steps; the same code over all XCDs reads stale data at once): a barrier is an atomic at
+// that L2, a store is visible to the others once it has left the CU (write-through L1, s_waitcnt), and a reader only has
+// to bypass its own L1 (sc1 loads) -- no fence wider than the workgroup.  The kernel is launched with more workgroups
+// than it needs; each reads the hardware register XCC_ID, those on XCD 0 take a ticket, the first P of them take part
+// and the rest exit at once.  A thread owns up to 8 rows (row statistics in registers), a merge is: the two rows of the
+// symmetric matrix (sc1 loads), the new distances and their mirror, two partial minima per workgroup -> slots -> ONE
+// barrier -> every workgroup reduces the P slots and knows the new row's minimum and the next (Lmin, Rmin).
+// Semantics are upgma_step_kernel's (= UPGMA::computeTree, tree/UPGMA.cpp:198-288), statement for statement.
+__device__ __forceinline__ unsigned chain_xcc_id()
+{
+    return (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xFu; // hwreg(HW_REG_XCC_ID), 32 bits
+}
+__device__ __forceinline__ uint32_t chain_ld(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float chain_ld(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__device__ __forceinline__ bool chain_barrier(uint32_t* counter, uint32_t target, int max_spins)
+{
+    __builtin_amdgcn_s_waitcnt(0); // this lane's stores have been acknowledged by the L2
+    __syncthreads();
+    __shared__ int s_ok;
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int spins = 0, ok = 1;
+        while (chain_ld(counter) < target)
+            if (++spins > max_spins) { ok = 0; break; }
+        s_ok = ok;
+    }
+    __syncthreads();
+    return s_ok != 0;
+}
+
+// (d, j, nr) first minimum over the workgroup's 1024 threads, result in every thread
+__device__ __forceinline__ void chain_wg_min3(float& d, uint32_t& j, uint32_t& nr, float* s_d, uint32_t* s_j, uint32_t* s_n)
+{
+    for (int off = 32; off > 0; off >>= 1) {
+        const float d2 = __shfl_xor(d, off);
+        const uint32_t j2 = __shfl_xor(j, off), n2 = __shfl_xor(nr, off);
+        if (d2 < d || (d2 == d && j2 < j)) { d = d2; j = j2; nr = n2; }
+    }
+    const int tid = threadIdx.x, w = tid >> 6;
+    __syncthreads();
+    if ((tid & 63) == 0) { s_d[w] = d; s_j[w] = j; s_n[w] = nr; }
+    __syncthreads();
+    d = s_d[0]; j = s_j[0]; nr = s_n[0];
+#pragma unroll
+    for (int k = 1; k < UPGMA_CHAIN_THREADS / 64; ++k) {
+        const float d2 = s_d[k];
+        const uint32_t j2 = s_j[k];
+        if (d2 < d || (d2 == d && j2 < j)) { d = d2; j = j2; nr = s_n[k]; }
+    }
+}
+
+template <bool MODIFIED>
+__global__ __launch_bounds__(UPGMA_CHAIN_THREADS) void upgma_chain_kernel(UpgmaArgs a, int P, unsigned want_xcd)
+{
+    __shared__ unsigned s_rank;
+    __shared__ float s_d[16];
+    __shared__ uint32_t s_j[16], s_n[16];
+    const int tid = threadIdx.x, n = a.n;
+    if (tid == 0) {
+        unsigned r = ~0u;
+        if (chain_xcc_id() == want_xcd) r = atomicAdd(&a.chain_ctl[0], 1u);
+        s_rank = r;
+    }
+    __syncthreads();
+    const unsigned rank = s_rank;
+    if (rank >= (unsigned)P) return;
+    uint32_t* bar = a.chain_ctl + 32;
+    uint32_t epoch = 0;
+    // assembly: if XCD `want_xcd` did not receive P workgroups nobody gets past this, and nothing has been touched
+    if (!chain_barrier(bar, ++epoch * P, 2000000)) {
+        if (tid == 0) atomicMax(&a.sel[9], 2u);
+        return;
+    }
+    const int T = P * UPGMA_CHAIN_THREADS, g = (int)rank * UPGMA_CHAIN_THREADS + tid;
+    float md[UPGMA_CHAIN_ROWS];
+    uint32_t nr[UPGMA_CHAIN_ROWS];
+    unsigned alive = 0;
+#pragma unroll
+    for (int k = 0; k < UPGMA_CHAIN_ROWS; ++k) {
+        const int j = g + k * T;
+        md[k] = UPGMA_BIG;
+        nr[k] = UPGMA_NONE;
+        if (j < n) {
+            md[k] = a.min_dist[j];
+            nr[k] = a.nearest[j];
+            alive |= 1u << k;
+        }
+    }
+    float* D = a.D;
+    uint32_t L = UPGMA_NONE, R = UPGMA_NONE; // the merge being applied
+    float new_d = UPGMA_BIG;                 // the previous merge's new row: its minimum and nearest
+    uint32_t new_j = UPGMA_NONE;
+    for (int it = -1; it < n - 1; ++it) {
+        // ---- apply merge `it` (it = -1: nothing to apply, only the first pick) ----
+        float nd = UPGMA_BIG;
+        uint32_t nj = UPGMA_NONE, nn = UPGMA_NONE;
+        if (it >= 0) {
+            const size_t rowL = (size_t)L * (size_t)n, rowR = (size_t)R * (size_t)n;
+#pragma unroll
+            for (int k = 0; k < UPGMA_CHAIN_ROWS; ++k) {
+                const int j = g + k * T;
+                if (!((alive >> k) & 1u) || (uint32_t)j == L || (uint32_t)j == R) continue;
+                const float dL = chain_ld(D + rowL + j), dR = chain_ld(D + rowR + j);
+                float v;
+                if (MODIFIED) v = __fadd_rn(__fmul_rn(0.05f, __fadd_rn(dL, dR)), __fmul_rn(0.9f, fminf(dL, dR)));
+                else v = __fmul_rn(__fadd_rn(dL, dR), 0.5f);
+                if (nr[k] == R) nr[k] = L;
+                D[rowL + j] = v;
+                D[(size_t)j * (size_t)n + L] = v; // the mirror
+                if (v < nd) { nd = v; nj = (uint32_t)j; } // ascending j inside the thread
+            }
+#pragma unroll
+            for (int k = 0; k < UPGMA_CHAIN_ROWS; ++k)
+                if ((uint32_t)(g + k * T) == R) alive &= ~(1u << k); // the right child's row is deleted
+            if (rank == 0 && tid == 0) { // tree bookkeeping: node_index is this thread's alone
+                a.left[it] = (int32_t)a.node_index[L];
+                a.right[it] = (int32_t)a.node_index[R];
+                a.node_index[L] = (uint32_t)n + (uint32_t)it;
+                a.node_index[R] = UPGMA_NONE;
+            }
+            if (it == n - 2) break; // the last merge needs no successor
+        }
+        // ---- this workgroup's candidates for the next pick: its rows other than Lmin (whose new minimum is pending) ----
+        float cd = UPGMA_BIG;
+        uint32_t cj = UPGMA_NONE, cn = UPGMA_NONE;
+#pragma unroll
+        for (int k = 0; k < UPGMA_CHAIN_ROWS; ++k) {
+            const int j = g + k * T;
+            if (((alive >> k) & 1u) && (uint32_t)j != L) take_first_min3(md[k], (uint32_t)j, nr[k], cd, cj, cn);
+        }
+        chain_wg_min3(nd, nj, nn, s_d, s_j, s_n);
+        chain_wg_min3(cd, cj, cn, s_d, s_j, s_n);
+        const int par = (it + 1) & 1;
+        uint32_t* slots = a.chain_slots + (size_t)par * UPGMA_CHAIN_MAX_WG * 8;
+        if (tid == 0) {
+            uint32_t* s = slots + rank * 8;
+            s[0] = __float_as_uint(nd);
+            s[1] = nj;
+            s[2] = __float_as_uint(cd);
+            s[3] = cj;
+            s[4] = cn;
+        }
+        if (!chain_barrier(bar, ++epoch * P, 40000000)) {
+            if (tid == 0) atomicMax(&a.sel[9], 3u);
+            return;
+        }
+        // ---- every workgroup: the new row's minimum, then the pick, from the P slots ----
+        float gd = UPGMA_BIG, pd = UPGMA_BIG;
+        uint32_t gj = UPGMA_NONE, pj = UPGMA_NONE, pn = UPGMA_NONE;
+        const int lane = tid & 63;
+        if (lane < P) {
+            const uint32_t* s = slots + lane * 8;
+            gd = __uint_as_float(chain_ld(s + 0));
+            gj = chain_ld(s + 1);
+            pd = __uint_as_float(chain_ld(s + 2));
+            pj = chain_ld(s + 3);
+            pn = chain_ld(s + 4);
+            if (!(gd < UPGMA_BIG)) { gd = UPGMA_BIG; gj = UPGMA_NONE; }
+            if (!(pd < UPGMA_BIG)) { pd = UPGMA_BIG; pj = UPGMA_NONE; pn = UPGMA_NONE; }
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            const float d2 = __shfl_xor(gd, off);
+            const uint32_t j2 = __shfl_xor(gj, off);
+            if (d2 < gd || (d2 == gd && j2 < gj)) { gd = d2; gj = j2; }
+            const float d3 = __shfl_xor(pd, off);
+            const uint32_t j3 = __shfl_xor(pj, off), n3 = __shfl_xor(pn, off);
+            if (d3 < pd || (d3 == pd && j3 < pj)) { pd = d3; pj = j3; pn = n3; }
+        }
+        if (it >= 0) { // the merged row takes its new minimum and takes part in the pick
+            new_d = gd;
+            new_j = gj;
+#pragma unroll
+            for (int k = 0; k < UPGMA_CHAIN_ROWS; ++k)
+                if ((uint32_t)(g + k * T) == L) { md[k] = new_d; nr[k] = new_j; }
+            take_first_min3(new_d, L, new_j, pd, pj, pn);
+        }
+        L = pj;
+        R = pn;
+        if (L == UPGMA_NONE || R == UPGMA_NONE || R >= (uint32_t)n) { // degenerate input (the reference: undefined)
+            if (rank == 0 && tid == 0) a.sel[8] = 1;
+            break;
+        }
+    }
+    if (rank == 0 && tid == 0) atomicMax(&a.sel[9], 1u);
+}
+
+hipError_t launch_upgma_prologue(const UpgmaArgs& a, const void* lcs, int elem_size, const uint32_t* lens, const float* pow_f32,
+                                 int kind, hipStream_t stream)
 {
     const int n = a.n;
     if (a.square) {
@@ -536,6 +728,12 @@ hipError_t launch_upgma(const UpgmaArgs& a, const void* lcs, int elem_size, cons
                                pow_f32, kind, n, a.D);
         hipLaunchKernelGGL(upgma_init_kernel<false>, dim3(n), dim3(256), 0, stream, a);
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_upgma_steps(const UpgmaArgs& a, bool modified, hipStream_t stream)
+{
+    const int n = a.n;
     hipLaunchKernelGGL(upgma_block_min_kernel, dim3(a.n_blocks), dim3(256), 0, stream, a);
     for (int it = 0; it < n; ++it) {
 #define UPGMA_STEP(M, S) hipLaunchKernelGGL((upgma_step_kernel<M, S>), dim3(a.n_blocks), dim3(256), 0, stream, a, it)
@@ -544,6 +742,23 @@ hipError_t launch_upgma(const UpgmaArgs& a, const void* lcs, int elem_size, cons
 #undef UPGMA_STEP
     }
     return hipGetLastError();
+}
+
+hipError_t launch_upgma_chain(const UpgmaArgs& a, bool modified, int P, hipStream_t stream)
+{
+    // workgroups go to the XCDs round robin: 8 x (P + 8) of them give XCD 0 P + 8; which of them take part is decided by
+    // where they really run (XCC_ID), not by this expectation
+    const dim3 grid((unsigned)(8 * (P + 8)));
+    if (modified) hipLaunchKernelGGL(upgma_chain_kernel<true>, grid, dim3(UPGMA_CHAIN_THREADS), 0, stream, a, P, 0u);
+    else hipLaunchKernelGGL(upgma_chain_kernel<false>, grid, dim3(UPGMA_CHAIN_THREADS), 0, stream, a, P, 0u);
+    return hipGetLastError();
+}
+
+hipError_t launch_upgma(const UpgmaArgs& a, const void* lcs, int elem_size, const uint32_t* lens,
+                        const float* pow_f32, int kind, bool modified, hipStream_t stream)
+{
+    hipError_t e = launch_upgma_prologue(a, lcs, elem_size, lens, pow_f32, kind, stream);
+    return e != hipSuccess ? e : launch_upgma_steps(a, modified, stream);
 }
 
 } // namespace lcsgpu
