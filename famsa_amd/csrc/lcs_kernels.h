@@ -187,6 +187,7 @@ struct UpgmaArgs {
     int32_t n_blocks;
     uint32_t* chain_ctl;   // 64 words, zeroed: [0] tickets of the merge chain's workgroups, [32] its barrier counter
     uint32_t* chain_slots; // [2][UPGMA_CHAIN_MAX_WG][8] the workgroups' partial minima of a merge, alternating by parity
+    unsigned long long* chain_dbg; // measurement aid (LCSGPU_UPGMA_CHAIN_DBG): 8 phase totals in 10 ns ticks, or NULL
 };
 // distances + initial row minima; then EITHER the n launches of the merge steps ...
 hipError_t launch_upgma_prologue(const UpgmaArgs& a, const void* lcs, int elem_size, const uint32_t* lens, const float* pow_f32,

@@ -771,12 +771,18 @@ int upgma_reduce(lcsgpu_ctx* ctx, Lane& L, int elem, int distance_kind, int modi
     a.sel = (uint32_t*)(base + o_sel);
     a.chain_ctl = (uint32_t*)(base + o_ctl);
     a.chain_slots = (uint32_t*)(base + o_slots);
+    a.chain_dbg = getenv("LCSGPU_UPGMA_CHAIN_DBG") ? (unsigned long long*)(base + o_sel + 128) : nullptr; // 8 x 8 B inside the flag block
     a.left = (int32_t*)(base + o_left);
     a.right = (int32_t*)(base + o_right);
     a.n = n;
     a.n_blocks = blocks;
+    const bool profile = getenv("LCSGPU_PROFILE") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_pro = 0, t_merge = 0;
+    if (profile) { HIP_TRY(hipStreamSynchronize(L.stream)); t_pro = now(); }
     HIP_TRY(lcsgpu::launch_upgma_prologue(a, L.d_out.p, elem, (const uint32_t*)ctx->d_lens.p, (const float*)ctx->d_powf.p,
                                           distance_kind, L.stream));
+    if (profile) { HIP_TRY(hipStreamSynchronize(L.stream)); t_merge = now(); }
     // The n-1 merges: inside ONE kernel whose workgroups all run on one XCD and synchronise through its L2
     // (tree_kernels.hip, upgma_chain_kernel) when the distances are the symmetric matrix; else -- or if that kernel could
     // not assemble its workgroups, in which case it has touched nothing -- one launch per merge.
@@ -791,6 +797,12 @@ int upgma_reduce(lcsgpu_ctx* ctx, Lane& L, int elem, int distance_kind, int modi
         HIP_TRY(hipMemcpyAsync(sel, a.sel, 48, hipMemcpyDeviceToHost, L.stream));
         HIP_TRY(hipStreamSynchronize(L.stream));
         if (sel[9] == 1) merged = true;
+        if (a.chain_dbg) {
+            unsigned long long tk[8];
+            HIP_TRY(hipMemcpy(tk, a.chain_dbg, 64, hipMemcpyDeviceToHost));
+            static const char* what[6] = {"rows arrive", "averages + stores issued", "stores acknowledged", "workgroup minima", "barrier", "slots"};
+            for (int i = 0; i < 6; ++i) fprintf(stderr, "  chain phase %-26s %.2f us per merge\n", what[i], tk[i] * 0.01 / std::max(n - 1, 1));
+        }
         else if (sel[9] == 2) {
             if (getenv("LCSGPU_PROFILE")) fprintf(stderr, "lcsgpu_upgma: the one-XCD merge kernel could not assemble %d workgroups; one launch per merge\n", wg);
             HIP_TRY(hipMemsetAsync(base + o_sel, 0, 256, L.stream));
@@ -803,6 +815,10 @@ int upgma_reduce(lcsgpu_ctx* ctx, Lane& L, int elem, int distance_kind, int modi
     HIP_TRY(hipMemcpyAsync(sel, a.sel, 48, hipMemcpyDeviceToHost, L.stream));
     HIP_TRY(hipStreamSynchronize(L.stream));
     L.plan_in_flight = false;
+    if (profile)
+        fprintf(stderr, "lcsgpu_upgma: n = %d, %s layout, distances + row minima %.3f s, %d merges %.3f s = %.2f us each (%s)\n", n,
+                square ? "square" : "triangle", t_merge - t_pro, n - 1, now() - t_merge, 1e6 * (now() - t_merge) / std::max(n - 1, 1),
+                merged ? "one kernel on one XCD" : "one launch per merge");
     if (sel[8])
         return fail(LCSGPU_E_INVALID, "UPGMA: no finite nearest neighbour (a pair with LCS 0?) -- the reference's "
                                       "algorithm is undefined for this input");

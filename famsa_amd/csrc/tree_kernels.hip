@@ -294,16 +294,75 @@ __global__ __launch_bounds__(256) void upgma_init_kernel(UpgmaArgs a)
     }
 }
 
+// ---- wave-level (value, index) minimum by DPP ------------------------------------------------------------------------
+// __shfl_xor compiles to ds_bpermute_b32 -- a trip through the LDS crossbar per value and step -- and a reduction of a
+// (float, index) pair took ~0.6 us per wave; the merge kernels do four of them per merge.  The data-parallel-primitive
+// controls of gfx9 move a value between lanes inside the VALU (quad_perm, row_half_mirror, row_mirror: a butterfly inside
+// a row of 16 lanes; row_bcast:15 / row_bcast:31: the rows' totals into the next row / the upper half), six steps, the
+// result in lane 63, read out as a wave-uniform value.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROW_MASK, 0xF, false); // lanes not written keep v
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void dpp_min_step(float& d, uint32_t& j)
+{
+    const float d2 = __uint_as_float(dpp_u32<CTRL, ROW_MASK>(__float_as_uint(d)));
+    const uint32_t j2 = dpp_u32<CTRL, ROW_MASK>(j);
+    if (d2 < d || (d2 == d && j2 < j)) { d = d2; j = j2; }
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void dpp_min_step3(float& d, uint32_t& j, uint32_t& nr)
+{
+    const float d2 = __uint_as_float(dpp_u32<CTRL, ROW_MASK>(__float_as_uint(d)));
+    const uint32_t j2 = dpp_u32<CTRL, ROW_MASK>(j), n2 = dpp_u32<CTRL, ROW_MASK>(nr);
+    if (d2 < d || (d2 == d && j2 < j)) { d = d2; j = j2; nr = n2; }
+}
+constexpr int DPP_QUAD_1032 = 0xB1, DPP_QUAD_2301 = 0x4E, DPP_ROW_HALF_MIRROR = 0x141, DPP_ROW_MIRROR = 0x140,
+              DPP_ROW_BCAST15 = 0x142, DPP_ROW_BCAST31 = 0x143;
+// the wave's (smaller value, then smaller index): in every lane of the last row, returned wave-uniform
+__device__ __forceinline__ void wave_first_min(float& d, uint32_t& j)
+{
+    dpp_min_step<DPP_QUAD_1032, 0xF>(d, j);
+    dpp_min_step<DPP_QUAD_2301, 0xF>(d, j);
+    dpp_min_step<DPP_ROW_HALF_MIRROR, 0xF>(d, j);
+    dpp_min_step<DPP_ROW_MIRROR, 0xF>(d, j);
+    dpp_min_step<DPP_ROW_BCAST15, 0xA>(d, j);
+    dpp_min_step<DPP_ROW_BCAST31, 0xC>(d, j);
+    d = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(d), 63));
+    j = (uint32_t)__builtin_amdgcn_readlane((int)j, 63);
+}
+__device__ __forceinline__ void wave_first_min3(float& d, uint32_t& j, uint32_t& nr)
+{
+    dpp_min_step3<DPP_QUAD_1032, 0xF>(d, j, nr);
+    dpp_min_step3<DPP_QUAD_2301, 0xF>(d, j, nr);
+    dpp_min_step3<DPP_ROW_HALF_MIRROR, 0xF>(d, j, nr);
+    dpp_min_step3<DPP_ROW_MIRROR, 0xF>(d, j, nr);
+    dpp_min_step3<DPP_ROW_BCAST15, 0xA>(d, j, nr);
+    dpp_min_step3<DPP_ROW_BCAST31, 0xC>(d, j, nr);
+    d = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(d), 63));
+    j = (uint32_t)__builtin_amdgcn_readlane((int)j, 63);
+    nr = (uint32_t)__builtin_amdgcn_readlane((int)nr, 63);
+}
+// the same over the first 16 lanes only (one row): quad butterflies + the two mirrors; result from lane 0
+__device__ __forceinline__ void row_first_min3(float& d, uint32_t& j, uint32_t& nr)
+{
+    dpp_min_step3<DPP_QUAD_1032, 0xF>(d, j, nr);
+    dpp_min_step3<DPP_QUAD_2301, 0xF>(d, j, nr);
+    dpp_min_step3<DPP_ROW_HALF_MIRROR, 0xF>(d, j, nr);
+    dpp_min_step3<DPP_ROW_MIRROR, 0xF>(d, j, nr);
+    d = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(d)));
+    j = (uint32_t)__builtin_amdgcn_readfirstlane((int)j);
+    nr = (uint32_t)__builtin_amdgcn_readfirstlane((int)nr);
+}
+
 // (value, index) minimum of a workgroup: smaller value, then smaller index; values >= UPGMA_BIG never win
 // against the (UPGMA_BIG, UPGMA_NONE) start ("dtDist < dtMinDist" from BIG_DIST in the reference)
 __device__ __forceinline__ void block_first_min(float& d, uint32_t& j, float* s_d, uint32_t* s_j)
 {
-    // inside a wave by lane exchange, then the 4 wave results through LDS: two barriers per reduction
-    for (int off = 32; off > 0; off >>= 1) {
-        const float d2 = __shfl_xor(d, off);
-        const uint32_t j2 = __shfl_xor(j, off);
-        if (d2 < d || (d2 == d && j2 < j)) { d = d2; j = j2; }
-    }
+    // inside a wave by DPP (wave_first_min), then the 4 wave results through LDS: two barriers per reduction
+    wave_first_min(d, j);
     const int tid = threadIdx.x;
     __syncthreads(); // the previous reduction's readers are done with s_d / s_j
     if ((tid & 63) == 0) {
@@ -553,22 +612,15 @@ __device__ __forceinline__ bool chain_barrier(uint32_t* counter, uint32_t target
 // (d, j, nr) first minimum over the workgroup's 1024 threads, result in every thread
 __device__ __forceinline__ void chain_wg_min3(float& d, uint32_t& j, uint32_t& nr, float* s_d, uint32_t* s_j, uint32_t* s_n)
 {
-    for (int off = 32; off > 0; off >>= 1) {
-        const float d2 = __shfl_xor(d, off);
-        const uint32_t j2 = __shfl_xor(j, off), n2 = __shfl_xor(nr, off);
-        if (d2 < d || (d2 == d && j2 < j)) { d = d2; j = j2; nr = n2; }
-    }
+    wave_first_min3(d, j, nr);
     const int tid = threadIdx.x, w = tid >> 6;
     __syncthreads();
     if ((tid & 63) == 0) { s_d[w] = d; s_j[w] = j; s_n[w] = nr; }
     __syncthreads();
-    d = s_d[0]; j = s_j[0]; nr = s_n[0];
-#pragma unroll
-    for (int k = 1; k < UPGMA_CHAIN_THREADS / 64; ++k) {
-        const float d2 = s_d[k];
-        const uint32_t j2 = s_j[k];
-        if (d2 < d || (d2 == d && j2 < j)) { d = d2; j = j2; nr = s_n[k]; }
-    }
+    // the 16 waves' results: one per lane of a row, reduced by every wave for itself (no third barrier)
+    const int l = tid & 15;
+    d = s_d[l]; j = s_j[l]; nr = s_n[l];
+    row_first_min3(d, j, nr);
 }
 
 template <bool MODIFIED>
@@ -594,6 +646,7 @@ __global__ __launch_bounds__(UPGMA_CHAIN_THREADS) void upgma_chain_kernel(UpgmaA
         return;
     }
     const int T = P * UPGMA_CHAIN_THREADS, g = (int)rank * UPGMA_CHAIN_THREADS + tid;
+    const int kmax = (n + T - 1) / T; // rows per thread in use (wave-uniform)
     float md[UPGMA_CHAIN_ROWS];
     uint32_t nr[UPGMA_CHAIN_ROWS];
     unsigned alive = 0;
@@ -609,6 +662,15 @@ __global__ __launch_bounds__(UPGMA_CHAIN_THREADS) void upgma_chain_kernel(UpgmaA
         }
     }
     float* D = a.D;
+    const bool dbg = a.chain_dbg != nullptr && rank == 0; // phase timing (wall_clock64: 100 MHz), workgroup 0 only
+    unsigned long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = 0;
+#define CHAIN_TICK(i)                                                        \
+    if (dbg) {                                                               \
+        const unsigned long long t_now = wall_clock64();                     \
+        tk[i] += t_now - t_prev;                                             \
+        t_prev = t_now;                                                      \
+    }
+    if (dbg) t_prev = wall_clock64();
     uint32_t L = UPGMA_NONE, R = UPGMA_NONE; // the merge being applied
     float new_d = UPGMA_BIG;                 // the previous merge's new row: its minimum and nearest
     uint32_t new_j = UPGMA_NONE;
@@ -618,11 +680,22 @@ __global__ __launch_bounds__(UPGMA_CHAIN_THREADS) void upgma_chain_kernel(UpgmaA
         uint32_t nj = UPGMA_NONE, nn = UPGMA_NONE;
         if (it >= 0) {
             const size_t rowL = (size_t)L * (size_t)n, rowR = (size_t)R * (size_t)n;
+            // all of this thread's elements of the two rows are requested before the first is used (clamped addresses, no
+            // branch in between): ONE trip to memory per merge, not one per row the thread owns
+            float dLv[UPGMA_CHAIN_ROWS], dRv[UPGMA_CHAIN_ROWS];
+#pragma unroll
+            for (int k = 0; k < UPGMA_CHAIN_ROWS; ++k)
+                if (k < kmax) {
+                    const int jc = min(g + k * T, n - 1);
+                    dLv[k] = chain_ld(D + rowL + jc);
+                    dRv[k] = chain_ld(D + rowR + jc);
+                }
+            if (dbg) { __builtin_amdgcn_s_waitcnt(0); CHAIN_TICK(0) } // the two rows have arrived
 #pragma unroll
             for (int k = 0; k < UPGMA_CHAIN_ROWS; ++k) {
                 const int j = g + k * T;
-                if (!((alive >> k) & 1u) || (uint32_t)j == L || (uint32_t)j == R) continue;
-                const float dL = chain_ld(D + rowL + j), dR = chain_ld(D + rowR + j);
+                if (k >= kmax || !((alive >> k) & 1u) || (uint32_t)j == L || (uint32_t)j == R) continue;
+                const float dL = dLv[k], dR = dRv[k];
                 float v;
                 if (MODIFIED) v = __fadd_rn(__fmul_rn(0.05f, __fadd_rn(dL, dR)), __fmul_rn(0.9f, fminf(dL, dR)));
                 else v = __fmul_rn(__fadd_rn(dL, dR), 0.5f);
@@ -641,6 +714,8 @@ __global__ __launch_bounds__(UPGMA_CHAIN_THREADS) void upgma_chain_kernel(UpgmaA
                 a.node_index[R] = UPGMA_NONE;
             }
             if (it == n - 2) break; // the last merge needs no successor
+            CHAIN_TICK(1) // averages, stores issued
+            if (dbg) { __builtin_amdgcn_s_waitcnt(0); CHAIN_TICK(2) } // stores acknowledged
         }
         // ---- this workgroup's candidates for the next pick: its rows other than Lmin (whose new minimum is pending) ----
         float cd = UPGMA_BIG;
@@ -652,6 +727,7 @@ __global__ __launch_bounds__(UPGMA_CHAIN_THREADS) void upgma_chain_kernel(UpgmaA
         }
         chain_wg_min3(nd, nj, nn, s_d, s_j, s_n);
         chain_wg_min3(cd, cj, cn, s_d, s_j, s_n);
+        CHAIN_TICK(3) // the workgroup's two minima
         const int par = (it + 1) & 1;
         uint32_t* slots = a.chain_slots + (size_t)par * UPGMA_CHAIN_MAX_WG * 8;
         if (tid == 0) {
@@ -666,6 +742,7 @@ __global__ __launch_bounds__(UPGMA_CHAIN_THREADS) void upgma_chain_kernel(UpgmaA
             if (tid == 0) atomicMax(&a.sel[9], 3u);
             return;
         }
+        CHAIN_TICK(4) // barrier
         // ---- every workgroup: the new row's minimum, then the pick, from the P slots ----
         float gd = UPGMA_BIG, pd = UPGMA_BIG;
         uint32_t gj = UPGMA_NONE, pj = UPGMA_NONE, pn = UPGMA_NONE;
@@ -680,14 +757,9 @@ __global__ __launch_bounds__(UPGMA_CHAIN_THREADS) void upgma_chain_kernel(UpgmaA
             if (!(gd < UPGMA_BIG)) { gd = UPGMA_BIG; gj = UPGMA_NONE; }
             if (!(pd < UPGMA_BIG)) { pd = UPGMA_BIG; pj = UPGMA_NONE; pn = UPGMA_NONE; }
         }
-        for (int off = 32; off > 0; off >>= 1) {
-            const float d2 = __shfl_xor(gd, off);
-            const uint32_t j2 = __shfl_xor(gj, off);
-            if (d2 < gd || (d2 == gd && j2 < gj)) { gd = d2; gj = j2; }
-            const float d3 = __shfl_xor(pd, off);
-            const uint32_t j3 = __shfl_xor(pj, off), n3 = __shfl_xor(pn, off);
-            if (d3 < pd || (d3 == pd && j3 < pj)) { pd = d3; pj = j3; pn = n3; }
-        }
+        uint32_t g_unused = 0;
+        wave_first_min3(gd, gj, g_unused);
+        wave_first_min3(pd, pj, pn);
         if (it >= 0) { // the merged row takes its new minimum and takes part in the pick
             new_d = gd;
             new_j = gj;
@@ -698,11 +770,15 @@ __global__ __launch_bounds__(UPGMA_CHAIN_THREADS) void upgma_chain_kernel(UpgmaA
         }
         L = pj;
         R = pn;
+        CHAIN_TICK(5) // slots read and reduced
         if (L == UPGMA_NONE || R == UPGMA_NONE || R >= (uint32_t)n) { // degenerate input (the reference: undefined)
             if (rank == 0 && tid == 0) a.sel[8] = 1;
             break;
         }
     }
+#undef CHAIN_TICK
+    if (dbg && tid == 0)
+        for (int i = 0; i < 8; ++i) a.chain_dbg[i] = tk[i];
     if (rank == 0 && tid == 0) atomicMax(&a.sel[9], 1u);
 }
 
