@@ -783,26 +783,28 @@ int upgma_reduce(lcsgpu_ctx* ctx, Lane& L, int elem, int distance_kind, int modi
     HIP_TRY(lcsgpu::launch_upgma_prologue(a, L.d_out.p, elem, (const uint32_t*)ctx->d_lens.p, (const float*)ctx->d_powf.p,
                                           distance_kind, L.stream));
     if (profile) { HIP_TRY(hipStreamSynchronize(L.stream)); t_merge = now(); }
-    // The n-1 merges: inside ONE kernel whose workgroups all run on one XCD and synchronise through its L2
-    // (tree_kernels.hip, upgma_chain_kernel) when the distances are the symmetric matrix; else -- or if that kernel could
-    // not assemble its workgroups, in which case it has touched nothing -- one launch per merge.
+    // The n-1 merges: one launch per merge (default), or -- LCSGPU_UPGMA_CHAIN=1, symmetric matrix only -- inside ONE kernel
+    // whose workgroups all run on one XCD and synchronise through its L2 (tree_kernels.hip, upgma_chain_kernel; if it cannot
+    // assemble its workgroups it has touched nothing and the launches run).  Measured (scripts/upgma_chain_ab.sh): the chain
+    // is bit-identical and its barrier cheap, but every merge scatters n/2 mirror stores through the 16-32 CUs of one XCD:
+    // 13 us per merge at 100 000 sequences against 8.4 us for a launch, 9.3 against 7.4 at 10 000.
     uint32_t sel[12] = {0};
     bool merged = false;
     int wg = std::max(4, std::min<int>(lcsgpu::UPGMA_CHAIN_MAX_WG, (n + 4 * lcsgpu::UPGMA_CHAIN_THREADS - 1) / (4 * lcsgpu::UPGMA_CHAIN_THREADS)));
     if (const char* e = getenv("LCSGPU_UPGMA_CHAIN_WG")) wg = std::max(1, std::min<int>(lcsgpu::UPGMA_CHAIN_MAX_WG, atoi(e)));
     const bool chain_fits = (int64_t)wg * lcsgpu::UPGMA_CHAIN_THREADS * lcsgpu::UPGMA_CHAIN_ROWS >= n;
-    const char* chain_env = getenv("LCSGPU_UPGMA_CHAIN"); // "0" = always one launch per merge
-    if (square && chain_fits && n >= 64 && !(chain_env && !strcmp(chain_env, "0"))) {
+    const char* chain_env = getenv("LCSGPU_UPGMA_CHAIN");
+    if (square && chain_fits && n >= 64 && chain_env && !strcmp(chain_env, "1")) {
         HIP_TRY(lcsgpu::launch_upgma_chain(a, modified != 0, wg, L.stream));
         HIP_TRY(hipMemcpyAsync(sel, a.sel, 48, hipMemcpyDeviceToHost, L.stream));
         HIP_TRY(hipStreamSynchronize(L.stream));
-        if (sel[9] == 1) merged = true;
         if (a.chain_dbg) {
             unsigned long long tk[8];
             HIP_TRY(hipMemcpy(tk, a.chain_dbg, 64, hipMemcpyDeviceToHost));
             static const char* what[6] = {"rows arrive", "averages + stores issued", "stores acknowledged", "workgroup minima", "barrier", "slots"};
             for (int i = 0; i < 6; ++i) fprintf(stderr, "  chain phase %-26s %.2f us per merge\n", what[i], tk[i] * 0.01 / std::max(n - 1, 1));
         }
+        if (sel[9] == 1) merged = true;
         else if (sel[9] == 2) {
             if (getenv("LCSGPU_PROFILE")) fprintf(stderr, "lcsgpu_upgma: the one-XCD merge kernel could not assemble %d workgroups; one launch per merge\n", wg);
             HIP_TRY(hipMemsetAsync(base + o_sel, 0, 256, L.stream));

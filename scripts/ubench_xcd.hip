@@ -81,9 +81,27 @@ int main()
     hipMalloc(&ctl, 4096); hipMalloc(&slots, 256 * 128); hipMalloc(&rows, 256 * 64 * 4); hipMalloc(&stats, 256);
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
     const int iters = 20000;
-    for (int mode = 0; mode < 2; ++mode)
-        for (int P : {8, 16, 32, 64}) {
+    // mode 2: any XCD, but the shared words live in UNCACHED (fine-grained) device memory: coherent between the XCDs
+    // without write-back / invalidate, at the price of every access going to memory
+    unsigned *u_ctl, *u_slots;
+    float* u_rows;
+    hipExtMallocWithFlags((void**)&u_ctl, 4096, hipDeviceMallocUncached);
+    hipExtMallocWithFlags((void**)&u_slots, 256 * 128, hipDeviceMallocUncached);
+    hipExtMallocWithFlags((void**)&u_rows, 256 * 64 * 4, hipDeviceMallocUncached);
+    for (int mode = 0; mode < 3; ++mode)
+        for (int P : {8, 16, 32, 64, 128, 256}) {
             if (mode == 0 && P > 64) continue;
+            if (mode == 2) {
+                hipMemset(u_ctl, 0, 4096); hipMemset(u_slots, 0, 256 * 128); hipMemset(u_rows, 0, 256 * 64 * 4); hipMemset(stats, 0, 256);
+                hipEventRecord(a);
+                hipLaunchKernelGGL(k_chain, dim3(P), dim3(256), 0, 0, u_ctl, u_slots, u_rows, P, iters, 1, 0u, stats);
+                hipEventRecord(b);
+                hipError_t e = hipEventSynchronize(b);
+                float ms = 0; hipEventElapsedTime(&ms, a, b);
+                unsigned h[64]; hipMemcpy(h, stats, 256, hipMemcpyDeviceToHost);
+                printf("any XCD, UNCACHED mem  P=%3d: %.2f us per step, timeouts %u, stale reads %u  [%s]\n", P, 1e3 * ms / iters, h[0], h[1], hipGetErrorString(e));
+                continue;
+            }
             hipMemset(ctl, 0, 4096); hipMemset(slots, 0, 256 * 128); hipMemset(rows, 0, 256 * 64 * 4); hipMemset(stats, 0, 256);
             const int grid = mode == 0 ? 8 * (P + 16) : P; // enough workgroups for XCD 0 to receive P of them
             hipEventRecord(a);

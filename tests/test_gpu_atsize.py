@@ -83,13 +83,17 @@ def test_c4_single_linkage_tree(synth100k, tmp_path):
     assert file_sha(out) == META["synth100k"]["sl_newick_sha256"]
 
 
-@pytest.mark.parametrize("gt,layout", [("upgma", "square"), ("upgma_modified", "square"), ("upgma", "triangle")])
+@pytest.mark.parametrize("gt,layout", [("upgma", "square"), ("upgma_modified", "square"), ("upgma", "triangle"),
+                                       ("upgma_modified", "square+chain")])
 def test_c4_upgma_trees(synth100k, tmp_path, gt, layout):
     """100 000 merges on the device (one launch each) over the float distances -- the 40 GB symmetric matrix (default)
     or the 20 GB packed triangle: the per-workgroup minima are two per thread at this size (391 workgroups), which no
     smaller case reaches.  Against the sha256 of the REFERENCE's own runs (oracle/make_golden_large.py c4upgma)."""
     out = str(tmp_path / f"{gt}.dnd")
-    cli("-gt", gt, "-gt_export", synth100k[2], out, env={"LCSGPU_UPGMA_LAYOUT": layout})
+    env = {"LCSGPU_UPGMA_LAYOUT": layout.split("+")[0]}
+    if layout.endswith("chain"):  # the one-XCD merge kernel (opt-in): 100 000 merges inside one launch
+        env["LCSGPU_UPGMA_CHAIN"] = "1"
+    cli("-gt", gt, "-gt_export", synth100k[2], out, env=env)
     assert file_sha(out) == META["synth100k"][f"{gt}_newick_sha256"]
 
 

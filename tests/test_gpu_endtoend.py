@@ -165,7 +165,7 @@ def test_trees_of_a_set_with_a_giant_sequence(host, oracle, tmp_path, gt):
     assert host.tree_gpu(fasta, gt) == host.tree_from_matrix(fasta, square, gt)
 
 
-@pytest.mark.parametrize("layout", ["square", "triangle"])
+@pytest.mark.parametrize("layout", ["square", "triangle", "square+chain"])
 @pytest.mark.parametrize("gt", ["upgma", "upgma_modified"])
 @pytest.mark.parametrize("shape", ["ties", "family"])
 def test_device_upgma_on_tie_heavy_and_larger_sets(host, oracle, tmp_path, monkeypatch, gt, shape, layout):
@@ -174,7 +174,9 @@ def test_device_upgma_on_tie_heavy_and_larger_sets(host, oracle, tmp_path, monke
     touch the same workgroup twice in a row.  Both layouts of the float distances: the full symmetric matrix (the
     default while 4 B x n^2 fit) and the packed triangle."""
     import numpy as np
-    monkeypatch.setenv("LCSGPU_UPGMA_LAYOUT", layout)
+    monkeypatch.setenv("LCSGPU_UPGMA_LAYOUT", layout.split("+")[0])
+    if layout.endswith("chain"):  # all merges inside one kernel whose workgroups run on one XCD (opt-in, tree_kernels.hip)
+        monkeypatch.setenv("LCSGPU_UPGMA_CHAIN", "1")
     rng = np.random.Generator(np.random.PCG64(61))
     if shape == "ties":
         seqs = [rng.integers(0, 3, size=int(rng.integers(8, 15))).astype(np.uint8) for _ in range(1300)]
