@@ -40,6 +40,29 @@ __device__ __forceinline__ size_t tri_at(int i, int j)
     return i >= j ? (size_t)j + (size_t)i * (i - 1) / 2 : (size_t)i + (size_t)j * (j - 1) / 2;
 }
 
+// wave-level reductions by DPP (see tree_kernels.hip, wave_first_min): the moves between lanes stay inside the VALU
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xF, false); }
+// (value, index) with "a valid index beats none, then the smaller value, then the smaller index"; result wave-uniform
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void dpp_first_min_step(float& v, int& i)
+{
+    const float ov = __int_as_float(dpp_i32<CTRL, ROW_MASK>(__float_as_int(v)));
+    const int oi = dpp_i32<CTRL, ROW_MASK>(i);
+    if (oi != INT_MAX && (i == INT_MAX || ov < v || (ov == v && oi < i))) { v = ov; i = oi; }
+}
+__device__ __forceinline__ void wave_first_min_valid(float& v, int& i)
+{
+    dpp_first_min_step<0xB1, 0xF>(v, i);  // quad_perm [1,0,3,2]
+    dpp_first_min_step<0x4E, 0xF>(v, i);  // quad_perm [2,3,0,1]
+    dpp_first_min_step<0x141, 0xF>(v, i); // row_half_mirror
+    dpp_first_min_step<0x140, 0xF>(v, i); // row_mirror
+    dpp_first_min_step<0x142, 0xA>(v, i); // row_bcast:15
+    dpp_first_min_step<0x143, 0xC>(v, i); // row_bcast:31
+    v = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+    i = __builtin_amdgcn_readlane(i, 63);
+}
+
 enum { ST_P = 0, ST_DONE = 1, ST_LOG_LEN = 2, ST_ROUNDS = 3, ST_ARRIVE = 4, ST_COST = 5, ST_ERR = 6, ST_WIN = 7,
        ST_OFF = 8, ST_STAGE = 9, ST_FIRST = 10 };
 
@@ -330,20 +353,23 @@ __global__ __launch_bounds__(512) void clarans_eval_kernel(ClaransBatch batch)
 #pragma unroll
     for (int q = 0; q < KPT; ++q)
         if (slot[q] >= a.n_fixed && slot[q] < khi && (bk == INT_MAX || acc[q] < best)) { best = acc[q]; bk = slot[q]; }
-    s_v[tid] = best;
-    s_k[tid] = bk;
+    wave_first_min_valid(best, bk); // the wave's first minimum, then the 8 waves' through LDS: one barrier instead of ten
+    if (lane == 0) {
+        s_v[wave] = best;
+        s_k[wave] = bk;
+    }
     __syncthreads();
-    for (int s = 256; s > 0; s >>= 1) {
-        if (tid < s) {
-            const float v2 = s_v[tid + s];
-            const int k2 = s_k[tid + s];
-            const int k1 = s_k[tid];
-            if (k2 != INT_MAX && (k1 == INT_MAX || v2 < s_v[tid] || (v2 == s_v[tid] && k2 < k1))) {
-                s_v[tid] = v2;
-                s_k[tid] = k2;
-            }
+    if (tid == 0) {
+        float v = s_v[0];
+        int kk = s_k[0];
+#pragma unroll
+        for (int w = 1; w < 8; ++w) {
+            const float v2 = s_v[w];
+            const int k2 = s_k[w];
+            if (k2 != INT_MAX && (kk == INT_MAX || v2 < v || (v2 == v && k2 < kk))) { v = v2; kk = k2; }
         }
-        __syncthreads();
+        s_v[0] = v;
+        s_k[0] = kk;
     }
     if (tid == 0) {
         a.res_delta[b] = s_v[0];
@@ -445,21 +471,13 @@ __global__ __launch_bounds__(64) void clarans_apply_kernel(ClaransBatch batch)
             const int mm = tid + 64 * u;
             if (mm < k && (dv[u] < v1 || i1 == INT_MAX)) { v1 = dv[u]; i1 = mm; }
         }
-        for (int off = 32; off > 0; off >>= 1) {
-            const float ov = __shfl_xor(v1, off);
-            const int oi = __shfl_xor(i1, off);
-            if (oi != INT_MAX && (i1 == INT_MAX || ov < v1 || (ov == v1 && oi < i1))) { v1 = ov; i1 = oi; }
-        }
+        wave_first_min_valid(v1, i1);
 #pragma unroll
         for (int u = 0; u < CLARANS_MAX_MEDOIDS / 64; ++u) {
             const int mm = tid + 64 * u;
             if (mm < k && mm != i1 && (dv[u] < v2 || i2 == INT_MAX)) { v2 = dv[u]; i2 = mm; }
         }
-        for (int off = 32; off > 0; off >>= 1) {
-            const float ov = __shfl_xor(v2, off);
-            const int oi = __shfl_xor(i2, off);
-            if (oi != INT_MAX && (i2 == INT_MAX || ov < v2 || (ov == v2 && oi < i2))) { v2 = ov; i2 = oi; }
-        }
+        wave_first_min_valid(v2, i2);
         if (tid == 0) {
             // the scan starts from (FLT_MAX, -1): a slot at FLT_MAX never replaces it
             const bool has1 = i1 != INT_MAX && v1 < FLT_MAX, has2 = i2 != INT_MAX && v2 < FLT_MAX;

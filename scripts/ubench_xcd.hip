@@ -42,6 +42,9 @@ __device__ __forceinline__ bool xcd_barrier(unsigned* counter, unsigned target)
 }
 
 // mode 0: participants = the first P ticket holders on XCD `want_xcd`;  mode 1: participants = blocks 0..P-1 wherever they run
+// FENCE: the readers use PLAIN loads and an agent-scope ACQUIRE fence after the barrier (invalidates the CU's L1) instead
+// of sc1 loads -- what a kernel with many loads would rather do
+template <bool FENCE>
 __global__ __launch_bounds__(256) void k_chain(unsigned* ctl, unsigned* slots, float* rows, int P, int iters, int mode, unsigned want_xcd,
                                                unsigned* stats)
 {
@@ -64,10 +67,18 @@ __global__ __launch_bounds__(256) void k_chain(unsigned* ctl, unsigned* slots, f
         if (threadIdx.x == 0) slots[rank * 32] = (unsigned)it + 1u;                 // 128-byte stride
         if (threadIdx.x < 64) rows[rank * 64 + threadIdx.x] = (float)(it + 1) + 0.5f; // a plain store
         if (!xcd_barrier(&ctl[32], (unsigned)(it + 1) * 2u * P - P)) { atomicAdd(&stats[0], 1u); return; }
-        for (int w = threadIdx.x; w < P; w += 256)
-            if (ld_u32(&slots[w * 32]) != (unsigned)it + 1u) ++errors;
-        for (int e = threadIdx.x; e < P * 64; e += 256)
-            if (ld_f32(&rows[e]) != (float)(it + 1) + 0.5f) ++errors;
+        if (FENCE) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            for (int w = threadIdx.x; w < P; w += 256)
+                if (((volatile unsigned*)slots)[w * 32] != (unsigned)it + 1u) ++errors;
+            for (int e = threadIdx.x; e < P * 64; e += 256)
+                if (((volatile float*)rows)[e] != (float)(it + 1) + 0.5f) ++errors;
+        } else {
+            for (int w = threadIdx.x; w < P; w += 256)
+                if (ld_u32(&slots[w * 32]) != (unsigned)it + 1u) ++errors;
+            for (int e = threadIdx.x; e < P * 64; e += 256)
+                if (ld_f32(&rows[e]) != (float)(it + 1) + 0.5f) ++errors;
+        }
         // second barrier: nobody overwrites its slot for step it+1 while another workgroup still reads step it
         if (!xcd_barrier(&ctl[32], (unsigned)(it + 1) * 2u * P)) { atomicAdd(&stats[0], 1u); return; }
     }
@@ -94,7 +105,7 @@ int main()
             if (mode == 2) {
                 hipMemset(u_ctl, 0, 4096); hipMemset(u_slots, 0, 256 * 128); hipMemset(u_rows, 0, 256 * 64 * 4); hipMemset(stats, 0, 256);
                 hipEventRecord(a);
-                hipLaunchKernelGGL(k_chain, dim3(P), dim3(256), 0, 0, u_ctl, u_slots, u_rows, P, iters, 1, 0u, stats);
+                hipLaunchKernelGGL(k_chain<false>, dim3(P), dim3(256), 0, 0, u_ctl, u_slots, u_rows, P, iters, 1, 0u, stats);
                 hipEventRecord(b);
                 hipError_t e = hipEventSynchronize(b);
                 float ms = 0; hipEventElapsedTime(&ms, a, b);
@@ -105,7 +116,7 @@ int main()
             hipMemset(ctl, 0, 4096); hipMemset(slots, 0, 256 * 128); hipMemset(rows, 0, 256 * 64 * 4); hipMemset(stats, 0, 256);
             const int grid = mode == 0 ? 8 * (P + 16) : P; // enough workgroups for XCD 0 to receive P of them
             hipEventRecord(a);
-            hipLaunchKernelGGL(k_chain, dim3(grid), dim3(256), 0, 0, ctl, slots, rows, P, iters, mode, 0u, stats);
+            hipLaunchKernelGGL(k_chain<false>, dim3(grid), dim3(256), 0, 0, ctl, slots, rows, P, iters, mode, 0u, stats);
             hipEventRecord(b);
             hipError_t e = hipEventSynchronize(b);
             float ms = 0; hipEventElapsedTime(&ms, a, b);
@@ -115,5 +126,15 @@ int main()
             for (int x = 0; x < 8; ++x) printf(" %u", h[8 + x]);
             printf("  [%s]\n", hipGetErrorString(e));
         }
+    for (int P : {16, 32, 64}) { // one XCD, plain loads behind an acquire fence
+        hipMemset(ctl, 0, 4096); hipMemset(slots, 0, 256 * 128); hipMemset(rows, 0, 256 * 64 * 4); hipMemset(stats, 0, 256);
+        hipEventRecord(a);
+        hipLaunchKernelGGL(k_chain<true>, dim3(8 * (P + 16)), dim3(256), 0, 0, ctl, slots, rows, P, iters, 0, 0u, stats);
+        hipEventRecord(b);
+        hipError_t e = hipEventSynchronize(b);
+        float ms = 0; hipEventElapsedTime(&ms, a, b);
+        unsigned h[64]; hipMemcpy(h, stats, 256, hipMemcpyDeviceToHost);
+        printf("one XCD, plain loads + acquire fence P=%2d: %.2f us per step, timeouts %u, stale reads %u  [%s]\n", P, 1e3 * ms / iters, h[0], h[1], hipGetErrorString(e));
+    }
     return 0;
 }
