@@ -563,6 +563,469 @@ __global__ __launch_bounds__(64) void clarans_apply_kernel(ClaransBatch batch)
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The rounds of a search inside ONE launch, kept on ONE XCD (opt-in, LCSGPU_CLARANS_CHAIN=1).
+//
+// A round is two dependent steps (evaluate the stage's pending steps; apply the first improving one), and as two launches
+// it pays two kernel boundaries and, after each, a trip to memory per dependent load level -- a boundary leaves nothing in
+// the caches that another XCD wrote.  Workgroups that all run on the SAME XCD share one L2: a barrier among them is an
+// atomic at that L2 (about 1 us for 17 workgroups, scripts/ubench_xcd.hip), a store is visible to the others once it has
+// left the CU (s_waitcnt vmcnt(0); the vector L1 is write-through) and a reader only has to bypass its own L1 -- no fence
+// wider than the workgroup.  So: every array another workgroup of the search writes during the launch (cand, st, DMt, the
+// windows, the step results, the cost log) is read with sc1 loads (ldc below); the distances D are read-only and take
+// the ordinary path.  The workgroups are picked by where they really run: each reads XCC_ID and takes a ticket of a
+// search assigned to that XCD; the first P are that search's ranks, everything else exits at once.  Ranks 0 .. P-2
+// evaluate the steps of a stage (step b -> rank b mod (P-1)) and apply an accepted step to their share of the positions;
+// rank P-1 keeps the running cost and does the apply kernel's last-workgroup part.  The control state (next draw, window,
+// stage, ...) is computed by every workgroup from the same step results, so a round needs exactly two barriers.
+// Arithmetic, comparison directions and the order of every float addition are those of the two kernels above.
+enum { CH_TICKET = 16, CH_GO = 17, CH_BAR = 32 }; // words of the search's 64-word state block (zeroed by the host before every launch)
+
+template <typename T>
+__device__ __forceinline__ T ldc(const T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float4 ldc4(const float4* p)
+{
+    const uint64_t* q = reinterpret_cast<const uint64_t*>(p);
+    const uint64_t lo = ldc(q), hi = ldc(q + 1);
+    return make_float4(__uint_as_float((uint32_t)lo), __uint_as_float((uint32_t)(lo >> 32)), __uint_as_float((uint32_t)hi),
+                       __uint_as_float((uint32_t)(hi >> 32)));
+}
+__device__ __forceinline__ unsigned xcc_id()
+{
+    // s_getreg_b32 hwreg(HW_REG_XCC_ID = 20), offset 0, size 32
+    return (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xFu;
+}
+// all P ranks of a search arrive; nothing but the workgroup's own stores having left the CU is waited for
+__device__ __forceinline__ bool chain_barrier(int* counter, int target)
+{
+    __shared__ int s_ok;
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int spins = 0, ok = 1;
+        while (ldc(counter) < target)
+            if (++spins > (1 << 20)) { ok = 0; break; } // ~1 s: a rank of this search is gone
+        s_ok = ok;
+    }
+    __syncthreads();
+    return s_ok != 0;
+}
+
+// running cost: c += addend for the logged addends, in order (the cost workgroup of clarans_eval_kernel); valid in thread 0
+__device__ __forceinline__ float chain_cost(const ClaransArgs& a, int len, float c, float* s_f, float* s_nz)
+{
+    constexpr int CH = 2048, PER = CH / 512;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint64_t lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
+    for (int c0 = 0; c0 < len; c0 += CH) {
+        const int cnt = min(CH, len - c0);
+        float v[PER];
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int t = tid + 512 * u;
+            v[u] = t < cnt ? ldc(&a.cost_log[c0 + t]) : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < PER; ++u) s_f[tid + 512 * u] = v[u];
+        __syncthreads();
+        if (wave == 0) {
+            int m = 0;
+            for (int base = 0; base < cnt; base += 256) {
+                float g[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) g[u] = s_f[base + 64 * u + lane];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint64_t mask = __ballot(g[u] != 0.0f);
+                    if (g[u] != 0.0f) s_nz[m + __popcll(mask & lt_mask)] = g[u];
+                    m += __popcll(mask);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) {
+                int t = 0;
+                for (; t + 8 <= m; t += 8) {
+                    float g[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) g[u] = s_nz[t + u];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) c = __fadd_rn(c, g[u]);
+                }
+                for (; t < m; ++t) c = __fadd_rn(c, s_nz[t]);
+            }
+        }
+        __syncthreads();
+    }
+    return c;
+}
+
+// deltas[slot] of the member x drawn at position xx and their first minimum over the free slots (the body of
+// clarans_eval_kernel); the result is valid in thread 0
+template <int KPT>
+__device__ __forceinline__ void chain_eval_step(const ClaransArgs& a, int xx, int x, float4* s_e, float4 (*s_we)[128], float& best_out,
+                                                int& bk_out)
+{
+    constexpr int CH = 2048, PER = CH / 512, HALF = CH / 2, SUB = 128;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int k = a.n_medoids, n = a.n_elems;
+    const uint64_t lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
+    const int kpw = (k + 7) >> 3;
+    const int klo = wave * kpw, khi = min(k, klo + kpw);
+    float acc[KPT];
+    int slot[KPT];
+#pragma unroll
+    for (int q = 0; q < KPT; ++q) {
+        acc[q] = 0.0f;
+        slot[q] = klo + lane + 64 * q;
+    }
+    for (int c0 = k; c0 < n; c0 += CH) {
+        const int cnt = min(CH, n - c0);
+        int y_pre[PER];
+        float4 s_pre[PER];
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int t = tid + 512 * u;
+            y_pre[u] = t < cnt ? ldc(&a.cand[c0 + t]) : 0;
+            s_pre[u] = t < cnt ? ldc4(&a.st[c0 + t]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        float dxy[PER];
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int t = tid + 512 * u;
+            dxy[u] = (t < cnt && c0 + t != xx) ? a.D[tri_at(x, y_pre[u])] : 0.0f;
+        }
+        float4 ent[PER];
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int t = tid + 512 * u;
+            ent[u] = make_float4(0.0f, 0.0f, __int_as_float(-1), 0.0f);
+            if (t < cnt && c0 + t != xx) {
+                const float dn = s_pre[u].x, ds = s_pre[u].y;
+                const float m = ds < dxy[u] ? ds : dxy[u];
+                const float change = __fsub_rn(dxy[u], dn);
+                ent[u].x = __fsub_rn(m, dn);
+                ent[u].y = change < 0.0f ? change : 0.0f;
+                ent[u].z = s_pre[u].z;
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int hcnt = min(HALF, cnt - h * HALF);
+            if (hcnt <= 0) break;
+#pragma unroll
+            for (int u = 0; u < PER / 2; ++u) {
+                const int t = tid + 512 * u;
+                if (t < hcnt) s_e[t] = ent[h * (PER / 2) + u];
+            }
+            __syncthreads();
+            for (int s0 = 0; s0 < hcnt; s0 += SUB) {
+                float4 e[SUB / 64];
+#pragma unroll
+                for (int u = 0; u < SUB / 64; ++u) {
+                    const int t = s0 + 64 * u + lane;
+                    e[u] = t < hcnt ? s_e[t] : make_float4(0.0f, 0.0f, __int_as_float(-1), 0.0f);
+                }
+                int m = 0;
+#pragma unroll
+                for (int u = 0; u < SUB / 64; ++u) {
+                    const int nn = __float_as_int(e[u].z);
+                    const bool mine = e[u].y < 0.0f || (nn >= klo && nn < khi);
+                    const uint64_t mask = __ballot(mine);
+                    if (mine) s_we[wave][m + __popcll(mask & lt_mask)] = e[u];
+                    m += __popcll(mask);
+                }
+                __builtin_amdgcn_wave_barrier();
+                int i = 0;
+                for (; i + 8 <= m; i += 8) {
+                    float4 f[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) f[u] = s_we[wave][i + u];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int nn = __float_as_int(f[u].z);
+#pragma unroll
+                        for (int q = 0; q < KPT; ++q) acc[q] = __fadd_rn(acc[q], slot[q] == nn ? f[u].x : f[u].y);
+                    }
+                }
+                for (; i < m; ++i) {
+                    const float4 f = s_we[wave][i];
+                    const int nn = __float_as_int(f.z);
+#pragma unroll
+                    for (int q = 0; q < KPT; ++q) acc[q] = __fadd_rn(acc[q], slot[q] == nn ? f.x : f.y);
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            __syncthreads();
+        }
+    }
+    float* s_v = reinterpret_cast<float*>(&s_we[0][0]);
+    int* s_k = reinterpret_cast<int*>(&s_we[1][0]);
+    float best = 0.0f;
+    int bk = INT_MAX;
+#pragma unroll
+    for (int q = 0; q < KPT; ++q)
+        if (slot[q] >= a.n_fixed && slot[q] < khi && (bk == INT_MAX || acc[q] < best)) { best = acc[q]; bk = slot[q]; }
+    wave_first_min_valid(best, bk);
+    if (lane == 0) {
+        s_v[wave] = best;
+        s_k[wave] = bk;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float v = s_v[0];
+        int kk = s_k[0];
+#pragma unroll
+        for (int w = 1; w < 8; ++w) {
+            const float v2 = s_v[w];
+            const int k2 = s_k[w];
+            if (k2 != INT_MAX && (kk == INT_MAX || v2 < v || (v2 == v && k2 < kk))) { v = v2; kk = k2; }
+        }
+        best_out = v;
+        bk_out = kk;
+    }
+    __syncthreads(); // the staging areas are free for the next step
+}
+
+template <int KPT>
+__global__ __launch_bounds__(512) void clarans_chain_kernel(ClaransBatch batch, int P, int max_rounds)
+{
+    __shared__ float4 s_e[1024];    // 16 KB
+    __shared__ float4 s_we[8][128]; // 16 KB
+    __shared__ int s_rank, s_search;
+    const int tid = threadIdx.x, lane = tid & 63;
+    if (tid == 0) {
+        int rank = -1, search = -1;
+        for (int i = (int)xcc_id(); i < batch.n; i += 8) { // the searches assigned to the XCD this workgroup runs on
+            const int t = atomicAdd(&batch.s[i].state[CH_TICKET], 1);
+            if (t < P) {
+                rank = t;
+                search = i;
+                break;
+            }
+        }
+        s_rank = rank;
+        s_search = search;
+    }
+    __syncthreads();
+    const int rank = s_rank;
+    if (rank < 0) return;
+    const ClaransArgs& a = batch.s[s_search];
+    int* st = a.state;
+    // assembly: rank 0 decides whether all P ranks have found a seat on this XCD; if not, nothing has been touched
+    // and the host runs this look as ordinary rounds
+    if (tid == 0) {
+        if (rank == 0) {
+            int spins = 0, go = 1;
+            while (ldc(&st[CH_TICKET]) < P) {
+                if (++spins > (1 << 11)) { go = 2; break; } // ~3 ms: this XCD has no room for the search right now
+                __builtin_amdgcn_s_sleep(8);
+            }
+            __hip_atomic_store(&st[CH_GO], go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            while (ldc(&st[CH_GO]) == 0) __builtin_amdgcn_s_sleep(2);
+        }
+    }
+    __syncthreads();
+    if (ldc(&st[CH_GO]) != 1) return;
+
+    const int corrected = a.corrected, k = a.n_medoids, n = a.n_elems;
+    int p = st[ST_P], done = st[ST_DONE], log_len = st[ST_LOG_LEN], accepts = st[ST_ROUNDS], err = st[ST_ERR], win = st[ST_WIN] & 1,
+        off = st[ST_OFF], stage = st[ST_STAGE], first = st[ST_FIRST];
+    float cost = __int_as_float(st[ST_COST]);
+    const bool tail = rank == P - 1;
+    const int n_eval = P - 1;
+    const int W_next = window_size(corrected, 0);
+    int bar = 0;
+    // where the time of a round goes (s_memtime ticks of 10 ns), ranks 0 and P-1: evaluate, wait, apply, wait
+    unsigned long long t_ph[4] = {0, 0, 0, 0}, t0 = wall_clock64();
+    int n_rounds = 0;
+    auto lap = [&](int ph) {
+        const unsigned long long t1 = wall_clock64();
+        t_ph[ph] += t1 - t0;
+        t0 = t1;
+    };
+    for (int r = 0; r < max_rounds && !done; ++r) {
+        const int W = window_size(corrected, first);
+        const int S = stage_size(stage, W - off);
+        ++n_rounds;
+        // ---- evaluate
+        if (tail) {
+            if (log_len) cost = chain_cost(a, log_len, cost, reinterpret_cast<float*>(s_e), reinterpret_cast<float*>(s_we));
+        } else if (!err) {
+            for (int b = rank; b < S; b += n_eval) {
+                const int xx = ldc(&a.win_xx[win * a.win_cap + off + b]);
+                const int x = ldc(&a.win_x[win * a.win_cap + off + b]);
+                float best = 0.0f;
+                int bk = INT_MAX;
+                chain_eval_step<KPT>(a, xx, x, s_e, s_we, best, bk);
+                if (tid == 0) {
+                    a.res_delta[b] = best;
+                    a.res_mm[b] = bk;
+                }
+            }
+        }
+        lap(0);
+        bar += P;
+        if (!chain_barrier(&st[CH_BAR], bar)) {
+            if (tid == 0) atomicExch(&st[ST_ERR], 2);
+            return;
+        }
+        lap(1);
+        // ---- apply: the first step of the stage with a negative delta
+        const bool in_stage = !err && lane < S;
+        const float rd = in_stage ? ldc(&a.res_delta[lane]) : 0.0f;
+        const uint64_t neg = __ballot(in_stage && rd < 0.0f);
+        const bool accept = neg != 0;
+        const int w = accept ? __ffsll((unsigned long long)neg) - 1 : 0;
+        const int j = off + w;
+        if (accept) {
+            const int xx = ldc(&a.win_xx[win * a.win_cap + j]);
+            const int x = ldc(&a.win_x[win * a.win_cap + j]); // the new medoid
+            const int mm_new = ldc(&a.res_mm[w]);
+            if (tail) {
+                const int p_new = p + j + 1;
+                if (tid < 64) {
+                    const int m_old = ldc(&a.cand[mm_new]); // the medoid that is replaced; from now on it sits at position xx
+                    if (p_new + W_next <= a.draws_len) {
+                        int32_t* nxx = a.win_xx + (1 - win) * a.win_cap;
+                        int32_t* nx = a.win_x + (1 - win) * a.win_cap;
+                        for (int q = tid; q < W_next; q += 64) {
+                            const int xn = a.draws[p_new + q];
+                            nxx[q] = xn;
+                            nx[q] = xn == xx ? m_old : ldc(&a.cand[xn]); // draws are non-medoid positions
+                        }
+                    }
+                    const float old_dn = ldc4(&a.st[xx]).x;
+                    float dv[CLARANS_MAX_MEDOIDS / 64];
+#pragma unroll
+                    for (int u = 0; u < CLARANS_MAX_MEDOIDS / 64; ++u) {
+                        const int mm = tid + 64 * u;
+                        dv[u] = FLT_MAX;
+                        if (mm < k) {
+                            dv[u] = a.D[tri_at(mm == mm_new ? x : ldc(&a.cand[mm]), m_old)];
+                            a.DMt[(size_t)mm * n + xx] = dv[u];
+                        }
+                    }
+                    float v1 = FLT_MAX, v2 = FLT_MAX;
+                    int i1 = INT_MAX, i2 = INT_MAX;
+#pragma unroll
+                    for (int u = 0; u < CLARANS_MAX_MEDOIDS / 64; ++u) {
+                        const int mm = tid + 64 * u;
+                        if (mm < k && (dv[u] < v1 || i1 == INT_MAX)) { v1 = dv[u]; i1 = mm; }
+                    }
+                    wave_first_min_valid(v1, i1);
+#pragma unroll
+                    for (int u = 0; u < CLARANS_MAX_MEDOIDS / 64; ++u) {
+                        const int mm = tid + 64 * u;
+                        if (mm < k && mm != i1 && (dv[u] < v2 || i2 == INT_MAX)) { v2 = dv[u]; i2 = mm; }
+                    }
+                    wave_first_min_valid(v2, i2);
+                    if (tid == 0) {
+                        const bool has1 = i1 != INT_MAX && v1 < FLT_MAX, has2 = i2 != INT_MAX && v2 < FLT_MAX;
+                        a.st[xx] = pack_state(has1 ? v1 : FLT_MAX, has2 ? v2 : FLT_MAX, has1 ? i1 : -1, has2 ? i2 : -1);
+                        a.cost_log[0] = -old_dn;
+                        a.cost_log[1 + xx - k] = has1 ? v1 : FLT_MAX;
+                        // the swap itself: nobody else reads cand between the two barriers of a round
+                        a.cand[mm_new] = x;
+                        a.cand[xx] = m_old;
+                    }
+                }
+            } else {
+                for (int yy = k + rank * 512 + tid; yy < n; yy += n_eval * 512) {
+                    if (yy == xx) continue;
+                    const int y_mine = ldc(&a.cand[yy]);
+                    const float4 s = ldc4(&a.st[yy]);
+                    const float d_new = a.D[tri_at(x, y_mine)];
+                    a.DMt[(size_t)mm_new * n + yy] = d_new;
+                    const float dn_y = s.x, ds_y = s.y;
+                    const int an_y = __float_as_int(s.z), as_y = __float_as_int(s.w);
+                    float addend = 0.0f;
+                    bool rescan = false;
+                    float4 out = s;
+                    if (an_y == mm_new) { // its medoid is the one that left
+                        if (d_new < ds_y) {
+                            out.x = d_new;
+                            addend = __fsub_rn(d_new, dn_y);
+                        } else {
+                            rescan = true;
+                            addend = __fsub_rn(ds_y, dn_y);
+                        }
+                    } else if (d_new < dn_y) {
+                        out = pack_state(d_new, dn_y, mm_new, an_y);
+                        addend = __fsub_rn(d_new, dn_y);
+                    } else if (as_y != mm_new && d_new < ds_y) {
+                        out.y = d_new;
+                        out.w = __int_as_float(mm_new);
+                    } else {
+                        rescan = true;
+                    }
+                    if (rescan) { // CLARANS::updateAssignment over the new medoid set
+                        Nearest2 nb;
+                        const float* col = a.DMt + yy;
+                        for (int m0 = 0; m0 < k; m0 += 8) {
+                            float v[8];
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) v[u] = ldc(&col[(size_t)min(m0 + u, k - 1) * n]);
+#pragma unroll
+                            for (int u = 0; u < 8; ++u)
+                                if (m0 + u < k) nb.feed(m0 + u == mm_new ? d_new : v[u], m0 + u);
+                        }
+                        out = pack_state(nb.dn, nb.ds, nb.an, nb.as);
+                    }
+                    a.st[yy] = out;
+                    a.cost_log[1 + yy - k] = addend;
+                }
+            }
+        }
+        lap(2);
+        bar += P;
+        if (!chain_barrier(&st[CH_BAR], bar)) {
+            if (tid == 0) atomicExch(&st[ST_ERR], 2);
+            return;
+        }
+        lap(3);
+        // ---- the control state, the same in every workgroup
+        if (accept) {
+            const int p_new = p + j + 1;
+            if (p_new + W_next > a.draws_len) err = 1;
+            p = p_new;
+            log_len = 1 + n - k;
+            ++accepts;
+            win = 1 - win;
+            off = 0;
+            stage = 0;
+            first = 0;
+        } else {
+            log_len = 0;
+            if (err || off + S >= W) { // error, or `corrected` steps without an accept: this local search is over
+                p = p + (err ? 0 : W);
+                done = 1;
+            } else {
+                off += S;
+                ++stage;
+            }
+        }
+    }
+    if (tail && tid == 0) {
+        st[ST_P] = p;
+        st[ST_DONE] = done;
+        st[ST_LOG_LEN] = log_len;
+        st[ST_ROUNDS] = accepts;
+        st[ST_COST] = __float_as_int(cost);
+        st[ST_ERR] = err;
+        st[ST_WIN] = win;
+        st[ST_OFF] = off;
+        st[ST_STAGE] = stage;
+        st[ST_FIRST] = first;
+    }
+    if ((tail || rank == 0) && tid == 0) { // words 48 .. 57: LCSGPU_PROFILE
+        int* dbg = st + (tail ? 53 : 48);
+        dbg[0] = n_rounds;
+        for (int q = 0; q < 4; ++q) dbg[1 + q] = (int)(t_ph[q] & 0x7fffffff);
+    }
+}
+
 hipError_t launch_subset_distances(const void* lcs, int elem_size, const int32_t* ids, const uint32_t* lens,
                                    const float* pow_f32, int kind, int n, float* D, hipStream_t stream)
 {
@@ -600,6 +1063,19 @@ hipError_t launch_clarans_rounds(const ClaransBatch& b, int rounds, hipStream_t 
         else hipLaunchKernelGGL(clarans_eval_kernel<2>, grid, block, 0, stream, b);
         hipLaunchKernelGGL(clarans_apply_kernel, dim3(apply_blocks, b.n), dim3(64), 0, stream, b);
     }
+    return hipGetLastError();
+}
+
+// Up to `rounds` rounds of every search of the batch inside one launch (LCSGPU_CLARANS_CHAIN=1): search i runs on XCD i mod 8
+// with `ranks` workgroups.  The caller has zeroed words 16 .. 47 of every search's state block on the same stream.
+hipError_t launch_clarans_chain(const ClaransBatch& b, int rounds, int ranks, hipStream_t stream)
+{
+    int kpt = 1;
+    for (int i = 0; i < b.n; ++i) kpt = std::max(kpt, ((b.s[i].n_medoids + 7) / 8 + 63) / 64);
+    const int per_xcd = (b.n + 7) / 8;
+    const dim3 grid(8 * (per_xcd * ranks + 16)), block(512); // XCDs get workgroups round robin: enough for every XCD to seat its searches
+    if (kpt <= 1) hipLaunchKernelGGL(clarans_chain_kernel<1>, grid, block, 0, stream, b, ranks, rounds);
+    else hipLaunchKernelGGL(clarans_chain_kernel<2>, grid, block, 0, stream, b, ranks, rounds);
     return hipGetLastError();
 }
 

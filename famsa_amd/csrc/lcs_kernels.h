@@ -281,5 +281,6 @@ hipError_t launch_subset_distances(const void* lcs, int elem_size, const int32_t
                                    const float* pow_f32, int kind, int n, float* D, hipStream_t stream);
 hipError_t launch_clarans_init(const ClaransArgs& a, hipStream_t stream);
 hipError_t launch_clarans_rounds(const ClaransBatch& b, int rounds, hipStream_t stream);
+hipError_t launch_clarans_chain(const ClaransBatch& b, int rounds, int ranks, hipStream_t stream);
 
 } // namespace lcsgpu

@@ -88,7 +88,7 @@ int ensure_batcher(lcsgpu_ctx* ctx, ClaransBatcher& B)
     if (greatest != least) HIP_TRY(hipStreamCreateWithPriority(&B.stream, hipStreamNonBlocking, greatest));
     else HIP_TRY(hipStreamCreateWithFlags(&B.stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&B.ev, hipEventBlockingSync | hipEventDisableTiming));
-    HIP_TRY(B.h_states.reserve(lcsgpu::CLARANS_MAX_BATCH * 64));
+    HIP_TRY(B.h_states.reserve(lcsgpu::CLARANS_MAX_BATCH * 256));
     return LCSGPU_OK;
 }
 
@@ -495,8 +495,10 @@ int lcsgpu_destroy(lcsgpu_ctx* ctx)
         if (getenv("LCSGPU_PROFILE"))
             for (int i = 1; i <= lcsgpu::CLARANS_MAX_BATCH; ++i)
                 if (B.prof_looks[i])
-                    fprintf(stderr, "clarans.batch[%d searches]: %ld looks of 32 rounds, %.3f s, %.1f us per round\n", i,
-                            B.prof_looks[i], B.prof_seconds[i], 1e6 * B.prof_seconds[i] / B.prof_looks[i] / 32);
+                    fprintf(stderr, "clarans.batch[%d searches]: %ld looks, %.3f s, %.1f us per look\n", i, B.prof_looks[i],
+                            B.prof_seconds[i], 1e6 * B.prof_seconds[i] / B.prof_looks[i]);
+        if (getenv("LCSGPU_PROFILE") && B.prof_chain_fallbacks)
+            fprintf(stderr, "clarans.chain_fallbacks=%ld\n", B.prof_chain_fallbacks);
         if (B.stream) { (void)hipStreamSynchronize(B.stream); (void)hipStreamDestroy(B.stream); }
         if (B.ev) (void)hipEventDestroy(B.ev);
         B.h_states.release();

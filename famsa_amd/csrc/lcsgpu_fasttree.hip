@@ -8,6 +8,17 @@ using lcsgpu::RowsArgs;
 
 namespace {
 
+bool env_on(const char* name)
+{
+    const char* e = getenv(name);
+    return e && *e && *e != '0';
+}
+int env_int(const char* name, int dflt)
+{
+    const char* e = getenv(name);
+    return e && *e ? atoi(e) : dflt;
+}
+
 // det_uniform_int_distribution<int>(n_medoids, n_elems - 1) over the owner's generator
 // (deterministic_random.h:62-76), appended to the job's draws and copied to the device.
 int clarans_extend_draws(ClaransJob& j, size_t want, hipStream_t stream)
@@ -37,13 +48,18 @@ int clarans_extend_draws(ClaransJob& j, size_t want, hipStream_t stream)
 // One stint as the driver: rounds for everything joined, until nothing is left or `mine` is done.
 void clarans_drive(lcsgpu_ctx* ctx, ClaransBatcher& B, ClaransJob* mine)
 {
-    const int rounds_per_look = 32;
+    // LCSGPU_CLARANS_CHAIN=1: the rounds of a look inside one launch, every search on one XCD (clarans_chain_kernel)
+    static const bool chain = env_on("LCSGPU_CLARANS_CHAIN");
+    static const int chain_rounds = env_int("LCSGPU_CLARANS_CHAIN_ROUNDS", 128), chain_ranks = env_int("LCSGPU_CLARANS_CHAIN_RANKS", 17),
+                     chain_batch = std::min(env_int("LCSGPU_CLARANS_CHAIN_BATCH", 8), lcsgpu::CLARANS_MAX_BATCH);
+    const int rounds_per_look = chain ? chain_rounds : 32;
+    const int max_batch = chain ? chain_batch : lcsgpu::CLARANS_MAX_BATCH;
     for (;;) {
         std::vector<ClaransJob*> now;
         {
             std::lock_guard<std::mutex> lk(B.mu);
             for (ClaransJob* j : B.joined)
-                if ((int)now.size() < lcsgpu::CLARANS_MAX_BATCH) now.push_back(j);
+                if ((int)now.size() < max_batch) now.push_back(j);
             if (now.empty() || mine->done) {
                 B.driver_present = false;
                 B.cv.notify_all();
@@ -61,13 +77,46 @@ void clarans_drive(lcsgpu_ctx* ctx, ClaransBatcher& B, ClaransJob* mine)
         auto hip_ok = [&](hipError_t e, const char* what) {
             if (e != hipSuccess && rc == LCSGPU_OK) rc = fail(LCSGPU_E_HIP, "%s failed: %s", what, hipGetErrorString(e));
         };
-        if (rc == LCSGPU_OK) hip_ok(lcsgpu::launch_clarans_rounds(batch, rounds_per_look, B.stream), "CLARANS rounds");
         int32_t* hs = (int32_t*)B.h_states.p;
-        for (size_t i = 0; i < now.size() && rc == LCSGPU_OK; ++i)
-            hip_ok(hipMemcpyAsync(hs + 16 * i, now[i]->a.state, 64, hipMemcpyDeviceToHost, B.stream), "state read-back");
-        if (rc == LCSGPU_OK) hip_ok(hipEventRecord(B.ev, B.stream), "hipEventRecord");
-        if (rc == LCSGPU_OK) hip_ok(hipEventSynchronize(B.ev), "hipEventSynchronize");
-        else (void)hipStreamSynchronize(B.stream);
+        auto read_states = [&](const std::vector<ClaransJob*>& which, const std::vector<size_t>& slot) {
+            for (size_t i = 0; i < which.size() && rc == LCSGPU_OK; ++i)
+                hip_ok(hipMemcpyAsync(hs + 64 * slot[i], which[i]->a.state, 256, hipMemcpyDeviceToHost, B.stream), "state read-back");
+            if (rc == LCSGPU_OK) hip_ok(hipEventRecord(B.ev, B.stream), "hipEventRecord");
+            if (rc == LCSGPU_OK) hip_ok(hipEventSynchronize(B.ev), "hipEventSynchronize");
+            else (void)hipStreamSynchronize(B.stream);
+        };
+        std::vector<size_t> all(now.size());
+        for (size_t i = 0; i < now.size(); ++i) all[i] = i;
+        if (chain) {
+            for (size_t i = 0; i < now.size() && rc == LCSGPU_OK; ++i) // ticket, go flag, barrier counter
+                hip_ok(hipMemsetAsync(now[i]->a.state + 16, 0, 128, B.stream), "hipMemsetAsync");
+            if (rc == LCSGPU_OK) hip_ok(lcsgpu::launch_clarans_chain(batch, rounds_per_look, chain_ranks, B.stream), "CLARANS chain");
+            read_states(now, all);
+            if (rc == LCSGPU_OK && getenv("LCSGPU_CLARANS_CHAIN_DBG"))
+                for (size_t i = 0; i < now.size(); ++i) {
+                    const int32_t* d = hs + 64 * i + 48;
+                    fprintf(stderr, "clarans.chain n=%d k=%d: %d rounds; rank 0 eval %d wait %d apply %d wait %d; tail eval %d wait %d apply %d wait %d (ticks)\n",
+                            now[i]->a.n_elems, now[i]->a.n_medoids, d[0], d[1], d[2], d[3], d[4], d[6], d[7], d[8], d[9]);
+                }
+            // a search whose ranks found no room on its XCD has not been touched: this look as ordinary rounds
+            std::vector<ClaransJob*> again;
+            std::vector<size_t> again_slot;
+            lcsgpu::ClaransBatch rest{};
+            for (size_t i = 0; i < now.size() && rc == LCSGPU_OK; ++i)
+                if (hs[64 * i + 17] != 1) {
+                    again.push_back(now[i]);
+                    again_slot.push_back(i);
+                    rest.s[rest.n++] = now[i]->a;
+                }
+            if (!again.empty() && rc == LCSGPU_OK) {
+                B.prof_chain_fallbacks += again.size();
+                hip_ok(lcsgpu::launch_clarans_rounds(rest, 32, B.stream), "CLARANS rounds");
+                read_states(again, again_slot);
+            }
+        } else {
+            if (rc == LCSGPU_OK) hip_ok(lcsgpu::launch_clarans_rounds(batch, rounds_per_look, B.stream), "CLARANS rounds");
+            read_states(now, all);
+        }
         {
             std::lock_guard<std::mutex> lk(B.mu);
             const std::string msg = rc == LCSGPU_OK ? std::string() : std::string(lcsgpu_last_error());
@@ -76,11 +125,12 @@ void clarans_drive(lcsgpu_ctx* ctx, ClaransBatcher& B, ClaransJob* mine)
             for (size_t i = 0; i < now.size(); ++i) {
                 ClaransJob* j = now[i];
                 if (rc == LCSGPU_OK) {
-                    memcpy(j->state, hs + 16 * i, 64);
+                    memcpy(j->state, hs + 64 * i, 64);
                     j->p_host = j->state[0];
                     if (j->state[6]) {
                         j->rc = LCSGPU_E_STATE;
-                        j->error = "CLARANS: the device search ran out of pre-drawn steps";
+                        j->error = j->state[6] == 2 ? "CLARANS: a barrier of the one-XCD kernel timed out"
+                                                    : "CLARANS: the device search ran out of pre-drawn steps";
                     }
                 } else {
                     j->rc = rc;

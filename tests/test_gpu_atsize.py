@@ -149,14 +149,15 @@ def test_c4_row_block_contexts_tree_and_sampled_triangle(oracle, synth100k):
             e.close()
 
 
-@pytest.mark.parametrize("n", [200000, 1000000])
-def test_c5_medoid_tree(tmp_path, n):
+@pytest.mark.parametrize("n,env", [(200000, {}), (1000000, {}), (200000, {"LCSGPU_CLARANS_CHAIN": "1"})],
+                         ids=["200000", "1000000", "200000-one-xcd-clarans"])
+def test_c5_medoid_tree(tmp_path, n, env):
     rec = META[f"family{n}"]
     path = str(tmp_path / f"family_{n}.fasta")
     seqio.family_fasta(n, rec["len"], path)
     assert file_sha(path) == rec["fasta_sha256"]
     out = str(tmp_path / "medoid.dnd")
-    cli("-medoidtree", "-gt", "upgma", "-gt_export", path, out)
+    cli("-medoidtree", "-gt", "upgma", "-gt_export", path, out, env=env)
     assert os.path.getsize(out) == rec["newick_bytes"]
     assert file_sha(out) == rec["medoid_upgma_newick_sha256"]
 

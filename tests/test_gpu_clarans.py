@@ -152,3 +152,21 @@ def test_concurrent_searches_share_the_batch(engine):
         [t.join() for t in threads]
         assert not errors, errors
         assert together == alone
+
+
+def test_one_xcd_chain_kernel_gives_the_same_searches():
+    """LCSGPU_CLARANS_CHAIN=1 (opt-in, read once per process, hence the subprocess): the rounds of a look inside ONE
+    launch, each search's workgroups on one XCD with barriers at that XCD's L2 and L1-bypassing loads instead of
+    kernel boundaries (clarans_chain_kernel).  Every shape of this file against the reference's CLARANS again, and
+    the concurrent searches."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("LCSGPU_CLARANS_CHAIN"):
+        pytest.skip("already inside the chain run")
+    env = dict(os.environ)
+    env["LCSGPU_CLARANS_CHAIN"] = "1"
+    p = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-x", "-k",
+                        "matches_reference or concurrent"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       text=True)
+    assert p.returncode == 0 and " passed" in p.stdout, p.stdout[-3000:]
