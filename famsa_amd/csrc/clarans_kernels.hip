@@ -664,8 +664,14 @@ __device__ __forceinline__ float chain_cost(const ClaransArgs& a, int len, float
 // clarans_eval_kernel); the result is valid in thread 0
 template <int KPT>
 __device__ __forceinline__ void chain_eval_step(const ClaransArgs& a, int xx, int x, float4* s_e, float4 (*s_we)[128], float& best_out,
-                                                int& bk_out)
+                                                int& bk_out, unsigned long long* t_ev)
 {
+    unsigned long long te0 = wall_clock64();
+    auto elap = [&](int ph) {
+        const unsigned long long t1 = wall_clock64();
+        t_ev[ph] += t1 - te0;
+        te0 = t1;
+    };
     constexpr int CH = 2048, PER = CH / 512, HALF = CH / 2, SUB = 128;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int k = a.n_medoids, n = a.n_elems;
@@ -709,6 +715,8 @@ __device__ __forceinline__ void chain_eval_step(const ClaransArgs& a, int xx, in
                 ent[u].z = s_pre[u].z;
             }
         }
+        if (ent[0].x == 12345.678f) __builtin_amdgcn_s_sleep(1); // (timing only: the loads have arrived)
+        elap(0);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int hcnt = min(HALF, cnt - h * HALF);
@@ -719,6 +727,7 @@ __device__ __forceinline__ void chain_eval_step(const ClaransArgs& a, int xx, in
                 if (t < hcnt) s_e[t] = ent[h * (PER / 2) + u];
             }
             __syncthreads();
+            elap(1);
             for (int s0 = 0; s0 < hcnt; s0 += SUB) {
                 float4 e[SUB / 64];
 #pragma unroll
@@ -756,7 +765,9 @@ __device__ __forceinline__ void chain_eval_step(const ClaransArgs& a, int xx, in
                 }
                 __builtin_amdgcn_wave_barrier();
             }
+            elap(2); // this wave's own walk
             __syncthreads();
+            elap(3); // waiting for the slowest wave
         }
     }
     float* s_v = reinterpret_cast<float*>(&s_we[0][0]);
@@ -785,6 +796,7 @@ __device__ __forceinline__ void chain_eval_step(const ClaransArgs& a, int xx, in
         bk_out = kk;
     }
     __syncthreads(); // the staging areas are free for the next step
+    elap(4);
 }
 
 template <int KPT>
@@ -840,6 +852,7 @@ __global__ __launch_bounds__(512) void clarans_chain_kernel(ClaransBatch batch, 
     // where the time of a round goes (s_memtime ticks of 10 ns), ranks 0 and P-1: evaluate, wait, apply, wait
     unsigned long long t_ph[4] = {0, 0, 0, 0}, t0 = wall_clock64();
     int n_rounds = 0;
+    unsigned long long t_ev[5] = {0, 0, 0, 0, 0}; // inside an evaluation: loads, staging, own walk, slowest wave, reduction
     auto lap = [&](int ph) {
         const unsigned long long t1 = wall_clock64();
         t_ph[ph] += t1 - t0;
@@ -858,7 +871,7 @@ __global__ __launch_bounds__(512) void clarans_chain_kernel(ClaransBatch batch, 
                 const int x = ldc(&a.win_x[win * a.win_cap + off + b]);
                 float best = 0.0f;
                 int bk = INT_MAX;
-                chain_eval_step<KPT>(a, xx, x, s_e, s_we, best, bk);
+                chain_eval_step<KPT>(a, xx, x, s_e, s_we, best, bk, t_ev);
                 if (tid == 0) {
                     a.res_delta[b] = best;
                     a.res_mm[b] = bk;
@@ -1023,6 +1036,8 @@ __global__ __launch_bounds__(512) void clarans_chain_kernel(ClaransBatch batch, 
         int* dbg = st + (tail ? 53 : 48);
         dbg[0] = n_rounds;
         for (int q = 0; q < 4; ++q) dbg[1 + q] = (int)(t_ph[q] & 0x7fffffff);
+        if (!tail)
+            for (int q = 0; q < 5; ++q) st[58 + q] = (int)(t_ev[q] & 0x7fffffff);
     }
 }
 
