@@ -2,8 +2,12 @@
 // per-row minima: the LCS triangle stays in HBM, the kernels of tree_kernels.hip consume it there.
 #include "lcsgpu_internal.h"
 
+#include <dlfcn.h>
+
 #include <memory>
 #include <queue>
+
+#include <rccl/rccl.h> // declarations only: librccl is loaded with dlopen when LCSGPU_EXCHANGE=rccl asks for it
 
 using namespace lcsgpu_impl;
 
@@ -676,6 +680,85 @@ int copy_between(lcsgpu_ctx* dst_ctx, void* dst, lcsgpu_ctx* src_ctx, const void
     return LCSGPU_OK;
 }
 
+// ---- the key exchange of the Boruvka rounds as an RCCL all-gather (LCSGPU_EXCHANGE=rccl) ------------------------------
+// One communicator per context of the call (ncclCommInitAll: one process, one rank per device), cached by device list
+// for the life of the process; librccl (0.5 GB, seconds to initialise) is loaded only when this is asked for, so the
+// library keeps depending on the HIP runtime alone.  A round's exchange is then ONE grouped ncclAllGather, in place
+// (rank k's keys already sit in slot k of its own gather buffer), on the lanes' streams: no events, no copies by hand.
+// RCCL wants one device per rank: contexts that share a device cannot use it (the peer-copy form handles those).
+struct Rccl {
+    void* lib = nullptr;
+    decltype(&ncclCommInitAll) comm_init_all = nullptr;
+    decltype(&ncclAllGather) all_gather = nullptr;
+    decltype(&ncclGroupStart) group_start = nullptr;
+    decltype(&ncclGroupEnd) group_end = nullptr;
+    decltype(&ncclGetErrorString) error_string = nullptr;
+    std::map<std::vector<int>, std::vector<ncclComm_t>> comms;
+    std::string why; // why it is unusable
+};
+std::mutex g_rccl_mu;
+Rccl g_rccl;
+
+bool exchange_is_rccl()
+{
+    const char* e = getenv("LCSGPU_EXCHANGE");
+    return e && !strcmp(e, "rccl");
+}
+
+// communicators for these devices, in this order
+int rccl_comms(const std::vector<int>& devices, const std::vector<ncclComm_t>** out)
+{
+    std::lock_guard<std::mutex> lk(g_rccl_mu);
+    Rccl& R = g_rccl;
+    if (!R.lib && R.why.empty()) {
+        for (const char* name : {"librccl.so.1", "librccl.so"})
+            if ((R.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL))) break;
+        if (!R.lib) R.why = std::string("dlopen(librccl.so.1): ") + dlerror();
+        else {
+            R.comm_init_all = (decltype(R.comm_init_all))dlsym(R.lib, "ncclCommInitAll");
+            R.all_gather = (decltype(R.all_gather))dlsym(R.lib, "ncclAllGather");
+            R.group_start = (decltype(R.group_start))dlsym(R.lib, "ncclGroupStart");
+            R.group_end = (decltype(R.group_end))dlsym(R.lib, "ncclGroupEnd");
+            R.error_string = (decltype(R.error_string))dlsym(R.lib, "ncclGetErrorString");
+            if (!R.comm_init_all || !R.all_gather || !R.group_start || !R.group_end || !R.error_string) {
+                R.why = "librccl lacks ncclCommInitAll / ncclAllGather / ncclGroupStart / ncclGroupEnd";
+                R.lib = nullptr;
+            }
+        }
+    }
+    if (!R.lib) return fail(LCSGPU_E_UNSUPPORTED, "LCSGPU_EXCHANGE=rccl: %s", R.why.c_str());
+    for (size_t a = 0; a < devices.size(); ++a)
+        for (size_t b = 0; b < a; ++b)
+            if (devices[a] == devices[b])
+                return fail(LCSGPU_E_UNSUPPORTED, "LCSGPU_EXCHANGE=rccl: contexts %zu and %zu share device %d (RCCL wants one device per "
+                                                  "rank; unset LCSGPU_EXCHANGE for the peer-copy exchange)", b, a, devices[a]);
+    auto it = R.comms.find(devices);
+    if (it == R.comms.end()) {
+        std::vector<ncclComm_t> c(devices.size(), nullptr);
+        const ncclResult_t e = R.comm_init_all(c.data(), (int)devices.size(), devices.data());
+        if (e != ncclSuccess) return fail(LCSGPU_E_HIP, "ncclCommInitAll over %zu devices failed: %s", devices.size(), R.error_string(e));
+        it = R.comms.emplace(devices, std::move(c)).first;
+    }
+    *out = &it->second;
+    return LCSGPU_OK;
+}
+
+// every context's keys (slot k of its own buffer) into every context's buffer: base[k] = the N-slot buffer of context k
+int rccl_all_gather_keys(const std::vector<ncclComm_t>& comms, const std::vector<char*>& base, size_t key_bytes,
+                         const std::vector<hipStream_t>& streams, const std::vector<int>& devices)
+{
+    Rccl& R = g_rccl;
+    ncclResult_t e = R.group_start();
+    for (size_t k = 0; k < comms.size() && e == ncclSuccess; ++k) {
+        HIP_TRY(hipSetDevice(devices[k]));
+        e = R.all_gather(base[k] + k * key_bytes, base[k], key_bytes / 8, ncclUint64, comms[k], streams[k]);
+    }
+    const ncclResult_t e2 = R.group_end();
+    if (e == ncclSuccess) e = e2;
+    if (e != ncclSuccess) return fail(LCSGPU_E_HIP, "ncclAllGather of the best-edge keys failed: %s", R.error_string(e));
+    return LCSGPU_OK;
+}
+
 // The whole LCS triangle of the uploaded set into lane 0's result buffer of ctxs[0]: row blocks of equal
 // pair counts, one per context, each computed on its own GPU at the same time; the blocks of the other
 // contexts travel into place over xGMI (copy_between: hipMemcpyPeerAsync on the producer's stream, peer access
@@ -929,7 +1012,8 @@ int lcsgpu_multi_mst_prim(lcsgpu_ctx* const* ctxs, int32_t n_ctx, int distance_k
 {
     int rc = check_multi(ctxs, n_ctx);
     if (rc) return rc;
-    if (n_ctx == 1) return lcsgpu_mst_prim(ctxs[0], distance_kind, out_edges);
+    const bool rccl = exchange_is_rccl(); // asked for by name: also with one context, so that a 1-GPU box runs the calls
+    if (n_ctx == 1 && !rccl) return lcsgpu_mst_prim(ctxs[0], distance_kind, out_edges);
     const bool triangle_orientation = (distance_kind & LCSGPU_MST_TRIANGLE_ORIENTATION) != 0;
     const int kind = distance_kind & ~LCSGPU_MST_TRIANGLE_ORIENTATION;
     if (!valid_kind(kind)) return fail(LCSGPU_E_INVALID, "unknown distance kind %d", kind);
@@ -967,6 +1051,14 @@ int lcsgpu_multi_mst_prim(lcsgpu_ctx* const* ctxs, int32_t n_ctx, int distance_k
     const int elem = ctxs[0]->max_len > 65535 ? 4 : 2;
     const std::vector<int32_t> cut = equal_pair_cuts(0, n, n_ctx);
     const size_t key_bytes = (size_t)n * sizeof(lcsgpu_mst_key);
+    const std::vector<ncclComm_t>* comms = nullptr;
+    std::vector<int> devices(n_ctx);
+    std::vector<hipStream_t> streams(n_ctx);
+    for (int k = 0; k < n_ctx; ++k) {
+        devices[k] = ctxs[k]->device;
+        streams[k] = g.lanes[k]->stream;
+    }
+    if (rccl && (rc = rccl_comms(devices, &comms))) return rc;
     for (int k = 0; k < n_ctx; ++k) {
         Lane& L = *g.lanes[k];
         const int32_t r0 = cut[k], r1 = cut[k + 1];
@@ -1004,6 +1096,7 @@ int lcsgpu_multi_mst_prim(lcsgpu_ctx* const* ctxs, int32_t n_ctx, int distance_k
             char* own = (char*)ctxs[k]->d_gather.p + ((size_t)half * n_ctx + k) * key_bytes;
             rc = shard_best(ctxs[k], *g.lanes[k], own, nullptr); // straight into its own slot
             if (rc) return rc;
+            if (comms) continue; // the exchange is one grouped all-gather below
             for (int j = 0; j < n_ctx; ++j) {
                 if (j == k) continue;
                 char* slot = (char*)ctxs[j]->d_gather.p + ((size_t)half * n_ctx + k) * key_bytes;
@@ -1013,9 +1106,15 @@ int lcsgpu_multi_mst_prim(lcsgpu_ctx* const* ctxs, int32_t n_ctx, int distance_k
             HIP_TRY(hipSetDevice(ctxs[k]->device));
             HIP_TRY(hipEventRecord(pushed[(size_t)half * n_ctx + k], g.lanes[k]->stream));
         }
+        if (comms) {
+            std::vector<char*> base(n_ctx);
+            for (int k = 0; k < n_ctx; ++k) base[k] = (char*)ctxs[k]->d_gather.p + (size_t)half * n_ctx * key_bytes;
+            rc = rccl_all_gather_keys(*comms, base, key_bytes, streams, devices);
+            if (rc) return rc;
+        }
         for (int j = 0; j < n_ctx; ++j) { // global halves: each context over all N slots, once they have landed
             HIP_TRY(hipSetDevice(ctxs[j]->device));
-            for (int k = 0; k < n_ctx; ++k)
+            for (int k = 0; k < n_ctx && !comms; ++k) // (the all-gather is ordered on the lane's own stream)
                 if (k != j) HIP_TRY(hipStreamWaitEvent(g.lanes[j]->stream, pushed[(size_t)half * n_ctx + k], 0));
             rc = shard_merge_async(ctxs[j], *g.lanes[j], (char*)ctxs[j]->d_gather.p + (size_t)half * n_ctx * key_bytes, n_ctx);
             if (rc) return rc;

@@ -282,7 +282,10 @@ int lcsgpu_nj(lcsgpu_ctx* ctx, int distance_kind, int32_t* out_left, int32_t* ou
  * lcsgpu_multi_mst_prim: as lcsgpu_mst_prim, by the sharded Boruvka rounds above with the exchange in DEVICE memory:
  *   per round every context pushes its n keys (16 B each) into its slot of every other context's gathered buffer
  *   (peer copies over xGMI on the producer's stream = the all-gather), every context runs the same global half on
- *   its own GPU, and the host synchronises once (the edge count).  LCSGPU_E_UNSUPPORTED for orientation-sensitive
+ *   its own GPU, and the host synchronises once (the edge count).  With LCSGPU_EXCHANGE=rccl in the environment the
+ *   exchange is ONE grouped ncclAllGather per round instead (in place, on the contexts' streams; librccl is loaded on
+ *   demand and a communicator per device list is kept for the life of the process) -- RCCL wants one device per rank:
+ *   LCSGPU_E_UNSUPPORTED when two contexts share a device.  LCSGPU_E_UNSUPPORTED also for orientation-sensitive
  *   sets in MSTPrim's own orientation (run lcsgpu_mst_prim on one context then).
  * Device-to-device copies between contexts switch peer access on for the device pair at first use; where the
  * devices cannot address each other the copy is staged through pinned host memory (slower, same result).  Test

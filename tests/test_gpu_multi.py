@@ -94,6 +94,34 @@ def test_group_calls_over_the_other_transports(engine, monkeypatch, switch):
         grp.close()
 
 
+def test_key_exchange_as_an_rccl_all_gather(engine, monkeypatch):
+    """LCSGPU_EXCHANGE=rccl: the per-round key exchange of lcsgpu_multi_mst_prim is one grouped ncclAllGather on the
+    contexts' streams (librccl loaded on demand, ncclCommInitAll over the contexts' devices).  RCCL wants one device
+    per rank, so what a 1-GPU box can run is the group of ONE context -- communicator, in-place all-gather and
+    stream ordering all execute (with this switch the call does not shortcut to lcsgpu_mst_prim) -- and the refusal
+    of contexts that share a device."""
+    monkeypatch.setenv("LCSGPU_EXCHANGE", "rccl")
+    seqs = _sets()["family"]
+    engine.upload_seqs(seqs)
+    one = famsa_amd.LcsGpuGroup([0])
+    two = famsa_amd.LcsGpuGroup([0, 0])
+    try:
+        one.upload_seqs(seqs)
+        for kind in (1, 0):
+            a = one.mst_prim(kind)
+            monkeypatch.delenv("LCSGPU_EXCHANGE")
+            b = engine.mst_prim(kind)
+            monkeypatch.setenv("LCSGPU_EXCHANGE", "rccl")
+            assert (a["from"] == b["from"]).all() and (a["to"] == b["to"]).all()
+            assert (a["dist"].view(np.uint64) == b["dist"].view(np.uint64)).all()
+        two.upload_seqs(seqs)
+        with pytest.raises(famsa_amd.LcsGpuError, match="share device"):
+            two.mst_prim(1)
+    finally:
+        one.close()
+        two.close()
+
+
 def test_group_refuses_what_it_cannot_do(engine):
     seqs = [np.zeros(192, np.uint8)] + _sets()["family"][:300]  # a carry-quirk (orientation-sensitive) sequence
     grp = famsa_amd.LcsGpuGroup([0, 0])
