@@ -64,16 +64,20 @@ __device__ __forceinline__ void wave_first_min_valid(float& v, int& i)
 }
 
 enum { ST_P = 0, ST_DONE = 1, ST_LOG_LEN = 2, ST_ROUNDS = 3, ST_ARRIVE = 4, ST_COST = 5, ST_ERR = 6, ST_WIN = 7,
-       ST_OFF = 8, ST_STAGE = 9, ST_FIRST = 10 };
+       ST_OFF = 8, ST_STAGE = 9, ST_FIRST = 10,
+       ST_N_ROUNDS = 11, ST_N_STEPS = 12, ST_N_USEFUL = 13 }; // statistics of the search (LCSGPU_PROFILE): rounds, steps evaluated, steps up to the accepted one
 
-// A window of pending steps is evaluated in stages of 16, 32, 64, 64, ... steps: most accepts come
-// within the first few steps, and the steps after the accepted one are wasted work that other
-// searches running at the same time have to queue behind.
+// A window of pending steps is evaluated in stages of 16, 32, 64, 64, ... steps (ClaransArgs::stage0 = 16,
+// LCSGPU_CLARANS_STAGE0): the steps after the accepted one are wasted work that other searches running at
+// the same time have to queue behind.  Measured at 3 x 10^6 sequences (LCSGPU_PROFILE prints the counts): 878
+// searches, 282 000 rounds, 224 000 accepts, 5.9 M steps evaluated of which 2.7 M up to the accepted one (the
+// accepted step is the 8th of its round on average); a first stage of 4 / 8 / 16 / 24 steps gives a tree stage
+// of 2.37 / 2.20 / 2.09-2.14 / 2.05 s -- the rate of dependent rounds, not the evaluation work, is the limit.
 constexpr int STAGE_MAX = 64; // = the apply kernel's workgroup size: one result per lane
 __device__ __forceinline__ int window_size(int corrected, int first) { return first ? corrected : (corrected > 0 ? corrected - 1 : 0); }
-__device__ __forceinline__ int stage_size(int stage, int left)
+__device__ __forceinline__ int stage_size(int stage, int left, int stage0)
 {
-    const int want = stage >= 2 ? STAGE_MAX : (16 << stage);
+    const int want = min(STAGE_MAX, stage0 << min(stage, 6));
     return left < want ? (left < 0 ? 0 : left) : want;
 }
 
@@ -139,6 +143,9 @@ __global__ __launch_bounds__(256) void clarans_init_kernel(ClaransArgs a)
         a.state[ST_OFF] = 0;
         a.state[ST_STAGE] = 0;
         a.state[ST_FIRST] = 1;
+        a.state[ST_N_ROUNDS] = 0;
+        a.state[ST_N_STEPS] = 0;
+        a.state[ST_N_USEFUL] = 0;
         if (p + W > a.draws_len) a.state[ST_ERR] = 1;
     }
     if (p + W <= a.draws_len)
@@ -193,7 +200,7 @@ __global__ __launch_bounds__(512) void clarans_eval_kernel(ClaransBatch batch)
     const int4 st2 = *reinterpret_cast<const int4*>(a.state + 8);
     const int win = st1.w & 1;
     const bool cost_wg = b == (int)gridDim.x - 1;
-    const int S = stage_size(st2.y, window_size(corrected, st2.z) - st2.x); // steps evaluated in this round
+    const int S = stage_size(st2.y, window_size(corrected, st2.z) - st2.x, a.stage0); // steps evaluated in this round
     if (!cost_wg && b >= S) return;
     const int bb = cost_wg ? 0 : st2.x + b; // index of this workgroup's step in the window
     const int xx = a.win_xx[win * a.win_cap + bb];
@@ -400,7 +407,7 @@ __global__ __launch_bounds__(64) void clarans_apply_kernel(ClaransBatch batch)
     const int4 st1 = *reinterpret_cast<const int4*>(st + 4);
     const int4 st2 = *reinterpret_cast<const int4*>(st + 8);
     const int W = window_size(corrected, st2.z), off = st2.x;
-    const int S = stage_size(st2.y, W - off);
+    const int S = stage_size(st2.y, W - off, a.stage0);
     const int W_next = window_size(corrected, 0);
     const int yy = k + blockIdx.x * 64 + tid;
     const bool have = !last_wg && yy < n;
@@ -539,6 +546,9 @@ __global__ __launch_bounds__(64) void clarans_apply_kernel(ClaransBatch batch)
     __syncthreads();
     if (s_last && tid == 0) {
         st[ST_ARRIVE] = 0;
+        st[ST_N_ROUNDS] += 1;
+        st[ST_N_STEPS] += st1.z ? 0 : S;
+        st[ST_N_USEFUL] += accept ? w + 1 : (st1.z ? 0 : S);
         if (accept) {
             const int mo = a.cand[mm_new];
             a.cand[mm_new] = x;
@@ -860,7 +870,7 @@ __global__ __launch_bounds__(512) void clarans_chain_kernel(ClaransBatch batch, 
     };
     for (int r = 0; r < max_rounds && !done; ++r) {
         const int W = window_size(corrected, first);
-        const int S = stage_size(stage, W - off);
+        const int S = stage_size(stage, W - off, a.stage0);
         ++n_rounds;
         // ---- evaluate
         if (tail) {

@@ -268,6 +268,7 @@ struct ClaransArgs {
                          // [8] steps of the window already evaluated  [9] stage  [10] no accept yet in this search
     int32_t n_elems, n_medoids, n_fixed, draws_len, win_cap;
     int32_t corrected;   // steps without an accept that end a local search (Clustering.cpp:21-29)
+    int32_t stage0;      // steps evaluated in the first round of a window; doubled per round without an accept, at most 64
 };
 // Searches that are advanced together, one grid row each: however many host threads are searching,
 // a round costs two launches (evaluate, apply) in total instead of two per search -- with one launch

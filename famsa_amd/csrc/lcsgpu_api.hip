@@ -497,6 +497,9 @@ int lcsgpu_destroy(lcsgpu_ctx* ctx)
                 if (B.prof_looks[i])
                     fprintf(stderr, "clarans.batch[%d searches]: %ld looks, %.3f s, %.1f us per look\n", i, B.prof_looks[i],
                             B.prof_seconds[i], 1e6 * B.prof_seconds[i] / B.prof_looks[i]);
+        if (getenv("LCSGPU_PROFILE") && B.prof_searches)
+            fprintf(stderr, "clarans.searches=%ld accepts=%ld rounds=%ld steps_evaluated=%ld steps_up_to_the_accept=%ld\n", B.prof_searches,
+                    B.prof_accepts, B.prof_rounds, B.prof_steps, B.prof_useful);
         if (getenv("LCSGPU_PROFILE") && B.prof_chain_fallbacks)
             fprintf(stderr, "clarans.chain_fallbacks=%ld\n", B.prof_chain_fallbacks);
         if (B.stream) { (void)hipStreamSynchronize(B.stream); (void)hipStreamDestroy(B.stream); }

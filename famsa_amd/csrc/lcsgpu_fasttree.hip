@@ -137,6 +137,11 @@ void clarans_drive(lcsgpu_ctx* ctx, ClaransBatcher& B, ClaransJob* mine)
                     j->error = msg;
                 }
                 if (j->rc != LCSGPU_OK || j->state[1]) {
+                    B.prof_searches += 1;
+                    B.prof_accepts += j->state[3];
+                    B.prof_rounds += j->state[11];
+                    B.prof_steps += j->state[12];
+                    B.prof_useful += j->state[13];
                     j->done = true;
                     B.joined.erase(std::find(B.joined.begin(), B.joined.end(), j));
                 }
@@ -566,6 +571,8 @@ int lcsgpu_clarans(lcsgpu_ctx* ctx, const int32_t* ids, int32_t n_ids, int dista
     a.n_fixed = n_fixed;
 
     a.corrected = corrected;
+    static const int stage0 = std::max(1, std::min(64, env_int("LCSGPU_CLARANS_STAGE0", 16)));
+    a.stage0 = stage0;
     // The two generators of Clustering.cpp:43-44.  Neither looks at the search state, so the host
     // runs them: gen_nodes shuffles the candidate order before every local search, gen_positions
     // yields the step positions, handed to the device as a growing array of draws.

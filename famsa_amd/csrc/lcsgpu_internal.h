@@ -143,6 +143,7 @@ struct ClaransBatcher {
     // LCSGPU_PROFILE: looks and seconds by number of searches in the batch
     long prof_looks[lcsgpu::CLARANS_MAX_BATCH + 1] = {0};
     double prof_seconds[lcsgpu::CLARANS_MAX_BATCH + 1] = {0};
+    long prof_rounds = 0, prof_steps = 0, prof_useful = 0, prof_accepts = 0, prof_searches = 0; // over finished searches
     long prof_chain_fallbacks = 0; // LCSGPU_CLARANS_CHAIN: searches of a look that found no room on their XCD
 };
 
