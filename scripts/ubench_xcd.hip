@@ -41,10 +41,12 @@ __device__ __forceinline__ bool xcd_barrier(unsigned* counter, unsigned target)
     return ok;
 }
 
+// WT (mode 3): the writers use agent-scope relaxed atomic STORES (sc1: written through the XCD's L2) -- with sc1 loads on the
+// other side that should be coherent between XCDs without any fence, which plain stores are not
 // mode 0: participants = the first P ticket holders on XCD `want_xcd`;  mode 1: participants = blocks 0..P-1 wherever they run
 // FENCE: the readers use PLAIN loads and an agent-scope ACQUIRE fence after the barrier (invalidates the CU's L1) instead
 // of sc1 loads -- what a kernel with many loads would rather do
-template <bool FENCE>
+template <bool FENCE, bool WT = false>
 __global__ __launch_bounds__(256) void k_chain(unsigned* ctl, unsigned* slots, float* rows, int P, int iters, int mode, unsigned want_xcd,
                                                unsigned* stats)
 {
@@ -64,8 +66,13 @@ __global__ __launch_bounds__(256) void k_chain(unsigned* ctl, unsigned* slots, f
     if (rank >= (unsigned)P) return;
     unsigned errors = 0;
     for (int it = 0; it < iters; ++it) {
-        if (threadIdx.x == 0) slots[rank * 32] = (unsigned)it + 1u;                 // 128-byte stride
-        if (threadIdx.x < 64) rows[rank * 64 + threadIdx.x] = (float)(it + 1) + 0.5f; // a plain store
+        if (WT) {
+            if (threadIdx.x == 0) __hip_atomic_store(&slots[rank * 32], (unsigned)it + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (threadIdx.x < 64) __hip_atomic_store(&rows[rank * 64 + threadIdx.x], (float)(it + 1) + 0.5f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            if (threadIdx.x == 0) slots[rank * 32] = (unsigned)it + 1u;                 // 128-byte stride
+            if (threadIdx.x < 64) rows[rank * 64 + threadIdx.x] = (float)(it + 1) + 0.5f; // a plain store
+        }
         if (!xcd_barrier(&ctl[32], (unsigned)(it + 1) * 2u * P - P)) { atomicAdd(&stats[0], 1u); return; }
         if (FENCE) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -89,7 +96,7 @@ int main()
 {
     unsigned *ctl, *slots, *stats;
     float* rows;
-    hipMalloc(&ctl, 4096); hipMalloc(&slots, 256 * 128); hipMalloc(&rows, 256 * 64 * 4); hipMalloc(&stats, 256);
+    hipMalloc(&ctl, 4096); hipMalloc(&slots, 1024 * 128); hipMalloc(&rows, 1024 * 64 * 4); hipMalloc(&stats, 256);
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
     const int iters = 20000;
     // mode 2: any XCD, but the shared words live in UNCACHED (fine-grained) device memory: coherent between the XCDs
@@ -135,6 +142,16 @@ int main()
         float ms = 0; hipEventElapsedTime(&ms, a, b);
         unsigned h[64]; hipMemcpy(h, stats, 256, hipMemcpyDeviceToHost);
         printf("one XCD, plain loads + acquire fence P=%2d: %.2f us per step, timeouts %u, stale reads %u  [%s]\n", P, 1e3 * ms / iters, h[0], h[1], hipGetErrorString(e));
+    }
+    for (int P : {8, 16, 32, 64, 128, 256, 512, 1024}) { // any XCD, write-through stores + sc1 loads, no fence
+        hipMemset(ctl, 0, 4096); hipMemset(slots, 0, 1024 * 128); hipMemset(rows, 0, 1024 * 64 * 4); hipMemset(stats, 0, 256);
+        hipEventRecord(a);
+        hipLaunchKernelGGL((k_chain<false, true>), dim3(P), dim3(256), 0, 0, ctl, slots, rows, P, iters, 1, 0u, stats);
+        hipEventRecord(b);
+        hipError_t e = hipEventSynchronize(b);
+        float ms = 0; hipEventElapsedTime(&ms, a, b);
+        unsigned h[64]; hipMemcpy(h, stats, 256, hipMemcpyDeviceToHost);
+        printf("any XCD, sc1 STORES + sc1 loads, no fence P=%4d: %.2f us per step, timeouts %u, stale reads %u  [%s]\n", P, 1e3 * ms / iters, h[0], h[1], hipGetErrorString(e));
     }
     return 0;
 }
