@@ -589,6 +589,7 @@ __global__ __launch_bounds__(64) void clarans_apply_kernel(ClaransBatch batch)
 // rank P-1 keeps the running cost and does the apply kernel's last-workgroup part.  The control state (next draw, window,
 // stage, ...) is computed by every workgroup from the same step results, so a round needs exactly two barriers.
 // Arithmetic, comparison directions and the order of every float addition are those of the two kernels above.
+constexpr int CHAIN_SUB = 128; // entries per compaction pass of an evaluation (256: walk -9 %, 48 KB of LDS)
 enum { CH_TICKET = 16, CH_GO = 17, CH_BAR = 32 }; // words of the search's 64-word state block (zeroed by the host before every launch)
 
 template <typename T>
@@ -673,7 +674,7 @@ __device__ __forceinline__ float chain_cost(const ClaransArgs& a, int len, float
 // deltas[slot] of the member x drawn at position xx and their first minimum over the free slots (the body of
 // clarans_eval_kernel); the result is valid in thread 0
 template <int KPT>
-__device__ __forceinline__ void chain_eval_step(const ClaransArgs& a, int xx, int x, float4* s_e, float4 (*s_we)[128], float& best_out,
+__device__ __forceinline__ void chain_eval_step(const ClaransArgs& a, int xx, int x, float4* s_e, float4 (*s_we)[CHAIN_SUB], float& best_out,
                                                 int& bk_out, unsigned long long* t_ev)
 {
     unsigned long long te0 = wall_clock64();
@@ -682,7 +683,7 @@ __device__ __forceinline__ void chain_eval_step(const ClaransArgs& a, int xx, in
         t_ev[ph] += t1 - te0;
         te0 = t1;
     };
-    constexpr int CH = 2048, PER = CH / 512, HALF = CH / 2, SUB = 128;
+    constexpr int CH = 2048, PER = CH / 512, HALF = CH / 2, SUB = CHAIN_SUB;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int k = a.n_medoids, n = a.n_elems;
     const uint64_t lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
@@ -813,7 +814,7 @@ template <int KPT>
 __global__ __launch_bounds__(512) void clarans_chain_kernel(ClaransBatch batch, int P, int max_rounds)
 {
     __shared__ float4 s_e[1024];    // 16 KB
-    __shared__ float4 s_we[8][128]; // 16 KB
+    __shared__ float4 s_we[8][CHAIN_SUB];
     __shared__ int s_rank, s_search;
     const int tid = threadIdx.x, lane = tid & 63;
     if (tid == 0) {
@@ -862,6 +863,7 @@ __global__ __launch_bounds__(512) void clarans_chain_kernel(ClaransBatch batch, 
     // where the time of a round goes (s_memtime ticks of 10 ns), ranks 0 and P-1: evaluate, wait, apply, wait
     unsigned long long t_ph[4] = {0, 0, 0, 0}, t0 = wall_clock64();
     int n_rounds = 0;
+    const unsigned long long clk0 = __builtin_readcyclecounter(), wall0 = wall_clock64(); // shader clocks per 10 ns tick = the clock the kernel ran at
     unsigned long long t_ev[5] = {0, 0, 0, 0, 0}; // inside an evaluation: loads, staging, own walk, slowest wave, reduction
     auto lap = [&](int ph) {
         const unsigned long long t1 = wall_clock64();
@@ -1048,6 +1050,8 @@ __global__ __launch_bounds__(512) void clarans_chain_kernel(ClaransBatch batch, 
         for (int q = 0; q < 4; ++q) dbg[1 + q] = (int)(t_ph[q] & 0x7fffffff);
         if (!tail)
             for (int q = 0; q < 5; ++q) st[58 + q] = (int)(t_ev[q] & 0x7fffffff);
+            const unsigned long long dw = wall_clock64() - wall0;
+            st[63] = dw ? (int)((__builtin_readcyclecounter() - clk0) * 100 / dw) : 0; // MHz
     }
 }
 

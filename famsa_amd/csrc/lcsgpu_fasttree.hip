@@ -95,8 +95,8 @@ void clarans_drive(lcsgpu_ctx* ctx, ClaransBatcher& B, ClaransJob* mine)
             if (rc == LCSGPU_OK && getenv("LCSGPU_CLARANS_CHAIN_DBG"))
                 for (size_t i = 0; i < now.size(); ++i) {
                     const int32_t* d = hs + 64 * i + 48;
-                    fprintf(stderr, "clarans.chain n=%d k=%d: %d rounds; rank 0 eval %d wait %d apply %d wait %d; tail eval %d wait %d apply %d wait %d; rank 0's evaluations: loads %d staging %d own walk %d slowest wave %d reduction %d (ticks of 10 ns)\n",
-                            now[i]->a.n_elems, now[i]->a.n_medoids, d[0], d[1], d[2], d[3], d[4], d[6], d[7], d[8], d[9], d[10], d[11], d[12], d[13], d[14]);
+                    fprintf(stderr, "clarans.chain n=%d k=%d: %d rounds; rank 0 eval %d wait %d apply %d wait %d; tail eval %d wait %d apply %d wait %d; rank 0's evaluations: loads %d staging %d own walk %d slowest wave %d reduction %d (ticks of 10 ns); shader clock %d MHz\n",
+                            now[i]->a.n_elems, now[i]->a.n_medoids, d[0], d[1], d[2], d[3], d[4], d[6], d[7], d[8], d[9], d[10], d[11], d[12], d[13], d[14], d[15]);
                 }
             // a search whose ranks found no room on its XCD has not been touched: this look as ordinary rounds
             std::vector<ClaransJob*> again;
