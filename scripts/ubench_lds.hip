@@ -14,7 +14,7 @@ __global__ __launch_bounds__(512) void k(float* out, unsigned long long* cyc, in
     __shared__ int s_z[1024];
     __shared__ float4 s_we[8][128 + 16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i = tid; i < 1024; i += 512) {
+    for (int i = tid; i < 1024; i += blockDim.x) {
         const int nn = (i * 7) % 100;
         s_e[i] = make_float4(1.0f + i, (i % 37) ? 0.0f : -1.0f, __int_as_float(nn), 0.0f);
         s_x[i] = 1.0f + i; s_y[i] = (i % 37) ? 0.0f : -1.0f; s_z[i] = nn;
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(512) void k(float* out, unsigned long long* cyc, in
         }
     }
     const unsigned long long t1 = __builtin_readcyclecounter();
-    out[blockIdx.x * 512 + tid] = acc;
+    out[blockIdx.x * blockDim.x + tid] = acc;
     if (tid == 0) cyc[blockIdx.x] = t1 - t0;
 }
 
@@ -129,5 +129,14 @@ int main()
             printf("%4d workgroups, %-34s: %.0f clocks per 128-entry pass of one wave (8 waves share the array)\n", blocks, names[mode],
                    (double)h / iters / 8);
         }
+    // fewer waves per workgroup, more slots per wave: the own entries are walked once whatever the split, the negative
+    // ones and the padding once per wave, and a SIMD then runs one wave's compaction instead of two
+    for (int waves : {8, 4, 2}) {
+        hipLaunchKernelGGL(k<3>, dim3(1024), dim3(64 * waves), 0, 0, out, cyc, iters, 0, 100 / waves + 1);
+        hipDeviceSynchronize();
+        unsigned long long h = 0; hipMemcpy(&h, cyc, 8, hipMemcpyDeviceToHost);
+        printf("1024 workgroups of %d waves, each wave owning %d of 100 slots: %.0f clocks per 128-entry pass\n", waves, 100 / waves + 1,
+               (double)h / iters / 8);
+    }
     return 0;
 }
