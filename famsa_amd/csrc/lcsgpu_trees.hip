@@ -749,12 +749,14 @@ int rccl_all_gather_keys(const std::vector<ncclComm_t>& comms, const std::vector
 {
     Rccl& R = g_rccl;
     ncclResult_t e = R.group_start();
-    for (size_t k = 0; k < comms.size() && e == ncclSuccess; ++k) {
-        HIP_TRY(hipSetDevice(devices[k]));
-        e = R.all_gather(base[k] + k * key_bytes, base[k], key_bytes / 8, ncclUint64, comms[k], streams[k]);
+    hipError_t he = hipSuccess;
+    for (size_t k = 0; k < comms.size() && e == ncclSuccess && he == hipSuccess; ++k) {
+        he = hipSetDevice(devices[k]);
+        if (he == hipSuccess) e = R.all_gather(base[k] + k * key_bytes, base[k], key_bytes / 8, ncclUint64, comms[k], streams[k]);
     }
-    const ncclResult_t e2 = R.group_end();
+    const ncclResult_t e2 = R.group_end(); // whatever happened inside: the group must be closed
     if (e == ncclSuccess) e = e2;
+    if (he != hipSuccess) return fail(LCSGPU_E_HIP, "hipSetDevice failed: %s", hipGetErrorString(he));
     if (e != ncclSuccess) return fail(LCSGPU_E_HIP, "ncclAllGather of the best-edge keys failed: %s", R.error_string(e));
     return LCSGPU_OK;
 }
