@@ -462,7 +462,8 @@ int lcsgpu_mst_prim(lcsgpu_ctx* ctx, int distance_kind, lcsgpu_mst_edge* out_edg
         else {
             rc = run_rows(ctx, L, lcsgpu::MODE_TRIANGLE, nullptr, 0, r_fit, nullptr, 0, r_fit - 1, L.d_out.p, 0, 0, elem);
             if (!rc) rc = shard_begin(ctx, L, L.d_out.p, elem, 0, r_fit, distance_kind);
-            if (!rc) HIP_TRY(ctx->d_gather.reserve(2 * (size_t)n * sizeof(lcsgpu_mst_key)));
+            if (!rc && ctx->d_gather.reserve(2 * (size_t)n * sizeof(lcsgpu_mst_key)) != hipSuccess)
+                rc = fail(LCSGPU_E_NOMEM, "no device memory for the keys of the two row blocks");
         }
         const bool hybrid = r_fit > 0 && r_fit < n;
         if (getenv("LCSGPU_PROFILE"))
@@ -488,7 +489,10 @@ int lcsgpu_mst_prim(lcsgpu_ctx* ctx, int distance_kind, lcsgpu_mst_edge* out_edg
             rest.best = gathered + n;
             rc = fused_rows(ctx, L, rest, nullptr, elem, ctx->mst.rounds > 0);
             if (rc) break;
-            HIP_TRY(lcsgpu::launch_boruvka_fuse_fold(rest, L.stream));
+            if (const hipError_t e = lcsgpu::launch_boruvka_fuse_fold(rest, L.stream)) {
+                rc = fail(LCSGPU_E_HIP, "the fold of the recomputed rows failed: %s", hipGetErrorString(e));
+                break;
+            }
             rc = shard_merge(ctx, L, gathered, 2, nullptr);
         }
         if (!rc) rc = shard_finish(ctx, L, out_edges);
