@@ -167,105 +167,94 @@ __global__ __launch_bounds__(256) void clarans_init_kernel(ClaransArgs a)
     a.cost_log[pos - k] = nb.dn;
 }
 
-// A kernel boundary leaves nothing in the caches that another XCD wrote, so every DEPENDENT global
-// load of these small kernels costs a trip to memory (~1.5 us): both kernels are laid out to have as
-// few dependent levels as possible -- everything whose address does not depend on the step is
-// requested first, the pending steps' positions/members are precomputed by the previous kernel.
-
-// One workgroup per pending step b of the window: deltas[slot] of the member win_x[b]
-// (Clustering.cpp:93-118) and their first minimum over the free slots (cpp:121-122).
-// Every slot's delta is a sequential float sum over the non-medoids in position order.  A
-// non-medoid adds to its own nearest slot always and to all others only when the candidate is
-// closer to it than its medoid (rare), so each of the 8 waves -- wave w owns the slots
-// [w * kpw, (w + 1) * kpw) -- first compacts, in order, the entries that can change one of ITS
-// slots and then walks only those: skipped entries would add +0.0f, the identity.
-// Workgroup W adds the previous round's cost addends to the running cost, in order.
-template <int KPT>
-__global__ __launch_bounds__(512) void clarans_eval_kernel(ClaransBatch batch)
+// loads of what another workgroup of the SAME launch wrote (the one-XCD kernel below): they bypass this CU's L1 (sc1)
+template <typename T>
+__device__ __forceinline__ T ldc(const T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float4 ldc4(const float4* p)
 {
-    const ClaransArgs& a = batch.s[blockIdx.y];
-    const int corrected = a.corrected;
-    // 32 KB of LDS and 512 lanes per workgroup: four fit a CU, so the 65 x 16 workgroups of a full
-    // batch of searches are resident together
-    constexpr int CH = 2048, PER = CH / 512; // positions whose data a workgroup keeps in registers at a time
-    constexpr int HALF = CH / 2;             // ... and stages through LDS in two halves
-    constexpr int SUB = 128;
-    __shared__ float4 s_e[HALF];        // 16 KB
-    __shared__ float4 s_we[8][SUB];     // 16 KB: per wave, the entries of one sub-chunk that concern its slots
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int k = a.n_medoids, n = a.n_elems;
-    // level 1: state, this step, and the first chunk's per-position data
-    const int4 st0 = *reinterpret_cast<const int4*>(a.state);
-    const int4 st1 = *reinterpret_cast<const int4*>(a.state + 4);
-    const int4 st2 = *reinterpret_cast<const int4*>(a.state + 8);
-    const int win = st1.w & 1;
-    const bool cost_wg = b == (int)gridDim.x - 1;
-    const int S = stage_size(st2.y, window_size(corrected, st2.z) - st2.x, a.stage0); // steps evaluated in this round
-    if (!cost_wg && b >= S) return;
-    const int bb = cost_wg ? 0 : st2.x + b; // index of this workgroup's step in the window
-    const int xx = a.win_xx[win * a.win_cap + bb];
-    const int x = a.win_x[win * a.win_cap + bb];
-    int y_pre[PER];
-    float4 s_pre[PER];
-#pragma unroll
-    for (int u = 0; u < PER; ++u) {
-        const int yy = k + tid + 512 * u;
-        y_pre[u] = yy < n ? a.cand[yy] : 0;
-        s_pre[u] = yy < n ? a.st[yy] : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    if (st0.y) return; // done
+    const uint64_t* q = reinterpret_cast<const uint64_t*>(p);
+    const uint64_t lo = ldc(q), hi = ldc(q + 1);
+    return make_float4(__uint_as_float((uint32_t)lo), __uint_as_float((uint32_t)(lo >> 32)), __uint_as_float((uint32_t)hi),
+                       __uint_as_float((uint32_t)(hi >> 32)));
+}
+template <bool COH, typename T>
+__device__ __forceinline__ T ld(const T* p) { return COH ? ldc(p) : *p; }
+template <bool COH>
+__device__ __forceinline__ float4 ld4(const float4* p) { return COH ? ldc4(p) : *p; }
+
+// running cost: c += addend for every logged addend, in order; zeros are the identity (c starts at +0.0f and can
+// never become -0.0f), so only the others are walked.  Valid in thread 0.
+template <bool COH>
+__device__ __forceinline__ float cost_accumulate(const ClaransArgs& a, int len, float c, float* s_f, float* s_nz)
+{
+    constexpr int CH = 2048, PER = CH / 512;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint64_t lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
-    if (cost_wg) {
-        // running cost: c += addend for every logged addend, in order; zeros are the identity
-        // (c starts at +0.0f and can never become -0.0f), so only the others are walked
-        const int len = st0.z;
-        if (len == 0) return;
-        float c = __int_as_float(st1.y);
-        float* s_f = reinterpret_cast<float*>(s_e);      // CH floats: the addends of one pass
-        float* s_nz = reinterpret_cast<float*>(s_we);    // CH floats: the non-zero ones, in order
-        for (int c0 = 0; c0 < len; c0 += CH) {
-            const int cnt = min(CH, len - c0);
-            float v[PER];
+    for (int c0 = 0; c0 < len; c0 += CH) {
+        const int cnt = min(CH, len - c0);
+        float v[PER];
 #pragma unroll
-            for (int u = 0; u < PER; ++u) { // one trip to memory for the whole pass
-                const int t = tid + 512 * u;
-                v[u] = t < cnt ? a.cost_log[c0 + t] : 0.0f;
-            }
-#pragma unroll
-            for (int u = 0; u < PER; ++u) s_f[tid + 512 * u] = v[u];
-            __syncthreads();
-            if (wave == 0) {
-                int m = 0;
-                for (int base = 0; base < cnt; base += 256) {
-                    float g[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) g[u] = s_f[base + 64 * u + lane]; // zero beyond cnt
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const uint64_t mask = __ballot(g[u] != 0.0f);
-                        if (g[u] != 0.0f) s_nz[m + __popcll(mask & lt_mask)] = g[u];
-                        m += __popcll(mask);
-                    }
-                }
-                __builtin_amdgcn_wave_barrier(); // same wave: its LDS writes are performed before its later reads
-                if (lane == 0) {
-                    int t = 0;
-                    for (; t + 8 <= m; t += 8) {
-                        float g[8];
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) g[u] = s_nz[t + u];
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) c = __fadd_rn(c, g[u]);
-                    }
-                    for (; t < m; ++t) c = __fadd_rn(c, s_nz[t]);
-                }
-            }
-            __syncthreads();
+        for (int u = 0; u < PER; ++u) { // one trip to memory for the whole pass
+            const int t = tid + 512 * u;
+            v[u] = t < cnt ? ld<COH>(&a.cost_log[c0 + t]) : 0.0f;
         }
-        if (tid == 0) a.state[ST_COST] = __float_as_int(c);
-        return;
+#pragma unroll
+        for (int u = 0; u < PER; ++u) s_f[tid + 512 * u] = v[u];
+        __syncthreads();
+        if (wave == 0) {
+            int m = 0;
+            for (int base = 0; base < cnt; base += 256) {
+                float g[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) g[u] = s_f[base + 64 * u + lane]; // zero beyond cnt
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint64_t mask = __ballot(g[u] != 0.0f);
+                    if (g[u] != 0.0f) s_nz[m + __popcll(mask & lt_mask)] = g[u];
+                    m += __popcll(mask);
+                }
+            }
+            __builtin_amdgcn_wave_barrier(); // same wave: its LDS writes are performed before its later reads
+            if (lane == 0) {
+                int t = 0;
+                for (; t + 8 <= m; t += 8) {
+                    float g[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) g[u] = s_nz[t + u];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) c = __fadd_rn(c, g[u]);
+                }
+                for (; t < m; ++t) c = __fadd_rn(c, s_nz[t]);
+            }
+        }
+        __syncthreads();
     }
-    if (st1.z) return; // error flagged: apply ends the search
+    return c;
+}
+
+// deltas[slot] of the member x drawn at position xx (Clustering.cpp:93-118) and their first minimum over the free slots
+// (cpp:121-122); the result is valid in thread 0.  Every slot's delta is a sequential float sum over the non-medoids in
+// position order.  A non-medoid adds to its own nearest slot always and to all others only when the candidate is closer
+// to it than its medoid (rare), so each of the 8 waves -- wave w owns the slots [w * kpw, (w + 1) * kpw) -- first
+// compacts, in order, the entries that can change one of ITS slots and then walks only those: skipped entries would add
+// +0.0f, the identity.  y_pre / s_pre: the first chunk's members and states when the caller has requested them already
+// (PRE), else loaded here.  TIMED: phase timers (loads, staging, own walk, slowest wave, reduction; ticks of 10 ns).
+template <int KPT, bool COH, bool PRE, bool TIMED>
+__device__ __forceinline__ void evaluate_step(const ClaransArgs& a, int xx, int x, int* y_pre, float4* s_pre, float4* s_e,
+                                              float4 (*s_we)[128], float& best_out, int& bk_out, unsigned long long* t_ev)
+{
+    constexpr int CH = 2048, PER = CH / 512, HALF = CH / 2, SUB = 128;
+    unsigned long long te0 = TIMED ? wall_clock64() : 0;
+    auto elap = [&](int ph) {
+        if (TIMED) {
+            const unsigned long long t1 = wall_clock64();
+            t_ev[ph] += t1 - te0;
+            te0 = t1;
+        }
+    };
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int k = a.n_medoids, n = a.n_elems;
+    const uint64_t lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
     const int kpw = (k + 7) >> 3;
     const int klo = wave * kpw, khi = min(k, klo + kpw);
     float acc[KPT];
@@ -280,11 +269,11 @@ __global__ __launch_bounds__(512) void clarans_eval_kernel(ClaransBatch batch)
         // entries of this chunk: (addend for the own slot, addend for the other slots, own slot)
         float dxy[PER];
 #pragma unroll
-        for (int u = 0; u < PER; ++u) { // level 2: the gathers from the triangle, all in flight together
+        for (int u = 0; u < PER; ++u) { // the gathers from the triangle, all in flight together
             const int t = tid + 512 * u;
-            if (c0 != k) {
-                y_pre[u] = t < cnt ? a.cand[c0 + t] : 0;
-                s_pre[u] = t < cnt ? a.st[c0 + t] : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!PRE || c0 != k) {
+                y_pre[u] = t < cnt ? ld<COH>(&a.cand[c0 + t]) : 0;
+                s_pre[u] = t < cnt ? ld4<COH>(&a.st[c0 + t]) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
             dxy[u] = (t < cnt && c0 + t != xx) ? a.D[tri_at(x, y_pre[u])] : 0.0f;
         }
@@ -302,6 +291,8 @@ __global__ __launch_bounds__(512) void clarans_eval_kernel(ClaransBatch batch)
                 ent[u].z = s_pre[u].z;
             }
         }
+        if (TIMED && ent[0].x == 12345.678f) __builtin_amdgcn_s_sleep(1); // (the loads have arrived)
+        elap(0);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int hcnt = min(HALF, cnt - h * HALF);
@@ -312,6 +303,7 @@ __global__ __launch_bounds__(512) void clarans_eval_kernel(ClaransBatch batch)
                 if (t < hcnt) s_e[t] = ent[h * (PER / 2) + u];
             }
             __syncthreads();
+            elap(1);
             for (int s0 = 0; s0 < hcnt; s0 += SUB) {
                 float4 e[SUB / 64];
 #pragma unroll
@@ -349,7 +341,9 @@ __global__ __launch_bounds__(512) void clarans_eval_kernel(ClaransBatch batch)
                 }
                 __builtin_amdgcn_wave_barrier();
             }
+            elap(2); // this wave's own walk
             __syncthreads();
+            elap(3); // waiting for the slowest wave
         }
     }
     // std::min_element over slots [n_fixed, k): smallest value, earliest slot among equals
@@ -375,12 +369,65 @@ __global__ __launch_bounds__(512) void clarans_eval_kernel(ClaransBatch batch)
             const int k2 = s_k[w];
             if (k2 != INT_MAX && (kk == INT_MAX || v2 < v || (v2 == v && k2 < kk))) { v = v2; kk = k2; }
         }
-        s_v[0] = v;
-        s_k[0] = kk;
+        best_out = v;
+        bk_out = kk;
     }
+    elap(4);
+}
+
+// A kernel boundary leaves nothing in the caches that another XCD wrote, so every DEPENDENT global
+// load of these small kernels costs a trip to memory (~1.5 us): both kernels are laid out to have as
+// few dependent levels as possible -- everything whose address does not depend on the step is
+// requested first, the pending steps' positions/members are precomputed by the previous kernel.
+
+// One workgroup per pending step b of the window: evaluate_step for the member win_x[b].
+// Workgroup W adds the previous round's cost addends to the running cost, in order.
+template <int KPT>
+__global__ __launch_bounds__(512) void clarans_eval_kernel(ClaransBatch batch)
+{
+    const ClaransArgs& a = batch.s[blockIdx.y];
+    const int corrected = a.corrected;
+    // 32 KB of LDS and 512 lanes per workgroup: four fit a CU, so the 65 x 16 workgroups of a full
+    // batch of searches are resident together
+    constexpr int CH = 2048, PER = CH / 512; // positions whose data a workgroup keeps in registers at a time
+    __shared__ float4 s_e[CH / 2];      // 16 KB: the chunk's entries, staged in two halves
+    __shared__ float4 s_we[8][128];     // 16 KB: per wave, the entries of one sub-chunk that concern its slots
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int k = a.n_medoids, n = a.n_elems;
+    // level 1: state, this step, and the first chunk's per-position data
+    const int4 st0 = *reinterpret_cast<const int4*>(a.state);
+    const int4 st1 = *reinterpret_cast<const int4*>(a.state + 4);
+    const int4 st2 = *reinterpret_cast<const int4*>(a.state + 8);
+    const int win = st1.w & 1;
+    const bool cost_wg = b == (int)gridDim.x - 1;
+    const int S = stage_size(st2.y, window_size(corrected, st2.z) - st2.x, a.stage0); // steps evaluated in this round
+    if (!cost_wg && b >= S) return;
+    const int bb = cost_wg ? 0 : st2.x + b; // index of this workgroup's step in the window
+    const int xx = a.win_xx[win * a.win_cap + bb];
+    const int x = a.win_x[win * a.win_cap + bb];
+    int y_pre[PER];
+    float4 s_pre[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int yy = k + tid + 512 * u;
+        y_pre[u] = yy < n ? a.cand[yy] : 0;
+        s_pre[u] = yy < n ? a.st[yy] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (st0.y) return; // done
+    if (cost_wg) { // adds the previous round's cost addends to the running cost, in order
+        const int len = st0.z;
+        if (len == 0) return;
+        const float c = cost_accumulate<false>(a, len, __int_as_float(st1.y), reinterpret_cast<float*>(s_e), reinterpret_cast<float*>(s_we));
+        if (tid == 0) a.state[ST_COST] = __float_as_int(c);
+        return;
+    }
+    if (st1.z) return; // error flagged: apply ends the search
+    float best = 0.0f;
+    int bk = INT_MAX;
+    evaluate_step<KPT, false, true, false>(a, xx, x, y_pre, s_pre, s_e, s_we, best, bk, nullptr);
     if (tid == 0) {
-        a.res_delta[b] = s_v[0];
-        a.res_mm[b] = s_k[0];
+        a.res_delta[b] = best;
+        a.res_mm[b] = bk;
     }
 }
 
@@ -589,18 +636,8 @@ __global__ __launch_bounds__(64) void clarans_apply_kernel(ClaransBatch batch)
 // rank P-1 keeps the running cost and does the apply kernel's last-workgroup part.  The control state (next draw, window,
 // stage, ...) is computed by every workgroup from the same step results, so a round needs exactly two barriers.
 // Arithmetic, comparison directions and the order of every float addition are those of the two kernels above.
-constexpr int CHAIN_SUB = 128; // entries per compaction pass of an evaluation (256: walk -9 %, 48 KB of LDS)
 enum { CH_TICKET = 16, CH_GO = 17, CH_BAR = 32 }; // words of the search's 64-word state block (zeroed by the host before every launch)
 
-template <typename T>
-__device__ __forceinline__ T ldc(const T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ float4 ldc4(const float4* p)
-{
-    const uint64_t* q = reinterpret_cast<const uint64_t*>(p);
-    const uint64_t lo = ldc(q), hi = ldc(q + 1);
-    return make_float4(__uint_as_float((uint32_t)lo), __uint_as_float((uint32_t)(lo >> 32)), __uint_as_float((uint32_t)hi),
-                       __uint_as_float((uint32_t)(hi >> 32)));
-}
 __device__ __forceinline__ unsigned xcc_id()
 {
     // s_getreg_b32 hwreg(HW_REG_XCC_ID = 20), offset 0, size 32
@@ -623,198 +660,11 @@ __device__ __forceinline__ bool chain_barrier(int* counter, int target)
     return s_ok != 0;
 }
 
-// running cost: c += addend for the logged addends, in order (the cost workgroup of clarans_eval_kernel); valid in thread 0
-__device__ __forceinline__ float chain_cost(const ClaransArgs& a, int len, float c, float* s_f, float* s_nz)
-{
-    constexpr int CH = 2048, PER = CH / 512;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint64_t lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
-    for (int c0 = 0; c0 < len; c0 += CH) {
-        const int cnt = min(CH, len - c0);
-        float v[PER];
-#pragma unroll
-        for (int u = 0; u < PER; ++u) {
-            const int t = tid + 512 * u;
-            v[u] = t < cnt ? ldc(&a.cost_log[c0 + t]) : 0.0f;
-        }
-#pragma unroll
-        for (int u = 0; u < PER; ++u) s_f[tid + 512 * u] = v[u];
-        __syncthreads();
-        if (wave == 0) {
-            int m = 0;
-            for (int base = 0; base < cnt; base += 256) {
-                float g[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) g[u] = s_f[base + 64 * u + lane];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const uint64_t mask = __ballot(g[u] != 0.0f);
-                    if (g[u] != 0.0f) s_nz[m + __popcll(mask & lt_mask)] = g[u];
-                    m += __popcll(mask);
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-            if (lane == 0) {
-                int t = 0;
-                for (; t + 8 <= m; t += 8) {
-                    float g[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) g[u] = s_nz[t + u];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) c = __fadd_rn(c, g[u]);
-                }
-                for (; t < m; ++t) c = __fadd_rn(c, s_nz[t]);
-            }
-        }
-        __syncthreads();
-    }
-    return c;
-}
-
-// deltas[slot] of the member x drawn at position xx and their first minimum over the free slots (the body of
-// clarans_eval_kernel); the result is valid in thread 0
-template <int KPT>
-__device__ __forceinline__ void chain_eval_step(const ClaransArgs& a, int xx, int x, float4* s_e, float4 (*s_we)[CHAIN_SUB], float& best_out,
-                                                int& bk_out, unsigned long long* t_ev)
-{
-    unsigned long long te0 = wall_clock64();
-    auto elap = [&](int ph) {
-        const unsigned long long t1 = wall_clock64();
-        t_ev[ph] += t1 - te0;
-        te0 = t1;
-    };
-    constexpr int CH = 2048, PER = CH / 512, HALF = CH / 2, SUB = CHAIN_SUB;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int k = a.n_medoids, n = a.n_elems;
-    const uint64_t lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
-    const int kpw = (k + 7) >> 3;
-    const int klo = wave * kpw, khi = min(k, klo + kpw);
-    float acc[KPT];
-    int slot[KPT];
-#pragma unroll
-    for (int q = 0; q < KPT; ++q) {
-        acc[q] = 0.0f;
-        slot[q] = klo + lane + 64 * q;
-    }
-    for (int c0 = k; c0 < n; c0 += CH) {
-        const int cnt = min(CH, n - c0);
-        int y_pre[PER];
-        float4 s_pre[PER];
-#pragma unroll
-        for (int u = 0; u < PER; ++u) {
-            const int t = tid + 512 * u;
-            y_pre[u] = t < cnt ? ldc(&a.cand[c0 + t]) : 0;
-            s_pre[u] = t < cnt ? ldc4(&a.st[c0 + t]) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        float dxy[PER];
-#pragma unroll
-        for (int u = 0; u < PER; ++u) {
-            const int t = tid + 512 * u;
-            dxy[u] = (t < cnt && c0 + t != xx) ? a.D[tri_at(x, y_pre[u])] : 0.0f;
-        }
-        float4 ent[PER];
-#pragma unroll
-        for (int u = 0; u < PER; ++u) {
-            const int t = tid + 512 * u;
-            ent[u] = make_float4(0.0f, 0.0f, __int_as_float(-1), 0.0f);
-            if (t < cnt && c0 + t != xx) {
-                const float dn = s_pre[u].x, ds = s_pre[u].y;
-                const float m = ds < dxy[u] ? ds : dxy[u];
-                const float change = __fsub_rn(dxy[u], dn);
-                ent[u].x = __fsub_rn(m, dn);
-                ent[u].y = change < 0.0f ? change : 0.0f;
-                ent[u].z = s_pre[u].z;
-            }
-        }
-        if (ent[0].x == 12345.678f) __builtin_amdgcn_s_sleep(1); // (timing only: the loads have arrived)
-        elap(0);
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int hcnt = min(HALF, cnt - h * HALF);
-            if (hcnt <= 0) break;
-#pragma unroll
-            for (int u = 0; u < PER / 2; ++u) {
-                const int t = tid + 512 * u;
-                if (t < hcnt) s_e[t] = ent[h * (PER / 2) + u];
-            }
-            __syncthreads();
-            elap(1);
-            for (int s0 = 0; s0 < hcnt; s0 += SUB) {
-                float4 e[SUB / 64];
-#pragma unroll
-                for (int u = 0; u < SUB / 64; ++u) {
-                    const int t = s0 + 64 * u + lane;
-                    e[u] = t < hcnt ? s_e[t] : make_float4(0.0f, 0.0f, __int_as_float(-1), 0.0f);
-                }
-                int m = 0;
-#pragma unroll
-                for (int u = 0; u < SUB / 64; ++u) {
-                    const int nn = __float_as_int(e[u].z);
-                    const bool mine = e[u].y < 0.0f || (nn >= klo && nn < khi);
-                    const uint64_t mask = __ballot(mine);
-                    if (mine) s_we[wave][m + __popcll(mask & lt_mask)] = e[u];
-                    m += __popcll(mask);
-                }
-                __builtin_amdgcn_wave_barrier();
-                int i = 0;
-                for (; i + 8 <= m; i += 8) {
-                    float4 f[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) f[u] = s_we[wave][i + u];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const int nn = __float_as_int(f[u].z);
-#pragma unroll
-                        for (int q = 0; q < KPT; ++q) acc[q] = __fadd_rn(acc[q], slot[q] == nn ? f[u].x : f[u].y);
-                    }
-                }
-                for (; i < m; ++i) {
-                    const float4 f = s_we[wave][i];
-                    const int nn = __float_as_int(f.z);
-#pragma unroll
-                    for (int q = 0; q < KPT; ++q) acc[q] = __fadd_rn(acc[q], slot[q] == nn ? f.x : f.y);
-                }
-                __builtin_amdgcn_wave_barrier();
-            }
-            elap(2); // this wave's own walk
-            __syncthreads();
-            elap(3); // waiting for the slowest wave
-        }
-    }
-    float* s_v = reinterpret_cast<float*>(&s_we[0][0]);
-    int* s_k = reinterpret_cast<int*>(&s_we[1][0]);
-    float best = 0.0f;
-    int bk = INT_MAX;
-#pragma unroll
-    for (int q = 0; q < KPT; ++q)
-        if (slot[q] >= a.n_fixed && slot[q] < khi && (bk == INT_MAX || acc[q] < best)) { best = acc[q]; bk = slot[q]; }
-    wave_first_min_valid(best, bk);
-    if (lane == 0) {
-        s_v[wave] = best;
-        s_k[wave] = bk;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        float v = s_v[0];
-        int kk = s_k[0];
-#pragma unroll
-        for (int w = 1; w < 8; ++w) {
-            const float v2 = s_v[w];
-            const int k2 = s_k[w];
-            if (k2 != INT_MAX && (kk == INT_MAX || v2 < v || (v2 == v && k2 < kk))) { v = v2; kk = k2; }
-        }
-        best_out = v;
-        bk_out = kk;
-    }
-    __syncthreads(); // the staging areas are free for the next step
-    elap(4);
-}
-
 template <int KPT>
 __global__ __launch_bounds__(512) void clarans_chain_kernel(ClaransBatch batch, int P, int max_rounds)
 {
     __shared__ float4 s_e[1024];    // 16 KB
-    __shared__ float4 s_we[8][CHAIN_SUB];
+    __shared__ float4 s_we[8][128]; // 16 KB
     __shared__ int s_rank, s_search;
     const int tid = threadIdx.x, lane = tid & 63;
     if (tid == 0) {
@@ -876,14 +726,17 @@ __global__ __launch_bounds__(512) void clarans_chain_kernel(ClaransBatch batch, 
         ++n_rounds;
         // ---- evaluate
         if (tail) {
-            if (log_len) cost = chain_cost(a, log_len, cost, reinterpret_cast<float*>(s_e), reinterpret_cast<float*>(s_we));
+            if (log_len) cost = cost_accumulate<true>(a, log_len, cost, reinterpret_cast<float*>(s_e), reinterpret_cast<float*>(s_we));
         } else if (!err) {
             for (int b = rank; b < S; b += n_eval) {
                 const int xx = ldc(&a.win_xx[win * a.win_cap + off + b]);
                 const int x = ldc(&a.win_x[win * a.win_cap + off + b]);
                 float best = 0.0f;
                 int bk = INT_MAX;
-                chain_eval_step<KPT>(a, xx, x, s_e, s_we, best, bk, t_ev);
+                int y_pre[4];
+                float4 s_pre[4];
+                evaluate_step<KPT, true, false, true>(a, xx, x, y_pre, s_pre, s_e, s_we, best, bk, t_ev);
+                __syncthreads(); // the staging areas are free for the next step
                 if (tid == 0) {
                     a.res_delta[b] = best;
                     a.res_mm[b] = bk;
