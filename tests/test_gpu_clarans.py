@@ -154,6 +154,23 @@ def test_concurrent_searches_share_the_batch(engine):
         assert together == alone
 
 
+@pytest.mark.parametrize("stage0", ["1", "5", "64"])
+def test_stage_size_does_not_change_the_search(stage0):
+    """LCSGPU_CLARANS_STAGE0 (read once per process, hence the subprocess): how many pending steps a round evaluates --
+    1: every round is one step, the reference's own loop; 5: stages 5, 10, 20, 40, 64; 64: whole windows -- only
+    decides how much is evaluated speculatively, never which step is accepted."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("LCSGPU_CLARANS_STAGE0") or os.environ.get("LCSGPU_CLARANS_CHAIN"):
+        pytest.skip("already inside a nested run")
+    env = dict(os.environ)
+    env["LCSGPU_CLARANS_STAGE0"] = stage0
+    p = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-x", "-k",
+                        "matches_reference"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert p.returncode == 0 and " passed" in p.stdout, p.stdout[-3000:]
+
+
 def test_one_xcd_chain_kernel_gives_the_same_searches():
     """LCSGPU_CLARANS_CHAIN=1 (opt-in, read once per process, hence the subprocess): the rounds of a look inside ONE
     launch, each search's workgroups on one XCD with barriers at that XCD's L2 and L1-bypassing loads instead of
@@ -162,8 +179,8 @@ def test_one_xcd_chain_kernel_gives_the_same_searches():
     import os
     import subprocess
     import sys
-    if os.environ.get("LCSGPU_CLARANS_CHAIN"):
-        pytest.skip("already inside the chain run")
+    if os.environ.get("LCSGPU_CLARANS_CHAIN") or os.environ.get("LCSGPU_CLARANS_STAGE0"):
+        pytest.skip("already inside a nested run")
     env = dict(os.environ)
     env["LCSGPU_CLARANS_CHAIN"] = "1"
     p = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-x", "-k",
