@@ -16,6 +16,15 @@ same for every N.
     python bench.py [--gpus N --steps K --warmup W] [--n-seqs 100000 --seq-len 400]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+Both forms work for N > 1: started plainly (no WORLD_SIZE in the environment), `bench.py --gpus N` starts its
+N ranks itself (one process per GPU, LOCAL_RANK binding, rendezvous on 127.0.0.1) and relays rank 0's line.
+With more than one rank a fail-closed SELF-CHECK runs before the timed loop: a 2000-sequence family set, the
+sharded tree of all ranks against the single-context tree every rank computes alone -- any difference, HIP
+or RCCL error ends the run with the rank, the transport and the error text instead of a number.
+`--mode contexts`: ONE process, N engine contexts (one per GPU) driven through lcsgpu_multi_mst_prim -- the
+library's own multi-GPU path behind `famsa-gpu -gpu a,b,..` (key exchange: grouped ncclAllGather when every
+context has its own device, else peer copies).
+
 Rank 0 prints ONE JSON line.  After the timed region a sample of the triangle the last step left
 in HBM is compared with the oracle (oracle/lcs_oracle.c) -- `parity`.  `cpu_baseline` times the
 REFERENCE's own AVX2 path (oracle/_ref/libfamsa_ref.so = /root/reference sources +
@@ -110,20 +119,31 @@ def cpu_baseline(n, length, target_s=12.0):
     }
 
 
-def pmc_traffic(n, length, world, my_pairs, total_pairs):
-    """(2 x FETCH_SIZE + WRITE_SIZE) x 1024 of the hot kernel's launch, from profiles/pmc_r*.json (the newest round)."""
+def pmc_traffic(n, length, world, my_pairs, total_pairs, kernel, library):
+    """(2 x FETCH_SIZE + WRITE_SIZE) x 1024 of the hot kernel's launch as the PMC passes of scripts/profile_round.sh
+    recorded it (profiles/pmc_r*.json, newest round) -- IMPORTED, not measured by this run, so it is only passed on
+    when the record is about this very thing: same workload, same kernel instantiation, same library build string.
+    Returns (bytes or None, source or the reason for None)."""
     import glob
-    best = None
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "pmc_r*.json"))):
+    if world != 1 or my_pairs != total_pairs:
+        return None, "no PMC record for a row block (the committed passes cover the one-GPU launch)"
+    why = "no profiles/pmc_r*.json for this workload"
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "pmc_r*.json")), reverse=True):
         try:
             d = json.load(open(path))
         except Exception:
             continue
-        if d.get("n_seqs") == n and d.get("seq_len") == length and "traffic_bytes" in d:
-            best = d
-    if best is None or world != 1 or my_pairs != total_pairs:
-        return None
-    return best["traffic_bytes"]
+        if d.get("n_seqs") != n or d.get("seq_len") != length or "traffic_bytes" not in d:
+            continue
+        name = os.path.relpath(path, ROOT)
+        if d.get("kernel") != kernel:
+            why = f"{name} is about kernel {d.get('kernel')!r}, this run launched {kernel!r}"
+            continue
+        if d.get("library") != library:
+            why = f"{name} was recorded with {d.get('library')!r}, this run uses {library!r}"
+            continue
+        return d["traffic_bytes"], name
+    return None, why
 
 
 def sampled_parity(eng, tri, r0, r1, codes, offsets, n_samples=6000, seed=11):
@@ -152,6 +172,95 @@ def sampled_parity(eng, tri, r0, r1, codes, offsets, n_samples=6000, seed=11):
     return n_samples, bad
 
 
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
+        sock.bind(("127.0.0.1", 0))
+        return sock.getsockname()[1]
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` started plainly: start the N ranks (what torch.distributed.run would do -- one
+    process per GPU with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in its environment), wait for them, relay rank 0's
+    JSON line.  The first rank that fails ends the others (by their PIDs) and the exit code says so."""
+    import subprocess
+    import famsa_amd
+    n = args.gpus
+    have = famsa_amd.load_library().lcsgpu_device_count()
+    if not args.emulate_ranks_on_one_gpu and have < n:
+        raise SystemExit(f"bench.py --gpus {n}: {have} GPU(s) visible on this host, {n} needed (one rank per GPU).  "
+                         f"--emulate-ranks-on-one-gpu runs the {n}-rank path functionally on one GPU (gloo exchange).")
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    failed = None
+    alive = set(range(n))
+    while alive and failed is None:
+        for r in sorted(alive):
+            rc = procs[r].poll()
+            if rc is None:
+                continue
+            alive.discard(r)
+            if rc != 0:
+                failed = (r, rc)
+                break
+        time.sleep(0.05)
+    if failed is not None:
+        for r in alive:
+            procs[r].terminate()
+        for r in alive:
+            try:
+                procs[r].wait(timeout=20)
+            except Exception:
+                procs[r].kill()
+        print(f"bench.py: rank {failed[0]} of {n} exited with code {failed[1]}; the other ranks were stopped", file=sys.stderr)
+        raise SystemExit(failed[1] if failed[1] > 0 else 1)
+
+
+def self_check(eng, torch, dist, rank, world, dev, make_exchange, transport):
+    """Fail closed before any number is produced with more than one rank: on a 2000-sequence family set (ragged
+    lengths, near ties) every rank builds the tree alone (lcsgpu_mst_prim, the single-context path the oracle's
+    recurrence pins in the test suite) and the ranks build it together over the same exchange the timed loop uses;
+    every rank's sharded edge-list hash must equal every rank's single-context hash."""
+    from famsa_amd import seqio
+    from famsa_amd.rowblock import row_cuts, pairs_in_rows, sharded_mst_device, edge_list_sha256
+    t0 = time.perf_counter()
+    try:
+        seqs = seqio.synth_family(2000, 160, seed=0xC4EC)
+        eng.upload_seqs(seqs)
+        n = len(seqs)
+        alone = edge_list_sha256(eng.mst_prim(1))
+        cuts = row_cuts(n, world)
+        r0, r1 = cuts[rank], cuts[rank + 1]
+        tri = torch.empty(max(pairs_in_rows(r0, r1), 1), dtype=torch.int16, device=dev)
+        keys, gathered, all_gather = make_exchange(n)
+        torch.cuda.synchronize()
+        eng.lcs_triangle_dev(r0, r1, tri.data_ptr(), 2)
+        edges, rounds = sharded_mst_device(eng, tri.data_ptr(), 2, r0, r1, 1, keys, gathered, all_gather)
+        together = edge_list_sha256(edges)
+        eng.sync()
+        rec = [None] * world
+        if world > 1 or dist is not None:
+            dist.all_gather_object(rec, (alone, together))
+        else:
+            rec = [(alone, together)]
+    except BaseException as e:  # HIP / RCCL / rendezvous errors included: say where and over what, then stop
+        print(f"bench.py SELF-CHECK FAILED on rank {rank} of {world} (transport: {transport}): {type(e).__name__}: {e}",
+              file=sys.stderr, flush=True)
+        os._exit(3)
+    hashes = {h for pair in rec for h in pair}
+    if len(hashes) != 1:
+        lines = "; ".join(f"rank {r}: alone {a[:12]} together {t[:12]}" for r, (a, t) in enumerate(rec))
+        print(f"bench.py SELF-CHECK FAILED on rank {rank} of {world} (transport: {transport}): the sharded tree differs from the "
+              f"single-context tree -- {lines}", file=sys.stderr, flush=True)
+        os._exit(3)
+    return {"n_seqs": n, "rounds": int(rounds), "edges_sha256": alone, "ranks_agree": True, "seconds": time.perf_counter() - t0}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -161,8 +270,12 @@ def main():
     ap.add_argument("--seq-len", dest="len", type=int, default=400)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--mode", choices=["ranks", "contexts"], default="ranks",
+                    help="ranks (default): one process per GPU, torch.distributed over RCCL, the lcsgpu_mst_shard_* protocol; "
+                         "contexts: ONE process, one engine context per GPU, lcsgpu_multi_mst_prim (the library's own "
+                         "multi-GPU single linkage: what famsa-gpu -gpu a,b,.. runs)")
     ap.add_argument("--emulate-ranks-on-one-gpu", action="store_true",
-                    help="functional test of the N>1 path on a 1-GPU box: all ranks use cuda:0, gloo exchange")
+                    help="functional test of the N>1 path on a 1-GPU box: all ranks / contexts use cuda:0 (ranks: gloo exchange)")
     ap.add_argument("--mst-mode", choices=["fused", "passes"], default="passes",
                     help="passes (default): plain LCS launch, every Boruvka round streams the resident triangle; "
                          "fused: the LCS launch does round 0's local half on the values it holds in registers "
@@ -171,7 +284,14 @@ def main():
     ap.add_argument("--force-collective", action="store_true",
                     help="with one rank: initialise the nccl (RCCL) backend anyway and run the real "
                          "all_gather_into_tensor + stream hand-off every Boruvka round, as the N>1 path does")
+    ap.add_argument("--self-check", action="store_true",
+                    help="run the multi-rank self-check also with one rank (it always runs with more than one)")
     args = ap.parse_args()
+
+    if args.mode == "contexts":
+        return main_contexts(args)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return launch_ranks(args)
 
     import torch
     import famsa_amd
@@ -183,27 +303,71 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"bench.py --gpus {args.gpus} was started with WORLD_SIZE={world}: launch with "
+                         f"--nproc-per-node {args.gpus}, or plainly (python bench.py --gpus {args.gpus} starts its ranks itself)")
     dist = None
     emulate = args.emulate_ranks_on_one_gpu
     if emulate:
         local_rank = 0
     collective = world > 1 or args.force_collective  # the exchange runs as a real collective
+    transport = "none (one block)"
+    rccl_ranks = None
     if collective:
+        import datetime
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        if emulate:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        try:
+            if emulate:
+                transport = f"gloo (host memory), {world} ranks sharing cuda:0"
+                dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=600))
+            else:
+                n_dev = torch.cuda.device_count()
+                if local_rank >= n_dev:
+                    raise RuntimeError(f"LOCAL_RANK {local_rank} but {n_dev} GPU(s) visible")
+                transport = f"nccl = RCCL all_gather_into_tensor (device memory), {world} ranks, rank {rank} on cuda:{local_rank}"
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank),
+                                        timeout=datetime.timedelta(seconds=600))
+                rccl_ranks = dist.get_world_size()
+        except BaseException as e:
+            print(f"bench.py: rank {rank} of {world} could not join the process group (transport: {transport}): "
+                  f"{type(e).__name__}: {e}", file=sys.stderr, flush=True)
+            os._exit(4)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
     n, L = args.n, args.len
-    codes, offsets = seqio.synth_uniform(n, L)
     eng = famsa_amd.LcsGpu(local_rank)
+    ext = torch.cuda.ExternalStream(eng._lib.lcsgpu_stream(eng._ctx), device=dev)
+
+    def make_exchange(n_keys):
+        """(keys, gathered, all_gather) for a set of n_keys sequences: this rank's lcsgpu_mst_key records, every rank's,
+        and the call that fills the latter from the former in the right stream order."""
+        keys = torch.zeros(2 * n_keys, dtype=torch.int64, device=dev)
+        gathered = torch.zeros(world * 2 * n_keys, dtype=torch.int64, device=dev) if collective else keys
+        if not collective:
+            def all_gather(g, k):
+                pass                                   # one block: its keys are the gathered keys
+        elif not emulate:
+            def all_gather(g, k):
+                cur = torch.cuda.current_stream()
+                cur.wait_stream(ext)                   # the keys are produced on the engine's stream
+                dist.all_gather_into_tensor(g, k)      # RCCL over xGMI: n x 16 B per rank
+                ext.wait_stream(cur)                   # the merge kernels read the gathered keys
+        else:
+            def all_gather(g, k):
+                eng.sync()
+                h = torch.empty(g.shape, dtype=g.dtype)
+                dist.all_gather_into_tensor(h, k.cpu())
+                g.copy_(h)
+                torch.cuda.synchronize()
+        return keys, gathered, all_gather
+
+    check = None
+    if world > 1 or args.self_check:
+        check = self_check(eng, torch, dist if collective else None, rank, world, dev, make_exchange, transport)
+
+    codes, offsets = seqio.synth_uniform(n, L)
     eng.upload(codes, offsets)  # inputs resident in HBM before the timed region
 
     cuts = row_cuts(n, world)
@@ -211,27 +375,8 @@ def main():
     my_pairs = pairs_in_rows(r0, r1)
     total_pairs = n * (n - 1) // 2
     tri = torch.empty(max(my_pairs, 1), dtype=torch.int16, device=dev)
-    keys = torch.zeros(2 * n, dtype=torch.int64, device=dev)          # this rank's lcsgpu_mst_key records
-    gathered = torch.zeros(world * 2 * n, dtype=torch.int64, device=dev) if collective else keys
-    ext = torch.cuda.ExternalStream(eng._lib.lcsgpu_stream(eng._ctx), device=dev)
+    keys, gathered, all_gather = make_exchange(n)
     torch.cuda.synchronize()  # torch zero-fills on ITS stream; the engine writes these buffers on its own
-
-    if not collective:
-        def all_gather(g, k):
-            pass                                   # one block: its keys are the gathered keys
-    elif not emulate:
-        def all_gather(g, k):
-            cur = torch.cuda.current_stream()
-            cur.wait_stream(ext)                   # the keys are produced on the engine's stream
-            dist.all_gather_into_tensor(g, k)      # RCCL over xGMI: n x 16 B per rank
-            ext.wait_stream(cur)                   # the merge kernels read the gathered keys
-    else:
-        def all_gather(g, k):
-            eng.sync()
-            h = torch.empty(g.shape, dtype=g.dtype)
-            dist.all_gather_into_tensor(h, k.cpu())
-            g.copy_(h)
-            torch.cuda.synchronize()
 
     kernel_ms, mst_ms = [], []
     last = {}
@@ -289,88 +434,197 @@ def main():
     sampled, bad = (0, 0) if args.no_parity else sampled_parity(eng, tri, r0, r1, codes, offsets)
     edges = last["edges"]
     edges_hash = edge_list_sha256(edges)
+    k_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
+    per_rank_kernel_ms = [k_ms]
     if collective:
         rec = [None] * world
-        dist.all_gather_object(rec, (edges_hash, sampled, bad))
-        assert len({h for h, _, _ in rec}) == 1, "ranks disagree on the tree"
-        sampled, bad = sum(s for _, s, _ in rec), sum(b for _, _, b in rec)
+        dist.all_gather_object(rec, (edges_hash, sampled, bad, k_ms))
+        assert len({h for h, _, _, _ in rec}) == 1, "ranks disagree on the tree"
+        sampled, bad = sum(s for _, s, _, _ in rec), sum(b for _, _, b, _ in rec)
+        per_rank_kernel_ms = [k for _, _, _, k in rec]
     assert bad == 0, f"{bad} of {sampled} sampled pairs differ from the oracle"
     assert len(edges) == n - 1 and (edges["from"] < edges["to"]).all()
 
     if rank == 0:
-        cells = float(total_pairs) * L * L
-        ms_per_step = elapsed / args.steps * 1e3
-        value = cells * args.steps / elapsed / 1e9
-        k_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
-        H = (L + 31) // 32
-        algo_bytes = my_pairs * (L + ALGO_BYTES_PER_PAIR_EXTRA)
-        achieved = algo_bytes / (k_ms * 1e-3) / 1e9
-        ops_per_pair = 3 * L * H  # three VALU lane-ops per partner residue and 32-bit half-word of the ref
-        valu_rate = my_pairs * ops_per_pair / (k_ms * 1e-3)
-        out = {
-            "metric": "lcs_gcell_updates_per_s",
-            "value": value,
-            "unit": "Gcell/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": ms_per_step,
-            "higher_is_better": True,
-            "scaling": "strong",
-            "vs_baseline": None,
-            "dtype": "u64",
-            "data": "synthetic",
-            "config": {
-                "workload": f"synthetic {n} proteins x {L} aa (uniform over 20 residues), full all-pairs LCS "
-                            f"lower triangle -> uint16 in HBM -> single-linkage MST (n-1 edges, Prim's order) on the host",
-                "n_seqs": n, "seq_len": L, "pairs": total_pairs,
-                "parallelism": f"rowblock{world}" + ("+allgather(n x 16 B best-edge keys per Boruvka round)" if collective else ""),
-                "exchange": ("gloo (host memory)" if emulate else "nccl = RCCL (device memory)") if collective else "none (one block)",
-            },
-            "pairs_per_s": total_pairs * args.steps / elapsed,
-            "mst": {"mode": args.mst_mode, "n_edges": int(len(edges)), "rounds": int(last["rounds"]), "edges_sha256": edges_hash,
-                    "ms_per_step": float(np.mean(mst_ms)), "exchange_bytes_per_rank_per_round": 16 * n},
-            "parity": {"sampled_pairs": int(sampled), "mismatches": int(bad),
-                       "checker": "oracle/lcs_oracle.c on a sample of the triangle the last timed step left in HBM"},
-            "roofline": {
-                "bound": "hbm",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                # HBM-side bytes per launch: not measurable in this run (PMC passes are separate rocprofv3 runs of this very
-                # command, scripts/profile_round.sh); taken from the committed summary of those passes when it is for this
-                # workload, else null
-                "traffic": pmc_traffic(n, L, world, my_pairs, total_pairs),
-                "kernel": f"lcsgpu::lcs_rows_kernel_pipe<{H}, {4 if H <= 16 else 2 if H <= 32 else 1}, 4, {'true' if fused else 'false'}>",
-                "kernel_ms": k_ms,
-                "algorithmic_bytes_per_pair": L + ALGO_BYTES_PER_PAIR_EXTRA,
-                "pairs_per_launch": my_pairs,
-                "note": "the contract figure: algorithmic bytes / kernel time against the HBM peak; the kernel is "
-                        "integer-VALU bound by construction (SURVEY 8d), `valu` is the roof that binds",
-                "valu": {
-                    "ops_per_pair": ops_per_pair,
-                    "achieved_ops_per_s": valu_rate,
-                    "peak_ops_per_s": VALU_PEAK_LANE_OPS,
-                    "frac": valu_rate / VALU_PEAK_LANE_OPS,
-                    "unit": "32-bit lane-ops/s; peak = 256 CU x 4 SIMD-32 x 32 lanes x 2.4 GHz nominal",
-                },
-            },
-        }
+        exchange = ("gloo (host memory)" if emulate else "nccl = RCCL (device memory)") if collective else "none (one block)"
+        out = result_line(args, n, L, world, elapsed, k_ms, my_pairs, total_pairs, fused,
+                          parallelism=f"rowblock{world}" + ("+allgather(n x 16 B best-edge keys per Boruvka round)" if collective else ""),
+                          exchange=exchange, edges=edges, edges_hash=edges_hash, rounds=last["rounds"], mst_ms=float(np.mean(mst_ms)),
+                          sampled=sampled, bad=bad, library=eng._lib.lcsgpu_version().decode())
+        out["ranks"] = {"mode": "ranks", "world": world, "rccl_ranks": rccl_ranks, "transport": transport,
+                        "kernel_ms_per_rank": per_rank_kernel_ms, "kernel_ms_min": float(min(per_rank_kernel_ms)),
+                        "kernel_ms_max": float(max(per_rank_kernel_ms)), "self_check": check}
         if not args.no_cpu_baseline and world == 1:
             try:
                 cb = cpu_baseline(n, L)
             except Exception as e:  # the baseline is a report, never a reason to lose the GPU number
                 cb = {"error": repr(e)}
             out["cpu_baseline"] = cb
-        try:  # RCCL writes its version banner through C stdio: out with it before the one JSON line, not after
-            import ctypes
-            ctypes.CDLL(None).fflush(None)
-        except Exception:
-            pass
-        print(json.dumps(out), flush=True)
+        emit(out)
     if collective:
         dist.destroy_process_group()
+
+
+def emit(out):
+    try:  # RCCL writes its version banner through C stdio: out with it before the one JSON line, not after
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    print(json.dumps(out), flush=True)
+
+
+def result_line(args, n, L, world, elapsed, k_ms, my_pairs, total_pairs, fused, parallelism, exchange, edges, edges_hash, rounds,
+                mst_ms, sampled, bad, library):
+    cells = float(total_pairs) * L * L
+    ms_per_step = elapsed / args.steps * 1e3
+    value = cells * args.steps / elapsed / 1e9
+    H = (L + 31) // 32
+    algo_bytes = my_pairs * (L + ALGO_BYTES_PER_PAIR_EXTRA)
+    achieved = algo_bytes / (k_ms * 1e-3) / 1e9
+    ops_per_pair = 3 * L * H  # three VALU lane-ops per partner residue and 32-bit half-word of the ref
+    valu_rate = my_pairs * ops_per_pair / (k_ms * 1e-3)
+    kernel = f"lcsgpu::lcs_rows_kernel_pipe<{H}, {4 if H <= 16 else 2 if H <= 32 else 1}, 4, {'true' if fused else 'false'}>"
+    traffic, traffic_source = pmc_traffic(n, L, world, my_pairs, total_pairs, kernel, library)
+    return {
+        "metric": "lcs_gcell_updates_per_s",
+        "value": value,
+        "unit": "Gcell/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "u64",
+        "data": "synthetic",
+        "config": {
+            "workload": f"synthetic {n} proteins x {L} aa (uniform over 20 residues), full all-pairs LCS "
+                        f"lower triangle -> uint16 in HBM -> single-linkage MST (n-1 edges, Prim's order) on the host",
+            "n_seqs": n, "seq_len": L, "pairs": total_pairs,
+            "parallelism": parallelism,
+            "exchange": exchange,
+        },
+        "library": library,
+        "pairs_per_s": total_pairs * args.steps / elapsed,
+        "mst": {"mode": args.mst_mode, "n_edges": int(len(edges)), "rounds": None if rounds is None else int(rounds), "edges_sha256": edges_hash,
+                "ms_per_step": mst_ms, "exchange_bytes_per_rank_per_round": 16 * n},
+        "parity": {"sampled_pairs": int(sampled), "mismatches": int(bad),
+                   "checker": "oracle/lcs_oracle.c on a sample of the triangle the last timed step left in HBM"},
+        "roofline": {
+            "bound": "hbm",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            # HBM-side bytes per launch: not measurable in this run (PMC passes are separate rocprofv3 runs of this very
+            # command, scripts/profile_round.sh).  Imported from the committed record of those passes ONLY when that record
+            # names this workload, this kernel instantiation and this library build (traffic_source); else null, with the reason
+            "traffic": traffic,
+            "traffic_source": traffic_source,
+            "kernel": kernel,
+            "kernel_ms": k_ms,
+            "algorithmic_bytes_per_pair": L + ALGO_BYTES_PER_PAIR_EXTRA,
+            "pairs_per_launch": my_pairs,
+            "note": "the contract figure: algorithmic bytes / kernel time against the HBM peak; the kernel is "
+                    "integer-VALU bound by construction (SURVEY 8d), `valu` is the roof that binds",
+            "valu": {
+                "ops_per_pair": ops_per_pair,
+                "achieved_ops_per_s": valu_rate,
+                "peak_ops_per_s": VALU_PEAK_LANE_OPS,
+                "frac": valu_rate / VALU_PEAK_LANE_OPS,
+                "unit": "32-bit lane-ops/s; peak = 256 CU x 4 SIMD-32 x 32 lanes x 2.4 GHz nominal",
+            },
+        },
+    }
+
+
+def main_contexts(args):
+    """--mode contexts: one process, N engine contexts (context k on GPU k), one lcsgpu_multi_mst_prim per step: every
+    context computes its row block of the LCS triangle into its own HBM and the local half of each Boruvka round, the
+    keys are exchanged device to device (the library picks: one grouped ncclAllGather per round when every context has
+    its own device, else peer copies), every context runs the same global half, context 0's edge list comes back in
+    Prim's order.  The product path behind `famsa-gpu -gpu 0,1,..`; no torch.distributed."""
+    import torch
+    import famsa_amd
+    from famsa_amd import seqio
+    from famsa_amd.lcsgpu import LcsGpuGroup
+    from famsa_amd.rowblock import edge_list_sha256
+    N = args.gpus
+    have = famsa_amd.load_library().lcsgpu_device_count()
+    if args.emulate_ranks_on_one_gpu:
+        devices = [0] * N
+    elif have < N:
+        raise SystemExit(f"bench.py --mode contexts --gpus {N}: {have} GPU(s) visible, {N} needed "
+                         f"(--emulate-ranks-on-one-gpu puts all contexts on cuda:0)")
+    else:
+        devices = list(range(N))
+    group = LcsGpuGroup(devices)
+    n, L = args.n, args.len
+    try:
+        if N > 1 or args.self_check:  # fail closed, as in the ranks mode: the contexts' tree against one context's
+            t0 = time.perf_counter()
+            seqs = seqio.synth_family(2000, 160, seed=0xC4EC)
+            group.upload_seqs(seqs)
+            alone = edge_list_sha256(group.engs[0].mst_prim(1))
+            together = edge_list_sha256(group.mst_prim(1))
+            if alone != together:
+                raise RuntimeError(f"the {N}-context tree ({together[:12]}) differs from the single-context tree ({alone[:12]})")
+            check = {"n_seqs": len(seqs), "edges_sha256": alone, "contexts_agree": True, "seconds": time.perf_counter() - t0}
+        else:
+            check = None
+    except BaseException as e:
+        print(f"bench.py SELF-CHECK FAILED ({N} contexts on devices {devices}; {group.transport()!r}): {type(e).__name__}: {e}",
+              file=sys.stderr, flush=True)
+        os._exit(3)
+    codes, offsets = seqio.synth_uniform(n, L)
+    group.upload(codes, offsets)
+    total_pairs = n * (n - 1) // 2
+    kernel_ms, edges = [], None
+    for _ in range(args.warmup):
+        group.mst_prim(1)
+    for e in group.engs:
+        e.sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        edges = group.mst_prim(1)
+        kernel_ms.append(group.last_kernel_ms())
+    for e in group.engs:
+        e.sync()
+    elapsed = time.perf_counter() - t0
+    per_ctx = [float(np.mean([k[c] for k in kernel_ms])) for c in range(N)]
+    # parity: the whole triangle is inside the library in this mode; check a sample of pairs through the same contexts' LCS path
+    sampled = bad = 0
+    if not args.no_parity:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_bind
+        oracle = oracle_bind.Oracle()
+        rng = np.random.Generator(np.random.PCG64(11))
+        rows = rng.integers(1, n, size=64).astype(np.int32)
+        cols = np.sort(rng.integers(0, n, size=96)).astype(np.int32)
+        o = offsets.astype(np.int64)
+        for c, eng in enumerate(group.engs):
+            got = eng.lcs_rect(rows, cols)
+            for a in range(0, len(rows), 7):
+                for b in range(c, len(cols), 5):
+                    i, j = int(rows[a]), int(cols[b])
+                    sampled += 1
+                    bad += int(oracle.lcs(codes[o[i]:o[i + 1]], codes[o[j]:o[j + 1]]) != int(got[a, b]))
+    assert bad == 0, f"{bad} of {sampled} sampled pairs differ from the oracle"
+    assert len(edges) == n - 1 and (edges["from"] < edges["to"]).all()
+    my_pairs = total_pairs // N
+    out = result_line(args, n, L, N, elapsed, float(max(per_ctx)), my_pairs, total_pairs, False,
+                      parallelism=f"rowblock{N}, one process, {N} contexts (lcsgpu_multi_mst_prim)",
+                      exchange=group.transport().splitlines()[-1], edges=edges, edges_hash=edge_list_sha256(edges), rounds=None,
+                      mst_ms=float("nan"), sampled=sampled, bad=bad, library=group._lib.lcsgpu_version().decode())
+    out["mst"]["ms_per_step"] = elapsed / args.steps * 1e3 - float(max(per_ctx))  # everything of a step that is not the slowest block's LCS launch
+    out["parity"]["checker"] = "oracle/lcs_oracle.c on sampled pairs recomputed through every context (the triangles stay inside the library in this mode)"
+    out["ranks"] = {"mode": "contexts", "world": N, "devices": devices, "transport": group.transport(), "rccl_ranks": None,
+                    "kernel_ms_per_rank": per_ctx, "kernel_ms_min": float(min(per_ctx)), "kernel_ms_max": float(max(per_ctx)),
+                    "self_check": check}
+    emit(out)
+    group.close()
 
 
 if __name__ == "__main__":

@@ -68,6 +68,8 @@ struct RowsArgs {
 
 const char* recolor_state();       // "on" | "off" | "failed": see csrc/Makefile, RECOLOR (the plain LCS kernels)
 const char* recolor_state_fused(); // ... the translation unit of the fused instantiations
+const char* kernel_id();           // sha256 prefix of the assembled listing of the plain / the fused unit
+const char* kernel_id_fused();
 // instantiated half-word (32-bit) counts: exact 1..32, even 34..64; 0 = the long-sequence path
 int h_class(uint32_t len);
 int quirk_h_class(uint32_t len);

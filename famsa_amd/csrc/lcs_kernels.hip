@@ -798,8 +798,14 @@ __global__ __launch_bounds__(256) void lcs_long_kernel(RowsArgs a, uint16_t* car
 #ifndef LCSGPU_RECOLOR_STATE
 #define LCSGPU_RECOLOR_STATE "off"
 #endif
+// the first 10 hex digits of the sha256 of the listing this unit's device code was assembled from: two libraries with
+// the same id run the same LCS kernels, instruction for instruction (profiles are matched to a library by it)
+#ifndef LCSGPU_KERNEL_ID
+#define LCSGPU_KERNEL_ID "unknown"
+#endif
 #ifndef LCS_FUSED_TU
 const char* recolor_state() { return LCSGPU_RECOLOR_STATE; }
+const char* kernel_id() { return LCSGPU_KERNEL_ID; }
 
 int h_class(uint32_t len)
 {
@@ -917,6 +923,7 @@ static hipError_t launch_long_t(bool quirk, const RowsArgs& a, int grid_x, int g
 // units compile (and get their register pass) side by side.
 #ifdef LCS_FUSED_TU
 const char* recolor_state_fused() { return LCSGPU_RECOLOR_STATE; }
+const char* kernel_id_fused() { return LCSGPU_KERNEL_ID; }
 hipError_t launch_rows_fused(int h, bool quirk, const RowsArgs& a, int grid_x, int grid_y, hipStream_t stream)
 {
     return launch_rows_t<true>(h, quirk, a, grid_x, grid_y, stream);

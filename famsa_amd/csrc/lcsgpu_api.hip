@@ -344,6 +344,7 @@ void finish_host_call(lcsgpu_ctx* ctx, Lane& L)
     float f = 0.f;
     if (L.timing_valid && L.last_launches > 0 && hipEventElapsedTime(&f, L.ev_start, L.ev_stop) != hipSuccess) f = 0.f;
     g_last.ctx = ctx;
+    g_last.also.clear();
     g_last.pending_on_lane0 = false;
     g_last.ms = f;
     g_last.launches = L.last_launches;
@@ -352,9 +353,14 @@ void finish_host_call(lcsgpu_ctx* ctx, Lane& L)
 }
 
 
-void note_async_call(lcsgpu_ctx* ctx)
+void note_async_call(lcsgpu_ctx* ctx, bool also_this)
 {
+    if (also_this) {
+        g_last.also.push_back(ctx);
+        return;
+    }
     g_last.ctx = ctx;
+    g_last.also.clear();
     g_last.pending_on_lane0 = true;
 }
 
@@ -369,7 +375,8 @@ const char* lcsgpu_version(void)
 {
     // both LCS translation units went through the register pass and its check, or the string says what did not
     static const std::string a = lcsgpu::recolor_state(), b = lcsgpu::recolor_state_fused();
-    static const std::string v = std::string("lcsgpu 0.3 gfx950 recolor=") + (a == b ? a : (a == "failed" || b == "failed") ? "failed" : "off");
+    static const std::string v = std::string("lcsgpu 0.4 gfx950 recolor=") + (a == b ? a : (a == "failed" || b == "failed") ? "failed" : "off") +
+                                 " kernels=" + lcsgpu::kernel_id() + "/" + lcsgpu::kernel_id_fused();
     return v.c_str();
 }
 const char* lcsgpu_last_error(void) { return g_err.c_str(); }
@@ -857,8 +864,9 @@ int lcsgpu_last_kernel_ms(lcsgpu_ctx* ctx, double* ms, int32_t* n_launches)
     if (!ctx || !ms) return fail(LCSGPU_E_INVALID, "NULL argument");
     *ms = 0.0;
     if (n_launches) *n_launches = 0;
-    if (g_last.ctx != ctx) return LCSGPU_OK;
-    if (!g_last.pending_on_lane0) { // a completed host-memory call of this thread
+    const bool further = std::find(g_last.also.begin(), g_last.also.end(), ctx) != g_last.also.end();
+    if (g_last.ctx != ctx && !further) return LCSGPU_OK;
+    if (!g_last.pending_on_lane0 && !further) { // a completed host-memory call of this thread
         *ms = g_last.ms;
         if (n_launches) *n_launches = g_last.launches;
         return LCSGPU_OK;

@@ -381,6 +381,13 @@ int lcsgpu_leaf_upgma_batch(lcsgpu_ctx* ctx, const int32_t* ids, const int64_t* 
         return fail(LCSGPU_E_INVALID, "unknown distance kind %d", distance_kind);
     if (n_groups < 0 || (n_groups > 0 && !group_offsets)) return fail(LCSGPU_E_INVALID, "bad group table");
     if (n_groups == 0) return LCSGPU_OK;
+    // the whole group table before anything is derived from it (node_base, the order, the caller's output sizes)
+    if (group_offsets[0] != 0) return fail(LCSGPU_E_INVALID, "group_offsets[0] must be 0");
+    for (int32_t g = 0; g < n_groups; ++g)
+        if (group_offsets[g + 1] < group_offsets[g]) return fail(LCSGPU_E_INVALID, "group_offsets not ascending (list %d)", g);
+    if (group_offsets[n_groups] > 0 && !ids) return fail(LCSGPU_E_INVALID, "NULL ids");
+    for (int64_t k = 0; k < group_offsets[n_groups]; ++k)
+        if (ids[k] < 0 || ids[k] >= ctx->n) return fail(LCSGPU_E_INVALID, "ids[%lld] = %d is not a sequence of the uploaded set", (long long)k, ids[k]);
     if (ctx->max_len > 65535) return fail(LCSGPU_E_UNSUPPORTED, "the leaf reducer reads uint16 LCS values");
     std::vector<int64_t> node_base((size_t)n_groups, 0);
     std::vector<int32_t> order((size_t)n_groups);

@@ -192,6 +192,7 @@ namespace lcsgpu_impl {
 
 struct LastCall { // timing of this thread's most recent call, for lcsgpu_last_kernel_ms
     lcsgpu_ctx* ctx = nullptr;
+    std::vector<lcsgpu_ctx*> also; // the other contexts of a multi-context call: each answers for its own lane 0
     bool pending_on_lane0 = false;
     double ms = 0;
     int launches = 0;
@@ -293,6 +294,7 @@ int run_rows(lcsgpu_ctx* ctx, Lane& L, int mode, const int32_t* ref_ids, int32_t
 // After a host-memory call has been synchronised: account its kernel time.
 void finish_host_call(lcsgpu_ctx* ctx, Lane& L);
 // A *_dev call was queued on lane 0: its timing is read on demand.
-void note_async_call(lcsgpu_ctx* ctx);
+// also_this: a further context of the same multi-context call (the first one is noted without the flag).
+void note_async_call(lcsgpu_ctx* ctx, bool also_this = false);
 
 } // namespace lcsgpu_impl

@@ -6,8 +6,21 @@
 
 #include <memory>
 #include <queue>
+#include <thread>
 
-#include <rccl/rccl.h> // declarations only: librccl is loaded with dlopen when LCSGPU_EXCHANGE=rccl asks for it
+// RCCL: declarations only -- librccl is loaded with dlopen when the exchange of lcsgpu_multi_mst_prim wants it.  A ROCm
+// installation without the RCCL development headers still builds the library: the RCCL exchange is then compiled out
+// (LCSGPU_EXCHANGE=rccl answers LCSGPU_E_UNSUPPORTED, the automatic choice is the peer-copy exchange).
+#if defined(__has_include)
+#if __has_include(<rccl/rccl.h>)
+#include <rccl/rccl.h>
+#define LCSGPU_HAVE_RCCL_HEADERS 1
+#endif
+#endif
+#ifndef LCSGPU_HAVE_RCCL_HEADERS
+#define LCSGPU_HAVE_RCCL_HEADERS 0
+typedef void* ncclComm_t; // placeholders so that the signatures below compile; no RCCL call is made
+#endif
 
 using namespace lcsgpu_impl;
 
@@ -140,6 +153,7 @@ static int shard_best(lcsgpu_ctx* ctx, Lane& L, void* d_keys, lcsgpu_mst_key* h_
         HIP_TRY(lcsgpu::launch_boruvka_fuse_fold(b, L.stream));
     } else if (ctx->mst.fused_ready && ctx->mst.rounds == 0) {
         HIP_TRY(lcsgpu::launch_boruvka_fuse_fold(b, L.stream)); // the launch that filled the triangle did round 0
+        ctx->mst.fused_ready = false;                           // its records are spent: from here on the passes
     } else
         HIP_TRY(lcsgpu::launch_boruvka_best(b, ctx->mst.elem, L.stream));
     if (h_keys) {
@@ -307,6 +321,10 @@ int lcsgpu_mst_shard_set_components(lcsgpu_ctx* ctx, const int32_t* comp)
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipMemcpyAsync(ctx->mst.b.comp, comp, (size_t)ctx->n * 4, hipMemcpyHostToDevice, L.stream));
     HIP_TRY(hipStreamSynchronize(L.stream));
+    // A round of the host-merge protocol ends here (shard_best -> lcsgpu_mst_merge_host -> this call), as a round of the
+    // device protocol ends in shard_merge_async: from now on the labels count (the fused launches fold with them, the
+    // records round 0's launch left behind are spent and the passes take over).
+    ++ctx->mst.rounds;
     return LCSGPU_OK;
 }
 
@@ -650,6 +668,9 @@ bool peer_access(int from, int to)
     } else
         (void)hipGetLastError();
     g_peer.push_back({{from, to}, ok});
+    if (getenv("LCSGPU_PROFILE")) // once per ordered pair and process
+        fprintf(stderr, "lcsgpu: device %d -> device %d: %s\n", from, to,
+                ok ? "peer access on (copies are hipMemcpyPeerAsync, one xGMI hop)" : "no peer access (copies are staged through pinned host memory)");
     return ok;
 }
 
@@ -684,34 +705,60 @@ int copy_between(lcsgpu_ctx* dst_ctx, void* dst, lcsgpu_ctx* src_ctx, const void
     return LCSGPU_OK;
 }
 
-// ---- the key exchange of the Boruvka rounds as an RCCL all-gather (LCSGPU_EXCHANGE=rccl) ------------------------------
+// ---- the key exchange of the Boruvka rounds as an RCCL all-gather ---------------------------------------------------
 // One communicator per context of the call (ncclCommInitAll: one process, one rank per device), cached by device list
 // for the life of the process; librccl (0.5 GB, seconds to initialise) is loaded only when this is asked for, so the
 // library keeps depending on the HIP runtime alone.  A round's exchange is then ONE grouped ncclAllGather, in place
 // (rank k's keys already sit in slot k of its own gather buffer), on the lanes' streams: no events, no copies by hand.
 // RCCL wants one device per rank: contexts that share a device cannot use it (the peer-copy form handles those).
+//
+// Which exchange lcsgpu_multi_mst_prim uses (LCSGPU_EXCHANGE = auto | rccl | peer; unset = auto):
+//   auto  the grouped ncclAllGather when there are >= 2 contexts, every context sits on its own device, librccl loads and
+//         the communicators initialise -- the north star's "RCCL allgather of per-row minima over xGMI"; else the peer
+//         copies, and g_exchange_note says why (lcsgpu_multi_transport reports it).
+//   rccl  the all-gather or an error (also with ONE context, so that a 1-GPU box executes the RCCL calls)
+//   peer  the N x (N-1) peer copies of copy_between
+// The first round a communicator set ever serves is cross-checked: the same round's keys also travel by peer copies into
+// the idle half of the gathered buffers and every context's two halves are compared on the host, byte for byte; a
+// difference ends the call with LCSGPU_E_HIP naming the context and the slot (LCSGPU_EXCHANGE_CHECK=0 skips the check,
+// =always repeats it every call).
+struct RcclComms {
+    std::vector<ncclComm_t> comm;
+    bool verified = false; // the cross-check against the peer copies has passed once
+};
 struct Rccl {
     void* lib = nullptr;
+#if LCSGPU_HAVE_RCCL_HEADERS
     decltype(&ncclCommInitAll) comm_init_all = nullptr;
     decltype(&ncclAllGather) all_gather = nullptr;
     decltype(&ncclGroupStart) group_start = nullptr;
     decltype(&ncclGroupEnd) group_end = nullptr;
     decltype(&ncclGetErrorString) error_string = nullptr;
-    std::map<std::vector<int>, std::vector<ncclComm_t>> comms;
+#endif
+    std::map<std::vector<int>, RcclComms> comms;
     std::string why; // why it is unusable
 };
 std::mutex g_rccl_mu;
 Rccl g_rccl;
+std::string g_exchange_note = "no multi-context single-linkage call yet"; // what the last lcsgpu_multi_mst_prim used, and why
 
-bool exchange_is_rccl()
+enum class Exchange { AUTO, RCCL, PEER };
+Exchange exchange_wanted()
 {
     const char* e = getenv("LCSGPU_EXCHANGE");
-    return e && !strcmp(e, "rccl");
+    if (e && !strcmp(e, "rccl")) return Exchange::RCCL;
+    if (e && !strcmp(e, "peer")) return Exchange::PEER;
+    return Exchange::AUTO;
 }
 
 // communicators for these devices, in this order
-int rccl_comms(const std::vector<int>& devices, const std::vector<ncclComm_t>** out)
+int rccl_comms(const std::vector<int>& devices, RcclComms** out)
 {
+#if !LCSGPU_HAVE_RCCL_HEADERS
+    (void)devices;
+    (void)out;
+    return fail(LCSGPU_E_UNSUPPORTED, "the RCCL exchange was compiled out: <rccl/rccl.h> was not found when liblcsgpu was built");
+#else
     std::lock_guard<std::mutex> lk(g_rccl_mu);
     Rccl& R = g_rccl;
     if (!R.lib && R.why.empty()) {
@@ -730,27 +777,33 @@ int rccl_comms(const std::vector<int>& devices, const std::vector<ncclComm_t>** 
             }
         }
     }
-    if (!R.lib) return fail(LCSGPU_E_UNSUPPORTED, "LCSGPU_EXCHANGE=rccl: %s", R.why.c_str());
+    if (!R.lib) return fail(LCSGPU_E_UNSUPPORTED, "RCCL exchange: %s", R.why.c_str());
     for (size_t a = 0; a < devices.size(); ++a)
         for (size_t b = 0; b < a; ++b)
             if (devices[a] == devices[b])
-                return fail(LCSGPU_E_UNSUPPORTED, "LCSGPU_EXCHANGE=rccl: contexts %zu and %zu share device %d (RCCL wants one device per "
-                                                  "rank; unset LCSGPU_EXCHANGE for the peer-copy exchange)", b, a, devices[a]);
+                return fail(LCSGPU_E_UNSUPPORTED, "RCCL exchange: contexts %zu and %zu share device %d (RCCL wants one device per "
+                                                  "rank; LCSGPU_EXCHANGE=peer or unset for the peer-copy exchange)", b, a, devices[a]);
     auto it = R.comms.find(devices);
     if (it == R.comms.end()) {
-        std::vector<ncclComm_t> c(devices.size(), nullptr);
-        const ncclResult_t e = R.comm_init_all(c.data(), (int)devices.size(), devices.data());
+        RcclComms c;
+        c.comm.assign(devices.size(), nullptr);
+        const ncclResult_t e = R.comm_init_all(c.comm.data(), (int)devices.size(), devices.data());
         if (e != ncclSuccess) return fail(LCSGPU_E_HIP, "ncclCommInitAll over %zu devices failed: %s", devices.size(), R.error_string(e));
         it = R.comms.emplace(devices, std::move(c)).first;
     }
     *out = &it->second;
     return LCSGPU_OK;
+#endif
 }
 
 // every context's keys (slot k of its own buffer) into every context's buffer: base[k] = the N-slot buffer of context k
 int rccl_all_gather_keys(const std::vector<ncclComm_t>& comms, const std::vector<char*>& base, size_t key_bytes,
                          const std::vector<hipStream_t>& streams, const std::vector<int>& devices)
 {
+#if !LCSGPU_HAVE_RCCL_HEADERS
+    (void)comms; (void)base; (void)key_bytes; (void)streams; (void)devices;
+    return fail(LCSGPU_E_UNSUPPORTED, "the RCCL exchange was compiled out");
+#else
     Rccl& R = g_rccl;
     ncclResult_t e = R.group_start();
     hipError_t he = hipSuccess;
@@ -763,6 +816,15 @@ int rccl_all_gather_keys(const std::vector<ncclComm_t>& comms, const std::vector
     if (he != hipSuccess) return fail(LCSGPU_E_HIP, "hipSetDevice failed: %s", hipGetErrorString(he));
     if (e != ncclSuccess) return fail(LCSGPU_E_HIP, "ncclAllGather of the best-edge keys failed: %s", R.error_string(e));
     return LCSGPU_OK;
+#endif
+}
+
+// how a copy between two contexts travels (copy_between's decision, without making the copy)
+const char* transport_between(int sd, int dd)
+{
+    if (env_flag("LCSGPU_FORCE_HOST_STAGING")) return "host-staging(forced)";
+    if (sd == dd) return env_flag("LCSGPU_FORCE_PEER_COPY") ? "peer-copy(same device, forced)" : "same-device";
+    return peer_access(sd, dd) && peer_access(dd, sd) ? "peer-copy" : "host-staging";
 }
 
 // The whole LCS triangle of the uploaded set into lane 0's result buffer of ctxs[0]: row blocks of equal
@@ -1018,8 +1080,8 @@ int lcsgpu_multi_mst_prim(lcsgpu_ctx* const* ctxs, int32_t n_ctx, int distance_k
 {
     int rc = check_multi(ctxs, n_ctx);
     if (rc) return rc;
-    const bool rccl = exchange_is_rccl(); // asked for by name: also with one context, so that a 1-GPU box runs the calls
-    if (n_ctx == 1 && !rccl) return lcsgpu_mst_prim(ctxs[0], distance_kind, out_edges);
+    const Exchange wanted = exchange_wanted(); // rccl asked for by name: also with one context, so that a 1-GPU box runs the calls
+    if (n_ctx == 1 && wanted != Exchange::RCCL) return lcsgpu_mst_prim(ctxs[0], distance_kind, out_edges);
     const bool triangle_orientation = (distance_kind & LCSGPU_MST_TRIANGLE_ORIENTATION) != 0;
     const int kind = distance_kind & ~LCSGPU_MST_TRIANGLE_ORIENTATION;
     if (!valid_kind(kind)) return fail(LCSGPU_E_INVALID, "unknown distance kind %d", kind);
@@ -1057,14 +1119,37 @@ int lcsgpu_multi_mst_prim(lcsgpu_ctx* const* ctxs, int32_t n_ctx, int distance_k
     const int elem = ctxs[0]->max_len > 65535 ? 4 : 2;
     const std::vector<int32_t> cut = equal_pair_cuts(0, n, n_ctx);
     const size_t key_bytes = (size_t)n * sizeof(lcsgpu_mst_key);
-    const std::vector<ncclComm_t>* comms = nullptr;
     std::vector<int> devices(n_ctx);
     std::vector<hipStream_t> streams(n_ctx);
+    bool distinct = true;
     for (int k = 0; k < n_ctx; ++k) {
         devices[k] = ctxs[k]->device;
         streams[k] = g.lanes[k]->stream;
+        for (int j = 0; j < k; ++j) distinct = distinct && devices[j] != devices[k];
     }
-    if (rccl && (rc = rccl_comms(devices, &comms))) return rc;
+    // the exchange of this call (see the comment above struct Rccl)
+    RcclComms* rc_comms = nullptr;
+    std::string note;
+    if (wanted == Exchange::RCCL) {
+        if ((rc = rccl_comms(devices, &rc_comms))) return rc;
+        note = "rccl: one grouped ncclAllGather per round (LCSGPU_EXCHANGE=rccl)";
+    } else if (wanted == Exchange::AUTO && n_ctx > 1 && distinct) {
+        if (rccl_comms(devices, &rc_comms) == LCSGPU_OK) note = "rccl: one grouped ncclAllGather per round (automatic: every context on its own device)";
+        else {
+            rc_comms = nullptr;
+            note = std::string("peer copies, because RCCL is not usable: ") + lcsgpu_last_error();
+        }
+    } else
+        note = wanted == Exchange::PEER ? "peer copies (LCSGPU_EXCHANGE=peer)" : "peer copies (automatic: contexts share a device, RCCL wants one device per rank)";
+    const std::vector<ncclComm_t>* comms = rc_comms ? &rc_comms->comm : nullptr;
+    const char* chk = getenv("LCSGPU_EXCHANGE_CHECK");
+    const bool cross_check = comms && !(chk && !strcmp(chk, "0")) && (!rc_comms->verified || (chk && !strcmp(chk, "always")));
+    {
+        std::lock_guard<std::mutex> lk(g_rccl_mu);
+        g_exchange_note = note;
+    }
+    if (getenv("LCSGPU_PROFILE")) fprintf(stderr, "lcsgpu_multi_mst_prim: %d contexts, key exchange by %s%s\n", n_ctx, note.c_str(),
+                                          cross_check ? " -- first round cross-checked against peer copies" : "");
     for (int k = 0; k < n_ctx; ++k) {
         Lane& L = *g.lanes[k];
         const int32_t r0 = cut[k], r1 = cut[k + 1];
@@ -1097,15 +1182,18 @@ int lcsgpu_multi_mst_prim(lcsgpu_ctx* const* ctxs, int32_t n_ctx, int distance_k
     for (int round = 0; found < n - 1; ++round) {
         if (round > 64) return fail(LCSGPU_E_STATE, "MST: the Boruvka rounds do not converge");
         const int half = round & 1;
+        const bool check_now = cross_check && round == 0;
         for (int k = 0; k < n_ctx; ++k) { // local halves everywhere, each followed by its pushes
             HIP_TRY(hipSetDevice(ctxs[k]->device));
             char* own = (char*)ctxs[k]->d_gather.p + ((size_t)half * n_ctx + k) * key_bytes;
             rc = shard_best(ctxs[k], *g.lanes[k], own, nullptr); // straight into its own slot
             if (rc) return rc;
-            if (comms) continue; // the exchange is one grouped all-gather below
+            if (comms && !check_now) continue; // the exchange is one grouped all-gather below
+            // peer copies: the exchange itself -- or, in the cross-checked round, the second opinion, into the idle half
+            const int to_half = comms ? half ^ 1 : half;
             for (int j = 0; j < n_ctx; ++j) {
-                if (j == k) continue;
-                char* slot = (char*)ctxs[j]->d_gather.p + ((size_t)half * n_ctx + k) * key_bytes;
+                if (j == k && !comms) continue;
+                char* slot = (char*)ctxs[j]->d_gather.p + ((size_t)to_half * n_ctx + k) * key_bytes;
                 rc = copy_between(ctxs[j], slot, ctxs[k], own, key_bytes, g.lanes[k]->stream);
                 if (rc) return rc;
             }
@@ -1117,6 +1205,26 @@ int lcsgpu_multi_mst_prim(lcsgpu_ctx* const* ctxs, int32_t n_ctx, int distance_k
             for (int k = 0; k < n_ctx; ++k) base[k] = (char*)ctxs[k]->d_gather.p + (size_t)half * n_ctx * key_bytes;
             rc = rccl_all_gather_keys(*comms, base, key_bytes, streams, devices);
             if (rc) return rc;
+        }
+        if (check_now) {
+            // both forms have been queued: wait for every producer, then compare the two halves of every context
+            for (int k = 0; k < n_ctx; ++k) {
+                HIP_TRY(hipSetDevice(ctxs[k]->device));
+                HIP_TRY(hipStreamSynchronize(g.lanes[k]->stream));
+            }
+            std::vector<char> by_rccl((size_t)n_ctx * key_bytes), by_peer((size_t)n_ctx * key_bytes);
+            for (int j = 0; j < n_ctx; ++j) {
+                HIP_TRY(hipSetDevice(ctxs[j]->device));
+                HIP_TRY(hipMemcpy(by_rccl.data(), (char*)ctxs[j]->d_gather.p + (size_t)half * n_ctx * key_bytes, by_rccl.size(), hipMemcpyDeviceToHost));
+                HIP_TRY(hipMemcpy(by_peer.data(), (char*)ctxs[j]->d_gather.p + (size_t)(half ^ 1) * n_ctx * key_bytes, by_peer.size(), hipMemcpyDeviceToHost));
+                for (int k = 0; k < n_ctx; ++k)
+                    if (memcmp(by_rccl.data() + (size_t)k * key_bytes, by_peer.data() + (size_t)k * key_bytes, key_bytes))
+                        return fail(LCSGPU_E_HIP, "the RCCL all-gather and the peer copies disagree: context %d (device %d) holds different keys "
+                                                  "of context %d (device %d) in the two forms (%s) -- LCSGPU_EXCHANGE=peer selects the peer copies",
+                                    j, devices[j], k, devices[k], transport_between(devices[k], devices[j]));
+            }
+            std::lock_guard<std::mutex> lk(g_rccl_mu);
+            rc_comms->verified = true;
         }
         for (int j = 0; j < n_ctx; ++j) { // global halves: each context over all N slots, once they have landed
             HIP_TRY(hipSetDevice(ctxs[j]->device));
@@ -1130,10 +1238,62 @@ int lcsgpu_multi_mst_prim(lcsgpu_ctx* const* ctxs, int32_t n_ctx, int distance_k
         if (rc) return rc;
         for (int k = 1; k < n_ctx; ++k) ctxs[k]->mst.found = found; // same keys, same kernels: same count everywhere
     }
+    // The loop watched context 0 only.  Before its edge list is taken for the answer: every other context must have
+    // run to the end without a HIP error and without the merge kernels' inconsistent-keys flag, and must have counted
+    // the same edges -- a failed push, all-gather or merge on another GPU would otherwise pass unseen.
+    for (int k = 1; k < n_ctx; ++k) {
+        HIP_TRY(hipSetDevice(ctxs[k]->device));
+        int32_t c[2] = {0, 0};
+        hipError_t e = hipMemcpyAsync(c, ctxs[k]->mst.b.counters, 8, hipMemcpyDeviceToHost, g.lanes[k]->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(g.lanes[k]->stream);
+        if (e != hipSuccess) return fail(LCSGPU_E_HIP, "context %d (device %d) failed during the Boruvka rounds: %s", k, devices[k], hipGetErrorString(e));
+        g.lanes[k]->plan_in_flight = false;
+        if (c[1]) return fail(LCSGPU_E_STATE, "MST: context %d (device %d) saw inconsistent keys (a hooking cycle)", k, devices[k]);
+        if (c[0] != found)
+            return fail(LCSGPU_E_STATE, "MST: context %d (device %d) recorded %d edges, context 0 recorded %d -- the contexts did not "
+                                        "see the same keys (exchange: %s)", k, devices[k], c[0], found, note.c_str());
+    }
     HIP_TRY(hipSetDevice(ctxs[0]->device));
     rc = shard_finish(ctxs[0], *g.lanes[0], out_edges); // context 0's copy of the edge list, in Prim's order
     if (rc) return rc;
-    for (int k = 0; k < n_ctx; ++k) note_async_call(ctxs[k]);
+    note_async_call(ctxs[0]);
+    for (int k = 1; k < n_ctx; ++k) note_async_call(ctxs[k], true); // lcsgpu_last_kernel_ms answers for every context of the call
+    return LCSGPU_OK;
+}
+
+// How the contexts of a list reach each other, as text (one line per fact, '\n' separated, NUL terminated, truncated to
+// cap): the transport copy_between would pick for every ordered pair of contexts -- counted per kind, with the pairs that
+// do NOT get a peer copy named -- and the key exchange the last lcsgpu_multi_mst_prim of this process used and why.
+// Asking switches peer access on for the pairs (as the first copy would).
+int lcsgpu_multi_transport(lcsgpu_ctx* const* ctxs, int32_t n_ctx, char* buf, size_t cap)
+{
+    if (!ctxs || n_ctx < 1 || !buf || cap < 2) return fail(LCSGPU_E_INVALID, "bad argument");
+    for (int k = 0; k < n_ctx; ++k)
+        if (!ctxs[k]) return fail(LCSGPU_E_INVALID, "NULL ctx");
+    std::map<std::string, int> kinds;
+    std::string odd;
+    for (int a = 0; a < n_ctx; ++a)
+        for (int b = 0; b < n_ctx; ++b) {
+            if (a == b) continue;
+            const char* t = transport_between(ctxs[a]->device, ctxs[b]->device);
+            ++kinds[t];
+            if (strcmp(t, "peer-copy") && strcmp(t, "same-device") && odd.size() < 400) {
+                char one[96];
+                snprintf(one, sizeof one, " %d->%d(dev %d->%d)", a, b, ctxs[a]->device, ctxs[b]->device);
+                odd += one;
+            }
+        }
+    std::string text = "contexts: " + std::to_string(n_ctx) + " on devices";
+    for (int k = 0; k < n_ctx; ++k) text += " " + std::to_string(ctxs[k]->device);
+    text += "\ncopies between contexts:";
+    if (kinds.empty()) text += " none (one context)";
+    for (const auto& kv : kinds) text += " " + kv.first + " x" + std::to_string(kv.second);
+    if (!odd.empty()) text += "\nnot by peer copy:" + odd;
+    {
+        std::lock_guard<std::mutex> lk(g_rccl_mu);
+        text += "\nkey exchange of the last single-linkage call: " + g_exchange_note;
+    }
+    snprintf(buf, cap, "%s", text.c_str());
     return LCSGPU_OK;
 }
 
@@ -1162,16 +1322,38 @@ int lcsgpu_multi_lcs_triangle(lcsgpu_ctx* const* ctxs, int32_t n_ctx, int32_t ro
         rc = run_rows(ctxs[k], L, lcsgpu::MODE_TRIANGLE, nullptr, r0, r1 - r0, nullptr, 0, std::max(0, r1 - 1), L.d_out.p, 0, off, elem_size, r0);
         if (rc) return rc;
     }
-    for (int k = 0; k < n_ctx; ++k) { // every GPU is computing by now; collect in order
+    // Every GPU is computing by now.  Each block leaves over its own GPU's PCIe link, all links at the same time: one
+    // host thread per context (a copy into pageable host memory is staged by the runtime on the calling thread, so
+    // queueing the copies from ONE thread would still drain the GPUs one after the other -- at 100 000 sequences 10 GB
+    // over one link, ~0.4 s, instead of 1.25 GB over each of eight).  LCSGPU_SERIAL_DRAIN=1: the old order (A/B, tests).
+    std::vector<int> status(n_ctx, LCSGPU_OK);
+    std::vector<std::string> what(n_ctx);
+    auto drain = [&](int k) {
         const int32_t r0 = cut[k], r1 = cut[k + 1];
-        if (r1 <= r0) continue;
+        if (r1 <= r0) return;
         Lane& L = *g.lanes[k];
         const int64_t off = tri_offset(r0);
-        HIP_TRY(hipSetDevice(ctxs[k]->device));
-        HIP_TRY(hipMemcpyAsync((char*)out + (size_t)(off - base) * elem_size, L.d_out.p, (size_t)(tri_offset(r1) - off) * elem_size,
-                               hipMemcpyDeviceToHost, L.stream));
-        HIP_TRY(hipStreamSynchronize(L.stream));
-        finish_host_call(ctxs[k], L);
+        hipError_t e = hipSetDevice(ctxs[k]->device);
+        if (e == hipSuccess)
+            e = hipMemcpyAsync((char*)out + (size_t)(off - base) * elem_size, L.d_out.p, (size_t)(tri_offset(r1) - off) * elem_size,
+                               hipMemcpyDeviceToHost, L.stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(L.stream);
+        if (e != hipSuccess) {
+            status[k] = LCSGPU_E_HIP;
+            what[k] = hipGetErrorString(e);
+        }
+    };
+    if (env_flag("LCSGPU_SERIAL_DRAIN"))
+        for (int k = 0; k < n_ctx; ++k) drain(k);
+    else {
+        std::vector<std::thread> workers;
+        for (int k = 1; k < n_ctx; ++k) workers.emplace_back(drain, k);
+        drain(0);
+        for (auto& t : workers) t.join();
+    }
+    for (int k = 0; k < n_ctx; ++k) {
+        if (status[k]) return fail(status[k], "row block %d (device %d) did not arrive: %s", k, ctxs[k]->device, what[k].c_str());
+        if (cut[k + 1] > cut[k]) finish_host_call(ctxs[k], *g.lanes[k]);
     }
     return LCSGPU_OK;
 }

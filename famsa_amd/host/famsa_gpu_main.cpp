@@ -170,6 +170,15 @@ int main(int argc, char** argv)
                       << "time.newick=" << t.newick_s << "\n"
                       << "time.store=" << t.store_s << "\n"
                       << "gpu.lcs_kernel_ms=" << t.kernel_ms << "\n";
+            if (!t.transport.empty()) { // several GPUs: one "gpu.transport=" line per fact
+                size_t at = 0;
+                while (at < t.transport.size()) {
+                    const size_t nl = t.transport.find('\n', at);
+                    std::cerr << "gpu.transport=" << t.transport.substr(at, nl == std::string::npos ? std::string::npos : nl - at) << "\n";
+                    if (nl == std::string::npos) break;
+                    at = nl + 1;
+                }
+            }
         }
         // The result is on disk.  Tearing the HIP runtime down (contexts, queues, code objects) costs ~0.1 s,
         // a third of a small run's wall time; the process ends here instead (FAMSA_GPU_CLEAN_EXIT=1 for

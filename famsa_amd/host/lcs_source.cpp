@@ -66,6 +66,14 @@ GpuLcsSource::~GpuLcsSource()
     for (lcsgpu_ctx* c : ctxs_) lcsgpu_destroy(c);
 }
 
+std::string GpuLcsSource::transport() const
+{
+    if (ctxs_.size() < 2) return std::string();
+    char buf[2048];
+    if (lcsgpu_multi_transport(ctxs_.data(), (int32_t)ctxs_.size(), buf, sizeof buf) != LCSGPU_OK) return std::string("unknown: ") + lcsgpu_last_error();
+    return buf;
+}
+
 void GpuLcsSource::expect_threads(int n_threads)
 {
     const int per_ctx = (n_threads + (int)ctxs_.size() - 1) / (int)ctxs_.size();

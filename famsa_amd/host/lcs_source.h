@@ -108,6 +108,8 @@ public:
     bool assign_seeds(const int* seeds, int n_seeds, const int* cols, int n_cols, int distance_kind, int first_k, float* dist,
                       int* assign) override;
     double kernel_ms_total() const { return kernel_ms_; }
+    // several devices: lcsgpu_multi_transport's text (empty with one context)
+    std::string transport() const;
     void add_kernel_ms(lcsgpu_ctx* ctx);
 
 private:

@@ -96,6 +96,7 @@ std::string guide_tree_newick_gpu(const SeqSet& s, int device, const TreeOptions
         t->init_s = t1b - t1;
         t->upload_s = t2 - t1b;
         t->kernel_ms = src.kernel_ms_total();
+        t->transport = src.transport();
     }
     if (g_abandon_engine_at_return && !getenv("FAMSA_GPU_PROFILE")) (void)held.release();
     return nwk;
@@ -120,6 +121,7 @@ void dist_export_gpu(const SeqSet& s, int device, Distance dist, bool square, bo
         t->upload_s = t2 - t1;
         t->tree_s = t3 - t2;
         t->kernel_ms = src.kernel_ms_total();
+        t->transport = src.transport();
     }
     if (g_abandon_engine_at_return && !getenv("FAMSA_GPU_PROFILE")) (void)held.release();
 }

@@ -14,6 +14,7 @@ namespace famsa_host {
 
 struct Timings {
     double load_s = 0, sort_s = 0, init_s = 0, upload_s = 0, tree_s = 0, newick_s = 0, store_s = 0, kernel_ms = 0;
+    std::string transport; // several GPUs: lcsgpu_multi_transport's report (how the contexts reached each other, which key exchange ran)
 };
 
 // Newick for the whole input (duplicates re-attached), LCS values from `src_of_unique`, whose

@@ -66,6 +66,7 @@ def load_library():
         "lcsgpu_multi_upgma": (C.c_int, [vp, i32, C.c_int, C.c_int, vp, vp]),
         "lcsgpu_multi_nj": (C.c_int, [vp, i32, C.c_int, vp, vp]),
         "lcsgpu_multi_mst_prim": (C.c_int, [vp, i32, C.c_int, vp]),
+        "lcsgpu_multi_transport": (C.c_int, [vp, i32, C.c_char_p, sz]),
         "lcsgpu_upgma": (C.c_int, [vp, C.c_int, C.c_int, vp, vp]),
         "lcsgpu_nj": (C.c_int, [vp, C.c_int, vp, vp]),
         "lcsgpu_lcs_triangles_batch": (C.c_int, [vp, pi32, C.POINTER(C.c_int64), i32, vp, C.c_int]),
@@ -383,6 +384,16 @@ class LcsGpuGroup:
         out = np.zeros(max(self.n - 1, 0), dtype=MST_EDGE)
         self._check(self._lib.lcsgpu_multi_mst_prim(self._arr, len(self.engs), kind, out.ctypes.data if out.size else None))
         return out
+
+    def transport(self):
+        """lcsgpu_multi_transport: how the contexts reach each other + the key exchange of the last mst_prim (text)."""
+        buf = C.create_string_buffer(2048)
+        self._check(self._lib.lcsgpu_multi_transport(self._arr, len(self.engs), buf, len(buf)))
+        return buf.value.decode()
+
+    def last_kernel_ms(self):
+        """Per context: LCS kernel milliseconds of its row block in the last multi-context call."""
+        return [e.last_kernel_ms()[0] for e in self.engs]
 
     def upgma(self, kind=1, modified=False):
         left = np.zeros(max(self.n - 1, 1), dtype=np.int32)

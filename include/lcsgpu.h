@@ -47,8 +47,10 @@ extern "C" {
 
 typedef struct lcsgpu_ctx lcsgpu_ctx;
 
-/* Library / build information: "lcsgpu <version> gfx950 recolor=<on|off|failed>" -- the last field says how the hot
- * kernels were built: with the register-bank renaming pass and its equivalence check passed ("on"), without the pass
+/* Library / build information: "lcsgpu <version> gfx950 recolor=<on|off|failed> kernels=<id>/<id>" -- kernels= names the
+ * device code of the two LCS translation units (sha256 prefix of the listings they were assembled from: equal ids =
+ * the same kernels instruction for instruction; bench.py matches committed profiles to the running library by it);
+ * recolor= says how the hot kernels were built: with the register-bank renaming pass and its equivalence check passed ("on"), without the pass
  * on request ("off", make RECOLOR=0), or as compiled because the pass or its check failed ("failed": results are the
  * same, the LCS kernels ~5 % slower). */
 const char* lcsgpu_version(void);
@@ -276,17 +278,26 @@ int lcsgpu_nj(lcsgpu_ctx* ctx, int distance_kind, int32_t* out_left, int32_t* ou
  * is tiled by row blocks of equal pair counts, block k on ctxs[k]; all GPUs compute at the same time.
  *
  * lcsgpu_multi_lcs_triangle: as lcsgpu_lcs_triangle, HOST output -- the row producers of UPGMA::computeDistances
- *   (tree/UPGMA.cpp:75-109) / DistanceCalculator::run (tree/DistanceCalculator.cpp:28-82), one block per GPU.
+ *   (tree/UPGMA.cpp:75-109) / DistanceCalculator::run (tree/DistanceCalculator.cpp:28-82), one block per GPU; the
+ *   blocks come back over all the GPUs' PCIe links at the same time (one host thread per context drains its block).
  * lcsgpu_multi_upgma / lcsgpu_multi_nj: as lcsgpu_upgma / lcsgpu_nj; the row blocks of the other GPUs are copied
  *   into ctxs[0]'s HBM over xGMI (device-to-device), where the sequential merges run.
- * lcsgpu_multi_mst_prim: as lcsgpu_mst_prim, by the sharded Boruvka rounds above with the exchange in DEVICE memory:
- *   per round every context pushes its n keys (16 B each) into its slot of every other context's gathered buffer
- *   (peer copies over xGMI on the producer's stream = the all-gather), every context runs the same global half on
- *   its own GPU, and the host synchronises once (the edge count).  With LCSGPU_EXCHANGE=rccl in the environment the
- *   exchange is ONE grouped ncclAllGather per round instead (in place, on the contexts' streams; librccl is loaded on
- *   demand and a communicator per device list is kept for the life of the process) -- RCCL wants one device per rank:
- *   LCSGPU_E_UNSUPPORTED when two contexts share a device.  LCSGPU_E_UNSUPPORTED also for orientation-sensitive
- *   sets in MSTPrim's own orientation (run lcsgpu_mst_prim on one context then).
+ * lcsgpu_multi_mst_prim: as lcsgpu_mst_prim, by the sharded Boruvka rounds above with the exchange in DEVICE memory, in one
+ *   of two forms.  (a) RCCL: ONE grouped ncclAllGather of n keys (16 B each) per context and round, in place, on the
+ *   contexts' streams (librccl is loaded on demand and a communicator set per device list is kept for the life of the
+ *   process) -- the "RCCL allgather of per-row minima over xGMI".  (b) Peer copies: every context pushes its n keys into
+ *   its slot of every other context's gathered buffer (N x (N-1) copies on the producers' streams).  Either way every
+ *   context runs the same global half on its own GPU and the host synchronises once per round (the edge count).
+ *   LCSGPU_EXCHANGE in the environment chooses: unset / "auto" = (a) when there are >= 2 contexts, each on its own
+ *   device, and RCCL loads and initialises, else (b) with the reason kept for lcsgpu_multi_transport; "rccl" = (a) or an
+ *   error -- LCSGPU_E_UNSUPPORTED when two contexts share a device (RCCL wants one device per rank) or librccl is
+ *   missing; "peer" = (b).  The first round a communicator set ever serves is cross-checked: the round's keys also
+ *   travel by (b) into the idle half of the gathered buffers and the two results are compared byte for byte on the host
+ *   (LCSGPU_E_HIP naming the context pair on a difference; LCSGPU_EXCHANGE_CHECK=0 skips it, =always repeats it every
+ *   call).  Before the edge list of context 0 is returned every other context is synchronised and must report no HIP
+ *   error, no inconsistent keys and the same edge count.  LCSGPU_E_UNSUPPORTED also for orientation-sensitive sets in
+ *   MSTPrim's own orientation (run lcsgpu_mst_prim on one context then).  lcsgpu_last_kernel_ms afterwards answers for
+ *   EVERY context of the call (its own block's LCS launch), so a caller sees how balanced the row blocks ran.
  * Device-to-device copies between contexts switch peer access on for the device pair at first use; where the
  * devices cannot address each other the copy is staged through pinned host memory (slower, same result).  Test
  * switches (environment): LCSGPU_FORCE_PEER_COPY=1 makes same-device contexts take the peer-copy branch,
@@ -297,6 +308,14 @@ int lcsgpu_multi_upgma(lcsgpu_ctx* const* ctxs, int32_t n_ctx, int distance_kind
                        int32_t* out_right);
 int lcsgpu_multi_nj(lcsgpu_ctx* const* ctxs, int32_t n_ctx, int distance_kind, int32_t* out_left, int32_t* out_right);
 int lcsgpu_multi_mst_prim(lcsgpu_ctx* const* ctxs, int32_t n_ctx, int distance_kind, lcsgpu_mst_edge* out_edges);
+/* How the contexts of a list reach each other, as text for a log (lines separated by '\n', NUL terminated, truncated to
+ * cap bytes): the transport a copy between every ordered pair of contexts takes -- "peer-copy" (hipMemcpyPeerAsync with
+ * peer access on: one xGMI hop), "host-staging" (no peer access: pinned host memory, two PCIe crossings),
+ * "same-device" -- counted per kind, the pairs that get no peer copy named; and which key exchange the last
+ * lcsgpu_multi_mst_prim of this process used and why (see above).  Asking switches peer access on for the pairs, as
+ * the first copy would.  famsa-gpu -v prints it.  Nothing comparable exists in the reference (one process, host
+ * threads: tree/MSTPrim.cpp:330-538). */
+int lcsgpu_multi_transport(lcsgpu_ctx* const* ctxs, int32_t n_ctx, char* buf, size_t cap);
 
 /* The lower triangles of several id lists in one call (the leaf sub-trees of one FastTree split):
  * list g = ids[group_offsets[g] .. group_offsets[g+1]), m_g members; out receives the packed

@@ -38,6 +38,15 @@ for line in txt.splitlines():
     m = re.match(r"\s+lcsgpu::(boruvka_\w+_kernel)<[^>]*>\S*\s+(FETCH_SIZE|WRITE_SIZE|GRBM_GUI_ACTIVE|SQ_INSTS_VALU|SQ_INSTS_SALU)\s+n=(\d+)\s+sum=(\d+)\s+mean=([\d.]+)", line)
     if m:
         out.setdefault(m.group(1), {})[m.group(2)] = float(m.group(5))
+# which kernel and which library build these counters are about: bench.py passes the traffic figure on only to a run of the same
+out["kernel"] = "lcsgpu::lcs_rows_kernel_pipe<13, 4, 4, false>"
+try:
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(sys.argv[2]))))
+    import famsa_amd
+    out["library"] = famsa_amd.load_library().lcsgpu_version().decode()
+except Exception as e:
+    out["library"] = None
 if "FETCH_SIZE" in out and "WRITE_SIZE" in out:
     out["traffic_bytes"] = (2 * out["FETCH_SIZE"] + out["WRITE_SIZE"]) * 1024
 json.dump(out, open(sys.argv[2], "w"), indent=1)

@@ -3,6 +3,8 @@ reports the missing GPU loudly (no CPU fallback), and the host-only entry points
 import ctypes as C
 import os
 import re
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -74,3 +76,10 @@ def test_null_and_bad_arguments_return_codes():
     n = C.c_size_t(0)
     assert lib.lcsgpu_encode(None, 3, None, C.byref(n)) == -1
     assert b"NULL" in lib.lcsgpu_last_error()
+
+
+def test_bench_needs_its_gpus():
+    """More ranks than GPUs without the emulation switch: an error that says so, not a hang and not a number."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64", "--steps", "1"],
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and "GPU(s) visible" in p.stderr and "{" not in p.stdout

@@ -154,6 +154,42 @@ def test_row_block_shards_with_the_fold_in_the_launch(engine, parts, resident):
             e.close()
 
 
+@pytest.mark.parametrize("parts", [1, 3])
+@pytest.mark.parametrize("resident", [True, False])
+def test_host_merge_protocol_with_the_fold_in_the_launch(engine, parts, resident):
+    """LCSGPU_MST_COMPUTE with the HOST form of the protocol include/lcsgpu.h documents: shard_best (host keys) ->
+    lcsgpu_mst_merge_host -> lcsgpu_mst_shard_set_components.  The round state must advance in set_components too:
+    from round 1 on the fused launches fold with the labels (no triangle) resp. the passes replace the spent round-0
+    records (resident triangle) -- else the keys name edges inside a component and the merge refuses them."""
+    import torch
+    from famsa_amd.rowblock import sharded_mst_host
+    seqs = _sets()["mixed_sorted"]
+    engine.upload_seqs(seqs)
+    want = engine.mst_prim(1)
+    n = len(seqs)
+    cuts = row_cuts(n, parts)
+    engs, tris = [], []
+    try:
+        for p in range(parts):
+            e = famsa_amd.LcsGpu(0)
+            e.upload_seqs(seqs)
+            engs.append(e)
+            tris.append(torch.empty(max(pairs_in_rows(cuts[p], cuts[p + 1]), 1), dtype=torch.int16, device="cuda:0") if resident else None)
+        torch.cuda.synchronize()
+        for p, e in enumerate(engs):
+            e.mst_shard_begin(tris[p].data_ptr() if resident else None, 2, cuts[p], cuts[p + 1], 1 | MST_COMPUTE)
+
+        def set_components(comp):
+            for e in engs:
+                e.mst_shard_set_components(comp)
+
+        got, rounds = sharded_mst_host(n, lambda: np.stack([e.mst_shard_best(host=True) for e in engs]), lambda k: k, set_components)
+        assert rounds > 1 and same(got, want)
+    finally:
+        for e in engs:
+            e.close()
+
+
 def test_group_call_without_triangles(engine, monkeypatch):
     """lcsgpu_multi_mst_prim with every context in recompute mode (what N GPUs do beyond ~1.5 M sequences)."""
     seqs = _sets()["family"]

@@ -122,6 +122,62 @@ def test_key_exchange_as_an_rccl_all_gather(engine, monkeypatch):
         two.close()
 
 
+def test_exchange_choice_cross_check_and_transport_report(engine, monkeypatch, capfd):
+    """Which exchange lcsgpu_multi_mst_prim picks and what lcsgpu_multi_transport says about it.  On one device the
+    automatic choice must be the peer copies (RCCL wants one device per rank) and say so; LCSGPU_EXCHANGE=rccl on one
+    context runs the all-gather WITH the first-use cross-check against the peer-copy form (LCSGPU_EXCHANGE_CHECK=always
+    repeats it); the per-context kernel times of the call are all readable afterwards."""
+    seqs = _sets()["family"]
+    engine.upload_seqs(seqs)
+    want = engine.mst_prim(1)
+    grp = famsa_amd.LcsGpuGroup([0, 0, 0])
+    one = famsa_amd.LcsGpuGroup([0])
+    try:
+        grp.upload_seqs(seqs)
+        got = grp.mst_prim(1)
+        assert (got["from"] == want["from"]).all() and (got["to"] == want["to"]).all()
+        text = grp.transport()
+        assert "contexts: 3 on devices 0 0 0" in text and "same-device x6" in text, text
+        assert "peer copies (automatic: contexts share a device" in text, text
+        ms = grp.last_kernel_ms()
+        assert len(ms) == 3 and all(m > 0 for m in ms), ms
+        monkeypatch.setenv("LCSGPU_FORCE_HOST_STAGING", "1")
+        assert "host-staging(forced) x6" in grp.transport() and "not by peer copy: 0->1" in grp.transport()
+        monkeypatch.delenv("LCSGPU_FORCE_HOST_STAGING")
+        monkeypatch.setenv("LCSGPU_EXCHANGE", "peer")
+        grp.mst_prim(1)
+        assert "peer copies (LCSGPU_EXCHANGE=peer)" in grp.transport()
+        # the RCCL form with its cross-check, on the one shape a 1-GPU box can give RCCL
+        one.upload_seqs(seqs)
+        monkeypatch.setenv("LCSGPU_EXCHANGE", "rccl")
+        monkeypatch.setenv("LCSGPU_EXCHANGE_CHECK", "always")
+        monkeypatch.setenv("LCSGPU_PROFILE", "1")
+        got = one.mst_prim(1)
+        err = capfd.readouterr().err
+        assert "first round cross-checked against peer copies" in err, err
+        assert (got["from"] == want["from"]).all() and (got["dist"].view(np.uint64) == want["dist"].view(np.uint64)).all()
+        assert "rccl: one grouped ncclAllGather per round" in one.transport()
+    finally:
+        grp.close()
+        one.close()
+
+
+def test_row_blocks_come_back_over_all_links_at_once(engine, monkeypatch):
+    """lcsgpu_multi_lcs_triangle drains every context's block on its own host thread (one PCIe link per GPU, all at the
+    same time); LCSGPU_SERIAL_DRAIN=1 is the one-after-the-other order of earlier rounds.  Same bytes either way."""
+    seqs = _sets()["family"]
+    engine.upload_seqs(seqs)
+    want = engine.lcs_triangle()
+    grp = famsa_amd.LcsGpuGroup([0, 0, 0, 0])
+    try:
+        grp.upload_seqs(seqs)
+        assert (grp.lcs_triangle() == want).all()
+        monkeypatch.setenv("LCSGPU_SERIAL_DRAIN", "1")
+        assert (grp.lcs_triangle() == want).all()
+    finally:
+        grp.close()
+
+
 def test_group_refuses_what_it_cannot_do(engine):
     seqs = [np.zeros(192, np.uint8)] + _sets()["family"][:300]  # a carry-quirk (orientation-sensitive) sequence
     grp = famsa_amd.LcsGpuGroup([0, 0])

@@ -189,10 +189,11 @@ def test_row_minima_of_a_row_block(engine, oracle):
                 assert d[i - r0] == m and j[i - r0] == int(np.max(np.nonzero(dd == m)[0])), (kind, r0, i)
 
 
-def _bench(args, world):
+def _bench(args, world, torchrun=True):
     env = dict(os.environ)
-    env.pop("RANK", None)
-    if world == 1:
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    if world == 1 or not torchrun:
         cmd = [sys.executable, os.path.join(ROOT, "bench.py")]
     else:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
@@ -217,6 +218,37 @@ def test_bench_step_ends_in_the_same_tree_for_every_rank_count():
     assert two["parity"]["mismatches"] == 0
 
 
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus N` WITHOUT torchrun (how the N = 1 record is produced, and what a driver that starts
+    N > 1 the same way gets): the script starts its N ranks itself, runs the fail-closed self-check (the ranks' sharded
+    tree on a 2000-sequence family set against every rank's single-context tree) and prints one line with the per-rank
+    kernel times; the hash equals the one-rank hash."""
+    args = ["--steps", "1", "--warmup", "1", "--n-seqs", "5000", "--seq-len", "120", "--no-cpu-baseline"]
+    one = _bench(args, 1)
+    two = _bench(args + ["--emulate-ranks-on-one-gpu"], 2, torchrun=False)
+    three = _bench(args + ["--emulate-ranks-on-one-gpu"], 3, torchrun=False)
+    for rec, w in ((two, 2), (three, 3)):
+        assert rec["n_gpus"] == w and rec["mst"]["edges_sha256"] == one["mst"]["edges_sha256"]
+        r = rec["ranks"]
+        assert r["world"] == w and len(r["kernel_ms_per_rank"]) == w and r["kernel_ms_min"] > 0
+        assert r["self_check"]["ranks_agree"] and r["self_check"]["n_seqs"] == 2000
+        assert rec["parity"]["mismatches"] == 0
+    assert one["ranks"]["self_check"] is None and one["ranks"]["rccl_ranks"] is None
+
+
+def test_bench_contexts_mode():
+    """--mode contexts: one process, N contexts, lcsgpu_multi_mst_prim -- the library's own multi-GPU path -- with its
+    self-check; same tree as the ranks mode, per-context kernel times, the transport report in the line."""
+    args = ["--steps", "1", "--warmup", "1", "--n-seqs", "5000", "--seq-len", "120", "--no-cpu-baseline"]
+    one = _bench(args, 1)
+    ctx3 = _bench(args + ["--mode", "contexts", "--emulate-ranks-on-one-gpu"], 3, torchrun=False)
+    assert ctx3["mst"]["edges_sha256"] == one["mst"]["edges_sha256"] and ctx3["n_gpus"] == 3
+    r = ctx3["ranks"]
+    assert r["mode"] == "contexts" and len(r["kernel_ms_per_rank"]) == 3 and r["kernel_ms_min"] > 0
+    assert r["self_check"]["contexts_agree"] and "peer copies" in r["transport"]
+    assert ctx3["parity"]["sampled_pairs"] > 0 and ctx3["parity"]["mismatches"] == 0
+
+
 def test_bench_with_the_real_collective_on_one_rank():
     """bench.py --force-collective: one rank, but the exchange of every Boruvka round is the N > 1 path's own --
     torch.distributed initialised with the nccl (= RCCL) backend, all_gather_into_tensor on device tensors, the
@@ -224,7 +256,8 @@ def test_bench_with_the_real_collective_on_one_rank():
     MI355X in every GPU test run, not for the first time on an 8-GPU node.  Same tree as without it."""
     args = ["--steps", "2", "--warmup", "1", "--n-seqs", "6000", "--seq-len", "120", "--no-cpu-baseline"]
     plain = _bench(args, 1)
-    forced = _bench(args + ["--force-collective"], 1)
+    forced = _bench(args + ["--force-collective", "--self-check"], 1)
     assert forced["config"]["exchange"].startswith("nccl") and plain["config"]["exchange"].startswith("none")
+    assert forced["ranks"]["rccl_ranks"] == 1 and forced["ranks"]["self_check"]["ranks_agree"]
     assert forced["mst"]["edges_sha256"] == plain["mst"]["edges_sha256"]
     assert forced["mst"]["rounds"] == plain["mst"]["rounds"] and forced["parity"]["mismatches"] == 0
