@@ -205,6 +205,31 @@ hipError_t launch_upgma(const UpgmaArgs& a, const void* lcs, int elem_size, cons
                         const float* pow_f32, int kind, bool modified, hipStream_t stream);
 
 
+// ---- several merges per launch (upgma_batch_kernels.hip; symmetric-matrix layout only) ----
+constexpr int UPGMA_BATCH_MAX = 32;  // merges per batch at most (template instances: 8, 16, 32)
+constexpr int UPGMA_BATCH_CAND = 64; // entries of the sorted order handed to the next batch's walk (2 x the largest batch)
+struct UpgmaBatchArgs {
+    float* D;             // the symmetric n x n matrix
+    float* min_dist;      // [n]   as UpgmaArgs
+    uint32_t* nearest;    // [n]
+    uint32_t* node_index; // [n]
+    int32_t* left;        // [n-1]
+    int32_t* right;
+    int32_t n;
+    int32_t n_blocks;     // ceil(n / 256)
+    uint2* sorted0;       // [n + 1] the active rows as (min_dist bits, row), ascending; batch parity 0 reads it, 1 writes it
+    uint2* sorted1;       //         ... and the other way round
+    uint32_t* pos;        // [n] where a row's entry sits in the current order
+    uint4* cand;          // [UPGMA_BATCH_CAND] the first entries of the current order with their rows' nearest
+    uint32_t* state;      // [2][8]: merges committed, entries of the order, error, batches cut short -- by batch parity
+    uint32_t* hdr;        // [512] the pending batch: count, then per merge (L, R, key bits, creator of R, positions)
+    float* side;          // [UPGMA_BATCH_MAX][n] the rows the pending batch creates
+    float* part_d;        // [UPGMA_BATCH_MAX][n_blocks] per-workgroup first minima of those rows
+    uint32_t* part_j;
+};
+hipError_t launch_upgma_batch_init(const UpgmaBatchArgs& a, hipStream_t stream);
+hipError_t launch_upgma_batches(const UpgmaBatchArgs& a, bool modified, int k, int first, int count, hipStream_t stream);
+
 // ---- leaf sub-trees of the FastTree recursion: UPGMA, one workgroup per leaf (tree_kernels.hip) ----
 constexpr int LEAF_MAX = 2048; // members of a leaf (the reference's default threshold is 2000)
 struct LeafArgs {

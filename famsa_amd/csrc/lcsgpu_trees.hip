@@ -962,6 +962,69 @@ int upgma_reduce(lcsgpu_ctx* ctx, Lane& L, int elem, int distance_kind, int modi
         } else
             return fail(LCSGPU_E_HIP, "UPGMA: the merge kernel lost its workgroups on the way (status %u)", sel[9]);
     }
+    // Several merges per launch (upgma_batch_kernels.hip): the default while the symmetric matrix is in use.  A batch = the
+    // next <= K entries of the rows' sorted (min_dist, index) order, computed together and committed as far as the
+    // reference would have picked them in that order (practically always all K).  LCSGPU_UPGMA_BATCH=0 keeps one launch per
+    // merge; = 8 | 16 | 32 selects K (32).
+    int batch_k = 32;
+    if (const char* e = getenv("LCSGPU_UPGMA_BATCH")) batch_k = atoi(e);
+    int n_batches = 0, n_cut = 0;
+    if (!merged && square && batch_k >= 8 && n >= 3) {
+        batch_k = batch_k >= 32 ? 32 : batch_k >= 16 ? 16 : 8;
+        const size_t nb = (size_t)blocks;
+        const size_t b_s0 = 0, b_s1 = b_s0 + a16(((size_t)n + 1) * 8), b_pos = b_s1 + a16(((size_t)n + 1) * 8),
+                     b_cand = b_pos + a16((size_t)n * 4), b_state = b_cand + a16((size_t)lcsgpu::UPGMA_BATCH_CAND * 16),
+                     b_hdr = b_state + 256, b_side = b_hdr + 2048, b_pd = b_side + a16((size_t)lcsgpu::UPGMA_BATCH_MAX * n * 4),
+                     b_pj = b_pd + a16((size_t)lcsgpu::UPGMA_BATCH_MAX * nb * 4), b_total = b_pj + a16((size_t)lcsgpu::UPGMA_BATCH_MAX * nb * 4);
+        HIP_TRY(ctx->d_qrows.reserve(b_total)); // (a buffer the UPGMA path does not otherwise use)
+        char* bb = (char*)ctx->d_qrows.p;
+        lcsgpu::UpgmaBatchArgs ba{};
+        ba.D = a.D;
+        ba.min_dist = a.min_dist;
+        ba.nearest = a.nearest;
+        ba.node_index = a.node_index;
+        ba.left = a.left;
+        ba.right = a.right;
+        ba.n = n;
+        ba.n_blocks = blocks;
+        ba.sorted0 = (uint2*)(bb + b_s0);
+        ba.sorted1 = (uint2*)(bb + b_s1);
+        ba.pos = (uint32_t*)(bb + b_pos);
+        ba.cand = (uint4*)(bb + b_cand);
+        ba.state = (uint32_t*)(bb + b_state);
+        ba.hdr = (uint32_t*)(bb + b_hdr);
+        ba.side = (float*)(bb + b_side);
+        ba.part_d = (float*)(bb + b_pd);
+        ba.part_j = (uint32_t*)(bb + b_pj);
+        HIP_TRY(hipMemsetAsync(bb + b_state, 0, 256 + 2048, L.stream));
+        HIP_TRY(lcsgpu::launch_upgma_batch_init(ba, L.stream));
+        // The host does not know how many batches it takes (the validity check may cut one short): enqueue what the
+        // remaining merges need if every batch is full, look at the committed count, repeat.  Batches past the end do nothing.
+        uint32_t st[8] = {0};
+        int done = 0;
+        while (done < n - 1) {
+            const int want = (n - 1 - done + batch_k - 1) / batch_k + (n_batches ? 2 : 0);
+            HIP_TRY(lcsgpu::launch_upgma_batches(ba, modified != 0, batch_k, n_batches, want, L.stream));
+            n_batches += want;
+            HIP_TRY(hipMemcpyAsync(st, ba.state + 8 * (n_batches & 1), 32, hipMemcpyDeviceToHost, L.stream));
+            HIP_TRY(hipStreamSynchronize(L.stream));
+            if (st[2]) {
+                sel[8] = 1;
+                break;
+            }
+            if ((int)st[0] <= done && want > 0 && (int)st[0] < n - 1)
+                return fail(LCSGPU_E_STATE, "UPGMA: %d batches committed nothing (%u of %d merges)", want, st[0], n - 1);
+            done = (int)st[0];
+            n_cut = (int)st[3];
+        }
+        merged = true;
+        if (st[2]) {
+            L.plan_in_flight = false;
+            return fail(LCSGPU_E_INVALID, "UPGMA: no finite nearest neighbour (a pair with LCS 0?) -- the reference's "
+                                          "algorithm is undefined for this input");
+        }
+    }
+    const bool batched = n_batches > 0;
     if (!merged) HIP_TRY(lcsgpu::launch_upgma_steps(a, modified != 0, L.stream));
     HIP_TRY(hipMemcpyAsync(out_left, a.left, (size_t)(n - 1) * 4, hipMemcpyDeviceToHost, L.stream));
     HIP_TRY(hipMemcpyAsync(out_right, a.right, (size_t)(n - 1) * 4, hipMemcpyDeviceToHost, L.stream));
@@ -971,7 +1034,10 @@ int upgma_reduce(lcsgpu_ctx* ctx, Lane& L, int elem, int distance_kind, int modi
     if (profile)
         fprintf(stderr, "lcsgpu_upgma: n = %d, %s layout, distances + row minima %.3f s, %d merges %.3f s = %.2f us each (%s)\n", n,
                 square ? "square" : "triangle", t_merge - t_pro, n - 1, now() - t_merge, 1e6 * (now() - t_merge) / std::max(n - 1, 1),
-                merged ? "one kernel on one XCD" : "one launch per merge");
+                batched ? "batches of merges, two launches each" : merged ? "one kernel on one XCD" : "one launch per merge");
+    if (profile && batched)
+        fprintf(stderr, "lcsgpu_upgma: %d batches of <= %d merges (%.1f merges per batch, %d cut short by a new row's key)\n", n_batches, batch_k,
+                (double)(n - 1) / n_batches, n_cut);
     if (sel[8])
         return fail(LCSGPU_E_INVALID, "UPGMA: no finite nearest neighbour (a pair with LCS 0?) -- the reference's "
                                       "algorithm is undefined for this input");

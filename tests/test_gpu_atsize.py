@@ -84,7 +84,7 @@ def test_c4_single_linkage_tree(synth100k, tmp_path):
 
 
 @pytest.mark.parametrize("gt,layout", [("upgma", "square"), ("upgma_modified", "square"), ("upgma", "triangle"),
-                                       ("upgma_modified", "square+chain")])
+                                       ("upgma_modified", "square+chain"), ("upgma", "square+steps")])
 def test_c4_upgma_trees(synth100k, tmp_path, gt, layout):
     """100 000 merges on the device (one launch each) over the float distances -- the 40 GB symmetric matrix (default)
     or the 20 GB packed triangle: the per-workgroup minima are two per thread at this size (391 workgroups), which no
@@ -93,6 +93,8 @@ def test_c4_upgma_trees(synth100k, tmp_path, gt, layout):
     env = {"LCSGPU_UPGMA_LAYOUT": layout.split("+")[0]}
     if layout.endswith("chain"):  # the one-XCD merge kernel (opt-in): 100 000 merges inside one launch
         env["LCSGPU_UPGMA_CHAIN"] = "1"
+    if layout.endswith("steps"):  # one launch per merge (the default until round 4: batches of 32 merges per launch pair)
+        env["LCSGPU_UPGMA_BATCH"] = "0"
     cli("-gt", gt, "-gt_export", synth100k[2], out, env=env)
     assert file_sha(out) == META["synth100k"][f"{gt}_newick_sha256"]
 

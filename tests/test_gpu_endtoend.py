@@ -122,12 +122,18 @@ def test_cli_medoidtree_duplicates(tmp_path):
     assert open(out, "rb").read() == open(os.path.join(G, "hemopexin_duplicates", "medoid-sl-dups.dnd"), "rb").read()
 
 
+@pytest.mark.parametrize("batch", ["32", "8", "0"])
 @pytest.mark.parametrize("gt", ["upgma", "upgma_modified", "nj"])
-def test_device_upgma_on_tie_heavy_inputs(host, tmp_path, gt):
+def test_device_upgma_on_tie_heavy_inputs(host, tmp_path, monkeypatch, gt, batch):
     """Device UPGMA / NJ vs the host restatement (itself pinned against the reference on tie-heavy random inputs):
-    small alphabets give many equal float distances, so every '<' / first-minimum rule is exercised."""
+    small alphabets give many equal float distances, so every '<' / first-minimum rule is exercised.  UPGMA in batches
+    of up to 32 / 8 merges per launch pair (upgma_batch_kernels.hip; with this many equal keys the validity check cuts
+    batches short all the time) and with one launch per merge (0)."""
     import numpy as np
     import oracle_bind as ob
+    if gt == "nj" and batch != "32":
+        pytest.skip("the batch size is a UPGMA parameter")
+    monkeypatch.setenv("LCSGPU_UPGMA_BATCH", batch)
     oracle = ob.Oracle()
     for seed, (n, max_len, alpha) in enumerate([(2, 5, "AC"), (3, 8, "AC"), (40, 12, "AC"), (257, 20, "ACD"),
                                                 (700, 60, "ACDE"), (1500, 150, "ARNDCQEGHILKMFPSTWYV")]):
@@ -165,21 +171,34 @@ def test_trees_of_a_set_with_a_giant_sequence(host, oracle, tmp_path, gt):
     assert host.tree_gpu(fasta, gt) == host.tree_from_matrix(fasta, square, gt)
 
 
-@pytest.mark.parametrize("layout", ["square", "triangle", "square+chain"])
+@pytest.mark.parametrize("layout", ["square", "square+b16", "square+b8", "square+steps", "triangle", "square+chain"])
 @pytest.mark.parametrize("gt", ["upgma", "upgma_modified"])
-@pytest.mark.parametrize("shape", ["ties", "family"])
+@pytest.mark.parametrize("shape", ["ties", "family", "hub"])
 def test_device_upgma_on_tie_heavy_and_larger_sets(host, oracle, tmp_path, monkeypatch, gt, shape, layout):
-    """The one-launch-per-merge UPGMA against the host restatement (pinned to the reference by the CPU suite)
-    fed with the oracle's matrix: thousands of exact distance ties, several workgroups of rows, merges that
-    touch the same workgroup twice in a row.  Both layouts of the float distances: the full symmetric matrix (the
-    default while 4 B x n^2 fit) and the packed triangle."""
+    """The device UPGMA against the host restatement (pinned to the reference by the CPU suite) fed with the oracle's
+    matrix: thousands of exact distance ties, several workgroups of rows, merges that touch the same workgroup twice
+    in a row, a hub every other row is nearest to (one cluster that swallows a row per merge: the chained merges of a
+    batch).  Both layouts of the float distances -- the full symmetric matrix (the default while 4 B x n^2 fit; merges
+    in batches of 32 / 16 / 8 per launch pair, or one launch per merge, or the one-XCD chain) and the packed triangle."""
     import numpy as np
     monkeypatch.setenv("LCSGPU_UPGMA_LAYOUT", layout.split("+")[0])
     if layout.endswith("chain"):  # all merges inside one kernel whose workgroups run on one XCD (opt-in, tree_kernels.hip)
         monkeypatch.setenv("LCSGPU_UPGMA_CHAIN", "1")
+    if "+b" in layout:
+        monkeypatch.setenv("LCSGPU_UPGMA_BATCH", layout.split("+b")[1])
+    if layout.endswith("steps"):
+        monkeypatch.setenv("LCSGPU_UPGMA_BATCH", "0")
     rng = np.random.Generator(np.random.PCG64(61))
     if shape == "ties":
         seqs = [rng.integers(0, 3, size=int(rng.integers(8, 15))).astype(np.uint8) for _ in range(1300)]
+    elif shape == "hub":  # every member is the hub with a few substitutions of its own: the hub is everyone's nearest
+        hub = rng.integers(0, 20, size=120, dtype=np.uint8)
+        seqs = [hub]
+        for _ in range(900):
+            s = hub.copy()
+            m = rng.random(120) < rng.uniform(0.02, 0.3)
+            s[m] = rng.integers(0, 20, size=int(m.sum()), dtype=np.uint8)
+            seqs.append(s)
     else:
         anc = rng.integers(0, 20, size=150, dtype=np.uint8)
         seqs = []
