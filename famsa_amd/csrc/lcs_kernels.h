@@ -173,6 +173,7 @@ struct UpgmaArgs {
     float* D;             // float distances (updated in place): the packed lower triangle, or -- square -- the full
                           // symmetric n x n matrix, in which both rows a merge reads are contiguous
     int32_t square;
+    int64_t ld;           // square: floats from one row of D to the next (n; 2n in the slot layout of upgma_batch_kernels.hip)
     float* min_dist;      // [n]
     uint32_t* nearest;    // [n]
     uint32_t* node_index; // [n]
@@ -209,23 +210,28 @@ hipError_t launch_upgma(const UpgmaArgs& a, const void* lcs, int elem_size, cons
 constexpr int UPGMA_BATCH_MAX = 32;  // merges per batch at most (template instances: 8, 16, 32)
 constexpr int UPGMA_BATCH_CAND = 64; // entries of the sorted order handed to the next batch's walk (2 x the largest batch)
 struct UpgmaBatchArgs {
-    float* D;             // the symmetric n x n matrix
+    float* D;             // D[row * ld + slot]: n rows x ld slots (ld >= 2n - 1; see upgma_batch_kernels.hip, LAYOUT)
+    int64_t ld;
+    uint32_t* slot_of;    // [n]  the slot a row's cluster sits in
+    uint32_t* row_of;     // [ld] the row a slot stands for, NONE when the slot is dead / not used yet
     float* min_dist;      // [n]   as UpgmaArgs
     uint32_t* nearest;    // [n]
     uint32_t* node_index; // [n]
     int32_t* left;        // [n-1]
     int32_t* right;
     int32_t n;
-    int32_t n_blocks;     // ceil(n / 256)
+    int32_t n_blocks;     // ceil(ld / 256): workgroups that cover every slot
     uint2* sorted0;       // [n + 1] the active rows as (min_dist bits, row), ascending; batch parity 0 reads it, 1 writes it
     uint2* sorted1;       //         ... and the other way round
     uint32_t* pos;        // [n] where a row's entry sits in the current order
     uint4* cand;          // [UPGMA_BATCH_CAND] the first entries of the current order with their rows' nearest
     uint32_t* state;      // [2][8]: merges committed, entries of the order, error, batches cut short -- by batch parity
-    uint32_t* hdr;        // [512] the pending batch: count, then per merge (L, R, key bits, creator of R, positions)
-    float* side;          // [UPGMA_BATCH_MAX][n] the rows the pending batch creates
+    uint32_t* hdr;        // [512] the pending batch: count, then per merge (L, R, key bits, creator of R, positions, slots)
+    uint32_t* rec;        // [8 + 4 K + K^2] what the resolve kernel found: V, per merge (new min_dist, nearest, die), cross entries
+    float* side;          // [UPGMA_BATCH_MAX][ld] the rows the pending batch creates, along the slots
     float* part_d;        // [UPGMA_BATCH_MAX][n_blocks] per-workgroup first minima of those rows
     uint32_t* part_j;
+    unsigned long long* dbg; // measurement aid (LCSGPU_UPGMA_BATCH_DBG): 16 phase totals in 10 ns ticks, or NULL
 };
 hipError_t launch_upgma_batch_init(const UpgmaBatchArgs& a, hipStream_t stream);
 hipError_t launch_upgma_batches(const UpgmaBatchArgs& a, bool modified, int k, int first, int count, hipStream_t stream);

@@ -890,9 +890,30 @@ int upgma_reduce(lcsgpu_ctx* ctx, Lane& L, int elem, int distance_kind, int modi
     // triangle|square forces one (tests, measurements).
     bool square = (size_t)n * n * sizeof(float) <= ((size_t)200 << 30);
     if (const char* e = getenv("LCSGPU_UPGMA_LAYOUT")) square = !strcmp(e, "square");
+    // Several merges per launch (upgma_batch_kernels.hip) -- the default while its layout fits: n rows x 2n SLOTS (a new
+    // cluster keeps its left child's row but gets a new column, so that a batch's columns are consecutive: 80 GB at 100 000
+    // sequences, up to ~158 000 on 288 GB).  A batch = the next <= K entries of the rows' sorted (min_dist, index) order,
+    // computed together and committed as far as the reference would have picked them in that order (practically always all
+    // K).  LCSGPU_UPGMA_BATCH=0 keeps one launch per merge on the n x n matrix; = 8 | 16 | 32 selects K (32).
+    int batch_k = 32;
+    if (const char* e = getenv("LCSGPU_UPGMA_BATCH")) batch_k = atoi(e);
+    batch_k = batch_k >= 32 ? 32 : batch_k >= 16 ? 16 : batch_k >= 8 ? 8 : 0;
+    const char* chain_on = getenv("LCSGPU_UPGMA_CHAIN");
+    if (n < 3 || (chain_on && !strcmp(chain_on, "1"))) batch_k = 0;
+    size_t ld = (size_t)n;
     int rc = LCSGPU_E_NOMEM;
-    if (square) rc = reserve_big(ctx, ctx->d_dist, (size_t)n * n * sizeof(float), "the float distance matrix");
+    if (square && batch_k) {
+        ld = ((size_t)2 * n + 63) & ~(size_t)63;
+        if ((size_t)n * ld * sizeof(float) <= ((size_t)230 << 30))
+            rc = reserve_big(ctx, ctx->d_dist, (size_t)n * ld * sizeof(float), "the float distance matrix (rows x slots)");
+        if (rc == LCSGPU_E_NOMEM) {
+            batch_k = 0;
+            ld = (size_t)n;
+        }
+    }
+    if (square && !batch_k) rc = reserve_big(ctx, ctx->d_dist, (size_t)n * n * sizeof(float), "the float distance matrix");
     if (rc == LCSGPU_E_NOMEM) {
+        batch_k = 0;
         square = false;
         rc = reserve_big(ctx, ctx->d_dist, (size_t)tri_offset(n) * sizeof(float), "the float distance triangle");
     }
@@ -914,6 +935,7 @@ int upgma_reduce(lcsgpu_ctx* ctx, Lane& L, int elem, int distance_kind, int modi
     a.bm_near = (uint32_t*)(base + o_bn);
     a.D = (float*)ctx->d_dist.p;
     a.square = square ? 1 : 0;
+    a.ld = (int64_t)ld;
     a.min_dist = (float*)(base + o_min);
     a.nearest = (uint32_t*)(base + o_near);
     a.node_index = (uint32_t*)(base + o_node);
@@ -962,40 +984,39 @@ int upgma_reduce(lcsgpu_ctx* ctx, Lane& L, int elem, int distance_kind, int modi
         } else
             return fail(LCSGPU_E_HIP, "UPGMA: the merge kernel lost its workgroups on the way (status %u)", sel[9]);
     }
-    // Several merges per launch (upgma_batch_kernels.hip): the default while the symmetric matrix is in use.  A batch = the
-    // next <= K entries of the rows' sorted (min_dist, index) order, computed together and committed as far as the
-    // reference would have picked them in that order (practically always all K).  LCSGPU_UPGMA_BATCH=0 keeps one launch per
-    // merge; = 8 | 16 | 32 selects K (32).
-    int batch_k = 32;
-    if (const char* e = getenv("LCSGPU_UPGMA_BATCH")) batch_k = atoi(e);
     int n_batches = 0, n_cut = 0;
-    if (!merged && square && batch_k >= 8 && n >= 3) {
-        batch_k = batch_k >= 32 ? 32 : batch_k >= 16 ? 16 : 8;
-        const size_t nb = (size_t)blocks;
+    if (!merged && square && batch_k) {
+        const size_t nb = (ld + 255) / 256;
         const size_t b_s0 = 0, b_s1 = b_s0 + a16(((size_t)n + 1) * 8), b_pos = b_s1 + a16(((size_t)n + 1) * 8),
-                     b_cand = b_pos + a16((size_t)n * 4), b_state = b_cand + a16((size_t)lcsgpu::UPGMA_BATCH_CAND * 16),
-                     b_hdr = b_state + 256, b_side = b_hdr + 2048, b_pd = b_side + a16((size_t)lcsgpu::UPGMA_BATCH_MAX * n * 4),
+                     b_slot = b_pos + a16((size_t)n * 4), b_rowof = b_slot + a16((size_t)n * 4),
+                     b_cand = b_rowof + a16(ld * 4), b_state = b_cand + a16((size_t)lcsgpu::UPGMA_BATCH_CAND * 16),
+                     b_hdr = b_state + 256, b_rec = b_hdr + 2048, b_side = b_rec + 8192, b_pd = b_side + a16((size_t)lcsgpu::UPGMA_BATCH_MAX * ld * 4),
                      b_pj = b_pd + a16((size_t)lcsgpu::UPGMA_BATCH_MAX * nb * 4), b_total = b_pj + a16((size_t)lcsgpu::UPGMA_BATCH_MAX * nb * 4);
         HIP_TRY(ctx->d_qrows.reserve(b_total)); // (a buffer the UPGMA path does not otherwise use)
         char* bb = (char*)ctx->d_qrows.p;
         lcsgpu::UpgmaBatchArgs ba{};
         ba.D = a.D;
+        ba.ld = (int64_t)ld;
+        ba.slot_of = (uint32_t*)(bb + b_slot);
+        ba.row_of = (uint32_t*)(bb + b_rowof);
         ba.min_dist = a.min_dist;
         ba.nearest = a.nearest;
         ba.node_index = a.node_index;
         ba.left = a.left;
         ba.right = a.right;
         ba.n = n;
-        ba.n_blocks = blocks;
+        ba.n_blocks = (int32_t)nb;
         ba.sorted0 = (uint2*)(bb + b_s0);
         ba.sorted1 = (uint2*)(bb + b_s1);
         ba.pos = (uint32_t*)(bb + b_pos);
         ba.cand = (uint4*)(bb + b_cand);
         ba.state = (uint32_t*)(bb + b_state);
         ba.hdr = (uint32_t*)(bb + b_hdr);
+        ba.rec = (uint32_t*)(bb + b_rec);
         ba.side = (float*)(bb + b_side);
         ba.part_d = (float*)(bb + b_pd);
         ba.part_j = (uint32_t*)(bb + b_pj);
+        ba.dbg = getenv("LCSGPU_UPGMA_BATCH_DBG") ? (unsigned long long*)(bb + b_hdr + 1536) : nullptr; // 16 x 8 B behind the header's 264 words
         HIP_TRY(hipMemsetAsync(bb + b_state, 0, 256 + 2048, L.stream));
         HIP_TRY(lcsgpu::launch_upgma_batch_init(ba, L.stream));
         // The host does not know how many batches it takes (the validity check may cut one short): enqueue what the
@@ -1018,6 +1039,15 @@ int upgma_reduce(lcsgpu_ctx* ctx, Lane& L, int elem, int distance_kind, int modi
             n_cut = (int)st[3];
         }
         merged = true;
+        if (ba.dbg) {
+            unsigned long long tk[16];
+            HIP_TRY(hipMemcpy(tk, ba.dbg, sizeof tk, hipMemcpyDeviceToHost));
+            static const char* what[16] = {"rows: level-1 loads", "rows: walk", "rows: the rows arrive", "rows: averages, side stores, minima", "", "", "", "",
+                                           "resolve: level 1 + partial minima", "resolve: level 2", "resolve: cross entries, minima, validity", "",
+                                           "commit: level 1", "commit: stores issued", "commit: renames + sorted order", ""};
+            for (int i = 0; i < 16; ++i)
+                if (what[i][0]) fprintf(stderr, "  batch phase %-40s %.2f us per batch\n", what[i], tk[i] * 0.01 / std::max(n_batches, 1));
+        }
         if (st[2]) {
             L.plan_in_flight = false;
             return fail(LCSGPU_E_INVALID, "UPGMA: no finite nearest neighbour (a pair with LCS 0?) -- the reference's "
@@ -1034,7 +1064,7 @@ int upgma_reduce(lcsgpu_ctx* ctx, Lane& L, int elem, int distance_kind, int modi
     if (profile)
         fprintf(stderr, "lcsgpu_upgma: n = %d, %s layout, distances + row minima %.3f s, %d merges %.3f s = %.2f us each (%s)\n", n,
                 square ? "square" : "triangle", t_merge - t_pro, n - 1, now() - t_merge, 1e6 * (now() - t_merge) / std::max(n - 1, 1),
-                batched ? "batches of merges, two launches each" : merged ? "one kernel on one XCD" : "one launch per merge");
+                batched ? "batches of merges, three launches each" : merged ? "one kernel on one XCD" : "one launch per merge");
     if (profile && batched)
         fprintf(stderr, "lcsgpu_upgma: %d batches of <= %d merges (%.1f merges per batch, %d cut short by a new row's key)\n", n_batches, batch_k,
                 (double)(n - 1) / n_batches, n_cut);

@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256) void upgma_dist_kernel(const T* __restrict__ l
 template <typename T>
 __global__ __launch_bounds__(256) void upgma_dist_square_kernel(const T* __restrict__ lcs, const uint32_t* __restrict__ lens,
                                                                 const float* __restrict__ pow_f32, int kind, int n,
-                                                                float* __restrict__ D)
+                                                                size_t ld, float* __restrict__ D)
 {
     __shared__ float tile[32][33];
     // tile (ti, tj), tj <= ti, from the linear workgroup id
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256) void upgma_dist_square_kernel(const T* __restr
                 d = __fdiv_rn(pow_f32[indel], (float)l);
             else
                 d = __fdiv_rn((float)indel, (float)l);
-            D[(size_t)i * n + j] = d;
+            D[(size_t)i * ld + j] = d;
         }
         tile[ty + 8 * r][tx] = d;
     }
@@ -250,18 +250,18 @@ __global__ __launch_bounds__(256) void upgma_dist_square_kernel(const T* __restr
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int j = tj * 32 + ty + 8 * r, i = ti * 32 + tx; // element (j, i) of the upper half = tile[i][j]
-        if (i < n && j < i) D[(size_t)j * n + i] = tile[tx][ty + 8 * r];
+        if (i < n && j < i) D[(size_t)j * ld + i] = tile[tx][ty + 8 * r];
     }
     if (ti == tj && threadIdx.x < 32) { // the diagonal is never read; keep it defined
         const int i = ti * 32 + threadIdx.x;
-        if (i < n) D[(size_t)i * n + i] = 0.0f;
+        if (i < n) D[(size_t)i * ld + i] = 0.0f;
     }
 }
 
 template <bool SQUARE>
 __device__ __forceinline__ size_t upgma_index(const UpgmaArgs& a, uint64_t row, uint64_t col)
 {
-    return SQUARE ? (size_t)(row * (uint64_t)a.n + col) : tri_index(row, col);
+    return SQUARE ? (size_t)(row * (uint64_t)a.ld + col) : tri_index(row, col);
 }
 
 // initial row minima over the FULL row of x (columns y != x), first strict minimum in ascending y
@@ -487,7 +487,7 @@ __global__ __launch_bounds__(256) void upgma_step_kernel(UpgmaArgs a, int it)
             if (!touched && j == own_bm_j) a.bm_near[b] = near_j;
         }
         a.D[vL] = v;
-        if (SQUARE) a.D[(size_t)j * (size_t)n + L] = v; // the mirror: a strided store, off the dependent path
+        if (SQUARE) a.D[(size_t)j * (size_t)a.ld + L] = v; // the mirror: a strided store, off the dependent path
         nd = v;
         nj = j;
     }
@@ -618,7 +618,7 @@ __global__ __launch_bounds__(UPGMA_CHAIN_THREADS) void upgma_chain_kernel(UpgmaA
         float nd = UPGMA_BIG;
         uint32_t nj = UPGMA_NONE, nn = UPGMA_NONE;
         if (it >= 0) {
-            const size_t rowL = (size_t)L * (size_t)n, rowR = (size_t)R * (size_t)n;
+            const size_t rowL = (size_t)L * (size_t)a.ld, rowR = (size_t)R * (size_t)a.ld;
             // all of this thread's elements of the two rows are requested before the first is used (clamped addresses, no
             // branch in between): ONE trip to memory per merge, not one per row the thread owns
             float dLv[UPGMA_CHAIN_ROWS], dRv[UPGMA_CHAIN_ROWS];
@@ -640,7 +640,7 @@ __global__ __launch_bounds__(UPGMA_CHAIN_THREADS) void upgma_chain_kernel(UpgmaA
                 else v = __fmul_rn(__fadd_rn(dL, dR), 0.5f);
                 if (nr[k] == R) nr[k] = L;
                 D[rowL + j] = v;
-                D[(size_t)j * (size_t)n + L] = v; // the mirror
+                D[(size_t)j * (size_t)a.ld + L] = v; // the mirror
                 if (v < nd) { nd = v; nj = (uint32_t)j; } // ascending j inside the thread
             }
 #pragma unroll
@@ -729,10 +729,10 @@ hipError_t launch_upgma_prologue(const UpgmaArgs& a, const void* lcs, int elem_s
         const long long t = (n + 31) / 32, tiles = t * (t + 1) / 2;
         if (elem_size == 2)
             hipLaunchKernelGGL(upgma_dist_square_kernel<uint16_t>, dim3((unsigned)tiles), dim3(256), 0, stream, (const uint16_t*)lcs,
-                               lens, pow_f32, kind, n, a.D);
+                               lens, pow_f32, kind, n, (size_t)a.ld, a.D);
         else
             hipLaunchKernelGGL(upgma_dist_square_kernel<uint32_t>, dim3((unsigned)tiles), dim3(256), 0, stream, (const uint32_t*)lcs,
-                               lens, pow_f32, kind, n, a.D);
+                               lens, pow_f32, kind, n, (size_t)a.ld, a.D);
         hipLaunchKernelGGL(upgma_init_kernel<true>, dim3(n), dim3(256), 0, stream, a);
     } else {
         if (elem_size == 2)

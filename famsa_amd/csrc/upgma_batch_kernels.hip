@@ -15,7 +15,7 @@
 //     where one hub sequence is everybody's nearest neighbour) reads that value from its own registers / LDS.
 //     Only the columns of rows created IN the batch see each other (K x K "cross" entries): those are left to the
 //     commit kernel, which has every column's result in front of it.
-// A batch is two launches:
+// A batch is three launches:
 //   upgma_batch_rows_kernel    every workgroup walks the first entries of the sorted order (one wave, DPP / ballots:
 //                              no LDS, no barrier) to the batch's <= K merges (L_t, R_t), then thread j computes
 //                              column j of every merge from the COMMITTED matrix (all row loads issued at once)
@@ -31,9 +31,21 @@
 //                              with the first 2K entries and their nearest as the next batch's candidates.
 // Merges t >= V are dropped (their side rows are never committed) and the next batch starts from the committed state,
 // so the sequence of merges, every float operation and every tie rule are the reference's, whatever V is.
-// Needs the full symmetric matrix (both rows of a merge contiguous); the packed triangle keeps one launch per merge.
+//
+// LAYOUT: rows and SLOTS.  The reference lets a new cluster take over its left child's row AND column of the matrix;
+// writing that column is n scattered 4-byte stores per merge, each to a different page of a 40 GB matrix -- 3 of the 4 us
+// a merge cost in the first batched form.  Here a cluster keeps its left child's ROW (row indices decide ties, so they
+// stay the reference's) but gets a NEW COLUMN: slot n + k for the k-th merge.  The matrix is D[row][slot], n rows x
+// (2n - 1) slots; slot_of[row] / row_of[slot] translate (a slot whose row died or moved is dead: row_of = NONE).  The
+// columns of the V clusters a batch commits are then V CONSECUTIVE slots: every surviving row gets one contiguous run
+// of V floats (128 B at V = 32) instead of V scattered words, and a cluster's own row is written along the slots
+// (coalesced).  Thread p of the launches stands for slot p; first minima stay (value, ROW) so that ties resolve by row
+// index exactly as the reference's ascending scans do.  Price: 2 x the matrix (n x 2n floats: 80 GB at 100 000
+// sequences, fits up to ~158 000 on 288 GB; beyond that the n x n matrix with one launch per merge, then the triangle).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include <algorithm>
 
 #include "dpp_min.h"
 #include "lcs_kernels.h"
@@ -61,6 +73,26 @@ __device__ __forceinline__ bool ub_less(uint32_t k1, uint32_t r1, uint32_t k2, u
 {
     return k1 < k2 || (k1 == k2 && r1 < r2);
 }
+// measurement aid (LCSGPU_UPGMA_BATCH_DBG): thread 0 of ONE workgroup in the middle of the grid adds the 10 ns ticks
+// between its phase marks to dbg[slot]
+struct UbTimer {
+    unsigned long long* dbg;
+    unsigned long long last;
+    bool on;
+    __device__ UbTimer(unsigned long long* d, int first_slot) : dbg(d + first_slot), last(0)
+    {
+        on = d != nullptr && threadIdx.x == 0 && blockIdx.x == gridDim.x / 2;
+        if (on) last = wall_clock64();
+    }
+    __device__ void mark(int slot)
+    {
+        if (!on) return;
+        const unsigned long long now = wall_clock64();
+        atomicAdd(dbg + slot, now - last);
+        last = now;
+    }
+};
+
 __device__ __forceinline__ uint32_t lane_u32(uint32_t v, int lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, lane); }
 __device__ __forceinline__ int lane_i32(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
 
@@ -86,8 +118,10 @@ __global__ __launch_bounds__(256) void upgma_batch_rank_kernel(UpgmaBatchArgs a)
     if (j < (uint32_t)n) {
         a.sorted0[rank] = make_uint2(my, j);
         a.pos[j] = rank;
+        a.slot_of[j] = j; // leaf j sits in slot j
         if (rank < (uint32_t)UPGMA_BATCH_CAND) a.cand[rank] = make_uint4(my, j, a.nearest[j], 0u);
     }
+    for (uint32_t p = j; p < (uint32_t)a.ld; p += gridDim.x * 256) a.row_of[p] = p < (uint32_t)n ? p : UB_NONE;
     if (j == 0) {
         a.state[0] = 0u;          // merges committed
         a.state[1] = (uint32_t)n; // entries of the sorted order = active rows
@@ -98,7 +132,8 @@ __global__ __launch_bounds__(256) void upgma_batch_rank_kernel(UpgmaBatchArgs a)
 }
 
 // hdr: [0] = m (merges of the pending batch), [1] = error seen by the walk, then per merge t, at 8 + 8 t:
-//   L, R, key bits, src (merge of this batch that created R, or -1), position of L in the order, position of R (or NONE)
+//   L, R, key bits, src (merge of this batch that created R, or -1), position of L in the order, position of R (or NONE),
+//   slot of L, slot of R (or NONE when R was created in this batch)
 constexpr int UB_HDR0 = 8, UB_HDR_STRIDE = 8;
 
 // ---- launch 1 of a batch ------------------------------------------------------------------------------------------------
@@ -106,17 +141,18 @@ template <int K, bool MODIFIED>
 __global__ __launch_bounds__(256) void upgma_batch_rows_kernel(UpgmaBatchArgs a, int parity)
 {
     static_assert(2 * K <= 64, "the candidates of a batch sit in the lanes of one wave");
-    __shared__ float s_new[K][256]; // column tid of every row the batch creates (read back by the same thread only)
-    __shared__ float s_pd[K][4];
-    __shared__ uint32_t s_pj[K][4];
+    constexpr int STRIDE = 256 + 8; // (the minima below read 8 rows of this at once: a stride of 8 banks keeps them apart)
+    __shared__ float s_new[K][STRIDE]; // slot tid's entry of every row the batch creates (BIG where the slot takes no part)
+    __shared__ uint32_t s_x[256];
     const int tid = threadIdx.x, b = blockIdx.x, n = a.n, nb = a.n_blocks;
+    const size_t ld = (size_t)a.ld;
     const int lane = tid & 63, wave = tid >> 6;
-    const uint32_t j = (uint32_t)b * 256 + tid;
-    const bool in = j < (uint32_t)n;
+    const uint32_t p = (uint32_t)b * 256 + tid; // my slot
+    UbTimer tm(a.dbg, 0);
     // ---- level 1: everything whose address is known before the launch ----
     const uint32_t* st = a.state + 8 * parity;
     const uint32_t done = st[0], ns = st[1], err = st[2];
-    const uint32_t my_node = in ? a.node_index[j] : UB_NONE;
+    const uint32_t x = p < (uint32_t)a.ld ? a.row_of[p] : UB_NONE; // the row my slot stands for (NONE: dead / not yet used)
     uint4 c = make_uint4(0xFFFFFFFFu, UB_NONE, UB_NONE, 0u);
     if (lane < 2 * K) c = a.cand[lane];
     const int n_cand = (int)min(ns, (uint32_t)(2 * K));
@@ -124,6 +160,7 @@ __global__ __launch_bounds__(256) void upgma_batch_rows_kernel(UpgmaBatchArgs a,
         if (b == 0 && tid == 0) a.hdr[0] = 0u;
         return;
     }
+    tm.mark(0); // level-1 loads
     // ---- the walk: lane t of every wave ends up holding merge t ----
     uint32_t mL = UB_NONE, mR = UB_NONE, mKey = 0u;
     int mSrc = -1, mPos = 0;
@@ -152,187 +189,225 @@ __global__ __launch_bounds__(256) void upgma_batch_rows_kernel(UpgmaBatchArgs a,
             uint32_t* h = a.hdr + UB_HDR0 + UB_HDR_STRIDE * lane;
             h[0] = mL; h[1] = mR; h[2] = mKey; h[3] = (uint32_t)mSrc; h[4] = (uint32_t)mPos;
             h[5] = mSrc < 0 ? a.pos[mR] : UB_NONE;
+            h[6] = a.slot_of[mL];
+            h[7] = mSrc < 0 ? a.slot_of[mR] : UB_NONE;
         }
     }
     if (m == 0) return;
-    // ---- my column's part in the batch ----
-    int createAt = UB_INF, dieAt = UB_INF;
+    tm.mark(1); // the walk
+    // ---- my slot's part in the batch: it is a column of merge t until its row is merged itself ----
+    int dieAt = UB_INF;
 #pragma unroll
-    for (int t = 0; t < K; ++t) {
-        if (t < m) {
-            if (lane_u32(mL, t) == j) createAt = t;
-            if (lane_u32(mR, t) == j && dieAt == UB_INF) dieAt = t;
-        }
-    }
-    const bool alive0 = in && my_node != UB_NONE;
+    for (int t = 0; t < K; ++t)
+        if (t < m && dieAt == UB_INF && (lane_u32(mL, t) == x || lane_u32(mR, t) == x)) dieAt = t;
+    if (x == UB_NONE) dieAt = -1;
     float dl[K], dr[K];
 #pragma unroll
     for (int t = 0; t < K; ++t) { // every row load of the batch, issued together
         dl[t] = 0.0f;
         dr[t] = 0.0f;
-        if (t < m) {
-            const bool normal = alive0 && createAt > t && dieAt > t;
-            const uint32_t Lt = lane_u32(mL, t), Rt = lane_u32(mR, t);
-            const int src = lane_i32(mSrc, t);
-            if (normal) {
-                dl[t] = a.D[(size_t)Lt * (size_t)n + j];
-                if (src < 0) dr[t] = a.D[(size_t)Rt * (size_t)n + j];
-            }
+        if (t < m && dieAt > t) {
+            dl[t] = a.D[(size_t)lane_u32(mL, t) * ld + p];
+            if (lane_i32(mSrc, t) < 0) dr[t] = a.D[(size_t)lane_u32(mR, t) * ld + p];
         }
     }
+    if (tm.on) { // (the loads land: what the timer sees as "rows arrive")
+        float sink = 0.0f;
+#pragma unroll
+        for (int t = 0; t < K; ++t) sink += dl[t] + dr[t];
+        if (sink == 1.2345e-30f) a.hdr[2] = 1u;
+    }
+    tm.mark(2);
+    s_x[tid] = x;
 #pragma unroll
     for (int t = 0; t < K; ++t) {
         if (t < m) {
-            const bool normal = alive0 && createAt > t && dieAt > t;
             const int src = lane_i32(mSrc, t);
-            float nd = UB_BIG;
-            uint32_t nj = UB_NONE;
-            if (normal) {
+            float v = UB_BIG;
+            if (dieAt > t) {
                 const float dR = src < 0 ? dr[t] : s_new[src][tid];
-                const float v = ub_average<MODIFIED>(dl[t], dR);
-                s_new[t][tid] = v;
-                a.side[(size_t)t * (size_t)n + j] = v;
-                ub_take(v, j, nd, nj);
+                v = ub_average<MODIFIED>(dl[t], dR);
+                a.side[(size_t)t * ld + p] = v;
             }
-            wave_first_min(nd, nj);
-            if (lane == 0) { s_pd[t][wave] = nd; s_pj[t][wave] = nj; }
+            s_new[t][tid] = v;
         }
     }
     __syncthreads();
-    if (tid < m) {
-        float d = UB_BIG;
-        uint32_t dj = UB_NONE;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) ub_take(s_pd[tid][w], s_pj[tid][w], d, dj);
-        a.part_d[(size_t)tid * nb + b] = d;
-        a.part_j[(size_t)tid * nb + b] = dj;
+    // first minimum of every new row over this workgroup's slots, ties by ROW index (the reference scans the rows in
+    // ascending order): 256 / K threads per merge read its 256 entries back, then a DPP minimum inside the group
+    constexpr int TPM = 256 / K; // 8, 16 or 32 consecutive lanes
+    {
+        const int t = tid / TPM, sub = tid % TPM;
+        float nd = UB_BIG;
+        uint32_t nj = UB_NONE;
+        if (t < m) {
+#pragma unroll 8
+            for (int q = 0; q < K; ++q) ub_take(s_new[t][q * TPM + sub], s_x[q * TPM + sub], nd, nj);
+        }
+        dpp_min_step<DPP_QUAD_1032, 0xF>(nd, nj);
+        dpp_min_step<DPP_QUAD_2301, 0xF>(nd, nj);
+        dpp_min_step<DPP_ROW_HALF_MIRROR, 0xF>(nd, nj); // 8 lanes
+        if (TPM >= 16) dpp_min_step<DPP_ROW_MIRROR, 0xF>(nd, nj);
+        if (TPM >= 32) dpp_min_step<DPP_ROW_BCAST15, 0xA>(nd, nj); // result in the last lane of the group
+        const bool holder = TPM >= 32 ? sub == TPM - 1 : sub == 0;
+        if (t < m && holder) {
+            a.part_d[(size_t)t * nb + b] = nd;
+            a.part_j[(size_t)t * nb + b] = nj;
+        }
     }
+    tm.mark(3); // averages, side stores issued, minima
 }
 
-// ---- launch 2 of a batch ------------------------------------------------------------------------------------------------
+// ---- launch 2 of a batch: ONE workgroup resolves it ---------------------------------------------------------------------
+// What every workgroup of the commit needs but only one has to work out: the new rows' minima (the rows kernel's
+// per-workgroup partials + the K x K cross entries between the clusters the batch creates), the validity prefix V, the
+// merged rows' bookkeeping.  Result record `rec` (words): [0] = V, [8 + 4t ..] = (new min_dist bits, new nearest, die)
+// per merge, [8 + 4K ..] = the cross entries tab[t][u] as floats.
+constexpr int UB_REC0 = 8;
 template <int K, bool MODIFIED>
-__global__ __launch_bounds__(256) void upgma_batch_commit_kernel(UpgmaBatchArgs a, int parity)
+__global__ __launch_bounds__(1024) void upgma_batch_resolve_kernel(UpgmaBatchArgs a, int parity, int grid_rows)
 {
-    __shared__ float s_side[K][2 * K]; // side row u at the columns of the batch's rows: [u][k] = L_k, [u][K + k] = R_k
-    __shared__ float s_tab[K][K];      // cross entries: [t][u] = D[L_t][L_u] right after merge t (u < t)
-    __shared__ float s_rd[256];
-    __shared__ uint32_t s_rj[256];
-    __shared__ float s_pm_d[K];
-    __shared__ uint32_t s_pm_j[K];
-    __shared__ uint32_t s_L[K], s_R[K], s_near[K], s_minbits[K], s_posL[K], s_posR[K];
+    __shared__ float s_side[K][2 * K]; // side row u at the slots of the batch's rows: [u][k] = L_k, [u][K + k] = R_k
+    __shared__ float s_tab[K][K + 1];  // cross entries: [t][u] = D[L_t][L_u] right after merge t (u < t)
+    __shared__ float s_pm_d[K], s_min[K];
+    __shared__ uint32_t s_pm_j[K], s_near[K];
+    __shared__ uint32_t s_L[K], s_R[K], s_slotL[K], s_slotR[K];
     __shared__ int s_src[K], s_die[K];
-    __shared__ int s_V;
-    const int tid = threadIdx.x, b = blockIdx.x, n = a.n, nb = a.n_blocks;
+    const int tid = threadIdx.x, n = a.n, nb = a.n_blocks;
+    const size_t ld = (size_t)a.ld;
     const int lane = tid & 63, wave = tid >> 6;
-    const uint32_t gid = (uint32_t)b * 256 + tid; // row j AND position p of the sorted order
-    const bool in = gid < (uint32_t)n;
+    UbTimer tm(a.dbg, 8);
     const uint32_t* st = a.state + 8 * parity;
     uint32_t* st_next = a.state + 8 * (parity ^ 1);
+    uint32_t* rec = a.rec;
     // ---- level 1 ----
     const uint32_t done = st[0], ns = st[1], err = st[2], cuts = st[3];
     const int m = (int)a.hdr[0];
     const uint32_t walk_err = a.hdr[1];
-    uint32_t mL = UB_NONE, mR = UB_NONE, mKey = 0u, mPosL = UB_NONE, mPosR = UB_NONE;
+    uint32_t mL = UB_NONE, mR = UB_NONE, mKey = 0u, mSlotL = UB_NONE, mSlotR = UB_NONE;
     int mSrc = -1;
     if (lane < K) { // (unconditional: entries beyond m are stale words of an earlier batch, never used)
         const uint32_t* h = a.hdr + UB_HDR0 + UB_HDR_STRIDE * lane;
-        mL = h[0]; mR = h[1]; mKey = h[2]; mSrc = (int)h[3]; mPosL = h[4]; mPosR = h[5];
+        mL = h[0]; mR = h[1]; mKey = h[2]; mSrc = (int)h[3]; mSlotL = h[6]; mSlotR = h[7];
     }
-    const uint32_t my_node = in ? a.node_index[gid] : UB_NONE;
-    const uint32_t my_near = in ? a.nearest[gid] : UB_NONE;
-    const uint2* cur = parity ? a.sorted1 : a.sorted0;
-    uint2* nxt = parity ? a.sorted0 : a.sorted1;
-    uint2 e = make_uint2(0xFFFFFFFFu, UB_NONE), ep = make_uint2(0u, 0u);
-    if (gid < ns) e = cur[gid];
-    if (gid > 0 && gid <= ns) ep = cur[gid - 1];
-    float sv[K];
-#pragma unroll
-    for (int t = 0; t < K; ++t) sv[t] = in ? a.side[(size_t)t * (size_t)n + gid] : 0.0f;
-    // the partial minima of the new rows: 256 / K threads per merge
-    constexpr int TPM = 256 / K;
-    {
-        const int t = tid / TPM, sub = tid % TPM;
+    { // the partial minima of the new rows: 32 lanes per merge, the loads of a lane in flight together
+        const int t = tid >> 5, sub = tid & 31;
         float d = UB_BIG;
         uint32_t dj = UB_NONE;
-        for (int x = sub; x < nb; x += TPM) ub_take(a.part_d[(size_t)t * nb + x], a.part_j[(size_t)t * nb + x], d, dj);
-        s_rd[tid] = d;
-        s_rj[tid] = dj;
+        if (t < K) {
+            const float* pd = a.part_d + (size_t)t * nb;
+            const uint32_t* pj = a.part_j + (size_t)t * nb;
+            for (int x0 = sub; x0 < grid_rows; x0 += 32 * 8) {
+                float vd[8];
+                uint32_t vj[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int xx = x0 + 32 * q;
+                    vd[q] = xx < grid_rows ? pd[xx] : UB_BIG;
+                    vj[q] = xx < grid_rows ? pj[xx] : UB_NONE;
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) ub_take(vd[q], vj[q], d, dj); // (ascending x: any order gives the same first minimum)
+            }
+        }
+        dpp_min_step<DPP_QUAD_1032, 0xF>(d, dj);
+        dpp_min_step<DPP_QUAD_2301, 0xF>(d, dj);
+        dpp_min_step<DPP_ROW_HALF_MIRROR, 0xF>(d, dj);
+        dpp_min_step<DPP_ROW_MIRROR, 0xF>(d, dj);
+        dpp_min_step<DPP_ROW_BCAST15, 0xA>(d, dj);
+        if (t < K && sub == 31) { s_pm_d[t] = d; s_pm_j[t] = dj; }
     }
+    tm.mark(0); // level 1 + the partial minima
     if (m == 0 || err) { // nothing pending (finished, or an error): the state moves on unchanged
-        if (b == 0 && tid == 0) {
+        if (tid == 0) {
             st_next[0] = done; st_next[1] = ns; st_next[2] = err | walk_err; st_next[3] = cuts;
+            rec[0] = 0u;
         }
         return;
     }
     if (tid < K) {
-        s_L[tid] = mL; s_R[tid] = mR; s_src[tid] = mSrc; s_posL[tid] = mPosL; s_posR[tid] = mPosR;
+        s_L[tid] = mL; s_R[tid] = mR; s_src[tid] = mSrc; s_slotL[tid] = mSlotL; s_slotR[tid] = mSlotR;
     }
     __syncthreads();
-    // ---- level 2: side rows at the batch's own columns; the nodes of the merged rows ----
-    for (int idx = tid; idx < K * 2 * K; idx += 256) {
+    // ---- level 2: side rows at the batch's own slots; the nodes of the merged rows ----
+    for (int idx = tid; idx < K * 2 * K; idx += 1024) {
         const int u = idx / (2 * K), k = idx % (2 * K);
         const int t = k < K ? k : k - K;
         float v = 0.0f;
         if (u < m && t < m) {
-            const uint32_t x = k < K ? s_L[t] : s_R[t];
-            v = a.side[(size_t)u * (size_t)n + x];
+            const uint32_t slot = k < K ? s_slotL[t] : s_slotR[t];
+            if (slot != UB_NONE) v = a.side[(size_t)u * ld + slot];
         }
         s_side[u][k] = v;
     }
     uint32_t nodeL = UB_NONE, nodeR = UB_NONE;
-    if (b == 0 && wave == 0 && lane < m) {
-        nodeL = a.node_index[mL];
-        nodeR = mSrc < 0 ? a.node_index[mR] : UB_NONE;
-    }
-    if (tid < K) {
-        float d = UB_BIG;
-        uint32_t dj = UB_NONE;
-        for (int s = 0; s < TPM; ++s) ub_take(s_rd[tid * TPM + s], s_rj[tid * TPM + s], d, dj);
-        s_pm_d[tid] = d;
-        s_pm_j[tid] = dj;
-    }
-    __syncthreads();
-    // ---- the cross entries, the new rows' minima, the validity prefix: wave 0 ----
+    int die = UB_INF; // the merge at which the row created by merge `lane` dies again (it is a later merge's R), or INF
     if (wave == 0) {
-        // die[u]: the merge at which the row created by merge u dies again (it is some later merge's R), or INF
-        int die = UB_INF;
+        if (lane < m) {
+            nodeL = a.node_index[mL];
+            nodeR = mSrc < 0 ? a.node_index[mR] : UB_NONE;
+        }
         for (int w = 0; w < m; ++w) {
             const uint32_t Rw = lane_u32(mR, w);
             if (lane < w && lane < m && mL == Rw && die == UB_INF) die = w;
         }
-        float newmin = UB_BIG;
-        uint32_t newnear = UB_NONE;
-        for (int t = 0; t < m; ++t) {
-            const int src_t = lane_i32(mSrc, t);
-            float cd = UB_BIG;
-            uint32_t cj = UB_NONE;
-            if (lane < t && die > t) { // column L_lane is alive at merge t: a cross entry
+        if (lane < K) s_die[lane] = die;
+    }
+    __syncthreads();
+    tm.mark(1); // level 2
+    // ---- the cross entries: D[L_t][L_u] for the clusters the batch creates ----
+    // A merge whose partner is an old row needs nothing of the table: all those entries at once, one per thread.  A
+    // merge whose partner was created in the batch reads the table: those go in merge order (wave 0, lane = u).
+    for (int idx = tid; idx < K * K; idx += 1024) {
+        const int t = idx / K, u = idx % K;
+        if (t < m && u < t && s_die[u] > t && s_src[t] < 0) s_tab[t][u] = ub_average<MODIFIED>(s_side[u][t], s_side[u][K + t]);
+    }
+    __syncthreads();
+    if (wave == 0) {
+        for (int t = 1; t < m; ++t) {
+            const int src_t = s_src[t];
+            if (src_t < 0) continue;
+            if (lane < t && die > t) { // the cluster of merge `lane` is alive at merge t
                 const int u = lane;
-                const float a1 = s_side[u][t]; // D[L_t][L_u] before merge t: row L_u (made by merge u) at column L_t
-                float a2;
-                if (src_t < 0) a2 = s_side[u][K + t];
-                else a2 = src_t > u ? s_tab[src_t][u] : s_tab[u][src_t];
-                const float v = ub_average<MODIFIED>(a1, a2);
-                s_tab[t][u] = v;
-                ub_take(v, mL, cd, cj);
+                const float a1 = s_side[u][t]; // D[L_t][L_u] before merge t: the row made by merge u at L_t's slot
+                const float a2 = src_t > u ? s_tab[src_t][u] : s_tab[u][src_t];
+                s_tab[t][u] = ub_average<MODIFIED>(a1, a2);
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            wave_first_min(cd, cj);
-            float d = s_pm_d[t];
-            uint32_t dj = s_pm_j[t];
-            ub_take(cd, cj, d, dj); // (first minimum: smaller value, then smaller column)
-            if (d >= UB_BIG) { d = UB_BIG; dj = UB_NONE; }
-            if (lane == t) { newmin = d; newnear = dj; }
         }
+    }
+    __syncthreads();
+    // ---- the new rows' minima: 32 lanes per merge over (partials, cross entries), ties by row ----
+    {
+        const int t = tid >> 5, u = tid & 31;
+        float d = UB_BIG;
+        uint32_t dj = UB_NONE;
+        if (t < m && u < t && s_die[u] > t) ub_take(s_tab[t][u], s_L[u], d, dj);
+        if (t < m && u == 31) ub_take(s_pm_d[t], s_pm_j[t], d, dj);
+        dpp_min_step<DPP_QUAD_1032, 0xF>(d, dj);
+        dpp_min_step<DPP_QUAD_2301, 0xF>(d, dj);
+        dpp_min_step<DPP_ROW_HALF_MIRROR, 0xF>(d, dj);
+        dpp_min_step<DPP_ROW_MIRROR, 0xF>(d, dj);
+        dpp_min_step<DPP_ROW_BCAST15, 0xA>(d, dj);
+        if (t < K && u == 31) {
+            if (d >= UB_BIG) { d = UB_BIG; dj = UB_NONE; }
+            s_min[t] = d;
+            s_near[t] = dj;
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        const float newmin = lane < K ? s_min[lane] : UB_BIG;
+        uint32_t newnear = lane < K ? s_near[lane] : UB_NONE;
         // merge t stands iff the reference would have picked L_t: its key beats every row created before it in the
         // batch that is still alive at that point
         bool ok = true;
-        for (int s = 0; s < m; ++s) {
-            const float ms = __uint_as_float(lane_u32(__float_as_uint(newmin), s));
-            const uint32_t Ls = lane_u32(mL, s);
-            const int ds = lane_i32(die, s);
-            if (s < lane && ds >= lane) { // (alive when merge `lane` is picked -- also as that merge's own partner)
+        for (int s2 = 0; s2 < m; ++s2) {
+            const float ms = __uint_as_float(lane_u32(__float_as_uint(newmin), s2));
+            const uint32_t Ls = lane_u32(mL, s2);
+            const int ds = lane_i32(die, s2);
+            if (s2 < lane && ds >= lane) { // (alive when merge `lane` is picked -- also as that merge's own partner)
                 const float mk = __uint_as_float(mKey);
                 if (!(mk < ms || (mk == ms && mL < Ls))) ok = false;
             }
@@ -345,86 +420,157 @@ __global__ __launch_bounds__(256) void upgma_batch_commit_kernel(UpgmaBatchArgs 
             if (w > lane && newnear == Rw) newnear = Lw;
         }
         if (lane < K) {
-            s_near[lane] = newnear;
-            s_minbits[lane] = __float_as_uint(newmin);
-            s_die[lane] = die;
+            rec[UB_REC0 + 4 * lane + 0] = __float_as_uint(newmin);
+            rec[UB_REC0 + 4 * lane + 1] = newnear;
+            rec[UB_REC0 + 4 * lane + 2] = (uint32_t)die;
         }
-        if (lane == 0) s_V = V;
-        if (b == 0 && lane < V) { // the merged rows' bookkeeping (UPGMA.cpp:268-287)
+        if (lane == 0) rec[0] = (uint32_t)V;
+        if (lane < V) { // the merged rows' bookkeeping (UPGMA.cpp:268-287) and their slots
             a.left[done + lane] = (int32_t)nodeL;
             a.right[done + lane] = (int32_t)(mSrc < 0 ? nodeR : (uint32_t)n + done + (uint32_t)mSrc);
             const bool dies = die < V;
-            a.node_index[mL] = dies ? UB_NONE : (uint32_t)n + done + (uint32_t)lane;
+            const uint32_t new_slot = (uint32_t)n + done + (uint32_t)lane;
+            a.node_index[mL] = dies ? UB_NONE : new_slot; // (node id of the k-th cluster = n + k = its slot)
             if (mSrc < 0) a.node_index[mR] = UB_NONE;
+            a.row_of[mSlotL] = UB_NONE;
+            if (mSrc < 0) a.row_of[mSlotR] = UB_NONE;
+            a.row_of[new_slot] = dies ? UB_NONE : mL;
             if (!dies) {
+                a.slot_of[mL] = new_slot;
                 a.min_dist[mL] = newmin;
                 a.nearest[mL] = newnear;
             }
         }
-        if (b == 0 && lane == 0) {
+        if (lane == 0) {
             st_next[0] = done + (uint32_t)V;
             st_next[1] = ns - (uint32_t)V;
             st_next[2] = err | walk_err;
             st_next[3] = cuts + (V < m ? 1u : 0u);
         }
     }
-    __syncthreads();
-    const int V = s_V;
-    // ---- commit my row / column ----
-    int createAt = UB_INF, dieAt = UB_INF;
-    for (int t = 0; t < V; ++t) {
-        if (s_L[t] == gid) createAt = t;
-        if (s_R[t] == gid && dieAt == UB_INF) dieAt = t;
+    // the cross entries for the commit (only the pairs it will write are read there)
+    for (int idx = tid; idx < K * K; idx += 1024) rec[UB_REC0 + 4 * K + idx] = __float_as_uint(s_tab[idx / K][idx % K]);
+    tm.mark(2); // cross entries, minima, validity, bookkeeping
+}
+
+// ---- launch 3 of a batch: the commit ----------------------------------------------------------------------------------
+// (the bookkeeping of the merged rows -- node_index, row_of, slot_of, min_dist, nearest -- has been written by the resolve
+//  kernel: a slot whose row took part in a standing merge already reads row_of = NONE here, the new clusters' slots
+//  read their rows)
+template <int K, bool MODIFIED>
+__global__ __launch_bounds__(256) void upgma_batch_commit_kernel(UpgmaBatchArgs a, int parity)
+{
+    __shared__ float s_sv[K][256 + 1]; // the side values of my 256 slots, to be written out row by row
+    __shared__ uint32_t s_xrow[256];   // the row of each of those slots, NONE where nothing is written
+    const int tid = threadIdx.x, b = blockIdx.x, n = a.n;
+    const size_t ld = (size_t)a.ld;
+    const int lane = tid & 63, wave = tid >> 6;
+    const uint32_t gid = (uint32_t)b * 256 + tid; // slot p, row j AND position of the sorted order
+    UbTimer tm(a.dbg, 12);
+    const uint32_t* st = a.state + 8 * parity;
+    const uint32_t* rec = a.rec;
+    // ---- level 1: lane t of every wave holds merge t's record ----
+    const uint32_t done = st[0], ns = st[1];
+    const int V = (int)rec[0];
+    uint32_t mL = UB_NONE, mR = UB_NONE, mPosL = UB_NONE, mPosR = UB_NONE, mMinBits = 0u, mNear = UB_NONE;
+    int mDie = UB_INF;
+    if (lane < K) {
+        const uint32_t* h = a.hdr + UB_HDR0 + UB_HDR_STRIDE * lane;
+        mL = h[0]; mR = h[1]; mPosL = h[4]; mPosR = h[5];
+        mMinBits = rec[UB_REC0 + 4 * lane + 0];
+        mNear = rec[UB_REC0 + 4 * lane + 1];
+        mDie = (int)rec[UB_REC0 + 4 * lane + 2];
     }
-    const bool alive0 = in && my_node != UB_NONE;
-    if (alive0 && createAt == UB_INF && dieAt == UB_INF) { // a row the batch only passes through
+    const bool is_row = gid < (uint32_t)n, is_slot = gid < (uint32_t)a.ld;
+    const uint32_t my_node = is_row ? a.node_index[gid] : UB_NONE;
+    const uint32_t my_near = is_row ? a.nearest[gid] : UB_NONE;
+    const uint32_t x = is_slot ? a.row_of[gid] : UB_NONE; // the row of my slot
+    const uint2* cur = parity ? a.sorted1 : a.sorted0;
+    uint2* nxt = parity ? a.sorted0 : a.sorted1;
+    uint2 e = make_uint2(0xFFFFFFFFu, UB_NONE), ep = make_uint2(0u, 0u);
+    if (gid < ns) e = cur[gid];
+    if (gid > 0 && gid <= ns) ep = cur[gid - 1];
+    float sv[K];
 #pragma unroll
-        for (int t = 0; t < K; ++t) {
-            if (t < V) {
-                const uint32_t Lt = s_L[t];
-                a.D[(size_t)Lt * (size_t)n + gid] = sv[t];
-                a.D[(size_t)gid * (size_t)n + Lt] = sv[t]; // the mirror
-            }
-        }
-        uint32_t near = my_near;
-        for (int t = 0; t < V; ++t)
-            if (near == s_R[t]) near = s_L[t];
-        if (near != my_near) a.nearest[gid] = near;
-    }
-    // (rows that take part in a standing merge: their entries towards earlier merges' rows are superseded by the cross
-    //  entries or belong to a dead row; what they keep is written below / by workgroup 0 above)
-    if (b == 0) {
-        for (int idx = tid; idx < K * K; idx += 256) {
-            const int t = idx / K, u = idx % K;
-            if (u < t && t < V && s_die[u] > t) {
-                const float v = s_tab[t][u];
-                a.D[(size_t)s_L[t] * (size_t)n + s_L[u]] = v;
-                a.D[(size_t)s_L[u] * (size_t)n + s_L[t]] = v;
-            }
-        }
-    }
-    // ---- the sorted order of the next batch: position gid of the current one (gid == ns: the place behind the end) ----
-    if (gid <= ns) {
-        bool removed = gid == ns;
-        uint32_t before = 0; // entries in front of me that leave
-        for (int t = 0; t < V; ++t) {
-            const uint32_t pl = s_posL[t], pr = s_posR[t];
+    for (int t = 0; t < K; ++t) sv[t] = is_slot ? a.side[(size_t)t * ld + gid] : 0.0f;
+    if (V == 0) return; // nothing stands (finished, or an error)
+    tm.mark(0); // level 1
+    // ---- commit my slot: the entries of the V new clusters towards my row ----
+    bool passes = x != UB_NONE; // my row only passes through the batch (it is in no standing merge)
+    bool mine = is_row && my_node != UB_NONE;
+    uint32_t near = my_near;
+    bool removed = gid == ns;
+    uint32_t before = 0; // entries of the order in front of position gid that leave
+#pragma unroll
+    for (int t = 0; t < K; ++t) {
+        if (t < V) {
+            const uint32_t Lt = lane_u32(mL, t), Rt = lane_u32(mR, t), pl = lane_u32(mPosL, t), pr = lane_u32(mPosR, t);
+            passes = passes && Lt != x && Rt != x;
+            mine = mine && Lt != gid && Rt != gid;
+            if (near == Rt) near = Lt; // the renames of the batch, in merge order
             removed = removed || pl == gid || pr == gid;
             before += (pl < gid ? 1u : 0u) + (pr != UB_NONE && pr < gid ? 1u : 0u);
         }
+    }
+    // (only now is `passes` final: the slot of a NEW cluster reads its row from row_of -- the resolve kernel has set it --
+    //  and must not write: what the clusters hold towards each other are the cross entries below)
+#pragma unroll
+    for (int t = 0; t < K; ++t) {
+        if (t < V) {
+            if (passes) a.D[(size_t)lane_u32(mL, t) * ld + gid] = sv[t]; // the cluster's own row (it keeps its left child's), along the slots
+            s_sv[t][tid] = sv[t];
+        }
+    }
+    s_xrow[tid] = passes ? x : UB_NONE;
+    __syncthreads();
+    {   // my row at the new clusters' slots: V consecutive floats per row -- K lanes write one row's run together
+        constexpr int RPI = 64 / K; // rows per store instruction of a wave
+        const int tt = lane % K, sub = lane / K;
+        const size_t first = (size_t)n + done;
+#pragma unroll 4
+        for (int q = 0; q < 64 / RPI; ++q) {
+            const int r = wave * 64 + q * RPI + sub;
+            const uint32_t xr = s_xrow[r];
+            if (xr != UB_NONE && tt < V) a.D[(size_t)xr * ld + first + tt] = s_sv[tt][r];
+        }
+    }
+    // (slots of rows that take part in a standing merge are dead from here on; what the new clusters hold towards each
+    //  other are the cross entries)
+    if (b == 0) {
+        for (int idx = tid; idx < K * K; idx += 256) {
+            const int t = idx / K, u = idx % K;
+            if (u < t && t < V && (int)rec[UB_REC0 + 4 * u + 2] > t) {
+                const float v = __uint_as_float(rec[UB_REC0 + 4 * K + idx]);
+                const uint32_t Lt = a.hdr[UB_HDR0 + UB_HDR_STRIDE * t], Lu = a.hdr[UB_HDR0 + UB_HDR_STRIDE * u];
+                a.D[(size_t)Lt * ld + ((size_t)n + done + u)] = v;
+                a.D[(size_t)Lu * ld + ((size_t)n + done + t)] = v;
+            }
+        }
+    }
+    tm.mark(1); // commit stores issued
+    // ---- my row's nearest under the renames of the batch ----
+    if (mine && near != my_near) a.nearest[gid] = near;
+    // ---- the sorted order of the next batch: position gid of the current one (gid == ns: the place behind the end) ----
+    if (gid <= ns) {
         uint32_t ins_before = 0;
-        for (int s = 0; s < V; ++s) { // rows the batch created and that are still alive: they enter at their new keys
-            if (s_die[s] < V) continue;
-            const uint32_t kb = s_minbits[s], row = s_L[s];
-            if (ub_less(kb, row, e.x, e.y)) { // in front of me (my slot e is +inf at gid == ns)
-                ++ins_before;
-                if (gid == 0 || !ub_less(kb, row, ep.x, ep.y)) { // ... and not in front of my predecessor: I place it
-                    uint32_t at = gid - before;
-                    for (int s2 = 0; s2 < V; ++s2)
-                        if (s2 != s && s_die[s2] >= V && ub_less(s_minbits[s2], s_L[s2], kb, row)) ++at;
-                    nxt[at] = make_uint2(kb, row);
-                    a.pos[row] = at;
-                    if (at < (uint32_t)UPGMA_BATCH_CAND) a.cand[at] = make_uint4(kb, row, s_near[s], 0u);
+#pragma unroll
+        for (int s2 = 0; s2 < K; ++s2) { // rows the batch created and that are still alive: they enter at their new keys
+            if (s2 < V) {
+                const int die = lane_i32(mDie, s2);
+                const uint32_t kb = lane_u32(mMinBits, s2), row = lane_u32(mL, s2);
+                if (die >= V && ub_less(kb, row, e.x, e.y)) { // in front of me (my slot e is +inf at gid == ns)
+                    ++ins_before;
+                    if (gid == 0 || !ub_less(kb, row, ep.x, ep.y)) { // ... and not in front of my predecessor: I place it
+                        uint32_t at = gid - before;
+                        for (int s3 = 0; s3 < V; ++s3) {
+                            const int die3 = lane_i32(mDie, s3); // (readlane: also from lanes that are not in this branch)
+                            const uint32_t kb3 = lane_u32(mMinBits, s3), row3 = lane_u32(mL, s3);
+                            if (s3 != s2 && die3 >= V && ub_less(kb3, row3, kb, row)) ++at;
+                        }
+                        nxt[at] = make_uint2(kb, row);
+                        a.pos[row] = at;
+                        if (at < (uint32_t)UPGMA_BATCH_CAND) a.cand[at] = make_uint4(kb, row, lane_u32(mNear, s2), 0u);
+                    }
                 }
             }
         }
@@ -433,13 +579,16 @@ __global__ __launch_bounds__(256) void upgma_batch_commit_kernel(UpgmaBatchArgs 
             nxt[at] = e;
             a.pos[e.y] = at;
             if (at < (uint32_t)UPGMA_BATCH_CAND) {
-                uint32_t near = a.nearest[e.y]; // (a row the batch only passed through: its stored nearest is the old one)
-                for (int t = 0; t < V; ++t)
-                    if (near == s_R[t]) near = s_L[t];
-                a.cand[at] = make_uint4(e.x, e.y, near, 0u);
+                uint32_t nr = a.nearest[e.y]; // (a row the batch only passed through: its stored nearest is the old one)
+                for (int t = 0; t < V; ++t) {
+                    const uint32_t Rt = lane_u32(mR, t), Lt = lane_u32(mL, t);
+                    if (nr == Rt) nr = Lt;
+                }
+                a.cand[at] = make_uint4(e.x, e.y, nr, 0u);
             }
         }
     }
+    tm.mark(2); // renames + the sorted order
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------------------
@@ -449,19 +598,25 @@ hipError_t launch_upgma_batch_init(const UpgmaBatchArgs& a, hipStream_t stream)
     return hipGetLastError();
 }
 
-// `count` batches (two launches each), the first of them batch number `first` (its parity selects the state buffers)
+// `count` batches (three launches each), the first of them batch number `first` (its parity selects the state buffers).
+// Batch i can have committed at most i * k merges before it, so its launches cover the slots [0, n + min(i * k, n - 1)).
 hipError_t launch_upgma_batches(const UpgmaBatchArgs& a, bool modified, int k, int first, int count, hipStream_t stream)
 {
-    const dim3 grid_rows(a.n_blocks), grid_commit((unsigned)(a.n / 256 + 1)), block(256);
+    const dim3 block(256);
     for (int i = first; i < first + count; ++i) {
         const int parity = i & 1;
+        const long long slots = (long long)a.n + std::min<long long>((long long)i * k, a.n - 1);
+        const int g = (int)std::min<long long>((slots + 255) / 256, a.n_blocks);
+        const dim3 grid_rows((unsigned)g), grid_commit((unsigned)std::max<long long>(g, a.n / 256 + 1));
 #define UB_LAUNCH(KK)                                                                                                     \
     do {                                                                                                                  \
         if (modified) {                                                                                                   \
             hipLaunchKernelGGL((upgma_batch_rows_kernel<KK, true>), grid_rows, block, 0, stream, a, parity);              \
+            hipLaunchKernelGGL((upgma_batch_resolve_kernel<KK, true>), dim3(1), dim3(1024), 0, stream, a, parity, g);     \
             hipLaunchKernelGGL((upgma_batch_commit_kernel<KK, true>), grid_commit, block, 0, stream, a, parity);          \
         } else {                                                                                                          \
             hipLaunchKernelGGL((upgma_batch_rows_kernel<KK, false>), grid_rows, block, 0, stream, a, parity);             \
+            hipLaunchKernelGGL((upgma_batch_resolve_kernel<KK, false>), dim3(1), dim3(1024), 0, stream, a, parity, g);    \
             hipLaunchKernelGGL((upgma_batch_commit_kernel<KK, false>), grid_commit, block, 0, stream, a, parity);         \
         }                                                                                                                 \
     } while (0)
