@@ -16,19 +16,21 @@
 //     Only the columns of rows created IN the batch see each other (K x K "cross" entries): those are left to the
 //     commit kernel, which has every column's result in front of it.
 // A batch is three launches:
-//   upgma_batch_rows_kernel    every workgroup walks the first entries of the sorted order (one wave, DPP / ballots:
-//                              no LDS, no barrier) to the batch's <= K merges (L_t, R_t), then thread j computes
-//                              column j of every merge from the COMMITTED matrix (all row loads issued at once)
-//                              into side rows [K][n], with per-workgroup first minima of every new row.  Nothing
+//   upgma_batch_rows_kernel    every workgroup walks the first entries of the sorted order (one wave, readlanes / ballots:
+//                              no LDS, no barrier) to the batch's <= K merges (L_t, R_t), then thread p computes slot
+//                              p's entry of every merge from the COMMITTED matrix (all row loads issued at once)
+//                              into side rows [K][slots], with per-workgroup first minima of every new row.  Nothing
 //                              of the committed state is written.
-//   upgma_batch_commit_kernel  every workgroup: the new rows' minima (partials + cross entries), the validity
-//                              prefix V -- merge t stands iff (key_t, L_t) < (new minimum, row) of every row
-//                              created before it in the batch and still alive: exactly "the reference would have
-//                              picked L_t" -- then for t < V: rows and mirror columns of the symmetric matrix from
-//                              the side rows, the cross entries, nearest renames, min_dist / nearest / node_index
-//                              of the merged rows, left / right; and the sorted order rewritten (entries of
-//                              merged rows out, the new rows in at their keys, every entry one coalesced copy),
-//                              with the first 2K entries and their nearest as the next batch's candidates.
+//   upgma_batch_resolve_kernel ONE workgroup: the new rows' minima (partials + the cross entries between the batch's
+//                              own clusters), the validity prefix V -- merge t stands iff (key_t, L_t) < (new minimum,
+//                              row) of every row created before it in the batch and still alive: exactly "the
+//                              reference would have picked L_t" -- and for t < V the merged rows' bookkeeping
+//                              (left / right, node_index, min_dist, nearest, slots).  What it finds goes into a
+//                              record every workgroup of the commit reads.
+//   upgma_batch_commit_kernel  for t < V: the clusters' rows along the slots and every surviving row's run of V new
+//                              entries from the side rows, the cross entries, nearest renames; and the sorted order
+//                              rewritten (entries of merged rows out, the new rows in at their keys, every entry one
+//                              coalesced copy), with its first 64 entries and their nearest as the next batch's candidates.
 // Merges t >= V are dropped (their side rows are never committed) and the next batch starts from the committed state,
 // so the sequence of merges, every float operation and every tie rule are the reference's, whatever V is.
 //
