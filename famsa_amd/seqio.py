@@ -119,3 +119,23 @@ def family_fasta(n, length, path, seed=1234):
                 out.write(A[S[i, : lens[i]]].tobytes())
                 out.write(b"\n")
     return path
+
+
+REALMIX_PARTS = [("af", "adeno_fiber/adeno_fiber"), ("hp", "hemopexin/hemopexin"), ("afd", "adeno_fiber_duplicates/adeno_fiber_duplicates"),
+                 ("hpd", "hemopexin_duplicates/hemopexin_duplicates"), ("afx", "adeno_fiber_extra/adeno_fiber_extra")]
+
+
+def realmix_fasta(golden_dir, path):
+    """One FASTA from the upstream REAL sets held as fixtures under tests/golden (the reference's test/ directory):
+    adeno_fiber + hemopexin + both duplicates sets + adeno_fiber_extra (non-standard residue symbols J, U) = 13 774
+    records, 21-210 residues, exact duplicates (x2 / x3) and heavy distance ties included -- the short, ragged,
+    tie-heavy regime no synthetic set has.  Ids get a per-set prefix so that every record name is unique; the record
+    order is the files' order, the sets one after the other.  Returns the number of records."""
+    n = 0
+    with open(path, "w") as out:
+        for tag, rel in REALMIX_PARTS:
+            ids, seqs = read_fasta(golden_dir + "/" + rel)
+            for i, (name, res) in enumerate(zip(ids, seqs)):
+                out.write(f">{tag}{i}|{name[1:]}\n{res}\n")
+                n += 1
+    return n

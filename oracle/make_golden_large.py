@@ -4,7 +4,7 @@
 only; minutes of CPU.  Writes tests/golden/meta_large.json (sha256 values only -- the data is
 regenerated deterministically by famsa_amd/seqio.py on the GPU box).
 
-    python oracle/make_golden_large.py [c3] [c4] [c5] [c5huge] [c4upgma]      (default: c3 c5 c4)
+    python oracle/make_golden_large.py [c3] [c4] [c5] [c5huge] [c4upgma] [realmix]      (default: c3 c5 c4)
 
 c5huge = the 3 000 000-sequence family set (BASELINE config C5's size); c4upgma = -gt upgma / upgma_modified at
 100 000 x 400 aa (the reference holds the 20 GB float triangle in host memory).
@@ -118,13 +118,48 @@ def c5(ref, meta, sizes=(200000, 1000000)):
         save(meta)
 
 
+def realmix(ref, meta):
+    """The upstream real sets in one FASTA (famsa_amd/seqio.py: realmix_fasta; 13 774 records): every tree method with
+    and without duplicate removal, the medoid heuristic, the distance export -- the reference's own runs."""
+    path = "/tmp/golden_realmix.fasta"
+    n = seqio.realmix_fasta(oracle_bind.GOLDEN, path)
+    rec = {"n": n, "fasta_sha256": sha(open(path, "rb").read())}
+    h = ref.open_fasta(path)
+    for gt in ("sl", "slink", "upgma", "upgma_modified", "nj"):
+        for keep in (0, 1):
+            if gt == "nj" and keep:
+                continue  # (O(n^3) on one thread in the reference: hours at 13 774)
+            t0 = time.time()
+            rec[f"{gt}{'_keepdups' if keep else ''}_newick_sha256"] = sha(ref.tree(h, gt, keep_dups=keep, threads=THREADS))
+            print("realmix", gt, keep, "%.0f s" % (time.time() - t0), flush=True)
+    for gt in ("sl", "upgma"):
+        t0 = time.time()
+        rec[f"medoid_{gt}_newick_sha256"] = sha(ref.tree(h, gt, heuristic=2, threads=THREADS))
+        rec[f"medoid_{gt}_keepdups_newick_sha256"] = sha(ref.tree(h, gt, heuristic=2, keep_dups=1, threads=THREADS))
+        print("realmix medoid", gt, "%.0f s" % (time.time() - t0), flush=True)
+    out = "/tmp/golden_realmix_dist.csv"
+    t0 = time.time()
+    ref.dist_export(h, out, threads=THREADS)
+    hh = hashlib.sha256()
+    with open(out, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 24), b""):
+            hh.update(blk)
+    rec["dist_export_sha256"] = hh.hexdigest()
+    rec["dist_export_bytes"] = os.path.getsize(out)
+    os.unlink(out)
+    print("realmix dist_export %.0f s" % (time.time() - t0), flush=True)
+    ref.close(h)
+    meta["realmix"] = rec
+    save(meta)
+
+
 def main():
     which = sys.argv[1:] or ["c3", "c5", "c4"]
     ref = oracle_bind.Ref()
     meta = load()
     for w in which:
         {"c3": c3, "c3more": c3more, "c4": c4, "c5": c5, "c5huge": lambda r, m: c5(r, m, (3000000,)),
-         "c4upgma": lambda r, m: c4(r, m, ("upgma", "upgma_modified"))}[w](ref, meta)
+         "c4upgma": lambda r, m: c4(r, m, ("upgma", "upgma_modified")), "realmix": realmix}[w](ref, meta)
     print(json.dumps(load(), indent=1))
 
 
