@@ -65,7 +65,8 @@ __device__ __forceinline__ void wave_first_min_valid(float& v, int& i)
 
 enum { ST_P = 0, ST_DONE = 1, ST_LOG_LEN = 2, ST_ROUNDS = 3, ST_ARRIVE = 4, ST_COST = 5, ST_ERR = 6, ST_WIN = 7,
        ST_OFF = 8, ST_STAGE = 9, ST_FIRST = 10,
-       ST_N_ROUNDS = 11, ST_N_STEPS = 12, ST_N_USEFUL = 13 }; // statistics of the search (LCSGPU_PROFILE): rounds, steps evaluated, steps up to the accepted one
+       ST_N_ROUNDS = 11, ST_N_STEPS = 12, ST_N_USEFUL = 13,
+       ST_N_COMMON = 14, ST_N_GENERAL = 15 }; // list evaluations: entries that add to every other slot (summed over the steps), steps that took the general walk // statistics of the search (LCSGPU_PROFILE): rounds, steps evaluated, steps up to the accepted one
 
 // A window of pending steps is evaluated in stages of 16, 32, 64, 64, ... steps (ClaransArgs::stage0 = 16,
 // LCSGPU_CLARANS_STAGE0): the steps after the accepted one are wasted work that other searches running at
@@ -146,6 +147,8 @@ __global__ __launch_bounds__(256) void clarans_init_kernel(ClaransArgs a)
         a.state[ST_N_ROUNDS] = 0;
         a.state[ST_N_STEPS] = 0;
         a.state[ST_N_USEFUL] = 0;
+        a.state[ST_N_COMMON] = 0;
+        a.state[ST_N_GENERAL] = 0;
         if (p + W > a.draws_len) a.state[ST_ERR] = 1;
     }
     if (p + W <= a.draws_len)
@@ -375,6 +378,276 @@ __device__ __forceinline__ void evaluate_step(const ClaransArgs& a, int xx, int 
     elap(4);
 }
 
+// ---- the same evaluation with PER-SLOT LISTS (round 4) ------------------------------------------------------------------
+// evaluate_step's walk hands every entry to all 64 lanes of the wave that owns its slot -- a broadcast read of 16 B by 64
+// lanes per entry and wave, 1 KB through the CU's LDS return port: 10.6 of an evaluation's 18 us, and what two or three
+// evaluations resident on one CU fight over.  But a slot's delta only ever adds (a) the entries of ITS
+// members, and (b) the few entries whose member is closer to the candidate than to its own medoid (they add to every
+// other slot).  So: sort the entries by slot, stably (= by position inside a slot), once per evaluation, and let lane m
+// walk slot m's own run -- every lane reads a DIFFERENT 8 bytes per step -- merging in the short list (b) by position.
+// The additions each slot sees are the same, in the same order; only who reads what has changed.
+//   1. entries in position order, 4 per thread (as before); list (b) is compacted in position order (ballots);
+//   2. per 64-position chunk (one wave, four chunks each) every lane finds its rank among the lanes holding the same
+//      slot -- a ballot per slot bit, nothing moves -- and the last lane of each slot leaves the count in LDS;
+//   3. per slot: prefix of the counts over the 32 chunks (chunk order = position order), prefix of the totals over the
+//      slots = where each slot's run starts; every lane scatters its (addend, position) to its place;
+//   4. lane l < 32 of wave w walks slot 8 l + w (k <= 256).
+// Shapes outside (more than 2048 non-medoids, more than 256 medoids, more than 256 entries in list (b)) take
+// evaluate_step.  Returns false when the caller has to do that.
+// MEASURED (round 4, 2000 members / 100 medoids, profiles/clarans_lists_r04.txt): bit-identical on all 23 shapes and the
+// 3 x 10^6-sequence tree, an evaluation's phases sum to 15 us on average (loads 1.4, ranks 1.7, prefixes + scatter 1.4,
+// walks 5.1, waiting for the slowest wave 5.6 -- the largest cluster's chain) against 17.7 us for the broadcast walk --
+// and the KERNEL takes 33.7 us against 19.9 us: a launch lasts as long as its slowest step, and a step whose candidate is
+// closer to many members than their medoids pays per entry of list (b) in every lane, where the broadcast walk pays one
+// more entry per wave.  So this stays opt-in (LCSGPU_CLARANS_LISTS=1); the default is evaluate_step.
+constexpr int LISTS_MAX_S = 2048, LISTS_MAX_K = 256, LISTS_MAX_COMMON = 256;
+// measurement aid (LCSGPU_CLARANS_LISTS=2): 10 ns ticks per phase of evaluate_step_lists, summed over the evaluations
+// of workgroup 0's thread 0, and their count at [7]
+__device__ unsigned long long g_lists_ticks[8];
+template <bool TIMED>
+__device__ __forceinline__ bool evaluate_step_lists(const ClaransArgs& a, int xx, int x, const int* y_pre, const float4* s_pre,
+                                                    float4* s_e, float4 (*s_we)[128], uint32_t* s_misc, float& best_out, int& bk_out,
+                                                    unsigned long long* t_ev)
+{
+    unsigned long long te0 = TIMED ? wall_clock64() : 0;
+    auto elap = [&](int ph) {
+        if (TIMED) {
+            const unsigned long long t1 = wall_clock64();
+            t_ev[ph] += t1 - te0;
+            te0 = t1;
+        }
+    };
+    constexpr int PER = 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int k = a.n_medoids, n = a.n_elems;
+    const int S = n - k;
+    const uint64_t lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
+    // LDS: s_e (16 KB) = the sorted (addend, position) pairs; s_we (16 KB) = counts per (chunk, slot) as uint16;
+    // s_misc (4 KB) = run starts [k + 1], list (b): positions, slots, values [256 each], its per-chunk counts [32]
+    float2* s_ent = reinterpret_cast<float2*>(s_e);
+    uint16_t* s_cnt = reinterpret_cast<uint16_t*>(&s_we[0][0]); // [32][k]
+    uint32_t* s_start = s_misc;                                     // [257]
+    uint16_t* s_cpos = reinterpret_cast<uint16_t*>(s_misc + 260);   // [256]
+    uint16_t* s_cslot = s_cpos + LISTS_MAX_COMMON;                  // [256]
+    float* s_cval = reinterpret_cast<float*>(s_misc + 260 + 256);   // [256]
+    uint32_t* s_cc = s_misc + 260 + 512;                            // [32] + total at [32]
+    // ---- 1. the entries, in position order ----
+    float dxy[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int t = tid + 512 * u;
+        dxy[u] = (t < S && k + t != xx) ? a.D[tri_at(x, y_pre[u])] : 0.0f;
+    }
+    for (int i = tid; i < 32 * k / 2; i += 512) reinterpret_cast<uint32_t*>(s_cnt)[i] = 0u; // (k even or not: the tail word below)
+    if (tid == 0 && (k & 1)) s_cnt[32 * k - 1] = 0;
+    float own[PER], other[PER];
+    int slot[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int t = tid + 512 * u;
+        own[u] = 0.0f;
+        other[u] = 0.0f;
+        slot[u] = -1; // position xx and the places behind the end: no entry
+        if (t < S && k + t != xx) {
+            const float dn = s_pre[u].x, ds = s_pre[u].y;
+            const float m = ds < dxy[u] ? ds : dxy[u]; // std::min(dxy, ds)
+            const float change = __fsub_rn(dxy[u], dn);
+            own[u] = __fsub_rn(m, dn);                  // goes to deltas[nearest(y)]
+            other[u] = change < 0.0f ? change : 0.0f;   // goes to every other slot when negative
+            slot[u] = __float_as_int(s_pre[u].z);
+        }
+    }
+    elap(0);
+    __syncthreads(); // the counts are zero
+    // ---- 2. per chunk (chunk u * 8 + wave = positions 512 u + 64 wave ...): list (b) counts; my rank among the lanes of
+    // the chunk that hold the same slot, in lane = position order.  "The lanes with my slot" = the AND over the slot's bits
+    // of (lanes whose bit is set) or its complement: a ballot and two selects per bit, nothing moves between lanes. ----
+    int nbits = 1;
+    while ((1 << nbits) < k) ++nbits;
+    int rank[PER];
+    uint64_t cmask[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        cmask[u] = __ballot(other[u] < 0.0f);
+        if (lane == 0) s_cc[u * 8 + wave] = (uint32_t)__popcll(cmask[u]);
+        const bool ent = slot[u] >= 0;
+        uint64_t same = __ballot(ent);
+        for (int bit = 0; bit < nbits; ++bit) {
+            const bool one = ((slot[u] >> bit) & 1) != 0;
+            const uint64_t ones = __ballot(one);
+            same &= one ? ones : ~ones;
+        }
+        rank[u] = __popcll(same & lt_mask);
+        const bool is_last = ent && (lane == 63 || (same >> (lane + 1)) == 0ull);
+        if (is_last) s_cnt[(u * 8 + wave) * k + slot[u]] = (uint16_t)__popcll(same);
+    }
+    __syncthreads();
+    elap(1);
+    // ---- 3. where every (chunk, slot) piece goes ----
+    if (tid < k) { // counts -> exclusive prefix over the chunks, in place; the slot's total (all reads first: one LDS round trip)
+        uint32_t h[32];
+#pragma unroll
+        for (int c = 0; c < 32; ++c) h[c] = s_cnt[c * k + tid];
+        uint32_t run = 0;
+#pragma unroll
+        for (int c = 0; c < 32; ++c) {
+            s_cnt[c * k + tid] = (uint16_t)run;
+            run += h[c];
+        }
+        s_start[tid + 1] = run; // (totals for now)
+    }
+    if (wave == 7) { // list (b): exclusive prefix of the per-chunk counts (one wave, lane = chunk)
+        const uint32_t h = lane < 32 ? s_cc[lane] : 0u;
+        uint32_t incl = h;
+#pragma unroll
+        for (int d = 1; d < 32; d <<= 1) {
+            const uint32_t o = (uint32_t)__builtin_amdgcn_ds_bpermute(((lane - d) & 63) << 2, (int)incl);
+            if (lane >= d) incl += o;
+        }
+        if (lane < 32) s_cc[lane] = incl - h;
+        if (lane == 31) s_cc[32] = incl;
+    }
+    __syncthreads();
+    if (wave == 0) { // inclusive scan of the totals over the slots: 4 per lane, then across the lanes
+        uint32_t v[4], sum = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int m = lane * 4 + q;
+            v[q] = m < k ? s_start[m + 1] : 0u;
+            sum += v[q];
+        }
+        uint32_t incl = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = (uint32_t)__builtin_amdgcn_ds_bpermute(((lane - d) & 63) << 2, (int)incl);
+            if (lane >= d) incl += o;
+        }
+        uint32_t run = incl - sum;
+        if (lane == 0) s_start[0] = 0u;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int m = lane * 4 + q;
+            run += v[q];
+            if (m < k) s_start[m + 1] = run;
+        }
+    }
+    __syncthreads();
+    const int n_common = (int)s_cc[32];
+    if (TIMED && tid == 0) { // (statistics; an atomic per evaluation on the search's state block costs microseconds per round)
+        atomicAdd(&a.state[ST_N_COMMON], n_common);
+        if (n_common > LISTS_MAX_COMMON) atomicAdd(&a.state[ST_N_GENERAL], 1);
+    }
+    if (n_common > LISTS_MAX_COMMON) return false; // (uniform) a candidate this central: the general walk
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int c = u * 8 + wave;
+        if (slot[u] >= 0) {
+            const uint32_t at = s_start[slot[u]] + s_cnt[c * k + slot[u]] + (uint32_t)rank[u];
+            s_ent[at] = make_float2(own[u], __int_as_float(tid + 512 * u));
+        }
+        if (other[u] < 0.0f) { // list (b), in position order
+            const uint32_t at = s_cc[c] + (uint32_t)__popcll(cmask[u] & lt_mask);
+            s_cpos[at] = (uint16_t)(tid + 512 * u);
+            s_cslot[at] = (uint16_t)slot[u];
+            s_cval[at] = other[u];
+        }
+    }
+    __syncthreads();
+    elap(2);
+    // ---- 4. lane l < 32 of wave w: the delta of slot 8 l + w (the slots of a wave are spread over the clusters) ----
+    const int m = lane * 8 + wave;
+    const bool has = lane < 32 && m < k;
+    int i = has ? (int)s_start[m] : 0;
+    const int e = has ? (int)s_start[m + 1] : 0;
+    float acc = 0.0f;
+    // A slot's additions are one dependent chain, and the largest cluster's chain is what the workgroup waits for: the
+    // members are read eight at a time (independent ds_read_b64), and a batch that lies wholly in front of the next entry
+    // of list (b) -- nearly all of them: that list holds a handful of entries -- is eight bare additions.
+    // The window f[0..7] holds the members base .. base + 7 of my run (clamped to its end), the batch behind it is
+    // prefetched while it is added; `off` of its members are consumed already.  An entry of list (b) costs a lane one
+    // comparison unless members of its own lie in front of it (then: the window's additions, predicated).
+    const int e_last = max(e - 1, 0);
+    int base = i, off = 0;
+    float2 f[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) f[q] = s_ent[min(base + q, e_last)];
+    int next_pos = base < e ? __float_as_int(f[0].y) : 0x7FFFFFFF; // position of my next member
+    for (int ci = 0; ci <= n_common; ++ci) {
+        int bound = 0x7FFFFFFF, cs = -1;
+        float cv = 0.0f;
+        if (ci < n_common) { // (uniform: broadcast reads)
+            bound = (int)s_cpos[ci];
+            cs = (int)s_cslot[ci];
+            cv = s_cval[ci];
+        }
+        while (next_pos < bound) { // members of my own in front of that entry
+            if (off == 0 && base + 8 <= e && __float_as_int(f[7].y) < bound) { // the whole window: eight bare additions
+                float2 g[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) g[q] = s_ent[min(base + 8 + q, e_last)];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) acc = __fadd_rn(acc, f[q].x);
+                base += 8;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) f[q] = g[q];
+                next_pos = base < e ? __float_as_int(f[0].y) : 0x7FFFFFFF;
+            } else {
+                bool go = true;
+                int np = 0x7FFFFFFF;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const bool live = q >= off && base + q < e;                 // not consumed yet, inside my run
+                    const bool take = go && live && __float_as_int(f[q].y) < bound;
+                    acc = __fadd_rn(acc, take ? f[q].x : 0.0f); // (+0.0f is the identity: acc is never -0.0f)
+                    off += take ? 1 : 0;
+                    if (live && !take && go) np = __float_as_int(f[q].y); // the first member that stays
+                    go = go && (take || !live);
+                }
+                if (off == 8 || base + off >= e) { // the window is used up
+                    base += 8;
+                    off = 0;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) f[q] = s_ent[min(base + q, e_last)];
+                    np = base < e ? __float_as_int(f[0].y) : 0x7FFFFFFF;
+                    if (base >= e) base = e;
+                }
+                next_pos = np;
+            }
+        }
+        if (ci < n_common && has && cs != m) acc = __fadd_rn(acc, cv);
+        // (an entry of list (b) that is my own member is added with its own-slot addend: positions are unique and
+        //  `< bound` stops in front of it, so the next turn of the loop takes it)
+    }
+    elap(3);
+    __syncthreads(); // every wave is done with the lists: the reduction below reuses s_we
+    // std::min_element over slots [n_fixed, k): smallest value, earliest slot among equals
+    float* s_v = reinterpret_cast<float*>(&s_we[0][0]);
+    int* s_k = reinterpret_cast<int*>(&s_we[1][0]);
+    float best = 0.0f;
+    int bk = INT_MAX;
+    if (has && m >= a.n_fixed) { best = acc; bk = m; }
+    wave_first_min_valid(best, bk);
+    if (lane == 0) {
+        s_v[wave] = best;
+        s_k[wave] = bk;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float v = s_v[0];
+        int kk = s_k[0];
+#pragma unroll
+        for (int w = 1; w < 8; ++w) {
+            const float v2 = s_v[w];
+            const int k2 = s_k[w];
+            if (k2 != INT_MAX && (kk == INT_MAX || v2 < v || (v2 == v && k2 < kk))) { v = v2; kk = k2; }
+        }
+        best_out = v;
+        bk_out = kk;
+    }
+    elap(4);
+    return true;
+}
+
 // A kernel boundary leaves nothing in the caches that another XCD wrote, so every DEPENDENT global
 // load of these small kernels costs a trip to memory (~1.5 us): both kernels are laid out to have as
 // few dependent levels as possible -- everything whose address does not depend on the step is
@@ -392,6 +665,7 @@ __global__ __launch_bounds__(512) void clarans_eval_kernel(ClaransBatch batch)
     constexpr int CH = 2048, PER = CH / 512; // positions whose data a workgroup keeps in registers at a time
     __shared__ float4 s_e[CH / 2];      // 16 KB: the chunk's entries, staged in two halves
     __shared__ float4 s_we[8][128];     // 16 KB: per wave, the entries of one sub-chunk that concern its slots
+    __shared__ uint32_t s_misc[1024];   //  4 KB: evaluate_step_lists' run starts and its short list
     const int b = blockIdx.x, tid = threadIdx.x;
     const int k = a.n_medoids, n = a.n_elems;
     // level 1: state, this step, and the first chunk's per-position data
@@ -424,7 +698,24 @@ __global__ __launch_bounds__(512) void clarans_eval_kernel(ClaransBatch batch)
     if (st1.z) return; // error flagged: apply ends the search
     float best = 0.0f;
     int bk = INT_MAX;
-    evaluate_step<KPT, false, true, false>(a, xx, x, y_pre, s_pre, s_e, s_we, best, bk, nullptr);
+    bool evaluated = false;
+    if (a.lists == 2 && n - k <= LISTS_MAX_S && k <= LISTS_MAX_K) {
+        unsigned long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        evaluated = evaluate_step_lists<true>(a, xx, x, y_pre, s_pre, s_e, s_we, s_misc, best, bk, tk);
+        if (tid == 0) { // (every step's workgroup: the kernel lasts as long as its slowest)
+            for (int i = 0; i < 5; ++i) atomicAdd(&g_lists_ticks[i], tk[i]);
+            atomicAdd(&g_lists_ticks[7], 1ull);
+            if (!evaluated) atomicAdd(&g_lists_ticks[6], 1ull);
+            unsigned long long tot = 0;
+            for (int i = 0; i < 5; ++i) tot += tk[i];
+            atomicMax(&g_lists_ticks[5], tot);
+        }
+    } else if (a.lists && n - k <= LISTS_MAX_S && k <= LISTS_MAX_K)
+        evaluated = evaluate_step_lists<false>(a, xx, x, y_pre, s_pre, s_e, s_we, s_misc, best, bk, nullptr);
+    if (!evaluated) {
+        __syncthreads();
+        evaluate_step<KPT, false, true, false>(a, xx, x, y_pre, s_pre, s_e, s_we, best, bk, nullptr);
+    }
     if (tid == 0) {
         a.res_delta[b] = best;
         a.res_mm[b] = bk;
@@ -930,6 +1221,11 @@ hipError_t launch_clarans_init(const ClaransArgs& a, hipStream_t stream)
 // `rounds` x (evaluate the next stage of every search's window, apply).  The first window of a local
 // search has `corrected` steps, the later ones corrected - 1 (the reference resets its step counter
 // to 1 after an accept).
+hipError_t clarans_lists_ticks(unsigned long long out[8])
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lists_ticks), 64, 0, hipMemcpyDeviceToHost);
+}
+
 hipError_t launch_clarans_rounds(const ClaransBatch& b, int rounds, hipStream_t stream)
 {
     int kpt = 1, apply_blocks = 1, steps = 0;

@@ -498,6 +498,15 @@ int lcsgpu_destroy(lcsgpu_ctx* ctx)
         if (l.fork) (void)hipEventDestroy(l.fork);
         if (l.stream) (void)hipStreamDestroy(l.stream);
     }
+    if (const char* e = getenv("LCSGPU_CLARANS_LISTS"))
+        if (atoi(e) == 2) {
+            unsigned long long tk[8] = {0};
+            if (lcsgpu::clarans_lists_ticks(tk) == hipSuccess && tk[7]) {
+                static const char* what[5] = {"loads + entries", "ranks per chunk", "prefixes + scatter", "the slots' walks", "reduction"};
+                for (int i = 0; i < 5; ++i) fprintf(stderr, "clarans.lists phase %-20s %.2f us per evaluation\n", what[i], tk[i] * 0.01 / tk[7]);
+                fprintf(stderr, "clarans.lists: %llu evaluations, %llu of them fell back to the general walk, slowest %.2f us\n", tk[7], tk[6], tk[5] * 0.01);
+            }
+        }
     for (ClaransBatcher& B : ctx->clarans_groups) {
         if (getenv("LCSGPU_PROFILE"))
             for (int i = 1; i <= lcsgpu::CLARANS_MAX_BATCH; ++i)
@@ -505,8 +514,9 @@ int lcsgpu_destroy(lcsgpu_ctx* ctx)
                     fprintf(stderr, "clarans.batch[%d searches]: %ld looks, %.3f s, %.1f us per look\n", i, B.prof_looks[i],
                             B.prof_seconds[i], 1e6 * B.prof_seconds[i] / B.prof_looks[i]);
         if (getenv("LCSGPU_PROFILE") && B.prof_searches)
-            fprintf(stderr, "clarans.searches=%ld accepts=%ld rounds=%ld steps_evaluated=%ld steps_up_to_the_accept=%ld\n", B.prof_searches,
-                    B.prof_accepts, B.prof_rounds, B.prof_steps, B.prof_useful);
+            fprintf(stderr, "clarans.searches=%ld accepts=%ld rounds=%ld steps_evaluated=%ld steps_up_to_the_accept=%ld "
+                            "common_entries_per_step=%.1f general_walk_steps=%ld\n", B.prof_searches,
+                    B.prof_accepts, B.prof_rounds, B.prof_steps, B.prof_useful, (double)B.prof_common / std::max(1L, B.prof_steps), B.prof_general);
         if (getenv("LCSGPU_PROFILE") && B.prof_chain_fallbacks)
             fprintf(stderr, "clarans.chain_fallbacks=%ld\n", B.prof_chain_fallbacks);
         if (B.stream) { (void)hipStreamSynchronize(B.stream); (void)hipStreamDestroy(B.stream); }

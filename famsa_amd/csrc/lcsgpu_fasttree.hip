@@ -142,6 +142,8 @@ void clarans_drive(lcsgpu_ctx* ctx, ClaransBatcher& B, ClaransJob* mine)
                     B.prof_rounds += j->state[11];
                     B.prof_steps += j->state[12];
                     B.prof_useful += j->state[13];
+                    B.prof_common += j->state[14];
+                    B.prof_general += j->state[15];
                     j->done = true;
                     B.joined.erase(std::find(B.joined.begin(), B.joined.end(), j));
                 }
@@ -580,6 +582,11 @@ int lcsgpu_clarans(lcsgpu_ctx* ctx, const int32_t* ids, int32_t n_ids, int dista
     a.corrected = corrected;
     static const int stage0 = std::max(1, std::min(64, env_int("LCSGPU_CLARANS_STAGE0", 16)));
     a.stage0 = stage0;
+    // 1: evaluate with per-slot lists (clarans_kernels.hip, evaluate_step_lists; 2 = with phase timers) -- built in round 4,
+    // bit-identical, and SLOWER where it counts (the kernel lasts as long as its slowest step: 33-45 us against 19.9 us
+    // for the broadcast walk at 2000 members / 100 medoids), so it is opt-in
+    static const int lists = env_int("LCSGPU_CLARANS_LISTS", 0);
+    a.lists = lists;
     // The two generators of Clustering.cpp:43-44.  Neither looks at the search state, so the host
     // runs them: gen_nodes shuffles the candidate order before every local search, gen_positions
     // yields the step positions, handed to the device as a growing array of draws.

@@ -144,6 +144,7 @@ struct ClaransBatcher {
     long prof_looks[lcsgpu::CLARANS_MAX_BATCH + 1] = {0};
     double prof_seconds[lcsgpu::CLARANS_MAX_BATCH + 1] = {0};
     long prof_rounds = 0, prof_steps = 0, prof_useful = 0, prof_accepts = 0, prof_searches = 0; // over finished searches
+    long prof_common = 0, prof_general = 0; // list evaluations: entries adding to every other slot (summed), steps that fell back to the general walk
     long prof_chain_fallbacks = 0; // LCSGPU_CLARANS_CHAIN: searches of a look that found no room on their XCD
 };
 
