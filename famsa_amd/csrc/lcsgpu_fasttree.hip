@@ -585,7 +585,7 @@ int lcsgpu_clarans(lcsgpu_ctx* ctx, const int32_t* ids, int32_t n_ids, int dista
     // 1: evaluate with per-slot lists (clarans_kernels.hip, evaluate_step_lists; 2 = with phase timers) -- built in round 4,
     // bit-identical, and SLOWER where it counts (the kernel lasts as long as its slowest step: 33-45 us against 19.9 us
     // for the broadcast walk at 2000 members / 100 medoids), so it is opt-in
-    static const int lists = env_int("LCSGPU_CLARANS_LISTS", 0);
+    const int lists = env_int("LCSGPU_CLARANS_LISTS", 0); // (read per call: the tests switch it inside one process)
     a.lists = lists;
     // The two generators of Clustering.cpp:43-44.  Neither looks at the search state, so the host
     // runs them: gen_nodes shuffles the candidate order before every local search, gen_positions

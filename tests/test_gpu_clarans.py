@@ -162,7 +162,7 @@ def test_stage_size_does_not_change_the_search(stage0):
     import os
     import subprocess
     import sys
-    if os.environ.get("LCSGPU_CLARANS_STAGE0") or os.environ.get("LCSGPU_CLARANS_CHAIN"):
+    if os.environ.get("LCSGPU_CLARANS_STAGE0") or os.environ.get("LCSGPU_CLARANS_CHAIN") or os.environ.get("LCSGPU_CLARANS_LISTS"):
         pytest.skip("already inside a nested run")
     env = dict(os.environ)
     env["LCSGPU_CLARANS_STAGE0"] = stage0
@@ -179,10 +179,29 @@ def test_one_xcd_chain_kernel_gives_the_same_searches():
     import os
     import subprocess
     import sys
-    if os.environ.get("LCSGPU_CLARANS_CHAIN") or os.environ.get("LCSGPU_CLARANS_STAGE0"):
+    if os.environ.get("LCSGPU_CLARANS_CHAIN") or os.environ.get("LCSGPU_CLARANS_STAGE0") or os.environ.get("LCSGPU_CLARANS_LISTS"):
         pytest.skip("already inside a nested run")
     env = dict(os.environ)
     env["LCSGPU_CLARANS_CHAIN"] = "1"
+    p = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-x", "-k",
+                        "matches_reference or concurrent"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       text=True)
+    assert p.returncode == 0 and " passed" in p.stdout, p.stdout[-3000:]
+
+
+def test_per_slot_list_evaluation_gives_the_same_searches():
+    """LCSGPU_CLARANS_LISTS=1 (opt-in, round 4): every step's deltas from per-slot runs -- stable ranks by ballots, the
+    runs in LDS, lane m walking slot m's members and merging in the entries that add to every other slot by position
+    (clarans_kernels.hip, evaluate_step_lists; shapes beyond 2048 non-medoids / 256 medoids / 256 such entries take the
+    general walk inside the same kernel).  The additions every slot sees are the same in the same order: every shape of
+    this file against the reference's CLARANS again, and the concurrent searches."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("LCSGPU_CLARANS_LISTS") or os.environ.get("LCSGPU_CLARANS_CHAIN") or os.environ.get("LCSGPU_CLARANS_STAGE0"):
+        pytest.skip("already inside a nested run")
+    env = dict(os.environ)
+    env["LCSGPU_CLARANS_LISTS"] = "1"
     p = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-x", "-k",
                         "matches_reference or concurrent"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                        text=True)
