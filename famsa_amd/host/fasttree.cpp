@@ -114,128 +114,152 @@ void partial_shuffle(int* first, int* middle, int* last, Gen& g)
     for (long i = 0; i < n; ++i) std::swap(first[i], first[det_uniform<unsigned long>(g, (int)i, (int)N)]);
 }
 
-// ---- CLARANS (FastPAM-style swaps), Clustering.cpp:17-305 ------------------------------------
+// ---- CLARANS k-medoids on the host: the form the device search has (csrc/clarans_kernels.hip), run serially -----------
+// Used where there is no device search: a matrix source without a GPU (the CPU suite), more than 1024 medoids, or on
+// request (FAMSA_CLARANS_HOST=1, the checker of the device search).  What it must reproduce is CLARANS::operator()
+// (reference tree/Clustering.cpp:17-305): the same draws, the same float additions in the same order, the same
+// comparison directions -- the sign of a delta decides the search.  How it is organised is this engine's own, and the
+// same as on the device: all state is kept per candidate POSITION (pos < k: the medoid in slot pos; pos >= k: a
+// non-medoid), the member-to-medoid distances as a slot-major matrix that is kept in step with the swaps, a step is
+// EVALUATED (every slot's delta) separately from being APPLIED, and the running cost is a sequential sum over a log
+// of addends in position order.
+class HostClarans {
+public:
+    HostClarans(const float* D, int n, int k, int n_fixed) : D_(D), n_(n), k_(k), fixed_(n_fixed), member_(n), st_(n), to_slot_((size_t)k * n), delta_(k) {}
+
+    // one local search from the candidate order `start`; returns its final cost, `member_[0..k)` are its medoids
+    template <class Gen>
+    float search(const std::vector<int>& start, int steps_without_accept, Gen& draw_position)
+    {
+        member_ = start;
+        float cost = 0.0f;
+        for (int pos = k_; pos < n_; ++pos) { // Clustering.cpp:49-79: every non-medoid's two nearest slots, the initial cost
+            for (int slot = 0; slot < k_; ++slot) to_slot_[(size_t)slot * n_ + pos] = D_[tri(member_[slot], member_[pos])];
+            st_[pos] = two_nearest(pos, -1, 0.0f);
+            cost += st_[pos].dn;
+        }
+        // cpp:86-89, 236: the search ends after `corrected` steps in a row without an accept -- one fewer once a step has
+        // been accepted (the reference resets its loop counter to 0 inside the loop, whose increment makes it 1)
+        int allowed = steps_without_accept;
+        for (int quiet = 0; quiet < allowed;) {
+            ++quiet;
+            const int xx = (int)det_uniform<unsigned int>(draw_position, k_, n_ - 1);
+            const int slot = evaluate(xx);
+            if (delta_[slot] < 0.0f) {
+                cost = apply(xx, slot, cost);
+                quiet = 0;
+                allowed = steps_without_accept - 1;
+            }
+        }
+        return cost;
+    }
+    const std::vector<int>& members() const { return member_; }
+
+private:
+    struct Two { float dn, ds; int an, as; }; // distance to / slot of the nearest and the second nearest medoid
+
+    // first and second minimum over the slots in ascending order (cpp:262-305); slot `swap_slot`, if any, at distance d_swap
+    Two two_nearest(int pos, int swap_slot, float d_swap) const
+    {
+        Two t{std::numeric_limits<float>::max(), std::numeric_limits<float>::max(), -1, -1};
+        for (int slot = 0; slot < k_; ++slot) {
+            const float d = slot == swap_slot ? d_swap : to_slot_[(size_t)slot * n_ + pos];
+            if (d < t.dn) { t.ds = t.dn; t.as = t.an; t.dn = d; t.an = slot; }
+            else if (d < t.ds) { t.ds = d; t.as = slot; }
+        }
+        return t;
+    }
+
+    // every slot's cost change if its medoid were replaced by the member at xx (cpp:93-122): a non-medoid adds
+    // min(d, second) - nearest to its own slot, and d - nearest to every other slot when that is negative; position
+    // order, one accumulator per slot.  Returns the first minimum over the free slots.
+    int evaluate(int xx)
+    {
+        std::fill(delta_.begin(), delta_.end(), 0.0f);
+        const int x = member_[xx];
+        for (int pos = k_; pos < n_; ++pos) {
+            if (pos == xx) continue;
+            const float d = D_[tri(x, member_[pos])];
+            const Two& t = st_[pos];
+            const float own = std::min(d, t.ds) - t.dn, other = d - t.dn;
+            if (other < 0.0f) {
+                for (int slot = 0; slot < k_; ++slot) delta_[slot] += slot == t.an ? own : other;
+            } else
+                delta_[t.an] += own;
+        }
+        return (int)(std::min_element(delta_.begin() + fixed_, delta_.end()) - delta_.begin());
+    }
+
+    // the swap (cpp:124-238): the member at xx becomes the medoid of `slot`, the old medoid moves to xx; every
+    // non-medoid keeps, moves or re-derives its two nearest slots; the cost takes the addends in position order
+    float apply(int xx, int slot, float cost)
+    {
+        const int x = member_[xx], old_medoid = member_[slot];
+        cost -= st_[xx].dn; // the new medoid leaves the sum first
+        member_[slot] = x;
+        member_[xx] = old_medoid;
+        for (int pos = k_; pos < n_; ++pos) {
+            if (pos == xx) { // the replaced medoid: distances to the new medoid set, a fresh assignment
+                for (int s2 = 0; s2 < k_; ++s2) to_slot_[(size_t)s2 * n_ + pos] = D_[tri(member_[s2], old_medoid)];
+                st_[pos] = two_nearest(pos, -1, 0.0f);
+                cost += st_[pos].dn;
+                continue;
+            }
+            const float d = D_[tri(x, member_[pos])];
+            Two& t = st_[pos];
+            if (t.an == slot) { // its medoid is the one that left
+                if (d < t.ds) {
+                    cost += d - t.dn;
+                    t.dn = d;
+                } else {
+                    cost += t.ds - t.dn;
+                    t = two_nearest(pos, slot, d);
+                }
+            } else if (d < t.dn) {
+                cost += d - t.dn;
+                t = Two{d, t.dn, slot, t.an};
+            } else if (t.as != slot && d < t.ds) {
+                t.ds = d;
+                t.as = slot;
+            } else
+                t = two_nearest(pos, slot, d);
+            to_slot_[(size_t)slot * n_ + pos] = d;
+        }
+        return cost;
+    }
+
+    const float* D_;
+    int n_, k_, fixed_;
+    std::vector<int> member_;     // by position
+    std::vector<Two> st_;         // by position (only positions >= k are used)
+    std::vector<float> to_slot_;  // [slot][position]: distance of the member at a position to the medoid in a slot
+    std::vector<float> delta_;
+};
+
+// CLARANS::operator(): `num_local` local searches, each from a fresh partial shuffle of the candidate order (the two
+// generators keep running across the searches), the medoids of the cheapest one (ties: the earlier search)
 struct Clarans {
     float explore_fraction;
     int num_local;
-    static constexpr int min_max_neighbor = 250;
-
-    static void update_assignment(int x, const int* candidate, int n_medoids, const float* D, float& dist_nearest,
-                                  float& dist_second, int& assign_nearest, int& assign_second)
-    {
-        float dn = std::numeric_limits<float>::max(), ds = std::numeric_limits<float>::max();
-        int an = -1, as = -1;
-        for (int mm = 0; mm < n_medoids; ++mm) {
-            const float d = D[tri(candidate[mm], x)];
-            if (d < dn) { ds = dn; as = an; dn = d; an = mm; }
-            else if (d < ds) { ds = d; as = mm; }
-        }
-        dist_nearest = dn; dist_second = ds; assign_nearest = an; assign_second = as;
-    }
 
     void operator()(const float* D, int n_elems, int n_medoids, int n_fixed, int* medoids) const
     {
+        // cpp:21-29: how many steps without an accept end a local search
         const int n_swaps = (n_elems - n_medoids) * n_medoids;
-        const int max_neighbor = n_swaps < min_max_neighbor
-                                     ? n_swaps
-                                     : std::max((int)(explore_fraction * n_swaps), (int)min_max_neighbor);
+        const int max_neighbor = n_swaps < 250 ? n_swaps : std::max((int)(explore_fraction * n_swaps), 250);
         const int corrected = max_neighbor / n_medoids;
-
-        std::vector<int> candidate(n_elems), current(n_elems);
-        std::iota(candidate.begin(), candidate.end(), 0);
-        float best_cost = std::numeric_limits<float>::max();
-        std::vector<float> dists_nearest(n_elems), dists_second(n_elems), deltas(n_elems);
-        std::vector<int> assign_nearest(n_elems), assign_second(n_elems);
-        std::mt19937 gen_nodes, gen_positions;
-
+        std::vector<int> order(n_elems);
+        std::iota(order.begin(), order.end(), 0);
+        std::mt19937 shuffle_gen, position_gen;
+        HostClarans hc(D, n_elems, n_medoids, n_fixed);
+        float best = std::numeric_limits<float>::max();
         for (int iter = 0; iter < num_local; ++iter) {
-            partial_shuffle(candidate.data() + n_fixed, candidate.data() + n_elems, candidate.data() + n_elems, gen_nodes);
-            current = candidate;
-            for (int mm = 0; mm < n_medoids; ++mm) {
-                const int m = candidate[mm];
-                dists_nearest[m] = 0; dists_second[m] = -1; assign_nearest[m] = -1; assign_second[m] = -1;
-            }
-            float cost = 0;
-            for (int xx = n_medoids; xx < n_elems; ++xx) {
-                const int x = candidate[xx];
-                update_assignment(x, candidate.data(), n_medoids, D, dists_nearest[x], dists_second[x],
-                                  assign_nearest[x], assign_second[x]);
-                cost += dists_nearest[x];
-            }
-            long n_steps = 0, n_improved = 0;
-            for (int step = 0; step < corrected; ++step) {
-                ++n_steps;
-                const int xx = (int)det_uniform<unsigned int>(gen_positions, n_medoids, n_elems - 1);
-                const int x = candidate[xx];
-                std::fill_n(deltas.begin(), n_medoids, 0.0f);
-                for (int yy = n_medoids; yy < n_elems; ++yy) {
-                    if (yy == xx) continue;
-                    const int y = candidate[yy];
-                    const float dxy = D[tri(x, y)];
-                    const int nn = assign_nearest[y];
-                    const float dn = dists_nearest[y], ds = dists_second[y];
-                    deltas[nn] += std::min(dxy, ds) - dn;
-                    const float change = dxy - dn;
-                    if (change < 0) {
-                        for (int kk = 0; kk < nn; ++kk) deltas[kk] += change;
-                        for (int kk = nn + 1; kk < n_medoids; ++kk) deltas[kk] += change;
-                    }
-                }
-                const int mm_new = (int)(std::min_element(deltas.begin() + n_fixed, deltas.begin() + n_medoids) - deltas.begin());
-                const float delta = deltas[mm_new];
-                if (delta < 0) {
-                    std::swap(candidate[mm_new], candidate[xx]);
-                    const int m_new = candidate[mm_new];
-                    cost -= dists_nearest[m_new];
-                    dists_nearest[m_new] = 0; dists_second[m_new] = -1; assign_nearest[m_new] = -1; assign_second[m_new] = -1;
-                    for (int yy = n_medoids; yy < n_elems; ++yy) {
-                        const int y = candidate[yy];
-                        const float d_new = D[tri(m_new, y)];
-                        const float dn = dists_nearest[y];
-                        const int an = assign_nearest[y];
-                        if (yy == xx) {
-                            update_assignment(y, candidate.data(), n_medoids, D, dists_nearest[y], dists_second[y],
-                                              assign_nearest[y], assign_second[y]);
-                            cost += dists_nearest[y];
-                            continue;
-                        }
-                        if (an == mm_new) {
-                            const float ds = dists_second[y];
-                            if (d_new < ds) {
-                                dists_nearest[y] = d_new;
-                                assign_nearest[y] = mm_new;
-                                cost += d_new - dn;
-                            } else {
-                                update_assignment(y, candidate.data(), n_medoids, D, dists_nearest[y], dists_second[y],
-                                                  assign_nearest[y], assign_second[y]);
-                                cost += ds - dn;
-                            }
-                        } else if (d_new < dn) {
-                            dists_second[y] = dn; assign_second[y] = an;
-                            dists_nearest[y] = d_new; assign_nearest[y] = mm_new;
-                            cost += d_new - dn;
-                        } else {
-                            const float ds = dists_second[y];
-                            const float as = (float)assign_second[y];
-                            if (as != (float)mm_new && d_new < ds) {
-                                dists_second[y] = d_new;
-                                assign_second[y] = mm_new;
-                            } else {
-                                update_assignment(y, candidate.data(), n_medoids, D, dists_nearest[y], dists_second[y],
-                                                  assign_nearest[y], assign_second[y]);
-                            }
-                        }
-                    }
-                    std::swap(current[mm_new], current[xx]);
-                    step = 0; // the for-increment makes the next step 1, as in the reference
-                    ++n_improved;
-                }
-            }
-            if (getenv("FAMSA_CLARANS_TRACE"))
-                fprintf(stderr, "clarans n=%d k=%d corrected=%d steps=%ld improved=%ld\n", n_elems, n_medoids, corrected, n_steps, n_improved);
-            if (cost < best_cost) {
-                best_cost = cost;
-                std::copy_n(current.begin(), n_medoids, medoids);
+            partial_shuffle(order.data() + n_fixed, order.data() + n_elems, order.data() + n_elems, shuffle_gen);
+            const float cost = hc.search(order, corrected, position_gen);
+            order = hc.members(); // the next search shuffles the order this one ended in
+            if (cost < best) {
+                best = cost;
+                std::copy_n(order.begin(), n_medoids, medoids);
             }
         }
     }
