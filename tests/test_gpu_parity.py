@@ -495,3 +495,22 @@ print("SPREAD_OK")
     env["LCSGPU_SPREAD"] = "1"
     p = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     assert p.returncode == 0 and "SPREAD_OK" in p.stdout, p.stderr[-2000:]
+
+
+@pytest.mark.parametrize("batch", ["32", "0"])
+def test_upgma_without_a_finite_neighbour_is_an_error(engine, monkeypatch, batch):
+    """A sequence that shares no residue with any other (all X: LCS 0, distance FLT_MAX >= the reference's BIG_DIST) leaves
+    UPGMA::computeTree without a row to pick at the last merge -- undefined behaviour in the reference
+    (tree/UPGMA.cpp:198-220 reads index 0x7FFFFFFF).  The device reducers answer LCSGPU_E_INVALID, in batches of merges
+    (upgma_batch_kernels.hip: the walk meets a key >= BIG_DIST) and with one launch per merge."""
+    import famsa_amd
+    monkeypatch.setenv("LCSGPU_UPGMA_BATCH", batch)
+    rng = np.random.Generator(np.random.PCG64(5))
+    seqs = [rng.integers(0, 20, size=int(l)).astype(np.uint8) for l in rng.integers(30, 90, size=300)]
+    seqs.insert(137, np.full(40, 22, np.uint8))
+    engine.upload_seqs(seqs)
+    with pytest.raises(famsa_amd.LcsGpuError, match="no finite nearest neighbour"):
+        engine.upgma(1, False)
+    engine.upload_seqs(seqs[:137] + seqs[138:])  # without it: a tree
+    left, right = engine.upgma(1, False)
+    assert len(left) == 299 and left.max() < 2 * 300 - 2
