@@ -10,6 +10,7 @@
 #include <fstream>
 #include <limits>
 #include <queue>
+#include <set>
 #include <stdexcept>
 #include <thread>
 
@@ -363,98 +364,113 @@ void float_triangle(LcsSource& src, std::vector<float>& dist)
     }
 }
 
-// -gt upgma / upgma_modified : the nearest-neighbour-array formulation the reference uses
+// -gt upgma / upgma_modified.  What has to come out is UPGMA::computeTree's tree (reference tree/UPGMA.cpp:114-295): its
+// row statistics are deliberately stale (a row's minimum is only ever replaced when the row itself is re-created by a
+// merge; nearest[] changes only by the rename "partner of the merge -> merged row") and every tie goes to the smaller row
+// index.  That staleness is what this form -- the host twin of csrc/upgma_batch_kernels.hip -- builds on: because a row's key
+// never changes while the row lives, the next pick is simply the smallest (key, row) of an ORDERED SET of the live rows
+// instead of a scan over all of them, and the live rows are a linked list in index order, so a merge touches only rows
+// that still exist.  The float operations and their order are the reference's.
 template <bool MODIFIED>
 void upgma_tree(std::vector<float>& D, int n, tree_structure& tree)
 {
-    const float BIG = 1e29f;
-    const uint64_t NONE = 0x7FFFFFFF;
+    constexpr float BIG = 1e29f; // UPGMA::BIG_DIST: a row whose minimum is not below it is never picked
+    constexpr int NONE = 0x7FFFFFFF;
     auto average = [](float x, float y) -> float {
         if (MODIFIED) return 0.05f * (x + y) + 0.9f * std::min(x, y);
         return (x + y) * 0.5f;
     };
-    std::vector<uint64_t> node_index(n), nearest(n, NONE), left(n - 1, NONE), right(n - 1, NONE);
-    std::vector<float> min_dist(n, BIG);
-    for (int i = 0; i < n; ++i) node_index[i] = i;
-    for (int i = 1; i < n; ++i) {
-        const float* row = D.data() + tri(i, 0);
-        for (int j = 0; j < i; ++j) {
-            const float d = row[j];
-            if (d < min_dist[i]) { min_dist[i] = d; nearest[i] = j; }
-            if (d < min_dist[j]) { min_dist[j] = d; nearest[j] = i; }
+    // every row's first strict minimum over the other rows in ascending index, and the node each row stands for
+    std::vector<float> key(n, BIG);
+    std::vector<int> partner(n, NONE), node(n), next(n + 1), prev(n + 1);
+    for (int x = 0; x < n; ++x) {
+        node[x] = x;
+        next[x] = x + 1;
+        prev[x + 1] = x;
+        for (int y = 0; y < n; ++y) {
+            if (y == x) continue;
+            const float d = D[tri(x, y)];
+            if (d < key[x]) { key[x] = d; partner[x] = y; }
         }
     }
-    for (int it = 0; it < n - 1; ++it) {
-        uint64_t Lmin = NONE, Rmin = NONE;
-        float best = BIG;
-        for (int j = 0; j < n; ++j) {
-            if (node_index[j] == NONE) continue;
-            if (min_dist[j] < best) { best = min_dist[j]; Lmin = j; Rmin = nearest[j]; }
-        }
-        if (Lmin == NONE || Rmin == NONE)
+    int first = 0; // head of the list of live rows (next[] ends at n)
+    std::set<std::pair<float, int>> order;
+    for (int x = 0; x < n; ++x)
+        if (key[x] < BIG) order.emplace(key[x], x);
+    auto unlink = [&](int x) {
+        if (x == first) first = next[x];
+        else next[prev[x]] = next[x];
+        prev[next[x]] = prev[x];
+    };
+    for (int made = 0; made < n - 1; ++made) {
+        if (order.empty() || partner[order.begin()->second] == NONE)
             throw std::runtime_error("UPGMA: no finite nearest neighbour (a pair with LCS 0?) -- the reference's "
                                      "algorithm is undefined for this input");
-        float new_min = BIG;
-        uint64_t new_nearest = NONE;
-        for (uint64_t j = 0; j < (uint64_t)n; ++j) {
-            if (j == Lmin || j == Rmin || node_index[j] == NONE) continue;
-            const size_t vL = tri(Lmin, j), vR = tri(Rmin, j);
-            const float nd = average(D[vL], D[vR]);
-            if (nearest[j] == Rmin) nearest[j] = Lmin;
-            D[vL] = nd;
-            if (nd < new_min) { new_min = nd; new_nearest = j; }
+        const int keep = order.begin()->second, gone = partner[keep]; // the merged cluster keeps the picked row
+        order.erase(order.begin());
+        if (key[gone] < BIG) order.erase({key[gone], gone});
+        unlink(gone);
+        float best = BIG;
+        int best_row = NONE;
+        for (int j = first; j < n; j = next[j]) { // ascending: the first strict minimum is the reference's
+            if (j == keep) continue;
+            float& cell = D[tri(keep, j)];
+            cell = average(cell, D[tri(gone, j)]);
+            if (partner[j] == gone) partner[j] = keep;
+            if (cell < best) { best = cell; best_row = j; }
         }
-        left[it] = node_index[Lmin];
-        right[it] = node_index[Rmin];
-        node_index[Lmin] = (uint64_t)n + it;
-        nearest[Lmin] = new_nearest;
-        min_dist[Lmin] = new_min;
-        node_index[Rmin] = NONE;
+        tree.emplace_back(node[keep], node[gone]);
+        node[keep] = n + made;
+        key[keep] = best;
+        partner[keep] = best_row;
+        if (best < BIG) order.emplace(best, keep);
     }
-    for (int i = 0; i < n - 1; ++i) tree.emplace_back((int)left[i], (int)right[i]);
 }
 
-// -gt nj
+// -gt nj.  NeighborJoining::computeTree (reference tree/NeighborJoining.cpp:33-118): q(i, j) = (m - 2) d(i, j) - s_i - s_j over
+// the live clusters in ascending order of their rows, first strict minimum; the sums s are float accumulations whose order
+// is part of the result.  Here the live rows are a linked list in index order (the reference erases from a vector: the same
+// order), the sums live per row.
 void nj_tree(std::vector<float>& D, int n, tree_structure& tree)
 {
-    struct Cluster { float sum; int row, node; };
-    std::vector<Cluster> cl(n);
-    for (int i = 0; i < n; ++i) {
-        cl[i].row = cl[i].node = i;
-        cl[i].sum = 0;
-        for (int j = 0; j < n; ++j)
-            if (i != j) cl[i].sum += D[tri(i, j)];
+    std::vector<float> sum(n, 0.0f);
+    std::vector<int> node(n), next(n + 1), prev(n + 1);
+    for (int x = 0; x < n; ++x) {
+        node[x] = x;
+        next[x] = x + 1;
+        prev[x + 1] = x;
+        for (int y = 0; y < n; ++y)
+            if (y != x) sum[x] += D[tri(x, y)];
     }
-    int iter = 0;
-    for (int n_clusters = n; n_clusters > 2; ++iter) {
-        float min_q = std::numeric_limits<float>::max();
-        int mi = 0, mj = 0;
-        for (int i = 0; i < n_clusters; ++i)
-            for (int j = i + 1; j < n_clusters; ++j) {
-                const float q = (n_clusters - 2) * D[tri(cl[i].row, cl[j].row)] - cl[i].sum - cl[j].sum;
-                if (q < min_q) { min_q = q; mi = i; mj = j; }
+    int first = 0;
+    int made = 0;
+    for (int live = n; live > 2; --live, ++made) {
+        float q_min = std::numeric_limits<float>::max();
+        int a = first, b = first;
+        for (int x = first; x < n; x = next[x])
+            for (int y = next[x]; y < n; y = next[y]) {
+                const float q = (live - 2) * D[tri(x, y)] - sum[x] - sum[y];
+                if (q < q_min) { q_min = q; a = x; b = y; }
             }
-        Cluster& ci = cl[mi];
-        Cluster& cj = cl[mj];
-        const float Dij = D[tri(ci.row, cj.row)];
-        tree.emplace_back(ci.node, cj.node);
-        ci.sum = 0;
-        ci.node = n + iter;
-        for (int k = 0; k < n_clusters; ++k) {
-            if (k == mi || k == mj) continue;
-            Cluster& ck = cl[k];
-            float Dik = D[tri(ci.row, ck.row)];
-            const float Djk = D[tri(cj.row, ck.row)];
-            ck.sum -= Dik + Djk;
-            Dik = (Dik + Djk - Dij) / 2;
-            ck.sum += Dik;
-            ci.sum += Dik;
-            D[tri(ci.row, ck.row)] = Dik;
+        const float d_ab = D[tri(a, b)];
+        tree.emplace_back(node[a], node[b]);
+        node[a] = n + made; // the joined cluster keeps row a; row b leaves
+        sum[a] = 0.0f;
+        for (int z = first; z < n; z = next[z]) {
+            if (z == a || z == b) continue;
+            float& d_az = D[tri(a, z)];
+            const float d_bz = D[tri(b, z)];
+            sum[z] -= d_az + d_bz;
+            d_az = (d_az + d_bz - d_ab) / 2;
+            sum[z] += d_az;
+            sum[a] += d_az;
         }
-        cl.erase(cl.begin() + mj);
-        --n_clusters;
+        if (b == first) first = next[b];
+        else next[prev[b]] = next[b];
+        prev[next[b]] = prev[b];
     }
-    tree.emplace_back(cl[0].node, cl[1].node);
+    const int x = first, y = next[first];
+    tree.emplace_back(node[x], node[y]);
 }
 
 // the partial generators: append n-1 internal nodes (local ids)
