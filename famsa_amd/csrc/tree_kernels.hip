@@ -422,7 +422,8 @@ __global__ __launch_bounds__(256) void upgma_step_kernel(UpgmaArgs a, int it)
         }
     }
     uint32_t nodeLp = UPGMA_NONE, nodeRp = UPGMA_NONE;
-    if (it > 0 && b == 0 && tid == 0) { // in flight during the reductions below
+    const bool prev_ok = it > 0 && Lp != UPGMA_NONE && Rp != UPGMA_NONE; // (no previous pick: the input is degenerate, sel[8] says so)
+    if (prev_ok && b == 0 && tid == 0) { // in flight during the reductions below
         nodeLp = a.node_index[Lp];
         nodeRp = a.node_index[Rp];
     }
@@ -444,7 +445,7 @@ __global__ __launch_bounds__(256) void upgma_step_kernel(UpgmaArgs a, int it)
     uint32_t R = UPGMA_NONE;
     if (it < n - 1 && L != UPGMA_NONE) R = cn;
     if (b == 0 && tid == 0) {
-        if (it > 0) {
+        if (prev_ok) {
             a.left[it - 1] = (int32_t)nodeLp;
             a.right[it - 1] = (int32_t)nodeRp;
             a.node_index[Lp] = (uint32_t)n + (uint32_t)(it - 1);
