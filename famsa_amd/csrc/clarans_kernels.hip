@@ -852,6 +852,11 @@ __global__ __launch_bounds__(64) void clarans_apply_kernel(ClaransBatch batch)
         } else if (as_y != mm_new && d_new < ds_y) {
             out.y = d_new;
             out.w = __int_as_float(mm_new);
+        } else if (as_y != mm_new && d_new > ds_y) {
+            // Neither of its two nearest slots is the one that changed, and the new medoid is strictly farther than
+            // the second: updateAssignment (first minimum over the slots, then first minimum over the rest) gives what
+            // it gave before -- the reference rescans here (Clustering.cpp:228-232) and arrives at the same four
+            // values.  (Equality with the second stays with the rescan: the slot order decides a tie.)
         } else {
             rescan = true;
         }
