@@ -260,6 +260,10 @@ int lcsgpu_mst_order_edges(lcsgpu_mst_edge* edges, int32_t n);
  * out_left/out_right (HOST, n-1 entries each): children of internal node n+k, k = 0..n-2, ids as in
  * tree_structure (leaves 0..n-1).  Returns LCSGPU_E_INVALID for inputs on which the reference's
  * algorithm is undefined (no finite nearest neighbour, e.g. a sequence with LCS 0 to all others).
+ * How the n-1 merges run (all forms give the reference's tree bit for bit): while n x 2n floats fit next to
+ * the LCS triangle (n <= ~158 000 on 288 GB) in batches of up to 32 merges per three launches -- the next picks are the
+ * next entries of the rows' sorted (min_dist, index) order, checked afterwards against the keys of the clusters the batch
+ * created (LCSGPU_UPGMA_BATCH=0|8|16|32); else on the n x n matrix, or on the packed triangle, with one launch per merge.
  * Replaces: UPGMA::computeDistances + UPGMA::computeTree (tree/UPGMA.cpp:75-109, 114-295). */
 int lcsgpu_upgma(lcsgpu_ctx* ctx, int distance_kind, int modified, int32_t* out_left, int32_t* out_right);
 
