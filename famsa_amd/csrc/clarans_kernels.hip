@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256) void clarans_init_kernel(ClaransArgs a)
         a.state[ST_DONE] = 0;
         a.state[ST_LOG_LEN] = n - k;
         a.state[ST_ROUNDS] = 0;
-        a.state[ST_ARRIVE] = 0;
+        a.state[ST_ARRIVE] = a.fused ? 1 : 0; // (fused rounds: "no round has run yet")
         a.state[ST_COST] = __float_as_int(0.0f);
         a.state[ST_WIN] = 0;
         a.state[ST_OFF] = 0;
@@ -188,7 +188,7 @@ __device__ __forceinline__ float4 ld4(const float4* p) { return COH ? ldc4(p) : 
 // running cost: c += addend for every logged addend, in order; zeros are the identity (c starts at +0.0f and can
 // never become -0.0f), so only the others are walked.  Valid in thread 0.
 template <bool COH>
-__device__ __forceinline__ float cost_accumulate(const ClaransArgs& a, int len, float c, float* s_f, float* s_nz)
+__device__ __forceinline__ float cost_accumulate(const float* cost_log, int len, float c, float* s_f, float* s_nz)
 {
     constexpr int CH = 2048, PER = CH / 512;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -199,7 +199,7 @@ __device__ __forceinline__ float cost_accumulate(const ClaransArgs& a, int len, 
 #pragma unroll
         for (int u = 0; u < PER; ++u) { // one trip to memory for the whole pass
             const int t = tid + 512 * u;
-            v[u] = t < cnt ? ld<COH>(&a.cost_log[c0 + t]) : 0.0f;
+            v[u] = t < cnt ? ld<COH>(&cost_log[c0 + t]) : 0.0f;
         }
 #pragma unroll
         for (int u = 0; u < PER; ++u) s_f[tid + 512 * u] = v[u];
@@ -691,7 +691,7 @@ __global__ __launch_bounds__(512) void clarans_eval_kernel(ClaransBatch batch)
     if (cost_wg) { // adds the previous round's cost addends to the running cost, in order
         const int len = st0.z;
         if (len == 0) return;
-        const float c = cost_accumulate<false>(a, len, __int_as_float(st1.y), reinterpret_cast<float*>(s_e), reinterpret_cast<float*>(s_we));
+        const float c = cost_accumulate<false>(a.cost_log, len, __int_as_float(st1.y), reinterpret_cast<float*>(s_e), reinterpret_cast<float*>(s_we));
         if (tid == 0) a.state[ST_COST] = __float_as_int(c);
         return;
     }
@@ -917,6 +917,325 @@ __global__ __launch_bounds__(64) void clarans_apply_kernel(ClaransBatch batch)
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// A ROUND AS ONE LAUNCH (round 4; LCSGPU_CLARANS_FUSED, the default where the shape allows).
+//
+// evaluate + apply are two dependent launches per round, and under load the apply -- 31 one-wave workgroups whose 3-4
+// dependent load levels each wait behind the LCS launches and the other searches' evaluations -- costs 38 of a round's
+// 101 us.  But what the apply does to a position is small (one gather, a handful of comparisons, rarely a rescan over the k
+// slots), and the evaluation workgroups already hold every position's state in registers, four positions per thread.  So
+// every step's workgroup APPLIES THE PREVIOUS ROUND'S ACCEPT ITSELF, to its own register copy of the state, and then
+// evaluates its step of this round against it: one launch per round.
+//   * All buffers a workgroup reads at its first load level and another writes in the same launch exist twice, by round
+//     parity: state block, candidate order, per-position state, cost log, step results.  The parity-0 copies are the
+//     arrays the two-launch form uses (what the host reads after an even number of rounds).
+//   * Workgroup 0 is also the COMMITTER: it writes the applied state to the other parity (whole arrays: every thread its
+//     four positions), the new column / row of the member-to-medoid matrix (in place: nobody consumes those entries in
+//     the same launch -- a rescan overrides the changed slot, the replaced medoid's position is rebuilt from D), the
+//     cost addends and the state block.  The last workgroup keeps the running cost, as before.
+//   * The control flow of the two kernels (first improving step of the stage; stages 16, 32, 64, 64 ... of a window;
+//     corrected / corrected - 1 steps without an accept end the search) is recomputed by every workgroup from the same
+//     state block and step results; the arithmetic of the apply and of the evaluation is the two kernels', line by line.
+// Shapes: n - k <= 2048 (the state of all positions in the registers of one workgroup), n > k.
+enum { ST_FRESH = ST_ARRIVE }; // (the arrival counter of the two-launch form is free here) 1 = no round has run yet
+template <int KPT>
+__global__ __launch_bounds__(512) void clarans_round_kernel(ClaransBatch batch, int par)
+{
+    const ClaransArgs& a = batch.s[blockIdx.y];
+    constexpr int PER = 4;
+    __shared__ float4 s_e[1024];        // 16 KB   evaluate_step's staging
+    __shared__ float4 s_we[8][128];     // 16 KB
+    __shared__ float4 s_xx_state;       // the rebuilt state of the position that received the replaced medoid
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int k = a.n_medoids, n = a.n_elems, corrected = a.corrected;
+    const int32_t* stA = par ? a.state1 : a.state;
+    int32_t* stB = par ? a.state : a.state1;
+    const int32_t* candA = par ? a.cand1 : a.cand;
+    int32_t* candB = par ? a.cand : a.cand1;
+    const float4* sA = par ? a.st1 : a.st;
+    float4* sB = par ? a.st : a.st1;
+    const float* logA = par ? a.log1 : a.cost_log;
+    float* logB = par ? a.cost_log : a.log1;
+    const int32_t* resA = a.res2 + par * 256; // [4][64]: best delta (bits), its slot, the step's position, its member
+    int32_t* resB = a.res2 + (1 - par) * 256;
+    // ---- level 1 ----
+    const int4 st0 = *reinterpret_cast<const int4*>(stA);
+    const int4 st1 = *reinterpret_cast<const int4*>(stA + 4);
+    const int4 st2 = *reinterpret_cast<const int4*>(stA + 8);
+    const int4 st3 = *reinterpret_cast<const int4*>(stA + 12);
+    const float r_delta = __int_as_float(resA[lane]);
+    const int r_mm = resA[64 + lane], r_xx = resA[128 + lane], r_x = resA[192 + lane];
+    int y_pre[PER];
+    float4 s_pre[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int pos = k + tid + 512 * u;
+        y_pre[u] = pos < n ? candA[pos] : 0;
+        s_pre[u] = pos < n ? sA[pos] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    int med_pre[CLARANS_MAX_MEDOIDS / 64]; // wave 0: the medoids before the swap, slots lane, lane + 64, ...
+#pragma unroll
+    for (int u = 0; u < CLARANS_MAX_MEDOIDS / 64; ++u) med_pre[u] = (wave == 0 && lane + 64 * u < k) ? candA[lane + 64 * u] : 0;
+    const bool cost_wg = b == (int)gridDim.x - 1;
+    const int P = st0.x, done = st0.y, log_len = st0.z, rounds = st0.w, fresh = st1.x, err = st1.z;
+    const int off = st2.x, stage = st2.y, first = st2.z;
+    if (done) { // finished in an earlier round: the state travels on unchanged (both parities stay readable)
+        if (b == 0 && tid < 16) stB[tid] = stA[tid];
+        return;
+    }
+    if (cost_wg) { // the running cost: + the addends the previous round's committer logged, in order
+        float c = __int_as_float(st1.y);
+        if (log_len > 0) {
+            c = cost_accumulate<false>(logA, log_len, c, reinterpret_cast<float*>(s_e), reinterpret_cast<float*>(s_we));
+        }
+        if (tid == 0) stB[ST_COST] = __float_as_int(c);
+        return;
+    }
+    // ---- what the previous round's results mean (every workgroup, the same) ----
+    const int W = window_size(corrected, first);
+    const int S_prev = fresh ? 0 : stage_size(stage, W - off, a.stage0);
+    const unsigned long long neg = __ballot(lane < S_prev && !err && r_delta < 0.0f);
+    const bool accept = neg != 0ull;
+    const int w = accept ? (int)__builtin_ctzll(neg) : 0;
+    const int mm_new = __builtin_amdgcn_readlane(r_mm, w), xx_acc = __builtin_amdgcn_readlane(r_xx, w),
+              x_acc = __builtin_amdgcn_readlane(r_x, w);
+    int P_n = P, done_n = 0, log_n = 0, rounds_n = rounds, err_n = err, off_n = off, stage_n = stage, first_n = first;
+    if (accept) {
+        P_n = P + off + w + 1;
+        log_n = 1 + n - k;
+        rounds_n = rounds + 1;
+        off_n = 0;
+        stage_n = 0;
+        first_n = 0;
+        if (P_n + window_size(corrected, 0) > a.draws_len) err_n = 1;
+    } else if (!fresh) {
+        if (err || off + S_prev >= W) { // error, or `corrected` steps without an accept: this local search is over
+            P_n = P + (err ? 0 : W);
+            done_n = 1;
+        } else {
+            off_n = off + S_prev;
+            stage_n = stage + 1;
+        }
+    }
+    const int W_n = window_size(corrected, first_n);
+    const int S_now = (done_n || err_n) ? 0 : stage_size(stage_n, W_n - off_n, a.stage0);
+    const bool committer = b == 0;
+    if (!committer && b >= S_now) return; // no step for this workgroup in this round
+    // ---- level 2: the accept's gathers, this round's draw ----
+    int m_old = 0;
+    float d_new[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) d_new[u] = 0.0f;
+    if (accept) {
+        m_old = candA[mm_new];
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int pos = k + tid + 512 * u;
+            if (pos < n && pos != xx_acc) d_new[u] = a.D[tri_at(x_acc, y_pre[u])];
+        }
+    }
+    const bool have_step = b < S_now;
+    const int xx = have_step ? a.draws[P_n + off_n + b] : k;
+    // ---- the accept applied to my positions (clarans_apply_kernel's branches; Clustering.cpp:124-238) ----
+    float addend[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) addend[u] = 0.0f;
+    float old_dn_xx = 0.0f;
+    if (accept) {
+        // the position that receives the replaced medoid: distances to the new medoid set, a fresh assignment -- wave 0
+        if (wave == 0) {
+            float dv[CLARANS_MAX_MEDOIDS / 64];
+#pragma unroll
+            for (int u = 0; u < CLARANS_MAX_MEDOIDS / 64; ++u) {
+                const int mm = lane + 64 * u;
+                dv[u] = FLT_MAX;
+                if (mm < k) {
+                    dv[u] = a.D[tri_at(mm == mm_new ? x_acc : med_pre[u], m_old)];
+                    if (committer) a.DMt[(size_t)mm * n + xx_acc] = dv[u];
+                }
+            }
+            float v1 = FLT_MAX, v2 = FLT_MAX;
+            int i1 = INT_MAX, i2 = INT_MAX;
+#pragma unroll
+            for (int u = 0; u < CLARANS_MAX_MEDOIDS / 64; ++u) {
+                const int mm = lane + 64 * u;
+                if (mm < k && (dv[u] < v1 || i1 == INT_MAX)) { v1 = dv[u]; i1 = mm; }
+            }
+            wave_first_min_valid(v1, i1);
+#pragma unroll
+            for (int u = 0; u < CLARANS_MAX_MEDOIDS / 64; ++u) {
+                const int mm = lane + 64 * u;
+                if (mm < k && mm != i1 && (dv[u] < v2 || i2 == INT_MAX)) { v2 = dv[u]; i2 = mm; }
+            }
+            wave_first_min_valid(v2, i2);
+            if (lane == 0) {
+                const bool has1 = i1 != INT_MAX && v1 < FLT_MAX, has2 = i2 != INT_MAX && v2 < FLT_MAX;
+                s_xx_state = pack_state(has1 ? v1 : FLT_MAX, has2 ? v2 : FLT_MAX, has1 ? i1 : -1, has2 ? i2 : -1);
+            }
+        }
+        __syncthreads();
+        bool need[PER]; // this position has to look at all k slots again
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int pos = k + tid + 512 * u;
+            need[u] = false;
+            if (pos >= n) continue;
+            if (pos == xx_acc) {
+                old_dn_xx = s_pre[u].x;
+                s_pre[u] = s_xx_state;
+                y_pre[u] = m_old;
+                addend[u] = s_pre[u].x;
+                continue;
+            }
+            const float4 s0 = s_pre[u];
+            const float dn_y = s0.x, ds_y = s0.y;
+            const int an_y = __float_as_int(s0.z), as_y = __float_as_int(s0.w);
+            const float dnw = d_new[u];
+            float4 out = s0;
+            if (an_y == mm_new) { // its medoid is the one that left
+                if (dnw < ds_y) {
+                    out.x = dnw;
+                    addend[u] = __fsub_rn(dnw, dn_y);
+                } else {
+                    need[u] = true;
+                    addend[u] = __fsub_rn(ds_y, dn_y);
+                }
+            } else if (dnw < dn_y) {
+                out = pack_state(dnw, dn_y, mm_new, an_y);
+                addend[u] = __fsub_rn(dnw, dn_y);
+            } else if (as_y != mm_new && dnw < ds_y) {
+                out.y = dnw;
+                out.w = __int_as_float(mm_new);
+            } else if (as_y != mm_new && dnw > ds_y) {
+                // (unchanged: see clarans_apply_kernel)
+            } else {
+                need[u] = true;
+            }
+            s_pre[u] = out;
+        }
+        // The rescans (a few dozen positions per accept, but nearly every wave has one): a lane walking its position's k
+        // distances alone waits for k / 8 dependent batches of scattered loads.  Instead the WAVE takes each such position:
+        // lane m loads the distance to slot m (+ 64, ...), all of a group's loads in flight together, and the two nearest
+        // slots are two wave minima -- "first minimum over the slots, then first minimum over the rest", which is what
+        // the sequential scan of Clustering.cpp:262-305 arrives at (see clarans_apply_kernel's last workgroup).
+        const int kq = (k + 63) >> 6;
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            unsigned long long todo = __ballot(need[u]);
+            while (todo) {
+                int rl[4];
+                int cnt = 0;
+                while (cnt < 4 && todo) {
+                    rl[cnt++] = (int)__builtin_ctzll(todo);
+                    todo &= todo - 1;
+                }
+                if (kq <= 2) {
+                    float v[4][2];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const int pos_r = k + wave * 64 + (c < cnt ? rl[c] : rl[0]) + 512 * u;
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            const int mm = lane + 64 * q;
+                            v[c][q] = (c < cnt && mm < k) ? a.DMt[(size_t)mm * n + pos_r] : FLT_MAX;
+                        }
+                    }
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        if (c >= cnt) break;
+                        const float dnw_r = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d_new[u]), rl[c]));
+                        float dv[2];
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) dv[q] = (lane + 64 * q == mm_new) ? dnw_r : v[c][q];
+                        float v1 = FLT_MAX, v2 = FLT_MAX;
+                        int i1 = INT_MAX, i2 = INT_MAX;
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            const int mm = lane + 64 * q;
+                            if (mm < k && (dv[q] < v1 || i1 == INT_MAX)) { v1 = dv[q]; i1 = mm; }
+                        }
+                        wave_first_min_valid(v1, i1);
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            const int mm = lane + 64 * q;
+                            if (mm < k && mm != i1 && (dv[q] < v2 || i2 == INT_MAX)) { v2 = dv[q]; i2 = mm; }
+                        }
+                        wave_first_min_valid(v2, i2);
+                        const bool has1 = i1 != INT_MAX && v1 < FLT_MAX, has2 = i2 != INT_MAX && v2 < FLT_MAX;
+                        if (lane == rl[c]) s_pre[u] = pack_state(has1 ? v1 : FLT_MAX, has2 ? v2 : FLT_MAX, has1 ? i1 : -1, has2 ? i2 : -1);
+                    }
+                } else { // more than 128 slots: every such lane scans its own column (the apply kernel's loop)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        if (c < cnt && lane == rl[c]) {
+                            const int pos = k + tid + 512 * u;
+                            const float dnw = d_new[u];
+                            Nearest2 nb;
+                            const float* col = a.DMt + pos;
+                            for (int m0 = 0; m0 < k; m0 += 8) {
+                                float vv[8];
+#pragma unroll
+                                for (int q = 0; q < 8; ++q) vv[q] = col[(size_t)min(m0 + q, k - 1) * n];
+#pragma unroll
+                                for (int q = 0; q < 8; ++q)
+                                    if (m0 + q < k) nb.feed(m0 + q == mm_new ? dnw : vv[q], m0 + q);
+                            }
+                            s_pre[u] = pack_state(nb.dn, nb.ds, nb.an, nb.as);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    // ---- the committer: the applied state into the other parity ----
+    if (committer) {
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int pos = k + tid + 512 * u;
+            if (pos >= n) continue;
+            candB[pos] = y_pre[u];
+            sB[pos] = s_pre[u];
+            if (accept) {
+                logB[1 + pos - k] = addend[u];
+                if (pos == xx_acc) logB[0] = -old_dn_xx;
+                else a.DMt[(size_t)mm_new * n + pos] = d_new[u];
+            }
+        }
+        for (int mm = tid; mm < k; mm += 512) candB[mm] = (accept && mm == mm_new) ? x_acc : candA[mm];
+        if (tid == 0) {
+            stB[ST_P] = P_n;
+            stB[ST_DONE] = done_n;
+            stB[ST_LOG_LEN] = log_n;
+            stB[ST_ROUNDS] = rounds_n;
+            stB[ST_FRESH] = 0;
+            // (ST_COST: the cost workgroup)
+            stB[ST_ERR] = err_n;
+            stB[ST_WIN] = 0;
+            stB[ST_OFF] = off_n;
+            stB[ST_STAGE] = stage_n;
+            stB[ST_FIRST] = first_n;
+            stB[ST_N_ROUNDS] = st2.w + (fresh ? 0 : 1);
+            stB[ST_N_STEPS] = st3.x + (err ? 0 : S_prev);
+            stB[ST_N_USEFUL] = st3.y + (accept ? w + 1 : (err ? 0 : S_prev));
+            stB[ST_N_COMMON] = st3.z;
+            stB[ST_N_GENERAL] = st3.w;
+        }
+    }
+    if (!have_step) return;
+    // ---- level 3 / 4: my step of this round against the applied state ----
+    const int x = (accept && xx == xx_acc) ? m_old : candA[xx];
+    float best = 0.0f;
+    int bk = INT_MAX;
+    __syncthreads(); // (s_xx_state has been consumed; evaluate_step stages through LDS)
+    evaluate_step<KPT, false, true, false>(a, xx, x, y_pre, s_pre, s_e, s_we, best, bk, nullptr);
+    if (tid == 0) {
+        resB[b] = __float_as_int(best);
+        resB[64 + b] = bk;
+        resB[128 + b] = xx;
+        resB[192 + b] = x;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // The rounds of a search inside ONE launch, kept on ONE XCD (opt-in, LCSGPU_CLARANS_CHAIN=1).
 //
 // A round is two dependent steps (evaluate the stage's pending steps; apply the first improving one), and as two launches
@@ -1022,7 +1341,7 @@ __global__ __launch_bounds__(512) void clarans_chain_kernel(ClaransBatch batch, 
         ++n_rounds;
         // ---- evaluate
         if (tail) {
-            if (log_len) cost = cost_accumulate<true>(a, log_len, cost, reinterpret_cast<float*>(s_e), reinterpret_cast<float*>(s_we));
+            if (log_len) cost = cost_accumulate<true>(a.cost_log, log_len, cost, reinterpret_cast<float*>(s_e), reinterpret_cast<float*>(s_we));
         } else if (!err) {
             for (int b = rank; b < S; b += n_eval) {
                 const int xx = ldc(&a.win_xx[win * a.win_cap + off + b]);
@@ -1226,6 +1545,23 @@ hipError_t launch_clarans_init(const ClaransArgs& a, hipStream_t stream)
 // `rounds` x (evaluate the next stage of every search's window, apply).  The first window of a local
 // search has `corrected` steps, the later ones corrected - 1 (the reference resets its step counter
 // to 1 after an accept).
+// `rounds` launches of clarans_round_kernel (an even number: the host reads the parity-0 buffers)
+hipError_t launch_clarans_rounds_fused(const ClaransBatch& b, int rounds, hipStream_t stream)
+{
+    int kpt = 1, steps = 0;
+    for (int i = 0; i < b.n; ++i) {
+        const ClaransArgs& a = b.s[i];
+        kpt = std::max(kpt, ((a.n_medoids + 7) / 8 + 63) / 64);
+        steps = std::max(steps, std::max(1, std::min(a.corrected, STAGE_MAX)));
+    }
+    const dim3 grid(steps + 1, b.n), block(512); // a stage has at most STAGE_MAX steps; + the cost workgroup
+    for (int r = 0; r < rounds; ++r) {
+        if (kpt <= 1) hipLaunchKernelGGL(clarans_round_kernel<1>, grid, block, 0, stream, b, r & 1);
+        else hipLaunchKernelGGL(clarans_round_kernel<2>, grid, block, 0, stream, b, r & 1);
+    }
+    return hipGetLastError();
+}
+
 hipError_t clarans_lists_ticks(unsigned long long out[8])
 {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lists_ticks), 64, 0, hipMemcpyDeviceToHost);

@@ -303,6 +303,14 @@ struct ClaransArgs {
     int32_t corrected;   // steps without an accept that end a local search (Clustering.cpp:21-29)
     int32_t stage0;      // steps evaluated in the first round of a window; doubled per round without an accept, at most 64
     int32_t lists;       // evaluate with per-slot lists where the shape allows (clarans_kernels.hip, evaluate_step_lists)
+    // a round as ONE launch (clarans_round_kernel): the second copy of everything a workgroup reads at its first load
+    // level and another writes in the same launch; the parity-0 copies are cand / st / cost_log / state above
+    int32_t fused;
+    int32_t* cand1;
+    float4* st1;
+    float* log1;
+    int32_t* state1;
+    int32_t* res2;       // [2][4][64] step results by round parity: best delta (bits), its slot, the step's position, its member
 };
 // Searches that are advanced together, one grid row each: however many host threads are searching,
 // a round costs two launches (evaluate, apply) in total instead of two per search -- with one launch
@@ -316,6 +324,7 @@ hipError_t launch_subset_distances(const void* lcs, int elem_size, const int32_t
                                    const float* pow_f32, int kind, int n, float* D, hipStream_t stream);
 hipError_t launch_clarans_init(const ClaransArgs& a, hipStream_t stream);
 hipError_t launch_clarans_rounds(const ClaransBatch& b, int rounds, hipStream_t stream);
+hipError_t launch_clarans_rounds_fused(const ClaransBatch& b, int rounds, hipStream_t stream); // every search of b: fused != 0
 hipError_t clarans_lists_ticks(unsigned long long out[8]); // LCSGPU_CLARANS_LISTS=2: phase ticks of the list evaluation
 hipError_t launch_clarans_chain(const ClaransBatch& b, int rounds, int ranks, hipStream_t stream);
 

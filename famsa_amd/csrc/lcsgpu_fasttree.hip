@@ -114,7 +114,12 @@ void clarans_drive(lcsgpu_ctx* ctx, ClaransBatcher& B, ClaransJob* mine)
                 read_states(again, again_slot);
             }
         } else {
-            if (rc == LCSGPU_OK) hip_ok(lcsgpu::launch_clarans_rounds(batch, rounds_per_look, B.stream), "CLARANS rounds");
+            // the searches of a look advance together; those whose shape takes the one-launch rounds and the others are two
+            // launch sequences (FAMSA's samples all have one size: a mixed look is the exception)
+            lcsgpu::ClaransBatch one{}, two{};
+            for (int i = 0; i < batch.n; ++i) (batch.s[i].fused ? one : two).s[(batch.s[i].fused ? one : two).n++] = batch.s[i];
+            if (rc == LCSGPU_OK && one.n) hip_ok(lcsgpu::launch_clarans_rounds_fused(one, rounds_per_look, B.stream), "CLARANS rounds (one launch each)");
+            if (rc == LCSGPU_OK && two.n) hip_ok(lcsgpu::launch_clarans_rounds(two, rounds_per_look, B.stream), "CLARANS rounds");
             read_states(now, all);
         }
         {
@@ -549,11 +554,14 @@ int lcsgpu_clarans(lcsgpu_ctx* ctx, const int32_t* ids, int32_t n_ids, int dista
     const size_t o_D = 0, o_DM = o_D + a256(pairs * 4), o_cand = o_DM + a256((size_t)n * k * 4),
                  o_st = o_cand + a256((size_t)n * 4), o_rd = o_st + a256((size_t)n * 16), o_rm = o_rd + a256(std::max<size_t>(window, 64) * 4),
                  o_wxx = o_rm + a256(std::max<size_t>(window, 64) * 4), o_wx = o_wxx + a256(window * 8), o_log = o_wx + a256(window * 8), o_state = o_log + a256((size_t)(n + 1) * 4), o_ids = o_state + 256,
-                 total = o_ids + a256((size_t)n * 4);
+                 // the second copies of the one-launch rounds (clarans_round_kernel)
+                 o_cand1 = o_ids + a256((size_t)n * 4), o_st1 = o_cand1 + a256((size_t)n * 4), o_log1 = o_st1 + a256((size_t)n * 16),
+                 o_state1 = o_log1 + a256((size_t)(n + 1) * 4), o_res2 = o_state1 + 256, total = o_res2 + 2048;
     HIP_TRY(L.d_work.reserve(total));
     HIP_TRY(L.h_small.reserve(64));
     char* base = (char*)L.d_work.p;
     HIP_TRY(hipMemsetAsync(base + o_state, 0, 256, L.stream));
+    HIP_TRY(hipMemsetAsync(base + o_state1, 0, 256 + 2048, L.stream));
     HIP_TRY(hipMemcpyAsync(base + o_ids, ids, (size_t)n * 4, hipMemcpyHostToDevice, L.stream));
     if (pairs > 0) {
         HIP_TRY(L.d_out.reserve(pairs * elem));
@@ -587,6 +595,14 @@ int lcsgpu_clarans(lcsgpu_ctx* ctx, const int32_t* ids, int32_t n_ids, int dista
     // for the broadcast walk at 2000 members / 100 medoids), so it is opt-in
     const int lists = env_int("LCSGPU_CLARANS_LISTS", 0); // (read per call: the tests switch it inside one process)
     a.lists = lists;
+    // a round as one launch (clarans_round_kernel) where every position's state fits the registers of one workgroup;
+    // LCSGPU_CLARANS_FUSED=0: the two launches of rounds 1-3 (also taken by the per-slot lists and the one-XCD chain)
+    a.cand1 = (int32_t*)(base + o_cand1);
+    a.st1 = (float4*)(base + o_st1);
+    a.log1 = (float*)(base + o_log1);
+    a.state1 = (int32_t*)(base + o_state1);
+    a.res2 = (int32_t*)(base + o_res2);
+    a.fused = (env_int("LCSGPU_CLARANS_FUSED", 1) != 0 && !lists && !env_on("LCSGPU_CLARANS_CHAIN") && n > k && n - k <= 2048) ? 1 : 0;
     // The two generators of Clustering.cpp:43-44.  Neither looks at the search state, so the host
     // runs them: gen_nodes shuffles the candidate order before every local search, gen_positions
     // yields the step positions, handed to the device as a growing array of draws.
