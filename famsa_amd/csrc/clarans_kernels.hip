@@ -938,7 +938,7 @@ __global__ __launch_bounds__(64) void clarans_apply_kernel(ClaransBatch batch)
 // Shapes: n - k <= 2048 (the state of all positions in the registers of one workgroup), n > k.
 enum { ST_FRESH = ST_ARRIVE }; // (the arrival counter of the two-launch form is free here) 1 = no round has run yet
 template <int KPT>
-__global__ __launch_bounds__(512) void clarans_round_kernel(ClaransBatch batch, int par)
+__global__ __launch_bounds__(512) void clarans_round_kernel(ClaransBatch batch, int par, int last)
 {
     const ClaransArgs& a = batch.s[blockIdx.y];
     constexpr int PER = 4;
@@ -978,8 +978,13 @@ __global__ __launch_bounds__(512) void clarans_round_kernel(ClaransBatch batch, 
     const bool cost_wg = b == (int)gridDim.x - 1;
     const int P = st0.x, done = st0.y, log_len = st0.z, rounds = st0.w, fresh = st1.x, err = st1.z;
     const int off = st2.x, stage = st2.y, first = st2.z;
+    // the last round of a look also leaves the state block where the host reads it without a copy (mapped host memory)
+    int32_t* host = last ? a.host_state : nullptr;
     if (done) { // finished in an earlier round: the state travels on unchanged (both parities stay readable)
-        if (b == 0 && tid < 16) stB[tid] = stA[tid];
+        if (b == 0 && tid < 16) {
+            stB[tid] = stA[tid];
+            if (host) host[tid] = stA[tid];
+        }
         return;
     }
     if (cost_wg) { // the running cost: + the addends the previous round's committer logged, in order
@@ -987,7 +992,10 @@ __global__ __launch_bounds__(512) void clarans_round_kernel(ClaransBatch batch, 
         if (log_len > 0) {
             c = cost_accumulate<false>(logA, log_len, c, reinterpret_cast<float*>(s_e), reinterpret_cast<float*>(s_we));
         }
-        if (tid == 0) stB[ST_COST] = __float_as_int(c);
+        if (tid == 0) {
+            stB[ST_COST] = __float_as_int(c);
+            if (host) host[ST_COST] = __float_as_int(c);
+        }
         return;
     }
     // ---- what the previous round's results mean (every workgroup, the same) ----
@@ -1218,6 +1226,12 @@ __global__ __launch_bounds__(512) void clarans_round_kernel(ClaransBatch batch, 
             stB[ST_N_USEFUL] = st3.y + (accept ? w + 1 : (err ? 0 : S_prev));
             stB[ST_N_COMMON] = st3.z;
             stB[ST_N_GENERAL] = st3.w;
+            if (host) { // (every word but the cost, which the cost workgroup leaves there)
+                host[ST_P] = P_n; host[ST_DONE] = done_n; host[ST_LOG_LEN] = log_n; host[ST_ROUNDS] = rounds_n; host[ST_FRESH] = 0;
+                host[ST_ERR] = err_n; host[ST_WIN] = 0; host[ST_OFF] = off_n; host[ST_STAGE] = stage_n; host[ST_FIRST] = first_n;
+                host[ST_N_ROUNDS] = st2.w + (fresh ? 0 : 1); host[ST_N_STEPS] = st3.x + (err ? 0 : S_prev);
+                host[ST_N_USEFUL] = st3.y + (accept ? w + 1 : (err ? 0 : S_prev)); host[ST_N_COMMON] = st3.z; host[ST_N_GENERAL] = st3.w;
+            }
         }
     }
     if (!have_step) return;
@@ -1556,8 +1570,9 @@ hipError_t launch_clarans_rounds_fused(const ClaransBatch& b, int rounds, hipStr
     }
     const dim3 grid(steps + 1, b.n), block(512); // a stage has at most STAGE_MAX steps; + the cost workgroup
     for (int r = 0; r < rounds; ++r) {
-        if (kpt <= 1) hipLaunchKernelGGL(clarans_round_kernel<1>, grid, block, 0, stream, b, r & 1);
-        else hipLaunchKernelGGL(clarans_round_kernel<2>, grid, block, 0, stream, b, r & 1);
+        const int last = r == rounds - 1 ? 1 : 0;
+        if (kpt <= 1) hipLaunchKernelGGL(clarans_round_kernel<1>, grid, block, 0, stream, b, r & 1, last);
+        else hipLaunchKernelGGL(clarans_round_kernel<2>, grid, block, 0, stream, b, r & 1, last);
     }
     return hipGetLastError();
 }

@@ -311,6 +311,7 @@ struct ClaransArgs {
     float* log1;
     int32_t* state1;
     int32_t* res2;       // [2][4][64] step results by round parity: best delta (bits), its slot, the step's position, its member
+    int32_t* host_state; // mapped host memory (16 words) the last round of a look leaves the state block in, or NULL
 };
 // Searches that are advanced together, one grid row each: however many host threads are searching,
 // a round costs two launches (evaluate, apply) in total instead of two per search -- with one launch
@@ -324,7 +325,7 @@ hipError_t launch_subset_distances(const void* lcs, int elem_size, const int32_t
                                    const float* pow_f32, int kind, int n, float* D, hipStream_t stream);
 hipError_t launch_clarans_init(const ClaransArgs& a, hipStream_t stream);
 hipError_t launch_clarans_rounds(const ClaransBatch& b, int rounds, hipStream_t stream);
-hipError_t launch_clarans_rounds_fused(const ClaransBatch& b, int rounds, hipStream_t stream); // every search of b: fused != 0
+hipError_t launch_clarans_rounds_fused(const ClaransBatch& b, int rounds, hipStream_t stream); // every search of b: fused != 0; rounds even
 hipError_t clarans_lists_ticks(unsigned long long out[8]); // LCSGPU_CLARANS_LISTS=2: phase ticks of the list evaluation
 hipError_t launch_clarans_chain(const ClaransBatch& b, int rounds, int ranks, hipStream_t stream);
 

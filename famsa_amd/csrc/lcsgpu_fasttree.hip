@@ -52,7 +52,8 @@ void clarans_drive(lcsgpu_ctx* ctx, ClaransBatcher& B, ClaransJob* mine)
     static const bool chain = env_on("LCSGPU_CLARANS_CHAIN");
     static const int chain_rounds = env_int("LCSGPU_CLARANS_CHAIN_ROUNDS", 128), chain_ranks = env_int("LCSGPU_CLARANS_CHAIN_RANKS", 17),
                      chain_batch = std::min(env_int("LCSGPU_CLARANS_CHAIN_BATCH", 8), lcsgpu::CLARANS_MAX_BATCH);
-    const int rounds_per_look = chain ? chain_rounds : 32;
+    static const int look_env = std::max(2, env_int("LCSGPU_CLARANS_LOOK", 16)) & ~1; // rounds between two looks at the done flags (even); 3 x 10^6 sequences: 16 / 32 / 64 -> 1.76-1.82 / 1.86 / 1.85-1.91 s
+    const int rounds_per_look = chain ? chain_rounds : look_env;
     const int max_batch = chain ? chain_batch : lcsgpu::CLARANS_MAX_BATCH;
     for (;;) {
         std::vector<ClaransJob*> now;
@@ -116,11 +117,31 @@ void clarans_drive(lcsgpu_ctx* ctx, ClaransBatcher& B, ClaransJob* mine)
         } else {
             // the searches of a look advance together; those whose shape takes the one-launch rounds and the others are two
             // launch sequences (FAMSA's samples all have one size: a mixed look is the exception)
+            // The one-launch rounds leave their state block in the batch's pinned (device-mapped) buffer themselves: no copy
+            // per search and look (7-8 copies of 256 B were 110 us of a 2.4 ms look).
             lcsgpu::ClaransBatch one{}, two{};
-            for (int i = 0; i < batch.n; ++i) (batch.s[i].fused ? one : two).s[(batch.s[i].fused ? one : two).n++] = batch.s[i];
+            std::vector<ClaransJob*> copied;
+            std::vector<size_t> copied_slot;
+            int32_t* hs_dev = nullptr;
+            if (hipHostGetDevicePointer((void**)&hs_dev, B.h_states.p, 0) != hipSuccess) {
+                (void)hipGetLastError();
+                hs_dev = nullptr;
+            }
+            for (int i = 0; i < batch.n; ++i) {
+                if (batch.s[i].fused) {
+                    lcsgpu::ClaransArgs& s1 = one.s[one.n++];
+                    s1 = batch.s[i];
+                    s1.host_state = hs_dev ? hs_dev + 64 * i : nullptr;
+                    if (!hs_dev) { copied.push_back(now[i]); copied_slot.push_back((size_t)i); }
+                } else {
+                    two.s[two.n++] = batch.s[i];
+                    copied.push_back(now[i]);
+                    copied_slot.push_back((size_t)i);
+                }
+            }
             if (rc == LCSGPU_OK && one.n) hip_ok(lcsgpu::launch_clarans_rounds_fused(one, rounds_per_look, B.stream), "CLARANS rounds (one launch each)");
             if (rc == LCSGPU_OK && two.n) hip_ok(lcsgpu::launch_clarans_rounds(two, rounds_per_look, B.stream), "CLARANS rounds");
-            read_states(now, all);
+            read_states(copied, copied_slot); // (waits for the stream in any case)
         }
         {
             std::lock_guard<std::mutex> lk(B.mu);
