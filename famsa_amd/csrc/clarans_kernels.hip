@@ -13,8 +13,9 @@
 //   clarans_apply_kernel  takes the FIRST step of the window whose best delta is negative, swaps, and
 //                         re-derives nearest / second-nearest medoid of every non-medoid exactly as
 //                         the reference's update branch does (one lane per non-medoid).
-// One round = these two launches; the host enqueues rounds in batches and looks at the `done` flag
-// between batches.  Ties, comparison directions and float operation order follow the reference
+// One round = these two launches -- or, since round 4 and where every position's state fits the registers of one
+// workgroup, ONE: clarans_round_kernel applies the previous round's accept inside every step's workgroup and then
+// evaluates (below).  The host enqueues rounds in batches and looks at the `done` flag between batches.  Ties, comparison directions and float operation order follow the reference
 // line by line; the running cost is summed sequentially from a per-round log of its addends.
 //
 // Layout: D = float triangle over the sample members (D[i*(i-1)/2 + j], j < i).  All search state is
