@@ -485,11 +485,10 @@ struct FastTree {
         return n_seeds;
     }
 
-    int cluster_seeds(const std::vector<int>& ids, int n_seeds, int n_samples, std::vector<int>& seed_ids,
-                      float* dist_row, uint32_t seed)
-    { // FastTree::clusterSeeds, FastTree.cpp:366-436
+    int cluster_seeds(const std::vector<int>& ids, int n_seeds, int n_samples, std::vector<int>& seed_ids, uint32_t seed)
+    { // FastTree::clusterSeeds, FastTree.cpp:366-436.  (Its first statement, the distances of member 0 to all members, only
+      // initialises the assignment sweep of makeEvaluation: make_evaluation below takes care of it.)
         const int n = (int)ids.size();
-        row_distances(ids, 0, dist_row);
         std::vector<int> sample_ids;
         std::vector<int> sample_global;
         if (n_samples >= n) {
@@ -542,8 +541,19 @@ struct FastTree {
         const int n = (int)ids.size();
         std::vector<float> dist_row(n);
         const uint32_t seed = eval_num == 0 ? std::mt19937::default_seed : (uint32_t)std::hash<uint32_t>()((uint32_t)eval_num);
-        if (!prm.use_clustering) n_seeds = random_seeds(ids, prm.subtree_size, seed_ids, dist_row.data());
-        else n_seeds = cluster_seeds(ids, prm.subtree_size, prm.sample_size, seed_ids, dist_row.data(), seed);
+        // the row of member 0 (= seed 0): randomSeeds needs it to choose its seeds; after clusterSeeds it is only the
+        // start of the sweep -- one request fewer per split when the engine does the sweep: seed 0 joins it, from +inf
+        bool have_row0 = false;
+        if (!prm.use_clustering) {
+            n_seeds = random_seeds(ids, prm.subtree_size, seed_ids, dist_row.data());
+            have_row0 = true;
+        } else {
+            n_seeds = cluster_seeds(ids, prm.subtree_size, prm.sample_size, seed_ids, seed);
+            if (seed_ids[0] != 0) { // (cannot happen: slot 0 of the search is pinned to member 0 -- but then the row is needed)
+                row_distances(ids, 0, dist_row.data());
+                have_row0 = true;
+            }
+        }
 
         assignments.assign(n, 0);
         // seeds 1.. x all, in column chunks to bound host memory; per column the seeds are visited
@@ -551,10 +561,24 @@ struct FastTree {
         std::vector<int> refs(n_seeds - 1);
         for (int k = 1; k < n_seeds; ++k) refs[k - 1] = ids[seed_ids[k]];
         bool on_device = false;
-        if (n_seeds > 1) { // the sweep inside the engine when it offers that: 8 bytes per column come back
-            Scope t(g_phase.assign);
-            OffCpu w;
-            on_device = src.assign_seeds(refs.data(), n_seeds - 1, ids.data(), n, (int)D, 1, dist_row.data(), assignments.data());
+        if (have_row0) {
+            if (n_seeds > 1) { // the sweep inside the engine when it offers that: 8 bytes per column come back
+                Scope t(g_phase.assign);
+                OffCpu w;
+                on_device = src.assign_seeds(refs.data(), n_seeds - 1, ids.data(), n, (int)D, 1, dist_row.data(), assignments.data());
+            }
+        } else {
+            // d(seed 0, j) < +inf for every j, so starting the sweep one seed earlier from +inf leaves exactly the row the
+            // reference starts from (assignment 0), then the same strict-< updates in the same order
+            std::vector<int> all_refs(n_seeds);
+            for (int k = 0; k < n_seeds; ++k) all_refs[k] = ids[seed_ids[k]];
+            std::fill(dist_row.begin(), dist_row.end(), std::numeric_limits<float>::infinity());
+            {
+                Scope t(g_phase.assign);
+                OffCpu w;
+                on_device = src.assign_seeds(all_refs.data(), n_seeds, ids.data(), n, (int)D, 0, dist_row.data(), assignments.data());
+            }
+            if (!on_device) row_distances(ids, 0, dist_row.data()); // no sweep in the engine: the reference's own first statement
         }
         const int chunk = 1 << 18;
         LcsBuf buf;
