@@ -162,7 +162,7 @@ def test_stage_size_does_not_change_the_search(stage0):
     import os
     import subprocess
     import sys
-    if os.environ.get("LCSGPU_CLARANS_STAGE0") or os.environ.get("LCSGPU_CLARANS_CHAIN") or os.environ.get("LCSGPU_CLARANS_LISTS"):
+    if os.environ.get("LCSGPU_CLARANS_STAGE0") or os.environ.get("LCSGPU_CLARANS_CHAIN") or os.environ.get("LCSGPU_CLARANS_LISTS") or os.environ.get("LCSGPU_CLARANS_FUSED"):
         pytest.skip("already inside a nested run")
     env = dict(os.environ)
     env["LCSGPU_CLARANS_STAGE0"] = stage0
@@ -179,7 +179,7 @@ def test_one_xcd_chain_kernel_gives_the_same_searches():
     import os
     import subprocess
     import sys
-    if os.environ.get("LCSGPU_CLARANS_CHAIN") or os.environ.get("LCSGPU_CLARANS_STAGE0") or os.environ.get("LCSGPU_CLARANS_LISTS"):
+    if os.environ.get("LCSGPU_CLARANS_CHAIN") or os.environ.get("LCSGPU_CLARANS_STAGE0") or os.environ.get("LCSGPU_CLARANS_LISTS") or os.environ.get("LCSGPU_CLARANS_FUSED"):
         pytest.skip("already inside a nested run")
     env = dict(os.environ)
     env["LCSGPU_CLARANS_CHAIN"] = "1"
@@ -198,10 +198,28 @@ def test_per_slot_list_evaluation_gives_the_same_searches():
     import os
     import subprocess
     import sys
-    if os.environ.get("LCSGPU_CLARANS_LISTS") or os.environ.get("LCSGPU_CLARANS_CHAIN") or os.environ.get("LCSGPU_CLARANS_STAGE0"):
+    if os.environ.get("LCSGPU_CLARANS_LISTS") or os.environ.get("LCSGPU_CLARANS_CHAIN") or os.environ.get("LCSGPU_CLARANS_STAGE0") or os.environ.get("LCSGPU_CLARANS_FUSED"):
         pytest.skip("already inside a nested run")
     env = dict(os.environ)
     env["LCSGPU_CLARANS_LISTS"] = "1"
+    p = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-x", "-k",
+                        "matches_reference or concurrent"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       text=True)
+    assert p.returncode == 0 and " passed" in p.stdout, p.stdout[-3000:]
+
+
+def test_two_launch_rounds_give_the_same_searches():
+    """LCSGPU_CLARANS_FUSED=0: a round as the two launches of rounds 1-3 (evaluate, apply) instead of one launch whose
+    step workgroups apply the previous accept themselves (clarans_round_kernel, the default since round 4 where all
+    positions fit one workgroup's registers) -- the form that shapes beyond 2048 non-medoids still take.  Every shape of this
+    file against the reference's CLARANS again, and the concurrent searches."""
+    import os
+    import subprocess
+    import sys
+    if any(os.environ.get(v) for v in ("LCSGPU_CLARANS_FUSED", "LCSGPU_CLARANS_LISTS", "LCSGPU_CLARANS_CHAIN", "LCSGPU_CLARANS_STAGE0")):
+        pytest.skip("already inside a nested run")
+    env = dict(os.environ)
+    env["LCSGPU_CLARANS_FUSED"] = "0"
     p = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-x", "-k",
                         "matches_reference or concurrent"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                        text=True)
