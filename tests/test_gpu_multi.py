@@ -208,6 +208,18 @@ def test_cli_two_contexts_trees(tmp_path, case, gt):
     assert open(out, "rb").read() == open(os.path.join(G, gold), "rb").read()
 
 
+def test_cli_verbose_reports_the_transport(tmp_path):
+    """`famsa-gpu -v -gpu a,b`: the `gpu.transport=` lines of lcsgpu_multi_transport -- how the contexts reach each other and
+    which key exchange the single-linkage call used (on one device: peer copies, and why)."""
+    out = str(tmp_path / "t.dnd")
+    p = cli("-v", "-gpu", "0,0", "-gt", "sl", "-gt_export", os.path.join(G, "hemopexin", "hemopexin"), out)
+    lines = [l for l in p.stderr.splitlines() if l.startswith("gpu.transport=")]
+    assert any("contexts: 2 on devices 0 0" in l for l in lines), p.stderr[-1500:]
+    assert any("same-device x2" in l for l in lines)
+    assert any("key exchange of the last single-linkage call: peer copies (automatic" in l for l in lines)
+    assert open(out, "rb").read() == open(os.path.join(G, "hemopexin", "sl.dnd"), "rb").read()
+
+
 def test_cli_three_contexts_dist_export(tmp_path):
     out = str(tmp_path / "d.csv")
     cli("-gpu", "0,0,0", "-dist_export", os.path.join(G, "hemopexin", "hemopexin"), out)
