@@ -346,6 +346,10 @@ public:
             if (out.wide) out.v32[k - a] = all_->v32[offset_ + k]; else out.v16[k - a] = all_->v16[offset_ + k];
         }
     }
+    const void* triangle_view() const override
+    {
+        return all_->wide ? (const void*)(all_->v32.data() + offset_) : (const void*)(all_->v16.data() + offset_);
+    }
 
 private:
     std::shared_ptr<const LcsBuf> all_;

@@ -46,6 +46,9 @@ public:
     virtual void triangle_ids(const int* ids, int n_ids, LcsBuf& out);
     // values need 32 bits (some sequence longer than 65535 residues); sources cache this
     virtual bool wide() const;
+    // The whole lower triangle where the source already holds it in host memory (uint16, or uint32 if wide()):
+    // element i*(i-1)/2 + j, j < i.  NULL = not resident; call triangle().
+    virtual const void* triangle_view() const { return nullptr; }
     // a hint: requests will come from this many host threads at once (the FastTree pool)
     virtual void expect_threads(int /*n_threads*/) {}
     // Prim's MST computed by the source itself (the GPU engine does it on the device): n-1 edges

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <emmintrin.h>
 #include <fstream>
 #include <limits>
 #include <queue>
@@ -427,6 +428,250 @@ void upgma_tree(std::vector<float>& D, int n, tree_structure& tree)
     }
 }
 
+// ---- the same tree from a SQUARE float matrix: the form the leaves of the FastTree recursion take -------------------------
+// A leaf is at most `threshold` (2000) sequences and there are thousands of them, so what counts is the constant per matrix
+// element, not the order of growth: the triangle form above walks a linked list and reads down a column (one cache line per
+// element) for every row beyond the merged one.  Here the matrix is m x ld floats, symmetric: a merge averages two contiguous
+// rows four elements at a time (SSE2, part of the x86-64 baseline -- the same IEEE add / mul / min / div, one rounding each,
+// no contraction), rows that are gone are skipped by a lane mask instead of a list, the new row is mirrored into its column by
+// plain stores, and the next pick comes from a heap of (key, row) with lazy deletion (a row's key never changes while it
+// lives, see above).  Same picks, same float operations in the same order per element, same ties.
+constexpr int UPGMA_SQUARE_MAX = 4096; // 64 MB of floats; above that the triangle form
+
+inline float hmin4(__m128 v)
+{
+    v = _mm_min_ps(v, _mm_shuffle_ps(v, v, _MM_SHUFFLE(1, 0, 3, 2)));
+    v = _mm_min_ps(v, _mm_shuffle_ps(v, v, _MM_SHUFFLE(2, 3, 0, 1)));
+    return _mm_cvtss_f32(v);
+}
+inline __m128 select4(__m128 mask, __m128 a, __m128 b) { return _mm_or_ps(_mm_and_ps(mask, a), _mm_andnot_ps(mask, b)); }
+
+// first strict minimum below BIG of row[j] over the columns whose mask is set, ascending j: (value, column) or (BIG, NONE)
+inline void masked_first_min(const float* row, const uint32_t* mask, int ld, float big, float& value, int& column)
+{
+    const __m128 bigv = _mm_set1_ps(big);
+    __m128 best = bigv;
+    for (int j = 0; j < ld; j += 4)
+        best = _mm_min_ps(best, select4(_mm_castsi128_ps(_mm_loadu_si128((const __m128i*)(mask + j))), _mm_loadu_ps(row + j), bigv));
+    value = hmin4(best);
+    column = 0x7FFFFFFF;
+    if (!(value < big)) { value = big; return; }
+    const __m128 want = _mm_set1_ps(value);
+    for (int j = 0; j < ld; j += 4) {
+        const __m128 c = select4(_mm_castsi128_ps(_mm_loadu_si128((const __m128i*)(mask + j))), _mm_loadu_ps(row + j), bigv);
+        const int hit = _mm_movemask_ps(_mm_cmpeq_ps(c, want));
+        if (hit) { column = j + __builtin_ctz(hit); return; }
+    }
+}
+
+// pow(i, 0.75) as float, i <= upto: one table per thread, grown on demand (Transform<float, indel075_div_lcs>::pow075)
+inline const float* pow075_table(size_t upto)
+{
+    static thread_local std::vector<float> table;
+    if (upto >= table.size()) {
+        const size_t from = table.size();
+        table.resize(upto + 1);
+        for (size_t i = from; i <= upto; ++i) table[i] = (float)std::pow((double)(uint32_t)i, 0.75);
+    }
+    return table.data();
+}
+
+// out[j] = Transform<float, D>(l[j], len_i, lens[j]), j < count (reference tree/AbstractTreeGenerator.hpp:28-82): the division
+// four at a time, the table values gathered one by one; a pair without a common residue gets the reference's FLT_MAX
+template <Distance D, class E>
+void transform_row(const E* l, uint32_t len_i, const uint32_t* lens, int count, const float* pw, float* out)
+{
+    static_assert(D != Distance::pairwise_identity, "tree distances only");
+    const __m128 none = _mm_set1_ps(zero_lcs_distance<float>());
+    int j = 0;
+    const __m128i vlen = _mm_set1_epi32((int)len_i);
+    for (; j + 4 <= count; j += 4) {
+        __m128i li;
+        if (sizeof(E) == 2) li = _mm_unpacklo_epi16(_mm_loadl_epi64((const __m128i*)(l + j)), _mm_setzero_si128());
+        else li = _mm_loadu_si128((const __m128i*)(l + j));
+        const __m128i indel = _mm_sub_epi32(_mm_add_epi32(vlen, _mm_loadu_si128((const __m128i*)(lens + j))), _mm_add_epi32(li, li));
+        __m128 num;
+        if (D == Distance::indel075_div_lcs) {
+            alignas(16) uint32_t ix[4];
+            _mm_store_si128((__m128i*)ix, indel);
+            num = _mm_set_ps(pw[ix[3]], pw[ix[2]], pw[ix[1]], pw[ix[0]]);
+        } else {
+            num = _mm_cvtepi32_ps(indel);
+        }
+        const __m128 q = _mm_div_ps(num, _mm_cvtepi32_ps(li));
+        const __m128 is_zero = _mm_castsi128_ps(_mm_cmpeq_epi32(li, _mm_setzero_si128()));
+        _mm_storeu_ps(out + j, select4(is_zero, none, q));
+    }
+    for (; j < count; ++j) { // the tail, element by element
+        const uint32_t lj = l[j], indel = len_i + lens[j] - 2 * lj;
+        const float num = D == Distance::indel075_div_lcs ? pw[indel] : (float)indel;
+        out[j] = lj ? num / (float)lj : zero_lcs_distance<float>();
+    }
+}
+
+template <bool MODIFIED, Distance D>
+void upgma_square(LcsSource& src, tree_structure& tree)
+{
+    constexpr float BIG = 1e29f;
+    constexpr int NONE = 0x7FFFFFFF;
+    const int m = src.n();
+    int dim = m, ld = (m + 3) & ~3; // rows in the matrix (live or not) and its row pitch; both shrink when the matrix is packed
+    std::vector<uint32_t> lens(ld, 0u);
+    uint32_t longest = 0;
+    for (int i = 0; i < m; ++i) longest = std::max(longest, lens[i] = src.length(i));
+    const float* pw = D == Distance::indel075_div_lcs ? pow075_table((size_t)2 * longest) : nullptr;
+    static thread_local std::vector<float> matrix; // one per pool thread, as large as its largest leaf so far
+    if (matrix.size() < (size_t)m * ld) matrix.resize((size_t)m * ld);
+    float* const M = matrix.data();
+    std::vector<float> key(ld, BIG);
+    std::vector<int> partner(ld, NONE), node(m), live(m);
+
+    // 1. the distances, row by row over the lower triangle, and while a row is hot every vertex's first strict minimum in
+    //    ascending order of the other vertex: row x settles x against the y < x, then offers itself to every y < x -- so a
+    //    vertex sees its own row first and the rows below it in ascending order, as the reference's sweep does
+    {
+        LcsBuf own;
+        const void* view = src.triangle_view();
+        bool wide = src.wide();
+        if (!view) {
+            src.triangle(0, m, own);
+            wide = own.wide;
+            view = own.wide ? (const void*)own.v32.data() : (const void*)own.v16.data();
+        }
+        for (int i = 0; i < m; ++i) {
+            float* const row = M + (size_t)i * ld;
+            std::fill(row + i, row + std::min(ld, i + 4), BIG); // what the sweep below reads past its last column; the rest: the mirror
+            if (i == 0) continue;
+            const size_t first = (size_t)i * (i - 1) / 2;
+            if (wide) transform_row<D>((const uint32_t*)view + first, lens[i], lens.data(), i, pw, row);
+            else transform_row<D>((const uint16_t*)view + first, lens[i], lens.data(), i, pw, row);
+            __m128 best = _mm_set1_ps(BIG);
+            const __m128i vi = _mm_set1_epi32(i);
+            for (int j = 0; j < i; j += 4) { // columns i .. : BIG, never below a key
+                const __m128 d = _mm_loadu_ps(row + j), k = _mm_loadu_ps(key.data() + j);
+                best = _mm_min_ps(best, d);
+                const __m128 lt = _mm_cmplt_ps(d, k);
+                _mm_storeu_ps(key.data() + j, select4(lt, d, k));
+                const __m128i pj = _mm_loadu_si128((const __m128i*)(partner.data() + j)), ltm = _mm_castps_si128(lt);
+                _mm_storeu_si128((__m128i*)(partner.data() + j), _mm_or_si128(_mm_and_si128(ltm, vi), _mm_andnot_si128(ltm, pj)));
+            }
+            const float value = hmin4(best);
+            if (value < BIG) {
+                const __m128 want = _mm_set1_ps(value);
+                for (int j = 0; j < i; j += 4) {
+                    const int hit = _mm_movemask_ps(_mm_cmpeq_ps(_mm_loadu_ps(row + j), want));
+                    if (hit) { partner[i] = j + __builtin_ctz(hit); break; }
+                }
+                key[i] = value;
+            }
+        }
+    }
+    constexpr int TB = 32;
+    for (int i0 = 0; i0 < m; i0 += TB)
+        for (int j0 = 0; j0 <= i0; j0 += TB)
+            for (int i = i0; i < std::min(m, i0 + TB); ++i)
+                for (int j = j0; j < std::min(i, j0 + TB); ++j) M[(size_t)j * ld + i] = M[(size_t)i * ld + j];
+
+    // 2. the order of the picks: a heap of (key, row), entries of rows that left or were re-created are dropped when they surface
+    std::vector<uint32_t> mask(ld, 0u);
+    struct Entry { float key; int row, node; };
+    auto later = [](const Entry& a, const Entry& b) { return a.key > b.key || (a.key == b.key && a.row > b.row); };
+    std::vector<Entry> heap;
+    heap.reserve((size_t)2 * m);
+    for (int x = 0; x < m; ++x) {
+        node[x] = live[x] = x;
+        mask[x] = ~0u;
+        if (key[x] < BIG) heap.push_back(Entry{key[x], x, x});
+    }
+    std::make_heap(heap.begin(), heap.end(), later);
+    std::vector<int> place; // packing: old row -> new row
+
+    // 3. the merges
+    const __m128 bigv = _mm_set1_ps(BIG), half = _mm_set1_ps(0.5f), c005 = _mm_set1_ps(0.05f), c09 = _mm_set1_ps(0.9f);
+    for (int made = 0; made < m - 1; ++made) {
+        if ((int)live.size() * 2 <= dim && dim >= 128) {
+            // Half of the rows are gone: pack the live ones (their order, which settles every tie, stays) so that a merge
+            // sweeps and mirrors half as much and the matrix drops into the next cache level.  In place: every element moves
+            // towards the front, rows and columns in ascending order.
+            const int nl = (int)live.size(), nld = (nl + 3) & ~3;
+            place.assign(dim, NONE);
+            for (int r = 0; r < nl; ++r) place[live[r]] = r;
+            for (int r = 0; r < nl; ++r) {
+                const float* from = M + (size_t)live[r] * ld;
+                float* to = M + (size_t)r * nld;
+                for (int c = 0; c < nl; ++c) to[c] = from[live[c]];
+            }
+            heap.clear();
+            for (int r = 0; r < nl; ++r) {
+                const int o = live[r];
+                key[r] = key[o];
+                partner[r] = partner[o] == NONE ? NONE : place[partner[o]];
+                node[r] = node[o];
+                if (key[r] < BIG) heap.push_back(Entry{key[r], r, node[r]});
+            }
+            std::make_heap(heap.begin(), heap.end(), later);
+            for (int r = 0; r < nld; ++r) {
+                mask[r] = r < nl ? ~0u : 0u;
+                if (r >= nl) partner[r] = NONE;
+            }
+            for (int r = 0; r < nl; ++r) live[r] = r;
+            dim = nl;
+            ld = nld;
+        }
+        while (!heap.empty() && (mask[heap.front().row] == 0u || node[heap.front().row] != heap.front().node)) {
+            std::pop_heap(heap.begin(), heap.end(), later);
+            heap.pop_back();
+        }
+        if (heap.empty() || partner[heap.front().row] == NONE)
+            throw std::runtime_error("UPGMA: no finite nearest neighbour (a pair with LCS 0?) -- the reference's "
+                                     "algorithm is undefined for this input");
+        const int keep = heap.front().row, gone = partner[keep];
+        std::pop_heap(heap.begin(), heap.end(), later);
+        heap.pop_back();
+        mask[gone] = 0u;
+        live.erase(std::lower_bound(live.begin(), live.end(), gone));
+        mask[keep] = 0u; // not a candidate of its own row
+        float* const rk = M + (size_t)keep * ld;
+        const float* const rg = M + (size_t)gone * ld;
+        __m128 best = bigv;
+        for (int j = 0; j < ld; j += 4) {
+            const __m128 x = _mm_loadu_ps(rk + j), y = _mm_loadu_ps(rg + j);
+            const __m128 v = MODIFIED ? _mm_add_ps(_mm_mul_ps(c005, _mm_add_ps(x, y)), _mm_mul_ps(c09, _mm_min_ps(x, y)))
+                                      : _mm_mul_ps(_mm_add_ps(x, y), half);
+            _mm_storeu_ps(rk + j, v);
+            best = _mm_min_ps(best, select4(_mm_castsi128_ps(_mm_loadu_si128((const __m128i*)(mask.data() + j))), v, bigv));
+        }
+        float value = hmin4(best);
+        int column = NONE;
+        if (value < BIG) {
+            const __m128 want = _mm_set1_ps(value);
+            for (int j = 0; j < ld; j += 4) {
+                const __m128 c = select4(_mm_castsi128_ps(_mm_loadu_si128((const __m128i*)(mask.data() + j))), _mm_loadu_ps(rk + j), bigv);
+                const int hit = _mm_movemask_ps(_mm_cmpeq_ps(c, want));
+                if (hit) { column = j + __builtin_ctz(hit); break; }
+            }
+        } else {
+            value = BIG;
+        }
+        mask[keep] = ~0u;
+        for (const int j : live) M[(size_t)j * ld + keep] = rk[j]; // the mirror (j == keep: the diagonal, never a candidate)
+        const __m128i vg = _mm_set1_epi32(gone), vk = _mm_set1_epi32(keep);
+        for (int j = 0; j < ld; j += 4) { // rows whose stored neighbour was the row that left now name the merged row
+            const __m128i p = _mm_loadu_si128((const __m128i*)(partner.data() + j));
+            const __m128i eq = _mm_cmpeq_epi32(p, vg);
+            _mm_storeu_si128((__m128i*)(partner.data() + j), _mm_or_si128(_mm_and_si128(eq, vk), _mm_andnot_si128(eq, p)));
+        }
+        tree.emplace_back(node[keep], node[gone]);
+        node[keep] = m + made;
+        key[keep] = value;
+        partner[keep] = column;
+        if (value < BIG) {
+            heap.push_back(Entry{value, keep, node[keep]});
+            std::push_heap(heap.begin(), heap.end(), later);
+        }
+    }
+}
+
 // -gt nj.  NeighborJoining::computeTree (reference tree/NeighborJoining.cpp:33-118): q(i, j) = (m - 2) d(i, j) - s_i - s_j over
 // the live clusters in ascending order of their rows, first strict minimum; the sums s are float accumulations whose order
 // is part of the result.  Here the live rows are a linked list in index order (the reference erases from a vector: the same
@@ -485,6 +730,10 @@ void build_partial_d(LcsSource& src, GT method, tree_structure& tree)
         std::vector<int32_t> left, right;
         if (src.upgma_nodes((int)D, method == GT::UPGMA_modified, left, right)) { // merges ran on the device
             for (int i = 0; i < n - 1; ++i) tree.emplace_back(left[i], right[i]);
+            break;
+        }
+        if (n <= UPGMA_SQUARE_MAX && !getenv("FAMSA_UPGMA_TRIANGLE")) { // the leaves of the FastTree recursion
+            if (method == GT::UPGMA) upgma_square<false, D>(src, tree); else upgma_square<true, D>(src, tree);
             break;
         }
         std::vector<float> dist;

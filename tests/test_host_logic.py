@@ -287,3 +287,34 @@ def test_gzip_input_is_read_like_plain_text(host, tmp_path):
     open(bad, "wb").write(gzip.compress(raw)[: 5000])
     with pytest.raises(RuntimeError):
         host.records(bad, 2)
+
+
+@pytest.mark.parametrize("n,spread,zeros", [(130, 2, False), (257, 3, True), (700, 3, False), (1300, 40, True)])
+def test_the_two_host_upgma_forms_build_the_same_tree(host, tmp_path, monkeypatch, n, spread, zeros):
+    """UPGMA over a host-side matrix has two forms (trees.cpp): the triangle walk and, up to 4096 rows -- every leaf
+    of the FastTree recursion --, a square float matrix with SSE sweeps, a lazy heap and packing when half of the
+    rows are gone.  Same tree on tie-heavy random 'LCS' values (few distinct distances: every tie rule is hit), with
+    pairs that share nothing (distance FLT_MAX, never picked while a finite one is left) and across the packing
+    thresholds.  (Both forms against the reference itself: test_differential.py, n <= 257.)"""
+    rng = np.random.Generator(np.random.PCG64(77 + n))
+    lens = np.sort(rng.integers(250, 301, size=n))[::-1]
+    fasta = str(tmp_path / "in.fasta")
+    with open(fasta, "w") as f:
+        for i, L in enumerate(lens):
+            f.write(f">s{i}\n" + "".join("ACDEFGHIKLMNPQRSTVWY"[c] for c in rng.integers(0, 20, size=int(L))) + "\n")
+    m = rng.integers(90, 90 + spread, size=(n, n), dtype=np.uint32)
+    m = np.tril(m, -1)
+    if zeros:  # a few sequences share nothing with a few others
+        for a, b in rng.integers(1, n, size=(n // 20, 2)):
+            if a != b:
+                m[max(a, b), min(a, b)] = 0
+    m = np.ascontiguousarray(m + m.T)
+    m[np.arange(n), np.arange(n)] = lens
+    for gt in ("upgma", "upgma_modified"):
+        for dist in ("indel075_div_lcs", "indel_div_lcs"):
+            monkeypatch.delenv("FAMSA_UPGMA_TRIANGLE", raising=False)
+            square_form = host.tree_from_matrix(fasta, m, gt, distance=dist, keep_duplicates=True)
+            monkeypatch.setenv("FAMSA_UPGMA_TRIANGLE", "1")
+            triangle_form = host.tree_from_matrix(fasta, m, gt, distance=dist, keep_duplicates=True)
+            assert square_form == triangle_form, (gt, dist)
+            assert square_form.count(b",") == n - 1
