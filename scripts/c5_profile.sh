@@ -1,0 +1,18 @@
+#!/bin/bash
+# dev tool (GPU box): one -medoidtree -gt upgma run at N family sequences with the stage timers (-v) and the
+# thread-second accounts of the recursion (FAMSA_GPU_PROFILE=1) -> gpurun_out/c5_profile.txt
+cd "$(dirname "$0")/.."
+mkdir -p gpurun_out
+N=${1:-3000000}
+python - <<PY
+import sys, os
+sys.path.insert(0, '.')
+from famsa_amd import seqio
+f = "/tmp/fam_$N.fasta"
+if not os.path.exists(f):
+    seqio.family_fasta($N, 300, f)
+PY
+for rep in 1 2; do
+  t0=$(date +%s.%N); FAMSA_GPU_PROFILE=1 timeout 300 famsa_amd/famsa-gpu -v -medoidtree -gt upgma -gt_export /tmp/fam_$N.fasta /tmp/fam_$N.dnd 2> gpurun_out/c5_profile.txt; python3 -c "import time,sys; print('wall=%.3f s' % (time.time() - float(sys.argv[1])))" $t0 >> gpurun_out/c5_profile.txt
+done
+cat gpurun_out/c5_profile.txt
