@@ -236,9 +236,27 @@ template <typename T, int KIND, bool POW_LDS>
 __global__ __launch_bounds__(256) void boruvka_col_kernel(BoruvkaArgs a)
 {
     constexpr int UNR = 16; // rows per batch (two batches in flight)
-    const int c0 = blockIdx.x * COLS_PER_WG;
+    // Which (column block, chunk) this workgroup does.  Rows of the triangle start at any 2-byte offset, so the 512 B a
+    // workgroup reads of a row share their first and last cache line with the neighbouring column blocks: fetched once if
+    // the neighbours run on the same XCD at about the same time, once per L2 otherwise (round 3 measured 1.34 x the
+    // triangle per pass).  Workgroups go to the XCDs round-robin in dispatch order; the dispatch index is rearranged so
+    // that every XCD gets runs of XCD_RUN neighbouring column blocks (runs themselves still round-robin: the work per
+    // column block grows along the grid, an XCD must not get one contiguous eighth of it).
+    constexpr unsigned XCD_RUN = 8;
+    int bx = blockIdx.x, by = blockIdx.y;
+    {
+        const unsigned gx = gridDim.x, total = gx * gridDim.y, lin = blockIdx.y * gx + blockIdx.x;
+        const unsigned whole = total - total % (8u * XCD_RUN); // the tail keeps its place
+        if (lin < whole) {
+            const unsigned xcd = lin & 7u, slot = lin >> 3;
+            const unsigned moved = ((slot / XCD_RUN) * 8u + xcd) * XCD_RUN + slot % XCD_RUN;
+            bx = (int)(moved % gx);
+            by = (int)(moved / gx);
+        }
+    }
+    const int c0 = bx * COLS_PER_WG;
     const int v = c0 + threadIdx.x;
-    const int chunk = blockIdx.y;
+    const int chunk = by;
     const int u0 = a.r0 + chunk * a.rows_per_chunk, u1 = min(a.r1, u0 + a.rows_per_chunk);
     if (u0 >= u1 || c0 + 1 >= u1) return; // empty chunk, or every column of this workgroup lies at or above its last row: fold skips it
     extern __shared__ double s_pow[];
