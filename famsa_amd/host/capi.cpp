@@ -165,6 +165,22 @@ long famsa_host_records(const char* fasta, int n_threads, char* ids_buf, long id
 
 int famsa_host_format_distance(double v, char* out) { return format_distance(v, out); }
 
+// Newick text of a tree given as child arrays (node i < n_leaves: a leaf named names[i]; node i >= n_leaves: children
+// left[i - n_leaves], right[i - n_leaves]; the last node is the root), after GuideTree::fromUnique over `sorted2unique`
+// when that is not NULL (then the arrays describe the tree of the unique sequences and names has one entry per record).
+long famsa_host_newick(const int32_t* left, const int32_t* right, int n_leaves, int n_internal, const char* const* names,
+                       int n_names, const int32_t* sorted2unique, char* out, long cap)
+{
+    try {
+        tree_structure tree((size_t)n_leaves, node_t(-1, -1));
+        for (int i = 0; i < n_internal; ++i) tree.emplace_back(left[i], right[i]);
+        if (sorted2unique) tree_from_unique(tree, std::vector<int>(sorted2unique, sorted2unique + n_names));
+        return give(tree_to_newick(tree, std::vector<const char*>(names, names + n_names)), out, cap);
+    } catch (const std::exception& e) {
+        return fail(e);
+    }
+}
+
 // The host CLARANS search over a caller-supplied float distance triangle (tests compare the device search with it).
 int famsa_host_clarans(const float* triangle, int n_elems, int n_medoids, int n_fixed, float explore_fraction,
                        int num_local, int* medoids)

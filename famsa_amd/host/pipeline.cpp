@@ -15,8 +15,8 @@ std::string guide_tree_newick(const SeqSet& s, const WorkSet& w, LcsSource& src,
 {
     const double t0 = now_s();
     // names of the leaves = ids in sorted order (the reference reorders its sequence vector)
-    std::vector<std::string> names(w.n_sorted());
-    for (int k = 0; k < w.n_sorted(); ++k) names[k] = s.ids[w.sorted2input[k]];
+    std::vector<const char*> names(w.n_sorted());
+    for (int k = 0; k < w.n_sorted(); ++k) names[k] = s.ids[w.sorted2input[k]].c_str();
     if (w.n_unique() == 1) return std::string(); // the reference skips the tree stage entirely (msa.cpp:549-556)
     tree_structure tree;
     // CFAMSA::adjustParams (msa.cpp:83-88): the heuristic is dropped for inputs below the threshold

@@ -145,21 +145,6 @@ std::vector<char> gunzip(const unsigned char* in, size_t size, const std::string
     return out;
 }
 
-// FAMSA's working order as a strict weak order on input indices; the index breaks ties, which
-// makes a plain sort give the stable sort's result
-struct OrderLess {
-    const SeqSet& s;
-    bool operator()(int a, int b) const
-    {
-        const uint32_t la = s.length(a), lb = s.length(b);
-        if (la != lb) return la > lb;
-        // the reference compares symbol_t = (signed) char; codes are < 32 so unsigned bytes agree
-        const int c = la ? memcmp(s.data(a), s.data(b), la) : 0;
-        if (c != 0) return c < 0;
-        return a < b;
-    }
-};
-
 } // namespace
 
 SeqSet from_records(const std::vector<std::string>& ids, const std::vector<std::string>& residues)
@@ -254,44 +239,94 @@ SeqSet load_fasta(const std::string& path, int n_threads)
     return s;
 }
 
-std::vector<int> famsa_order(const SeqSet& s, int n_threads)
+// The order is the reference's stable sort by (length descending, residue codes ascending), input index last.  Sorting the
+// indices with a comparator that looks the sequences up costs two cache misses per comparison; here every record gets a
+// 16-byte key first -- length, the first 12 residue codes as one big-endian 60-bit number (codes are < 32), the index --
+// and the comparator touches the sequences only where length and prefix tie.  The index breaks the last tie, which makes a
+// plain sort give the stable sort's result.  (The reference compares symbol_t = signed char; codes are < 32, so unsigned
+// bytes agree.)
+namespace {
+struct OrderKey {
+    uint64_t prefix;
+    uint32_t len;
+    int idx;
+};
+constexpr uint32_t KEY_RESIDUES = 12;
+struct KeyLess {
+    const SeqSet& s;
+    bool operator()(const OrderKey& a, const OrderKey& b) const
+    {
+        if (a.len != b.len) return a.len > b.len;
+        if (a.prefix != b.prefix) return a.prefix < b.prefix;
+        if (a.len > KEY_RESIDUES) {
+            const int c = memcmp(s.data(a.idx) + KEY_RESIDUES, s.data(b.idx) + KEY_RESIDUES, a.len - KEY_RESIDUES);
+            if (c != 0) return c < 0;
+        }
+        return a.idx < b.idx;
+    }
+};
+} // namespace
+
+// order + (optionally) for every position whether its record holds the same residues as the one before it
+static std::vector<int> order_and_repeats(const SeqSet& s, int n_threads, std::vector<uint8_t>* repeats)
 {
     if (n_threads <= 0) n_threads = default_host_threads();
     const int n = (int)s.size();
-    std::vector<int> order(n);
-    std::iota(order.begin(), order.end(), 0);
-    const OrderLess less{s};
+    std::vector<OrderKey> keys(n);
     // sorted runs in parallel, then rounds of pairwise merges
     int runs = 1;
     while (runs < n_threads && n / (runs * 2) >= 4096) runs *= 2;
     std::vector<int> cut(runs + 1);
     for (int r = 0; r <= runs; ++r) cut[r] = (int)((int64_t)n * r / runs);
-    parallel_for(runs, n_threads, [&](int r) { std::sort(order.begin() + cut[r], order.begin() + cut[r + 1], less); });
-    std::vector<int> tmp(runs > 1 ? n : 0);
+    const KeyLess less{s};
+    parallel_for(runs, n_threads, [&](int r) {
+        for (int i = cut[r]; i < cut[r + 1]; ++i) {
+            const uint32_t len = s.length(i);
+            const uint8_t* d = len ? (const uint8_t*)s.data(i) : nullptr;
+            uint64_t prefix = 0;
+            for (uint32_t k = 0; k < KEY_RESIDUES; ++k) prefix = (prefix << 5) | (k < len ? (uint64_t)(d[k] & 31) : 0u);
+            keys[i] = OrderKey{prefix, len, i};
+        }
+        std::sort(keys.begin() + cut[r], keys.begin() + cut[r + 1], less);
+    });
+    std::vector<OrderKey> tmp(runs > 1 ? n : 0);
     for (int width = 1; width < runs; width *= 2) {
         const int pairs = runs / (2 * width);
         parallel_for(pairs, n_threads, [&](int q) {
             const int a = cut[2 * width * q], m = cut[2 * width * q + width], b = cut[2 * width * (q + 1)];
-            std::merge(order.begin() + a, order.begin() + m, order.begin() + m, order.begin() + b, tmp.begin() + a, less);
+            std::merge(keys.begin() + a, keys.begin() + m, keys.begin() + m, keys.begin() + b, tmp.begin() + a, less);
         });
-        order.swap(tmp);
+        keys.swap(tmp);
     }
+    std::vector<int> order(n);
+    if (repeats) repeats->assign(n, 0);
+    const int slices = std::max(1, std::min(n_threads, n / 65536));
+    parallel_for(slices, n_threads, [&](int t) {
+        const int k0 = (int)((int64_t)n * t / slices), k1 = (int)((int64_t)n * (t + 1) / slices);
+        for (int k = k0; k < k1; ++k) {
+            order[k] = keys[k].idx;
+            if (repeats && k > 0) {
+                const OrderKey &a = keys[k], &b = keys[k - 1];
+                (*repeats)[k] = a.len == b.len && a.prefix == b.prefix &&
+                                (a.len <= KEY_RESIDUES || memcmp(s.data(a.idx) + KEY_RESIDUES, s.data(b.idx) + KEY_RESIDUES, a.len - KEY_RESIDUES) == 0);
+            }
+        }
+    });
     return order;
 }
+
+std::vector<int> famsa_order(const SeqSet& s, int n_threads) { return order_and_repeats(s, n_threads, nullptr); }
 
 WorkSet make_workset(const SeqSet& s, bool keep_duplicates, int n_threads)
 {
     WorkSet w;
-    w.sorted2input = famsa_order(s, n_threads);
+    std::vector<uint8_t> repeats;
+    w.sorted2input = order_and_repeats(s, n_threads, keep_duplicates ? nullptr : &repeats);
     const int n = (int)w.sorted2input.size();
     w.sorted2unique.resize(n);
     int cur = -1;
     for (int k = 0; k < n; ++k) {
-        bool same = false;
-        if (!keep_duplicates && k > 0) {
-            const int a = w.sorted2input[k], b = w.sorted2input[k - 1];
-            same = s.length(a) == s.length(b) && (s.length(a) == 0 || memcmp(s.data(a), s.data(b), s.length(a)) == 0);
-        }
+        const bool same = !keep_duplicates && repeats[k] != 0;
         if (!same) {
             ++cur;
             w.unique2sorted.push_back(k);

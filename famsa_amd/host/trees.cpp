@@ -786,18 +786,30 @@ void tree_from_unique(tree_structure& vt, const std::vector<int>& sorted2unique)
     const int n_total = (int)sorted2unique.size();
     const int n_uniques = (int)(vt.size() + 1) / 2; // GuideTree::getSequenceCount
     const int n_dups = n_total - n_uniques;
-    std::vector<std::vector<int>> occ(n_uniques);
-    for (int i = 0; i < n_total; ++i) occ[sorted2unique[i]].push_back(i);
+    if (n_dups == 0) { // nothing was removed: the map is a permutation of the leaves (the identity for a WorkSet)
+        bool identity = true;
+        for (int i = 0; i < n_total && identity; ++i) identity = sorted2unique[i] == i;
+        if (identity) return;
+    }
+    // the records of every unique sequence, in ascending order: first[u] .. first[u + 1] in `members`
+    std::vector<int> first(n_uniques + 1, 0), members(n_total);
+    for (int i = 0; i < n_total; ++i) ++first[sorted2unique[i] + 1];
+    for (int u = 0; u < n_uniques; ++u) first[u + 1] += first[u];
+    {
+        std::vector<int> fill(first.begin(), first.end() - 1);
+        for (int i = 0; i < n_total; ++i) members[fill[sorted2unique[i]]++] = i;
+    }
     std::vector<int> out_ids(n_uniques);
     vt.insert(vt.begin() + n_uniques, (size_t)2 * n_dups, node_t(-1, -1));
     int node_id = n_uniques + n_dups;
     for (int u = 0; u < n_uniques; ++u) {
-        const std::vector<int>& o = occ[u];
-        for (int i = 1; i < (int)o.size(); ++i, ++node_id) {
+        const int* o = members.data() + first[u];
+        const int count = first[u + 1] - first[u];
+        for (int i = 1; i < count; ++i, ++node_id) {
             if (i == 1) vt[node_id] = node_t(o[0], o[1]);
             else vt[node_id] = node_t(o[i], node_id - 1);
         }
-        out_ids[u] = o.size() > 1 ? node_id - 1 : o[0];
+        out_ids[u] = count > 1 ? node_id - 1 : o[0];
     }
     for (int i = node_id; i < (int)vt.size(); ++i) {
         node_t& nd = vt[i];
@@ -806,11 +818,16 @@ void tree_from_unique(tree_structure& vt, const std::vector<int>& sorted2unique)
     }
 }
 
-std::string tree_to_newick(const tree_structure& tree, const std::vector<std::string>& names)
+// The text has a closed form: a leaf is `name:1.0`, an inner node `(` left `,` right `):1.0`, the root ends in `);` -- so
+// every node's length follows from its children's and every node's position from its parent's.  The generators append a node
+// after its children, which turns both into one sweep over the node array each (up for the lengths, down for the
+// positions), and then every node writes its own few characters wherever they belong, on all cores: at 10^6 leaves the
+// recursive walk spent its time on the cache misses of one thread.  A tree with a child after its parent (none of ours)
+// takes the walk.
+static std::string newick_by_walk(const tree_structure& tree, const std::vector<const char*>& names)
 {
     const int n_leaves = (int)names.size();
     std::string out;
-    if (tree.empty()) return out;
     const int root = (int)tree.size() - 1;
     // explicit stack: (node, state) with state 0 = open, 1 = between children, 2 = close
     std::vector<std::pair<int, int>> st;
@@ -819,7 +836,7 @@ std::string tree_to_newick(const tree_structure& tree, const std::vector<std::st
         auto& top = st.back();
         const int node = top.first;
         if (node < n_leaves) {
-            const char* name = names[node].c_str();
+            const char* name = names[node];
             if (*name == '>') ++name;
             out += name;
             out += ":1.0";
@@ -839,6 +856,69 @@ std::string tree_to_newick(const tree_structure& tree, const std::vector<std::st
             st.pop_back();
         }
     }
+    return out;
+}
+
+std::string tree_to_newick(const tree_structure& tree, const std::vector<std::string>& names)
+{
+    std::vector<const char*> p(names.size());
+    for (size_t i = 0; i < names.size(); ++i) p[i] = names[i].c_str();
+    return tree_to_newick(tree, p);
+}
+
+std::string tree_to_newick(const tree_structure& tree, const std::vector<const char*>& names)
+{
+    const int n_leaves = (int)names.size(), n_nodes = (int)tree.size();
+    if (tree.empty()) return std::string();
+    const int root = n_nodes - 1;
+    if (root < n_leaves) return newick_by_walk(tree, names); // a single leaf
+    for (int i = n_leaves; i < n_nodes; ++i)
+        if (tree[i].first < 0 || tree[i].second < 0 || tree[i].first >= i || tree[i].second >= i) return newick_by_walk(tree, names);
+    constexpr uint64_t UNSEEN = ~0ull;
+    std::vector<uint64_t> size(n_nodes), at(n_nodes, UNSEEN);
+    auto leaf_name = [&](int v, size_t& len) {
+        const char* p = names[v];
+        if (*p == '>') ++p;
+        len = strlen(p); // as the walk appends it: up to the first NUL
+        return p;
+    };
+    for (int i = 0; i < n_leaves; ++i) {
+        size_t len;
+        leaf_name(i, len);
+        size[i] = len + 4;
+    }
+    for (int i = n_leaves; i < n_nodes; ++i) size[i] = size[tree[i].first] + size[tree[i].second] + (i == root ? 4 : 7);
+    at[root] = 0;
+    for (int i = root; i >= n_leaves; --i) {
+        if (at[i] == UNSEEN) continue; // not part of the root's tree
+        at[tree[i].first] = at[i] + 1;
+        at[tree[i].second] = at[i] + 1 + size[tree[i].first] + 1;
+    }
+    std::string out(size[root], '\0');
+    char* const o = &out[0];
+    const int n_threads = std::max(1, default_host_threads());
+    const int slices = std::max(1, std::min(n_threads, n_nodes / 65536));
+    std::vector<std::thread> workers;
+    auto fill = [&](int t) {
+        const int i0 = (int)((int64_t)n_nodes * t / slices), i1 = (int)((int64_t)n_nodes * (t + 1) / slices);
+        for (int i = i0; i < i1; ++i) {
+            if (at[i] == UNSEEN) continue;
+            if (i < n_leaves) {
+                size_t len;
+                const char* p = leaf_name(i, len);
+                memcpy(o + at[i], p, len);
+                memcpy(o + at[i] + len, ":1.0", 4);
+            } else {
+                o[at[i]] = '(';
+                o[at[i] + size[tree[i].first] + 1] = ',';
+                if (i == root) memcpy(o + at[i] + size[i] - 2, ");", 2);
+                else memcpy(o + at[i] + size[i] - 5, "):1.0", 5);
+            }
+        }
+    };
+    for (int t = 1; t < slices; ++t) workers.emplace_back(fill, t);
+    fill(0);
+    for (auto& w : workers) w.join();
     return out;
 }
 

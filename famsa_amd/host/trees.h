@@ -56,6 +56,7 @@ void tree_from_unique(tree_structure& tree, const std::vector<int>& sorted2uniqu
 // NewickParser::store (reference tree/NewickParser.cpp:103-165); names[i] = id of leaf i
 // (a leading '>' is dropped), every branch ":1.0", no trailing newline.
 std::string tree_to_newick(const tree_structure& tree, const std::vector<std::string>& names);
+std::string tree_to_newick(const tree_structure& tree, const std::vector<const char*>& names); // the same over NUL-terminated names the caller keeps
 
 // -dist_export writer (reference tree/DistanceCalculator.cpp:11-122 with
 // utils/conversion.h:109-119): rows in input order, ref = row, partner = column.

@@ -35,6 +35,9 @@ class Host:
         lib.famsa_host_records.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_long, C.c_void_p, C.c_long, C.c_void_p,
                                            C.c_long]
         lib.famsa_host_clarans.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]
+        lib.famsa_host_newick.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_char_p,
+                                          C.c_long]
+        lib.famsa_host_newick.restype = C.c_long
         self.lib = lib
 
     def _err(self):
@@ -87,6 +90,19 @@ class Host:
         if u < 0:
             raise self._err()
         return u, a, b
+
+    def newick(self, left, right, names, sorted2unique=None):
+        """Newick text of the tree whose internal nodes (children left[i], right[i], leaves first) follow the leaves; with
+        sorted2unique the duplicates are re-attached first (GuideTree::fromUnique) and names has one entry per record."""
+        left = np.ascontiguousarray(left, np.int32)
+        right = np.ascontiguousarray(right, np.int32)
+        n_leaves = len(left) + 1
+        arr = (C.c_char_p * len(names))(*[n.encode() for n in names])
+        s2u = None if sorted2unique is None else np.ascontiguousarray(sorted2unique, np.int32)
+        cap = 64 + sum(len(n) + 12 for n in names)
+        return self._text(lambda buf: self.lib.famsa_host_newick(
+            left.ctypes.data, right.ctypes.data, n_leaves, len(left), C.cast(arr, C.c_void_p), len(names),
+            None if s2u is None else s2u.ctypes.data, buf, len(buf)), cap=cap)
 
     def format_distance(self, v):
         buf = C.create_string_buffer(64)

@@ -318,3 +318,113 @@ def test_the_two_host_upgma_forms_build_the_same_tree(host, tmp_path, monkeypatc
             triangle_form = host.tree_from_matrix(fasta, m, gt, distance=dist, keep_duplicates=True)
             assert square_form == triangle_form, (gt, dist)
             assert square_form.count(b",") == n - 1
+
+
+def _newick_walk(left, right, names):
+    """the recursive definition (reference tree/NewickParser.cpp:103-165), iteratively"""
+    n = len(names)
+    text, stack = [], [(n + len(left) - 1, 0)]
+    root = stack[0][0]
+    while stack:
+        node, state = stack.pop()
+        if node < n:
+            text.append(names[node].lstrip(">") if names[node].startswith(">") else names[node])
+            text.append(":1.0")
+        elif state == 0:
+            text.append("(")
+            stack.append((node, 1))
+            stack.append((int(left[node - n]), 0))
+        elif state == 1:
+            text.append(",")
+            stack.append((node, 2))
+            stack.append((int(right[node - n]), 0))
+        else:
+            text.append(");" if node == root else "):1.0")
+    return "".join(text).encode()
+
+
+@pytest.mark.parametrize("n,shape", [(2, "random"), (3, "chain"), (1000, "random"), (150000, "random"), (150000, "chain")])
+def test_newick_writer_closed_form_equals_the_walk(host, n, shape):
+    """The writer places every node's characters from lengths and positions computed in two sweeps and fills the text
+    on all cores (trees.cpp, tree_to_newick); the text is the recursive definition's, for bushy trees and for a chain
+    of 150 000 (no recursion anywhere), with names of different lengths and a leading '>' dropped."""
+    rng = np.random.Generator(np.random.PCG64(n))
+    names = [(">" if i % 3 == 0 else "") + "s%d" % (i * 7919 % 100003) + "x" * (i % 5) for i in range(n)]
+    left, right = np.zeros(n - 1, np.int32), np.zeros(n - 1, np.int32)
+    roots = list(range(n))
+    for k in range(n - 1):
+        if shape == "chain":
+            a, b = (roots.pop(), roots.pop()) if k == 0 else (roots.pop(0), roots.pop())
+        else:
+            a = roots.pop(int(rng.integers(0, len(roots))))
+            b = roots.pop(int(rng.integers(0, len(roots))))
+        left[k], right[k] = a, b
+        roots.append(n + k)
+    assert host.newick(left, right, names) == _newick_walk(left, right, [s.lstrip(">") for s in names])
+
+
+def test_newick_writer_takes_any_node_order(host):
+    """a child stored after its parent (no generator of ours does that): the writer falls back to the walk"""
+    names = ["a", "b", "c", "d"]
+    # nodes 4 = (5, 3), 5 = (0, 1), 6 = root = (4, 2): node 4 comes before its child 5
+    left, right = np.array([5, 0, 4], np.int32), np.array([3, 1, 2], np.int32)
+    assert host.newick(left, right, names) == b"(((a:1.0,b:1.0):1.0,d:1.0):1.0,c:1.0);"
+    # and the same tree in the usual order: 4 = (0, 1), 5 = (4, 3), 6 = (5, 2)
+    assert host.newick([0, 4, 5], [1, 3, 2], names) == b"(((a:1.0,b:1.0):1.0,d:1.0):1.0,c:1.0);"
+
+
+def test_duplicates_are_reattached_like_the_reference(host):
+    """GuideTree::fromUnique over a map with runs of duplicates (the CSR form of trees.cpp against the definition:
+    the first two records of a run become a node, every further one joins (record, previous node))"""
+    # records 0..6 in sorted order; unique sequences: u0 = {0}, u1 = {1, 2, 3}, u2 = {4}, u3 = {5, 6}
+    s2u = [0, 1, 1, 1, 2, 3, 3]
+    names = ["r%d" % i for i in range(7)]
+    # unique tree: leaves 0..3, internal 4 = (0, 1), 5 = (2, 3), 6 = (4, 5)
+    left, right = [0, 2, 4], [1, 3, 5]
+    got = host.newick(left, right, names, sorted2unique=s2u)
+    u1 = "(r3:1.0,(r1:1.0,r2:1.0):1.0):1.0"
+    u3 = "(r5:1.0,r6:1.0):1.0"
+    assert got == ("((r0:1.0,%s):1.0,(r4:1.0,%s):1.0);" % (u1, u3)).encode()
+
+
+def test_working_order_on_a_set_that_runs_the_parallel_sort(host, oracle, tmp_path):
+    """famsa_order sorts 16-byte keys (length, the first 12 residue codes, index) in parallel runs and merges them; the
+    sequences are looked at only where length and prefix tie.  20 000 records with few lengths, shared 12-residue
+    prefixes, prefixes that differ in the last key residue, records shorter than the prefix, and exact duplicates:
+    the order is the reference's stable sort (length descending, codes ascending), the duplicate map the adjacent-equal runs."""
+    rng = np.random.Generator(np.random.PCG64(4242))
+    alphabet = "ARNDCQEGHILKMFPSTWYVBZX"
+    stems = ["".join(alphabet[c] for c in rng.integers(0, 23, size=12)) for _ in range(6)]
+    seqs = []
+    for i in range(20000):
+        kind = i % 5
+        L = int(rng.choice([5, 11, 12, 13, 40, 41]))
+        if kind == 0 and seqs:
+            s = seqs[int(rng.integers(0, len(seqs)))]  # exact duplicate
+        elif kind == 1:
+            stem = stems[int(rng.integers(0, 6))]
+            s = (stem + "".join(alphabet[c] for c in rng.integers(0, 3, size=40)))[:L]  # tie on the prefix
+        elif kind == 2:
+            stem = stems[int(rng.integers(0, 6))]
+            s = (stem[:11] + alphabet[int(rng.integers(0, 23))] + "ACAC" * 10)[:L]  # differ at the key's last residue
+        else:
+            s = "".join(alphabet[c] for c in rng.integers(0, 23, size=L))
+        seqs.append(s)
+    f = str(tmp_path / "order.fasta")
+    with open(f, "w") as out:
+        for i, s in enumerate(seqs):
+            out.write(">q%d\n%s\n" % (i, s))
+    enc = [oracle.encode(s) for s in seqs]
+    want = seqio.sort_order(enc)
+    u, s2i, s2u = host.workset(f, len(seqs))
+    assert list(s2i) == want
+    assert u == len({bytes(e) for e in enc})
+    expect_u, cur, prev = [], -1, None
+    for k in want:
+        if prev is None or bytes(enc[k]) != prev:
+            cur += 1
+            prev = bytes(enc[k])
+        expect_u.append(cur)
+    assert list(s2u) == expect_u
+    u_keep, s2i_keep, s2u_keep = host.workset(f, len(seqs), keep_duplicates=True)
+    assert list(s2i_keep) == want and u_keep == len(seqs) and list(s2u_keep) == list(range(len(seqs)))
