@@ -82,6 +82,7 @@ void parse_piece(const char* p, const char* end, Piece& out)
     // whose lines hold only gaps is kept, as a sequence of length 0
     bool have_residues = false;
     size_t seq_begin = 0; // residues of the pending record start here in out.codes
+    out.codes.reserve((size_t)(end - p)); // an upper bound: no regrowth (and re-copying) while the piece is read
     auto emit = [&] {
         out.ids.push_back(id);
         out.ends.push_back(out.codes.size());
