@@ -1,5 +1,7 @@
 #include "pipeline.h"
 
+#include <thread>
+
 #include <chrono>
 #include <cstdlib>
 #include <stdexcept>
@@ -70,7 +72,33 @@ EngineFuture start_engine(const std::vector<int>& devices, int expect_threads)
     });
 }
 
+namespace {
+// a large buffer goes back to the system off the calling thread
+void release_in_background(std::vector<uint8_t>& bytes)
+{
+    if (bytes.capacity() < (size_t)64 << 20) {
+        std::vector<uint8_t>().swap(bytes);
+        return;
+    }
+    std::thread([held = std::move(bytes)]() mutable { std::vector<uint8_t>().swap(held); }).detach();
+    std::vector<uint8_t>().swap(bytes);
+}
+
+std::string newick_gpu(const SeqSet& s, SeqSet* consumable, int device, const TreeOptions& opt, Timings* t, EngineFuture* engine);
+} // namespace
+
 std::string guide_tree_newick_gpu(const SeqSet& s, int device, const TreeOptions& opt, Timings* t, EngineFuture* engine)
+{
+    return newick_gpu(s, nullptr, device, opt, t, engine);
+}
+
+std::string guide_tree_newick_gpu_consuming(SeqSet& s, int device, const TreeOptions& opt, Timings* t, EngineFuture* engine)
+{
+    return newick_gpu(s, &s, device, opt, t, engine);
+}
+
+namespace {
+std::string newick_gpu(const SeqSet& s, SeqSet* consumable, int device, const TreeOptions& opt, Timings* t, EngineFuture* engine)
 {
     EngineFuture own;
     if (!engine) {
@@ -90,6 +118,8 @@ std::string guide_tree_newick_gpu(const SeqSet& s, int device, const TreeOptions
     double t1b = now_s();
     src.upload(codes, offsets);
     double t2 = now_s();
+    release_in_background(codes); // on the device now
+    if (consumable) release_in_background(consumable->codes);
     std::string nwk = guide_tree_newick(s, w, src, opt, t);
     if (t) {
         t->sort_s = t1 - t0;
@@ -101,6 +131,7 @@ std::string guide_tree_newick_gpu(const SeqSet& s, int device, const TreeOptions
     if (g_abandon_engine_at_return && !getenv("FAMSA_GPU_PROFILE")) (void)held.release();
     return nwk;
 }
+} // namespace
 
 void dist_export_gpu(const SeqSet& s, int device, Distance dist, bool square, bool pid, const std::string& path,
                      Timings* t, EngineFuture* engine)

@@ -42,6 +42,11 @@ EngineFuture start_engine(int device);
 EngineFuture start_engine(const std::vector<int>& devices, int expect_threads = 0); // one context per entry (entries may repeat)
 std::string guide_tree_newick_gpu(const SeqSet& s, int device, const TreeOptions& opt, Timings* t,
                                   EngineFuture* engine = nullptr);
+// The same for a caller that does not need the residues afterwards: once they are on the device, `s.codes` and the
+// packed copy are given back to the system by a background thread while the tree is built (at 3 x 10^6 records the
+// process otherwise carries 1.5 GB to its exit, and the exit takes that much longer).  Ids, offsets and lengths stay.
+std::string guide_tree_newick_gpu_consuming(SeqSet& s, int device, const TreeOptions& opt, Timings* t,
+                                            EngineFuture* engine = nullptr);
 void dist_export_gpu(const SeqSet& s, int device, Distance dist, bool square, bool pid, const std::string& path,
                      Timings* t, EngineFuture* engine = nullptr);
 
