@@ -1531,10 +1531,11 @@ __global__ __launch_bounds__(512) void clarans_chain_kernel(ClaransBatch batch, 
         int* dbg = st + (tail ? 53 : 48);
         dbg[0] = n_rounds;
         for (int q = 0; q < 4; ++q) dbg[1 + q] = (int)(t_ph[q] & 0x7fffffff);
-        if (!tail)
+        if (!tail) {
             for (int q = 0; q < 5; ++q) st[58 + q] = (int)(t_ev[q] & 0x7fffffff);
             const unsigned long long dw = wall_clock64() - wall0;
             st[63] = dw ? (int)((__builtin_readcyclecounter() - clk0) * 100 / dw) : 0; // MHz
+        }
     }
 }
 

@@ -280,7 +280,7 @@ hipError_t launch_assign_seeds(const void* lcs, int elem_size, int64_t ld, const
 
 // ---- the uploaded set's device form (upload_kernels.hip) ----
 // tiles / quirk flags from the packed codes; flags[0] |= 1 if a symbol code >= 32 was met
-hipError_t launch_build_set(const uint8_t* codes, const uint64_t* offsets, const uint64_t* tile_base, int32_t n,
+hipError_t launch_build_set(const uint8_t* codes, const uint64_t* offsets, const int32_t* order, const uint64_t* tile_base, int32_t n,
                             uint8_t* tiles, uint8_t* quirk, int32_t* flags, const uint64_t* mask_base, uint64_t* masks,
                             hipStream_t stream);
 

@@ -575,8 +575,16 @@ int lcsgpu_encode(const char* residues, size_t n, uint8_t* codes, size_t* n_code
 
 int lcsgpu_upload(lcsgpu_ctx* ctx, const uint8_t* codes, const uint64_t* offsets, int32_t n)
 {
-    if (!ctx || !offsets || n < 0 || (!codes && n > 0 && offsets[n] > 0))
+    return lcsgpu_upload_ordered(ctx, codes, offsets, n, nullptr, n);
+}
+
+int lcsgpu_upload_ordered(lcsgpu_ctx* ctx, const uint8_t* codes, const uint64_t* offsets, int32_t n_records, const int32_t* order,
+                          int32_t n)
+{
+    if (!ctx || !offsets || n < 0 || n_records < 0 || (!order && n != n_records) || (!codes && n_records > 0 && offsets[n_records] > 0))
         return fail(LCSGPU_E_INVALID, "bad argument");
+    if (n > 0 && n_records == 0) return fail(LCSGPU_E_INVALID, "an order over no records");
+    auto record = [&](int32_t i) { return order ? order[i] : i; };
     LaneGuard guard(ctx, LaneGuard::ALL); // nothing may run while the set is replaced
     HIP_TRY(hipSetDevice(ctx->device));
     for (Lane& l : ctx->lanes)
@@ -587,8 +595,11 @@ int lcsgpu_upload(lcsgpu_ctx* ctx, const uint8_t* codes, const uint64_t* offsets
     std::vector<uint8_t> quirk(n);
     uint32_t max_len = 0;
     for (int32_t i = 0; i < n; ++i) {
-        if (offsets[i + 1] < offsets[i]) return fail(LCSGPU_E_INVALID, "offsets not monotone at %d", i);
-        const uint64_t len = offsets[i + 1] - offsets[i];
+        const int32_t r = record(i);
+        if (r < 0 || r >= n_records) return fail(LCSGPU_E_INVALID, "order[%d] = %d is not a record", i, r);
+        if (offsets[r + 1] < offsets[r] || offsets[r + 1] > offsets[n_records])
+            return fail(LCSGPU_E_INVALID, "offsets not monotone at %d", r);
+        const uint64_t len = offsets[r + 1] - offsets[r];
         if (len > 0x7fffffffu) return fail(LCSGPU_E_INVALID, "sequence %d too long", i);
         lens[i] = (uint32_t)len;
         max_len = std::max(max_len, lens[i]);
@@ -606,7 +617,7 @@ int lcsgpu_upload(lcsgpu_ctx* ctx, const uint8_t* codes, const uint64_t* offsets
     std::vector<uint64_t> mask_base((size_t)n + 1, 0); // rows of 32 x u64 per 64-residue word
     for (int32_t i = 0; i < n; ++i) mask_base[i + 1] = mask_base[i] + (lens[i] + 63) / 64;
     const size_t total = (size_t)tile_base[n_tiles];
-    const size_t raw_bytes = n ? (size_t)(offsets[n] - offsets[0]) : 0;
+    const size_t raw_bytes = n ? (size_t)(offsets[n_records] - offsets[0]) : 0;
     if (n && offsets[0] != 0) return fail(LCSGPU_E_INVALID, "offsets[0] must be 0");
     hipError_t e = hipSuccess;
     if ((e = ctx->d_tiles.reserve(std::max<size_t>(total, 16))) != hipSuccess ||
@@ -629,20 +640,22 @@ int lcsgpu_upload(lcsgpu_ctx* ctx, const uint8_t* codes, const uint64_t* offsets
         HIP_TRY(hipMemcpy(ctx->d_minlen.p, ml.data(), ml.size() * 4, hipMemcpyHostToDevice));
     }
     if (n) {
-        DevBuf d_raw, d_off, d_quirk; // only needed while the tiles are built
+        DevBuf d_raw, d_off, d_quirk, d_order; // only needed while the tiles are built
         struct Release {
-            DevBuf &a, &b, &c;
-            ~Release() { a.release(); b.release(); c.release(); }
-        } release{d_raw, d_off, d_quirk};
+            DevBuf &a, &b, &c, &d;
+            ~Release() { a.release(); b.release(); c.release(); d.release(); }
+        } release{d_raw, d_off, d_quirk, d_order};
         if ((e = d_raw.reserve(std::max<size_t>(raw_bytes, 16))) != hipSuccess ||
-            (e = d_off.reserve(((size_t)n + 1) * 8)) != hipSuccess || (e = d_quirk.reserve((size_t)n + 16)) != hipSuccess)
+            (e = d_off.reserve(((size_t)n_records + 1) * 8)) != hipSuccess || (e = d_quirk.reserve((size_t)n + 16)) != hipSuccess ||
+            (order && (e = d_order.reserve((size_t)n * 4)) != hipSuccess))
             return fail(LCSGPU_E_NOMEM, "device allocation failed: %s", hipGetErrorString(e));
         hipStream_t st = ctx->lanes[0].stream;
         if (raw_bytes) HIP_TRY(hipMemcpyAsync(d_raw.p, codes, raw_bytes, hipMemcpyHostToDevice, st));
-        HIP_TRY(hipMemcpyAsync(d_off.p, offsets, ((size_t)n + 1) * 8, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(d_off.p, offsets, ((size_t)n_records + 1) * 8, hipMemcpyHostToDevice, st));
+        if (order) HIP_TRY(hipMemcpyAsync(d_order.p, order, (size_t)n * 4, hipMemcpyHostToDevice, st));
         int32_t* d_flags = (int32_t*)((char*)d_quirk.p + (((size_t)n + 3) & ~(size_t)3));
         HIP_TRY(hipMemsetAsync(d_flags, 0, 4, st));
-        HIP_TRY(lcsgpu::launch_build_set((const uint8_t*)d_raw.p, (const uint64_t*)d_off.p,
+        HIP_TRY(lcsgpu::launch_build_set((const uint8_t*)d_raw.p, (const uint64_t*)d_off.p, order ? (const int32_t*)d_order.p : nullptr,
                                          (const uint64_t*)ctx->d_tile_base.p, n, (uint8_t*)ctx->d_tiles.p,
                                          (uint8_t*)d_quirk.p, d_flags, (const uint64_t*)ctx->d_mask_base.p,
                                          (uint64_t*)ctx->d_masks.p, st));

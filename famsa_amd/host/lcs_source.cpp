@@ -124,13 +124,27 @@ static void on_each_device(int parts, F fn)
 
 void GpuLcsSource::upload(const std::vector<uint8_t>& codes, const std::vector<uint64_t>& offsets)
 {
-    const int32_t n = (int32_t)offsets.size() - 1;
+    upload_records(codes, offsets, nullptr, (int32_t)offsets.size() - 1);
+}
+
+void GpuLcsSource::upload_ordered(const std::vector<uint8_t>& codes, const std::vector<uint64_t>& offsets, const std::vector<int>& order)
+{
+    static_assert(sizeof(int) == sizeof(int32_t), "order entries are int32");
+    upload_records(codes, offsets, order.data(), (int32_t)order.size());
+}
+
+void GpuLcsSource::upload_records(const std::vector<uint8_t>& codes, const std::vector<uint64_t>& offsets, const int* order, int32_t n)
+{
+    const int32_t n_records = (int32_t)offsets.size() - 1;
     on_each_device((int)ctxs_.size(), [&](int k) {
-        const int rc = lcsgpu_upload(ctxs_[k], codes.data(), offsets.data(), n);
+        const int rc = lcsgpu_upload_ordered(ctxs_[k], codes.data(), offsets.data(), n_records, order, n);
         if (rc != LCSGPU_OK) throw std::runtime_error(std::string("lcsgpu_upload failed (") + std::to_string(rc) + "): " + lcsgpu_last_error());
     });
     lens_.resize(n);
-    for (int i = 0; i < n; ++i) lens_[i] = (uint32_t)(offsets[i + 1] - offsets[i]);
+    for (int i = 0; i < n; ++i) {
+        const int r = order ? order[i] : i;
+        lens_[i] = (uint32_t)(offsets[r + 1] - offsets[r]);
+    }
     wide_ = LcsSource::wide();
     std::vector<uint8_t> flags(n ? n : 1);
     int32_t nq = lcsgpu_orientation_flags(ctx_, flags.data());

@@ -109,17 +109,13 @@ std::string newick_gpu(const SeqSet& s, SeqSet* consumable, int device, const Tr
     WorkSet w = make_workset(s, opt.keep_duplicates, opt.fast.n_threads);
     std::vector<int> in_of(w.n_unique());
     for (int a = 0; a < w.n_unique(); ++a) in_of[a] = w.sorted2input[w.unique2sorted[a]];
-    std::vector<uint8_t> codes;
-    std::vector<uint64_t> offsets;
-    pack(s, in_of, codes, offsets, opt.fast.n_threads);
     double t1 = now_s();
     std::unique_ptr<GpuLcsSource> held = engine->get(); // waits only for what the sort did not cover
     GpuLcsSource& src = *held;
     double t1b = now_s();
-    src.upload(codes, offsets);
+    src.upload_ordered(s.codes, s.offsets, in_of); // the records as they were read; the engine gathers the working order's on the device
     double t2 = now_s();
-    release_in_background(codes); // on the device now
-    if (consumable) release_in_background(consumable->codes);
+    if (consumable) release_in_background(consumable->codes); // on the device now
     std::string nwk = guide_tree_newick(s, w, src, opt, t);
     if (t) {
         t->sort_s = t1 - t0;

@@ -44,6 +44,7 @@ def load_library():
         "lcsgpu_reserve_lanes": (C.c_int, [vp, i32]),
         "lcsgpu_encode": (C.c_int, [C.c_char_p, sz, vp, C.POINTER(sz)]),
         "lcsgpu_upload": (C.c_int, [vp, vp, vp, i32]),
+        "lcsgpu_upload_ordered": (C.c_int, [vp, vp, vp, i32, vp, i32]),
         "lcsgpu_count": (i32, [vp]),
         "lcsgpu_length": (i32, [vp, i32]),
         "lcsgpu_orientation_flags": (i32, [vp, vp]),
@@ -169,6 +170,16 @@ class LcsGpu:
                                             offsets.ctypes.data, n))
         self.n = n
         self.lengths = np.diff(offsets.astype(np.int64)).astype(np.uint32)
+
+    def upload_ordered(self, codes, offsets, order):
+        """Sequence k of the set = record order[k] of (codes, offsets); records not named are left out."""
+        codes = np.ascontiguousarray(codes, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        order = np.ascontiguousarray(order, dtype=np.int32)
+        self._check(self._lib.lcsgpu_upload_ordered(self._ctx, codes.ctypes.data if codes.size else None, offsets.ctypes.data,
+                                                    len(offsets) - 1, order.ctypes.data, len(order)))
+        self.n = len(order)
+        self.lengths = np.diff(offsets.astype(np.int64)).astype(np.uint32)[order] if len(order) else np.zeros(0, np.uint32)
 
     def upload_seqs(self, seqs):
         """seqs: list of uint8 code arrays."""

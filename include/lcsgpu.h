@@ -84,6 +84,16 @@ int lcsgpu_encode(const char* residues, size_t n, uint8_t* codes, size_t* n_code
  * rebuilt on the device per launch). */
 int lcsgpu_upload(lcsgpu_ctx* ctx, const uint8_t* codes, const uint64_t* offsets, int32_t n);
 
+/* The same for a caller that holds its records in another order than it wants the set in: sequence k of the
+ * uploaded set (k < n) is record order[k] of (codes, offsets), 0 <= order[k] < n_records; records that no entry
+ * names are left out, a record may be named more than once.  order == NULL: lcsgpu_upload (n == n_records).
+ * Replaces: the re-ordering of the sequence vector itself in CFAMSA::sortAndExtendSequences (msa.cpp:245-279:
+ * stable_sort of the CSequence objects) and the erase of CFAMSA::removeDuplicates (msa.cpp:338-356) -- the caller
+ * computes the order and which records are kept (ids 0..n-1 = ranks in that order, msa.cpp:559-561), the residues
+ * are gathered on the device instead of being packed on the host first. */
+int lcsgpu_upload_ordered(lcsgpu_ctx* ctx, const uint8_t* codes, const uint64_t* offsets, int32_t n_records,
+                          const int32_t* order, int32_t n);
+
 /* Number of sequences / length of sequence i currently uploaded (negative on error). */
 int32_t lcsgpu_count(lcsgpu_ctx* ctx);
 int32_t lcsgpu_length(lcsgpu_ctx* ctx, int32_t i);

@@ -514,3 +514,44 @@ def test_upgma_without_a_finite_neighbour_is_an_error(engine, monkeypatch, batch
     engine.upload_seqs(seqs[:137] + seqs[138:])  # without it: a tree
     left, right = engine.upgma(1, False)
     assert len(left) == 299 and left.max() < 2 * 300 - 2
+
+
+def test_upload_ordered_is_the_upload_of_the_packed_order(engine, oracle):
+    """lcsgpu_upload_ordered gathers the caller's order on the device: the set built from (records, order) -- a
+    permutation that drops records, names one twice, holds empty, quirk-sensitive and > 2048-residue members, ragged
+    tiles -- answers every query like the set uploaded from the packed copy of that order: lengths, orientation
+    flags, the square of oriented LCS values (against the reference's golden where one exists, the oracle elsewhere)."""
+    ids, enc = load_set(os.path.join(G, "adversarial.fasta"))
+    rng = np.random.Generator(np.random.PCG64(31))
+    extra = [rng.integers(0, 20, size=int(L), dtype=np.uint8) for L in (0, 1, 63, 64, 65, 130, 700, 2500)]
+    records = list(enc) + extra
+    codes, offsets = seqio.pack(records)
+    order = rng.permutation(len(records))[: len(records) - 5].astype(np.int32)
+    order = np.concatenate([order, order[:3]])  # three records twice
+    engine.upload_ordered(codes, offsets, order)
+    n = len(order)
+    assert engine.n == n
+    got = engine.lcs_rect((0, n), (0, n), dtype=np.uint32)
+    flags_ordered = engine.orientation_flags()
+    tri_ordered = engine.lcs_triangle()
+    packed = [records[i] for i in order]
+    engine.upload_seqs(packed)
+    assert (engine.lengths == np.array([len(r) for r in packed], np.uint32)).all()
+    want = engine.lcs_rect((0, n), (0, n), dtype=np.uint32)
+    assert (got == want).all()
+    assert (flags_ordered == engine.orientation_flags()).all() and flags_ordered.any()
+    assert (tri_ordered == engine.lcs_triangle()).all()
+    pc, po = seqio.pack(packed)
+    sample = rng.integers(0, n, size=40)
+    assert (oracle.rect(pc, po, sample, sample) == got[np.ix_(sample, sample)]).all()
+    # the errors: an entry that is no record, NULL order with a different count
+    bad = order.copy()
+    bad[2] = len(records)
+    with pytest.raises(lcsgpu.LcsGpuError):
+        engine.upload_ordered(codes, offsets, bad)
+    bad[2] = -1
+    with pytest.raises(lcsgpu.LcsGpuError):
+        engine.upload_ordered(codes, offsets, bad)
+    # an empty order: an empty set
+    engine.upload_ordered(codes, offsets, np.zeros(0, np.int32))
+    assert engine.n == 0
