@@ -337,19 +337,4 @@ WorkSet make_workset(const SeqSet& s, bool keep_duplicates, int n_threads)
     return w;
 }
 
-void pack(const SeqSet& s, const std::vector<int>& input_ids, std::vector<uint8_t>& codes,
-          std::vector<uint64_t>& offsets, int n_threads)
-{
-    if (n_threads <= 0) n_threads = default_host_threads();
-    offsets.assign(input_ids.size() + 1, 0);
-    for (size_t k = 0; k < input_ids.size(); ++k) offsets[k + 1] = offsets[k] + s.length(input_ids[k]);
-    codes.resize(offsets.back());
-    const int slices = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_threads, input_ids.size() / 4096));
-    parallel_for(slices, n_threads, [&](int t) {
-        const size_t k0 = input_ids.size() * t / slices, k1 = input_ids.size() * (t + 1) / slices;
-        for (size_t k = k0; k < k1; ++k)
-            if (s.length(input_ids[k])) memcpy(codes.data() + offsets[k], s.data(input_ids[k]), s.length(input_ids[k]));
-    });
-}
-
 } // namespace famsa_host

@@ -47,8 +47,5 @@ struct WorkSet {
 };
 WorkSet make_workset(const SeqSet& s, bool keep_duplicates, int n_threads = 0);
 
-// Concatenated codes + offsets (the lcsgpu_upload layout) of the given input indices, in order.
-void pack(const SeqSet& s, const std::vector<int>& input_ids, std::vector<uint8_t>& codes,
-          std::vector<uint64_t>& offsets, int n_threads = 0);
 
 } // namespace famsa_host
