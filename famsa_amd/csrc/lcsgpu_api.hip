@@ -67,8 +67,9 @@ bool contiguous(const Bucket& b)
 bool create_lane(lcsgpu_ctx* ctx, Lane& l)
 {
     if (hipSetDevice(ctx->device) != hipSuccess) return false;
+    // (the copy stream of the sliced host-buffer triangle is made by its first user: a stream costs ~100 MB of resident
+    //  host memory and some milliseconds on this runtime, and the FastTree recursion's 16+ lanes never need it)
     const bool ok = hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking) == hipSuccess &&
-                    hipStreamCreateWithFlags(&l.copy_stream, hipStreamNonBlocking) == hipSuccess &&
                     hipEventCreate(&l.ev_start) == hipSuccess && hipEventCreate(&l.ev_stop) == hipSuccess &&
                     hipEventCreateWithFlags(&l.ev_done, hipEventBlockingSync | hipEventDisableTiming) == hipSuccess;
     if (!ok) (void)hipGetLastError();
@@ -804,6 +805,7 @@ int lcsgpu_lcs_triangle(lcsgpu_ctx* ctx, int32_t row_begin, int32_t row_end, voi
         } events{done};
         double ms = 0;
         int launches = 0;
+        if (!L.copy_stream) HIP_TRY(hipStreamCreateWithFlags(&L.copy_stream, hipStreamNonBlocking));
         auto copy_slice = [&](int k) -> int {
             const int64_t a0 = (int64_t)cut[k] * (cut[k] - 1) / 2 - off, a1 = (int64_t)cut[k + 1] * (cut[k + 1] - 1) / 2 - off;
             if (a1 <= a0) return LCSGPU_OK;

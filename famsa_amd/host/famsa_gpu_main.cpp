@@ -150,6 +150,7 @@ int main(int argc, char** argv)
         if (s.size() == 0) throw std::runtime_error("no sequences in " + input);
         Timings t;
         t.load_s = since(clock0);
+        t.rss_load_kb = resident_kb();
         if (export_dist) {
             dist_export_gpu(s, device, opt.dist, square, pid, output, &t, &engine);
         } else {
@@ -171,7 +172,16 @@ int main(int argc, char** argv)
                       << "time.newick=" << t.newick_s << "\n"
                       << "time.store=" << t.store_s << "\n"
                       << "gpu.lcs_kernel_ms=" << t.kernel_ms << "\n"
-                      << "time.main_until_exit=" << since(clock_main) << "\n"; // what the caller's wall clock adds: loading the HIP libraries before main, the teardown of the process after it
+                      << "time.main_until_exit=" << since(clock_main) << "\n";
+            std::cerr << "mem.after_load_kB=" << t.rss_load_kb << "\nmem.after_upload_kB=" << t.rss_upload_kb << "\nmem.after_tree_kB=" << t.rss_tree_kb
+                      << "\nmem.after_newick_kB=" << t.rss_newick_kb << "\n";
+            { // the host memory this process peaked at and holds now (what the system takes back after the exit)
+                std::ifstream st("/proc/self/status");
+                std::string line;
+                while (std::getline(st, line))
+                    if (line.compare(0, 6, "VmHWM:") == 0 || line.compare(0, 6, "VmRSS:") == 0)
+                        std::cerr << "mem." << line.substr(0, 5) << "_kB=" << atol(line.c_str() + 6) << "\n";
+            } // what the caller's wall clock adds: loading the HIP libraries before main, the teardown of the process after it
             if (!t.transport.empty()) { // several GPUs: one "gpu.transport=" line per fact
                 size_t at = 0;
                 while (at < t.transport.size()) {

@@ -1,12 +1,25 @@
 #include "pipeline.h"
 
 #include <thread>
+#include <unistd.h>
+#include <cstdio>
 
 #include <chrono>
 #include <cstdlib>
 #include <stdexcept>
 
 namespace famsa_host {
+
+long resident_kb()
+{
+    long kb = 0;
+    if (FILE* f = fopen("/proc/self/statm", "r")) {
+        long size = 0, res = 0;
+        if (fscanf(f, "%ld %ld", &size, &res) == 2) kb = res * (sysconf(_SC_PAGESIZE) / 1024);
+        fclose(f);
+    }
+    return kb;
+}
 
 static double now_s()
 {
@@ -33,11 +46,14 @@ std::string guide_tree_newick(const SeqSet& s, const WorkSet& w, LcsSource& src,
         build_tree(src, opt.method, opt.dist, tree, 1);
     }
     const double t1 = now_s();
+    const long rss_tree = t ? resident_kb() : 0;
     tree_from_unique(tree, w.sorted2unique);
     std::string nwk = tree_to_newick(tree, names);
     if (t) {
         t->tree_s = t1 - t0;
         t->newick_s = now_s() - t1;
+        t->rss_tree_kb = rss_tree;
+        t->rss_newick_kb = resident_kb();
     }
     return nwk;
 }
@@ -115,6 +131,7 @@ std::string newick_gpu(const SeqSet& s, SeqSet* consumable, int device, const Tr
     double t1b = now_s();
     src.upload_ordered(s.codes, s.offsets, in_of); // the records as they were read; the engine gathers the working order's on the device
     double t2 = now_s();
+    if (t) t->rss_upload_kb = resident_kb();
     if (consumable) release_in_background(consumable->codes); // on the device now
     std::string nwk = guide_tree_newick(s, w, src, opt, t);
     if (t) {

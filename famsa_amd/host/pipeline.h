@@ -14,6 +14,7 @@ namespace famsa_host {
 
 struct Timings {
     double load_s = 0, sort_s = 0, init_s = 0, upload_s = 0, tree_s = 0, newick_s = 0, store_s = 0, kernel_ms = 0;
+    long rss_load_kb = 0, rss_upload_kb = 0, rss_tree_kb = 0, rss_newick_kb = 0; // resident host memory after the stage (/proc/self/status)
     std::string transport; // several GPUs: lcsgpu_multi_transport's report (how the contexts reached each other, which key exchange ran)
 };
 
@@ -28,6 +29,7 @@ struct TreeOptions {
     FastTreeParams fast;
 };
 
+long resident_kb(); // VmRSS of this process
 std::string guide_tree_newick(const SeqSet& s, const WorkSet& w, LcsSource& src_of_unique, const TreeOptions& opt,
                               Timings* t = nullptr);
 
