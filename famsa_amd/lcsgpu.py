@@ -383,6 +383,11 @@ class LcsGpuGroup:
             e.upload(codes, offsets)
         self.n = self.engs[0].n
 
+    def upload_ordered(self, codes, offsets, order):
+        for e in self.engs:
+            e.upload_ordered(codes, offsets, order)
+        self.n = self.engs[0].n
+
     def lcs_triangle(self, row_begin=0, row_end=None, dtype=np.uint16):
         row_end = self.n if row_end is None else row_end
         count = row_end * (row_end - 1) // 2 - row_begin * (row_begin - 1) // 2
