@@ -122,22 +122,22 @@ static void on_each_device(int parts, F fn)
         if (!e.empty()) throw std::runtime_error(e);
 }
 
-void GpuLcsSource::upload(const std::vector<uint8_t>& codes, const std::vector<uint64_t>& offsets)
+void GpuLcsSource::upload(const uint8_t* codes, const std::vector<uint64_t>& offsets)
 {
     upload_records(codes, offsets, nullptr, (int32_t)offsets.size() - 1);
 }
 
-void GpuLcsSource::upload_ordered(const std::vector<uint8_t>& codes, const std::vector<uint64_t>& offsets, const std::vector<int>& order)
+void GpuLcsSource::upload_ordered(const uint8_t* codes, const std::vector<uint64_t>& offsets, const std::vector<int>& order)
 {
     static_assert(sizeof(int) == sizeof(int32_t), "order entries are int32");
     upload_records(codes, offsets, order.data(), (int32_t)order.size());
 }
 
-void GpuLcsSource::upload_records(const std::vector<uint8_t>& codes, const std::vector<uint64_t>& offsets, const int* order, int32_t n)
+void GpuLcsSource::upload_records(const uint8_t* codes, const std::vector<uint64_t>& offsets, const int* order, int32_t n)
 {
     const int32_t n_records = (int32_t)offsets.size() - 1;
     on_each_device((int)ctxs_.size(), [&](int k) {
-        const int rc = lcsgpu_upload_ordered(ctxs_[k], codes.data(), offsets.data(), n_records, order, n);
+        const int rc = lcsgpu_upload_ordered(ctxs_[k], codes, offsets.data(), n_records, order, n);
         if (rc != LCSGPU_OK) throw std::runtime_error(std::string("lcsgpu_upload failed (") + std::to_string(rc) + "): " + lcsgpu_last_error());
     });
     lens_.resize(n);

@@ -92,9 +92,9 @@ public:
     int n_devices() const { return (int)ctxs_.size(); }
     // the FastTree recursion calls from `n_threads` host threads: have the engine's lanes ready (lcsgpu_reserve_lanes)
     void expect_threads(int n_threads) override;
-    void upload(const std::vector<uint8_t>& codes, const std::vector<uint64_t>& offsets);
+    void upload(const uint8_t* codes, const std::vector<uint64_t>& offsets); // codes[offsets[i] .. offsets[i + 1]) = sequence i
     // sequence k of the set = record order[k] of (codes, offsets) (lcsgpu_upload_ordered: no packed host copy)
-    void upload_ordered(const std::vector<uint8_t>& codes, const std::vector<uint64_t>& offsets, const std::vector<int>& order);
+    void upload_ordered(const uint8_t* codes, const std::vector<uint64_t>& offsets, const std::vector<int>& order);
     int n() const override { return (int)lens_.size(); }
     uint32_t length(int i) const override { return lens_[i]; }
     bool orientation_sensitive() const override { return sensitive_; }
@@ -118,7 +118,7 @@ public:
     void add_kernel_ms(lcsgpu_ctx* ctx);
 
 private:
-    void upload_records(const std::vector<uint8_t>& codes, const std::vector<uint64_t>& offsets, const int* order, int32_t n);
+    void upload_records(const uint8_t* codes, const std::vector<uint64_t>& offsets, const int* order, int32_t n);
     void check(int rc, const char* what);
     lcsgpu_ctx* pick(); // the context for a small request: round robin over the devices
     std::vector<lcsgpu_ctx*> ctxs_;

@@ -90,14 +90,14 @@ EngineFuture start_engine(const std::vector<int>& devices, int expect_threads)
 
 namespace {
 // a large buffer goes back to the system off the calling thread
-void release_in_background(std::vector<uint8_t>& bytes)
+void release_in_background(Bytes& bytes)
 {
     if (bytes.capacity() < (size_t)64 << 20) {
-        std::vector<uint8_t>().swap(bytes);
+        Bytes().swap(bytes);
         return;
     }
-    std::thread([held = std::move(bytes)]() mutable { std::vector<uint8_t>().swap(held); }).detach();
-    std::vector<uint8_t>().swap(bytes);
+    std::thread([held = std::move(bytes)]() mutable { Bytes().swap(held); }).detach();
+    Bytes().swap(bytes);
 }
 
 std::string newick_gpu(const SeqSet& s, SeqSet* consumable, int device, const TreeOptions& opt, Timings* t, EngineFuture* engine);
@@ -129,7 +129,7 @@ std::string newick_gpu(const SeqSet& s, SeqSet* consumable, int device, const Tr
     std::unique_ptr<GpuLcsSource> held = engine->get(); // waits only for what the sort did not cover
     GpuLcsSource& src = *held;
     double t1b = now_s();
-    src.upload_ordered(s.codes, s.offsets, in_of); // the records as they were read; the engine gathers the working order's on the device
+    src.upload_ordered(s.codes.data(), s.offsets, in_of); // the records as they were read; the engine gathers the working order's on the device
     double t2 = now_s();
     if (t) t->rss_upload_kb = resident_kb();
     if (consumable) release_in_background(consumable->codes); // on the device now
@@ -157,7 +157,7 @@ void dist_export_gpu(const SeqSet& s, int device, Distance dist, bool square, bo
     double t1 = now_s();
     std::unique_ptr<GpuLcsSource> held = engine->get();
     GpuLcsSource& src = *held;
-    src.upload(s.codes, s.offsets); // input order, no sort, no dedup: the set as it was read
+    src.upload(s.codes.data(), s.offsets); // input order, no sort, no dedup: the set as it was read
     double t2 = now_s();
     write_distance_csv(src, s.ids, dist, square, pid, path);
     double t3 = now_s();

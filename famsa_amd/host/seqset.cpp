@@ -55,7 +55,7 @@ void parallel_for(int n_tasks, int n_threads, Fn fn)
         if (!e.empty()) throw std::runtime_error(e);
 }
 
-void append_codes(std::vector<uint8_t>& out, const char* residues, size_t n)
+void append_codes(Bytes& out, const char* residues, size_t n)
 {
     const size_t at = out.size();
     out.resize(at + n);
@@ -68,25 +68,68 @@ void append_codes(std::vector<uint8_t>& out, const char* residues, size_t n)
 // The reader's state machine (reference core/io_service.h:99-124) over the lines of one piece of
 // the file.  A piece starts at a header line (or at the start of the file), so it starts with
 // the machine's clean state; only the first piece can see residue lines before any header.
-struct Piece {
-    std::vector<std::string> ids;
-    std::vector<uint8_t> codes;
-    std::vector<uint64_t> ends; // end offset of every record inside `codes`
+// The machine runs twice over every piece with the same control flow: first into a sink that only counts (records,
+// code bytes), then -- every piece knowing where its records and bytes go -- into one that encodes straight into the
+// set's buffers.  (One pass into per-piece buffers and a copy afterwards touched every byte of the set twice more and
+// faulted twice the memory in.)
+// gaps in a residue line ('-': lcsgpu_encode drops them); memchr runs at vector speed over the usual line without any
+inline size_t count_gaps(const char* p, size_t n)
+{
+    size_t gaps = 0;
+    const char* end = p + n;
+    while (p < end) {
+        const char* g = (const char*)memchr(p, '-', (size_t)(end - p));
+        if (!g) break;
+        ++gaps;
+        p = g + 1;
+    }
+    return gaps;
+}
+
+struct CountSink {
+    size_t bytes = 0, records = 0, emitted_bytes = 0;
+    void residues(const char* p, size_t n) { bytes += n - count_gaps(p, n); }
+    void emit(const std::string&)
+    {
+        ++records;
+        emitted_bytes = bytes;
+    }
+};
+struct WriteSink {
+    uint8_t* dst;      // the piece's first byte in the set's code buffer
+    size_t limit;      // bytes of its records (CountSink::emitted_bytes): what lies beyond never gets a record
+    uint64_t base;     // offset of dst in the code buffer
+    std::string* ids;  // the piece's first record
+    uint64_t* ends;    // offsets[first record + 1 ...]
+    size_t at = 0, r = 0;
+    void residues(const char* p, size_t n)
+    {
+        const size_t m = n - count_gaps(p, n);
+        if (at + m <= limit) {
+            size_t wrote = 0;
+            if (n && lcsgpu_encode(p, n, dst + at, &wrote) != LCSGPU_OK)
+                throw std::runtime_error(std::string("lcsgpu_encode: ") + lcsgpu_last_error());
+        }
+        at += m;
+    }
+    void emit(const std::string& id)
+    {
+        ids[r] = id;
+        ends[r] = base + at;
+        ++r;
+    }
 };
 
-void parse_piece(const char* p, const char* end, Piece& out)
+template <class Sink>
+void read_piece(const char* p, const char* end, Sink& sink)
 {
     std::string id;
     bool have_id = false;
     // the reference tests the RAW residue text of the pending record (io_service.h:108,122): a record
     // whose lines hold only gaps is kept, as a sequence of length 0
     bool have_residues = false;
-    size_t seq_begin = 0; // residues of the pending record start here in out.codes
-    out.codes.reserve((size_t)(end - p)); // an upper bound: no regrowth (and re-copying) while the piece is read
     auto emit = [&] {
-        out.ids.push_back(id);
-        out.ends.push_back(out.codes.size());
-        seq_begin = out.codes.size();
+        sink.emit(id);
         have_residues = false;
     };
     while (p < end) {
@@ -100,14 +143,14 @@ void parse_piece(const char* p, const char* end, Piece& out)
                 id.assign(p, line_end);
                 have_id = true;
             } else {
-                append_codes(out.codes, p, (size_t)(line_end - p));
+                sink.residues(p, (size_t)(line_end - p));
                 have_residues = true;
             }
         }
         p = next;
     }
     if (have_id && have_residues) emit();
-    out.codes.resize(seq_begin); // residues that never got a record (no header at all)
+    // residues that never got a record (no header at all, or none after them) are past the last emit: not part of the set
 }
 
 // gzip input (the reference reads .gz transparently, core/io_service.h:95): all members of the file,
@@ -209,34 +252,30 @@ SeqSet load_fasta(const std::string& path, int n_threads)
         }
         start[k] = at;
     }
-    std::vector<Piece> pieces(n_pieces);
+    std::vector<CountSink> counted(n_pieces);
     try {
         parallel_for(n_pieces, n_threads, [&](int k) {
-            if (start[k] < start[k + 1]) parse_piece(buf + start[k], buf + start[k + 1], pieces[k]);
+            if (start[k] < start[k + 1]) read_piece(buf + start[k], buf + start[k + 1], counted[k]);
+        });
+        std::vector<size_t> rec0(n_pieces + 1, 0), byte0(n_pieces + 1, 0);
+        for (int k = 0; k < n_pieces; ++k) {
+            rec0[k + 1] = rec0[k] + counted[k].records;
+            byte0[k + 1] = byte0[k] + counted[k].emitted_bytes;
+        }
+        s.ids.resize(rec0[n_pieces]);
+        s.offsets.resize(rec0[n_pieces] + 1);
+        s.codes.resize(byte0[n_pieces]); // not zeroed (Bytes): every byte is written below
+        parallel_for(n_pieces, n_threads, [&](int k) {
+            if (start[k] >= start[k + 1]) return;
+            WriteSink w{s.codes.data() + byte0[k], counted[k].emitted_bytes, byte0[k], s.ids.data() + rec0[k], s.offsets.data() + rec0[k] + 1};
+            read_piece(buf + start[k], buf + start[k + 1], w);
+            if (w.r != counted[k].records) throw std::runtime_error("FASTA reader: the two passes disagree");
         });
     } catch (...) {
         munmap((void*)mapped, mapped_size);
         throw;
     }
     munmap((void*)mapped, mapped_size);
-    // stitch
-    std::vector<size_t> rec0(n_pieces + 1, 0), byte0(n_pieces + 1, 0);
-    for (int k = 0; k < n_pieces; ++k) {
-        rec0[k + 1] = rec0[k] + pieces[k].ids.size();
-        byte0[k + 1] = byte0[k] + pieces[k].codes.size();
-    }
-    s.ids.resize(rec0[n_pieces]);
-    s.offsets.resize(rec0[n_pieces] + 1);
-    s.codes.resize(byte0[n_pieces]);
-    parallel_for(n_pieces, n_threads, [&](int k) {
-        Piece& pc = pieces[k];
-        if (!pc.codes.empty()) memcpy(s.codes.data() + byte0[k], pc.codes.data(), pc.codes.size());
-        for (size_t r = 0; r < pc.ids.size(); ++r) {
-            s.ids[rec0[k] + r].swap(pc.ids[r]);
-            s.offsets[rec0[k] + r + 1] = byte0[k] + pc.ends[r];
-        }
-        Piece().codes.swap(pc.codes);
-    });
     return s;
 }
 
