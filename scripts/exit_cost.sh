@@ -15,7 +15,7 @@ PY
 OUT=gpurun_out/exit_cost.txt
 : > $OUT
 TIMEFORMAT='wall=%R user=%U sys=%S'
-for mode in fast; do
+for mode in fast clean; do
   if [ $mode = clean ]; then export FAMSA_GPU_CLEAN_EXIT=1; else unset FAMSA_GPU_CLEAN_EXIT; fi
   sleep 3
   { time timeout 300 famsa_amd/famsa-gpu -v -medoidtree -gt upgma -gt_export /tmp/fam_$N.fasta /tmp/fam_$N.dnd 2> /tmp/ec.err ; } 2> /tmp/ec.time
