@@ -53,7 +53,7 @@ def gpu(args, fasta, runs=2):
         # the driver hands the device memory of a process that has ended back only after a while, and a process started
         # meanwhile waits for it (scripts/back_to_back.sh: -gt upgma at 100 000 sequences 1.6 s after a rest, 2.5-4 s right
         # after another such run): every run starts from a rested device
-        time.sleep(3)
+        time.sleep(6)
         t0 = time.time()
         p = subprocess.run([cli, "-v", *args, "-gt_export", fasta, "/tmp/cmp_gpu.dnd"], stderr=subprocess.PIPE, text=True)
         assert p.returncode == 0, p.stderr
