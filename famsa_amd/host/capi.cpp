@@ -94,6 +94,25 @@ long famsa_host_tree_from_matrix(const char* fasta, const uint32_t* square, cons
     }
 }
 
+// The same with the rest of the CLI's tree options: -num_evals (0 = default), -gt chained's seed, -dump_seeds (NULL = none).
+long famsa_host_tree_from_matrix_ex(const char* fasta, const uint32_t* square, const char* method, int distance,
+                                    int keep_duplicates, int heuristic, int subtree_size, int sample_size,
+                                    int threshold, float cluster_fraction, int cluster_iters, int num_evals,
+                                    uint32_t chained_seed, const char* dump_seeds_path, char* out, long cap)
+{
+    try {
+        SeqSet s = load_fasta(fasta);
+        TreeOptions o = make_options(method, distance, keep_duplicates, heuristic, subtree_size, sample_size, threshold,
+                                     cluster_fraction, cluster_iters);
+        if (num_evals > 0) o.fast.num_evaluations = num_evals;
+        o.chained_seed = chained_seed;
+        if (dump_seeds_path) o.dump_seeds_path = dump_seeds_path;
+        return give(guide_tree_newick_from_matrix(s, square, o), out, cap);
+    } catch (const std::exception& e) {
+        return fail(e);
+    }
+}
+
 // `-dist_export [-pid] [-square_matrix]` written to `csv_path`, LCS values from `square`.
 int famsa_host_dist_export_from_matrix(const char* fasta, const uint32_t* square, int distance, int square_matrix,
                                        int pid, const char* csv_path)

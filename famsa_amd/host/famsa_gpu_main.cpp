@@ -1,13 +1,16 @@
 // famsa-gpu -- the guide-tree / distance-export front end of FAMSA on the MI355X LCS engine.
 // Accepts the reference CLI's flags for this path (reference core/params.cpp:136-294, help text
 // :60-134):   famsa-gpu [options] <input.fasta> <output>
-//   -gt <sl|slink|upgma|upgma_modified|nj>   guide tree method (default sl)
+//   -gt <sl|slink|upgma|upgma_modified|nj|chained [seed]>   guide tree method (default sl)
 //   -gt_export                               write the guide tree in Newick format and stop
 //   -dist_export [-pid] [-square_matrix]     write the distance (or identity) matrix as CSV
 //   -dist <indel_div_lcs|indel075_div_lcs>   distance measure (default indel075_div_lcs)
-//   -keep-duplicates, -t <n>, -v / -vv, -gpu <id[,id...]> | -gpus <n>   (several GPUs: the pair space is tiled
-//                                              by row blocks, FastTree batches are split between the devices)
-//   -medoidtree | -parttree [-medoid_threshold n -subtree_size n -sample_size n -cluster_fraction f -cluster_iters n]
+//   -keep-duplicates | -keep_duplicates, -t <n>, -v / -vv, -stats <file>, -gpu <id[,id...]> | -gpus <n>   (several GPUs: the
+//                                              pair space is tiled by row blocks, FastTree batches are split between the devices)
+//   -medoidtree | -parttree [-medoid_threshold n -subtree_size n -sample_size n -num_evals n -cluster_fraction f
+//                            -cluster_iters n -dump_seeds <file>]
+//   -shuffle <n>                             accepted and ignored (parsed by developer builds of the reference only,
+//                                            core/params.cpp:242-244, and consumed nowhere)
 // Everything downstream of the guide tree (profile alignment, refinement, gz I/O)
 // is outside this engine's scope and is refused with an error, not silently ignored.
 #include <algorithm>
@@ -17,6 +20,7 @@
 #include <cstdlib>
 #include <fstream>
 #include <iostream>
+#include <map>
 #include <stdexcept>
 #include <string>
 #include <thread>
@@ -49,16 +53,18 @@ bool find_option(std::vector<std::string>& p, const std::string& name, std::stri
 void usage()
 {
     std::cerr << "Usage: famsa-gpu [options] <input_file> <output_file>\n"
-                 "  -gt <sl | slink | upgma | upgma_modified | nj>  guide tree method (default: sl)\n"
+                 "  -gt <sl | slink | upgma | upgma_modified | nj | chained [seed]>  guide tree method (default: sl)\n"
                  "  -gt_export            export the guide tree to the output file in Newick format\n"
                  "  -dist_export          export the distance matrix to the output file in CSV format\n"
                  "  -square_matrix        generate a square distance matrix instead of the lower triangle\n"
                  "  -pid                  export pairwise identity (the number of matching residues divided\n"
                  "                        by the shorter sequence length) instead of distance\n"
                  "  -dist <measure>       indel_div_lcs | indel075_div_lcs (default)\n"
-                 "  -keep-duplicates      keep duplicated sequences during tree construction\n"
+                 "  -keep-duplicates      keep duplicated sequences during tree construction (also: -keep_duplicates)\n"
                  "  -medoidtree | -parttree   MedoidTree / PartTree heuristic (with -medoid_threshold, -subtree_size,\n"
-                 "                        -sample_size, -cluster_fraction, -cluster_iters as in FAMSA)\n"
+                 "                        -sample_size, -num_evals, -cluster_fraction, -cluster_iters as in FAMSA)\n"
+                 "  -dump_seeds <file>    with a heuristic: the ids of the top-level split's seeds, one per line\n"
+                 "  -stats <file>         the run's statistics as \"[stats]\" + key=value lines (what -v prints)\n"
                  "  -gpu <id[,id...]>     HIP device(s) (default 0); -gpus <n> = devices 0..n-1.  With several devices\n"
                  "                        the all-pairs work is tiled by row blocks over them\n"
                  "  -t <n>, -v, -vv       accepted for compatibility / verbosity\n";
@@ -77,9 +83,19 @@ int main(int argc, char** argv)
         std::string aux;
         TreeOptions opt;
         std::vector<int> devices{0};
-        if (find_option(params, "-gt", aux)) {
-            if (aux == "import") throw std::runtime_error("-gt import needs the alignment stage, which is outside this tool");
-            opt.method = gt_from_string(aux);
+        {   // -gt <method>; "chained" may be followed by its seed (core/params.cpp:178-189)
+            auto it = std::find(params.begin(), params.end(), std::string("-gt"));
+            if (it != params.end() && it + 1 != params.end()) {
+                aux = *(it + 1);
+                it = params.erase(it, it + 2);
+                if (aux == "import") throw std::runtime_error("-gt import needs the alignment stage, which is outside this tool");
+                opt.method = gt_from_string(aux);
+                if (opt.method == GT::chained && it != params.end() && !it->empty() &&
+                    it->find_first_not_of("0123456789") == std::string::npos) {
+                    opt.chained_seed = (uint32_t)std::stoul(*it);
+                    params.erase(it);
+                }
+            }
         }
         if (find_option(params, "-dist", aux)) {
             if (aux == "indel_div_lcs") opt.dist = Distance::indel_div_lcs;
@@ -92,6 +108,11 @@ int main(int argc, char** argv)
         if (find_option(params, "-medoid_threshold", aux)) opt.fast.threshold = std::stoi(aux);
         if (find_option(params, "-subtree_size", aux)) opt.fast.subtree_size = std::stoi(aux);
         if (find_option(params, "-sample_size", aux)) opt.fast.sample_size = std::stoi(aux);
+        if (find_option(params, "-num_evals", aux)) opt.fast.num_evaluations = std::stoi(aux);
+        if (find_option(params, "-dump_seeds", aux)) opt.dump_seeds_path = aux;
+        std::string stats_path;
+        (void)find_option(params, "-stats", stats_path);
+        (void)find_option(params, "-shuffle", aux); // developer builds of the reference parse it; nothing consumes it
         if (find_option(params, "-cluster_fraction", aux)) opt.fast.cluster_fraction = std::stof(aux);
         if (find_option(params, "-cluster_iters", aux)) opt.fast.cluster_iters = std::stoi(aux);
         if (find_option(params, "-gpu", aux)) {
@@ -119,6 +140,7 @@ int main(int argc, char** argv)
         const bool square = find_switch(params, "-square_matrix");
         const bool pid = find_switch(params, "-pid");
         opt.keep_duplicates = find_switch(params, "-keep-duplicates");
+        if (find_switch(params, "-keep_duplicates")) opt.keep_duplicates = true; // core/params.cpp:240: both spellings
         for (const char* unsupported : {"-gz", "-refine_mode", "-trim_columns", "-go", "-ge", "-r"})
             if (std::find(params.begin(), params.end(), unsupported) != params.end())
                 throw std::runtime_error(std::string(unsupported) + " is outside the scope of famsa-gpu (guide tree / distance stage only)");
@@ -162,6 +184,30 @@ int main(int argc, char** argv)
             f.close();
             if (f.fail()) throw std::runtime_error("writing " + output + " failed (disk full?)"); // before the fast exit below reports success
             t.store_s = since(clock1);
+        }
+        if (!stats_path.empty()) {
+            // the reference's statistics file (famsa.cpp:137-150, utils/statistics.h:77-87): "[stats]", then key=value lines
+            // in key order.  Its keys where this tool has the figure (input.*, time.sort, time.tree_build, time.tree_store,
+            // time.save, time.total), plus the engine's own.
+            std::map<std::string, std::string> kv;
+            auto put = [&kv](const std::string& k, double v) { kv[k] = std::to_string(v); };
+            kv["input.n_sequences"] = std::to_string(s.size());
+            if (!export_dist) kv["input.n_duplicates"] = std::to_string(t.n_duplicates);
+            put("time.load", t.load_s);
+            put("time.sort", t.sort_s);
+            put("time.tree_build", t.tree_s);
+            put("time.tree_store", t.newick_s + t.store_s);
+            put("time.save", 0.0); // no alignment is written
+            put("time.total", since(clock_main));
+            put("time.gpu_init", t.init_s);
+            put("time.gpu_upload", t.upload_s);
+            put("gpu.lcs_kernel_ms", t.kernel_ms);
+            kv["mem.after_tree_kB"] = std::to_string(t.rss_tree_kb);
+            std::ofstream f(stats_path);
+            f << "[stats]\n";
+            for (const auto& e : kv) f << e.first << "=" << e.second << "\n";
+            f.close();
+            if (f.fail()) throw std::runtime_error("writing " + stats_path + " failed");
         }
         if (verbose) {
             std::cerr << "time.load=" << t.load_s << "\n"

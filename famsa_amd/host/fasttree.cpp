@@ -661,6 +661,7 @@ struct FastTree {
             seeds[k] = ids[seed_ids[k]];
             assignments[seed_ids[k]] = k; // seeds belong to themselves
         }
+        if (parallel && prm.top_seeds) *prm.top_seeds = seeds; // the observers' notifySeedsSelected(seeds, depth 0), FastTree.cpp:120-123
         std::vector<std::vector<int>> subgroups(n_seeds);
         for (int j = 0; j < n; ++j) subgroups[assignments[j]].push_back(ids[j]);
 
@@ -833,6 +834,7 @@ void clarans_host(const float* distances, int n_elems, int n_medoids, int n_fixe
 
 void build_tree_fast(LcsSource& src, GT partial, Distance dist, const FastTreeParams& p, tree_structure& tree)
 {
+    if (partial == GT::chained) throw std::runtime_error("Error: Illegal guide tree method."); // msa.cpp:170: no generator to wrap
     if (partial == GT::MST_Prim) partial = GT::SLINK; // reference msa.cpp:134: MST+Prim is not a partial generator
     if (dist == Distance::indel_div_lcs) run_fast<Distance::indel_div_lcs>(src, partial, p, tree);
     else if (dist == Distance::indel075_div_lcs) run_fast<Distance::indel075_div_lcs>(src, partial, p, tree);

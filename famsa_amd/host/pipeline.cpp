@@ -38,10 +38,27 @@ std::string guide_tree_newick(const SeqSet& s, const WorkSet& w, LcsSource& src,
     // (counted on ALL input records); createTreeGenerator (msa.cpp:134-239) wraps the partial generator
     int heuristic = opt.heuristic;
     if (heuristic != 0 && (int)s.size() < opt.fast.threshold) heuristic = 0;
+    if (t) {
+        t->n_records = (int)s.size();
+        t->n_duplicates = w.n_sorted() - w.n_unique();
+    }
     if (heuristic != 0) {
         FastTreeParams fp = opt.fast;
         fp.use_clustering = heuristic == 2;
+        std::vector<int> top_seeds;
+        if (!opt.dump_seeds_path.empty()) fp.top_seeds = &top_seeds;
         build_tree_fast(src, opt.method, opt.dist, fp, tree);
+        if (!opt.dump_seeds_path.empty()) { // SeedDumper (msa.cpp:184-199): the ids without their '>', one per line
+            FILE* f = fopen(opt.dump_seeds_path.c_str(), "w");
+            if (!f) throw std::runtime_error("cannot open " + opt.dump_seeds_path);
+            for (int u : top_seeds) {
+                const std::string& id = s.ids[w.sorted2input[w.unique2sorted[u]]];
+                fprintf(f, "%s\n", id.c_str() + (!id.empty() && id[0] == '>' ? 1 : 0));
+            }
+            fclose(f);
+        }
+    } else if (opt.method == GT::chained) {
+        build_tree_chained(w.n_unique(), opt.chained_seed, tree);
     } else {
         build_tree(src, opt.method, opt.dist, tree, 1);
     }

@@ -15,6 +15,7 @@ namespace famsa_host {
 struct Timings {
     double load_s = 0, sort_s = 0, init_s = 0, upload_s = 0, tree_s = 0, newick_s = 0, store_s = 0, kernel_ms = 0;
     long rss_load_kb = 0, rss_upload_kb = 0, rss_tree_kb = 0, rss_newick_kb = 0; // resident host memory after the stage (/proc/self/status)
+    int n_records = 0, n_duplicates = 0; // input.n_sequences / input.n_duplicates of the reference's statistics (famsa.cpp:114, msa.cpp:662)
     std::string transport; // several GPUs: lcsgpu_multi_transport's report (how the contexts reached each other, which key exchange ran)
 };
 
@@ -27,6 +28,8 @@ struct TreeOptions {
     bool keep_duplicates = false;
     int heuristic = 0; // 0 none, 1 -parttree, 2 -medoidtree
     FastTreeParams fast;
+    uint32_t chained_seed = 0;        // -gt chained [seed]
+    std::string dump_seeds_path;      // -dump_seeds <file>: ids of the top-level split's seeds, one per line (msa.cpp:184-199)
 };
 
 long resident_kb(); // VmRSS of this process

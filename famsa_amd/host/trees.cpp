@@ -12,6 +12,7 @@
 #include <limits>
 #include <queue>
 #include <set>
+#include <random>
 #include <stdexcept>
 #include <thread>
 
@@ -24,6 +25,7 @@ GT gt_from_string(const std::string& name)
     if (name == "upgma") return GT::UPGMA;
     if (name == "upgma_modified") return GT::UPGMA_modified;
     if (name == "nj") return GT::NJ;
+    if (name == "chained") return GT::chained;
     throw std::runtime_error("Error: Illegal guide tree method.");
 }
 
@@ -771,6 +773,7 @@ void build_tree(LcsSource& src, GT method, Distance dist, tree_structure& tree, 
     const int n = src.n();
     tree.assign(std::max(n, 0), node_t(-1, -1));
     if (n < 2) return;
+    if (method == GT::chained) throw std::runtime_error("Error: Illegal guide tree method."); // no distances: build_tree_chained
     if (method == GT::MST_Prim) {
         if (dist == Distance::indel_div_lcs) mst_prim<Distance::indel_div_lcs>(src, tree);
         else if (dist == Distance::indel075_div_lcs) mst_prim<Distance::indel075_div_lcs>(src, tree);
@@ -778,6 +781,23 @@ void build_tree(LcsSource& src, GT method, Distance dist, tree_structure& tree, 
         return;
     }
     build_tree_partial(src, method, dist, tree);
+}
+
+void build_tree_chained(int n, uint32_t seed, tree_structure& tree)
+{
+    tree.assign(std::max(n, 0), node_t(-1, -1));
+    if (n < 2) return;
+    std::vector<int> idx(n);
+    for (int i = 0; i < n; ++i) idx[i] = i;
+    std::mt19937 g(seed);
+    for (int i = 0; i + 1 < n; ++i) { // Fisher-Yates; the draw is det_uniform_int_distribution<int>(i, n - 1) (utils/deterministic_random.h:62-76)
+        const uint32_t diff = (uint32_t)(n - 1 - i) + 1, bad = 0xffffffffu / diff;
+        uint32_t r;
+        do r = (uint32_t)g(); while (r / diff >= bad);
+        std::swap(idx[i], idx[i + (int)(r % diff)]);
+    }
+    tree.emplace_back(idx[0], idx[1]);
+    for (int i = 2; i < n; ++i) tree.emplace_back(idx[i], (int)tree.size() - 1);
 }
 
 // ---------------------------------------------------------------------------------------------

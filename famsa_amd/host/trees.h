@@ -17,13 +17,20 @@ namespace famsa_host {
 using node_t = std::pair<int, int>;
 using tree_structure = std::vector<node_t>;
 
-enum class GT { MST_Prim, SLINK, UPGMA, UPGMA_modified, NJ };
-GT gt_from_string(const std::string& name); // "sl" | "slink" | "upgma" | "upgma_modified" | "nj"
+enum class GT { MST_Prim, SLINK, UPGMA, UPGMA_modified, NJ, chained };
+GT gt_from_string(const std::string& name); // "sl" | "slink" | "upgma" | "upgma_modified" | "nj" | "chained"
 
 // Build the guide tree over src's sequences (ids 0..n-1 = the sorted unique working order).
 // Result has 2n-1 nodes.  Restates (reference, src/tree/): MSTPrim.cpp:280-549 + 784-833,
 // SingleLinkage.cpp:31-189, UPGMA.cpp:39-51 + 114-295, NeighborJoining.cpp:10-118.
 void build_tree(LcsSource& src, GT method, Distance dist, tree_structure& tree, int n_threads);
+
+// `-gt chained [seed]` (reference tree/TreeDefs.h:59,98; tree/Chained.h:8-35, developer builds only): a caterpillar over a
+// random order of the n leaves -- node n = (idx[0], idx[1]), node n + i - 1 = (idx[i], the previous node).  No distances
+// are computed.  The reference seeds its shuffle from std::random_device (a different tree on every run) and release
+// builds answer "Illegal guide tree method"; here the order is a Fisher-Yates shuffle driven by mt19937(seed) through the
+// reference's own det_uniform_int_distribution, so that a seed names one tree on every platform.
+void build_tree_chained(int n, uint32_t seed, tree_structure& tree);
 
 // IPartialGenerator::runPartial (reference tree/IPartialGenerator.h:13): APPEND the n-1 internal
 // nodes of the tree over src's n sequences to `tree`, with local ids (leaves 0..n-1, internal
@@ -42,6 +49,9 @@ struct FastTreeParams { // CParams::medoid, reference core/params.h:88-97
     float cluster_fraction = 0.1f;
     int cluster_iters = 2;
     int n_threads = 1; // host cores the recursion may keep busy
+    // -dump_seeds (reference msa.cpp:184-199, tree/FastTree.cpp:120-123): when set, receives the seeds the top-level
+    // split ends up with (depth 0 only), as ids of the source, in seed order
+    std::vector<int>* top_seeds = nullptr;
 };
 // threads of the recursion's task pool for `n_cpu` cores: the ones waiting for the GPU cost no core
 inline int fasttree_pool_threads(int n_cpu) { return n_cpu > 1 ? 2 * n_cpu : 1; }

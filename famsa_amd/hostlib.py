@@ -23,6 +23,9 @@ class Host:
         heur = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int]
         lib.famsa_host_tree_from_matrix.argtypes = [C.c_char_p, C.c_void_p, C.c_char_p, C.c_int, C.c_int, *heur,
                                                     C.c_char_p, C.c_long]
+        lib.famsa_host_tree_from_matrix_ex.restype = C.c_long
+        lib.famsa_host_tree_from_matrix_ex.argtypes = [C.c_char_p, C.c_void_p, C.c_char_p, C.c_int, C.c_int, *heur, C.c_int,
+                                                       C.c_uint32, C.c_char_p, C.c_char_p, C.c_long]
         lib.famsa_host_dist_export_from_matrix.argtypes = [C.c_char_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                                            C.c_char_p]
         lib.famsa_host_tree_gpu.restype = C.c_long
@@ -59,11 +62,14 @@ class Host:
 
     def tree_from_matrix(self, fasta, square, method, distance="indel075_div_lcs", keep_duplicates=False,
                          heuristic=None, subtree_size=0, sample_size=0, threshold=0, cluster_fraction=0.0,
-                         cluster_iters=0):
+                         cluster_iters=0, num_evals=0, chained_seed=0, dump_seeds=None):
+        """`-gt <method> -gt_export` over a caller-supplied oriented LCS matrix; num_evals / chained_seed / dump_seeds are the
+        CLI's -num_evals, the seed of -gt chained, and -dump_seeds <file>."""
         sq = np.ascontiguousarray(square, np.uint32)
-        return self._text(lambda buf: self.lib.famsa_host_tree_from_matrix(
+        return self._text(lambda buf: self.lib.famsa_host_tree_from_matrix_ex(
             fasta.encode(), sq.ctypes.data, method.encode(), DIST[distance], int(keep_duplicates), self.HEUR[heuristic],
-            subtree_size, sample_size, threshold, cluster_fraction, cluster_iters, buf, len(buf)))
+            subtree_size, sample_size, threshold, cluster_fraction, cluster_iters, num_evals, chained_seed,
+            dump_seeds.encode() if dump_seeds else None, buf, len(buf)))
 
     def dist_export_from_matrix(self, fasta, square, path, distance="indel075_div_lcs", square_matrix=False,
                                 pid=False):

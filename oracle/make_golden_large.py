@@ -4,7 +4,8 @@
 only; minutes of CPU.  Writes tests/golden/meta_large.json (sha256 values only -- the data is
 regenerated deterministically by famsa_amd/seqio.py on the GPU box).
 
-    python oracle/make_golden_large.py [c3] [c4] [c5] [c5huge] [c4upgma] [realmix]      (default: c3 c5 c4)
+    python oracle/make_golden_large.py [c3] [c4] [c5] [c5huge] [c4upgma] [realmix] [c4slink] [c3indel] [c4indel] [realmixnj]
+                                                                                    (default: c3 c5 c4)
 
 c5huge = the 3 000 000-sequence family set (BASELINE config C5's size); c4upgma = -gt upgma / upgma_modified at
 100 000 x 400 aa (the reference holds the 20 GB float triangle in host memory).
@@ -82,19 +83,21 @@ def c3more(ref, meta):
     ref.close(h)
 
 
-def c4(ref, meta, gts=("sl",)):
-    n, L = 100000, 400
+def c4(ref, meta, gts=("sl",), distance=1, n=100000, key="synth100k"):
+    """-gt <gts> at n x 400 aa; distance 0 = -dist indel_div_lcs (keys carry "_indel")."""
+    L = 400
     codes, offsets = seqio.synth_uniform(n, L)
-    path = "/tmp/golden_synth100k.fasta"
+    path = f"/tmp/golden_synth{n}.fasta"
     seqio.to_fasta(codes, offsets, path)
     h = ref.open_fasta(path)
-    rec = meta.get("synth100k", {"n": n, "len": L, "codes_sha256": sha(codes.tobytes())})
+    rec = meta.get(key, {"n": n, "len": L, "codes_sha256": sha(codes.tobytes())})
+    tag = "" if distance == 1 else "_indel"
     for gt in gts:
         t0 = time.time()
-        rec[f"{gt}_newick_sha256"] = sha(ref.tree(h, gt, threads=THREADS))
-        rec[f"{gt}_reference_seconds_{THREADS}_threads"] = round(time.time() - t0, 1)
-        print("c4", gt, "%.0f s" % (time.time() - t0), flush=True)
-        meta["synth100k"] = rec
+        rec[f"{gt}{tag}_newick_sha256"] = sha(ref.tree(h, gt, distance=distance, threads=THREADS))
+        rec[f"{gt}{tag}_reference_seconds_{THREADS}_threads"] = round(time.time() - t0, 1)
+        print(key, gt + tag, "%.0f s" % (time.time() - t0), flush=True)
+        meta[key] = rec
         save(meta)
     ref.close(h)
 
@@ -153,13 +156,30 @@ def realmix(ref, meta):
     save(meta)
 
 
+def realmix_nj_keepdups(ref, meta):
+    """-gt nj -keep-duplicates on the 13 774-record real set (the reference's O(n^3) loop on one thread)."""
+    path = "/tmp/golden_realmix.fasta"
+    seqio.realmix_fasta(oracle_bind.GOLDEN, path)
+    h = ref.open_fasta(path)
+    t0 = time.time()
+    meta["realmix"]["nj_keepdups_newick_sha256"] = sha(ref.tree(h, "nj", keep_dups=1, threads=THREADS))
+    meta["realmix"]["nj_keepdups_reference_seconds"] = round(time.time() - t0, 1)
+    print("realmix nj keepdups %.0f s" % (time.time() - t0), flush=True)
+    ref.close(h)
+    save(meta)
+
+
 def main():
     which = sys.argv[1:] or ["c3", "c5", "c4"]
     ref = oracle_bind.Ref()
     meta = load()
     for w in which:
         {"c3": c3, "c3more": c3more, "c4": c4, "c5": c5, "c5huge": lambda r, m: c5(r, m, (3000000,)),
-         "c4upgma": lambda r, m: c4(r, m, ("upgma", "upgma_modified")), "realmix": realmix}[w](ref, meta)
+         "c4upgma": lambda r, m: c4(r, m, ("upgma", "upgma_modified")), "realmix": realmix,
+         "c4slink": lambda r, m: c4(r, m, ("slink",)),
+         "c3indel": lambda r, m: c4(r, m, ("sl", "upgma"), distance=0, n=10000, key="synth10k"),
+         "c4indel": lambda r, m: c4(r, m, ("sl", "upgma"), distance=0),
+         "realmixnj": realmix_nj_keepdups}[w](ref, meta)
     print(json.dumps(load(), indent=1))
 
 

@@ -168,6 +168,19 @@ struct MedoidParams { // CParams::medoid, core/params.h:88-97
     int subtree_size = 100, sample_size = 2000, num_evaluations = 1, threshold = 2000;
     float cluster_fraction = 0.1f;
     int cluster_iters = 2;
+    std::string seed_file_name; // CParams::seed_file_name (-dump_seeds)
+};
+
+// the observer createTreeGenerator registers for -dump_seeds (msa.cpp:184-199), restated: the depth-0 seeds' ids
+class SeedDumper : public IFastTreeObserver {
+    std::ofstream ofs;
+public:
+    explicit SeedDumper(const std::string& fname) { ofs.open(fname); }
+    void notifySeedsSelected(const std::vector<CSequence*>& seeds, int depth) override
+    {
+        if (depth == 0)
+            for (const auto s : seeds) ofs << s->id.substr(1) << std::endl;
+    }
 };
 
 template <Distance D>
@@ -196,9 +209,11 @@ std::string run_tree(const RefSet& rs, int gt, int heuristic, const MedoidParams
     if (heuristic != 0) { // msa.cpp:172-239; heuristic 1 = parttree, 2 = medoidtree
         std::shared_ptr<IClustering> clustering =
             (heuristic == 1) ? nullptr : std::make_shared<CLARANS>(mp.cluster_fraction, mp.cluster_iters);
-        gen = std::make_shared<FastTree<D>>(n_threads, isa, std::dynamic_pointer_cast<IPartialGenerator>(gen),
-                                           mp.subtree_size, mp.sample_size, mp.num_evaluations, mp.threshold,
-                                           clustering);
+        auto ft = std::make_shared<FastTree<D>>(n_threads, isa, std::dynamic_pointer_cast<IPartialGenerator>(gen),
+                                                mp.subtree_size, mp.sample_size, mp.num_evaluations, mp.threshold,
+                                                clustering);
+        if (!mp.seed_file_name.empty()) ft->registerObserver(std::make_shared<SeedDumper>(mp.seed_file_name));
+        gen = ft;
     }
     pre_run(mapped);
     (*gen)(mapped, tree.raw());
@@ -301,6 +316,33 @@ long ref_tree_newick(void* h, int gt, int distance, int heuristic, int subtree_s
         if (threshold > 0) mp.threshold = threshold;
         if (cluster_fraction > 0) mp.cluster_fraction = cluster_fraction;
         if (cluster_iters > 0) mp.cluster_iters = cluster_iters;
+        std::string s = (distance == 0)
+            ? run_tree<Distance::indel_div_lcs>(*(RefSet*)h, gt, heuristic, mp, keep_dups != 0, n_threads, isa_of(isa))
+            : run_tree<Distance::indel075_div_lcs>(*(RefSet*)h, gt, heuristic, mp, keep_dups != 0, n_threads, isa_of(isa));
+        if ((long)s.size() + 1 > cap)
+            return -(long)s.size() - 1;
+        memcpy(out, s.c_str(), s.size() + 1);
+        return (long)s.size();
+    } catch (...) {
+        return -1;
+    }
+}
+
+// ref_tree_newick plus the two parameters it does not carry: -num_evals (core/params.cpp:206) and -dump_seeds
+// (params.cpp:217; seeds_path NULL or "" = none).
+long ref_tree_newick_ex(void* h, int gt, int distance, int heuristic, int subtree_size, int sample_size,
+                        int threshold, float cluster_fraction, int cluster_iters, int num_evals, const char* seeds_path,
+                        int keep_dups, int n_threads, int isa, char* out, long cap)
+{
+    try {
+        MedoidParams mp;
+        if (subtree_size > 0) mp.subtree_size = subtree_size;
+        if (sample_size > 0) mp.sample_size = sample_size;
+        if (threshold > 0) mp.threshold = threshold;
+        if (cluster_fraction > 0) mp.cluster_fraction = cluster_fraction;
+        if (cluster_iters > 0) mp.cluster_iters = cluster_iters;
+        if (num_evals > 0) mp.num_evaluations = num_evals;
+        if (seeds_path) mp.seed_file_name = seeds_path;
         std::string s = (distance == 0)
             ? run_tree<Distance::indel_div_lcs>(*(RefSet*)h, gt, heuristic, mp, keep_dups != 0, n_threads, isa_of(isa))
             : run_tree<Distance::indel075_div_lcs>(*(RefSet*)h, gt, heuristic, mp, keep_dups != 0, n_threads, isa_of(isa));

@@ -116,6 +116,8 @@ class Ref:
         lib.ref_lcs_rect.argtypes = [vp, vp, i, vp, i, i, vp]
         lib.ref_tree_newick.restype = C.c_long
         lib.ref_tree_newick.argtypes = [vp, i, i, i, i, i, i, C.c_float, i, i, i, i, C.c_char_p, C.c_long]
+        lib.ref_tree_newick_ex.restype = C.c_long
+        lib.ref_tree_newick_ex.argtypes = [vp, i, i, i, i, i, i, C.c_float, i, i, C.c_char_p, i, i, i, C.c_char_p, C.c_long]
         lib.ref_dist_export.argtypes = [vp, i, i, i, i, i, C.c_char_p]
         lib.ref_time_triangle.restype = C.c_double
         lib.ref_time_triangle.argtypes = [vp, i, i, i, C.POINTER(C.c_double), C.POINTER(C.c_double), vp]
@@ -152,10 +154,15 @@ class Ref:
         return out
 
     def tree(self, h, gt, distance=1, heuristic=0, subtree=0, sample=0, threshold=0, cluster_fraction=0.0,
-             cluster_iters=0, keep_dups=0, threads=4, isa=2, cap=1 << 25):
+             cluster_iters=0, keep_dups=0, threads=4, isa=2, cap=1 << 25, num_evals=0, dump_seeds=None):
         buf = C.create_string_buffer(cap)
-        n = self.lib.ref_tree_newick(h, self.GT[gt], distance, heuristic, subtree, sample, threshold,
-                                     cluster_fraction, cluster_iters, keep_dups, threads, isa, buf, len(buf))
+        if num_evals or dump_seeds:
+            n = self.lib.ref_tree_newick_ex(h, self.GT[gt], distance, heuristic, subtree, sample, threshold, cluster_fraction,
+                                            cluster_iters, num_evals, dump_seeds.encode() if dump_seeds else None,
+                                            keep_dups, threads, isa, buf, len(buf))
+        else:
+            n = self.lib.ref_tree_newick(h, self.GT[gt], distance, heuristic, subtree, sample, threshold,
+                                         cluster_fraction, cluster_iters, keep_dups, threads, isa, buf, len(buf))
         assert n >= 0, n
         return buf.raw[:n]
 

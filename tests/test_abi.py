@@ -60,7 +60,7 @@ def test_no_gpu_means_error_not_fallback():
         famsa_amd.LcsGpu(0)
     assert "no HIP device" in str(e.value)
     # the host tool fails the same way
-    import host_bind
+    from famsa_amd import hostlib as host_bind
     host = host_bind.Host()
     with pytest.raises(RuntimeError) as e2:
         host.tree_gpu(os.path.join(oracle_bind.GOLDEN, "adeno_fiber", "adeno_fiber"), "sl")

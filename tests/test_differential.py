@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-import host_bind
+from famsa_amd import hostlib as host_bind
 import oracle_bind
 from famsa_amd import seqio
 
@@ -118,6 +118,35 @@ def test_medoid_and_parttree_match_reference(host, ref, oracle, tmp_path, seed):
                 got = host.tree_from_matrix(fasta, sq, gt, heuristic=heur, subtree_size=8, sample_size=40, threshold=30,
                                             cluster_fraction=0.3, cluster_iters=2)
                 assert got == want, (gt, heur)
+    finally:
+        ref.close(h)
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_num_evals_and_dump_seeds_match_reference(host, ref, oracle, tmp_path, seed):
+    """-num_evals 3 (reference core/params.cpp:206: three evaluations per split, the cheapest kept) and -dump_seeds
+    (msa.cpp:184-199: the depth-0 seeds' ids) against the reference's own FastTree + observer."""
+    rng = np.random.Generator(np.random.PCG64(4100 + seed))
+    n = int(rng.integers(180, 420))
+    ids, seqs = random_set(rng, n, 60, "ACDEFG", 0.1)
+    fasta = str(tmp_path / "in.fasta")
+    with open(fasta, "w") as f:
+        for i, s in zip(ids, seqs):
+            f.write(f"{i}\n{s}\n")
+    enc = [oracle.encode(s) for s in seqs]
+    codes, offsets = seqio.pack(enc)
+    sq = oracle.rect(codes, offsets, np.arange(n), np.arange(n))
+    h = ref.open_fasta(fasta)
+    try:
+        for gt, heur_id, heur, evals in [("upgma", 2, "medoidtree", 3), ("sl", 2, "medoidtree", 2), ("upgma", 1, "parttree", 3),
+                                         ("upgma", 2, "medoidtree", 1)]:
+            a, b = str(tmp_path / "seeds_ref.txt"), str(tmp_path / "seeds_ours.txt")
+            want = ref.tree(h, gt, heuristic=heur_id, threads=3, subtree=8, sample=40, threshold=30, cluster_fraction=0.3,
+                            cluster_iters=2, num_evals=evals, dump_seeds=a)
+            got = host.tree_from_matrix(fasta, sq, gt, heuristic=heur, subtree_size=8, sample_size=40, threshold=30,
+                                        cluster_fraction=0.3, cluster_iters=2, num_evals=evals, dump_seeds=b)
+            assert got == want, (gt, heur, evals)
+            assert open(a).read() == open(b).read() and len(open(a).read().split()) == 8, (gt, heur, evals)
     finally:
         ref.close(h)
 

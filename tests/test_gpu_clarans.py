@@ -5,7 +5,7 @@ import time
 import numpy as np
 import pytest
 
-import host_bind
+from famsa_amd import hostlib as host_bind
 import oracle_bind
 from famsa_amd import seqio
 

@@ -7,7 +7,7 @@ import subprocess
 
 import pytest
 
-import host_bind
+from famsa_amd import hostlib as host_bind
 import oracle_bind
 from famsa_amd import seqio
 

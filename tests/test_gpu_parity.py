@@ -408,7 +408,7 @@ def test_sets_with_a_sequence_beyond_65535_residues(engine, oracle):
     gd, ga = d0.copy(), np.zeros(n, np.int32)
     engine.assign_seeds(seeds, ids, gd, ga)
     assert (ga == wa).all() and (gd.view(np.uint32) == wd.view(np.uint32)).all()
-    import host_bind
+    from famsa_amd import hostlib as host_bind
     sub = np.array([n - 1] + list(range(30)), np.int32)
     lcs_tri = want[np.ix_(sub, sub)][np.tril_indices(len(sub), -1)]
     dist = oracle.dist_triangle_f32(lcs_tri, np.array([lens[i] for i in sub], np.uint32), 1)

@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-import host_bind
+from famsa_amd import hostlib as host_bind
 import oracle_bind
 from famsa_amd import seqio
 
@@ -428,3 +428,51 @@ def test_working_order_on_a_set_that_runs_the_parallel_sort(host, oracle, tmp_pa
     assert list(s2u) == expect_u
     u_keep, s2i_keep, s2u_keep = host.workset(f, len(seqs), keep_duplicates=True)
     assert list(s2i_keep) == want and u_keep == len(seqs) and list(s2u_keep) == list(range(len(seqs)))
+
+
+def _mt19937(seed):
+    """The mt19937 stream (32-bit outputs) -- numpy's bit generator seeded the std::mt19937 way."""
+    from numpy.random import MT19937
+    bg = MT19937()
+    st = bg.state
+    key = np.zeros(624, np.uint32)
+    key[0] = seed & 0xFFFFFFFF
+    for i in range(1, 624):
+        key[i] = (1812433253 * (int(key[i - 1]) ^ (int(key[i - 1]) >> 30)) + i) & 0xFFFFFFFF
+    st["state"]["key"] = key
+    st["state"]["pos"] = 624
+    bg.state = st
+    return lambda: int(bg.random_raw())
+
+
+@pytest.mark.parametrize("seed", [0, 1, 77])
+def test_chained_tree_is_a_caterpillar_over_the_seeded_order(host, oracle, seed):
+    """-gt chained [seed] (reference tree/Chained.h:8-35, developer builds): node n = (idx[0], idx[1]), every later node
+    (idx[i], previous node); the order here is a Fisher-Yates shuffle by mt19937(seed) through the reference's
+    det_uniform_int_distribution -- restated below -- over the sorted unique working order; no distance is looked at."""
+    f = os.path.join(G, "adeno_fiber", "adeno_fiber")
+    ids, seqs = seqio.read_fasta(f)
+    n = len(ids)
+    zeros = np.zeros((n, n), np.uint32)  # the matrix must not matter
+    got = host.tree_from_matrix(f, zeros, "chained", chained_seed=seed)
+    u, s2i, s2u = host.workset(f, n)
+    assert u == n  # no duplicates in this set: leaf k of the tree = record s2i[k]
+    g = _mt19937(seed)
+    idx = list(range(n))
+    for i in range(n - 1):
+        diff = n - i
+        bad = 0xFFFFFFFF // diff
+        while True:
+            r = g()
+            if r // diff < bad:
+                break
+        j = i + r % diff
+        idx[i], idx[j] = idx[j], idx[i]
+    name = lambda k: ids[s2i[k]].lstrip(">")
+    text = "(%s:1.0,%s:1.0)" % (name(idx[0]), name(idx[1]))
+    for i in range(2, n):
+        text = "(%s:1.0,%s:1.0)" % (name(idx[i]), text)
+    assert got.decode() == text + ";"
+    assert host.tree_from_matrix(f, zeros, "chained", chained_seed=seed + 1) != got
+    with pytest.raises(RuntimeError, match="Illegal guide tree method"):  # nothing to wrap (reference msa.cpp:170)
+        host.tree_from_matrix(f, zeros, "chained", heuristic="medoidtree", threshold=10)
