@@ -188,20 +188,11 @@ struct UpgmaArgs {
     int32_t* right;
     int32_t n;
     int32_t n_blocks;
-    uint32_t* chain_ctl;   // 64 words, zeroed: [0] tickets of the merge chain's workgroups, [32] its barrier counter
-    uint32_t* chain_slots; // [2][UPGMA_CHAIN_MAX_WG][8] the workgroups' partial minima of a merge, alternating by parity
-    unsigned long long* chain_dbg; // measurement aid (LCSGPU_UPGMA_CHAIN_DBG): 8 phase totals in 10 ns ticks, or NULL
 };
-// distances + initial row minima; then EITHER the n launches of the merge steps ...
+// distances + initial row minima; then the n launches of the merge steps
 hipError_t launch_upgma_prologue(const UpgmaArgs& a, const void* lcs, int elem_size, const uint32_t* lens, const float* pow_f32,
                                  int kind, hipStream_t stream);
 hipError_t launch_upgma_steps(const UpgmaArgs& a, bool modified, hipStream_t stream);
-// ... OR all merges inside one kernel whose workgroups run on ONE XCD (square layout only; tree_kernels.hip).  a.sel[9]
-// afterwards: 1 = done, 2 = the workgroups could not be assembled (nothing was touched: run the steps), 3 = lost on the way
-constexpr int UPGMA_CHAIN_MAX_WG = 32;
-constexpr int UPGMA_CHAIN_THREADS = 1024;
-constexpr int UPGMA_CHAIN_ROWS = 8; // rows per thread at most
-hipError_t launch_upgma_chain(const UpgmaArgs& a, bool modified, int n_workgroups, hipStream_t stream);
 hipError_t launch_upgma(const UpgmaArgs& a, const void* lcs, int elem_size, const uint32_t* lens,
                         const float* pow_f32, int kind, bool modified, hipStream_t stream);
 
@@ -231,29 +222,9 @@ struct UpgmaBatchArgs {
     float* side;          // [UPGMA_BATCH_MAX][ld] the rows the pending batch creates, along the slots
     float* part_d;        // [UPGMA_BATCH_MAX][n_blocks] per-workgroup first minima of those rows
     uint32_t* part_j;
-    unsigned long long* dbg; // measurement aid (LCSGPU_UPGMA_BATCH_DBG): 16 phase totals in 10 ns ticks, or NULL
 };
 hipError_t launch_upgma_batch_init(const UpgmaBatchArgs& a, hipStream_t stream);
 hipError_t launch_upgma_batches(const UpgmaBatchArgs& a, bool modified, int k, int first, int count, hipStream_t stream);
-
-// ---- leaf sub-trees of the FastTree recursion: UPGMA, one workgroup per leaf (tree_kernels.hip) ----
-constexpr int LEAF_MAX = 2048; // members of a leaf (the reference's default threshold is 2000)
-struct LeafArgs {
-    const void* lcs;              // the batch's packed uint16 LCS triangles, list after list
-    const int32_t* ids;           // the concatenated id lists
-    const int64_t* group_offsets; // [n_groups + 1] into ids
-    const int64_t* tri_base;      // [n_groups] first pair of each list's triangle
-    const int64_t* node_base;     // [n_groups] first internal node of each list (sum of m_h - 1 over the lists before it)
-    const int32_t* order;         // [n_groups] lists by size, descending: workgroup b builds list order[b]
-    const uint32_t* lens;
-    const float* pow_f32;
-    int32_t kind;
-    float* D;                     // scratch: the float triangles, laid out like lcs
-    int32_t* left;                // children of the internal nodes, local ids (leaves 0..m-1, internal m..2m-2)
-    int32_t* right;
-    int32_t* err;                 // [0] set when a leaf has no finite nearest neighbour
-};
-hipError_t launch_leaf_upgma(const LeafArgs& a, int n_groups, bool modified, hipStream_t stream);
 
 // ---- device-side neighbour joining (tree_kernels.hip) ----
 struct NjArgs {
@@ -286,36 +257,32 @@ hipError_t launch_build_set(const uint8_t* codes, const uint64_t* offsets, const
 
 // ---- device-side CLARANS (clarans_kernels.hip) ----
 constexpr int CLARANS_MAX_MEDOIDS = 1024;
+constexpr int CLARANS_MAX_NONMEDOIDS = 2048; // every position's state in the registers of one workgroup
 struct ClaransArgs {
     const float* D;      // float distance triangle over the sample members
     float* DMt;          // [n_medoids][n_elems] distance of the member at a position to the medoid in a slot
     int32_t* cand;       // [n_elems] permutation of the members; positions < n_medoids are the medoids
     float4* st;          // [n_elems] by position: {d(nearest), d(second), slot(nearest), slot(second)}
     const int32_t* draws; // pre-drawn positions xx of the steps (the position generator's output)
-    int32_t* win_xx;     // [2][win_cap] positions of the pending steps (double-buffered, state[7] = current)
-    int32_t* win_x;      // [2][win_cap] the members at those positions
-    float* res_delta;    // [window] best delta of every pending step
-    int32_t* res_mm;     // [window] its medoid slot
     float* cost_log;     // [1 + n_elems] addends of the running cost, in the reference's order
-    int32_t* state;      // [0] next draw  [1] done  [2] log length  [3] accepts  [4] arrivals  [5] cost bits  [6] error  [7] window buffer
-                         // [8] steps of the window already evaluated  [9] stage  [10] no accept yet in this search
-    int32_t n_elems, n_medoids, n_fixed, draws_len, win_cap;
+    int32_t* state;      // [0] next draw  [1] done  [2] log length  [3] accepts  [4] no round yet  [5] cost bits  [6] error
+                         // [8] steps of the window already evaluated  [9] stage  [10] no accept yet in this search  [11..15] statistics
+    int32_t n_elems, n_medoids, n_fixed, draws_len;
     int32_t corrected;   // steps without an accept that end a local search (Clustering.cpp:21-29)
     int32_t stage0;      // steps evaluated in the first round of a window; doubled per round without an accept, at most 64
-    int32_t lists;       // evaluate with per-slot lists where the shape allows (clarans_kernels.hip, evaluate_step_lists)
-    // a round as ONE launch (clarans_round_kernel): the second copy of everything a workgroup reads at its first load
-    // level and another writes in the same launch; the parity-0 copies are cand / st / cost_log / state above
-    int32_t fused;
+    // the second copy of everything a workgroup reads at its first load level and another writes in the same launch
+    // (by round parity); the parity-0 copies are cand / st / cost_log / state above
     int32_t* cand1;
     float4* st1;
     float* log1;
     int32_t* state1;
-    int32_t* res2;       // [2][4][64] step results by round parity: best delta (bits), its slot, the step's position, its member
+    int32_t* res2;       // [2][5][64] step results by round parity: best delta (bits), its slot, the step's position, its member, why it ended
     int32_t* host_state; // mapped host memory (16 words) the last round of a look leaves the state block in, or NULL
 };
-// Searches that are advanced together, one grid row each: however many host threads are searching,
-// a round costs two launches (evaluate, apply) in total instead of two per search -- with one launch
-// pair per search the command processor, not the kernels, bounded the throughput beyond ~4 searches.
+constexpr size_t CLARANS_RES_BYTES = 2 * 5 * 64 * 4;
+// Searches that are advanced together, one grid row each: however many host threads are searching, a round costs one
+// launch in total instead of one per search -- with a launch per search the command processor, not the kernels,
+// bounded the throughput beyond ~4 searches.
 constexpr int CLARANS_MAX_BATCH = 16;
 struct ClaransBatch {
     ClaransArgs s[CLARANS_MAX_BATCH];
@@ -324,9 +291,6 @@ struct ClaransBatch {
 hipError_t launch_subset_distances(const void* lcs, int elem_size, const int32_t* ids, const uint32_t* lens,
                                    const float* pow_f32, int kind, int n, float* D, hipStream_t stream);
 hipError_t launch_clarans_init(const ClaransArgs& a, hipStream_t stream);
-hipError_t launch_clarans_rounds(const ClaransBatch& b, int rounds, hipStream_t stream);
-hipError_t launch_clarans_rounds_fused(const ClaransBatch& b, int rounds, hipStream_t stream); // every search of b: fused != 0; rounds even
-hipError_t clarans_lists_ticks(unsigned long long out[8]); // LCSGPU_CLARANS_LISTS=2: phase ticks of the list evaluation
-hipError_t launch_clarans_chain(const ClaransBatch& b, int rounds, int ranks, hipStream_t stream);
+hipError_t launch_clarans_rounds(const ClaransBatch& b, int rounds, hipStream_t stream); // rounds even
 
 } // namespace lcsgpu

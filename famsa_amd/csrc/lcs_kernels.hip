@@ -867,8 +867,7 @@ int refs_per_block_for(int h, bool quirk, long n_refs, long col_blocks, bool fus
 template <int H, int RG, bool QUIRK, bool FUSE>
 static hipError_t launch_one(const RowsArgs& a, dim3 grid, hipStream_t stream)
 {
-    static const size_t lds_pad = getenv("LCSGPU_LDS_PAD") ? (size_t)atoi(getenv("LCSGPU_LDS_PAD")) : 0; // measurement aid: fewer workgroups per CU
-    const size_t lds = (size_t)a.refs_per_block * ((H + 1) / 2) * 256 + (FUSE ? FUSE_LDS_BYTES : 0) + lds_pad;
+    const size_t lds = (size_t)a.refs_per_block * ((H + 1) / 2) * 256 + (FUSE ? FUSE_LDS_BYTES : 0);
     if constexpr (QUIRK)
         hipLaunchKernelGGL((lcs_rows_kernel_quirk<H, FUSE>), grid, dim3(256), lds, stream, a);
     else

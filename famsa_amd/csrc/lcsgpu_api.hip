@@ -8,6 +8,20 @@ namespace lcsgpu_impl {
 thread_local std::string g_err;
 thread_local LastCall g_last;
 
+int tune_int(const char* key, int dflt)
+{
+    const char* e = getenv("LCSGPU_TUNE");
+    if (!e) return dflt;
+    const size_t kl = strlen(key);
+    for (const char* p = e; *p;) {
+        const char* end = strchr(p, ',');
+        const size_t len = end ? (size_t)(end - p) : strlen(p);
+        if (len > kl + 1 && !strncmp(p, key, kl) && p[kl] == '=') return atoi(p + kl + 1);
+        p += len + (end ? 1 : 0);
+    }
+    return dflt;
+}
+
 int fail(int code, const char* fmt, ...)
 {
     char buf[512];
@@ -85,7 +99,6 @@ int ensure_batcher(lcsgpu_ctx* ctx, ClaransBatcher& B)
     // hundreds of microseconds each: their workgroups go first when slots free up
     int least = 0, greatest = 0;
     if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = greatest = 0;
-    if (getenv("LCSGPU_CLARANS_NO_PRIORITY")) greatest = least = 0;
     if (greatest != least) HIP_TRY(hipStreamCreateWithPriority(&B.stream, hipStreamNonBlocking, greatest));
     else HIP_TRY(hipStreamCreateWithFlags(&B.stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&B.ev, hipEventBlockingSync | hipEventDisableTiming));
@@ -220,37 +233,10 @@ int run_rows(lcsgpu_ctx* ctx, Lane& L, int mode, const int32_t* ref_ids, int32_t
     }
 
     HIP_TRY(hipEventRecord(L.ev_start, L.stream));
-    // several buckets: their launches go to the lane's side streams (see Lane::aux); the long-ref kernel shares the
-    // lane's carry scratch between its launches and stays on the main stream
-    // -- opt-in (LCSGPU_SPREAD=1): measured on hemopexin's 4 launches the overlap is worth 0.02 of 0.26 ms, while creating
-    // the side streams costs a lane ~30 ms once (a one-shot CLI run on a small input is 0.3 s in all)
-    static const bool spread_on = getenv("LCSGPU_SPREAD") != nullptr;
-    bool spread = spread_on && buckets.size() > 1;
-    if (spread && !L.aux_tried) {
-        L.aux_tried = true;
-        bool ok = hipEventCreateWithFlags(&L.fork, hipEventDisableTiming) == hipSuccess;
-        for (int k = 0; k < Lane::N_AUX && ok; ++k)
-            ok = hipStreamCreateWithFlags(&L.aux[k], hipStreamNonBlocking) == hipSuccess &&
-                 hipEventCreateWithFlags(&L.aux_done[k], hipEventDisableTiming) == hipSuccess;
-        if (!ok) (void)hipGetLastError();
-        L.aux_ok = ok;
-    }
-    spread = spread && L.aux_ok;
-    bool aux_used[Lane::N_AUX] = {false, false, false};
-    if (spread) HIP_TRY(hipEventRecord(L.fork, L.stream)); // behind the plan's copy
-    int next_side = 0;
-    const int rc_launch = [&]() -> int {
+    // (a call whose refs fall into several half-word classes is several launches, one after the other on the lane's stream)
     for (size_t b = 0; b < buckets.size(); ++b) {
         const Bucket& bk = buckets[b];
         hipStream_t st = L.stream;
-        if (spread && bk.bv != 0 && b > 0) {
-            const int k = next_side++ % Lane::N_AUX;
-            if (!aux_used[k]) {
-                HIP_TRY(hipStreamWaitEvent(L.aux[k], L.fork, 0));
-                aux_used[k] = true;
-            }
-            st = L.aux[k];
-        }
         RowsArgs a{};
         a.tiles = (const uint8_t*)ctx->d_tiles.p;
         a.tile_base = (const uint64_t*)ctx->d_tile_base.p;
@@ -325,14 +311,6 @@ int run_rows(lcsgpu_ctx* ctx, Lane& L, int mode, const int32_t* ref_ids, int32_t
             }
         }
     }
-    return LCSGPU_OK;
-    }();
-    for (int k = 0; k < Lane::N_AUX; ++k)
-        if (aux_used[k]) { // join: whatever follows on the lane's stream sees every bucket's results
-            HIP_TRY(hipEventRecord(L.aux_done[k], L.aux[k]));
-            HIP_TRY(hipStreamWaitEvent(L.stream, L.aux_done[k], 0));
-        }
-    if (rc_launch) return rc_launch; // (joined above: nothing of this call runs unordered behind the lane's stream)
     HIP_TRY(hipEventRecord(L.ev_stop, L.stream));
     L.timing_valid = true;
     return LCSGPU_OK;
@@ -437,8 +415,8 @@ int lcsgpu_create(int device_id, lcsgpu_ctx** out_ctx)
     if (profile)
         fprintf(stderr, "lcsgpu_create: HIP runtime start (hipGetDeviceCount) %.3f s, device properties %.3f s, context + first lane %.3f s\n",
                 t1 - t0, t2 - t1, now() - t2);
-    int n_groups = 4; // 3 x 10^6-sequence MedoidTree, tree stage: 1 group 2.92 s, 2: 2.79 s, 4: 2.71 s, 8: 4.13 s
-    if (const char* e = getenv("LCSGPU_CLARANS_GROUPS")) n_groups = std::max(1, std::min(16, atoi(e)));
+    // 3 x 10^6-sequence MedoidTree, tree stage (round 2): 1 group 2.92 s, 2: 2.79 s, 4: 2.71 s, 8: 4.13 s
+    const int n_groups = std::max(1, std::min(16, tune_int("clarans_groups", 4)));
     ctx->clarans_groups = std::vector<ClaransBatcher>(n_groups);
     *out_ctx = ctx;
     return LCSGPU_OK;
@@ -492,22 +470,8 @@ int lcsgpu_destroy(lcsgpu_ctx* ctx)
         if (l.ev_stop) (void)hipEventDestroy(l.ev_stop);
         if (l.ev_done) (void)hipEventDestroy(l.ev_done);
         if (l.copy_stream) (void)hipStreamDestroy(l.copy_stream);
-        for (int k = 0; k < Lane::N_AUX; ++k) {
-            if (l.aux[k]) { (void)hipStreamSynchronize(l.aux[k]); (void)hipStreamDestroy(l.aux[k]); }
-            if (l.aux_done[k]) (void)hipEventDestroy(l.aux_done[k]);
-        }
-        if (l.fork) (void)hipEventDestroy(l.fork);
         if (l.stream) (void)hipStreamDestroy(l.stream);
     }
-    if (const char* e = getenv("LCSGPU_CLARANS_LISTS"))
-        if (atoi(e) == 2) {
-            unsigned long long tk[8] = {0};
-            if (lcsgpu::clarans_lists_ticks(tk) == hipSuccess && tk[7]) {
-                static const char* what[5] = {"loads + entries", "ranks per chunk", "prefixes + scatter", "the slots' walks", "reduction"};
-                for (int i = 0; i < 5; ++i) fprintf(stderr, "clarans.lists phase %-20s %.2f us per evaluation\n", what[i], tk[i] * 0.01 / tk[7]);
-                fprintf(stderr, "clarans.lists: %llu evaluations, %llu of them fell back to the general walk, slowest %.2f us\n", tk[7], tk[6], tk[5] * 0.01);
-            }
-        }
     for (ClaransBatcher& B : ctx->clarans_groups) {
         if (getenv("LCSGPU_PROFILE"))
             for (int i = 1; i <= lcsgpu::CLARANS_MAX_BATCH; ++i)
@@ -516,10 +480,8 @@ int lcsgpu_destroy(lcsgpu_ctx* ctx)
                             B.prof_seconds[i], 1e6 * B.prof_seconds[i] / B.prof_looks[i]);
         if (getenv("LCSGPU_PROFILE") && B.prof_searches)
             fprintf(stderr, "clarans.searches=%ld accepts=%ld rounds=%ld steps_evaluated=%ld steps_up_to_the_accept=%ld "
-                            "common_entries_per_step=%.1f general_walk_steps=%ld\n", B.prof_searches,
-                    B.prof_accepts, B.prof_rounds, B.prof_steps, B.prof_useful, (double)B.prof_common / std::max(1L, B.prof_steps), B.prof_general);
-        if (getenv("LCSGPU_PROFILE") && B.prof_chain_fallbacks)
-            fprintf(stderr, "clarans.chain_fallbacks=%ld\n", B.prof_chain_fallbacks);
+                            "steps_without_a_closer_member=%ld steps_without_a_slot_that_can_go_negative=%ld\n", B.prof_searches,
+                    B.prof_accepts, B.prof_rounds, B.prof_steps, B.prof_useful, B.prof_no_b, B.prof_no_p);
         if (B.stream) { (void)hipStreamSynchronize(B.stream); (void)hipStreamDestroy(B.stream); }
         if (B.ev) (void)hipEventDestroy(B.ev);
         B.h_states.release();

@@ -8,17 +8,6 @@ using lcsgpu::RowsArgs;
 
 namespace {
 
-bool env_on(const char* name)
-{
-    const char* e = getenv(name);
-    return e && *e && *e != '0';
-}
-int env_int(const char* name, int dflt)
-{
-    const char* e = getenv(name);
-    return e && *e ? atoi(e) : dflt;
-}
-
 // det_uniform_int_distribution<int>(n_medoids, n_elems - 1) over the owner's generator
 // (deterministic_random.h:62-76), appended to the job's draws and copied to the device.
 int clarans_extend_draws(ClaransJob& j, size_t want, hipStream_t stream)
@@ -48,19 +37,15 @@ int clarans_extend_draws(ClaransJob& j, size_t want, hipStream_t stream)
 // One stint as the driver: rounds for everything joined, until nothing is left or `mine` is done.
 void clarans_drive(lcsgpu_ctx* ctx, ClaransBatcher& B, ClaransJob* mine)
 {
-    // LCSGPU_CLARANS_CHAIN=1: the rounds of a look inside one launch, every search on one XCD (clarans_chain_kernel)
-    static const bool chain = env_on("LCSGPU_CLARANS_CHAIN");
-    static const int chain_rounds = env_int("LCSGPU_CLARANS_CHAIN_ROUNDS", 128), chain_ranks = env_int("LCSGPU_CLARANS_CHAIN_RANKS", 17),
-                     chain_batch = std::min(env_int("LCSGPU_CLARANS_CHAIN_BATCH", 8), lcsgpu::CLARANS_MAX_BATCH);
-    static const int look_env = std::max(2, env_int("LCSGPU_CLARANS_LOOK", 16)) & ~1; // rounds between two looks at the done flags (even); 3 x 10^6 sequences: 16 / 32 / 64 -> 1.76-1.82 / 1.86 / 1.85-1.91 s
-    const int rounds_per_look = chain ? chain_rounds : look_env;
-    const int max_batch = chain ? chain_batch : lcsgpu::CLARANS_MAX_BATCH;
+    // rounds between two looks at the done flags (even: the host reads the parity-0 buffers); 3 x 10^6 sequences,
+    // round 4: 16 / 32 / 64 -> 1.76-1.82 / 1.86 / 1.85-1.91 s of tree stage
+    static const int rounds_per_look = std::max(2, tune_int("clarans_look", 16)) & ~1;
     for (;;) {
         std::vector<ClaransJob*> now;
         {
             std::lock_guard<std::mutex> lk(B.mu);
             for (ClaransJob* j : B.joined)
-                if ((int)now.size() < max_batch) now.push_back(j);
+                if ((int)now.size() < lcsgpu::CLARANS_MAX_BATCH) now.push_back(j);
             if (now.empty() || mine->done) {
                 B.driver_present = false;
                 B.cv.notify_all();
@@ -70,79 +55,33 @@ void clarans_drive(lcsgpu_ctx* ctx, ClaransBatcher& B, ClaransJob* mine)
         int rc = LCSGPU_OK;
         const auto t_look = std::chrono::steady_clock::now();
         lcsgpu::ClaransBatch batch{};
-        for (ClaransJob* j : now) {
-            if (rc == LCSGPU_OK && j->a.n_elems > j->a.n_medoids) // a round uses at most `corrected` draws and prepares the next window
-                rc = clarans_extend_draws(*j, (size_t)j->p_host + (size_t)(rounds_per_look + 1) * std::max(j->a.corrected, 1), B.stream);
-            batch.s[batch.n++] = j->a;
-        }
         auto hip_ok = [&](hipError_t e, const char* what) {
             if (e != hipSuccess && rc == LCSGPU_OK) rc = fail(LCSGPU_E_HIP, "%s failed: %s", what, hipGetErrorString(e));
         };
         int32_t* hs = (int32_t*)B.h_states.p;
-        auto read_states = [&](const std::vector<ClaransJob*>& which, const std::vector<size_t>& slot) {
-            for (size_t i = 0; i < which.size() && rc == LCSGPU_OK; ++i)
-                hip_ok(hipMemcpyAsync(hs + 64 * slot[i], which[i]->a.state, 256, hipMemcpyDeviceToHost, B.stream), "state read-back");
-            if (rc == LCSGPU_OK) hip_ok(hipEventRecord(B.ev, B.stream), "hipEventRecord");
-            if (rc == LCSGPU_OK) hip_ok(hipEventSynchronize(B.ev), "hipEventSynchronize");
-            else (void)hipStreamSynchronize(B.stream);
-        };
-        std::vector<size_t> all(now.size());
-        for (size_t i = 0; i < now.size(); ++i) all[i] = i;
-        if (chain) {
-            for (size_t i = 0; i < now.size() && rc == LCSGPU_OK; ++i) // ticket, go flag, barrier counter
-                hip_ok(hipMemsetAsync(now[i]->a.state + 16, 0, 128, B.stream), "hipMemsetAsync");
-            if (rc == LCSGPU_OK) hip_ok(lcsgpu::launch_clarans_chain(batch, rounds_per_look, chain_ranks, B.stream), "CLARANS chain");
-            read_states(now, all);
-            if (rc == LCSGPU_OK && getenv("LCSGPU_CLARANS_CHAIN_DBG"))
-                for (size_t i = 0; i < now.size(); ++i) {
-                    const int32_t* d = hs + 64 * i + 48;
-                    fprintf(stderr, "clarans.chain n=%d k=%d: %d rounds; rank 0 eval %d wait %d apply %d wait %d; tail eval %d wait %d apply %d wait %d; rank 0's evaluations: loads %d staging %d own walk %d slowest wave %d reduction %d (ticks of 10 ns); shader clock %d MHz\n",
-                            now[i]->a.n_elems, now[i]->a.n_medoids, d[0], d[1], d[2], d[3], d[4], d[6], d[7], d[8], d[9], d[10], d[11], d[12], d[13], d[14], d[15]);
-                }
-            // a search whose ranks found no room on its XCD has not been touched: this look as ordinary rounds
-            std::vector<ClaransJob*> again;
-            std::vector<size_t> again_slot;
-            lcsgpu::ClaransBatch rest{};
-            for (size_t i = 0; i < now.size() && rc == LCSGPU_OK; ++i)
-                if (hs[64 * i + 17] != 1) {
-                    again.push_back(now[i]);
-                    again_slot.push_back(i);
-                    rest.s[rest.n++] = now[i]->a;
-                }
-            if (!again.empty() && rc == LCSGPU_OK) {
-                B.prof_chain_fallbacks += again.size();
-                hip_ok(lcsgpu::launch_clarans_rounds(rest, 32, B.stream), "CLARANS rounds");
-                read_states(again, again_slot);
-            }
-        } else {
-            // the searches of a look advance together; those whose shape takes the one-launch rounds and the others are two
-            // launch sequences (FAMSA's samples all have one size: a mixed look is the exception)
-            // The one-launch rounds leave their state block in the batch's pinned (device-mapped) buffer themselves: no copy
-            // per search and look (7-8 copies of 256 B were 110 us of a 2.4 ms look).
-            lcsgpu::ClaransBatch one{}, two{};
-            std::vector<ClaransJob*> copied;
-            std::vector<size_t> copied_slot;
-            int32_t* hs_dev = nullptr;
-            if (hipHostGetDevicePointer((void**)&hs_dev, B.h_states.p, 0) != hipSuccess) {
-                (void)hipGetLastError();
-                hs_dev = nullptr;
-            }
-            for (int i = 0; i < batch.n; ++i) {
-                if (batch.s[i].fused) {
-                    lcsgpu::ClaransArgs& s1 = one.s[one.n++];
-                    s1 = batch.s[i];
-                    s1.host_state = hs_dev ? hs_dev + 64 * i : nullptr;
-                    if (!hs_dev) { copied.push_back(now[i]); copied_slot.push_back((size_t)i); }
-                } else {
-                    two.s[two.n++] = batch.s[i];
-                    copied.push_back(now[i]);
-                    copied_slot.push_back((size_t)i);
-                }
-            }
-            if (rc == LCSGPU_OK && one.n) hip_ok(lcsgpu::launch_clarans_rounds_fused(one, rounds_per_look, B.stream), "CLARANS rounds (one launch each)");
-            if (rc == LCSGPU_OK && two.n) hip_ok(lcsgpu::launch_clarans_rounds(two, rounds_per_look, B.stream), "CLARANS rounds");
-            read_states(copied, copied_slot); // (waits for the stream in any case)
+        // The rounds leave their state block in the batch's pinned (device-mapped) buffer themselves: no copy per search
+        // and look (7-8 copies of 256 B were 110 us of a 2.4 ms look); without the mapping: a copy each.
+        int32_t* hs_dev = nullptr;
+        if (hipHostGetDevicePointer((void**)&hs_dev, B.h_states.p, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            hs_dev = nullptr;
         }
+        for (ClaransJob* j : now) {
+            // a round uses at most `corrected` draws and prepares the next window
+            if (rc == LCSGPU_OK)
+                rc = clarans_extend_draws(*j, (size_t)j->p_host + (size_t)(rounds_per_look + 1) * std::max(j->a.corrected, 1), B.stream);
+            lcsgpu::ClaransArgs& s1 = batch.s[batch.n];
+            s1 = j->a;
+            s1.host_state = hs_dev ? hs_dev + 64 * batch.n : nullptr;
+            ++batch.n;
+        }
+        if (rc == LCSGPU_OK) hip_ok(lcsgpu::launch_clarans_rounds(batch, rounds_per_look, B.stream), "CLARANS rounds");
+        if (!hs_dev)
+            for (size_t i = 0; i < now.size() && rc == LCSGPU_OK; ++i)
+                hip_ok(hipMemcpyAsync(hs + 64 * i, now[i]->a.state, 64, hipMemcpyDeviceToHost, B.stream), "state read-back");
+        if (rc == LCSGPU_OK) hip_ok(hipEventRecord(B.ev, B.stream), "hipEventRecord");
+        if (rc == LCSGPU_OK) hip_ok(hipEventSynchronize(B.ev), "hipEventSynchronize");
+        else (void)hipStreamSynchronize(B.stream);
         {
             std::lock_guard<std::mutex> lk(B.mu);
             const std::string msg = rc == LCSGPU_OK ? std::string() : std::string(lcsgpu_last_error());
@@ -155,8 +94,7 @@ void clarans_drive(lcsgpu_ctx* ctx, ClaransBatcher& B, ClaransJob* mine)
                     j->p_host = j->state[0];
                     if (j->state[6]) {
                         j->rc = LCSGPU_E_STATE;
-                        j->error = j->state[6] == 2 ? "CLARANS: a barrier of the one-XCD kernel timed out"
-                                                    : "CLARANS: the device search ran out of pre-drawn steps";
+                        j->error = "CLARANS: the device search ran out of pre-drawn steps";
                     }
                 } else {
                     j->rc = rc;
@@ -168,8 +106,8 @@ void clarans_drive(lcsgpu_ctx* ctx, ClaransBatcher& B, ClaransJob* mine)
                     B.prof_rounds += j->state[11];
                     B.prof_steps += j->state[12];
                     B.prof_useful += j->state[13];
-                    B.prof_common += j->state[14];
-                    B.prof_general += j->state[15];
+                    B.prof_no_b += j->state[14];
+                    B.prof_no_p += j->state[15];
                     j->done = true;
                     B.joined.erase(std::find(B.joined.begin(), B.joined.end(), j));
                 }
@@ -209,8 +147,7 @@ extern "C" {
 } // extern "C"
 
 // The packed LCS triangles of several id lists into lane L's result buffer (device memory), list g at pair offset
-// tri_base[g]: validation, planning and the launches of lcsgpu_lcs_triangles_batch, shared with the batched leaf
-// reducers, which consume the triangles where they are.  *count = pairs in total (0: nothing to do).  On return the
+// tri_base[g]: validation, planning and the launches of lcsgpu_lcs_triangles_batch.  *count = pairs in total (0: nothing to do).  On return the
 // launches are queued on L.stream (or, with a ref beyond 2048 residues in the batch, already finished).
 static int batch_triangles_to_device(lcsgpu_ctx* ctx, Lane& L, const int32_t* ids, const int64_t* group_offsets, int32_t n_groups,
                                      int elem_size, std::vector<int64_t>& tri_base, int64_t* count_out, bool* had_long)
@@ -397,98 +334,6 @@ int lcsgpu_lcs_triangles_batch(lcsgpu_ctx* ctx, const int32_t* ids, const int64_
     return LCSGPU_OK;
 }
 
-// UPGMA sub-trees of several id lists in one call: the lists' LCS triangles are computed as by
-// lcsgpu_lcs_triangles_batch, stay in HBM, and one workgroup per list builds its tree there (tree_kernels.hip,
-// leaf_upgma_kernel); only the trees come back.
-int lcsgpu_leaf_upgma_batch(lcsgpu_ctx* ctx, const int32_t* ids, const int64_t* group_offsets, int32_t n_groups,
-                            int distance_kind, int modified, int32_t* out_left, int32_t* out_right)
-{
-    if (!ctx) return fail(LCSGPU_E_INVALID, "NULL ctx");
-    if (ctx->n < 0) return fail(LCSGPU_E_STATE, "no sequence set uploaded");
-    if (distance_kind != LCSGPU_DIST_INDEL_DIV_LCS && distance_kind != LCSGPU_DIST_INDEL075_DIV_LCS)
-        return fail(LCSGPU_E_INVALID, "unknown distance kind %d", distance_kind);
-    if (n_groups < 0 || (n_groups > 0 && !group_offsets)) return fail(LCSGPU_E_INVALID, "bad group table");
-    if (n_groups == 0) return LCSGPU_OK;
-    // the whole group table before anything is derived from it (node_base, the order, the caller's output sizes)
-    if (group_offsets[0] != 0) return fail(LCSGPU_E_INVALID, "group_offsets[0] must be 0");
-    for (int32_t g = 0; g < n_groups; ++g)
-        if (group_offsets[g + 1] < group_offsets[g]) return fail(LCSGPU_E_INVALID, "group_offsets not ascending (list %d)", g);
-    if (group_offsets[n_groups] > 0 && !ids) return fail(LCSGPU_E_INVALID, "NULL ids");
-    for (int64_t k = 0; k < group_offsets[n_groups]; ++k)
-        if (ids[k] < 0 || ids[k] >= ctx->n) return fail(LCSGPU_E_INVALID, "ids[%lld] = %d is not a sequence of the uploaded set", (long long)k, ids[k]);
-    if (ctx->max_len > 65535) return fail(LCSGPU_E_UNSUPPORTED, "the leaf reducer reads uint16 LCS values");
-    std::vector<int64_t> node_base((size_t)n_groups, 0);
-    std::vector<int32_t> order((size_t)n_groups);
-    int64_t nodes = 0;
-    for (int32_t g = 0; g < n_groups; ++g) {
-        const int64_t m = group_offsets[g + 1] - group_offsets[g];
-        if (m < 0) return fail(LCSGPU_E_INVALID, "group_offsets not ascending");
-        if (m > lcsgpu::LEAF_MAX)
-            return fail(LCSGPU_E_UNSUPPORTED, "list %d has %lld members; the leaf reducer takes up to %d", g, (long long)m, lcsgpu::LEAF_MAX);
-        node_base[g] = nodes;
-        nodes += std::max<int64_t>(m - 1, 0);
-        order[g] = g;
-    }
-    if (nodes == 0) return LCSGPU_OK;
-    if (!out_left || !out_right) return fail(LCSGPU_E_INVALID, "NULL output");
-    std::sort(order.begin(), order.end(), [&](int32_t x, int32_t y) {
-        return group_offsets[x + 1] - group_offsets[x] > group_offsets[y + 1] - group_offsets[y];
-    });
-    LaneGuard guard(ctx, LaneGuard::ANY);
-    Lane& L = guard.lane();
-    std::vector<int64_t> tri_base;
-    int64_t count = 0;
-    bool had_long = false;
-    int rc = batch_triangles_to_device(ctx, L, ids, group_offsets, n_groups, 2, tri_base, &count, &had_long);
-    if (rc) return rc;
-    if (count <= 0) return LCSGPU_OK; // (cannot happen with nodes > 0)
-    // tables + scratch of the reducer: [ids][group_offsets][tri_base][node_base][order][err][left][right] ... [D]
-    auto a16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
-    const int64_t n_total = group_offsets[n_groups];
-    const size_t o_ids = 0, o_go = o_ids + a16((size_t)n_total * 4), o_tb = o_go + a16(((size_t)n_groups + 1) * 8),
-                 o_nb = o_tb + a16((size_t)n_groups * 8), o_ord = o_nb + a16((size_t)n_groups * 8),
-                 o_err = o_ord + a16((size_t)n_groups * 4), o_left = o_err + 16, o_right = o_left + a16((size_t)nodes * 4),
-                 o_D = o_right + a16((size_t)nodes * 4), total = o_D + (size_t)count * sizeof(float);
-    HIP_TRY(L.d_work.reserve(total));
-    HIP_TRY(L.h_small.reserve(o_left));
-    char* h = (char*)L.h_small.p;
-    memset(h + o_err, 0, 16);
-    memcpy(h + o_ids, ids, (size_t)n_total * 4);
-    memcpy(h + o_go, group_offsets, ((size_t)n_groups + 1) * 8);
-    memcpy(h + o_tb, tri_base.data(), (size_t)n_groups * 8);
-    memcpy(h + o_nb, node_base.data(), (size_t)n_groups * 8);
-    memcpy(h + o_ord, order.data(), (size_t)n_groups * 4);
-    char* d = (char*)L.d_work.p;
-    HIP_TRY(hipMemcpyAsync(d, h, o_left, hipMemcpyHostToDevice, L.stream));
-    lcsgpu::LeafArgs a{};
-    a.lcs = L.d_out.p;
-    a.ids = (const int32_t*)(d + o_ids);
-    a.group_offsets = (const int64_t*)(d + o_go);
-    a.tri_base = (const int64_t*)(d + o_tb);
-    a.node_base = (const int64_t*)(d + o_nb);
-    a.order = (const int32_t*)(d + o_ord);
-    a.lens = (const uint32_t*)ctx->d_lens.p;
-    a.pow_f32 = (const float*)ctx->d_powf.p;
-    a.kind = distance_kind;
-    a.D = (float*)(d + o_D);
-    a.left = (int32_t*)(d + o_left);
-    a.right = (int32_t*)(d + o_right);
-    a.err = (int32_t*)(d + o_err);
-    HIP_TRY(lcsgpu::launch_leaf_upgma(a, n_groups, modified != 0, L.stream));
-    int32_t err = 0;
-    HIP_TRY(hipMemcpyAsync(out_left, a.left, (size_t)nodes * 4, hipMemcpyDeviceToHost, L.stream));
-    HIP_TRY(hipMemcpyAsync(out_right, a.right, (size_t)nodes * 4, hipMemcpyDeviceToHost, L.stream));
-    HIP_TRY(hipMemcpyAsync(&err, a.err, 4, hipMemcpyDeviceToHost, L.stream));
-    HIP_TRY(hipEventRecord(L.ev_done, L.stream));
-    HIP_TRY(hipEventSynchronize(L.ev_done)); // sleeps; worker threads must not burn a core per pending call
-    if (!had_long) finish_host_call(ctx, L);
-    if (err)
-        return fail(LCSGPU_E_INVALID, "UPGMA: a list with no finite nearest neighbour (a pair with LCS 0?) -- the reference's "
-                                      "algorithm is undefined for this input");
-    return LCSGPU_OK;
-}
-
-
 int lcsgpu_assign_seeds(lcsgpu_ctx* ctx, const int32_t* seed_ids, int32_t n_seeds, const int32_t* col_ids,
                         int32_t n_cols, int distance_kind, int32_t first_k, float* dist, int32_t* assign)
 {
@@ -553,8 +398,24 @@ int lcsgpu_clarans(lcsgpu_ctx* ctx, const int32_t* ids, int32_t n_ids, int dista
                     n_ids, num_local);
     for (int32_t i = 0; i < n_ids; ++i)
         if (ids[i] < 0 || ids[i] >= ctx->n) return fail(LCSGPU_E_INVALID, "sample id %d out of range", ids[i]);
-    if (n_medoids > lcsgpu::CLARANS_MAX_MEDOIDS)
-        return fail(LCSGPU_E_UNSUPPORTED, "device CLARANS handles at most %d medoids", lcsgpu::CLARANS_MAX_MEDOIDS);
+    if (n_medoids > lcsgpu::CLARANS_MAX_MEDOIDS || n_ids - n_medoids > lcsgpu::CLARANS_MAX_NONMEDOIDS)
+        return fail(LCSGPU_E_UNSUPPORTED, "device CLARANS handles at most %d medoids and %d other sample members (asked: %d, %d)",
+                    lcsgpu::CLARANS_MAX_MEDOIDS, lcsgpu::CLARANS_MAX_NONMEDOIDS, n_medoids, n_ids - n_medoids);
+    if (n_ids == n_medoids) {
+        // every member is a medoid: no step is ever drawn (corrected = 0), every search costs 0, the first one stands
+        // (Clustering.cpp:239-257: a later search has to be cheaper) -- its medoids are the order after the first shuffle
+        std::mt19937 gen_nodes;
+        std::vector<int32_t> cand(n_ids);
+        for (int32_t i = 0; i < n_ids; ++i) cand[i] = i;
+        int32_t* first = cand.data() + n_fixed;
+        const long cnt = n_ids - n_fixed, N = cnt - 1;
+        for (long i = 0; i < cnt; ++i) {
+            const unsigned long d = (unsigned long)N - (unsigned long)i + 1;
+            std::swap(first[i], first[((unsigned long)gen_nodes() % d) + (unsigned long)i]);
+        }
+        std::copy(cand.begin(), cand.end(), medoids_out);
+        return LCSGPU_OK;
+    }
 
     const int32_t n = n_ids, k = n_medoids;
     // Clustering.cpp:21-29: how many non-improving steps end a local search
@@ -571,18 +432,16 @@ int lcsgpu_clarans(lcsgpu_ctx* ctx, const int32_t* ids, int32_t n_ids, int dista
     const int elem = ctx->max_len > 65535 ? 4 : 2;
     const size_t pairs = (size_t)n * (n - 1) / 2;
     auto a256 = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    const size_t window = (size_t)std::max(corrected, 1);
-    const size_t o_D = 0, o_DM = o_D + a256(pairs * 4), o_cand = o_DM + a256((size_t)n * k * 4),
-                 o_st = o_cand + a256((size_t)n * 4), o_rd = o_st + a256((size_t)n * 16), o_rm = o_rd + a256(std::max<size_t>(window, 64) * 4),
-                 o_wxx = o_rm + a256(std::max<size_t>(window, 64) * 4), o_wx = o_wxx + a256(window * 8), o_log = o_wx + a256(window * 8), o_state = o_log + a256((size_t)(n + 1) * 4), o_ids = o_state + 256,
-                 // the second copies of the one-launch rounds (clarans_round_kernel)
+    const size_t o_D = 0, o_DM = o_D + a256(pairs * 4), o_cand = o_DM + a256((size_t)n * k * 4), o_st = o_cand + a256((size_t)n * 4),
+                 o_log = o_st + a256((size_t)n * 16), o_state = o_log + a256((size_t)(n + 1) * 4), o_ids = o_state + 256,
+                 // the second copies (by round parity) and the step results: clarans_round_kernel
                  o_cand1 = o_ids + a256((size_t)n * 4), o_st1 = o_cand1 + a256((size_t)n * 4), o_log1 = o_st1 + a256((size_t)n * 16),
-                 o_state1 = o_log1 + a256((size_t)(n + 1) * 4), o_res2 = o_state1 + 256, total = o_res2 + 2048;
+                 o_state1 = o_log1 + a256((size_t)(n + 1) * 4), o_res2 = o_state1 + 256, total = o_res2 + a256(lcsgpu::CLARANS_RES_BYTES);
     HIP_TRY(L.d_work.reserve(total));
     HIP_TRY(L.h_small.reserve(64));
     char* base = (char*)L.d_work.p;
     HIP_TRY(hipMemsetAsync(base + o_state, 0, 256, L.stream));
-    HIP_TRY(hipMemsetAsync(base + o_state1, 0, 256 + 2048, L.stream));
+    HIP_TRY(hipMemsetAsync(base + o_state1, 0, 256 + a256(lcsgpu::CLARANS_RES_BYTES), L.stream));
     HIP_TRY(hipMemcpyAsync(base + o_ids, ids, (size_t)n * 4, hipMemcpyHostToDevice, L.stream));
     if (pairs > 0) {
         HIP_TRY(L.d_out.reserve(pairs * elem));
@@ -597,33 +456,21 @@ int lcsgpu_clarans(lcsgpu_ctx* ctx, const int32_t* ids, int32_t n_ids, int dista
     a.DMt = (float*)(base + o_DM);
     a.cand = (int32_t*)(base + o_cand);
     a.st = (float4*)(base + o_st);
-    a.res_delta = (float*)(base + o_rd);
-    a.res_mm = (int32_t*)(base + o_rm);
-    a.win_xx = (int32_t*)(base + o_wxx);
-    a.win_x = (int32_t*)(base + o_wx);
-    a.win_cap = (int32_t)window;
     a.cost_log = (float*)(base + o_log);
     a.state = (int32_t*)(base + o_state);
     a.n_elems = n;
     a.n_medoids = k;
     a.n_fixed = n_fixed;
-
     a.corrected = corrected;
-    static const int stage0 = std::max(1, std::min(64, env_int("LCSGPU_CLARANS_STAGE0", 16)));
+    // steps evaluated in the first round of a window (1: every round is one step, the reference's own loop; 64: whole
+    // windows) -- decides how much is evaluated speculatively, never which step is accepted
+    static const int stage0 = std::max(1, std::min(64, tune_int("clarans_stage0", 16)));
     a.stage0 = stage0;
-    // 1: evaluate with per-slot lists (clarans_kernels.hip, evaluate_step_lists; 2 = with phase timers) -- built in round 4,
-    // bit-identical, and SLOWER where it counts (the kernel lasts as long as its slowest step: 33-45 us against 19.9 us
-    // for the broadcast walk at 2000 members / 100 medoids), so it is opt-in
-    const int lists = env_int("LCSGPU_CLARANS_LISTS", 0); // (read per call: the tests switch it inside one process)
-    a.lists = lists;
-    // a round as one launch (clarans_round_kernel) where every position's state fits the registers of one workgroup;
-    // LCSGPU_CLARANS_FUSED=0: the two launches of rounds 1-3 (also taken by the per-slot lists and the one-XCD chain)
     a.cand1 = (int32_t*)(base + o_cand1);
     a.st1 = (float4*)(base + o_st1);
     a.log1 = (float*)(base + o_log1);
     a.state1 = (int32_t*)(base + o_state1);
     a.res2 = (int32_t*)(base + o_res2);
-    a.fused = (env_int("LCSGPU_CLARANS_FUSED", 1) != 0 && !lists && !env_on("LCSGPU_CLARANS_CHAIN") && n > k && n - k <= 2048) ? 1 : 0;
     // The two generators of Clustering.cpp:43-44.  Neither looks at the search state, so the host
     // runs them: gen_nodes shuffles the candidate order before every local search, gen_positions
     // yields the step positions, handed to the device as a growing array of draws.
@@ -648,7 +495,7 @@ int lcsgpu_clarans(lcsgpu_ctx* ctx, const int32_t* ids, int32_t n_ids, int dista
             }
         }
         HIP_TRY(hipMemcpyAsync(a.cand, cand.data(), (size_t)n * 4, hipMemcpyHostToDevice, L.stream));
-        if (n > k) { // the init kernel already needs the first window's draws
+        {   // the first rounds' draws (the init kernel checks that a window's worth is there)
             int rc = clarans_extend_draws(job, (size_t)job.p_host + (size_t)std::max(corrected, 1), L.stream);
             if (rc) return rc;
         }

@@ -26,6 +26,10 @@ namespace lcsgpu_impl {
 
 // thread-local error text of lcsgpu_last_error(); returns `code`
 int fail(int code, const char* fmt, ...);
+// numeric tuning knobs, LCSGPU_TUNE="key=value,key=value" (no alternate code paths behind them): clarans_stage0 (steps a
+// round evaluates first, 16), clarans_look (rounds between two looks at the done flags, 16), clarans_groups (independent
+// batches of searches, 4), combine_wait_us (how long an LCS request waits for others to share its launches)
+int tune_int(const char* key, int dflt);
 
 #define HIP_TRY(expr)                                                                           \
     do {                                                                                        \
@@ -94,15 +98,6 @@ struct Lane {
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     hipEvent_t ev_done = nullptr; // blocking-sync event: host-memory calls sleep on it instead of spinning
     hipStream_t copy_stream = nullptr; // large host-buffer results leave in slices while the next slice is computed
-    // A call whose refs fall into several half-word classes is several launches; on one stream they run one after
-    // the other, each a few hundred workgroups that leave most of the chip idle (hemopexin: 7 launches, 3.3 ms).
-    // They are independent (different refs), so they are spread over these side streams, forked from and joined
-    // back into `stream` by events.  Opt-in (LCSGPU_SPREAD=1): see run_rows.
-    static constexpr int N_AUX = 3;
-    hipStream_t aux[N_AUX] = {nullptr, nullptr, nullptr};
-    hipEvent_t aux_done[N_AUX] = {nullptr, nullptr, nullptr};
-    hipEvent_t fork = nullptr;
-    bool aux_ok = false, aux_tried = false;
     lcsgpu_impl::DevBuf d_plan, d_out, d_carry;
     lcsgpu_impl::DevBuf d_work, d_draws; // CLARANS state and its pre-drawn step positions
     lcsgpu_impl::PinBuf h_plan, h_small;
@@ -144,8 +139,7 @@ struct ClaransBatcher {
     long prof_looks[lcsgpu::CLARANS_MAX_BATCH + 1] = {0};
     double prof_seconds[lcsgpu::CLARANS_MAX_BATCH + 1] = {0};
     long prof_rounds = 0, prof_steps = 0, prof_useful = 0, prof_accepts = 0, prof_searches = 0; // over finished searches
-    long prof_common = 0, prof_general = 0; // list evaluations: entries adding to every other slot (summed), steps that fell back to the general walk
-    long prof_chain_fallbacks = 0; // LCSGPU_CLARANS_CHAIN: searches of a look that found no room on their XCD
+    long prof_no_b = 0, prof_no_p = 0; // steps that ended without a walk: no member closer to the candidate than to its medoid / no slot able to go negative
 };
 
 struct lcsgpu_ctx {

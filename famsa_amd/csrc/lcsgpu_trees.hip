@@ -80,7 +80,6 @@ static int shard_begin(lcsgpu_ctx* ctx, Lane& L, void* d_tri, int elem, int32_t 
     // rows (the DRAM pages they share): n = 100 000, column passes of one tree: 2 chunks 21.2 ms, 8: 18.2, 16: 16.6,
     // 32: 15.4, 64: 14.1, 128: 13.7 (+0.5 fold), 256: 13.7 (+0.9), 512: 14.2 (+1.8) -> about 1024 rows per chunk
     int n_chunks = std::max(1, std::min(96, (rows + 1023) / 1024));
-    if (const char* e = getenv("LCSGPU_MST_CHUNKS")) n_chunks = std::max(1, std::min(1024, atoi(e))); // measurement aid
     if (!d_tri) n_chunks = 0; // no passes, no partials
     const int rows_per_chunk = std::max(1, (rows + std::max(n_chunks, 1) - 1) / std::max(n_chunks, 1));
     const size_t key = sizeof(lcsgpu::MstKey);
@@ -436,7 +435,8 @@ int lcsgpu_mst_prim(lcsgpu_ctx* ctx, int distance_kind, lcsgpu_mst_edge* out_edg
     for (int32_t i = 0; i < n && !triangle_orientation; ++i) nq += ctx->quirk[i] ? 1 : 0;
     int rc;
 
-    if ((triangle_orientation || nq == 0) && !getenv("LCSGPU_MST_PRIM")) {
+    const char* mode_env = getenv("LCSGPU_MST_MODE"); // passes | fused | recompute (below), prim = the step-by-step kernel on any set
+    if ((triangle_orientation || nq == 0) && !(mode_env && !strcmp(mode_env, "prim"))) {
         // Distances do not depend on which endpoint is the ref: Boruvka rounds (one block = all rows, no exchange),
         // then Prim's insertion order as a walk over the n-1 tree edges.  Where the rounds get their LCS values from:
         //   passes    (default while the triangle fits) the triangle is computed into HBM, every round streams it
@@ -448,7 +448,7 @@ int lcsgpu_mst_prim(lcsgpu_ctx* ctx, int distance_kind, lcsgpu_mst_edge* out_edg
         //             -- LCS launch 1318 -> 1338 ms for 4 ms of passes saved -- so it is not the default.
         // LCSGPU_MST_MODE=passes|fused|recompute overrides the choice (tests, measurements).
         enum { AUTO, FUSED, RECOMPUTE, PASSES } mode = AUTO;
-        if (const char* e = getenv("LCSGPU_MST_MODE"))
+        if (const char* e = mode_env)
             mode = !strcmp(e, "fused") ? FUSED : !strcmp(e, "recompute") ? RECOMPUTE : !strcmp(e, "passes") ? PASSES : AUTO;
         if (elem != 2) mode = PASSES;
         // rows [0, r_fit) of the triangle are kept in HBM, rows [r_fit, n) are recomputed every round
@@ -635,15 +635,15 @@ std::vector<int32_t> equal_pair_cuts(int32_t r0, int32_t r1, int parts)
 // of one xGMI hop (7 links x ~153 GB/s per GPU).  When the devices cannot address each other at all the copy goes
 // through a pinned host buffer here, in 64 MB pieces (two PCIe crossings, ~25 GB/s: the 8.75 GB a GPU receives for
 // lcsgpu_multi_upgma at 100 000 sequences then take ~0.35 s instead of ~0.06 s).
-//   LCSGPU_FORCE_PEER_COPY=1     same-device contexts take the hipMemcpyPeerAsync branch too (so a 1-GPU box runs it)
-//   LCSGPU_FORCE_HOST_STAGING=1  every copy between contexts takes the pinned-host path (the no-peer-access fallback)
+//   LCSGPU_TRANSPORT=peer   same-device contexts take the hipMemcpyPeerAsync branch too (so a 1-GPU box runs it)
+//   LCSGPU_TRANSPORT=host   every copy between contexts takes the pinned-host path (the no-peer-access fallback)
 std::mutex g_peer_mu;
 std::vector<std::pair<std::pair<int, int>, bool>> g_peer; // (accessing device, owner of the memory) -> usable
 
-bool env_flag(const char* name)
+bool transport_forced(const char* which)
 {
-    const char* e = getenv(name);
-    return e && *e && *e != '0';
+    const char* e = getenv("LCSGPU_TRANSPORT");
+    return e && !strcmp(e, which);
 }
 
 // may kernels / copy engines of device `from` address memory of device `to`?  Switches it on at first use.
@@ -681,7 +681,7 @@ int copy_between(lcsgpu_ctx* dst_ctx, void* dst, lcsgpu_ctx* src_ctx, const void
     if (!bytes) return LCSGPU_OK;
     const int sd = src_ctx->device, dd = dst_ctx->device;
     HIP_TRY(hipSetDevice(sd));
-    if (env_flag("LCSGPU_FORCE_HOST_STAGING") || (sd != dd && !(peer_access(sd, dd) && peer_access(dd, sd)))) {
+    if (transport_forced("host") || (sd != dd && !(peer_access(sd, dd) && peer_access(dd, sd)))) {
         static std::mutex mu; // one staging buffer per process: this path is the exception, not the design
         static PinBuf stage;
         std::lock_guard<std::mutex> lk(mu);
@@ -698,7 +698,7 @@ int copy_between(lcsgpu_ctx* dst_ctx, void* dst, lcsgpu_ctx* src_ctx, const void
         HIP_TRY(hipSetDevice(sd));
         return LCSGPU_OK;
     }
-    if (sd == dd && !env_flag("LCSGPU_FORCE_PEER_COPY"))
+    if (sd == dd && !transport_forced("peer"))
         HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, stream));
     else
         HIP_TRY(hipMemcpyPeerAsync(dst, dd, src, sd, bytes, stream));
@@ -822,8 +822,8 @@ int rccl_all_gather_keys(const std::vector<ncclComm_t>& comms, const std::vector
 // how a copy between two contexts travels (copy_between's decision, without making the copy)
 const char* transport_between(int sd, int dd)
 {
-    if (env_flag("LCSGPU_FORCE_HOST_STAGING")) return "host-staging(forced)";
-    if (sd == dd) return env_flag("LCSGPU_FORCE_PEER_COPY") ? "peer-copy(same device, forced)" : "same-device";
+    if (transport_forced("host")) return "host-staging(forced)";
+    if (sd == dd) return transport_forced("peer") ? "peer-copy(same device, forced)" : "same-device";
     return peer_access(sd, dd) && peer_access(dd, sd) ? "peer-copy" : "host-staging";
 }
 
@@ -898,8 +898,7 @@ int upgma_reduce(lcsgpu_ctx* ctx, Lane& L, int elem, int distance_kind, int modi
     int batch_k = 32;
     if (const char* e = getenv("LCSGPU_UPGMA_BATCH")) batch_k = atoi(e);
     batch_k = batch_k >= 32 ? 32 : batch_k >= 16 ? 16 : batch_k >= 8 ? 8 : 0;
-    const char* chain_on = getenv("LCSGPU_UPGMA_CHAIN");
-    if (n < 3 || (chain_on && !strcmp(chain_on, "1"))) batch_k = 0;
+    if (n < 3) batch_k = 0;
     size_t ld = (size_t)n;
     int rc = LCSGPU_E_NOMEM;
     if (square && batch_k) {
@@ -923,12 +922,11 @@ int upgma_reduce(lcsgpu_ctx* ctx, Lane& L, int elem, int distance_kind, int modi
     const size_t o_min = 0, o_near = o_min + a16((size_t)n * 4), o_node = o_near + a16((size_t)n * 4),
                  o_pd = o_node + a16((size_t)n * 4), o_pj = o_pd + a16((size_t)2 * blocks * 4),
                  o_bd = o_pj + a16((size_t)2 * blocks * 4), o_bj = o_bd + a16((size_t)blocks * 4),
-                 o_bn = o_bj + a16((size_t)blocks * 4), o_sel = o_bn + a16((size_t)blocks * 4), o_ctl = o_sel + 256,
-                 o_slots = o_ctl + 256, o_left = o_slots + (size_t)2 * lcsgpu::UPGMA_CHAIN_MAX_WG * 8 * 4,
+                 o_bn = o_bj + a16((size_t)blocks * 4), o_sel = o_bn + a16((size_t)blocks * 4), o_left = o_sel + 256,
                  o_right = o_left + a16((size_t)n * 4), total = o_right + a16((size_t)n * 4);
     HIP_TRY(ctx->d_prim.reserve(total));
     char* base = (char*)ctx->d_prim.p;
-    HIP_TRY(hipMemsetAsync(base + o_sel, 0, o_left - o_sel, L.stream)); // flags, the chain's tickets / barrier counter / slots
+    HIP_TRY(hipMemsetAsync(base + o_sel, 0, o_left - o_sel, L.stream)); // flags
     lcsgpu::UpgmaArgs a{};
     a.bm_d = (float*)(base + o_bd);
     a.bm_j = (uint32_t*)(base + o_bj);
@@ -942,9 +940,6 @@ int upgma_reduce(lcsgpu_ctx* ctx, Lane& L, int elem, int distance_kind, int modi
     a.part_d = (float*)(base + o_pd);
     a.part_j = (uint32_t*)(base + o_pj);
     a.sel = (uint32_t*)(base + o_sel);
-    a.chain_ctl = (uint32_t*)(base + o_ctl);
-    a.chain_slots = (uint32_t*)(base + o_slots);
-    a.chain_dbg = getenv("LCSGPU_UPGMA_CHAIN_DBG") ? (unsigned long long*)(base + o_sel + 128) : nullptr; // 8 x 8 B inside the flag block
     a.left = (int32_t*)(base + o_left);
     a.right = (int32_t*)(base + o_right);
     a.n = n;
@@ -956,34 +951,11 @@ int upgma_reduce(lcsgpu_ctx* ctx, Lane& L, int elem, int distance_kind, int modi
     HIP_TRY(lcsgpu::launch_upgma_prologue(a, L.d_out.p, elem, (const uint32_t*)ctx->d_lens.p, (const float*)ctx->d_powf.p,
                                           distance_kind, L.stream));
     if (profile) { HIP_TRY(hipStreamSynchronize(L.stream)); t_merge = now(); }
-    // The n-1 merges: one launch per merge (default), or -- LCSGPU_UPGMA_CHAIN=1, symmetric matrix only -- inside ONE kernel
-    // whose workgroups all run on one XCD and synchronise through its L2 (tree_kernels.hip, upgma_chain_kernel; if it cannot
-    // assemble its workgroups it has touched nothing and the launches run).  Measured (scripts/upgma_chain_ab.sh): the chain
-    // is bit-identical and its barrier cheap, but every merge scatters n/2 mirror stores through the 16-32 CUs of one XCD:
-    // 13 us per merge at 100 000 sequences against 8.4 us for a launch, 9.3 against 7.4 at 10 000.
+    // The n-1 merges: batches of up to K merges per three launches (upgma_batch_kernels.hip), else one launch per merge.
+    // (Round 3 also had all merges inside one kernel on one XCD: bit-identical, 11-13 us per merge at 100 000 sequences
+    // against 8.4 us for a launch -- profiles/upgma_chain_ab_r03.txt; removed in round 5.)
     uint32_t sel[12] = {0};
     bool merged = false;
-    int wg = std::max(4, std::min<int>(lcsgpu::UPGMA_CHAIN_MAX_WG, (n + 4 * lcsgpu::UPGMA_CHAIN_THREADS - 1) / (4 * lcsgpu::UPGMA_CHAIN_THREADS)));
-    if (const char* e = getenv("LCSGPU_UPGMA_CHAIN_WG")) wg = std::max(1, std::min<int>(lcsgpu::UPGMA_CHAIN_MAX_WG, atoi(e)));
-    const bool chain_fits = (int64_t)wg * lcsgpu::UPGMA_CHAIN_THREADS * lcsgpu::UPGMA_CHAIN_ROWS >= n;
-    const char* chain_env = getenv("LCSGPU_UPGMA_CHAIN");
-    if (square && chain_fits && n >= 64 && chain_env && !strcmp(chain_env, "1")) {
-        HIP_TRY(lcsgpu::launch_upgma_chain(a, modified != 0, wg, L.stream));
-        HIP_TRY(hipMemcpyAsync(sel, a.sel, 48, hipMemcpyDeviceToHost, L.stream));
-        HIP_TRY(hipStreamSynchronize(L.stream));
-        if (a.chain_dbg) {
-            unsigned long long tk[8];
-            HIP_TRY(hipMemcpy(tk, a.chain_dbg, 64, hipMemcpyDeviceToHost));
-            static const char* what[6] = {"rows arrive", "averages + stores issued", "stores acknowledged", "workgroup minima", "barrier", "slots"};
-            for (int i = 0; i < 6; ++i) fprintf(stderr, "  chain phase %-26s %.2f us per merge\n", what[i], tk[i] * 0.01 / std::max(n - 1, 1));
-        }
-        if (sel[9] == 1) merged = true;
-        else if (sel[9] == 2) {
-            if (getenv("LCSGPU_PROFILE")) fprintf(stderr, "lcsgpu_upgma: the one-XCD merge kernel could not assemble %d workgroups; one launch per merge\n", wg);
-            HIP_TRY(hipMemsetAsync(base + o_sel, 0, 256, L.stream));
-        } else
-            return fail(LCSGPU_E_HIP, "UPGMA: the merge kernel lost its workgroups on the way (status %u)", sel[9]);
-    }
     int n_batches = 0, n_cut = 0;
     if (!merged && square && batch_k) {
         const size_t nb = (ld + 255) / 256;
@@ -1016,7 +988,6 @@ int upgma_reduce(lcsgpu_ctx* ctx, Lane& L, int elem, int distance_kind, int modi
         ba.side = (float*)(bb + b_side);
         ba.part_d = (float*)(bb + b_pd);
         ba.part_j = (uint32_t*)(bb + b_pj);
-        ba.dbg = getenv("LCSGPU_UPGMA_BATCH_DBG") ? (unsigned long long*)(bb + b_hdr + 1536) : nullptr; // 16 x 8 B behind the header's 264 words
         HIP_TRY(hipMemsetAsync(bb + b_state, 0, 256 + 2048, L.stream));
         HIP_TRY(lcsgpu::launch_upgma_batch_init(ba, L.stream));
         // The host does not know how many batches it takes (the validity check may cut one short): enqueue what the
@@ -1039,15 +1010,6 @@ int upgma_reduce(lcsgpu_ctx* ctx, Lane& L, int elem, int distance_kind, int modi
             n_cut = (int)st[3];
         }
         merged = true;
-        if (ba.dbg) {
-            unsigned long long tk[16];
-            HIP_TRY(hipMemcpy(tk, ba.dbg, sizeof tk, hipMemcpyDeviceToHost));
-            static const char* what[16] = {"rows: level-1 loads", "rows: walk", "rows: the rows arrive", "rows: averages, side stores, minima", "", "", "", "",
-                                           "resolve: level 1 + partial minima", "resolve: level 2", "resolve: cross entries, minima, validity", "",
-                                           "commit: level 1", "commit: stores issued", "commit: renames + sorted order", ""};
-            for (int i = 0; i < 16; ++i)
-                if (what[i][0]) fprintf(stderr, "  batch phase %-40s %.2f us per batch\n", what[i], tk[i] * 0.01 / std::max(n_batches, 1));
-        }
         if (st[2]) {
             L.plan_in_flight = false;
             return fail(LCSGPU_E_INVALID, "UPGMA: no finite nearest neighbour (a pair with LCS 0?) -- the reference's "
@@ -1064,7 +1026,7 @@ int upgma_reduce(lcsgpu_ctx* ctx, Lane& L, int elem, int distance_kind, int modi
     if (profile)
         fprintf(stderr, "lcsgpu_upgma: n = %d, %s layout, distances + row minima %.3f s, %d merges %.3f s = %.2f us each (%s)\n", n,
                 square ? "square" : "triangle", t_merge - t_pro, n - 1, now() - t_merge, 1e6 * (now() - t_merge) / std::max(n - 1, 1),
-                batched ? "batches of merges, three launches each" : merged ? "one kernel on one XCD" : "one launch per merge");
+                batched ? "batches of merges, three launches each" : "one launch per merge");
     if (profile && batched)
         fprintf(stderr, "lcsgpu_upgma: %d batches of <= %d merges (%.1f merges per batch, %d cut short by a new row's key)\n", n_batches, batch_k,
                 (double)(n - 1) / n_batches, n_cut);
@@ -1421,7 +1383,7 @@ int lcsgpu_multi_lcs_triangle(lcsgpu_ctx* const* ctxs, int32_t n_ctx, int32_t ro
     // Every GPU is computing by now.  Each block leaves over its own GPU's PCIe link, all links at the same time: one
     // host thread per context (a copy into pageable host memory is staged by the runtime on the calling thread, so
     // queueing the copies from ONE thread would still drain the GPUs one after the other -- at 100 000 sequences 10 GB
-    // over one link, ~0.4 s, instead of 1.25 GB over each of eight).  LCSGPU_SERIAL_DRAIN=1: the old order (A/B, tests).
+    // over one link, ~0.4 s, instead of 1.25 GB over each of eight).
     std::vector<int> status(n_ctx, LCSGPU_OK);
     std::vector<std::string> what(n_ctx);
     auto drain = [&](int k) {
@@ -1439,9 +1401,7 @@ int lcsgpu_multi_lcs_triangle(lcsgpu_ctx* const* ctxs, int32_t n_ctx, int32_t ro
             what[k] = hipGetErrorString(e);
         }
     };
-    if (env_flag("LCSGPU_SERIAL_DRAIN"))
-        for (int k = 0; k < n_ctx; ++k) drain(k);
-    else {
+    {
         std::vector<std::thread> workers;
         for (int k = 1; k < n_ctx; ++k) workers.emplace_back(drain, k);
         drain(0);

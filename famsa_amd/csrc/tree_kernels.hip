@@ -513,215 +513,6 @@ __global__ __launch_bounds__(256) void upgma_step_kernel(UpgmaArgs a, int it)
     }
 }
 
-// ---- all merges in ONE kernel whose workgroups run on ONE XCD ----------------------------------------------------
-// One launch per merge costs ~9 us (a dependent launch, a level of loads, four block reductions, the two rows); a
-// device-wide barrier inside a persistent kernel costs more still (ubench_gridbar.hip: 20 us with 391 workgroups) because
-// ordinary device memory is only made coherent between the eight XCDs' L2 caches by writing back and invalidating them.
-// Workgroups on the SAME XCD share one L2 (scripts/ubench_xcd.hip: 16 workgroups, barrier + read-back 1.8 us per step,
-// not one stale read in 20 000 steps; the same code over all XCDs reads stale data at once): a barrier is an atomic at
-// that L2, a store is visible to the others once it has left the CU (write-through L1, s_waitcnt), and a reader only has
-// to bypass its own L1 (sc1 loads) -- no fence wider than the workgroup.  The kernel is launched with more workgroups
-// than it needs; each reads the hardware register XCC_ID, those on XCD 0 take a ticket, the first P of them take part
-// and the rest exit at once.  A thread owns up to 8 rows (row statistics in registers), a merge is: the two rows of the
-// symmetric matrix (sc1 loads), the new distances and their mirror, two partial minima per workgroup -> slots -> ONE
-// barrier -> every workgroup reduces the P slots and knows the new row's minimum and the next (Lmin, Rmin).
-// Semantics are upgma_step_kernel's (= UPGMA::computeTree, tree/UPGMA.cpp:198-288), statement for statement.
-__device__ __forceinline__ unsigned chain_xcc_id()
-{
-    return (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xFu; // hwreg(HW_REG_XCC_ID), 32 bits
-}
-__device__ __forceinline__ uint32_t chain_ld(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ float chain_ld(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
-__device__ __forceinline__ bool chain_barrier(uint32_t* counter, uint32_t target, int max_spins)
-{
-    __builtin_amdgcn_s_waitcnt(0); // this lane's stores have been acknowledged by the L2
-    __syncthreads();
-    __shared__ int s_ok;
-    if (threadIdx.x == 0) {
-        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        int spins = 0, ok = 1;
-        while (chain_ld(counter) < target)
-            if (++spins > max_spins) { ok = 0; break; }
-        s_ok = ok;
-    }
-    __syncthreads();
-    return s_ok != 0;
-}
-
-// (d, j, nr) first minimum over the workgroup's 1024 threads, result in every thread
-__device__ __forceinline__ void chain_wg_min3(float& d, uint32_t& j, uint32_t& nr, float* s_d, uint32_t* s_j, uint32_t* s_n)
-{
-    wave_first_min3(d, j, nr);
-    const int tid = threadIdx.x, w = tid >> 6;
-    __syncthreads();
-    if ((tid & 63) == 0) { s_d[w] = d; s_j[w] = j; s_n[w] = nr; }
-    __syncthreads();
-    // the 16 waves' results: one per lane of a row, reduced by every wave for itself (no third barrier)
-    const int l = tid & 15;
-    d = s_d[l]; j = s_j[l]; nr = s_n[l];
-    row_first_min3(d, j, nr);
-}
-
-template <bool MODIFIED>
-__global__ __launch_bounds__(UPGMA_CHAIN_THREADS) void upgma_chain_kernel(UpgmaArgs a, int P, unsigned want_xcd)
-{
-    __shared__ unsigned s_rank;
-    __shared__ float s_d[16];
-    __shared__ uint32_t s_j[16], s_n[16];
-    const int tid = threadIdx.x, n = a.n;
-    if (tid == 0) {
-        unsigned r = ~0u;
-        if (chain_xcc_id() == want_xcd) r = atomicAdd(&a.chain_ctl[0], 1u);
-        s_rank = r;
-    }
-    __syncthreads();
-    const unsigned rank = s_rank;
-    if (rank >= (unsigned)P) return;
-    uint32_t* bar = a.chain_ctl + 32;
-    uint32_t epoch = 0;
-    // assembly: if XCD `want_xcd` did not receive P workgroups nobody gets past this, and nothing has been touched
-    if (!chain_barrier(bar, ++epoch * P, 2000000)) {
-        if (tid == 0) atomicMax(&a.sel[9], 2u);
-        return;
-    }
-    const int T = P * UPGMA_CHAIN_THREADS, g = (int)rank * UPGMA_CHAIN_THREADS + tid;
-    const int kmax = (n + T - 1) / T; // rows per thread in use (wave-uniform)
-    float md[UPGMA_CHAIN_ROWS];
-    uint32_t nr[UPGMA_CHAIN_ROWS];
-    unsigned alive = 0;
-#pragma unroll
-    for (int k = 0; k < UPGMA_CHAIN_ROWS; ++k) {
-        const int j = g + k * T;
-        md[k] = UPGMA_BIG;
-        nr[k] = UPGMA_NONE;
-        if (j < n) {
-            md[k] = a.min_dist[j];
-            nr[k] = a.nearest[j];
-            alive |= 1u << k;
-        }
-    }
-    float* D = a.D;
-    const bool dbg = a.chain_dbg != nullptr && rank == 0; // phase timing (wall_clock64: 100 MHz), workgroup 0 only
-    unsigned long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = 0;
-#define CHAIN_TICK(i)                                                        \
-    if (dbg) {                                                               \
-        const unsigned long long t_now = wall_clock64();                     \
-        tk[i] += t_now - t_prev;                                             \
-        t_prev = t_now;                                                      \
-    }
-    if (dbg) t_prev = wall_clock64();
-    uint32_t L = UPGMA_NONE, R = UPGMA_NONE; // the merge being applied
-    float new_d = UPGMA_BIG;                 // the previous merge's new row: its minimum and nearest
-    uint32_t new_j = UPGMA_NONE;
-    for (int it = -1; it < n - 1; ++it) {
-        // ---- apply merge `it` (it = -1: nothing to apply, only the first pick) ----
-        float nd = UPGMA_BIG;
-        uint32_t nj = UPGMA_NONE, nn = UPGMA_NONE;
-        if (it >= 0) {
-            const size_t rowL = (size_t)L * (size_t)a.ld, rowR = (size_t)R * (size_t)a.ld;
-            // all of this thread's elements of the two rows are requested before the first is used (clamped addresses, no
-            // branch in between): ONE trip to memory per merge, not one per row the thread owns
-            float dLv[UPGMA_CHAIN_ROWS], dRv[UPGMA_CHAIN_ROWS];
-#pragma unroll
-            for (int k = 0; k < UPGMA_CHAIN_ROWS; ++k)
-                if (k < kmax) {
-                    const int jc = min(g + k * T, n - 1);
-                    dLv[k] = chain_ld(D + rowL + jc);
-                    dRv[k] = chain_ld(D + rowR + jc);
-                }
-            if (dbg) { __builtin_amdgcn_s_waitcnt(0); CHAIN_TICK(0) } // the two rows have arrived
-#pragma unroll
-            for (int k = 0; k < UPGMA_CHAIN_ROWS; ++k) {
-                const int j = g + k * T;
-                if (k >= kmax || !((alive >> k) & 1u) || (uint32_t)j == L || (uint32_t)j == R) continue;
-                const float dL = dLv[k], dR = dRv[k];
-                float v;
-                if (MODIFIED) v = __fadd_rn(__fmul_rn(0.05f, __fadd_rn(dL, dR)), __fmul_rn(0.9f, fminf(dL, dR)));
-                else v = __fmul_rn(__fadd_rn(dL, dR), 0.5f);
-                if (nr[k] == R) nr[k] = L;
-                D[rowL + j] = v;
-                D[(size_t)j * (size_t)a.ld + L] = v; // the mirror
-                if (v < nd) { nd = v; nj = (uint32_t)j; } // ascending j inside the thread
-            }
-#pragma unroll
-            for (int k = 0; k < UPGMA_CHAIN_ROWS; ++k)
-                if ((uint32_t)(g + k * T) == R) alive &= ~(1u << k); // the right child's row is deleted
-            if (rank == 0 && tid == 0) { // tree bookkeeping: node_index is this thread's alone
-                a.left[it] = (int32_t)a.node_index[L];
-                a.right[it] = (int32_t)a.node_index[R];
-                a.node_index[L] = (uint32_t)n + (uint32_t)it;
-                a.node_index[R] = UPGMA_NONE;
-            }
-            if (it == n - 2) break; // the last merge needs no successor
-            CHAIN_TICK(1) // averages, stores issued
-            if (dbg) { __builtin_amdgcn_s_waitcnt(0); CHAIN_TICK(2) } // stores acknowledged
-        }
-        // ---- this workgroup's candidates for the next pick: its rows other than Lmin (whose new minimum is pending) ----
-        float cd = UPGMA_BIG;
-        uint32_t cj = UPGMA_NONE, cn = UPGMA_NONE;
-#pragma unroll
-        for (int k = 0; k < UPGMA_CHAIN_ROWS; ++k) {
-            const int j = g + k * T;
-            if (((alive >> k) & 1u) && (uint32_t)j != L) take_first_min3(md[k], (uint32_t)j, nr[k], cd, cj, cn);
-        }
-        chain_wg_min3(nd, nj, nn, s_d, s_j, s_n);
-        chain_wg_min3(cd, cj, cn, s_d, s_j, s_n);
-        CHAIN_TICK(3) // the workgroup's two minima
-        const int par = (it + 1) & 1;
-        uint32_t* slots = a.chain_slots + (size_t)par * UPGMA_CHAIN_MAX_WG * 8;
-        if (tid == 0) {
-            uint32_t* s = slots + rank * 8;
-            s[0] = __float_as_uint(nd);
-            s[1] = nj;
-            s[2] = __float_as_uint(cd);
-            s[3] = cj;
-            s[4] = cn;
-        }
-        if (!chain_barrier(bar, ++epoch * P, 40000000)) {
-            if (tid == 0) atomicMax(&a.sel[9], 3u);
-            return;
-        }
-        CHAIN_TICK(4) // barrier
-        // ---- every workgroup: the new row's minimum, then the pick, from the P slots ----
-        float gd = UPGMA_BIG, pd = UPGMA_BIG;
-        uint32_t gj = UPGMA_NONE, pj = UPGMA_NONE, pn = UPGMA_NONE;
-        const int lane = tid & 63;
-        if (lane < P) {
-            const uint32_t* s = slots + lane * 8;
-            gd = __uint_as_float(chain_ld(s + 0));
-            gj = chain_ld(s + 1);
-            pd = __uint_as_float(chain_ld(s + 2));
-            pj = chain_ld(s + 3);
-            pn = chain_ld(s + 4);
-            if (!(gd < UPGMA_BIG)) { gd = UPGMA_BIG; gj = UPGMA_NONE; }
-            if (!(pd < UPGMA_BIG)) { pd = UPGMA_BIG; pj = UPGMA_NONE; pn = UPGMA_NONE; }
-        }
-        uint32_t g_unused = 0;
-        wave_first_min3(gd, gj, g_unused);
-        wave_first_min3(pd, pj, pn);
-        if (it >= 0) { // the merged row takes its new minimum and takes part in the pick
-            new_d = gd;
-            new_j = gj;
-#pragma unroll
-            for (int k = 0; k < UPGMA_CHAIN_ROWS; ++k)
-                if ((uint32_t)(g + k * T) == L) { md[k] = new_d; nr[k] = new_j; }
-            take_first_min3(new_d, L, new_j, pd, pj, pn);
-        }
-        L = pj;
-        R = pn;
-        CHAIN_TICK(5) // slots read and reduced
-        if (L == UPGMA_NONE || R == UPGMA_NONE || R >= (uint32_t)n) { // degenerate input (the reference: undefined)
-            if (rank == 0 && tid == 0) a.sel[8] = 1;
-            break;
-        }
-    }
-#undef CHAIN_TICK
-    if (dbg && tid == 0)
-        for (int i = 0; i < 8; ++i) a.chain_dbg[i] = tk[i];
-    if (rank == 0 && tid == 0) atomicMax(&a.sel[9], 1u);
-}
-
 hipError_t launch_upgma_prologue(const UpgmaArgs& a, const void* lcs, int elem_size, const uint32_t* lens, const float* pow_f32,
                                  int kind, hipStream_t stream)
 {
@@ -760,146 +551,11 @@ hipError_t launch_upgma_steps(const UpgmaArgs& a, bool modified, hipStream_t str
     return hipGetLastError();
 }
 
-hipError_t launch_upgma_chain(const UpgmaArgs& a, bool modified, int P, hipStream_t stream)
-{
-    // workgroups go to the XCDs round robin: 8 x (P + 8) of them give XCD 0 P + 8; which of them take part is decided by
-    // where they really run (XCC_ID), not by this expectation
-    const dim3 grid((unsigned)(8 * (P + 8)));
-    if (modified) hipLaunchKernelGGL(upgma_chain_kernel<true>, grid, dim3(UPGMA_CHAIN_THREADS), 0, stream, a, P, 0u);
-    else hipLaunchKernelGGL(upgma_chain_kernel<false>, grid, dim3(UPGMA_CHAIN_THREADS), 0, stream, a, P, 0u);
-    return hipGetLastError();
-}
-
 hipError_t launch_upgma(const UpgmaArgs& a, const void* lcs, int elem_size, const uint32_t* lens,
                         const float* pow_f32, int kind, bool modified, hipStream_t stream)
 {
     hipError_t e = launch_upgma_prologue(a, lcs, elem_size, lens, pow_f32, kind, stream);
     return e != hipSuccess ? e : launch_upgma_steps(a, modified, stream);
-}
-
-} // namespace lcsgpu
-
-// =============================================================================================
-// Leaf sub-trees of the FastTree recursion (UPGMA<D>::runPartial, reference tree/UPGMA.cpp:55-70: the distance
-// matrix of <= 2000 sequences + computeTree): ONE WORKGROUP PER LEAF, all leaves of a batch in one launch.  The
-// leaf's float triangle (<= 8 MB) sits in global scratch and stays in the XCD's L2; the row statistics
-// (min_dist, nearest, node_index: UPGMA.cpp:137-152) live in LDS; the m-1 merges are a loop inside the kernel with
-// workgroup barriers only -- no launch per merge, no device-wide synchronisation.  The arithmetic and every tie
-// rule are those of the whole-set kernels above (first strict minimum in ascending index, stale row minima,
-// (x+y)*0.5f resp. 0.05f*(x+y)+0.9f*min(x,y) without contraction).
-// =============================================================================================
-namespace lcsgpu {
-
-template <bool MODIFIED>
-__global__ __launch_bounds__(256) void leaf_upgma_kernel(LeafArgs a)
-{
-    __shared__ float s_min[LEAF_MAX];
-    __shared__ uint32_t s_near[LEAF_MAX];
-    __shared__ uint32_t s_node[LEAF_MAX];
-    __shared__ uint32_t s_len[LEAF_MAX];
-    __shared__ float s_d[4];
-    __shared__ uint32_t s_j[4];
-    const int tid = threadIdx.x;
-    const int g = a.order[blockIdx.x]; // largest leaves first
-    const int m = (int)(a.group_offsets[g + 1] - a.group_offsets[g]);
-    if (m < 2) return;
-    const int32_t* ids = a.ids + a.group_offsets[g];
-    const uint16_t* lcs = (const uint16_t*)a.lcs + a.tri_base[g];
-    float* D = a.D + a.tri_base[g];
-    int32_t* left = a.left + a.node_base[g];
-    int32_t* right = a.right + a.node_base[g];
-    for (int i = tid; i < m; i += 256) {
-        s_len[i] = a.lens[ids[i]];
-        s_node[i] = (uint32_t)i;
-    }
-    __syncthreads();
-    // distances (Transform<float, kind>) and the initial row minima in one sweep over the rows, in the reference's
-    // visiting order (UPGMA.cpp:182-199): vertex x sees y < x when row x is processed, then y > x row by row.
-    // Thread t owns the columns t, t + 256, ...: their running minima stay in its registers.
-    constexpr int Q = LEAF_MAX / 256;
-    float cmin[Q];
-    uint32_t carg[Q];
-#pragma unroll
-    for (int q = 0; q < Q; ++q) { cmin[q] = UPGMA_BIG; carg[q] = UPGMA_NONE; }
-    for (int i = 1; i < m; ++i) {
-        const size_t row = (size_t)i * (i - 1) / 2;
-        const uint32_t len_i = s_len[i];
-        float bd = UPGMA_BIG;
-        uint32_t bj = UPGMA_NONE;
-#pragma unroll
-        for (int q = 0; q < Q; ++q) {
-            const int j = tid + 256 * q;
-            if (j < i) {
-                const uint32_t l = lcs[row + j];
-                const uint32_t indel = len_i + s_len[j] - 2u * l;
-                float d;
-                if (l == 0) d = 3.40282347e38f;
-                else if (a.kind == 1) d = __fdiv_rn(a.pow_f32[indel], (float)l);
-                else d = __fdiv_rn((float)indel, (float)l);
-                D[row + j] = d;
-                if (d < bd) { bd = d; bj = (uint32_t)j; }                 // row i: ascending j inside the thread
-                if (d < cmin[q]) { cmin[q] = d; carg[q] = (uint32_t)i; }  // column j: ascending i over the sweep
-            }
-        }
-        block_first_min(bd, bj, s_d, s_j);
-        if ((i & 255) == tid && bd < UPGMA_BIG) { // the owner of vertex i: its row part comes before any column part
-#pragma unroll
-            for (int q = 0; q < Q; ++q)
-                if (q == (i >> 8)) { cmin[q] = bd; carg[q] = bj; }
-        }
-    }
-#pragma unroll
-    for (int q = 0; q < Q; ++q) {
-        const int j = tid + 256 * q;
-        if (j < m) { s_min[j] = cmin[q]; s_near[j] = carg[q]; }
-    }
-    __syncthreads();
-    for (int it = 0; it < m - 1; ++it) {
-        // Lmin = first minimum of min_dist over the active rows, Rmin = its nearest (UPGMA.cpp:203-219)
-        float pd = UPGMA_BIG;
-        uint32_t pj = UPGMA_NONE;
-        for (int j = tid; j < m; j += 256)
-            if (s_node[j] != UPGMA_NONE) take_first_min(s_min[j], (uint32_t)j, pd, pj);
-        block_first_min(pd, pj, s_d, s_j);
-        const uint32_t L = pj;
-        const uint32_t R = L != UPGMA_NONE ? s_near[L] : UPGMA_NONE;
-        if (L == UPGMA_NONE || R == UPGMA_NONE || R >= (uint32_t)m) { // degenerate input (the reference: undefined)
-            if (tid == 0) a.err[0] = 1;
-            return;
-        }
-        // distances to the new cluster, which takes row Lmin (UPGMA.cpp:221-250)
-        float nd = UPGMA_BIG;
-        uint32_t nj = UPGMA_NONE;
-        for (int j = tid; j < m; j += 256) {
-            if ((uint32_t)j == L || (uint32_t)j == R || s_node[j] == UPGMA_NONE) continue;
-            const size_t vL = tri_index(L, j), vR = tri_index(R, j);
-            const float dL = D[vL], dR = D[vR];
-            float v;
-            if (MODIFIED) v = __fadd_rn(__fmul_rn(0.05f, __fadd_rn(dL, dR)), __fmul_rn(0.9f, fminf(dL, dR)));
-            else v = __fmul_rn(__fadd_rn(dL, dR), 0.5f);
-            if (s_near[j] == R) s_near[j] = L;
-            D[vL] = v;
-            if (v < nd) { nd = v; nj = (uint32_t)j; }
-        }
-        block_first_min(nd, nj, s_d, s_j); // (its barriers also order this merge's D / LDS writes before the next reads)
-        if (tid == 0) {
-            left[it] = (int32_t)s_node[L];
-            right[it] = (int32_t)s_node[R];
-            s_node[L] = (uint32_t)(m + it);
-            s_near[L] = nj;
-            s_min[L] = nd;
-            s_node[R] = UPGMA_NONE;
-        }
-        __syncthreads();
-    }
-}
-
-hipError_t launch_leaf_upgma(const LeafArgs& a, int n_groups, bool modified, hipStream_t stream)
-{
-    if (n_groups <= 0) return hipSuccess;
-    if (modified) hipLaunchKernelGGL(leaf_upgma_kernel<true>, dim3(n_groups), dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL(leaf_upgma_kernel<false>, dim3(n_groups), dim3(256), 0, stream, a);
-    return hipGetLastError();
 }
 
 } // namespace lcsgpu

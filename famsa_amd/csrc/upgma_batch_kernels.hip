@@ -75,26 +75,6 @@ __device__ __forceinline__ bool ub_less(uint32_t k1, uint32_t r1, uint32_t k2, u
 {
     return k1 < k2 || (k1 == k2 && r1 < r2);
 }
-// measurement aid (LCSGPU_UPGMA_BATCH_DBG): thread 0 of ONE workgroup in the middle of the grid adds the 10 ns ticks
-// between its phase marks to dbg[slot]
-struct UbTimer {
-    unsigned long long* dbg;
-    unsigned long long last;
-    bool on;
-    __device__ UbTimer(unsigned long long* d, int first_slot) : dbg(d + first_slot), last(0)
-    {
-        on = d != nullptr && threadIdx.x == 0 && blockIdx.x == gridDim.x / 2;
-        if (on) last = wall_clock64();
-    }
-    __device__ void mark(int slot)
-    {
-        if (!on) return;
-        const unsigned long long now = wall_clock64();
-        atomicAdd(dbg + slot, now - last);
-        last = now;
-    }
-};
-
 __device__ __forceinline__ uint32_t lane_u32(uint32_t v, int lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, lane); }
 __device__ __forceinline__ int lane_i32(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
 
@@ -150,7 +130,6 @@ __global__ __launch_bounds__(256) void upgma_batch_rows_kernel(UpgmaBatchArgs a,
     const size_t ld = (size_t)a.ld;
     const int lane = tid & 63, wave = tid >> 6;
     const uint32_t p = (uint32_t)b * 256 + tid; // my slot
-    UbTimer tm(a.dbg, 0);
     // ---- level 1: everything whose address is known before the launch ----
     const uint32_t* st = a.state + 8 * parity;
     const uint32_t done = st[0], ns = st[1], err = st[2];
@@ -162,7 +141,6 @@ __global__ __launch_bounds__(256) void upgma_batch_rows_kernel(UpgmaBatchArgs a,
         if (b == 0 && tid == 0) a.hdr[0] = 0u;
         return;
     }
-    tm.mark(0); // level-1 loads
     // ---- the walk: lane t of every wave ends up holding merge t ----
     uint32_t mL = UB_NONE, mR = UB_NONE, mKey = 0u;
     int mSrc = -1, mPos = 0;
@@ -196,7 +174,6 @@ __global__ __launch_bounds__(256) void upgma_batch_rows_kernel(UpgmaBatchArgs a,
         }
     }
     if (m == 0) return;
-    tm.mark(1); // the walk
     // ---- my slot's part in the batch: it is a column of merge t until its row is merged itself ----
     int dieAt = UB_INF;
 #pragma unroll
@@ -213,13 +190,6 @@ __global__ __launch_bounds__(256) void upgma_batch_rows_kernel(UpgmaBatchArgs a,
             if (lane_i32(mSrc, t) < 0) dr[t] = a.D[(size_t)lane_u32(mR, t) * ld + p];
         }
     }
-    if (tm.on) { // (the loads land: what the timer sees as "rows arrive")
-        float sink = 0.0f;
-#pragma unroll
-        for (int t = 0; t < K; ++t) sink += dl[t] + dr[t];
-        if (sink == 1.2345e-30f) a.hdr[2] = 1u;
-    }
-    tm.mark(2);
     s_x[tid] = x;
 #pragma unroll
     for (int t = 0; t < K; ++t) {
@@ -257,7 +227,6 @@ __global__ __launch_bounds__(256) void upgma_batch_rows_kernel(UpgmaBatchArgs a,
             a.part_j[(size_t)t * nb + b] = nj;
         }
     }
-    tm.mark(3); // averages, side stores issued, minima
 }
 
 // ---- launch 2 of a batch: ONE workgroup resolves it ---------------------------------------------------------------------
@@ -278,7 +247,6 @@ __global__ __launch_bounds__(1024) void upgma_batch_resolve_kernel(UpgmaBatchArg
     const int tid = threadIdx.x, n = a.n, nb = a.n_blocks;
     const size_t ld = (size_t)a.ld;
     const int lane = tid & 63, wave = tid >> 6;
-    UbTimer tm(a.dbg, 8);
     const uint32_t* st = a.state + 8 * parity;
     uint32_t* st_next = a.state + 8 * (parity ^ 1);
     uint32_t* rec = a.rec;
@@ -319,7 +287,6 @@ __global__ __launch_bounds__(1024) void upgma_batch_resolve_kernel(UpgmaBatchArg
         dpp_min_step<DPP_ROW_BCAST15, 0xA>(d, dj);
         if (t < K && sub == 31) { s_pm_d[t] = d; s_pm_j[t] = dj; }
     }
-    tm.mark(0); // level 1 + the partial minima
     if (m == 0 || err) { // nothing pending (finished, or an error): the state moves on unchanged
         if (tid == 0) {
             st_next[0] = done; st_next[1] = ns; st_next[2] = err | walk_err; st_next[3] = cuts;
@@ -356,7 +323,6 @@ __global__ __launch_bounds__(1024) void upgma_batch_resolve_kernel(UpgmaBatchArg
         if (lane < K) s_die[lane] = die;
     }
     __syncthreads();
-    tm.mark(1); // level 2
     // ---- the cross entries: D[L_t][L_u] for the clusters the batch creates ----
     // A merge whose partner is an old row needs nothing of the table: all those entries at once, one per thread.  A
     // merge whose partner was created in the batch reads the table: those go in merge order (wave 0, lane = u).
@@ -452,7 +418,6 @@ __global__ __launch_bounds__(1024) void upgma_batch_resolve_kernel(UpgmaBatchArg
     }
     // the cross entries for the commit (only the pairs it will write are read there)
     for (int idx = tid; idx < K * K; idx += 1024) rec[UB_REC0 + 4 * K + idx] = __float_as_uint(s_tab[idx / K][idx % K]);
-    tm.mark(2); // cross entries, minima, validity, bookkeeping
 }
 
 // ---- launch 3 of a batch: the commit ----------------------------------------------------------------------------------
@@ -468,7 +433,6 @@ __global__ __launch_bounds__(256) void upgma_batch_commit_kernel(UpgmaBatchArgs 
     const size_t ld = (size_t)a.ld;
     const int lane = tid & 63, wave = tid >> 6;
     const uint32_t gid = (uint32_t)b * 256 + tid; // slot p, row j AND position of the sorted order
-    UbTimer tm(a.dbg, 12);
     const uint32_t* st = a.state + 8 * parity;
     const uint32_t* rec = a.rec;
     // ---- level 1: lane t of every wave holds merge t's record ----
@@ -496,7 +460,6 @@ __global__ __launch_bounds__(256) void upgma_batch_commit_kernel(UpgmaBatchArgs 
 #pragma unroll
     for (int t = 0; t < K; ++t) sv[t] = is_slot ? a.side[(size_t)t * ld + gid] : 0.0f;
     if (V == 0) return; // nothing stands (finished, or an error)
-    tm.mark(0); // level 1
     // ---- commit my slot: the entries of the V new clusters towards my row ----
     bool passes = x != UB_NONE; // my row only passes through the batch (it is in no standing merge)
     bool mine = is_row && my_node != UB_NONE;
@@ -549,7 +512,6 @@ __global__ __launch_bounds__(256) void upgma_batch_commit_kernel(UpgmaBatchArgs 
             }
         }
     }
-    tm.mark(1); // commit stores issued
     // ---- my row's nearest under the renames of the batch ----
     if (mine && near != my_near) a.nearest[gid] = near;
     // ---- the sorted order of the next batch: position gid of the current one (gid == ns: the place behind the end) ----
@@ -590,7 +552,6 @@ __global__ __launch_bounds__(256) void upgma_batch_commit_kernel(UpgmaBatchArgs 
             }
         }
     }
-    tm.mark(2); // renames + the sorted order
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------------------

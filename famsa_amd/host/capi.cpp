@@ -35,7 +35,7 @@ TreeOptions make_options(const char* method, int distance, int keep_duplicates, 
     if (threshold > 0) o.fast.threshold = threshold;
     if (cluster_fraction > 0) o.fast.cluster_fraction = cluster_fraction;
     if (cluster_iters > 0) o.fast.cluster_iters = cluster_iters;
-    if (const char* t = getenv("FAMSA_HOST_THREADS")) o.fast.n_threads = std::max(1, atoi(t));
+    o.fast.n_threads = std::max(1, host_test_int("threads", o.fast.n_threads));
     return o;
 }
 int fail(const std::exception& e)

@@ -25,12 +25,12 @@
 namespace famsa_host {
 namespace {
 
-// coarse phase timers, printed when FAMSA_GPU_PROFILE is set (dev aid)
+// coarse phase timers, printed when LCSGPU_PROFILE is set
 struct PhaseTimers {
     double lcs = 0, clarans = 0, partial = 0, assign = 0;
     ~PhaseTimers()
     {
-        if (getenv("FAMSA_GPU_PROFILE") && (lcs + clarans + partial + assign) > 0)
+        if (profile_on() && (lcs + clarans + partial + assign) > 0)
             fprintf(stderr, "fasttree.lcs_calls=%.3f\nfasttree.clarans=%.3f\nfasttree.partial_trees=%.3f\nfasttree.assign=%.3f\n",
                     lcs, clarans, partial, assign);
     }
@@ -312,13 +312,6 @@ public:
         std::vector<int> g((size_t)offsets[n_groups]);
         for (size_t i = 0; i < g.size(); ++i) g[i] = ids_[ids[i]];
         return p_.triangles_batch(g.data(), offsets, n_groups, out);
-    }
-    bool leaf_upgma_batch(const int* ids, const int64_t* offsets, int n_groups, int kind, bool modified,
-                          std::vector<int32_t>& left, std::vector<int32_t>& right) override
-    {
-        std::vector<int> g((size_t)offsets[n_groups]);
-        for (size_t i = 0; i < g.size(); ++i) g[i] = ids_[ids[i]];
-        return p_.leaf_upgma_batch(g.data(), offsets, n_groups, kind, modified, left, right);
     }
     bool clarans(const int* ids, int n_ids, int kind, int n_medoids, int n_fixed, float fraction, int num_local,
                  int* medoids) override
@@ -667,7 +660,7 @@ struct FastTree {
 
         std::vector<int> subroots(n_seeds, -1);
         const auto t_top1 = std::chrono::steady_clock::now();
-        if (parallel && getenv("FAMSA_GPU_PROFILE"))
+        if (parallel && profile_on())
             fprintf(stderr, "fasttree.top_evaluation_wall=%.3f\n", std::chrono::duration<double>(t_top1 - t_top0).count());
         {
             struct Task { int k, top; };
@@ -679,7 +672,7 @@ struct FastTree {
                     subroots[k] = previous_top - 1;
                 }
             std::vector<tree_structure> locals(tasks.size());
-            if (parallel && getenv("FAMSA_GPU_PROFILE")) {
+            if (parallel && profile_on()) {
                 std::vector<size_t> sz;
                 for (auto& t : tasks) sz.push_back(subgroups[t.k].size());
                 std::sort(sz.rbegin(), sz.rend());
@@ -703,32 +696,6 @@ struct FastTree {
                             const auto& g = subgroups[tasks[t].k];
                             ids.insert(ids.end(), g.begin(), g.end());
                             offs.push_back((int64_t)ids.size());
-                        }
-                        if (partial == GT::UPGMA || partial == GT::UPGMA_modified) {
-                            // the leaves' trees come from the source itself: their LCS triangles never leave the device
-                            std::vector<int32_t> left, right;
-                            bool built;
-                            {
-                                Scope tm(g_phase.lcs);
-                                OffCpu w;
-                                built = src.leaf_upgma_batch(ids.data(), offs.data(), (int)batch.size(), (int)D,
-                                                             partial == GT::UPGMA_modified, left, right);
-                            }
-                            if (built) {
-                                size_t node0 = 0;
-                                for (size_t t : batch) {
-                                    const auto& g = subgroups[tasks[t].k];
-                                    const int m = (int)g.size(), top = tasks[t].top;
-                                    tree_structure& out = locals[t];
-                                    out.resize((size_t)std::max(m - 1, 0));
-                                    for (int node = 0; node < m - 1; ++node) { // local ids -> ids of the whole tree (leaf_tree)
-                                        const int a = left[node0 + node], b = right[node0 + node];
-                                        out[node] = top > m ? node_t(a < m ? g[a] : a + top - m, b < m ? g[b] : b + top - m) : node_t(a, b);
-                                    }
-                                    node0 += (size_t)std::max(m - 1, 0);
-                                }
-                                return;
-                            }
                         }
                         auto buf = std::make_shared<LcsBuf>();
                         bool have;
@@ -777,7 +744,7 @@ struct FastTree {
                     do_step(subgroups[tasks[t].k], locals[t], tasks[t].top, false);
             }
             for (const auto& lt : locals) tree.insert(tree.end(), lt.begin(), lt.end());
-            if (parallel && getenv("FAMSA_GPU_PROFILE"))
+            if (parallel && profile_on())
                 fprintf(stderr, "fasttree.top_subtrees_wall=%.3f\n",
                         std::chrono::duration<double>(std::chrono::steady_clock::now() - t_top1).count());
         }
@@ -808,7 +775,6 @@ void run_fast(LcsSource& src, GT partial, const FastTreeParams& p, tree_structur
     // sequences, 16 cores, tree stage: 16 threads 2.6 s, 32: 2.2 s, 48: 2.15 s)
     const int n_cpu = std::max(1, p.n_threads);
     int n_pool = fasttree_pool_threads(n_cpu);
-    if (const char* e = getenv("FAMSA_GPU_POOL_THREADS")) n_pool = std::max(1, atoi(e));
     src.expect_threads(n_pool);
     g_cpu.reset(n_pool > n_cpu ? n_cpu : 0);
     g_cpu.acquire(); // this thread works too

@@ -6,12 +6,47 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <stdexcept>
 #include <thread>
 
 #include "../../include/lcsgpu.h"
 
 namespace famsa_host {
+
+static const char* find_test_key(const char* name, size_t* len_out)
+{
+    const char* e = getenv("FAMSA_HOST_TEST");
+    if (!e) return nullptr;
+    const size_t kl = strlen(name);
+    for (const char* p = e; *p;) {
+        const char* end = strchr(p, ',');
+        const size_t len = end ? (size_t)(end - p) : strlen(p);
+        if (len >= kl && !strncmp(p, name, kl) && (len == kl || p[kl] == '=')) {
+            *len_out = len;
+            return p;
+        }
+        p += len + (end ? 1 : 0);
+    }
+    return nullptr;
+}
+bool host_test(const char* name)
+{
+    size_t len = 0;
+    return find_test_key(name, &len) != nullptr;
+}
+int host_test_int(const char* key, int dflt)
+{
+    size_t len = 0;
+    const char* p = find_test_key(key, &len);
+    const size_t kl = strlen(key);
+    return p && len > kl + 1 ? atoi(p + kl + 1) : dflt;
+}
+bool profile_on()
+{
+    static const bool on = getenv("LCSGPU_PROFILE") != nullptr;
+    return on;
+}
 
 bool LcsSource::wide() const
 {
@@ -55,7 +90,7 @@ GpuLcsSource::GpuLcsSource(const std::vector<int>& devices)
 
 GpuLcsSource::~GpuLcsSource()
 {
-    if (getenv("FAMSA_GPU_PROFILE"))
+    if (profile_on())
         fprintf(stderr, "engine.rect: %ld calls %.3f thread-s %.3g pairs\nengine.triangle: %ld calls %.3f thread-s %.3g pairs\n"
                         "engine.triangle_ids: %ld calls %.3f thread-s %.3g pairs\nengine.clarans: %ld calls %.3f thread-s %.3g pairs\n"
                         "engine.triangles_batch: %ld calls %.3f thread-s %.3g pairs\nengine.assign_seeds: %ld calls %.3f thread-s %.3g pairs\n",
@@ -201,7 +236,7 @@ void GpuLcsSource::triangle_ids(const int* ids, int n_ids, LcsBuf& out)
 bool GpuLcsSource::prim_edges(int distance_kind, std::vector<MstEdge>& edges, bool triangle_orientation)
 {
     static_assert(sizeof(MstEdge) == sizeof(lcsgpu_mst_edge), "edge layout");
-    if (getenv("FAMSA_NO_DEVICE_MST")) return false; // test aid: what happens when the triangle does not fit the HBM
+    if (host_test("no_device_mst")) return false; // test aid: what happens when the triangle does not fit the HBM
     edges.resize(n() > 0 ? n() - 1 : 0);
     const int flags = triangle_orientation ? LCSGPU_MST_TRIANGLE_ORIENTATION : 0;
     int rc = LCSGPU_E_UNSUPPORTED;
@@ -280,63 +315,6 @@ bool GpuLcsSource::triangles_batch(const int* ids, const int64_t* offsets, int n
     return true;
 }
 
-bool GpuLcsSource::leaf_upgma_batch(const int* ids, const int64_t* offsets, int n_groups, int distance_kind, bool modified,
-                                    std::vector<int32_t>& left, std::vector<int32_t>& right)
-{
-    // Opt-in (FAMSA_LEAF_DEVICE=1).  Measured at 3 000 000 sequences (profiles/c5_leaf_r03.txt): the host spends 6.2
-    // thread-seconds less on leaf trees, but a batch call grows from 3 to 25 ms (a 2000-member leaf is 2000 dependent
-    // merges of ~3 us inside its workgroup) and the CLARANS rounds that share the chip with those long-running
-    // workgroups slow down by 40 % -- tree stage 2.22 -> 2.5-3.0 s.  So the leaves stay on the host's cores by default.
-    if (!getenv("FAMSA_LEAF_DEVICE")) return false;
-    std::vector<size_t> node0((size_t)n_groups + 1, 0), pairs0((size_t)n_groups + 1, 0);
-    for (int g = 0; g < n_groups; ++g) {
-        const size_t m = (size_t)(offsets[g + 1] - offsets[g]);
-        node0[g + 1] = node0[g] + (m > 0 ? m - 1 : 0);
-        pairs0[g + 1] = pairs0[g] + m * (m > 0 ? m - 1 : 0) / 2;
-    }
-    left.assign(node0[n_groups], 0);
-    right.assign(node0[n_groups], 0);
-    if (node0[n_groups] == 0) return true;
-    const double t0 = now_s();
-    const int parts = (int)std::min<size_t>(ctxs_.size(), (size_t)n_groups);
-    bool unsupported = false;
-    if (parts <= 1 || pairs0[n_groups] < (1u << 16)) {
-        lcsgpu_ctx* c = pick();
-        const int rc = lcsgpu_leaf_upgma_batch(c, ids, offsets, n_groups, distance_kind, modified ? 1 : 0, left.data(), right.data());
-        if (rc == LCSGPU_E_UNSUPPORTED) return false;
-        check(rc, "lcsgpu_leaf_upgma_batch");
-        add_kernel_ms(c);
-    } else { // consecutive lists per device, cut by pair count
-        std::vector<int> cut(parts + 1, n_groups);
-        cut[0] = 0;
-        for (int k = 1; k < parts; ++k) {
-            const size_t target = pairs0[n_groups] / parts * k;
-            int g = cut[k - 1];
-            while (g < n_groups && pairs0[g] < target) ++g;
-            cut[k] = g;
-        }
-        std::mutex mu;
-        on_each_device(parts, [&](int k) {
-            const int g0 = cut[k], g1 = cut[k + 1];
-            if (g1 <= g0) return;
-            std::vector<int64_t> rel((size_t)(g1 - g0) + 1);
-            for (int g = g0; g <= g1; ++g) rel[g - g0] = offsets[g] - offsets[g0];
-            const int rc = lcsgpu_leaf_upgma_batch(ctxs_[k], ids + offsets[g0], rel.data(), g1 - g0, distance_kind, modified ? 1 : 0,
-                                                   left.data() + node0[g0], right.data() + node0[g0]);
-            if (rc == LCSGPU_E_UNSUPPORTED) {
-                std::lock_guard<std::mutex> lk(mu);
-                unsupported = true;
-                return;
-            }
-            if (rc != LCSGPU_OK) throw std::runtime_error(std::string("lcsgpu_leaf_upgma_batch failed: ") + lcsgpu_last_error());
-            add_kernel_ms(ctxs_[k]);
-        });
-    }
-    if (unsupported) return false;
-    note(st_batch_, now_s() - t0, (double)pairs0[n_groups]);
-    return true;
-}
-
 bool GpuLcsSource::assign_seeds(const int* seeds, int n_seeds, const int* cols, int n_cols, int distance_kind, int first_k,
                                 float* dist, int* assign)
 {
@@ -362,8 +340,7 @@ bool GpuLcsSource::assign_seeds(const int* seeds, int n_seeds, const int* cols, 
 bool GpuLcsSource::clarans(const int* ids, int n_ids, int distance_kind, int n_medoids, int n_fixed,
                            float explore_fraction, int num_local, int* medoids)
 {
-    static const bool host_search = getenv("FAMSA_CLARANS_HOST") != nullptr; // A/B aid: keep the search on the host
-    if (host_search) return false;
+    if (host_test("clarans_host")) return false; // the checker of the device search: keep it on the host
     const double t0 = now_s();
     lcsgpu_ctx* c = pick();
     const int rc = lcsgpu_clarans(c, ids, n_ids, distance_kind, n_medoids, n_fixed, explore_fraction, num_local, medoids);

@@ -14,6 +14,15 @@ struct lcsgpu_ctx;
 
 namespace famsa_host {
 
+// Test hooks of the host layer, FAMSA_HOST_TEST="name,name,key=value": prim_streaming (MST-Prim's O(n)-memory host form on
+// any input), slink_from_mst (the MST -> SLINK conversion with Prim on the host), upgma_triangle (the leaf UPGMA's triangle
+// walk instead of the square matrix), no_device_mst (as if the triangle did not fit the device), clarans_host (the CLARANS
+// search on the host), threads=N (worker threads of the C test entry points).  Not read on any product default path.
+bool host_test(const char* name);
+int host_test_int(const char* key, int dflt);
+// LCSGPU_PROFILE: stage / call statistics on stderr (the library prints its own under the same switch)
+bool profile_on();
+
 // LCS values as uint16 (all sequences <= 65535 residues) or uint32.
 struct LcsBuf {
     bool wide = false;
@@ -65,11 +74,6 @@ public:
     // The packed triangles of several id lists in one request: list g = ids[offsets[g] .. offsets[g+1]),
     // its triangle at out[sum_{h<g} m_h(m_h-1)/2 ...].  False = not offered; ask list by list.
     virtual bool triangles_batch(const int* /*ids*/, const int64_t* /*offsets*/, int /*n_groups*/, LcsBuf& /*out*/) { return false; }
-    // The UPGMA sub-trees of several id lists built by the source itself (device): list g's m_g - 1 internal nodes at
-    // left / right[sum_{h<g} (m_h - 1) ...], children as local ids (as IPartialGenerator::runPartial appends them).
-    // False = not offered for this batch; ask for the triangles and build the trees on the host.
-    virtual bool leaf_upgma_batch(const int* /*ids*/, const int64_t* /*offsets*/, int /*n_groups*/, int /*distance_kind*/,
-                                  bool /*modified*/, std::vector<int32_t>& /*left*/, std::vector<int32_t>& /*right*/) { return false; }
     // Seed assignment of one FastTree evaluation done by the source itself: for r in order, a column moves to
     // seed first_k + r on a strictly smaller Transform<float> distance; dist / assign are updated in place.
     virtual bool assign_seeds(const int* /*seeds*/, int /*n_seeds*/, const int* /*cols*/, int /*n_cols*/, int /*distance_kind*/,
@@ -108,8 +112,6 @@ public:
     bool clarans(const int* ids, int n_ids, int distance_kind, int n_medoids, int n_fixed, float explore_fraction,
                  int num_local, int* medoids) override;
     bool triangles_batch(const int* ids, const int64_t* offsets, int n_groups, LcsBuf& out) override;
-    bool leaf_upgma_batch(const int* ids, const int64_t* offsets, int n_groups, int distance_kind, bool modified,
-                          std::vector<int32_t>& left, std::vector<int32_t>& right) override;
     bool assign_seeds(const int* seeds, int n_seeds, const int* cols, int n_cols, int distance_kind, int first_k, float* dist,
                       int* assign) override;
     double kernel_ms_total() const { return kernel_ms_; }

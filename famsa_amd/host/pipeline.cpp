@@ -158,7 +158,7 @@ std::string newick_gpu(const SeqSet& s, SeqSet* consumable, int device, const Tr
         t->kernel_ms = src.kernel_ms_total();
         t->transport = src.transport();
     }
-    if (g_abandon_engine_at_return && !getenv("FAMSA_GPU_PROFILE")) (void)held.release();
+    if (g_abandon_engine_at_return && !profile_on()) (void)held.release();
     return nwk;
 }
 } // namespace
@@ -184,7 +184,7 @@ void dist_export_gpu(const SeqSet& s, int device, Distance dist, bool square, bo
         t->kernel_ms = src.kernel_ms_total();
         t->transport = src.transport();
     }
-    if (g_abandon_engine_at_return && !getenv("FAMSA_GPU_PROFILE")) (void)held.release();
+    if (g_abandon_engine_at_return && !profile_on()) (void)held.release();
 }
 
 } // namespace famsa_host

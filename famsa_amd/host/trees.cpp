@@ -99,7 +99,7 @@ void mst_prim(LcsSource& src, tree_structure& tree)
         // (tree/MSTPrim.cpp:478); each step is one engine call, so this is a last resort, not a fast path.
         const bool sensitive = src.orientation_sensitive();
         const double values = sensitive ? (double)n * n : (double)n * (n - 1) / 2;
-        const bool streaming = values * (src.wide() ? 4 : 2) > 16e9 || getenv("FAMSA_PRIM_STREAMING") != nullptr;
+        const bool streaming = values * (src.wide() ? 4 : 2) > 16e9 || host_test("prim_streaming");
         LcsBuf buf, rowbuf;
         PrimLcs lcs;
         lcs.n = n;
@@ -292,7 +292,7 @@ void slink(LcsSource& src, tree_structure& tree)
             slink_from_mst(edges, n, tree);
             return;
         }
-        if (getenv("FAMSA_SLINK_FROM_MST")) { // test hook: the same conversion with Prim on the host
+        if (host_test("slink_from_mst")) { // test hook: the same conversion with Prim on the host
             host_prim_triangle<D>(src, edges);
             slink_from_mst(edges, n, tree);
             return;
@@ -734,7 +734,7 @@ void build_partial_d(LcsSource& src, GT method, tree_structure& tree)
             for (int i = 0; i < n - 1; ++i) tree.emplace_back(left[i], right[i]);
             break;
         }
-        if (n <= UPGMA_SQUARE_MAX && !getenv("FAMSA_UPGMA_TRIANGLE")) { // the leaves of the FastTree recursion
+        if (n <= UPGMA_SQUARE_MAX && !host_test("upgma_triangle")) { // the leaves of the FastTree recursion
             if (method == GT::UPGMA) upgma_square<false, D>(src, tree); else upgma_square<true, D>(src, tree);
             break;
         }

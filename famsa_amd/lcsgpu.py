@@ -71,7 +71,6 @@ def load_library():
         "lcsgpu_upgma": (C.c_int, [vp, C.c_int, C.c_int, vp, vp]),
         "lcsgpu_nj": (C.c_int, [vp, C.c_int, vp, vp]),
         "lcsgpu_lcs_triangles_batch": (C.c_int, [vp, pi32, C.POINTER(C.c_int64), i32, vp, C.c_int]),
-        "lcsgpu_leaf_upgma_batch": (C.c_int, [vp, pi32, C.POINTER(C.c_int64), i32, C.c_int, C.c_int, pi32, pi32]),
         "lcsgpu_assign_seeds": (C.c_int, [vp, pi32, i32, pi32, i32, C.c_int, i32, vp, vp]),
         "lcsgpu_clarans": (C.c_int, [vp, pi32, i32, C.c_int, i32, i32, C.c_float, i32, pi32]),
         "lcsgpu_sync": (C.c_int, [vp]),
@@ -242,25 +241,6 @@ class LcsGpu:
                                                          offs.ctypes.data_as(C.POINTER(C.c_int64)), len(groups),
                                                          out.ctypes.data, out.itemsize))
         return [out[base[g]:base[g + 1]].copy() for g in range(len(groups))]
-
-    def leaf_upgma_batch(self, groups, kind=1, modified=False):
-        """UPGMA sub-trees of several id lists built on the device; returns a list of (left, right) arrays with
-        local ids (leaves 0..m-1 = positions in the list, internal nodes m..2m-2)."""
-        sizes = [len(g) for g in groups]
-        offs = np.zeros(len(groups) + 1, dtype=np.int64)
-        np.cumsum(sizes, out=offs[1:])
-        ids = np.ascontiguousarray(np.concatenate([np.asarray(g, np.int32) for g in groups])
-                                   if offs[-1] else np.zeros(0, np.int32), dtype=np.int32)
-        nodes = [max(m - 1, 0) for m in sizes]
-        base = np.zeros(len(groups) + 1, dtype=np.int64)
-        np.cumsum(nodes, out=base[1:])
-        left = np.zeros(max(int(base[-1]), 1), dtype=np.int32)
-        right = np.zeros(max(int(base[-1]), 1), dtype=np.int32)
-        self._check(self._lib.lcsgpu_leaf_upgma_batch(self._ctx, ids.ctypes.data_as(C.POINTER(C.c_int32)),
-                                                      offs.ctypes.data_as(C.POINTER(C.c_int64)), len(groups), kind, int(modified),
-                                                      left.ctypes.data_as(C.POINTER(C.c_int32)),
-                                                      right.ctypes.data_as(C.POINTER(C.c_int32))))
-        return [(left[base[g]:base[g + 1]].copy(), right[base[g]:base[g + 1]].copy()) for g in range(len(groups))]
 
     def lcs_triangle_dev(self, row_begin, row_end, d_out_ptr, elem_size, sync=False):
         self._check(self._lib.lcsgpu_lcs_triangle_dev(self._ctx, row_begin, row_end, C.c_void_p(d_out_ptr),

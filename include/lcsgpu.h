@@ -342,22 +342,6 @@ int lcsgpu_multi_transport(lcsgpu_ctx* const* ctxs, int32_t n_ctx, char* buf, si
 int lcsgpu_lcs_triangles_batch(lcsgpu_ctx* ctx, const int32_t* ids, const int64_t* group_offsets, int32_t n_groups,
                                void* out, int elem_size);
 
-/* The UPGMA sub-trees of several id lists in one call (the leaf sub-trees of one FastTree split under -gt upgma /
- * upgma_modified): the lists' LCS triangles are computed as by lcsgpu_lcs_triangles_batch but stay in HBM, where one
- * workgroup per list turns its triangle into float distances (Transform<float, kind>) and runs the reference's
- * nearest-neighbour-array UPGMA over it, operation for operation (as lcsgpu_upgma); only the trees come back:
- * list g's m_g - 1 internal nodes at out_left / out_right[sum_{h<g} (m_h - 1) ...], children as LOCAL ids (leaves
- * 0..m_g-1 = positions in the list, internal nodes m_g .. 2 m_g - 2 in creation order), exactly what
- * IPartialGenerator::runPartial appends (tree/IPartialGenerator.h:13).  8 bytes per sequence leave the device instead
- * of 2 bytes per pair, and the host builds no leaf tree.
- * LCSGPU_E_UNSUPPORTED: a list with more than 2048 members, or a set with a sequence beyond 65535 residues (the
- * caller then fetches the triangles and runs its own reducer); LCSGPU_E_INVALID: a list on which the reference's
- * algorithm is undefined (no finite nearest neighbour).
- * Replaces: UPGMA<D>::runPartial (tree/UPGMA.cpp:55-70: calculateDistanceMatrix + computeTree) as FastTree::doStep
- * calls it on its sub-trees (tree/FastTree.cpp:82-103, 180-246). */
-int lcsgpu_leaf_upgma_batch(lcsgpu_ctx* ctx, const int32_t* ids, const int64_t* group_offsets, int32_t n_groups,
-                            int distance_kind, int modified, int32_t* out_left, int32_t* out_right);
-
 /* Seed assignment of one FastTree evaluation: for r = 0 .. n_seeds-1 in order,
  *   d = Transform<float>(LCS(ref = seed_ids[r], partner = col_ids[j]));  if (d < dist[j]) { dist[j] = d; assign[j] = first_k + r; }
  * dist / assign (HOST, n_cols entries each) are read and updated: the caller initialises them with the

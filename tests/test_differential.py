@@ -77,7 +77,7 @@ def test_trees_and_csv_match_reference(host, ref, oracle, tmp_path, seed, n, max
 @pytest.mark.parametrize("seed,n,max_len,alpha", CASES[:8])
 def test_slink_via_mst_matches_reference(host, ref, oracle, tmp_path, monkeypatch, seed, n, max_len, alpha):
     """The MST -> SLINK conversion used on the GPU path, on tie-heavy inputs, against the reference's SLINK."""
-    monkeypatch.setenv("FAMSA_SLINK_FROM_MST", "1")
+    monkeypatch.setenv("FAMSA_HOST_TEST", "slink_from_mst")
     rng = np.random.Generator(np.random.PCG64(1000 + seed))
     ids, seqs = random_set(rng, n, max_len, alpha, 0.25)
     fasta = str(tmp_path / "in.fasta")

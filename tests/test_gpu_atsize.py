@@ -84,15 +84,13 @@ def test_c4_single_linkage_tree(synth100k, tmp_path):
 
 
 @pytest.mark.parametrize("gt,layout", [("upgma", "square"), ("upgma_modified", "square"), ("upgma", "triangle"),
-                                       ("upgma_modified", "square+chain"), ("upgma", "square+steps")])
+                                       ("upgma_modified", "square+steps")])
 def test_c4_upgma_trees(synth100k, tmp_path, gt, layout):
     """100 000 merges on the device (one launch each) over the float distances -- the 40 GB symmetric matrix (default)
     or the 20 GB packed triangle: the per-workgroup minima are two per thread at this size (391 workgroups), which no
     smaller case reaches.  Against the sha256 of the REFERENCE's own runs (oracle/make_golden_large.py c4upgma)."""
     out = str(tmp_path / f"{gt}.dnd")
     env = {"LCSGPU_UPGMA_LAYOUT": layout.split("+")[0]}
-    if layout.endswith("chain"):  # the one-XCD merge kernel (opt-in): 100 000 merges inside one launch
-        env["LCSGPU_UPGMA_CHAIN"] = "1"
     if layout.endswith("steps"):  # one launch per merge (the default until round 4: batches of 32 merges per launch pair)
         env["LCSGPU_UPGMA_BATCH"] = "0"
     cli("-gt", gt, "-gt_export", synth100k[2], out, env=env)
@@ -151,8 +149,8 @@ def test_c4_row_block_contexts_tree_and_sampled_triangle(oracle, synth100k):
             e.close()
 
 
-@pytest.mark.parametrize("n,env", [(200000, {}), (1000000, {}), (200000, {"LCSGPU_CLARANS_CHAIN": "1"})],
-                         ids=["200000", "1000000", "200000-one-xcd-clarans"])
+@pytest.mark.parametrize("n,env", [(200000, {}), (1000000, {}), (200000, {"LCSGPU_TUNE": "clarans_stage0=5,clarans_look=6,clarans_groups=2"})],
+                         ids=["200000", "1000000", "200000-other-round-shapes"])
 def test_c5_medoid_tree(tmp_path, n, env):
     rec = META[f"family{n}"]
     path = str(tmp_path / f"family_{n}.fasta")
@@ -179,5 +177,5 @@ def test_c5_three_million(tmp_path):
     assert file_sha(a) == rec["medoid_upgma_newick_sha256"]
     if os.environ.get("FAMSA_TEST_HUGE"):
         b = str(tmp_path / "b.dnd")
-        cli("-medoidtree", "-gt", "upgma", "-t", "1", "-gt_export", path, b, env={"FAMSA_CLARANS_HOST": "1"})
+        cli("-medoidtree", "-gt", "upgma", "-t", "1", "-gt_export", path, b, env={"FAMSA_HOST_TEST": "clarans_host"})
         assert file_sha(b) == rec["medoid_upgma_newick_sha256"]

@@ -56,11 +56,12 @@ CASES = [
     ("one-medoid", "family", 40, 30, 1, 0, 0.1, 2, 1),
     ("tiny", "family", 8, 3, 2, 1, 0.1, 2, 1),
     ("single-member", "family", 8, 1, 1, 0, 0.1, 1, 1),
-    # few medoids: a candidate is closer than their medoid to a large part of the members;
-    # > 2048 non-medoids: a second pass over the positions
+    # few medoids: a candidate is closer than their medoid to a large part of the members (every slot can go negative)
     ("one-medoid-many-members", "family", 1300, 1200, 1, 0, 0.02, 2, 1),
-    ("three-medoids-two-passes", "family", 2600, 2500, 3, 1, 0.01, 2, 1),
-    ("many-samples", "family", 4400, 4300, 40, 1, 0.005, 1, 1),
+    ("three-medoids", "family", 2100, 2040, 3, 1, 0.01, 2, 1),
+    ("most-non-medoids-the-device-takes", "family", 2200, 2088, 40, 1, 0.01, 1, 1),
+    # duplicate members: distances tie exactly (d_new == dn with a smaller slot, equal second-nearest medoids)
+    ("duplicates-tie-exactly", "dups", 300, 280, 12, 1, 0.3, 2, 1),
 ]
 
 
@@ -68,7 +69,9 @@ CASES = [
 def test_device_clarans_matches_reference(engine, oracle, searcher, name, gen, n_set, n_sample, k, fixed, frac, iters,
                                           kind):
     rng = np.random.default_rng(int.from_bytes(name.encode(), "little") % (1 << 31))
-    seqs = _family(rng, n_set, 180, 0.25) if gen == "family" else _short(rng, n_set, 6, 14, 3)
+    seqs = _family(rng, n_set, 180, 0.25) if gen in ("family", "dups") else _short(rng, n_set, 6, 14, 3)
+    if gen == "dups":  # every sequence four times: members at distance 0 of each other, medoids at equal distances
+        seqs = [seqs[i // 4] for i in range(n_set)]
     engine.upload_seqs(seqs)
     ids = np.sort(rng.permutation(n_set)[:n_sample]).astype(np.int32)
     if name == "no-fixed-medoid":
@@ -79,6 +82,17 @@ def test_device_clarans_matches_reference(engine, oracle, searcher, name, gen, n
     got = engine.clarans(ids, k, fixed, frac, iters, kind)
     print(f"{name}: device search {1e3 * (time.time() - t0):.1f} ms")
     assert got.tolist() == want.tolist()
+
+
+def test_shapes_beyond_the_device_search_are_refused_not_approximated(engine):
+    """More than 2048 non-medoids (or 1024 medoids): LCSGPU_E_UNSUPPORTED -- the host layer then searches on the host
+    (famsa_amd/host/lcs_source.cpp: GpuLcsSource::clarans returns false)."""
+    import famsa_amd
+    rng = np.random.default_rng(6)
+    engine.upload_seqs(_family(rng, 2600, 60, 0.2))
+    with pytest.raises(famsa_amd.LcsGpuError) as e:
+        engine.clarans(np.arange(2500, dtype=np.int32), 3, 1, 0.01, 1)
+    assert "at most" in str(e.value)
 
 
 def test_device_clarans_rejects_bad_shapes(engine):
@@ -154,73 +168,19 @@ def test_concurrent_searches_share_the_batch(engine):
         assert together == alone
 
 
-@pytest.mark.parametrize("stage0", ["1", "5", "64"])
-def test_stage_size_does_not_change_the_search(stage0):
-    """LCSGPU_CLARANS_STAGE0 (read once per process, hence the subprocess): how many pending steps a round evaluates --
-    1: every round is one step, the reference's own loop; 5: stages 5, 10, 20, 40, 64; 64: whole windows -- only
-    decides how much is evaluated speculatively, never which step is accepted."""
+@pytest.mark.parametrize("tune", ["clarans_stage0=1", "clarans_stage0=5,clarans_look=2", "clarans_stage0=64,clarans_groups=1"])
+def test_round_shape_does_not_change_the_search(tune):
+    """LCSGPU_TUNE (read once per process, hence the subprocess): how many pending steps a round evaluates first -- 1: every
+    round is one step, the reference's own loop; 5: stages 5, 10, 20, 40, 64 with several steps per workgroup; 64: whole
+    windows -- how many rounds lie between two looks at the done flags, how many independent batches there are: only how
+    much is evaluated speculatively and when, never which step is accepted."""
     import os
     import subprocess
     import sys
-    if os.environ.get("LCSGPU_CLARANS_STAGE0") or os.environ.get("LCSGPU_CLARANS_CHAIN") or os.environ.get("LCSGPU_CLARANS_LISTS") or os.environ.get("LCSGPU_CLARANS_FUSED"):
+    if os.environ.get("LCSGPU_TUNE"):
         pytest.skip("already inside a nested run")
     env = dict(os.environ)
-    env["LCSGPU_CLARANS_STAGE0"] = stage0
+    env["LCSGPU_TUNE"] = tune
     p = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-x", "-k",
-                        "matches_reference"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-    assert p.returncode == 0 and " passed" in p.stdout, p.stdout[-3000:]
-
-
-def test_one_xcd_chain_kernel_gives_the_same_searches():
-    """LCSGPU_CLARANS_CHAIN=1 (opt-in, read once per process, hence the subprocess): the rounds of a look inside ONE
-    launch, each search's workgroups on one XCD with barriers at that XCD's L2 and L1-bypassing loads instead of
-    kernel boundaries (clarans_chain_kernel).  Every shape of this file against the reference's CLARANS again, and
-    the concurrent searches."""
-    import os
-    import subprocess
-    import sys
-    if os.environ.get("LCSGPU_CLARANS_CHAIN") or os.environ.get("LCSGPU_CLARANS_STAGE0") or os.environ.get("LCSGPU_CLARANS_LISTS") or os.environ.get("LCSGPU_CLARANS_FUSED"):
-        pytest.skip("already inside a nested run")
-    env = dict(os.environ)
-    env["LCSGPU_CLARANS_CHAIN"] = "1"
-    p = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-x", "-k",
-                        "matches_reference or concurrent"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
-                       text=True)
-    assert p.returncode == 0 and " passed" in p.stdout, p.stdout[-3000:]
-
-
-def test_per_slot_list_evaluation_gives_the_same_searches():
-    """LCSGPU_CLARANS_LISTS=1 (opt-in, round 4): every step's deltas from per-slot runs -- stable ranks by ballots, the
-    runs in LDS, lane m walking slot m's members and merging in the entries that add to every other slot by position
-    (clarans_kernels.hip, evaluate_step_lists; shapes beyond 2048 non-medoids / 256 medoids / 256 such entries take the
-    general walk inside the same kernel).  The additions every slot sees are the same in the same order: every shape of
-    this file against the reference's CLARANS again, and the concurrent searches."""
-    import os
-    import subprocess
-    import sys
-    if os.environ.get("LCSGPU_CLARANS_LISTS") or os.environ.get("LCSGPU_CLARANS_CHAIN") or os.environ.get("LCSGPU_CLARANS_STAGE0") or os.environ.get("LCSGPU_CLARANS_FUSED"):
-        pytest.skip("already inside a nested run")
-    env = dict(os.environ)
-    env["LCSGPU_CLARANS_LISTS"] = "1"
-    p = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-x", "-k",
-                        "matches_reference or concurrent"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
-                       text=True)
-    assert p.returncode == 0 and " passed" in p.stdout, p.stdout[-3000:]
-
-
-def test_two_launch_rounds_give_the_same_searches():
-    """LCSGPU_CLARANS_FUSED=0: a round as the two launches of rounds 1-3 (evaluate, apply) instead of one launch whose
-    step workgroups apply the previous accept themselves (clarans_round_kernel, the default since round 4 where all
-    positions fit one workgroup's registers) -- the form that shapes beyond 2048 non-medoids still take.  Every shape of this
-    file against the reference's CLARANS again, and the concurrent searches."""
-    import os
-    import subprocess
-    import sys
-    if any(os.environ.get(v) for v in ("LCSGPU_CLARANS_FUSED", "LCSGPU_CLARANS_LISTS", "LCSGPU_CLARANS_CHAIN", "LCSGPU_CLARANS_STAGE0")):
-        pytest.skip("already inside a nested run")
-    env = dict(os.environ)
-    env["LCSGPU_CLARANS_FUSED"] = "0"
-    p = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-x", "-k",
-                        "matches_reference or concurrent"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
-                       text=True)
+                        "matches_reference or concurrent"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert p.returncode == 0 and " passed" in p.stdout, p.stdout[-3000:]

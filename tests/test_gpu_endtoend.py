@@ -171,7 +171,7 @@ def test_trees_of_a_set_with_a_giant_sequence(host, oracle, tmp_path, gt):
     assert host.tree_gpu(fasta, gt) == host.tree_from_matrix(fasta, square, gt)
 
 
-@pytest.mark.parametrize("layout", ["square", "square+b16", "square+b8", "square+steps", "triangle", "square+chain"])
+@pytest.mark.parametrize("layout", ["square", "square+b16", "square+b8", "square+steps", "triangle"])
 @pytest.mark.parametrize("gt", ["upgma", "upgma_modified"])
 @pytest.mark.parametrize("shape", ["ties", "family", "hub"])
 def test_device_upgma_on_tie_heavy_and_larger_sets(host, oracle, tmp_path, monkeypatch, gt, shape, layout):
@@ -179,11 +179,9 @@ def test_device_upgma_on_tie_heavy_and_larger_sets(host, oracle, tmp_path, monke
     matrix: thousands of exact distance ties, several workgroups of rows, merges that touch the same workgroup twice
     in a row, a hub every other row is nearest to (one cluster that swallows a row per merge: the chained merges of a
     batch).  Both layouts of the float distances -- the full symmetric matrix (the default while 4 B x n^2 fit; merges
-    in batches of 32 / 16 / 8 per launch pair, or one launch per merge, or the one-XCD chain) and the packed triangle."""
+    in batches of 32 / 16 / 8 per launch pair, or one launch per merge) and the packed triangle."""
     import numpy as np
     monkeypatch.setenv("LCSGPU_UPGMA_LAYOUT", layout.split("+")[0])
-    if layout.endswith("chain"):  # all merges inside one kernel whose workgroups run on one XCD (opt-in, tree_kernels.hip)
-        monkeypatch.setenv("LCSGPU_UPGMA_CHAIN", "1")
     if "+b" in layout:
         monkeypatch.setenv("LCSGPU_UPGMA_BATCH", layout.split("+b")[1])
     if layout.endswith("steps"):
@@ -233,7 +231,7 @@ def test_deep_recursion_against_the_reference_library(host, tmp_path, monkeypatc
     codes, offsets = seqio.pack(seqs)
     fasta = str(tmp_path / "deep.fasta")
     seqio.to_fasta(codes, offsets, fasta)
-    monkeypatch.setenv("FAMSA_HOST_THREADS", "8")
+    monkeypatch.setenv("FAMSA_HOST_TEST", "threads=8")
     ref = oracle_bind.Ref()
     h = ref.open_fasta(fasta)
     try:
@@ -256,7 +254,7 @@ def test_single_linkage_without_the_resident_triangle(tmp_path, case, gold, gt):
     the engine for one row of the unprocessed vertices each (O(n) memory, MSTPrim::run_view's own structure,
     reference tree/MSTPrim.cpp:356-533), -gt slink by the row-blocked SLINK loop.  Forced here on small inputs."""
     out = str(tmp_path / "t.dnd")
-    env = dict(os.environ, FAMSA_NO_DEVICE_MST="1", FAMSA_PRIM_STREAMING="1")
+    env = dict(os.environ, FAMSA_HOST_TEST="no_device_mst,prim_streaming")
     p = subprocess.run([host_bind.CLI, "-gt", gt, "-gt_export", os.path.join(G, case), out], stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE, text=True, env=env)
     assert p.returncode == 0, p.stderr

@@ -72,13 +72,13 @@ def test_group_calls_equal_single_context(engine, name, devices):
         grp.close()
 
 
-@pytest.mark.parametrize("switch", ["LCSGPU_FORCE_PEER_COPY", "LCSGPU_FORCE_HOST_STAGING"])
+@pytest.mark.parametrize("switch", ["peer", "host"])
 def test_group_calls_over_the_other_transports(engine, monkeypatch, switch):
     """Contexts on ONE device copy with hipMemcpyAsync; these switches make the same calls take the branches two
     devices take: hipMemcpyPeerAsync (with peer access: xGMI) resp. the pinned-host staging used when two devices
     cannot address each other -- the row-block gather of lcsgpu_multi_upgma and the per-round key pushes of
     lcsgpu_multi_mst_prim."""
-    monkeypatch.setenv(switch, "1")
+    monkeypatch.setenv("LCSGPU_TRANSPORT", switch)
     seqs = _sets()["family"]
     engine.upload_seqs(seqs)
     grp = famsa_amd.LcsGpuGroup([0, 0, 0])
@@ -141,9 +141,9 @@ def test_exchange_choice_cross_check_and_transport_report(engine, monkeypatch, c
         assert "peer copies (automatic: contexts share a device" in text, text
         ms = grp.last_kernel_ms()
         assert len(ms) == 3 and all(m > 0 for m in ms), ms
-        monkeypatch.setenv("LCSGPU_FORCE_HOST_STAGING", "1")
+        monkeypatch.setenv("LCSGPU_TRANSPORT", "host")
         assert "host-staging(forced) x6" in grp.transport() and "not by peer copy: 0->1" in grp.transport()
-        monkeypatch.delenv("LCSGPU_FORCE_HOST_STAGING")
+        monkeypatch.delenv("LCSGPU_TRANSPORT")
         monkeypatch.setenv("LCSGPU_EXCHANGE", "peer")
         grp.mst_prim(1)
         assert "peer copies (LCSGPU_EXCHANGE=peer)" in grp.transport()
@@ -164,15 +164,13 @@ def test_exchange_choice_cross_check_and_transport_report(engine, monkeypatch, c
 
 def test_row_blocks_come_back_over_all_links_at_once(engine, monkeypatch):
     """lcsgpu_multi_lcs_triangle drains every context's block on its own host thread (one PCIe link per GPU, all at the
-    same time); LCSGPU_SERIAL_DRAIN=1 is the one-after-the-other order of earlier rounds.  Same bytes either way."""
+    same time): the same bytes as one context's triangle."""
     seqs = _sets()["family"]
     engine.upload_seqs(seqs)
     want = engine.lcs_triangle()
     grp = famsa_amd.LcsGpuGroup([0, 0, 0, 0])
     try:
         grp.upload_seqs(seqs)
-        assert (grp.lcs_triangle() == want).all()
-        monkeypatch.setenv("LCSGPU_SERIAL_DRAIN", "1")
         assert (grp.lcs_triangle() == want).all()
     finally:
         grp.close()

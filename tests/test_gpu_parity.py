@@ -457,44 +457,13 @@ def test_boruvka_mst_equals_the_prim_kernel(engine, monkeypatch, shape):
     engine.upload_seqs(seqs)
     assert engine.orientation_flags().sum() == 0
     for kind in (0, 1, 1 | 0x100):
-        monkeypatch.delenv("LCSGPU_MST_PRIM", raising=False)
+        monkeypatch.delenv("LCSGPU_MST_MODE", raising=False)
         fast = engine.mst_prim(kind)
-        monkeypatch.setenv("LCSGPU_MST_PRIM", "1")
+        monkeypatch.setenv("LCSGPU_MST_MODE", "prim")
         slow = engine.mst_prim(kind)
-        monkeypatch.delenv("LCSGPU_MST_PRIM", raising=False)
+        monkeypatch.delenv("LCSGPU_MST_MODE", raising=False)
         assert (fast["from"] == slow["from"]).all() and (fast["to"] == slow["to"]).all()
         assert (fast["dist"].view(np.uint64) == slow["dist"].view(np.uint64)).all()
-
-
-def test_launches_spread_over_side_streams(tmp_path):
-    """LCSGPU_SPREAD=1 (read once per process, hence the subprocess): the launches of a call's half-word classes go to
-    side streams of the lane, forked from and joined into its stream by events -- same triangle, same rectangles."""
-    import subprocess
-    import sys
-    code = r'''
-import sys, numpy as np
-sys.path.insert(0, %r); sys.path.insert(0, %r)
-import famsa_amd, oracle_bind
-from famsa_amd import seqio
-o = oracle_bind.Oracle()
-rng = np.random.Generator(np.random.PCG64(3))
-seqs = [rng.integers(0, 21, size=int(l)).astype(np.uint8) for l in rng.integers(1, 900, size=400)]
-seqs += [np.zeros(192, np.uint8), np.zeros(0, np.uint8)]
-codes, offsets = seqio.pack(seqs)
-eng = famsa_amd.LcsGpu(0)
-eng.upload_seqs(seqs)
-want = o.triangle(codes, offsets)
-for _ in range(3):
-    assert (eng.lcs_triangle(dtype=np.uint32) == want).all()
-n = len(seqs)
-sq = eng.lcs_rect((0, n), (0, n))
-assert (sq == o.rect(codes, offsets, np.arange(n), np.arange(n))).all()
-print("SPREAD_OK")
-''' % (ROOT, os.path.join(ROOT, "tests"))
-    env = dict(os.environ)
-    env["LCSGPU_SPREAD"] = "1"
-    p = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
-    assert p.returncode == 0 and "SPREAD_OK" in p.stdout, p.stderr[-2000:]
 
 
 @pytest.mark.parametrize("batch", ["32", "0"])

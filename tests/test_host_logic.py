@@ -88,7 +88,7 @@ def test_prim_with_one_row_per_step(host, oracle, monkeypatch, name, gold):
     """-gt sl when the triangle is not held anywhere: every Prim step asks the source for the row of the node just
     added against the unprocessed vertices (MSTPrim::run_view's own shape, reference tree/MSTPrim.cpp:356-533) --
     O(n) memory; the orientation-sensitive set shows that ref = the node just added is honoured."""
-    monkeypatch.setenv("FAMSA_PRIM_STREAMING", "1")
+    monkeypatch.setenv("FAMSA_HOST_TEST", "prim_streaming")
     f = os.path.join(G, name)
     m = square(oracle, f, symmetric_ok=(name != "adversarial_tree.fasta"))
     assert host.tree_from_matrix(f, m, "sl") == open(os.path.join(G, gold), "rb").read()
@@ -175,7 +175,7 @@ def test_parttree_vs_reference_library(host, oracle):
 
 def test_medoid_subtrees_built_by_worker_threads(host, oracle, monkeypatch):
     """The top-level sub-trees run on worker threads (as in the reference); the result must not change."""
-    monkeypatch.setenv("FAMSA_HOST_THREADS", "6")
+    monkeypatch.setenv("FAMSA_HOST_TEST", "threads=6")
     f = os.path.join(G, "hemopexin", "hemopexin")
     got = host.tree_from_matrix(f, square(oracle, f), "upgma", heuristic="medoidtree", subtree_size=10,
                                 sample_size=100, threshold=100, cluster_fraction=0.2, cluster_iters=1)
@@ -186,7 +186,7 @@ def test_slink_equals_canonical_pointer_representation_of_the_mst(host, oracle, 
     """On the GPU `-gt slink` = device Prim (triangle-orientation distances) + an O(n log n) conversion:
     SLINK's output is the canonical pointer representation of the single-linkage hierarchy under the
     strict (distance, packed ids) order.  Here the same conversion runs with Prim on the host."""
-    monkeypatch.setenv("FAMSA_SLINK_FROM_MST", "1")
+    monkeypatch.setenv("FAMSA_HOST_TEST", "slink_from_mst")
     for name in ("adeno_fiber/adeno_fiber", "adversarial_tree.fasta", "hemopexin/hemopexin"):
         f = os.path.join(G, name)
         gold = {"adeno_fiber/adeno_fiber": "adeno_fiber/slink.dnd", "adversarial_tree.fasta": "adversarial_tree_slink.dnd",
@@ -312,9 +312,9 @@ def test_the_two_host_upgma_forms_build_the_same_tree(host, tmp_path, monkeypatc
     m[np.arange(n), np.arange(n)] = lens
     for gt in ("upgma", "upgma_modified"):
         for dist in ("indel075_div_lcs", "indel_div_lcs"):
-            monkeypatch.delenv("FAMSA_UPGMA_TRIANGLE", raising=False)
+            monkeypatch.delenv("FAMSA_HOST_TEST", raising=False)
             square_form = host.tree_from_matrix(fasta, m, gt, distance=dist, keep_duplicates=True)
-            monkeypatch.setenv("FAMSA_UPGMA_TRIANGLE", "1")
+            monkeypatch.setenv("FAMSA_HOST_TEST", "upgma_triangle")
             triangle_form = host.tree_from_matrix(fasta, m, gt, distance=dist, keep_duplicates=True)
             assert square_form == triangle_form, (gt, dist)
             assert square_form.count(b",") == n - 1
