@@ -76,7 +76,10 @@ int quirk_h_class(uint32_t len);
 int refs_per_block(int h, bool quirk, bool fused = false);
 // ... reduced for launches that would otherwise have too few workgroups to fill the chip
 int refs_per_block_for(int h, bool quirk, long n_refs, long col_blocks, bool fused = false);
-hipError_t launch_rows(int h, bool quirk, const RowsArgs& a, int grid_x, int grid_y, hipStream_t stream);
+// lds_min: the dynamic LDS a workgroup claims at least -- a launch that shares the chip with chains of small dependent
+// kernels (the CLARANS rounds of the FastTree recursion) claims more than it needs so that fewer of its workgroups fit a
+// CU and every CU keeps room for one of theirs (lcsgpu_fasttree.hip, LCS_SHARE_LDS)
+hipError_t launch_rows(int h, bool quirk, const RowsArgs& a, int grid_x, int grid_y, hipStream_t stream, size_t lds_min = 0);
 // refs longer than 2048 residues: needs grid_x*grid_y*n_chunks_max*512 bytes of carry scratch
 size_t long_carry_bytes(int grid_x, int grid_y, int n_chunks_max);
 hipError_t launch_long(bool quirk, const RowsArgs& a, int grid_x, int grid_y, void* carry, int n_chunks_max,
@@ -189,13 +192,12 @@ struct UpgmaArgs {
     int32_t n;
     int32_t n_blocks;
 };
-// distances + initial row minima; then the n launches of the merge steps
-hipError_t launch_upgma_prologue(const UpgmaArgs& a, const void* lcs, int elem_size, const uint32_t* lens, const float* pow_f32,
-                                 int kind, hipStream_t stream);
+// float distances of the rows [r0, r1) from their LCS values (lcs = the packed triangle from row r0 on; square layout: r0
+// a multiple of 32), block after block; then the initial row minima; then the n launches of the merge steps
+hipError_t launch_upgma_distances(const UpgmaArgs& a, const void* lcs, int elem_size, const uint32_t* lens, const float* pow_f32,
+                                  int kind, int r0, int r1, hipStream_t stream);
+hipError_t launch_upgma_init(const UpgmaArgs& a, hipStream_t stream);
 hipError_t launch_upgma_steps(const UpgmaArgs& a, bool modified, hipStream_t stream);
-hipError_t launch_upgma(const UpgmaArgs& a, const void* lcs, int elem_size, const uint32_t* lens,
-                        const float* pow_f32, int kind, bool modified, hipStream_t stream);
-
 
 // ---- several merges per launch (upgma_batch_kernels.hip; symmetric-matrix layout only) ----
 constexpr int UPGMA_BATCH_MAX = 32;  // merges per batch at most (template instances: 8, 16, 32)
@@ -216,7 +218,8 @@ struct UpgmaBatchArgs {
     uint2* sorted1;       //         ... and the other way round
     uint32_t* pos;        // [n] where a row's entry sits in the current order
     uint4* cand;          // [UPGMA_BATCH_CAND] the first entries of the current order with their rows' nearest
-    uint32_t* state;      // [2][8]: merges committed, entries of the order, error, batches cut short -- by batch parity
+    uint32_t* state;      // [2][8]: merges committed, entries of the order, error, batches cut short, the next free slot -- by batch parity
+    uint32_t* remap;      // [ld] compaction: where a live slot moves to (upgma_compact_*_kernel)
     uint32_t* hdr;        // [512] the pending batch: count, then per merge (L, R, key bits, creator of R, positions, slots)
     uint32_t* rec;        // [8 + 4 K + K^2] what the resolve kernel found: V, per merge (new min_dist, nearest, die), cross entries
     float* side;          // [UPGMA_BATCH_MAX][ld] the rows the pending batch creates, along the slots
@@ -224,7 +227,11 @@ struct UpgmaBatchArgs {
     uint32_t* part_j;
 };
 hipError_t launch_upgma_batch_init(const UpgmaBatchArgs& a, hipStream_t stream);
-hipError_t launch_upgma_batches(const UpgmaBatchArgs& a, bool modified, int k, int first, int count, hipStream_t stream);
+// `count` batches, the first of them batch number `first`; slots_used = an upper bound of the next free slot before them
+hipError_t launch_upgma_batches(const UpgmaBatchArgs& a, bool modified, int k, int first, int count, long long slots_used, hipStream_t stream);
+// Compaction between two batches (the next one has parity `parity`): the live slots move to the front in order, the
+// matrix rows are packed in place; slots_used as above.  The next free slot afterwards = the number of live clusters.
+hipError_t launch_upgma_compact(const UpgmaBatchArgs& a, int parity, long long slots_used, hipStream_t stream);
 
 // ---- device-side neighbour joining (tree_kernels.hip) ----
 struct NjArgs {

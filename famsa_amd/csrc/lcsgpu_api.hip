@@ -22,6 +22,12 @@ int tune_int(const char* key, int dflt)
     return dflt;
 }
 
+size_t lcs_share_lds()
+{
+    static const size_t v = (size_t)std::max(0, std::min(64 * 1024, tune_int("lcs_share_lds", 41472)));
+    return v;
+}
+
 int fail(int code, const char* fmt, ...)
 {
     char buf[512];
@@ -47,19 +53,71 @@ struct Bucket {
     std::vector<RefItem> items;
 };
 
-// Split the refs by instantiated kernel (word-count class, quirk flag), keeping order.
+// Which instantiation the refs of every half-word class run in.  A call's classes are launches one after the other on
+// one stream, and a launch that cannot fill the chip lasts as long as one of its workgroups however few it has: the
+// sample triangle of a FastTree split (2000 family members, four classes of ~500 refs, ~500 workgroups each) took four
+// times ~160 us (profiles/clarans_rounds_r04.txt: 4373 such launches, 1.22 s of kernel time for work that fills the chip
+// for 0.3 s).  So neighbouring classes are run together in the larger one's kernel -- a ref's half-words beyond its own
+// are all-ones no-ops (h_class) -- as long as the group stays below the workgroup count a launch is planned for
+// (refs_per_block_for: 2048).  wgs[h] = workgroups class h would have with the fewest refs per workgroup; classes that
+// fill the chip on their own (every large triangle) are left alone, as are the orientation-sensitive and long refs.
+void merge_small_classes(const double* wgs, int* target)
+{
+    const double want = 2048.0;
+    for (int h = 0; h <= 64; ++h) target[h] = h;
+    int first = -1; // first class of the open group
+    double sum = 0;
+    auto close = [&](int last) {
+        if (first > 0)
+            for (int h = first; h <= last; ++h)
+                if (wgs[h] > 0) target[h] = last;
+        first = -1;
+        sum = 0;
+    };
+    int last_used = -1;
+    for (int h = 1; h <= 64; ++h) {
+        if (wgs[h] <= 0) continue;
+        if (first > 0 && sum + wgs[h] > want) close(last_used);
+        if (wgs[h] >= want) { // fills the chip by itself
+            close(last_used);
+            last_used = h;
+            continue;
+        }
+        if (first < 0) first = h;
+        sum += wgs[h];
+        last_used = h;
+    }
+    close(last_used);
+}
+
+// Split the refs by instantiated kernel (word-count class, quirk flag), keeping order.  col_blocks > 0: the
+// column blocks a ref meets, for merge_small_classes; 0 = every class its own launch.
 int make_buckets(lcsgpu_ctx* ctx, const int32_t* ref_ids, int32_t ref_begin, int32_t n_refs,
-                 int64_t row0, std::vector<Bucket>& out)
+                 int64_t row0, std::vector<Bucket>& out, long col_blocks = 0)
 {
     int index_of[160];
     std::fill(index_of, index_of + 160, -1);
+    int target[65];
+    for (int h = 0; h <= 64; ++h) target[h] = h;
+    if (col_blocks > 0) {
+        double wgs[65] = {0};
+        for (int32_t k = 0; k < n_refs; ++k) {
+            const int32_t id = ref_ids ? ref_ids[k] : ref_begin + k;
+            if (id < 0 || id >= ctx->n)
+                return fail(LCSGPU_E_INVALID, "ref id %d out of range [0,%d)", id, ctx->n);
+            if (ctx->quirk[id]) continue;
+            const int h = lcsgpu::h_class(ctx->lens[id]);
+            if (h > 0) wgs[h] += (double)col_blocks / lcsgpu::refs_per_block_for(h, false, 1, 1);
+        }
+        merge_small_classes(wgs, target);
+    }
     for (int32_t k = 0; k < n_refs; ++k) {
         const int32_t id = ref_ids ? ref_ids[k] : ref_begin + k;
         if (id < 0 || id >= ctx->n)
             return fail(LCSGPU_E_INVALID, "ref id %d out of range [0,%d)", id, ctx->n);
         const bool q = ctx->quirk[id] != 0;
         // bv = instantiated half-word count; 0 = the long-sequence kernel (> 2048 residues)
-        const int bv = q ? lcsgpu::quirk_h_class(ctx->lens[id]) : lcsgpu::h_class(ctx->lens[id]);
+        const int bv = q ? lcsgpu::quirk_h_class(ctx->lens[id]) : target[lcsgpu::h_class(ctx->lens[id])];
         const int key = bv * 2 + (q ? 1 : 0);
         if (index_of[key] < 0) {
             index_of[key] = (int)out.size();
@@ -140,7 +198,7 @@ int reserve_big(lcsgpu_ctx* ctx, DevBuf& buf, size_t bytes, const char* what)
 // Core: plan + launch.  d_out is a device pointer.
 int run_rows(lcsgpu_ctx* ctx, Lane& L, int mode, const int32_t* ref_ids, int32_t ref_begin, int32_t n_refs,
              const int32_t* col_ids, int32_t col_begin, int32_t n_cols, void* d_out, int64_t ld,
-             int64_t out_offset, int elem_size, int64_t first_row, const lcsgpu::FuseArgs* fuse)
+             int64_t out_offset, int elem_size, int64_t first_row, const lcsgpu::FuseArgs* fuse, size_t lds_min)
 {
     if (ctx->n < 0) return fail(LCSGPU_E_STATE, "no sequence set uploaded");
     if (elem_size != 2 && elem_size != 4) return fail(LCSGPU_E_INVALID, "elem_size must be 2 or 4");
@@ -164,7 +222,9 @@ int run_rows(lcsgpu_ctx* ctx, Lane& L, int mode, const int32_t* ref_ids, int32_t
                 return fail(LCSGPU_E_INVALID, "col id %d out of range", col_ids[c]);
 
     std::vector<Bucket> buckets;
-    int rc = make_buckets(ctx, ref_ids, ref_begin, n_refs, first_row, buckets);
+    // (triangle: about half of the column blocks of a ref tile lie below the diagonal; a fused launch keeps its classes)
+    const long call_col_blocks = std::max<long>(1, ((long)n_cols + 255) / 256 / (mode == lcsgpu::MODE_TRIANGLE ? 2 : 1));
+    int rc = make_buckets(ctx, ref_ids, ref_begin, n_refs, first_row, buckets, fuse ? 0 : call_col_blocks);
     if (rc) return rc;
 
     // staging: [col_ids][per non-contiguous bucket: rows(int64) then ids(int32)]
@@ -177,8 +237,7 @@ int run_rows(lcsgpu_ctx* ctx, Lane& L, int mode, const int32_t* ref_ids, int32_t
     std::vector<std::vector<int32_t>> tri_prefix(buckets.size());
     std::vector<int> refs_per_wg(buckets.size(), 0);
     for (size_t b = 0; b < buckets.size(); ++b) {
-        // triangle: about half of the column blocks of a ref tile lie below the diagonal
-        const long col_blocks = std::max<long>(1, ((long)n_cols + 255) / 256 / (mode == lcsgpu::MODE_TRIANGLE ? 2 : 1));
+        const long col_blocks = call_col_blocks;
         refs_per_wg[b] = lcsgpu::refs_per_block_for(buckets[b].bv, buckets[b].quirk, (long)buckets[b].items.size(), col_blocks, fuse != nullptr);
         is_contig[b] = contiguous(buckets[b]);
         if (is_contig[b] && mode == lcsgpu::MODE_TRIANGLE && buckets[b].bv != 0) {
@@ -280,12 +339,12 @@ int run_rows(lcsgpu_ctx* ctx, Lane& L, int mode, const int32_t* ref_ids, int32_t
             a.tri_rows = (int32_t)tri_prefix[b].size() - 1;
             const int total = tri_prefix[b].back();
             if (total > 0) {
-                HIP_TRY(lcsgpu::launch_rows(bk.bv, bk.quirk, a, total, 1, st));
+                HIP_TRY(lcsgpu::launch_rows(bk.bv, bk.quirk, a, total, 1, st, lds_min));
                 ++L.last_launches;
             }
         } else if (bk.bv != 0) {
             if (gy > 65535) return fail(LCSGPU_E_INVALID, "too many ref tiles in one call (%d)", gy);
-            HIP_TRY(lcsgpu::launch_rows(bk.bv, bk.quirk, a, gx, gy, st));
+            HIP_TRY(lcsgpu::launch_rows(bk.bv, bk.quirk, a, gx, gy, st, lds_min));
             ++L.last_launches;
         } else {
             // long refs: slices of ref blocks so the carry scratch stays bounded

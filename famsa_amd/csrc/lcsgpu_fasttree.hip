@@ -190,7 +190,7 @@ static int batch_triangles_to_device(lcsgpu_ctx* ctx, Lane& L, const int32_t* id
             if (m < 2) continue;
             const int32_t* gi = ids + group_offsets[g];
             int rc = run_rows(ctx, L, lcsgpu::MODE_TRIANGLE, gi, 0, m, gi, 0, m - 1,
-                              (char*)L.d_out.p + (size_t)tri_base[g] * elem_size, 0, 0, elem_size, 0);
+                              (char*)L.d_out.p + (size_t)tri_base[g] * elem_size, 0, 0, elem_size, 0, nullptr, lcs_share_lds());
             if (rc) return rc;
             HIP_TRY(hipStreamSynchronize(L.stream));
             finish_host_call(ctx, L);
@@ -215,12 +215,24 @@ static int batch_triangles_to_device(lcsgpu_ctx* ctx, Lane& L, const int32_t* id
     std::vector<BatchBucket> buckets;
     int index_of[160];
     std::fill(index_of, index_of + 160, -1);
+    int target[65];
+    {   // small neighbouring half-word classes share a launch (merge_small_classes, lcsgpu_api.hip)
+        double wgs[65] = {0};
+        for (int32_t g = 0; g < n_groups; ++g)
+            for (int64_t p = group_offsets[g] + 1; p < group_offsets[g + 1]; ++p) {
+                const int32_t id = ids[p];
+                if (ctx->quirk[id]) continue;
+                const int h = lcsgpu::h_class(ctx->lens[id]);
+                wgs[h] += (double)((p - group_offsets[g] + 255) / 256) / lcsgpu::refs_per_block_for(h, false, 1, 1);
+            }
+        merge_small_classes(wgs, target);
+    }
     for (int32_t g = 0; g < n_groups; ++g)
         for (int64_t p = group_offsets[g]; p < group_offsets[g + 1]; ++p) {
             if (p == group_offsets[g]) continue; // the first member of a list has no partner
             const int32_t id = ids[p];
             const bool q = ctx->quirk[id] != 0;
-            const int bv = q ? lcsgpu::quirk_h_class(ctx->lens[id]) : lcsgpu::h_class(ctx->lens[id]);
+            const int bv = q ? lcsgpu::quirk_h_class(ctx->lens[id]) : target[lcsgpu::h_class(ctx->lens[id])];
             const int key = bv * 2 + (q ? 1 : 0);
             if (index_of[key] < 0) {
                 index_of[key] = (int)buckets.size();
@@ -301,7 +313,7 @@ static int batch_triangles_to_device(lcsgpu_ctx* ctx, Lane& L, const int32_t* id
         a.elem_size = elem_size;
         a.mode = lcsgpu::MODE_TRIANGLE;
         a.refs_per_block = b.refs_per_wg;
-        HIP_TRY(lcsgpu::launch_rows(b.bv, b.quirk, a, (int)b.jobs.size(), 1, L.stream));
+        HIP_TRY(lcsgpu::launch_rows(b.bv, b.quirk, a, (int)b.jobs.size(), 1, L.stream, lcs_share_lds()));
         ++L.last_launches;
     }
     HIP_TRY(hipEventRecord(L.ev_stop, L.stream));
@@ -366,7 +378,7 @@ int lcsgpu_assign_seeds(lcsgpu_ctx* ctx, const int32_t* seed_ids, int32_t n_seed
         HIP_TRY(hipMemcpyAsync(base + o_cols, col_ids + c0, (size_t)cn * 4, hipMemcpyHostToDevice, L.stream));
         HIP_TRY(hipMemcpyAsync(base + o_dist, dist + c0, (size_t)cn * 4, hipMemcpyHostToDevice, L.stream));
         HIP_TRY(hipMemcpyAsync(base + o_assign, assign + c0, (size_t)cn * 4, hipMemcpyHostToDevice, L.stream));
-        int rc = run_rows(ctx, L, lcsgpu::MODE_RECT, seed_ids, 0, n_seeds, col_ids + c0, 0, cn, L.d_out.p, cn, 0, elem);
+        int rc = run_rows(ctx, L, lcsgpu::MODE_RECT, seed_ids, 0, n_seeds, col_ids + c0, 0, cn, L.d_out.p, cn, 0, elem, 0, nullptr, lcs_share_lds());
         if (rc) return rc;
         HIP_TRY(lcsgpu::launch_assign_seeds(L.d_out.p, elem, cn, (const int32_t*)(base + o_seeds), n_seeds,
                                             (const int32_t*)(base + o_cols), cn, (const uint32_t*)ctx->d_lens.p,
@@ -445,7 +457,7 @@ int lcsgpu_clarans(lcsgpu_ctx* ctx, const int32_t* ids, int32_t n_ids, int dista
     HIP_TRY(hipMemcpyAsync(base + o_ids, ids, (size_t)n * 4, hipMemcpyHostToDevice, L.stream));
     if (pairs > 0) {
         HIP_TRY(L.d_out.reserve(pairs * elem));
-        int rc = run_rows(ctx, L, lcsgpu::MODE_TRIANGLE, ids, 0, n, ids, 0, n - 1, L.d_out.p, 0, 0, elem, 0);
+        int rc = run_rows(ctx, L, lcsgpu::MODE_TRIANGLE, ids, 0, n, ids, 0, n - 1, L.d_out.p, 0, 0, elem, 0, nullptr, lcs_share_lds());
         if (rc) return rc;
         HIP_TRY(lcsgpu::launch_subset_distances(L.d_out.p, elem, (const int32_t*)(base + o_ids),
                                                 (const uint32_t*)ctx->d_lens.p, (const float*)ctx->d_powf.p,

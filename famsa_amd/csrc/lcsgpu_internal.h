@@ -285,7 +285,18 @@ int order_edges_like_prim(lcsgpu_mst_edge* edges, int32_t n);
 // per-vertex best-edge records (lcs_kernels.h, FuseArgs); d_out may then be NULL (nothing is stored).
 int run_rows(lcsgpu_ctx* ctx, Lane& L, int mode, const int32_t* ref_ids, int32_t ref_begin, int32_t n_refs,
              const int32_t* col_ids, int32_t col_begin, int32_t n_cols, void* d_out, int64_t ld,
-             int64_t out_offset, int elem_size, int64_t first_row = 0, const lcsgpu::FuseArgs* fuse = nullptr);
+             int64_t out_offset, int elem_size, int64_t first_row = 0, const lcsgpu::FuseArgs* fuse = nullptr, size_t lds_min = 0);
+// The LDS an LCS launch of the FastTree recursion claims per workgroup at least (launch_rows, lds_min): 40.5 KB -> three
+// of its workgroups per CU instead of five, so that every CU keeps 12 wave slots, 230 VGPRs per lane and 38 KB of LDS
+// free -- room for one workgroup of a CLARANS round (8 waves, 80 VGPRs, 37 KB).  Without it a chip-filling launch
+// (seed assignment of a large split, a batch of leaf matrices: workgroups of 100-300 us, launches of up to 10 ms) leaves
+// the rounds' workgroups waiting for TWO of its workgroups on one CU to retire together: the rounds' p50 was their
+// time alone (39 us) but their mean 63 us (profiles/c5_rounds_r05.txt).  Costs those launches ~8 % of their rate
+// (3 instead of 5 waves per SIMD: 543 vs 592 Tcell/s).  LCSGPU_TUNE lcs_share_lds=<bytes> (0 = off).
+size_t lcs_share_lds();
+// which instantiation the refs of half-word class h run in (target[h] >= h), given wgs[h] = the workgroups class h would
+// have on its own, h = 1 .. 64: small neighbouring classes share a launch (lcsgpu_api.hip)
+void merge_small_classes(const double* wgs, int* target);
 // After a host-memory call has been synchronised: account its kernel time.
 void finish_host_call(lcsgpu_ctx* ctx, Lane& L);
 // A *_dev call was queued on lane 0: its timing is read on demand.

@@ -881,42 +881,69 @@ int whole_triangle(lcsgpu_ctx* const* ctxs, int32_t n_ctx, MultiGuard& g, int el
     return LCSGPU_OK;
 }
 
-int upgma_reduce(lcsgpu_ctx* ctx, Lane& L, int elem, int distance_kind, int modified, int32_t* out_left, int32_t* out_right)
+// resident: the whole LCS triangle sits in L.d_out already (the multi-context gather); else this function computes it
+// itself, in row blocks that are turned into float distances one after the other -- 2 B per pair never exist all at once.
+int upgma_reduce(lcsgpu_ctx* ctx, Lane& L, int elem, int distance_kind, int modified, int32_t* out_left, int32_t* out_right, bool resident)
 {
     const int32_t n = ctx->n;
     HIP_TRY(hipSetDevice(ctx->device));
-    // The distances as a full symmetric matrix when 4 B x n^2 fit (n <= ~190 000 next to the LCS triangle on 288 GB):
-    // both rows a merge reads are then contiguous (tree_kernels.hip).  Else the packed triangle.  LCSGPU_UPGMA_LAYOUT=
-    // triangle|square forces one (tests, measurements).
-    bool square = (size_t)n * n * sizeof(float) <= ((size_t)200 << 30);
+    // The distances as a full symmetric matrix where that fits: both rows a merge reads are then contiguous
+    // (tree_kernels.hip).  Else the packed triangle.  LCSGPU_UPGMA_LAYOUT=triangle|square forces one (tests, measurements).
+    bool square = true;
     if (const char* e = getenv("LCSGPU_UPGMA_LAYOUT")) square = !strcmp(e, "square");
-    // Several merges per launch (upgma_batch_kernels.hip) -- the default while its layout fits: n rows x 2n SLOTS (a new
-    // cluster keeps its left child's row but gets a new column, so that a batch's columns are consecutive: 80 GB at 100 000
-    // sequences, up to ~158 000 on 288 GB).  A batch = the next <= K entries of the rows' sorted (min_dist, index) order,
-    // computed together and committed as far as the reference would have picked them in that order (practically always all
-    // K).  LCSGPU_UPGMA_BATCH=0 keeps one launch per merge on the n x n matrix; = 8 | 16 | 32 selects K (32).
+    // Several merges per launch (upgma_batch_kernels.hip) -- the default while its layout fits: n rows x (n + spare) SLOTS (a
+    // new cluster keeps its left child's row but gets a new column, so that a batch's columns are consecutive; when the spare
+    // is used up the live slots are compacted: 44 GB at 100 000 sequences, ~255 000 sequences on 288 GB).  A batch = the
+    // next <= K entries of the rows' sorted (min_dist, index) order, computed together and committed as far as the reference
+    // would have picked them in that order (practically always all K).  LCSGPU_UPGMA_BATCH=0 keeps one launch per merge on
+    // the n x n matrix; = 8 | 16 | 32 selects K (32).  LCSGPU_TUNE upgma_spare=<slots>: the spare (tests: a small one
+    // compacts every few batches).
     int batch_k = 32;
     if (const char* e = getenv("LCSGPU_UPGMA_BATCH")) batch_k = atoi(e);
     batch_k = batch_k >= 32 ? 32 : batch_k >= 16 ? 16 : batch_k >= 8 ? 8 : 0;
     if (n < 3) batch_k = 0;
+    // the LCS values of a row block (not resident): at most 2^30 pairs at a time
+    const int64_t block_pairs = std::min<int64_t>(tri_offset(n), (int64_t)1 << 30);
+    const size_t block_bytes = resident ? 0 : (size_t)block_pairs * elem;
+    size_t avail = 0;
+    {
+        int rc0 = device_free_bytes(ctx, &avail);
+        if (rc0) return rc0;
+        avail += ctx->d_dist.cap + (resident ? 0 : L.d_out.cap); // what these two buffers hold already is theirs to use
+        avail -= std::min(avail, block_bytes + ((size_t)64 << 20)); // the block's values and the small arrays come first
+    }
     size_t ld = (size_t)n;
     int rc = LCSGPU_E_NOMEM;
     if (square && batch_k) {
-        ld = ((size_t)2 * n + 63) & ~(size_t)63;
-        if ((size_t)n * ld * sizeof(float) <= ((size_t)230 << 30))
-            rc = reserve_big(ctx, ctx->d_dist, (size_t)n * ld * sizeof(float), "the float distance matrix (rows x slots)");
+        const int forced = tune_int("upgma_spare", 0);
+        for (size_t div : {10, 20, 40}) {
+            size_t spare = forced > 0 ? (size_t)forced : std::max<size_t>(2048, (size_t)n / div);
+            spare = std::max<size_t>(spare, (size_t)2 * batch_k);
+            ld = ((size_t)n + spare + 63) & ~(size_t)63;
+            if ((size_t)n * ld * sizeof(float) <= avail) {
+                rc = reserve_big(ctx, ctx->d_dist, (size_t)n * ld * sizeof(float), "the float distance matrix (rows x slots)");
+                if (rc != LCSGPU_E_NOMEM) break;
+            }
+            if (forced > 0) break;
+        }
         if (rc == LCSGPU_E_NOMEM) {
             batch_k = 0;
             ld = (size_t)n;
         }
     }
-    if (square && !batch_k) rc = reserve_big(ctx, ctx->d_dist, (size_t)n * n * sizeof(float), "the float distance matrix");
+    if (square && !batch_k && (size_t)n * n * sizeof(float) <= avail)
+        rc = reserve_big(ctx, ctx->d_dist, (size_t)n * n * sizeof(float), "the float distance matrix");
     if (rc == LCSGPU_E_NOMEM) {
         batch_k = 0;
         square = false;
+        ld = (size_t)n;
         rc = reserve_big(ctx, ctx->d_dist, (size_t)tri_offset(n) * sizeof(float), "the float distance triangle");
     }
     if (rc) return rc;
+    if (!resident) {
+        rc = reserve_big(ctx, L.d_out, block_bytes, "a row block of the LCS triangle");
+        if (rc) return rc;
+    }
     const int blocks = (n + 255) / 256;
     auto a16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
     const size_t o_min = 0, o_near = o_min + a16((size_t)n * 4), o_node = o_near + a16((size_t)n * 4),
@@ -948,22 +975,59 @@ int upgma_reduce(lcsgpu_ctx* ctx, Lane& L, int elem, int distance_kind, int modi
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double t_pro = 0, t_merge = 0;
     if (profile) { HIP_TRY(hipStreamSynchronize(L.stream)); t_pro = now(); }
-    HIP_TRY(lcsgpu::launch_upgma_prologue(a, L.d_out.p, elem, (const uint32_t*)ctx->d_lens.p, (const float*)ctx->d_powf.p,
-                                          distance_kind, L.stream));
+    // the LCS values -> float distances, row block by row block (whole tile rows of 32 in the square layout)
+    std::vector<hipEvent_t> t_ev;
+    struct EvGuard {
+        std::vector<hipEvent_t>& v;
+        ~EvGuard() { for (hipEvent_t e : v) if (e) (void)hipEventDestroy(e); }
+    } ev_guard{t_ev};
+    int lcs_launches = 0;
+    if (resident) {
+        HIP_TRY(lcsgpu::launch_upgma_distances(a, L.d_out.p, elem, (const uint32_t*)ctx->d_lens.p, (const float*)ctx->d_powf.p,
+                                               distance_kind, 0, n, L.stream));
+    } else {
+        for (int32_t r0 = 0; r0 < n;) {
+            int32_t r1 = n;
+            if (tri_offset(n) - tri_offset(r0) > block_pairs) { // the largest multiple of 32 whose rows fit the block
+                r1 = (int32_t)std::floor(0.5 + std::sqrt(0.25 + 2.0 * (double)(tri_offset(r0) + block_pairs)));
+                r1 = std::min(n, r1) & ~31;
+                while (r1 > r0 + 32 && tri_offset(r1) - tri_offset(r0) > block_pairs) r1 -= 32;
+                if (r1 <= r0) r1 = std::min(n, r0 + 32);
+                if (tri_offset(r1) - tri_offset(r0) > block_pairs)
+                    return fail(LCSGPU_E_NOMEM, "UPGMA: a block of 32 rows of the LCS triangle does not fit its buffer (n = %d)", n);
+            }
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            HIP_TRY(hipEventCreate(&e0));
+            t_ev.push_back(e0);
+            HIP_TRY(hipEventCreate(&e1));
+            t_ev.push_back(e1);
+            HIP_TRY(hipEventRecord(e0, L.stream));
+            rc = run_rows(ctx, L, lcsgpu::MODE_TRIANGLE, nullptr, r0, r1 - r0, nullptr, 0, std::max(0, r1 - 1), L.d_out.p, 0, tri_offset(r0),
+                          elem, r0);
+            if (rc) return rc;
+            lcs_launches += L.last_launches;
+            HIP_TRY(hipEventRecord(e1, L.stream));
+            HIP_TRY(lcsgpu::launch_upgma_distances(a, L.d_out.p, elem, (const uint32_t*)ctx->d_lens.p, (const float*)ctx->d_powf.p,
+                                                   distance_kind, r0, r1, L.stream));
+            r0 = r1; // (run_rows waits for the stream before it reuses the lane's plan staging)
+        }
+    }
+    HIP_TRY(lcsgpu::launch_upgma_init(a, L.stream));
     if (profile) { HIP_TRY(hipStreamSynchronize(L.stream)); t_merge = now(); }
     // The n-1 merges: batches of up to K merges per three launches (upgma_batch_kernels.hip), else one launch per merge.
     // (Round 3 also had all merges inside one kernel on one XCD: bit-identical, 11-13 us per merge at 100 000 sequences
     // against 8.4 us for a launch -- profiles/upgma_chain_ab_r03.txt; removed in round 5.)
     uint32_t sel[12] = {0};
     bool merged = false;
-    int n_batches = 0, n_cut = 0;
+    int n_batches = 0, n_cut = 0, n_compactions = 0;
     if (!merged && square && batch_k) {
         const size_t nb = (ld + 255) / 256;
         const size_t b_s0 = 0, b_s1 = b_s0 + a16(((size_t)n + 1) * 8), b_pos = b_s1 + a16(((size_t)n + 1) * 8),
                      b_slot = b_pos + a16((size_t)n * 4), b_rowof = b_slot + a16((size_t)n * 4),
                      b_cand = b_rowof + a16(ld * 4), b_state = b_cand + a16((size_t)lcsgpu::UPGMA_BATCH_CAND * 16),
                      b_hdr = b_state + 256, b_rec = b_hdr + 2048, b_side = b_rec + 8192, b_pd = b_side + a16((size_t)lcsgpu::UPGMA_BATCH_MAX * ld * 4),
-                     b_pj = b_pd + a16((size_t)lcsgpu::UPGMA_BATCH_MAX * nb * 4), b_total = b_pj + a16((size_t)lcsgpu::UPGMA_BATCH_MAX * nb * 4);
+                     b_pj = b_pd + a16((size_t)lcsgpu::UPGMA_BATCH_MAX * nb * 4), b_remap = b_pj + a16((size_t)lcsgpu::UPGMA_BATCH_MAX * nb * 4),
+                     b_total = b_remap + a16(ld * 4);
         HIP_TRY(ctx->d_qrows.reserve(b_total)); // (a buffer the UPGMA path does not otherwise use)
         char* bb = (char*)ctx->d_qrows.p;
         lcsgpu::UpgmaBatchArgs ba{};
@@ -988,18 +1052,29 @@ int upgma_reduce(lcsgpu_ctx* ctx, Lane& L, int elem, int distance_kind, int modi
         ba.side = (float*)(bb + b_side);
         ba.part_d = (float*)(bb + b_pd);
         ba.part_j = (uint32_t*)(bb + b_pj);
+        ba.remap = (uint32_t*)(bb + b_remap);
         HIP_TRY(hipMemsetAsync(bb + b_state, 0, 256 + 2048, L.stream));
         HIP_TRY(lcsgpu::launch_upgma_batch_init(ba, L.stream));
-        // The host does not know how many batches it takes (the validity check may cut one short): enqueue what the
-        // remaining merges need if every batch is full, look at the committed count, repeat.  Batches past the end do nothing.
+        // The host does not know how many batches it takes (the validity check may cut one short), and the slots run out:
+        // enqueue what the remaining merges need if every batch is full -- as far as the free slots reach --, look at the
+        // committed count and the next free slot, compact when fewer than a batch's worth of slots are left, repeat.
+        // Batches past the end do nothing.
         uint32_t st[8] = {0};
         int done = 0;
+        long long slots_used = n; // the next free slot (exact after every look)
         while (done < n - 1) {
-            const int want = (n - 1 - done + batch_k - 1) / batch_k + (n_batches ? 2 : 0);
-            HIP_TRY(lcsgpu::launch_upgma_batches(ba, modified != 0, batch_k, n_batches, want, L.stream));
+            if ((long long)ld - slots_used < batch_k) {
+                HIP_TRY(lcsgpu::launch_upgma_compact(ba, n_batches & 1, slots_used, L.stream));
+                slots_used = n - done; // = the live clusters
+                ++n_compactions;
+            }
+            const int fit = (int)(((long long)ld - slots_used) / batch_k);
+            const int want = std::min(fit, (n - 1 - done + batch_k - 1) / batch_k + (n_batches ? 2 : 0));
+            HIP_TRY(lcsgpu::launch_upgma_batches(ba, modified != 0, batch_k, n_batches, want, slots_used, L.stream));
             n_batches += want;
             HIP_TRY(hipMemcpyAsync(st, ba.state + 8 * (n_batches & 1), 32, hipMemcpyDeviceToHost, L.stream));
             HIP_TRY(hipStreamSynchronize(L.stream));
+            if (resident && L.d_out.cap >= ((size_t)1 << 30)) L.d_out.release(); // the gathered triangle has been consumed
             if (st[2]) {
                 sel[8] = 1;
                 break;
@@ -1008,6 +1083,9 @@ int upgma_reduce(lcsgpu_ctx* ctx, Lane& L, int elem, int distance_kind, int modi
                 return fail(LCSGPU_E_STATE, "UPGMA: %d batches committed nothing (%u of %d merges)", want, st[0], n - 1);
             done = (int)st[0];
             n_cut = (int)st[3];
+            slots_used = (long long)st[4];
+            if (slots_used > (long long)ld || slots_used < (long long)n - done)
+                return fail(LCSGPU_E_STATE, "UPGMA: slot bookkeeping out of range (%lld of %zu slots, %d merges)", slots_used, ld, done);
         }
         merged = true;
         if (st[2]) {
@@ -1028,12 +1106,27 @@ int upgma_reduce(lcsgpu_ctx* ctx, Lane& L, int elem, int distance_kind, int modi
                 square ? "square" : "triangle", t_merge - t_pro, n - 1, now() - t_merge, 1e6 * (now() - t_merge) / std::max(n - 1, 1),
                 batched ? "batches of merges, three launches each" : "one launch per merge");
     if (profile && batched)
-        fprintf(stderr, "lcsgpu_upgma: %d batches of <= %d merges (%.1f merges per batch, %d cut short by a new row's key)\n", n_batches, batch_k,
-                (double)(n - 1) / n_batches, n_cut);
+        fprintf(stderr, "lcsgpu_upgma: %d batches of <= %d merges (%.1f merges per batch, %d cut short by a new row's key), %zu slots for %d rows, %d compactions\n",
+                n_batches, batch_k, (double)(n - 1) / n_batches, n_cut, ld, n, n_compactions);
     if (sel[8])
         return fail(LCSGPU_E_INVALID, "UPGMA: no finite nearest neighbour (a pair with LCS 0?) -- the reference's "
                                       "algorithm is undefined for this input");
-    note_async_call(ctx);
+    if (resident) {
+        note_async_call(ctx);
+    } else { // this call's LCS launches, block by block (the stream has been synchronised)
+        double ms = 0;
+        for (size_t k = 0; k + 1 < t_ev.size(); k += 2) {
+            float f = 0.f;
+            if (hipEventElapsedTime(&f, t_ev[k], t_ev[k + 1]) == hipSuccess) ms += f;
+        }
+        g_last.ctx = ctx;
+        g_last.also.clear();
+        g_last.pending_on_lane0 = false;
+        g_last.ms = ms;
+        g_last.launches = lcs_launches;
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        ctx->total_kernel_ms += ms;
+    }
     return LCSGPU_OK;
 }
 
@@ -1094,9 +1187,11 @@ int lcsgpu_multi_upgma(lcsgpu_ctx* const* ctxs, int32_t n_ctx, int distance_kind
     if (!out_left || !out_right) return fail(LCSGPU_E_INVALID, "NULL output");
     MultiGuard g(ctxs, n_ctx);
     const int elem = ctxs[0]->max_len > 65535 ? 4 : 2;
+    if (n_ctx == 1) // one GPU: the triangle is computed block by block inside (2 B per pair never exist all at once)
+        return upgma_reduce(ctxs[0], *g.lanes[0], elem, distance_kind, modified, out_left, out_right, false);
     rc = whole_triangle(ctxs, n_ctx, g, elem);
     if (rc) return rc;
-    return upgma_reduce(ctxs[0], *g.lanes[0], elem, distance_kind, modified, out_left, out_right);
+    return upgma_reduce(ctxs[0], *g.lanes[0], elem, distance_kind, modified, out_left, out_right, true);
 }
 
 int lcsgpu_upgma(lcsgpu_ctx* ctx, int distance_kind, int modified, int32_t* out_left, int32_t* out_right)

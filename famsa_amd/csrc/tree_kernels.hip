@@ -192,14 +192,15 @@ __device__ __forceinline__ size_t tri_index(uint64_t i, uint64_t j) // TriangleM
 
 template <typename T>
 __global__ __launch_bounds__(256) void upgma_dist_kernel(const T* __restrict__ lcs, const uint32_t* __restrict__ lens,
-                                                         const float* __restrict__ pow_f32, int kind, int n,
+                                                         const float* __restrict__ pow_f32, int kind, int row0, size_t lcs_off,
                                                          float* __restrict__ D)
 {
-    const int i = blockIdx.x + 1; // row
+    // rows row0 .. of the triangle; lcs holds them from element lcs_off of the packed triangle on
+    const int i = row0 + blockIdx.x; // row (>= 1)
     const uint32_t len_i = lens[i];
     const size_t row = (size_t)i * (i - 1) / 2;
     for (int j = threadIdx.x; j < i; j += 256) {
-        const uint32_t l = lcs[row + j];
+        const uint32_t l = lcs[row + j - lcs_off];
         const uint32_t indel = len_i + lens[j] - 2u * l;
         float d;
         if (l == 0)
@@ -219,11 +220,12 @@ __global__ __launch_bounds__(256) void upgma_dist_kernel(const T* __restrict__ l
 template <typename T>
 __global__ __launch_bounds__(256) void upgma_dist_square_kernel(const T* __restrict__ lcs, const uint32_t* __restrict__ lens,
                                                                 const float* __restrict__ pow_f32, int kind, int n,
-                                                                size_t ld, float* __restrict__ D)
+                                                                size_t ld, float* __restrict__ D, long long tile0, size_t lcs_off)
 {
     __shared__ float tile[32][33];
-    // tile (ti, tj), tj <= ti, from the linear workgroup id
-    const long long b = blockIdx.x;
+    // tile (ti, tj), tj <= ti, from the linear workgroup id; a launch covers the tiles tile0 .. of whole tile rows, and
+    // lcs holds those rows' values from element lcs_off of the packed triangle on
+    const long long b = tile0 + blockIdx.x;
     int ti = (int)((sqrt(8.0 * (double)b + 1.0) - 1.0) * 0.5);
     while ((long long)(ti + 1) * (ti + 2) / 2 <= b) ++ti;
     while ((long long)ti * (ti + 1) / 2 > b) --ti;
@@ -234,7 +236,7 @@ __global__ __launch_bounds__(256) void upgma_dist_square_kernel(const T* __restr
         const int i = ti * 32 + ty + 8 * r, j = tj * 32 + tx;
         float d = 0.0f;
         if (i < n && j < i) {
-            const uint32_t l = lcs[(size_t)i * (i - 1) / 2 + j];
+            const uint32_t l = lcs[(size_t)i * (i - 1) / 2 + j - lcs_off];
             const uint32_t indel = lens[i] + lens[j] - 2u * l;
             if (l == 0)
                 d = 3.40282347e38f; // (float) nextafter((double) FLT_MAX, 0) rounds back to FLT_MAX
@@ -513,28 +515,40 @@ __global__ __launch_bounds__(256) void upgma_step_kernel(UpgmaArgs a, int it)
     }
 }
 
-hipError_t launch_upgma_prologue(const UpgmaArgs& a, const void* lcs, int elem_size, const uint32_t* lens, const float* pow_f32,
-                                 int kind, hipStream_t stream)
+// float distances of the rows [r0, r1) of the triangle (r0 a multiple of 32 in the square layout: whole tile rows);
+// lcs = those rows' LCS values, i.e. the packed triangle from element r0 (r0 - 1) / 2 on
+hipError_t launch_upgma_distances(const UpgmaArgs& a, const void* lcs, int elem_size, const uint32_t* lens, const float* pow_f32,
+                                  int kind, int r0, int r1, hipStream_t stream)
 {
     const int n = a.n;
+    const size_t off = (size_t)r0 * (size_t)(r0 > 0 ? r0 - 1 : 0) / 2;
+    if (r1 <= r0) return hipSuccess;
     if (a.square) {
-        const long long t = (n + 31) / 32, tiles = t * (t + 1) / 2;
+        const long long t0 = r0 / 32, t1 = ((long long)r1 + 31) / 32, tile0 = t0 * (t0 + 1) / 2, tiles = t1 * (t1 + 1) / 2 - tile0;
         if (elem_size == 2)
             hipLaunchKernelGGL(upgma_dist_square_kernel<uint16_t>, dim3((unsigned)tiles), dim3(256), 0, stream, (const uint16_t*)lcs,
-                               lens, pow_f32, kind, n, (size_t)a.ld, a.D);
+                               lens, pow_f32, kind, std::min(n, r1), (size_t)a.ld, a.D, tile0, off);
         else
             hipLaunchKernelGGL(upgma_dist_square_kernel<uint32_t>, dim3((unsigned)tiles), dim3(256), 0, stream, (const uint32_t*)lcs,
-                               lens, pow_f32, kind, n, (size_t)a.ld, a.D);
-        hipLaunchKernelGGL(upgma_init_kernel<true>, dim3(n), dim3(256), 0, stream, a);
+                               lens, pow_f32, kind, std::min(n, r1), (size_t)a.ld, a.D, tile0, off);
     } else {
+        const int first = std::max(r0, 1);
+        if (r1 <= first) return hipSuccess;
         if (elem_size == 2)
-            hipLaunchKernelGGL(upgma_dist_kernel<uint16_t>, dim3(n - 1), dim3(256), 0, stream, (const uint16_t*)lcs, lens,
-                               pow_f32, kind, n, a.D);
+            hipLaunchKernelGGL(upgma_dist_kernel<uint16_t>, dim3(r1 - first), dim3(256), 0, stream, (const uint16_t*)lcs, lens,
+                               pow_f32, kind, first, off, a.D);
         else
-            hipLaunchKernelGGL(upgma_dist_kernel<uint32_t>, dim3(n - 1), dim3(256), 0, stream, (const uint32_t*)lcs, lens,
-                               pow_f32, kind, n, a.D);
-        hipLaunchKernelGGL(upgma_init_kernel<false>, dim3(n), dim3(256), 0, stream, a);
+            hipLaunchKernelGGL(upgma_dist_kernel<uint32_t>, dim3(r1 - first), dim3(256), 0, stream, (const uint32_t*)lcs, lens,
+                               pow_f32, kind, first, off, a.D);
     }
+    return hipGetLastError();
+}
+
+// every row's first strict minimum over its full row (after all distances are in place)
+hipError_t launch_upgma_init(const UpgmaArgs& a, hipStream_t stream)
+{
+    if (a.square) hipLaunchKernelGGL(upgma_init_kernel<true>, dim3(a.n), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(upgma_init_kernel<false>, dim3(a.n), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 
@@ -549,13 +563,6 @@ hipError_t launch_upgma_steps(const UpgmaArgs& a, bool modified, hipStream_t str
 #undef UPGMA_STEP
     }
     return hipGetLastError();
-}
-
-hipError_t launch_upgma(const UpgmaArgs& a, const void* lcs, int elem_size, const uint32_t* lens,
-                        const float* pow_f32, int kind, bool modified, hipStream_t stream)
-{
-    hipError_t e = launch_upgma_prologue(a, lcs, elem_size, lens, pow_f32, kind, stream);
-    return e != hipSuccess ? e : launch_upgma_steps(a, modified, stream);
 }
 
 } // namespace lcsgpu
@@ -768,10 +775,10 @@ hipError_t launch_float_distances(const void* lcs, int elem_size, const uint32_t
     if (n < 2) return hipSuccess;
     if (elem_size == 2)
         hipLaunchKernelGGL(upgma_dist_kernel<uint16_t>, dim3(n - 1), dim3(256), 0, stream, (const uint16_t*)lcs, lens,
-                           pow_f32, kind, n, D);
+                           pow_f32, kind, 1, (size_t)0, D);
     else
         hipLaunchKernelGGL(upgma_dist_kernel<uint32_t>, dim3(n - 1), dim3(256), 0, stream, (const uint32_t*)lcs, lens,
-                           pow_f32, kind, n, D);
+                           pow_f32, kind, 1, (size_t)0, D);
     return hipGetLastError();
 }
 

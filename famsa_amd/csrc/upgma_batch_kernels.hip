@@ -37,13 +37,21 @@
 // LAYOUT: rows and SLOTS.  The reference lets a new cluster take over its left child's row AND column of the matrix;
 // writing that column is n scattered 4-byte stores per merge, each to a different page of a 40 GB matrix -- 3 of the 4 us
 // a merge cost in the first batched form.  Here a cluster keeps its left child's ROW (row indices decide ties, so they
-// stay the reference's) but gets a NEW COLUMN: slot n + k for the k-th merge.  The matrix is D[row][slot], n rows x
-// (2n - 1) slots; slot_of[row] / row_of[slot] translate (a slot whose row died or moved is dead: row_of = NONE).  The
+// stay the reference's) but gets a NEW COLUMN: the next free slot.  The matrix is D[row][slot], n rows x ld slots;
+// slot_of[row] / row_of[slot] translate (a slot whose row died or moved is dead: row_of = NONE).  The
 // columns of the V clusters a batch commits are then V CONSECUTIVE slots: every surviving row gets one contiguous run
 // of V floats (128 B at V = 32) instead of V scattered words, and a cluster's own row is written along the slots
 // (coalesced).  Thread p of the launches stands for slot p; first minima stay (value, ROW) so that ties resolve by row
-// index exactly as the reference's ascending scans do.  Price: 2 x the matrix (n x 2n floats: 80 GB at 100 000
-// sequences, fits up to ~158 000 on 288 GB; beyond that the n x n matrix with one launch per merge, then the triangle).
+// index exactly as the reference's ascending scans do.
+// COMPACTION (round 5).  Every merge kills two slots and makes one, so at most n slots are ever alive -- rounds 4's
+// n x 2n matrix (80 GB at 100 000 sequences) held mostly dead columns by the end.  Now ld = n + a spare of ~n/10 slots
+// (44 GB at 100 000; the batched form reaches ~255 000 sequences on 288 GB): when the spare is used up the live slots
+// move to the front in order (upgma_compact_map_kernel: remap[], row_of / slot_of rewritten, the next free slot = the
+// number of live clusters) and every live row is packed in place (upgma_compact_rows_kernel: chunk by chunk, read -
+// barrier - write; a value only ever moves to a smaller index).  The spare doubles with every compaction (the live
+// clusters halve the other way), so a tree needs about log2(n / spare) of them -- 3 at n/10 -- each one sweep over what
+// is left of the matrix (~15 ms the first at 100 000), and the batches after it cover fewer slots.  A cluster's node id
+// (n + k for the k-th merge) is no longer its slot.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -109,6 +117,7 @@ __global__ __launch_bounds__(256) void upgma_batch_rank_kernel(UpgmaBatchArgs a)
         a.state[1] = (uint32_t)n; // entries of the sorted order = active rows
         a.state[2] = 0u;          // error: no finite nearest neighbour
         a.state[3] = 0u;          // batches that were cut short by the validity check (statistics)
+        a.state[4] = (uint32_t)n; // the next free slot
         a.hdr[0] = 0u;
     }
 }
@@ -151,7 +160,10 @@ __global__ __launch_bounds__(256) void upgma_batch_rows_kernel(UpgmaBatchArgs a,
         const uint32_t L = lane_u32(c.y, i), key = lane_u32(c.x, i);
         uint32_t R = lane_u32(c.z, i);
         if (__ballot(lane < m && mR == L)) continue; // this row died earlier in the batch
-        if (key >= UB_BIG_BITS) { bad = true; break; } // no row left with a finite nearest neighbour (reference: undefined)
+        // no row left in the order with a finite nearest neighbour: an error (the reference's behaviour is undefined) only
+        // if the batch is empty -- the clusters of the m merges before it may get finite keys, and the reference, which
+        // would pick those next, goes on: commit the prefix, let the next batch see the new rows
+        if (key >= UB_BIG_BITS) { bad = m == 0; break; }
         for (;;) { // renames of the batch: a row that died became the row it merged into
             const unsigned long long hit = __ballot(lane < m && mR == R);
             if (!hit) break;
@@ -251,7 +263,7 @@ __global__ __launch_bounds__(1024) void upgma_batch_resolve_kernel(UpgmaBatchArg
     uint32_t* st_next = a.state + 8 * (parity ^ 1);
     uint32_t* rec = a.rec;
     // ---- level 1 ----
-    const uint32_t done = st[0], ns = st[1], err = st[2], cuts = st[3];
+    const uint32_t done = st[0], ns = st[1], err = st[2], cuts = st[3], sb = st[4]; // sb: the next free slot
     const int m = (int)a.hdr[0];
     const uint32_t walk_err = a.hdr[1];
     uint32_t mL = UB_NONE, mR = UB_NONE, mKey = 0u, mSlotL = UB_NONE, mSlotR = UB_NONE;
@@ -289,7 +301,7 @@ __global__ __launch_bounds__(1024) void upgma_batch_resolve_kernel(UpgmaBatchArg
     }
     if (m == 0 || err) { // nothing pending (finished, or an error): the state moves on unchanged
         if (tid == 0) {
-            st_next[0] = done; st_next[1] = ns; st_next[2] = err | walk_err; st_next[3] = cuts;
+            st_next[0] = done; st_next[1] = ns; st_next[2] = err | walk_err; st_next[3] = cuts; st_next[4] = sb;
             rec[0] = 0u;
         }
         return;
@@ -397,8 +409,8 @@ __global__ __launch_bounds__(1024) void upgma_batch_resolve_kernel(UpgmaBatchArg
             a.left[done + lane] = (int32_t)nodeL;
             a.right[done + lane] = (int32_t)(mSrc < 0 ? nodeR : (uint32_t)n + done + (uint32_t)mSrc);
             const bool dies = die < V;
-            const uint32_t new_slot = (uint32_t)n + done + (uint32_t)lane;
-            a.node_index[mL] = dies ? UB_NONE : new_slot; // (node id of the k-th cluster = n + k = its slot)
+            const uint32_t new_slot = sb + (uint32_t)lane;
+            a.node_index[mL] = dies ? UB_NONE : (uint32_t)n + done + (uint32_t)lane; // node id of the k-th cluster = n + k
             if (mSrc < 0) a.node_index[mR] = UB_NONE;
             a.row_of[mSlotL] = UB_NONE;
             if (mSrc < 0) a.row_of[mSlotR] = UB_NONE;
@@ -414,6 +426,7 @@ __global__ __launch_bounds__(1024) void upgma_batch_resolve_kernel(UpgmaBatchArg
             st_next[1] = ns - (uint32_t)V;
             st_next[2] = err | walk_err;
             st_next[3] = cuts + (V < m ? 1u : 0u);
+            st_next[4] = sb + (uint32_t)V;
         }
     }
     // the cross entries for the commit (only the pairs it will write are read there)
@@ -436,7 +449,7 @@ __global__ __launch_bounds__(256) void upgma_batch_commit_kernel(UpgmaBatchArgs 
     const uint32_t* st = a.state + 8 * parity;
     const uint32_t* rec = a.rec;
     // ---- level 1: lane t of every wave holds merge t's record ----
-    const uint32_t done = st[0], ns = st[1];
+    const uint32_t ns = st[1], sb = st[4];
     const int V = (int)rec[0];
     uint32_t mL = UB_NONE, mR = UB_NONE, mPosL = UB_NONE, mPosR = UB_NONE, mMinBits = 0u, mNear = UB_NONE;
     int mDie = UB_INF;
@@ -491,7 +504,7 @@ __global__ __launch_bounds__(256) void upgma_batch_commit_kernel(UpgmaBatchArgs 
     {   // my row at the new clusters' slots: V consecutive floats per row -- K lanes write one row's run together
         constexpr int RPI = 64 / K; // rows per store instruction of a wave
         const int tt = lane % K, sub = lane / K;
-        const size_t first = (size_t)n + done;
+        const size_t first = (size_t)sb;
 #pragma unroll 4
         for (int q = 0; q < 64 / RPI; ++q) {
             const int r = wave * 64 + q * RPI + sub;
@@ -507,8 +520,8 @@ __global__ __launch_bounds__(256) void upgma_batch_commit_kernel(UpgmaBatchArgs 
             if (u < t && t < V && (int)rec[UB_REC0 + 4 * u + 2] > t) {
                 const float v = __uint_as_float(rec[UB_REC0 + 4 * K + idx]);
                 const uint32_t Lt = a.hdr[UB_HDR0 + UB_HDR_STRIDE * t], Lu = a.hdr[UB_HDR0 + UB_HDR_STRIDE * u];
-                a.D[(size_t)Lt * ld + ((size_t)n + done + u)] = v;
-                a.D[(size_t)Lu * ld + ((size_t)n + done + t)] = v;
+                a.D[(size_t)Lt * ld + ((size_t)sb + u)] = v;
+                a.D[(size_t)Lu * ld + ((size_t)sb + t)] = v;
             }
         }
     }
@@ -561,14 +574,87 @@ hipError_t launch_upgma_batch_init(const UpgmaBatchArgs& a, hipStream_t stream)
     return hipGetLastError();
 }
 
+// ---- compaction: the live slots to the front (see LAYOUT) -------------------------------------------------------------
+// One workgroup: remap[p] = where slot p moves (NONE: dead), row_of packed in place (a slot only moves to a smaller
+// index, and a chunk is read completely before any of it is written), slot_of of the live rows, the next free slot.
+__global__ __launch_bounds__(1024) void upgma_compact_map_kernel(UpgmaBatchArgs a, int parity, uint32_t used)
+{
+    __shared__ uint32_t s_cnt[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint64_t lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
+    uint32_t base = 0;
+    for (uint32_t c0 = 0; c0 < used; c0 += 1024) {
+        const uint32_t p = c0 + (uint32_t)tid;
+        const uint32_t row = p < used ? a.row_of[p] : UB_NONE;
+        const bool live = row != UB_NONE;
+        const uint64_t mask = __ballot(live);
+        if (lane == 0) s_cnt[wave] = (uint32_t)__popcll(mask);
+        __syncthreads(); // (every row_of of the chunk has been read)
+        uint32_t before = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            const uint32_t c = s_cnt[w];
+            before += w < wave ? c : 0u;
+            total += c;
+        }
+        const uint32_t np = base + before + (uint32_t)__popcll(mask & lt_mask);
+        if (p < used) a.remap[p] = live ? np : UB_NONE;
+        if (live) {
+            a.row_of[np] = row;
+            a.slot_of[row] = np;
+        }
+        base += total;
+        __syncthreads(); // (s_cnt is read; the next chunk may overwrite it)
+    }
+    for (uint32_t p = base + (uint32_t)tid; p < used; p += 1024) a.row_of[p] = UB_NONE;
+    if (tid == 0) a.state[8 * parity + 4] = base;
+}
+
+// One workgroup per row: a live row's entries move to their slots' new places, 2048 slots at a time.
+__global__ __launch_bounds__(256) void upgma_compact_rows_kernel(UpgmaBatchArgs a, uint32_t used)
+{
+    constexpr int PER = 8;
+    const uint32_t x = blockIdx.x;
+    const int tid = threadIdx.x;
+    const uint32_t sx = a.slot_of[x]; // (already the new slot of a live row; anything of a dead one)
+    if (sx >= (uint32_t)a.ld || a.row_of[sx] != x) return;
+    float* row = a.D + (size_t)x * (size_t)a.ld;
+    for (uint32_t c0 = 0; c0 < used; c0 += 256 * PER) {
+        float v[PER];
+        uint32_t np[PER];
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const uint32_t p = c0 + (uint32_t)(u * 256 + tid);
+            np[u] = p < used ? a.remap[p] : UB_NONE;
+        }
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const uint32_t p = c0 + (uint32_t)(u * 256 + tid);
+            v[u] = np[u] != UB_NONE ? row[p] : 0.0f;
+        }
+        __syncthreads(); // the chunk is in registers: its values may now land on places of the same chunk (never beyond it)
+#pragma unroll
+        for (int u = 0; u < PER; ++u)
+            if (np[u] != UB_NONE) row[np[u]] = v[u];
+    }
+}
+
+hipError_t launch_upgma_compact(const UpgmaBatchArgs& a, int parity, long long slots_used, hipStream_t stream)
+{
+    const uint32_t used = (uint32_t)std::min<long long>(slots_used, a.ld);
+    hipLaunchKernelGGL(upgma_compact_map_kernel, dim3(1), dim3(1024), 0, stream, a, parity, used);
+    hipLaunchKernelGGL(upgma_compact_rows_kernel, dim3((unsigned)a.n), dim3(256), 0, stream, a, used);
+    return hipGetLastError();
+}
+
 // `count` batches (three launches each), the first of them batch number `first` (its parity selects the state buffers).
-// Batch i can have committed at most i * k merges before it, so its launches cover the slots [0, n + min(i * k, n - 1)).
-hipError_t launch_upgma_batches(const UpgmaBatchArgs& a, bool modified, int k, int first, int count, hipStream_t stream)
+// Before batch i at most slots_used + (i - first) * k slots are in use: its launches cover those.
+hipError_t launch_upgma_batches(const UpgmaBatchArgs& a, bool modified, int k, int first, int count, long long slots_used, hipStream_t stream)
 {
     const dim3 block(256);
     for (int i = first; i < first + count; ++i) {
         const int parity = i & 1;
-        const long long slots = (long long)a.n + std::min<long long>((long long)i * k, a.n - 1);
+        const long long slots = std::min<long long>(a.ld, slots_used + (long long)(i - first) * k);
         const int g = (int)std::min<long long>((slots + 255) / 256, a.n_blocks);
         const dim3 grid_rows((unsigned)g), grid_commit((unsigned)std::max<long long>(g, a.n / 256 + 1));
 #define UB_LAUNCH(KK)                                                                                                     \

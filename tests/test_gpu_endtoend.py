@@ -171,7 +171,7 @@ def test_trees_of_a_set_with_a_giant_sequence(host, oracle, tmp_path, gt):
     assert host.tree_gpu(fasta, gt) == host.tree_from_matrix(fasta, square, gt)
 
 
-@pytest.mark.parametrize("layout", ["square", "square+b16", "square+b8", "square+steps", "triangle"])
+@pytest.mark.parametrize("layout", ["square", "square+b16", "square+b8", "square+steps", "triangle", "square+spare64", "square+b8+spare32"])
 @pytest.mark.parametrize("gt", ["upgma", "upgma_modified"])
 @pytest.mark.parametrize("shape", ["ties", "family", "hub"])
 def test_device_upgma_on_tie_heavy_and_larger_sets(host, oracle, tmp_path, monkeypatch, gt, shape, layout):
@@ -179,11 +179,14 @@ def test_device_upgma_on_tie_heavy_and_larger_sets(host, oracle, tmp_path, monke
     matrix: thousands of exact distance ties, several workgroups of rows, merges that touch the same workgroup twice
     in a row, a hub every other row is nearest to (one cluster that swallows a row per merge: the chained merges of a
     batch).  Both layouts of the float distances -- the full symmetric matrix (the default while 4 B x n^2 fit; merges
-    in batches of 32 / 16 / 8 per launch pair, or one launch per merge) and the packed triangle."""
+    in batches of 32 / 16 / 8 per launch pair -- also with a spare of 64 / 32 slots only, i.e. a compaction of the live slots
+    every other batch --, or one launch per merge) and the packed triangle."""
     import numpy as np
     monkeypatch.setenv("LCSGPU_UPGMA_LAYOUT", layout.split("+")[0])
+    if "+spare" in layout:  # a small spare of slots: the live slots are compacted every few batches (upgma_compact_*_kernel)
+        monkeypatch.setenv("LCSGPU_TUNE", "upgma_spare=" + layout.split("+spare")[1])
     if "+b" in layout:
-        monkeypatch.setenv("LCSGPU_UPGMA_BATCH", layout.split("+b")[1])
+        monkeypatch.setenv("LCSGPU_UPGMA_BATCH", layout.split("+b")[1].split("+")[0])
     if layout.endswith("steps"):
         monkeypatch.setenv("LCSGPU_UPGMA_BATCH", "0")
     rng = np.random.Generator(np.random.PCG64(61))
@@ -211,6 +214,42 @@ def test_device_upgma_on_tie_heavy_and_larger_sets(host, oracle, tmp_path, monke
     ids = np.arange(len(seqs), dtype=np.int32)
     square = oracle.rect(codes, offsets, ids, ids)
     assert host.tree_gpu(fasta, gt, keep_duplicates=True) == host.tree_from_matrix(fasta, square, gt, keep_duplicates=True)
+
+
+@pytest.mark.parametrize("gt", ["upgma", "upgma_modified"])
+def test_device_upgma_forms_agree_where_the_reference_is_undefined(engine, monkeypatch, gt):
+    """Two families without a common residue: every distance between them is FLT_MAX (>= UPGMA::BIG_DIST), the reference's
+    algorithm is undefined once only such pairs are left (it reads out of bounds).  Whatever the device does -- an error
+    that says so, or a tree -- its batched form, its one-launch-per-merge form and a batched form that compacts all the
+    time must do the same."""
+    import famsa_amd
+    rng = np.random.Generator(np.random.PCG64(5))
+    a = [rng.integers(0, 2, size=int(rng.integers(20, 40))).astype(np.uint8) for _ in range(150)]       # A, R only
+    b = [(rng.integers(0, 2, size=int(rng.integers(20, 40))) + 2).astype(np.uint8) for _ in range(120)]  # N, D only
+    engine.upload_seqs(a + b)
+    outcomes = []
+    for env in ({"LCSGPU_UPGMA_BATCH": "32"}, {"LCSGPU_UPGMA_BATCH": "0"}, {"LCSGPU_UPGMA_BATCH": "16", "LCSGPU_TUNE": "upgma_spare=32"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        try:
+            left, right = engine.upgma(1, gt == "upgma_modified")
+            outcomes.append(("tree", left.tolist(), right.tolist()))
+        except famsa_amd.LcsGpuError as e:
+            outcomes.append(("error", "no finite nearest neighbour" in str(e)))
+        for k in env:
+            monkeypatch.delenv(k)
+    assert outcomes[0] == outcomes[1] == outcomes[2], [o[0] for o in outcomes]
+    # and a set where the rows run out one family at a time but every pair has a finite distance: a tree in all three forms
+    engine.upload_seqs([np.concatenate([s, [4]]).astype(np.uint8) for s in a + b])
+    trees = []
+    for env in ({"LCSGPU_UPGMA_BATCH": "32"}, {"LCSGPU_UPGMA_BATCH": "0"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        left, right = engine.upgma(1, gt == "upgma_modified")
+        trees.append((left.tolist(), right.tolist()))
+        for k in env:
+            monkeypatch.delenv(k)
+    assert trees[0] == trees[1]
 
 
 @pytest.mark.skipif(not oracle_bind.have_ref(), reason="oracle/_ref not built (needs /root/reference)")
