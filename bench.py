@@ -15,6 +15,21 @@ same for every N.
 
     python bench.py [--gpus N --steps K --warmup W] [--n-seqs 100000 --seq-len 400]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --workload family|realmix [--order sorted|input]     ragged lengths (below)
+    python bench.py --pmc                                                roofline.traffic measured by this run (below)
+
+Workloads.  The default (`uniform`: BASELINE.json's configs[3], 100 000 x 400 aa) and its line are what they always
+were.  `--workload family` (one ancestor of --seq-len 300 residues, 25 % substitutions, lengths uniform in [0.7 L, L]:
+the C5 shape) and `--workload realmix` (the upstream real sets held under tests/golden as one 13 774-record set,
+21-210 residues) measure the same step on ragged inputs, `--order sorted` in FAMSA's working order (length
+descending: what every tree generator uploads) or `--order input` as read (what -dist_export uploads).  Their line
+has the same fields; cells, algorithmic bytes and VALU operations are summed over the actual lengths
+(sum over pairs of len_partner x ceil(len_ref / 32) x 3 lane-ops), `config.workload` names the set and the order.
+
+`--pmc` (one rank): after the timed loop this command is run again twice under `rocprofv3 --kernel-trace --pmc FETCH_SIZE`
+resp. `WRITE_SIZE` (one step each, separate passes as MI355X_MICROARCH.md prescribes), and `roofline.traffic` =
+(2 x FETCH_SIZE + WRITE_SIZE) x 1024 summed over the LCS kernels of the step (gfx950: FETCH_SIZE counts half of a
+wide streaming read).  Without the flag, or without rocprofv3 on PATH, `traffic` is null -- it is never imported.
 
 Both forms work for N > 1: started plainly (no WORLD_SIZE in the environment), `bench.py --gpus N` starts its
 N ranks itself (one process per GPU, LOCAL_RANK binding, rendezvous on 127.0.0.1) and relays rank 0's line.
@@ -59,7 +74,7 @@ def cpu_quota():
     return None
 
 
-def cpu_baseline(n, length, target_s=12.0):
+def cpu_baseline(n, length, target_s=12.0, codes=None, offsets=None):
     """The reference's UPGMA::computeDistances (tree/UPGMA.cpp:75-109, AVX2 dispatch) on the first
     n_use sequences of the same synthetic set."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -71,7 +86,9 @@ def cpu_baseline(n, length, target_s=12.0):
     avail = len(os.sched_getaffinity(0))
     quota = cpu_quota()
     n_probe = min(n, 4000)
-    codes, offsets = seqio.synth_uniform(n, length)
+    ragged = codes is not None
+    if not ragged:
+        codes, offsets = seqio.synth_uniform(n, length)
     # the sample is a prefix of the same set (fixed length => already in the reference's order up to ties)
     n_load = min(n, 60000)
     path = f"/tmp/bench_synth_{n}_{length}_{n_load}.fasta"
@@ -112,38 +129,137 @@ def cpu_baseline(n, length, target_s=12.0):
         "host_cpu_quota_cores": quota,
         "probe_pairs_per_s_by_threads": {str(t): r for t, r in sorted(probe.items())},
         "sustained_pairs_per_s_by_threads": {str(t): r for t, r in sorted(sustained.items())},
-        "sample": f"reference UPGMA::computeDistances (AVX2 dispatch, {threads} threads = the fastest sustained of "
+        "sample": ("(the reference sorts its input by length first: the sample is the LONGEST sequences of the set) " if ragged else "") +
+                  f"reference UPGMA::computeDistances (AVX2 dispatch, {threads} threads = the fastest sustained of "
                   f"{'/'.join(str(t) for t in sorted(sustained))}; the container's CPU quota is "
                   f"{quota if quota else 'unlimited'} cores of {avail} hardware threads) on the first {n_use} of "
                   f"the {n} synthetic sequences = {int(pairs)} pairs",
     }
 
 
-def pmc_traffic(n, length, world, my_pairs, total_pairs, kernel, library):
-    """(2 x FETCH_SIZE + WRITE_SIZE) x 1024 of the hot kernel's launch as the PMC passes of scripts/profile_round.sh
-    recorded it (profiles/pmc_r*.json, newest round) -- IMPORTED, not measured by this run, so it is only passed on
-    when the record is about this very thing: same workload, same kernel instantiation, same library build string.
-    Returns (bytes or None, source or the reason for None)."""
-    import glob
-    if world != 1 or my_pairs != total_pairs:
-        return None, "no PMC record for a row block (the committed passes cover the one-GPU launch)"
-    why = "no profiles/pmc_r*.json for this workload"
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "pmc_r*.json")), reverse=True):
+def make_workload(args):
+    """(codes, offsets, description, uniform) of the set the steps run on."""
+    from famsa_amd import seqio
+    n, L = args.n, args.len
+    if args.workload == "uniform":
+        codes, offsets = seqio.synth_uniform(n, L)
+        return codes, offsets, None, True
+    if args.workload == "family":
+        codes, offsets = seqio.family_set(n, L)
+        what = f"synthetic family of {n} proteins (one ancestor of {L} aa, 25 % substitutions, lengths uniform in [{int(L * 0.7)}, {L}])"
+    else:
+        import famsa_amd
+        golden = os.path.join(ROOT, "tests", "golden")
+        seqs = []
+        for _, rel in seqio.REALMIX_PARTS:
+            seqs += [famsa_amd.lcsgpu.encode(r) for r in seqio.read_fasta(os.path.join(golden, rel))[1]]
+        codes, offsets = seqio.pack(seqs)
+        what = f"the upstream real sets as one input ({len(seqs)} records, {min(map(len, seqs))}-{max(map(len, seqs))} aa, duplicates kept)"
+    if args.order == "sorted":
+        o = offsets.astype(np.int64)
+        order = seqio.sort_order([codes[o[i]:o[i + 1]] for i in range(len(o) - 1)])
+        codes, offsets = seqio.reorder(codes, offsets, np.asarray(order, dtype=np.int64))
+        what += ", in FAMSA's working order (length descending, then residues)"
+    else:
+        what += ", in input order"
+    return codes, offsets, what, False
+
+
+def block_sums(offsets, r0, r1):
+    """Over the pairs (i, j < i) of the rows [r0, r1): cells = sum len_i len_j, algorithmic bytes = sum (len_j + 2),
+    VALU lane-ops = sum 3 len_j ceil(len_i / 32) -- exact integers as floats."""
+    lens = np.diff(offsets.astype(np.int64)).astype(np.float64)
+    before = np.concatenate([[0.0], np.cumsum(lens)[:-1]])  # residues of the partners j < i
+    rows = np.arange(len(lens), dtype=np.float64)
+    sl = slice(r0, r1)
+    H = np.ceil(lens[sl] / 32.0)
+    return {"cells": float((lens[sl] * before[sl]).sum()), "bytes": float((before[sl] + 2.0 * rows[sl]).sum()),
+            "valu_ops": float((3.0 * H * before[sl]).sum()), "pairs": float(rows[sl].sum()),
+            "classes": sorted({int(h) for h in H[lens[sl] > 0]})}
+
+
+def measure_traffic(argv):
+    """roofline.traffic measured by THIS run (--pmc): the command again, one step, under rocprofv3 with FETCH_SIZE resp.
+    WRITE_SIZE (separate passes, --kernel-trace only: MI355X_MICROARCH.md, HBM / rocprofv3 section); per step the sum over
+    the LCS kernels of (2 x FETCH_SIZE + WRITE_SIZE) KiB x 1024 (gfx950: FETCH_SIZE counts half of a wide streaming read).
+    Returns (bytes or None, how / why not)."""
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return None, "rocprofv3 is not on PATH"
+    keep = [a for a in argv if a not in ("--pmc",)]
+    sums = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="bench_pmc_", dir="/tmp")
+        cmd = [exe, "--kernel-trace", "--pmc", counter, "-d", d, "-o", "run", "--", sys.executable, os.path.abspath(__file__)] + keep + \
+              ["--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-parity"]
         try:
-            d = json.load(open(path))
-        except Exception:
-            continue
-        if d.get("n_seqs") != n or d.get("seq_len") != length or "traffic_bytes" not in d:
-            continue
-        name = os.path.relpath(path, ROOT)
-        if d.get("kernel") != kernel:
-            why = f"{name} is about kernel {d.get('kernel')!r}, this run launched {kernel!r}"
-            continue
-        if d.get("library") != library:
-            why = f"{name} was recorded with {d.get('library')!r}, this run uses {library!r}"
-            continue
-        return d["traffic_bytes"], name
-    return None, why
+            subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                           timeout=900, check=True)
+            dbs = [os.path.join(r, f) for r, _, fs in os.walk(d) for f in fs if f.endswith(".db")]
+            total = 0.0
+            for path in dbs:
+                cur = sqlite3.connect(path).cursor()
+                for name, value in cur.execute("select kernel_name, sum(value) from counters_collection where counter_name = ? "
+                                               "group by kernel_name", (counter,)):
+                    if "lcs_rows_kernel" in name or "lcs_long_kernel" in name:
+                        total += float(value)
+            if not dbs or total <= 0:
+                return None, f"the rocprofv3 pass for {counter} recorded nothing for the LCS kernels"
+            sums[counter] = total
+        except Exception as e:  # a report, never a reason to lose the line
+            return None, f"the rocprofv3 pass for {counter} failed: {type(e).__name__}: {e}"
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return (2.0 * sums["FETCH_SIZE"] + sums["WRITE_SIZE"]) * 1024.0, \
+        "measured by this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE, one step each, (2 x FETCH_SIZE + WRITE_SIZE) x 1024 over the step's LCS kernels"
+
+
+def transport_report(torch, world, rank, local_rank, emulate):
+    """What the ranks will reach each other over, before anything is timed: peer access between all device pairs, the
+    RCCL version torch was built with, the NCCL / RCCL / HSA settings in the environment, the xGMI topology as rocm-smi
+    prints it (rank 0, bounded)."""
+    rep = {"rank": rank, "local_rank": local_rank, "devices_visible": torch.cuda.device_count()}
+    try:
+        nd = torch.cuda.device_count()
+        rep["peer_access"] = [[bool(i == j or torch.cuda.can_device_access_peer(i, j)) for j in range(nd)] for i in range(nd)]
+    except Exception as e:
+        rep["peer_access"] = f"unavailable: {e}"
+    try:
+        rep["rccl_version"] = ".".join(str(x) for x in torch.cuda.nccl.version())
+    except Exception as e:
+        rep["rccl_version"] = f"unavailable: {e}"
+    rep["env"] = {k: v for k, v in os.environ.items() if k.startswith(("NCCL_", "RCCL_", "HSA_", "HIP_VISIBLE", "ROCR_VISIBLE", "LCSGPU_"))}
+    if rank == 0 and not emulate:
+        try:
+            import subprocess
+            p = subprocess.run(["rocm-smi", "--showtopotype"], capture_output=True, text=True, timeout=20)
+            rep["rocm_smi_topology"] = [ln for ln in p.stdout.splitlines() if ln.strip() and not ln.startswith("=")][:24]
+        except Exception as e:
+            rep["rocm_smi_topology"] = f"unavailable: {type(e).__name__}"
+    return rep
+
+
+class Watchdog:
+    """A phase that does not end within `seconds` ends the process with a message that names the rank and the phase
+    (a hung rendezvous or collective otherwise looks like a silent stall of the whole job)."""
+    def __init__(self, seconds, what):
+        import threading
+        self.t = threading.Timer(seconds, self._fire)
+        self.t.daemon = True
+        self.what, self.seconds = what, seconds
+    def _fire(self):
+        print(f"bench.py: {self.what} did not finish within {self.seconds:.0f} s -- giving up", file=sys.stderr, flush=True)
+        os._exit(5)
+    def __enter__(self):
+        self.t.start()
+        return self
+    def __exit__(self, *exc):
+        self.t.cancel()
+        return False
 
 
 def sampled_parity(eng, tri, r0, r1, codes, offsets, n_samples=6000, seed=11):
@@ -268,6 +384,15 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--n-seqs", dest="n", type=int, default=100000)
     ap.add_argument("--seq-len", dest="len", type=int, default=400)
+    ap.add_argument("--workload", choices=["uniform", "family", "realmix"], default="uniform",
+                    help="uniform (default): --n-seqs x --seq-len, BASELINE.json's config; family: ragged lengths in [0.7 L, L] "
+                         "(the C5 shape; --seq-len defaults to 300 then); realmix: the 13 774 upstream real sequences")
+    ap.add_argument("--order", choices=["sorted", "input"], default="sorted",
+                    help="ragged workloads: FAMSA's working order (length descending) or the order as read")
+    ap.add_argument("--pmc", action="store_true",
+                    help="measure roofline.traffic: this command again under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (one rank)")
+    ap.add_argument("--phase-timeout-s", type=float, default=600.0,
+                    help="rendezvous, self-check and every other untimed phase with more than one rank: give up after this long, naming the rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--mode", choices=["ranks", "contexts"], default="ranks",
@@ -287,8 +412,12 @@ def main():
     ap.add_argument("--self-check", action="store_true",
                     help="run the multi-rank self-check also with one rank (it always runs with more than one)")
     args = ap.parse_args()
+    if args.workload == "family" and "--seq-len" not in sys.argv:
+        args.len = 300
 
     if args.mode == "contexts":
+        if args.workload != "uniform":
+            raise SystemExit("bench.py --mode contexts runs the uniform workload only")
         return main_contexts(args)
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         return launch_ranks(args)
@@ -317,24 +446,30 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
+        rendezvous = Watchdog(args.phase_timeout_s, f"rank {rank} of {world}: the rendezvous on {os.environ['MASTER_ADDR']}:{os.environ['MASTER_PORT']}")
+        rendezvous.__enter__()
         try:
             if emulate:
                 transport = f"gloo (host memory), {world} ranks sharing cuda:0"
-                dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=600))
+                dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=args.phase_timeout_s))
             else:
                 n_dev = torch.cuda.device_count()
                 if local_rank >= n_dev:
                     raise RuntimeError(f"LOCAL_RANK {local_rank} but {n_dev} GPU(s) visible")
                 transport = f"nccl = RCCL all_gather_into_tensor (device memory), {world} ranks, rank {rank} on cuda:{local_rank}"
                 dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank),
-                                        timeout=datetime.timedelta(seconds=600))
+                                        timeout=datetime.timedelta(seconds=args.phase_timeout_s))
                 rccl_ranks = dist.get_world_size()
         except BaseException as e:
             print(f"bench.py: rank {rank} of {world} could not join the process group (transport: {transport}): "
                   f"{type(e).__name__}: {e}", file=sys.stderr, flush=True)
             os._exit(4)
+        rendezvous.__exit__()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    report = transport_report(torch, world, rank, local_rank, emulate) if world > 1 or args.force_collective or args.self_check else None
+    if report is not None and rank == 0:  # before anything is timed: what the ranks will talk over
+        print("bench.py transport report: " + json.dumps(report), file=sys.stderr, flush=True)
 
     n, L = args.n, args.len
     eng = famsa_amd.LcsGpu(local_rank)
@@ -365,9 +500,11 @@ def main():
 
     check = None
     if world > 1 or args.self_check:
-        check = self_check(eng, torch, dist if collective else None, rank, world, dev, make_exchange, transport)
+        with Watchdog(args.phase_timeout_s, f"rank {rank} of {world}: the self-check (transport: {transport})"):
+            check = self_check(eng, torch, dist if collective else None, rank, world, dev, make_exchange, transport)
 
-    codes, offsets = seqio.synth_uniform(n, L)
+    codes, offsets, workload_text, uniform = make_workload(args)
+    n = len(offsets) - 1
     eng.upload(codes, offsets)  # inputs resident in HBM before the timed region
 
     cuts = row_cuts(n, world)
@@ -447,16 +584,21 @@ def main():
 
     if rank == 0:
         exchange = ("gloo (host memory)" if emulate else "nccl = RCCL (device memory)") if collective else "none (one block)"
-        out = result_line(args, n, L, world, elapsed, k_ms, my_pairs, total_pairs, fused,
+        sums = None if uniform else {"mine": block_sums(offsets, r0, r1), "all": block_sums(offsets, 0, n), "text": workload_text,
+                                         "mean_len": float(np.diff(offsets.astype(np.int64)).mean())}
+        out = result_line(args, n, L, world, elapsed, k_ms, my_pairs, total_pairs, fused, sums,
                           parallelism=f"rowblock{world}" + ("+allgather(n x 16 B best-edge keys per Boruvka round)" if collective else ""),
                           exchange=exchange, edges=edges, edges_hash=edges_hash, rounds=last["rounds"], mst_ms=float(np.mean(mst_ms)),
                           sampled=sampled, bad=bad, library=eng._lib.lcsgpu_version().decode())
-        out["ranks"] = {"mode": "ranks", "world": world, "rccl_ranks": rccl_ranks, "transport": transport,
+        out["ranks"] = {"mode": "ranks", "world": world, "rccl_ranks": rccl_ranks, "transport": transport, "transport_report": report,
                         "kernel_ms_per_rank": per_rank_kernel_ms, "kernel_ms_min": float(min(per_rank_kernel_ms)),
                         "kernel_ms_max": float(max(per_rank_kernel_ms)), "self_check": check}
+        if args.pmc and world == 1:
+            eng.close()  # the profiled child gets the device to itself
+            out["roofline"]["traffic"], out["roofline"]["traffic_source"] = measure_traffic(sys.argv[1:])
         if not args.no_cpu_baseline and world == 1:
             try:
-                cb = cpu_baseline(n, L)
+                cb = cpu_baseline(n, L, codes=None if uniform else codes, offsets=None if uniform else offsets)
             except Exception as e:  # the baseline is a report, never a reason to lose the GPU number
                 cb = {"error": repr(e)}
             out["cpu_baseline"] = cb
@@ -474,18 +616,35 @@ def emit(out):
     print(json.dumps(out), flush=True)
 
 
-def result_line(args, n, L, world, elapsed, k_ms, my_pairs, total_pairs, fused, parallelism, exchange, edges, edges_hash, rounds,
+def result_line(args, n, L, world, elapsed, k_ms, my_pairs, total_pairs, fused, sums, parallelism, exchange, edges, edges_hash, rounds,
                 mst_ms, sampled, bad, library):
-    cells = float(total_pairs) * L * L
     ms_per_step = elapsed / args.steps * 1e3
+    if sums is None:  # uniform lengths: closed forms
+        cells = float(total_pairs) * L * L
+        H = (L + 31) // 32
+        algo_bytes = my_pairs * (L + ALGO_BYTES_PER_PAIR_EXTRA)
+        ops_per_pair = 3 * L * H  # three VALU lane-ops per partner residue and 32-bit half-word of the ref
+        my_ops = my_pairs * ops_per_pair
+        bytes_per_pair = L + ALGO_BYTES_PER_PAIR_EXTRA
+        kernel = f"lcsgpu::lcs_rows_kernel_pipe<{H}, {4 if H <= 16 else 2 if H <= 32 else 1}, 4, {'true' if fused else 'false'}>"
+        workload = (f"synthetic {n} proteins x {L} aa (uniform over 20 residues), full all-pairs LCS "
+                    f"lower triangle -> uint16 in HBM -> single-linkage MST (n-1 edges, Prim's order) on the host")
+        config_extra = {"n_seqs": n, "seq_len": L, "pairs": total_pairs}
+    else:  # ragged lengths: sums over the actual pairs
+        cells = sums["all"]["cells"]
+        algo_bytes = sums["mine"]["bytes"]
+        my_ops = sums["mine"]["valu_ops"]
+        ops_per_pair = my_ops / max(sums["mine"]["pairs"], 1.0)
+        bytes_per_pair = algo_bytes / max(sums["mine"]["pairs"], 1.0)
+        kernel = ("lcsgpu::lcs_rows_kernel_pipe<H, ..> for the half-word classes H = " + ",".join(str(h) for h in sums["mine"]["classes"]) +
+                  " of the refs (small neighbouring classes share a launch), one after the other")
+        workload = (f"{sums['text']}, full all-pairs LCS lower triangle -> uint16 in HBM -> single-linkage MST (n-1 edges, "
+                    f"Prim's order) on the host")
+        config_extra = {"n_seqs": n, "seq_len": L, "pairs": total_pairs, "order": args.order, "mean_len": sums["mean_len"]}
     value = cells * args.steps / elapsed / 1e9
-    H = (L + 31) // 32
-    algo_bytes = my_pairs * (L + ALGO_BYTES_PER_PAIR_EXTRA)
     achieved = algo_bytes / (k_ms * 1e-3) / 1e9
-    ops_per_pair = 3 * L * H  # three VALU lane-ops per partner residue and 32-bit half-word of the ref
-    valu_rate = my_pairs * ops_per_pair / (k_ms * 1e-3)
-    kernel = f"lcsgpu::lcs_rows_kernel_pipe<{H}, {4 if H <= 16 else 2 if H <= 32 else 1}, 4, {'true' if fused else 'false'}>"
-    traffic, traffic_source = pmc_traffic(n, L, world, my_pairs, total_pairs, kernel, library)
+    valu_rate = my_ops / (k_ms * 1e-3)
+    traffic, traffic_source = None, "not measured: run with --pmc (this command again under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
     return {
         "metric": "lcs_gcell_updates_per_s",
         "value": value,
@@ -500,9 +659,8 @@ def result_line(args, n, L, world, elapsed, k_ms, my_pairs, total_pairs, fused, 
         "dtype": "u64",
         "data": "synthetic",
         "config": {
-            "workload": f"synthetic {n} proteins x {L} aa (uniform over 20 residues), full all-pairs LCS "
-                        f"lower triangle -> uint16 in HBM -> single-linkage MST (n-1 edges, Prim's order) on the host",
-            "n_seqs": n, "seq_len": L, "pairs": total_pairs,
+            "workload": workload,
+            **config_extra,
             "parallelism": parallelism,
             "exchange": exchange,
         },
@@ -518,14 +676,12 @@ def result_line(args, n, L, world, elapsed, k_ms, my_pairs, total_pairs, fused, 
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
-            # HBM-side bytes per launch: not measurable in this run (PMC passes are separate rocprofv3 runs of this very
-            # command, scripts/profile_round.sh).  Imported from the committed record of those passes ONLY when that record
-            # names this workload, this kernel instantiation and this library build (traffic_source); else null, with the reason
+            # HBM-side bytes per step's LCS launches: measured by this run with --pmc (measure_traffic), else null
             "traffic": traffic,
             "traffic_source": traffic_source,
             "kernel": kernel,
             "kernel_ms": k_ms,
-            "algorithmic_bytes_per_pair": L + ALGO_BYTES_PER_PAIR_EXTRA,
+            "algorithmic_bytes_per_pair": bytes_per_pair,
             "pairs_per_launch": my_pairs,
             "note": "the contract figure: algorithmic bytes / kernel time against the HBM peak; the kernel is "
                     "integer-VALU bound by construction (SURVEY 8d), `valu` is the roof that binds",
@@ -614,7 +770,7 @@ def main_contexts(args):
     assert bad == 0, f"{bad} of {sampled} sampled pairs differ from the oracle"
     assert len(edges) == n - 1 and (edges["from"] < edges["to"]).all()
     my_pairs = total_pairs // N
-    out = result_line(args, n, L, N, elapsed, float(max(per_ctx)), my_pairs, total_pairs, False,
+    out = result_line(args, n, L, N, elapsed, float(max(per_ctx)), my_pairs, total_pairs, False, None,
                       parallelism=f"rowblock{N}, one process, {N} contexts (lcsgpu_multi_mst_prim)",
                       exchange=group.transport().splitlines()[-1], edges=edges, edges_hash=edge_list_sha256(edges), rounds=None,
                       mst_ms=float("nan"), sampled=sampled, bad=bad, library=group._lib.lcsgpu_version().decode())

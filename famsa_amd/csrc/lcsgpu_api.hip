@@ -606,6 +606,7 @@ int lcsgpu_upload_ordered(lcsgpu_ctx* ctx, const uint8_t* codes, const uint64_t*
     if (!ctx || !offsets || n < 0 || n_records < 0 || (!order && n != n_records) || (!codes && n_records > 0 && offsets[n_records] > 0))
         return fail(LCSGPU_E_INVALID, "bad argument");
     if (n > 0 && n_records == 0) return fail(LCSGPU_E_INVALID, "an order over no records");
+    if (n > 0 && offsets[0] != 0) return fail(LCSGPU_E_INVALID, "offsets[0] must be 0");
     auto record = [&](int32_t i) { return order ? order[i] : i; };
     LaneGuard guard(ctx, LaneGuard::ALL); // nothing may run while the set is replaced
     HIP_TRY(hipSetDevice(ctx->device));
@@ -640,7 +641,6 @@ int lcsgpu_upload_ordered(lcsgpu_ctx* ctx, const uint8_t* codes, const uint64_t*
     for (int32_t i = 0; i < n; ++i) mask_base[i + 1] = mask_base[i] + (lens[i] + 63) / 64;
     const size_t total = (size_t)tile_base[n_tiles];
     const size_t raw_bytes = n ? (size_t)(offsets[n_records] - offsets[0]) : 0;
-    if (n && offsets[0] != 0) return fail(LCSGPU_E_INVALID, "offsets[0] must be 0");
     hipError_t e = hipSuccess;
     if ((e = ctx->d_tiles.reserve(std::max<size_t>(total, 16))) != hipSuccess ||
         (e = ctx->d_tile_base.reserve(((size_t)n_tiles + 1) * 8)) != hipSuccess ||

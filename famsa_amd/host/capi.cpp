@@ -191,6 +191,18 @@ long famsa_host_newick(const int32_t* left, const int32_t* right, int n_leaves, 
                        int n_names, const int32_t* sorted2unique, char* out, long cap)
 {
     try {
+        if (n_leaves < 0 || n_internal < 0 || n_names < 0 || (n_leaves + n_internal > 0 && (!names || (n_internal > 0 && (!left || !right)))))
+            throw std::runtime_error("famsa_host_newick: bad argument");
+        if (sorted2unique ? n_names < n_leaves : n_names != n_leaves)
+            throw std::runtime_error("famsa_host_newick: " + std::to_string(n_names) + " names for " + std::to_string(n_leaves) + " leaves");
+        std::vector<char> seen((size_t)n_leaves + n_internal, 0);
+        for (int i = 0; i < n_internal; ++i)
+            for (int c : {left[i], right[i]}) { // a child is an earlier or later node of the tree, and of one parent only
+                if (c < 0 || c >= n_leaves + n_internal || c == n_leaves + i || seen[c])
+                    throw std::runtime_error("famsa_host_newick: node " + std::to_string(n_leaves + i) + " has the child " + std::to_string(c) +
+                                             (c >= 0 && c < n_leaves + n_internal && seen[c] ? ", which has a parent already" : ", which is not a node of the tree"));
+                seen[c] = 1;
+            }
         tree_structure tree((size_t)n_leaves, node_t(-1, -1));
         for (int i = 0; i < n_internal; ++i) tree.emplace_back(left[i], right[i]);
         if (sorted2unique) tree_from_unique(tree, std::vector<int>(sorted2unique, sorted2unique + n_names));

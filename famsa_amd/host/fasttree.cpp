@@ -774,7 +774,7 @@ void run_fast(LcsSource& src, GT partial, const FastTreeParams& p, tree_structur
     // `n_threads` cores' worth of host work, twice as many threads to keep GPU requests in flight (3 x 10^6
     // sequences, 16 cores, tree stage: 16 threads 2.6 s, 32: 2.2 s, 48: 2.15 s)
     const int n_cpu = std::max(1, p.n_threads);
-    int n_pool = fasttree_pool_threads(n_cpu);
+    int n_pool = host_test_int("pool", fasttree_pool_threads(n_cpu)); // (FAMSA_HOST_TEST pool=N: sweeps)
     src.expect_threads(n_pool);
     g_cpu.reset(n_pool > n_cpu ? n_cpu : 0);
     g_cpu.acquire(); // this thread works too

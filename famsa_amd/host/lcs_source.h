@@ -17,7 +17,8 @@ namespace famsa_host {
 // Test hooks of the host layer, FAMSA_HOST_TEST="name,name,key=value": prim_streaming (MST-Prim's O(n)-memory host form on
 // any input), slink_from_mst (the MST -> SLINK conversion with Prim on the host), upgma_triangle (the leaf UPGMA's triangle
 // walk instead of the square matrix), no_device_mst (as if the triangle did not fit the device), clarans_host (the CLARANS
-// search on the host), threads=N (worker threads of the C test entry points).  Not read on any product default path.
+// search on the host), threads=N (worker threads of the C test entry points), pool=N (threads of the FastTree recursion's task
+// pool instead of twice the cores: measurements).  Not read on any product default path.
 bool host_test(const char* name);
 int host_test_int(const char* key, int dflt);
 // LCSGPU_PROFILE: stage / call statistics on stderr (the library prints its own under the same switch)

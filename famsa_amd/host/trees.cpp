@@ -7,7 +7,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#if defined(__SSE2__)
 #include <emmintrin.h>
+#endif
 #include <fstream>
 #include <limits>
 #include <queue>
@@ -438,6 +440,7 @@ void upgma_tree(std::vector<float>& D, int n, tree_structure& tree)
 // no contraction), rows that are gone are skipped by a lane mask instead of a list, the new row is mirrored into its column by
 // plain stores, and the next pick comes from a heap of (key, row) with lazy deletion (a row's key never changes while it
 // lives, see above).  Same picks, same float operations in the same order per element, same ties.
+#if defined(__SSE2__)
 constexpr int UPGMA_SQUARE_MAX = 4096; // 64 MB of floats; above that the triangle form
 
 inline float hmin4(__m128 v)
@@ -522,7 +525,10 @@ void upgma_square(LcsSource& src, tree_structure& tree)
     uint32_t longest = 0;
     for (int i = 0; i < m; ++i) longest = std::max(longest, lens[i] = src.length(i));
     const float* pw = D == Distance::indel075_div_lcs ? pow075_table((size_t)2 * longest) : nullptr;
-    static thread_local std::vector<float> matrix; // one per pool thread, as large as its largest leaf so far
+    // one per pool thread (freed when the recursion's pool ends), as large as its largest recent leaf: given back when a
+    // leaf needs less than a quarter of it, so that one 2000-member leaf does not pin 16 MB per thread for a run of small ones
+    static thread_local std::vector<float> matrix;
+    if (matrix.capacity() > ((size_t)1 << 20) && (size_t)m * ld * 4 < matrix.capacity()) std::vector<float>().swap(matrix);
     if (matrix.size() < (size_t)m * ld) matrix.resize((size_t)m * ld);
     float* const M = matrix.data();
     std::vector<float> key(ld, BIG);
@@ -673,6 +679,11 @@ void upgma_square(LcsSource& src, tree_structure& tree)
         }
     }
 }
+#else  // no SSE2: the square form is written with its intrinsics; the triangle walk below serves every size
+constexpr int UPGMA_SQUARE_MAX = 0;
+template <bool MODIFIED, Distance D>
+void upgma_square(LcsSource&, tree_structure&) {}
+#endif
 
 // -gt nj.  NeighborJoining::computeTree (reference tree/NeighborJoining.cpp:33-118): q(i, j) = (m - 2) d(i, j) - s_i - s_j over
 // the live clusters in ascending order of their rows, first strict minimum; the sums s are float accumulations whose order

@@ -121,6 +121,38 @@ def family_fasta(n, length, path, seed=1234):
     return path
 
 
+def family_set(n, length, seed=1234):
+    """The sequences family_fasta writes (same generator, same seed: one ancestor, 25 % substitutions, member lengths
+    uniform in [0.7*length, length]), in memory: (codes, offsets), input order."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    anc = rng.integers(0, 20, size=length, dtype=np.uint8)
+    parts, lens_all = [], []
+    B = 20000
+    for b0 in range(0, n, B):
+        m = min(B, n - b0)
+        S = np.tile(anc, (m, 1))
+        mut = rng.random((m, length)) < 0.25
+        S[mut] = rng.integers(0, 20, size=int(mut.sum()), dtype=np.uint8)
+        lens = rng.integers(int(length * 0.7), length + 1, size=m)
+        keep = np.arange(length)[None, :] < lens[:, None]
+        parts.append(S[keep])
+        lens_all.append(lens)
+    lens = np.concatenate(lens_all).astype(np.uint64)
+    offsets = np.zeros(n + 1, dtype=np.uint64)
+    np.cumsum(lens, out=offsets[1:])
+    return np.concatenate(parts).astype(np.uint8), offsets
+
+
+def reorder(codes, offsets, order):
+    """The set with sequence k = the old sequence order[k]."""
+    o = offsets.astype(np.int64)
+    lens = (o[1:] - o[:-1])[order]
+    new_off = np.zeros(len(order) + 1, dtype=np.uint64)
+    np.cumsum(lens.astype(np.uint64), out=new_off[1:])
+    idx = np.concatenate([np.arange(o[i], o[i + 1]) for i in order]) if len(order) else np.zeros(0, np.int64)
+    return codes[idx], new_off
+
+
 REALMIX_PARTS = [("af", "adeno_fiber/adeno_fiber"), ("hp", "hemopexin/hemopexin"), ("afd", "adeno_fiber_duplicates/adeno_fiber_duplicates"),
                  ("hpd", "hemopexin_duplicates/hemopexin_duplicates"), ("afx", "adeno_fiber_extra/adeno_fiber_extra")]
 

@@ -90,7 +90,11 @@ int lcsgpu_upload(lcsgpu_ctx* ctx, const uint8_t* codes, const uint64_t* offsets
  * Replaces: the re-ordering of the sequence vector itself in CFAMSA::sortAndExtendSequences (msa.cpp:245-279:
  * stable_sort of the CSequence objects) and the erase of CFAMSA::removeDuplicates (msa.cpp:338-356) -- the caller
  * computes the order and which records are kept (ids 0..n-1 = ranks in that order, msa.cpp:559-561), the residues
- * are gathered on the device instead of being packed on the host first. */
+ * are gathered on the device instead of being packed on the host first.
+ * The WHOLE record buffer codes[0 .. offsets[n_records]) and all n_records + 1 offsets are staged on the device for the
+ * gather, whatever the order selects (transient device memory and host-to-device time are those of the records, not of
+ * the set); offsets must be non-decreasing from offsets[0] == 0 over the records the order names, and
+ * offsets[n_records] must be the end of the buffer. */
 int lcsgpu_upload_ordered(lcsgpu_ctx* ctx, const uint8_t* codes, const uint64_t* offsets, int32_t n_records,
                           const int32_t* order, int32_t n);
 

@@ -25,7 +25,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle_bind  # noqa: E402
 from famsa_amd import seqio  # noqa: E402
 
-OUT = os.path.join(oracle_bind.GOLDEN, "meta_large.json")
+OUT = os.environ.get("GOLDEN_OUT") or os.path.join(oracle_bind.GOLDEN, "meta_large.json")  # (GOLDEN_OUT: a second generator running next to the first)
 THREADS = len(os.sched_getaffinity(0))
 
 
@@ -38,7 +38,14 @@ def load():
 
 
 def save(meta):
-    json.dump(meta, open(OUT, "w"), indent=1, sort_keys=True)
+    """Merge into what the file holds now (another generator may have added sections or keys meanwhile), then write."""
+    cur = load()
+    for section, rec in meta.items():
+        if isinstance(rec, dict) and isinstance(cur.get(section), dict):
+            cur[section].update(rec)
+        else:
+            cur[section] = rec
+    json.dump(cur, open(OUT, "w"), indent=1, sort_keys=True)
 
 
 def c3(ref, meta):

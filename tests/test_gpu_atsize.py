@@ -2,9 +2,10 @@
 (oracle/make_golden_large.py -> tests/golden/meta_large.json; the inputs are regenerated here by the same
 deterministic generators).  Model: the reference's own at-size regression, .github/workflows/self-hosted.yml:424-461.
 
-  C3  synthetic 10 000 x 400 aa: the u16 LCS triangle and the sl / slink / upgma / upgma_modified / nj Newick
+  C3  synthetic 10 000 x 400 aa: the u16 LCS triangle and the sl / slink / upgma / upgma_modified / nj Newick;
+      -dist indel_div_lcs: sl / upgma (round 5)
   C4  synthetic 100 000 x 400 aa: -gt sl Newick (one GPU; the 2-context row-block form too), sampled oracle check;
-      -gt upgma / upgma_modified Newick
+      -gt upgma / upgma_modified Newick; round 5: -gt slink, and -dist indel_div_lcs with sl / upgma
   C5  'family' sets of 200 000 and 1 000 000 sequences: -medoidtree -gt upgma Newick
       and of 3 000 000 sequences (the C5 shape at its size); FAMSA_TEST_HUGE=1 adds the host-CLARANS / 1-thread run
 """
@@ -75,6 +76,30 @@ def test_c3_trees(synth10k, gt):
     multiply-add the compiler used to fuse.)"""
     got = famsa_amd.guide_tree(synth10k[2], gt)
     assert sha(got) == META["synth10k"][f"{gt}_newick_sha256"]
+
+
+def pinned(section, key):
+    """The reference's sha256, or a skip that says which generator run is missing (oracle/make_golden_large.py)."""
+    if key not in META.get(section, {}):
+        pytest.skip(f"tests/golden/meta_large.json has no {section}.{key}: the reference run (oracle/make_golden_large.py) is not committed yet")
+    return META[section][key]
+
+
+@pytest.mark.parametrize("gt", ["sl", "upgma"])
+def test_c3_trees_with_the_other_distance(synth10k, gt):
+    """-dist indel_div_lcs (Transform<.., indel_div_lcs>, reference tree/AbstractTreeGenerator.hpp:65-75) at C3's size."""
+    got = famsa_amd.guide_tree(synth10k[2], gt, distance="indel_div_lcs")
+    assert sha(got) == pinned("synth10k", f"{gt}_indel_newick_sha256")
+
+
+@pytest.mark.parametrize("gt,dist", [("slink", "indel075_div_lcs"), ("sl", "indel_div_lcs"), ("upgma", "indel_div_lcs")])
+def test_c4_trees_pinned_in_round_5(synth100k, tmp_path, gt, dist):
+    """-gt slink at 100 000 sequences (the device MST over SLINK's orientation + MST -> pointer representation, against the
+    reference's sequential SLINK: tree/SingleLinkage.cpp:31-189) and the other distance measure with sl / upgma."""
+    want = pinned("synth100k", f"{gt}{'_indel' if dist == 'indel_div_lcs' else ''}_newick_sha256")
+    out = str(tmp_path / f"{gt}.dnd")
+    cli("-gt", gt, "-dist", dist, "-gt_export", synth100k[2], out)
+    assert file_sha(out) == want
 
 
 def test_c4_single_linkage_tree(synth100k, tmp_path):

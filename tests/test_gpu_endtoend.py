@@ -40,6 +40,40 @@ def test_cli_default_is_sl_and_verbose_stats(tmp_path):
     assert "time.tree_build=" in p.stderr and "gpu.lcs_kernel_ms=" in p.stderr
 
 
+@pytest.mark.skipif(not oracle_bind.have_ref(), reason="oracle/_ref not built (needs /root/reference)")
+def test_cli_flags_added_in_round_5(tmp_path):
+    """-num_evals, -dump_seeds, -keep_duplicates, -stats, -shuffle and -gt chained on the command line (reference
+    core/params.cpp:178-254): hemopexin's MedoidTree with three evaluations per split and its depth-0 seeds against the
+    reference's own FastTree + observer; the statistics file's shape; a chained tree per seed."""
+    f = os.path.join(G, "hemopexin", "hemopexin")
+    ref = oracle_bind.Ref()
+    h = ref.open_fasta(f)
+    try:
+        for gt, evals, keep in [("upgma", 3, False), ("sl", 2, True)]:
+            want_seeds = str(tmp_path / "seeds_ref.txt")
+            want = ref.tree(h, gt, heuristic=2, threads=8, num_evals=evals, dump_seeds=want_seeds, keep_dups=int(keep))
+            out, seeds, stats = str(tmp_path / "m.dnd"), str(tmp_path / "seeds.txt"), str(tmp_path / "stats.txt")
+            run_cli("-medoidtree", "-gt", gt, "-num_evals", str(evals), "-dump_seeds", seeds, "-stats", stats, "-shuffle", "7",
+                    *(["-keep_duplicates"] if keep else []), "-gt_export", f, out)
+            assert open(out, "rb").read() == want
+            assert open(seeds).read() == open(want_seeds).read() and len(open(seeds).read().split()) == 100
+            lines = open(stats).read().splitlines()
+            assert lines[0] == "[stats]" and lines[1:] == sorted(lines[1:]) and all("=" in ln for ln in lines[1:])
+            keys = {ln.split("=")[0] for ln in lines[1:]}
+            assert {"input.n_sequences", "input.n_duplicates", "time.sort", "time.tree_build", "time.tree_store", "time.total"} <= keys
+            assert "input.n_sequences=4188" in lines
+    finally:
+        ref.close(h)
+    a, b, c = (str(tmp_path / n) for n in ("c0.dnd", "c1.dnd", "c0again.dnd"))
+    run_cli("-gt", "chained", "-gt_export", f, a)
+    run_cli("-gt", "chained", "5", "-gt_export", f, b)
+    run_cli("-gt", "chained", "0", "-gt_export", f, c)
+    ta, tb = open(a).read(), open(b).read()
+    assert ta == open(c).read() and ta != tb and ta.count(",") == 4187 and ta.endswith(");")
+    p = subprocess.run([host_bind.CLI, "-gt", "chained", "-medoidtree", "-gt_export", f, a], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert p.returncode != 0 and "Illegal guide tree method" in p.stderr
+
+
 @pytest.mark.parametrize("name,flags", [("dist", []), ("pid", ["-pid"]), ("dist_sq", ["-square_matrix"]),
                                         ("pid_sq", ["-square_matrix", "-pid"])])
 def test_cli_adeno_dist_export(tmp_path, name, flags):
@@ -222,6 +256,7 @@ def test_device_upgma_forms_agree_where_the_reference_is_undefined(engine, monke
     algorithm is undefined once only such pairs are left (it reads out of bounds).  Whatever the device does -- an error
     that says so, or a tree -- its batched form, its one-launch-per-merge form and a batched form that compacts all the
     time must do the same."""
+    import numpy as np
     import famsa_amd
     rng = np.random.Generator(np.random.PCG64(5))
     a = [rng.integers(0, 2, size=int(rng.integers(20, 40))).astype(np.uint8) for _ in range(150)]       # A, R only

@@ -476,3 +476,14 @@ def test_chained_tree_is_a_caterpillar_over_the_seeded_order(host, oracle, seed)
     assert host.tree_from_matrix(f, zeros, "chained", chained_seed=seed + 1) != got
     with pytest.raises(RuntimeError, match="Illegal guide tree method"):  # nothing to wrap (reference msa.cpp:170)
         host.tree_from_matrix(f, zeros, "chained", heuristic="medoidtree", threshold=10)
+
+
+def test_newick_entry_point_refuses_malformed_trees(host):
+    """famsa_host_newick is exported: a child out of range, a node with two parents, the wrong number of names are errors,
+    not out-of-bounds reads."""
+    names = ["a", "b", "c"]
+    assert host.newick([0, 3], [1, 2], names) == b"((a:1.0,b:1.0):1.0,c:1.0);"
+    for left, right, nm in [([0, 3], [1, 7], names), ([0, 0], [1, 2], names), ([0, -1], [1, 2], names), ([0, 3], [1, 2], names[:2]),
+                            ([0, 4], [1, 2], names)]:
+        with pytest.raises(RuntimeError, match="famsa_host_newick"):
+            host.newick(left, right, nm)
