@@ -24,7 +24,7 @@ probe() { # label, args...
 }
 probe "10k sl" -gt sl -gt_export /tmp/u_10000.fasta
 probe "200k medoid upgma" -medoidtree -gt upgma -gt_export /tmp/fam_200000.fasta
-FAMSA_GPU_POOL_THREADS=8 probe "200k medoid upgma, 8 pool threads" -medoidtree -gt upgma -gt_export /tmp/fam_200000.fasta
+FAMSA_HOST_TEST=pool=8 probe "200k medoid upgma, 8 pool threads" -medoidtree -gt upgma -gt_export /tmp/fam_200000.fasta
 probe "3M medoid upgma" -medoidtree -gt upgma -gt_export /tmp/fam_3000000.fasta
-FAMSA_GPU_POOL_THREADS=8 probe "3M medoid upgma, 8 pool threads" -medoidtree -gt upgma -gt_export /tmp/fam_3000000.fasta
+FAMSA_HOST_TEST=pool=8 probe "3M medoid upgma, 8 pool threads" -medoidtree -gt upgma -gt_export /tmp/fam_3000000.fasta
 cat $OUT

@@ -1,22 +1,17 @@
 #!/usr/bin/env python3
-"""Small sets: the LCS triangle of hemopexin (4188 sequences of 21-210 residues = 7 half-word classes = 7 launches) and of
-adeno_fiber, kernel time (HIP events) and host wall time of the call, one launch after the other (default) and with the
-launches spread over side streams (LCSGPU_SPREAD=1).  python scripts/small_launch.py"""
+"""Small sets: the LCS triangle of hemopexin (4188 sequences of 21-210 residues = 7 half-word classes; small neighbouring
+classes share a launch since round 5) and of adeno_fiber: kernel time (HIP events), launches and host wall time of the call.
+python scripts/small_launch.py"""
 import os, sys, time, subprocess, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-if len(sys.argv) == 1:
-    for env in ({}, {"LCSGPU_SPREAD": "1"}):
-        e = dict(os.environ); e.update(env)
-        print(subprocess.run([sys.executable, __file__, "run"], env=e, stdout=subprocess.PIPE, text=True).stdout.strip())
-    sys.exit(0)
 import numpy as np
 import famsa_amd
 from famsa_amd import seqio
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle_bind
 o = oracle_bind.Oracle()
-out = {"spread": "LCSGPU_SPREAD" in os.environ}
+out = {}
 eng = famsa_amd.LcsGpu(0)
 for name in ("hemopexin/hemopexin", "adeno_fiber/adeno_fiber"):
     seqs = []
