@@ -80,8 +80,18 @@ void clarans_drive(lcsgpu_ctx* ctx, ClaransBatcher& B, ClaransJob* mine)
             for (size_t i = 0; i < now.size() && rc == LCSGPU_OK; ++i)
                 hip_ok(hipMemcpyAsync(hs + 64 * i, now[i]->a.state, 64, hipMemcpyDeviceToHost, B.stream), "state read-back");
         if (rc == LCSGPU_OK) hip_ok(hipEventRecord(B.ev, B.stream), "hipEventRecord");
-        if (rc == LCSGPU_OK) hip_ok(hipEventSynchronize(B.ev), "hipEventSynchronize");
-        else (void)hipStreamSynchronize(B.stream);
+        if (rc == LCSGPU_OK) {
+            // the driver of a batch is on the critical path of up to 16 searches: with clarans_spin it polls for the end of
+            // the look (a few microseconds late) instead of sleeping on the event (50-100 us to wake up)
+            static const int spin = tune_int("clarans_spin", 0);
+            if (spin) {
+                hipError_t e;
+                while ((e = hipEventQuery(B.ev)) == hipErrorNotReady) std::this_thread::yield();
+                hip_ok(e, "hipEventQuery");
+            } else
+                hip_ok(hipEventSynchronize(B.ev), "hipEventSynchronize");
+        } else
+            (void)hipStreamSynchronize(B.stream);
         {
             std::lock_guard<std::mutex> lk(B.mu);
             const std::string msg = rc == LCSGPU_OK ? std::string() : std::string(lcsgpu_last_error());

@@ -17,6 +17,7 @@
 #include <mutex>
 #include <random>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/lcsgpu.h"
@@ -28,7 +29,8 @@ namespace lcsgpu_impl {
 int fail(int code, const char* fmt, ...);
 // numeric tuning knobs, LCSGPU_TUNE="key=value,key=value" (no alternate code paths behind them): clarans_stage0 (steps a
 // round evaluates first, 16), clarans_look (rounds between two looks at the done flags, 16), clarans_groups (independent
-// batches of searches, 4), combine_wait_us (how long an LCS request waits for others to share its launches)
+// batches of searches, 4), clarans_spin (1: a batch's driver polls for the end of a look instead of sleeping on it),
+// lcs_share_lds (below), upgma_spare (spare slots of the UPGMA matrix, n / 10)
 int tune_int(const char* key, int dflt);
 
 #define HIP_TRY(expr)                                                                           \
