@@ -195,6 +195,31 @@ int reserve_big(lcsgpu_ctx* ctx, DevBuf& buf, size_t bytes, const char* what)
     return LCSGPU_OK;
 }
 
+int lcs_launch_stream(lcsgpu_ctx* ctx, Lane& L, bool sharing, std::unique_lock<std::mutex>& lock, hipStream_t* out)
+{
+    static const int serial_knob = tune_int("lcs_serial", 0);
+    *out = L.stream;
+    if (!serial_knob || !sharing) return LCSGPU_OK;
+    lock.lock();
+    if (!ctx->serial_stream) HIP_TRY(hipStreamCreateWithFlags(&ctx->serial_stream, hipStreamNonBlocking));
+    if (!L.ev_fork) {
+        HIP_TRY(hipEventCreateWithFlags(&L.ev_fork, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&L.ev_join, hipEventDisableTiming));
+    }
+    HIP_TRY(hipEventRecord(L.ev_fork, L.stream)); // behind the plan's copy and whatever the lane queued before
+    HIP_TRY(hipStreamWaitEvent(ctx->serial_stream, L.ev_fork, 0));
+    *out = ctx->serial_stream;
+    return LCSGPU_OK;
+}
+
+int lcs_launch_join(Lane& L, hipStream_t run_stream)
+{
+    if (run_stream == L.stream) return LCSGPU_OK;
+    HIP_TRY(hipEventRecord(L.ev_join, run_stream));
+    HIP_TRY(hipStreamWaitEvent(L.stream, L.ev_join, 0));
+    return LCSGPU_OK;
+}
+
 // Core: plan + launch.  d_out is a device pointer.
 int run_rows(lcsgpu_ctx* ctx, Lane& L, int mode, const int32_t* ref_ids, int32_t ref_begin, int32_t n_refs,
              const int32_t* col_ids, int32_t col_begin, int32_t n_cols, void* d_out, int64_t ld,
@@ -291,11 +316,18 @@ int run_rows(lcsgpu_ctx* ctx, Lane& L, int mode, const int32_t* ref_ids, int32_t
         L.plan_in_flight = true;
     }
 
-    HIP_TRY(hipEventRecord(L.ev_start, L.stream));
+    // LCSGPU_TUNE lcs_serial=1: the launches of a sharing call (lds_min > 0: the FastTree recursion) go to the context's one
+    // LCS stream, forked from and joined into the lane's stream by events
+    bool serial = lds_min > 0 && !fuse;
+    for (const Bucket& bk : buckets) serial = serial && bk.bv != 0;
+    std::unique_lock<std::mutex> serial_lock(ctx->serial_mu, std::defer_lock);
+    hipStream_t run_stream = L.stream;
+    if (int rc2 = lcs_launch_stream(ctx, L, serial, serial_lock, &run_stream)) return rc2;
+    HIP_TRY(hipEventRecord(L.ev_start, run_stream));
     // (a call whose refs fall into several half-word classes is several launches, one after the other on the lane's stream)
     for (size_t b = 0; b < buckets.size(); ++b) {
         const Bucket& bk = buckets[b];
-        hipStream_t st = L.stream;
+        hipStream_t st = run_stream;
         RowsArgs a{};
         a.tiles = (const uint8_t*)ctx->d_tiles.p;
         a.tile_base = (const uint64_t*)ctx->d_tile_base.p;
@@ -370,7 +402,8 @@ int run_rows(lcsgpu_ctx* ctx, Lane& L, int mode, const int32_t* ref_ids, int32_t
             }
         }
     }
-    HIP_TRY(hipEventRecord(L.ev_stop, L.stream));
+    HIP_TRY(hipEventRecord(L.ev_stop, run_stream));
+    if (int rc2 = lcs_launch_join(L, run_stream)) return rc2;
     L.timing_valid = true;
     return LCSGPU_OK;
 }
@@ -528,6 +561,8 @@ int lcsgpu_destroy(lcsgpu_ctx* ctx)
         if (l.ev_start) (void)hipEventDestroy(l.ev_start);
         if (l.ev_stop) (void)hipEventDestroy(l.ev_stop);
         if (l.ev_done) (void)hipEventDestroy(l.ev_done);
+        if (l.ev_fork) (void)hipEventDestroy(l.ev_fork);
+        if (l.ev_join) (void)hipEventDestroy(l.ev_join);
         if (l.copy_stream) (void)hipStreamDestroy(l.copy_stream);
         if (l.stream) (void)hipStreamDestroy(l.stream);
     }
@@ -545,6 +580,7 @@ int lcsgpu_destroy(lcsgpu_ctx* ctx)
         if (B.ev) (void)hipEventDestroy(B.ev);
         B.h_states.release();
     }
+    if (ctx->serial_stream) { (void)hipStreamSynchronize(ctx->serial_stream); (void)hipStreamDestroy(ctx->serial_stream); }
     ctx->d_tiles.release();
     ctx->d_tile_base.release();
     ctx->d_lens.release();

@@ -300,7 +300,10 @@ static int batch_triangles_to_device(lcsgpu_ctx* ctx, Lane& L, const int32_t* id
     HIP_TRY(hipMemcpyAsync(L.d_plan.p, h, bytes, hipMemcpyHostToDevice, L.stream));
     L.plan_in_flight = true;
     L.last_launches = 0;
-    HIP_TRY(hipEventRecord(L.ev_start, L.stream));
+    std::unique_lock<std::mutex> serial_lock(ctx->serial_mu, std::defer_lock);
+    hipStream_t run_stream = L.stream;
+    if (int rc2 = lcs_launch_stream(ctx, L, true, serial_lock, &run_stream)) return rc2;
+    HIP_TRY(hipEventRecord(L.ev_start, run_stream));
     for (size_t bi = 0; bi < buckets.size(); ++bi) {
         const BatchBucket& b = buckets[bi];
         if (b.jobs.empty()) continue;
@@ -323,10 +326,11 @@ static int batch_triangles_to_device(lcsgpu_ctx* ctx, Lane& L, const int32_t* id
         a.elem_size = elem_size;
         a.mode = lcsgpu::MODE_TRIANGLE;
         a.refs_per_block = b.refs_per_wg;
-        HIP_TRY(lcsgpu::launch_rows(b.bv, b.quirk, a, (int)b.jobs.size(), 1, L.stream, lcs_share_lds()));
+        HIP_TRY(lcsgpu::launch_rows(b.bv, b.quirk, a, (int)b.jobs.size(), 1, run_stream, lcs_share_lds()));
         ++L.last_launches;
     }
-    HIP_TRY(hipEventRecord(L.ev_stop, L.stream));
+    HIP_TRY(hipEventRecord(L.ev_stop, run_stream));
+    if (int rc2 = lcs_launch_join(L, run_stream)) return rc2;
     L.timing_valid = true;
     return LCSGPU_OK;
 }

@@ -99,6 +99,7 @@ struct Lane {
     hipStream_t stream = nullptr;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     hipEvent_t ev_done = nullptr; // blocking-sync event: host-memory calls sleep on it instead of spinning
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr; // LCSGPU_TUNE lcs_serial: this lane's launches travel on the context's one LCS stream
     hipStream_t copy_stream = nullptr; // large host-buffer results leave in slices while the next slice is computed
     lcsgpu_impl::DevBuf d_plan, d_out, d_carry;
     lcsgpu_impl::DevBuf d_work, d_draws; // CLARANS state and its pre-drawn step positions
@@ -179,6 +180,10 @@ struct lcsgpu_ctx {
         bool fused_ready = false;
     } mst;
     double total_kernel_ms = 0; // completed host-memory calls
+    // LCSGPU_TUNE lcs_serial=1 (measurement): the LCS launches of the FastTree recursion, whichever lane asks, run one
+    // after the other on this stream instead of next to each other on the lanes' streams
+    std::mutex serial_mu;
+    hipStream_t serial_stream = nullptr;
     // searches are spread over a few independent batches (each its own stream and driver): rounds of
     // different batches overlap on the GPU, which hides part of a round's memory latency
     std::vector<ClaransBatcher> clarans_groups;
@@ -296,6 +301,11 @@ int run_rows(lcsgpu_ctx* ctx, Lane& L, int mode, const int32_t* ref_ids, int32_t
 // time alone (39 us) but their mean 63 us (profiles/c5_rounds_r05.txt).  Costs those launches ~8 % of their rate
 // (3 instead of 5 waves per SIMD: 543 vs 592 Tcell/s).  LCSGPU_TUNE lcs_share_lds=<bytes> (0 = off).
 size_t lcs_share_lds();
+// LCSGPU_TUNE lcs_serial=1 (measurement): the stream a sharing call's launches go to -- the lane's, or the context's one
+// LCS stream (then `lock` is taken and the stream waits for what the lane has queued); lcs_launch_join makes the lane's
+// stream wait for them again
+int lcs_launch_stream(lcsgpu_ctx* ctx, Lane& L, bool sharing, std::unique_lock<std::mutex>& lock, hipStream_t* out);
+int lcs_launch_join(Lane& L, hipStream_t run_stream);
 // which instantiation the refs of half-word class h run in (target[h] >= h), given wgs[h] = the workgroups class h would
 // have on its own, h = 1 .. 64: small neighbouring classes share a launch (lcsgpu_api.hip)
 void merge_small_classes(const double* wgs, int* target);
