@@ -14,7 +14,7 @@
 // operation order follow the reference line by line; the running cost is summed sequentially from a per-round log
 // of its addends.
 //
-// Layout: D = float triangle over the sample members (D[i*(i-1)/2 + j], j < i).  All search state is
+// Layout: D = the sample members' full symmetric float matrix (D[i*n + j]).  All search state is
 // kept per candidate POSITION (not per member), so the lanes of a wave read it coalesced:
 // st[pos] = nearest / second-nearest bookkeeping, DMt[mm*n + pos] = distance of the member at pos to
 // the medoid in slot mm (kept in step with the swaps so that the reference's updateAssignment scan
@@ -38,10 +38,12 @@ namespace lcsgpu {
 
 namespace {
 
-__device__ __forceinline__ size_t tri_at(int i, int j)
-{
-    return i >= j ? (size_t)j + (size_t)i * (i - 1) / 2 : (size_t)i + (size_t)j * (j - 1) / 2;
-}
+// D is the sample's FULL symmetric matrix, D[i * n + j]: the distances of one member to all others are one contiguous row
+// (n x 4 B = 8 KB at 2000 members), so the per-step gathers D[x][member at position ..] use every byte of the 32-byte
+// sectors they touch.  (In the packed triangle the part j > i of that "row" is a column walk, one sector per element:
+// 34 KB instead of 8 KB per gathered row, and the rounds of ~20 concurrent searches -- 16 step workgroups each, two
+// such rows per workgroup and round -- are bound by exactly that traffic)
+__device__ __forceinline__ size_t sq_at(int n, int i, int j) { return (size_t)i * (size_t)n + (size_t)j; }
 
 // wave-level reductions by DPP (see tree_kernels.hip, wave_first_min): the moves between lanes stay inside the VALU
 template <int CTRL, int ROW_MASK>
@@ -91,15 +93,19 @@ __device__ __forceinline__ int stage_size(int stage, int left, int stage0)
 
 } // namespace
 
-// float distances of the sample: D[tri(i,j)] = transform(LCS(ref = ids[i], partner = ids[j])), j < i
-// (Transform<float, ...>, tree/AbstractTreeGenerator.hpp:28-82, the float table built at upload)
+// float distances of the sample as a full symmetric matrix: D[i * n + j] = D[j * n + i] = transform(LCS(ref = ids[i],
+// partner = ids[j])), j < i (Transform<float, ...>, tree/AbstractTreeGenerator.hpp:28-82, the float table built at upload)
 template <typename T>
 __global__ __launch_bounds__(256) void subset_dist_kernel(const T* __restrict__ lcs, const int32_t* __restrict__ ids,
                                                           const uint32_t* __restrict__ lens,
-                                                          const float* __restrict__ pow_f32, int kind,
+                                                          const float* __restrict__ pow_f32, int kind, int n,
                                                           float* __restrict__ D)
 {
     const int i = blockIdx.x + 1;
+    if (threadIdx.x == 0) {
+        D[(size_t)i * n + i] = 0.0f; // (never read)
+        if (i == 1) D[0] = 0.0f;
+    }
     const uint32_t len_i = lens[ids[i]];
     const size_t row = (size_t)i * (i - 1) / 2;
     for (int j = threadIdx.x; j < i; j += 256) {
@@ -109,7 +115,8 @@ __global__ __launch_bounds__(256) void subset_dist_kernel(const T* __restrict__ 
         if (l == 0) d = FLT_MAX;
         else if (kind == 1) d = __fdiv_rn(pow_f32[indel], (float)l);
         else d = __fdiv_rn((float)indel, (float)l);
-        D[row + j] = d;
+        D[(size_t)i * n + j] = d;
+        D[(size_t)j * n + i] = d;
     }
 }
 
@@ -162,7 +169,7 @@ __global__ __launch_bounds__(256) void clarans_init_kernel(ClaransArgs a)
     Nearest2 nb;
 #pragma unroll 4
     for (int mm = 0; mm < k; ++mm) {
-        const float d = a.D[tri_at(a.cand[mm], y)];
+        const float d = a.D[sq_at(n, a.cand[mm], y)];
         a.DMt[(size_t)mm * n + pos] = d;
         nb.feed(d, mm);
     }
@@ -258,7 +265,7 @@ __device__ __forceinline__ void evaluate_step(const ClaransArgs& a, int xx, int 
 #pragma unroll
     for (int u = 0; u < PER; ++u) { // the gathers from the triangle, all in flight together
         const int t = tid + 512 * u;
-        dxy[u] = (t < cnt && k + t != xx) ? a.D[tri_at(x, y_pre[u])] : 0.0f;
+        dxy[u] = (t < cnt && k + t != xx) ? a.D[sq_at(n, x, y_pre[u])] : 0.0f;
     }
     for (int s = tid; s < k; s += 512) s_x[s] = 0.0f;
     if (tid == 0) s_x[CLARANS_MAX_MEDOIDS] = 0.0f;
@@ -520,7 +527,7 @@ __global__ __launch_bounds__(512, 6) void clarans_round_kernel(ClaransBatch batc
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
             const int pos = k + tid + 512 * u;
-            if (pos < n && pos != xx_acc) d_new[u] = a.D[tri_at(x_acc, y_pre[u])];
+            if (pos < n && pos != xx_acc) d_new[u] = a.D[sq_at(n, x_acc, y_pre[u])];
         }
     }
     const bool have_step = b < S_now;
@@ -540,7 +547,7 @@ __global__ __launch_bounds__(512, 6) void clarans_round_kernel(ClaransBatch batc
                 const int mm = lane + 64 * u;
                 dv[u] = FLT_MAX;
                 if (mm < k) {
-                    dv[u] = a.D[tri_at(mm == mm_new ? x_acc : med_pre[u], m_old)];
+                    dv[u] = a.D[sq_at(n, mm == mm_new ? x_acc : med_pre[u], m_old)];
                     if (committer) a.DMt[(size_t)mm * n + xx_acc] = dv[u];
                 }
             }
@@ -755,10 +762,10 @@ hipError_t launch_subset_distances(const void* lcs, int elem_size, const int32_t
     if (n < 2) return hipSuccess;
     if (elem_size == 2)
         hipLaunchKernelGGL(subset_dist_kernel<uint16_t>, dim3(n - 1), dim3(256), 0, stream, (const uint16_t*)lcs, ids,
-                           lens, pow_f32, kind, D);
+                           lens, pow_f32, kind, n, D);
     else
         hipLaunchKernelGGL(subset_dist_kernel<uint32_t>, dim3(n - 1), dim3(256), 0, stream, (const uint32_t*)lcs, ids,
-                           lens, pow_f32, kind, D);
+                           lens, pow_f32, kind, n, D);
     return hipGetLastError();
 }
 
@@ -770,7 +777,7 @@ hipError_t launch_clarans_init(const ClaransArgs& a, hipStream_t stream)
 
 // `rounds` launches of clarans_round_kernel (an even number: the host reads the parity-0 buffers).  The first window of a
 // local search has `corrected` steps, the later ones corrected - 1 (the reference resets its step counter to 1 after an accept).
-hipError_t launch_clarans_rounds(const ClaransBatch& b, int rounds, hipStream_t stream)
+hipError_t launch_clarans_rounds(const ClaransBatch& b, int rounds, int max_step_workgroups, hipStream_t stream)
 {
     int kpt = 1, steps = 1;
     for (int i = 0; i < b.n; ++i) {
@@ -778,6 +785,7 @@ hipError_t launch_clarans_rounds(const ClaransBatch& b, int rounds, hipStream_t 
         kpt = std::max(kpt, ((a.n_medoids + 7) / 8 + 63) / 64);
         steps = std::max(steps, std::min(std::min(a.corrected, STAGE_MAX), std::max(a.stage0, 1)));
     }
+    steps = std::max(1, std::min(steps, max_step_workgroups));
     const dim3 grid(steps + 1, b.n), block(512); // a first stage's steps (later stages: several steps per workgroup) + the cost workgroup
     for (int r = 0; r < rounds; ++r) {
         const int last = r == rounds - 1 ? 1 : 0;

@@ -266,7 +266,7 @@ hipError_t launch_build_set(const uint8_t* codes, const uint64_t* offsets, const
 constexpr int CLARANS_MAX_MEDOIDS = 1024;
 constexpr int CLARANS_MAX_NONMEDOIDS = 2048; // every position's state in the registers of one workgroup
 struct ClaransArgs {
-    const float* D;      // float distance triangle over the sample members
+    const float* D;      // the sample members' float distances, full symmetric matrix D[i * n_elems + j]
     float* DMt;          // [n_medoids][n_elems] distance of the member at a position to the medoid in a slot
     int32_t* cand;       // [n_elems] permutation of the members; positions < n_medoids are the medoids
     float4* st;          // [n_elems] by position: {d(nearest), d(second), slot(nearest), slot(second)}
@@ -298,6 +298,7 @@ struct ClaransBatch {
 hipError_t launch_subset_distances(const void* lcs, int elem_size, const int32_t* ids, const uint32_t* lens,
                                    const float* pow_f32, int kind, int n, float* D, hipStream_t stream);
 hipError_t launch_clarans_init(const ClaransArgs& a, hipStream_t stream);
-hipError_t launch_clarans_rounds(const ClaransBatch& b, int rounds, hipStream_t stream); // rounds even
+// rounds even; max_step_workgroups: step workgroups per search at most (fewer than a stage's steps: several steps each)
+hipError_t launch_clarans_rounds(const ClaransBatch& b, int rounds, int max_step_workgroups, hipStream_t stream);
 
 } // namespace lcsgpu

@@ -75,7 +75,8 @@ void clarans_drive(lcsgpu_ctx* ctx, ClaransBatcher& B, ClaransJob* mine)
             s1.host_state = hs_dev ? hs_dev + 64 * batch.n : nullptr;
             ++batch.n;
         }
-        if (rc == LCSGPU_OK) hip_ok(lcsgpu::launch_clarans_rounds(batch, rounds_per_look, B.stream), "CLARANS rounds");
+        static const int step_wgs = std::max(1, tune_int("clarans_wgs", 64)); // step workgroups per search and launch at most
+        if (rc == LCSGPU_OK) hip_ok(lcsgpu::launch_clarans_rounds(batch, rounds_per_look, step_wgs, B.stream), "CLARANS rounds");
         if (!hs_dev)
             for (size_t i = 0; i < now.size() && rc == LCSGPU_OK; ++i)
                 hip_ok(hipMemcpyAsync(hs + 64 * i, now[i]->a.state, 64, hipMemcpyDeviceToHost, B.stream), "state read-back");
@@ -458,7 +459,7 @@ int lcsgpu_clarans(lcsgpu_ctx* ctx, const int32_t* ids, int32_t n_ids, int dista
     const int elem = ctx->max_len > 65535 ? 4 : 2;
     const size_t pairs = (size_t)n * (n - 1) / 2;
     auto a256 = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    const size_t o_D = 0, o_DM = o_D + a256(pairs * 4), o_cand = o_DM + a256((size_t)n * k * 4), o_st = o_cand + a256((size_t)n * 4),
+    const size_t o_D = 0, o_DM = o_D + a256((size_t)n * n * 4), o_cand = o_DM + a256((size_t)n * k * 4), o_st = o_cand + a256((size_t)n * 4),
                  o_log = o_st + a256((size_t)n * 16), o_state = o_log + a256((size_t)(n + 1) * 4), o_ids = o_state + 256,
                  // the second copies (by round parity) and the step results: clarans_round_kernel
                  o_cand1 = o_ids + a256((size_t)n * 4), o_st1 = o_cand1 + a256((size_t)n * 4), o_log1 = o_st1 + a256((size_t)n * 16),
