@@ -513,7 +513,11 @@ int lcsgpu_mst_prim(lcsgpu_ctx* ctx, int distance_kind, lcsgpu_mst_edge* out_edg
             }
             rc = shard_merge(ctx, L, gathered, 2, nullptr);
         }
+        const auto t_fin = std::chrono::steady_clock::now();
         if (!rc) rc = shard_finish(ctx, L, out_edges);
+        if (getenv("LCSGPU_PROFILE"))
+            fprintf(stderr, "lcsgpu_mst_prim: %d rounds; edges to the host + Prim's order %.3f s\n", ctx->mst.rounds,
+                    std::chrono::duration<double>(std::chrono::steady_clock::now() - t_fin).count());
         ctx->mst.active = false; // the triangle it points to belongs to this call
         if (rc) return rc;
         note_async_call(ctx);

@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -88,7 +89,11 @@ void mst_prim(LcsSource& src, tree_structure& tree)
     prim_order[0] = next_order++;
 
     std::vector<LcsSource::MstEdge> dev_edges;
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto since_begin = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count(); };
+    double t_edges = 0;
     if (src.prim_edges((int)D, dev_edges, /*triangle_orientation=*/false)) {
+        t_edges = since_begin();
         // the engine ran the n-1 relaxation steps on the device; replay the bookkeeping
         for (const auto& e : dev_edges) {
             edges.push_back(Edge{e.from, e.to, next_order, -e.dist});
@@ -148,6 +153,7 @@ void mst_prim(LcsSource& src, tree_structure& tree)
         }
     }
 
+    const double t_replay = since_begin();
     // mst_to_dendogram (reference MSTPrim.cpp:784-833): split every range of the Prim order at
     // its heaviest edge, breadth first, node ids handed out from 2n-2 downwards
     std::vector<int> rev(n);
@@ -198,6 +204,9 @@ void mst_prim(LcsSource& src, tree_structure& tree)
         }
         tree[r.id] = node_t(left, right);
     }
+    if (profile_on())
+        fprintf(stderr, "mst_prim (host): the source's edges %.3f s, Prim bookkeeping %.3f s, MST -> dendrogram %.3f s\n", t_edges,
+                t_replay - t_edges, since_begin() - t_replay);
 }
 
 // ---------------------------------------------------------------------------------------------

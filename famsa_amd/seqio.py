@@ -114,10 +114,8 @@ def family_fasta(n, length, path, seed=1234):
             mut = rng.random((m, length)) < 0.25
             S[mut] = rng.integers(0, 20, size=int(mut.sum()), dtype=np.uint8)
             lens = rng.integers(int(length * 0.7), length + 1, size=m)
-            for i in range(m):
-                out.write(b">s%d\n" % (b0 + i))
-                out.write(A[S[i, : lens[i]]].tobytes())
-                out.write(b"\n")
+            rows = A[S]  # residue letters, one row per member
+            out.write(b"".join(b">s%d\n%s\n" % (b0 + i, rows[i, : lens[i]].tobytes()) for i in range(m)))
     return path
 
 

@@ -189,7 +189,12 @@ def test_row_minima_of_a_row_block(engine, oracle):
                 assert d[i - r0] == m and j[i - r0] == int(np.max(np.nonzero(dd == m)[0])), (kind, r0, i)
 
 
+_ONE_RANK = {}
+
+
 def _bench(args, world, torchrun=True):
+    if world == 1 and tuple(args) in _ONE_RANK:  # several tests compare with the same one-rank line
+        return _ONE_RANK[tuple(args)]
     env = dict(os.environ)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
@@ -202,18 +207,20 @@ def _bench(args, world, torchrun=True):
     p = subprocess.run(cmd + ["--gpus", str(world)] + args, capture_output=True, text=True, env=env, timeout=900)
     assert p.returncode == 0, p.stderr[-3000:]
     import json
-    return json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    rec = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    if world == 1:
+        _ONE_RANK[tuple(args)] = rec
+    return rec
 
 
 def test_bench_step_ends_in_the_same_tree_for_every_rank_count():
     """bench.py --gpus N (ranks sharing cuda:0, gloo exchange): the MST edge-list hash it prints does not
     depend on N, and the sampled oracle check of the timed triangle passes inside it."""
-    args = ["--steps", "1", "--warmup", "1", "--n-seqs", "6000", "--seq-len", "120", "--no-cpu-baseline"]
+    args = ["--steps", "1", "--warmup", "1", "--n-seqs", "5000", "--seq-len", "120", "--no-cpu-baseline"]
     one = _bench(args, 1)
-    two = _bench(args, 2)
-    three = _bench(args, 3)
-    assert one["mst"]["edges_sha256"] == two["mst"]["edges_sha256"] == three["mst"]["edges_sha256"]
-    assert one["mst"]["n_edges"] == 5999 and two["n_gpus"] == 2 and three["n_gpus"] == 3
+    two = _bench(args, 2)  # under torch.distributed.run, as the driver starts it
+    assert one["mst"]["edges_sha256"] == two["mst"]["edges_sha256"]
+    assert one["mst"]["n_edges"] == 4999 and two["n_gpus"] == 2
     assert one["parity"]["sampled_pairs"] > 0 and one["parity"]["mismatches"] == 0
     assert two["parity"]["mismatches"] == 0
 
@@ -225,14 +232,16 @@ def test_bench_starts_its_own_ranks():
     kernel times; the hash equals the one-rank hash."""
     args = ["--steps", "1", "--warmup", "1", "--n-seqs", "5000", "--seq-len", "120", "--no-cpu-baseline"]
     one = _bench(args, 1)
-    two = _bench(args + ["--emulate-ranks-on-one-gpu"], 2, torchrun=False)
     three = _bench(args + ["--emulate-ranks-on-one-gpu"], 3, torchrun=False)
-    for rec, w in ((two, 2), (three, 3)):
+    for rec, w in ((three, 3),):
         assert rec["n_gpus"] == w and rec["mst"]["edges_sha256"] == one["mst"]["edges_sha256"]
         r = rec["ranks"]
         assert r["world"] == w and len(r["kernel_ms_per_rank"]) == w and r["kernel_ms_min"] > 0
         assert r["self_check"]["ranks_agree"] and r["self_check"]["n_seqs"] == 2000
         assert rec["parity"]["mismatches"] == 0
+        # what the ranks talk over, collected before anything was timed
+        t = r["transport_report"]
+        assert t["devices_visible"] >= 1 and isinstance(t["peer_access"], list) and "rccl_version" in t
     assert one["ranks"]["self_check"] is None and one["ranks"]["rccl_ranks"] is None
 
 
