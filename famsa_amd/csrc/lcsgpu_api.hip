@@ -159,8 +159,11 @@ int ensure_batcher(lcsgpu_ctx* ctx, ClaransBatcher& B)
     if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = greatest = 0;
     if (greatest != least) HIP_TRY(hipStreamCreateWithPriority(&B.stream, hipStreamNonBlocking, greatest));
     else HIP_TRY(hipStreamCreateWithFlags(&B.stream, hipStreamNonBlocking));
-    HIP_TRY(hipEventCreateWithFlags(&B.ev, hipEventBlockingSync | hipEventDisableTiming));
-    HIP_TRY(B.h_states.reserve(lcsgpu::CLARANS_MAX_BATCH * 256));
+    for (int h = 0; h < 2; ++h) HIP_TRY(hipEventCreateWithFlags(&B.ev[h], hipEventBlockingSync | hipEventDisableTiming));
+    HIP_TRY(B.h_states.reserve((size_t)2 * lcsgpu::CLARANS_MAX_BATCH * 256));
+    HIP_TRY(B.d_slots.reserve((size_t)ClaransBatcher::N_SLOTS * 512));
+    B.free_slots.resize(ClaransBatcher::N_SLOTS);
+    for (int s = 0; s < ClaransBatcher::N_SLOTS; ++s) B.free_slots[s] = ClaransBatcher::N_SLOTS - 1 - s;
     return LCSGPU_OK;
 }
 
@@ -192,31 +195,6 @@ int reserve_big(lcsgpu_ctx* ctx, DevBuf& buf, size_t bytes, const char* what)
         return fail(LCSGPU_E_NOMEM, "%s: allocating %.1f GB of device memory failed: %s", what, bytes / 1e9,
                     hipGetErrorString(e));
     }
-    return LCSGPU_OK;
-}
-
-int lcs_launch_stream(lcsgpu_ctx* ctx, Lane& L, bool sharing, std::unique_lock<std::mutex>& lock, hipStream_t* out)
-{
-    static const int serial_knob = tune_int("lcs_serial", 0);
-    *out = L.stream;
-    if (!serial_knob || !sharing) return LCSGPU_OK;
-    lock.lock();
-    if (!ctx->serial_stream) HIP_TRY(hipStreamCreateWithFlags(&ctx->serial_stream, hipStreamNonBlocking));
-    if (!L.ev_fork) {
-        HIP_TRY(hipEventCreateWithFlags(&L.ev_fork, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&L.ev_join, hipEventDisableTiming));
-    }
-    HIP_TRY(hipEventRecord(L.ev_fork, L.stream)); // behind the plan's copy and whatever the lane queued before
-    HIP_TRY(hipStreamWaitEvent(ctx->serial_stream, L.ev_fork, 0));
-    *out = ctx->serial_stream;
-    return LCSGPU_OK;
-}
-
-int lcs_launch_join(Lane& L, hipStream_t run_stream)
-{
-    if (run_stream == L.stream) return LCSGPU_OK;
-    HIP_TRY(hipEventRecord(L.ev_join, run_stream));
-    HIP_TRY(hipStreamWaitEvent(L.stream, L.ev_join, 0));
     return LCSGPU_OK;
 }
 
@@ -316,13 +294,7 @@ int run_rows(lcsgpu_ctx* ctx, Lane& L, int mode, const int32_t* ref_ids, int32_t
         L.plan_in_flight = true;
     }
 
-    // LCSGPU_TUNE lcs_serial=1: the launches of a sharing call (lds_min > 0: the FastTree recursion) go to the context's one
-    // LCS stream, forked from and joined into the lane's stream by events
-    bool serial = lds_min > 0 && !fuse;
-    for (const Bucket& bk : buckets) serial = serial && bk.bv != 0;
-    std::unique_lock<std::mutex> serial_lock(ctx->serial_mu, std::defer_lock);
-    hipStream_t run_stream = L.stream;
-    if (int rc2 = lcs_launch_stream(ctx, L, serial, serial_lock, &run_stream)) return rc2;
+    const hipStream_t run_stream = L.stream;
     HIP_TRY(hipEventRecord(L.ev_start, run_stream));
     // (a call whose refs fall into several half-word classes is several launches, one after the other on the lane's stream)
     for (size_t b = 0; b < buckets.size(); ++b) {
@@ -403,7 +375,6 @@ int run_rows(lcsgpu_ctx* ctx, Lane& L, int mode, const int32_t* ref_ids, int32_t
         }
     }
     HIP_TRY(hipEventRecord(L.ev_stop, run_stream));
-    if (int rc2 = lcs_launch_join(L, run_stream)) return rc2;
     L.timing_valid = true;
     return LCSGPU_OK;
 }
@@ -561,8 +532,6 @@ int lcsgpu_destroy(lcsgpu_ctx* ctx)
         if (l.ev_start) (void)hipEventDestroy(l.ev_start);
         if (l.ev_stop) (void)hipEventDestroy(l.ev_stop);
         if (l.ev_done) (void)hipEventDestroy(l.ev_done);
-        if (l.ev_fork) (void)hipEventDestroy(l.ev_fork);
-        if (l.ev_join) (void)hipEventDestroy(l.ev_join);
         if (l.copy_stream) (void)hipStreamDestroy(l.copy_stream);
         if (l.stream) (void)hipStreamDestroy(l.stream);
     }
@@ -577,10 +546,11 @@ int lcsgpu_destroy(lcsgpu_ctx* ctx)
                             "steps_without_a_closer_member=%ld steps_without_a_slot_that_can_go_negative=%ld\n", B.prof_searches,
                     B.prof_accepts, B.prof_rounds, B.prof_steps, B.prof_useful, B.prof_no_b, B.prof_no_p);
         if (B.stream) { (void)hipStreamSynchronize(B.stream); (void)hipStreamDestroy(B.stream); }
-        if (B.ev) (void)hipEventDestroy(B.ev);
+        for (int h = 0; h < 2; ++h)
+            if (B.ev[h]) (void)hipEventDestroy(B.ev[h]);
         B.h_states.release();
+        B.d_slots.release();
     }
-    if (ctx->serial_stream) { (void)hipStreamSynchronize(ctx->serial_stream); (void)hipStreamDestroy(ctx->serial_stream); }
     ctx->d_tiles.release();
     ctx->d_tile_base.release();
     ctx->d_lens.release();

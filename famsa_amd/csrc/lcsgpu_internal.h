@@ -12,6 +12,7 @@
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <limits>
 #include <map>
 #include <mutex>
@@ -29,8 +30,9 @@ namespace lcsgpu_impl {
 int fail(int code, const char* fmt, ...);
 // numeric tuning knobs, LCSGPU_TUNE="key=value,key=value" (no alternate code paths behind them): clarans_stage0 (steps a
 // round evaluates first, 16), clarans_look (rounds between two looks at the done flags, 16), clarans_groups (independent
-// batches of searches, 4), clarans_spin (1: a batch's driver polls for the end of a look instead of sleeping on it),
-// lcs_share_lds (below), upgma_spare (spare slots of the UPGMA matrix, n / 10)
+// batches of searches, 4), clarans_depth (looks of a batch in flight, 2; 1 = the host reads a look before it enqueues the
+// next), clarans_wgs (step workgroups per search and launch, 64), lcs_share_lds (below),
+// upgma_spare (spare slots of the UPGMA matrix, n / 10)
 int tune_int(const char* key, int dflt);
 
 #define HIP_TRY(expr)                                                                           \
@@ -99,7 +101,6 @@ struct Lane {
     hipStream_t stream = nullptr;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     hipEvent_t ev_done = nullptr; // blocking-sync event: host-memory calls sleep on it instead of spinning
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr; // LCSGPU_TUNE lcs_serial: this lane's launches travel on the context's one LCS stream
     hipStream_t copy_stream = nullptr; // large host-buffer results leave in slices while the next slice is computed
     lcsgpu_impl::DevBuf d_plan, d_out, d_carry;
     lcsgpu_impl::DevBuf d_work, d_draws; // CLARANS state and its pre-drawn step positions
@@ -117,27 +118,50 @@ struct Lane {
 
 // Local searches of several host threads advanced together (lcs_kernels.h, ClaransBatch): every
 // search joins with its device state ready; whichever owner finds no driver becomes the driver and
-// enqueues the rounds for ALL joined searches, looking at their done flags every `rounds_per_look`
-// rounds; a driver whose own search has finished hands the role to one of the remaining owners.
+// enqueues the rounds for ALL joined searches in "looks" of `rounds_per_look` rounds, reading their done flags after
+// each; a driver whose own search has finished hands the role to one of the remaining owners.
+// TWO LOOKS ARE KEPT IN FLIGHT (round 5): the host's part of a look -- the draws, 16 launches, waking up on the event,
+// reading the states: ~0.3 ms against 0.9 ms of rounds -- used to leave the batch's stream idle a quarter of the time.
+// The look behind the one being read is enqueued before any result is known, so a search that has finished is still in
+// it (its rounds do nothing but pass its state block on).  Therefore: the state blocks live in the BATCHER's memory (a
+// slot per search, given back only when every look that names it has completed), the owner is released at once (what
+// the later look still reads of its lane's buffers is ignored), and a look's records are matched to searches by
+// ticket, never by pointer.
 struct ClaransJob {
     lcsgpu::ClaransArgs a;
     std::mt19937* gen_positions = nullptr; // the owner's position generator (Clustering.cpp:44)
     std::vector<int32_t>* draws = nullptr; // its output so far, as accepted draws
     lcsgpu_impl::DevBuf* d_draws = nullptr;
     int32_t p_host = 0;
+    uint64_t ticket = 0; // names this search in the batcher's looks
+    int slot = -1;       // its state blocks in the batcher's slot memory
     int32_t state[16] = {0};
     bool done = false;
     int rc = LCSGPU_OK;
     std::string error;
 };
+struct ClaransLook { // a look in flight
+    std::vector<uint64_t> tickets; // the searches it advances, in the order of its grid rows / state records
+    int half = 0;                  // which event and which half of the pinned state records it uses
+    int rc = 0;
+    std::string error;
+    std::chrono::steady_clock::time_point t0;
+};
 struct ClaransBatcher {
+    static constexpr int N_SLOTS = 256;
     std::mutex mu;
     std::condition_variable cv;
-    std::vector<ClaransJob*> joined;
+    std::map<uint64_t, ClaransJob*> live; // joined and not finished, by ticket (= by age)
+    uint64_t next_ticket = 1;
     bool driver_present = false;
     hipStream_t stream = nullptr;
-    hipEvent_t ev = nullptr;
-    lcsgpu_impl::PinBuf h_states;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    std::deque<ClaransLook> ring;         // looks in flight, oldest first (the driver's; at most two)
+    uint64_t looks_enqueued = 0, looks_completed = 0;
+    lcsgpu_impl::DevBuf d_slots;          // [N_SLOTS][2 parities][64 words]: the searches' state blocks
+    std::vector<int> free_slots;
+    std::vector<std::pair<int, uint64_t>> retiring; // (slot, free once looks_completed reaches this)
+    lcsgpu_impl::PinBuf h_states;         // [2 halves][CLARANS_MAX_BATCH][64 words]
     // LCSGPU_PROFILE: looks and seconds by number of searches in the batch
     long prof_looks[lcsgpu::CLARANS_MAX_BATCH + 1] = {0};
     double prof_seconds[lcsgpu::CLARANS_MAX_BATCH + 1] = {0};
@@ -180,10 +204,6 @@ struct lcsgpu_ctx {
         bool fused_ready = false;
     } mst;
     double total_kernel_ms = 0; // completed host-memory calls
-    // LCSGPU_TUNE lcs_serial=1 (measurement): the LCS launches of the FastTree recursion, whichever lane asks, run one
-    // after the other on this stream instead of next to each other on the lanes' streams
-    std::mutex serial_mu;
-    hipStream_t serial_stream = nullptr;
     // searches are spread over a few independent batches (each its own stream and driver): rounds of
     // different batches overlap on the GPU, which hides part of a round's memory latency
     std::vector<ClaransBatcher> clarans_groups;
@@ -301,11 +321,6 @@ int run_rows(lcsgpu_ctx* ctx, Lane& L, int mode, const int32_t* ref_ids, int32_t
 // time alone (39 us) but their mean 63 us (profiles/c5_rounds_r05.txt).  Costs those launches ~8 % of their rate
 // (3 instead of 5 waves per SIMD: 543 vs 592 Tcell/s).  LCSGPU_TUNE lcs_share_lds=<bytes> (0 = off).
 size_t lcs_share_lds();
-// LCSGPU_TUNE lcs_serial=1 (measurement): the stream a sharing call's launches go to -- the lane's, or the context's one
-// LCS stream (then `lock` is taken and the stream waits for what the lane has queued); lcs_launch_join makes the lane's
-// stream wait for them again
-int lcs_launch_stream(lcsgpu_ctx* ctx, Lane& L, bool sharing, std::unique_lock<std::mutex>& lock, hipStream_t* out);
-int lcs_launch_join(Lane& L, hipStream_t run_stream);
 // which instantiation the refs of half-word class h run in (target[h] >= h), given wgs[h] = the workgroups class h would
 // have on its own, h = 1 .. 64: small neighbouring classes share a launch (lcsgpu_api.hip)
 void merge_small_classes(const double* wgs, int* target);
