@@ -12,7 +12,6 @@
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
-#include <deque>
 #include <limits>
 #include <map>
 #include <mutex>
@@ -30,9 +29,7 @@ namespace lcsgpu_impl {
 int fail(int code, const char* fmt, ...);
 // numeric tuning knobs, LCSGPU_TUNE="key=value,key=value" (no alternate code paths behind them): clarans_stage0 (steps a
 // round evaluates first, 16), clarans_look (rounds between two looks at the done flags, 16), clarans_groups (independent
-// batches of searches, 4), clarans_depth (looks of a batch in flight, 2; 1 = the host reads a look before it enqueues the
-// next), clarans_wgs (step workgroups per search and launch, 64), lcs_share_lds (below),
-// upgma_spare (spare slots of the UPGMA matrix, n / 10)
+// batches of searches, 4), clarans_wgs (step workgroups per search and launch, 64), lcs_share_lds (below), upgma_spare (spare slots of the UPGMA matrix, n / 10)
 int tune_int(const char* key, int dflt);
 
 #define HIP_TRY(expr)                                                                           \
@@ -118,50 +115,27 @@ struct Lane {
 
 // Local searches of several host threads advanced together (lcs_kernels.h, ClaransBatch): every
 // search joins with its device state ready; whichever owner finds no driver becomes the driver and
-// enqueues the rounds for ALL joined searches in "looks" of `rounds_per_look` rounds, reading their done flags after
-// each; a driver whose own search has finished hands the role to one of the remaining owners.
-// TWO LOOKS ARE KEPT IN FLIGHT (round 5): the host's part of a look -- the draws, 16 launches, waking up on the event,
-// reading the states: ~0.3 ms against 0.9 ms of rounds -- used to leave the batch's stream idle a quarter of the time.
-// The look behind the one being read is enqueued before any result is known, so a search that has finished is still in
-// it (its rounds do nothing but pass its state block on).  Therefore: the state blocks live in the BATCHER's memory (a
-// slot per search, given back only when every look that names it has completed), the owner is released at once (what
-// the later look still reads of its lane's buffers is ignored), and a look's records are matched to searches by
-// ticket, never by pointer.
+// enqueues the rounds for ALL joined searches, looking at their done flags every `rounds_per_look`
+// rounds; a driver whose own search has finished hands the role to one of the remaining owners.
 struct ClaransJob {
     lcsgpu::ClaransArgs a;
     std::mt19937* gen_positions = nullptr; // the owner's position generator (Clustering.cpp:44)
     std::vector<int32_t>* draws = nullptr; // its output so far, as accepted draws
     lcsgpu_impl::DevBuf* d_draws = nullptr;
     int32_t p_host = 0;
-    uint64_t ticket = 0; // names this search in the batcher's looks
-    int slot = -1;       // its state blocks in the batcher's slot memory
     int32_t state[16] = {0};
     bool done = false;
     int rc = LCSGPU_OK;
     std::string error;
 };
-struct ClaransLook { // a look in flight
-    std::vector<uint64_t> tickets; // the searches it advances, in the order of its grid rows / state records
-    int half = 0;                  // which event and which half of the pinned state records it uses
-    int rc = 0;
-    std::string error;
-    std::chrono::steady_clock::time_point t0;
-};
 struct ClaransBatcher {
-    static constexpr int N_SLOTS = 256;
     std::mutex mu;
     std::condition_variable cv;
-    std::map<uint64_t, ClaransJob*> live; // joined and not finished, by ticket (= by age)
-    uint64_t next_ticket = 1;
+    std::vector<ClaransJob*> joined;
     bool driver_present = false;
     hipStream_t stream = nullptr;
-    hipEvent_t ev[2] = {nullptr, nullptr};
-    std::deque<ClaransLook> ring;         // looks in flight, oldest first (the driver's; at most two)
-    uint64_t looks_enqueued = 0, looks_completed = 0;
-    lcsgpu_impl::DevBuf d_slots;          // [N_SLOTS][2 parities][64 words]: the searches' state blocks
-    std::vector<int> free_slots;
-    std::vector<std::pair<int, uint64_t>> retiring; // (slot, free once looks_completed reaches this)
-    lcsgpu_impl::PinBuf h_states;         // [2 halves][CLARANS_MAX_BATCH][64 words]
+    hipEvent_t ev = nullptr;
+    lcsgpu_impl::PinBuf h_states;
     // LCSGPU_PROFILE: looks and seconds by number of searches in the batch
     long prof_looks[lcsgpu::CLARANS_MAX_BATCH + 1] = {0};
     double prof_seconds[lcsgpu::CLARANS_MAX_BATCH + 1] = {0};
