@@ -405,6 +405,123 @@ __device__ __forceinline__ void evaluate_step(const ClaransArgs& a, int xx, int 
     }
 }
 
+// What an accept -- the member x_acc becomes the medoid of slot mm_new -- does to a non-medoid position that keeps its
+// member (Clustering.cpp:124-238, branch by branch): dnw = the member's distance to the new medoid; the position's addend
+// to the running cost; `need`: the position has to look at all k slots again.
+__device__ __forceinline__ void apply_accept_to_position(float4& st, float dnw, int mm_new, float& addend, bool& need)
+{
+    const float4 s0 = st;
+    const float dn_y = s0.x, ds_y = s0.y;
+    const int an_y = __float_as_int(s0.z), as_y = __float_as_int(s0.w);
+    float4 out = s0;
+    if (an_y == mm_new) { // its medoid is the one that left
+        if (dnw < ds_y) {
+            out.x = dnw;
+            addend = __fsub_rn(dnw, dn_y);
+        } else {
+            need = true;
+            addend = __fsub_rn(ds_y, dn_y);
+        }
+    } else if (dnw < dn_y) {
+        out = pack_state(dnw, dn_y, mm_new, an_y);
+        addend = __fsub_rn(dnw, dn_y);
+    } else if (as_y != mm_new && dnw < ds_y) {
+        out.y = dnw;
+        out.w = __int_as_float(mm_new);
+    } else if (as_y != mm_new && dnw > ds_y) {
+        // Neither of its two nearest slots is the one that changed, and the new medoid is strictly farther than the
+        // second: the reference rescans here (Clustering.cpp:228-232) and arrives at the same two distances.  Which
+        // SLOTS it names can differ from what is kept here only among slots at EQUAL distance (the reference's
+        // incremental branches themselves leave such states: d_new == dn with a smaller slot keeps `an`; a later
+        // rescan swaps them) -- and with dn == ds either order gives the same addends (own = other = 0 or both
+        // d - dn), the same cost and the same later branches' values; only the labels of a tie may differ.
+        // Equality with the second stays with the rescan: there the slot order decides what is stored.
+    } else {
+        need = true;
+    }
+    st = out;
+}
+
+template <int PER>
+__device__ __forceinline__ void rescan_positions(const ClaransArgs& a, const bool* need, const float* d_new, float4* s_pre, int mm_new)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int k = a.n_medoids, n = a.n_elems;
+    // The rescans (a few dozen positions per accept, but nearly every wave has one): a lane walking its position's k
+    // distances alone waits for k / 8 dependent batches of scattered loads.  Instead the WAVE takes each such position:
+    // lane m loads the distance to slot m (+ 64, ...), all of a group's loads in flight together, and the two nearest
+    // slots are two wave minima -- "first minimum over the slots, then first minimum over the rest", which is what
+    // the sequential scan of Clustering.cpp:262-305 arrives at.
+    const int kq = (k + 63) >> 6;
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        unsigned long long todo = __ballot(need[u]);
+        while (todo) {
+            int rl[4];
+            int cnt = 0;
+            while (cnt < 4 && todo) {
+                rl[cnt++] = (int)__builtin_ctzll(todo);
+                todo &= todo - 1;
+            }
+            if (kq <= 2) {
+                float v[4][2];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int pos_r = k + wave * 64 + (c < cnt ? rl[c] : rl[0]) + 512 * u;
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const int mm = lane + 64 * q;
+                        v[c][q] = (c < cnt && mm < k) ? a.DMt[(size_t)mm * n + pos_r] : FLT_MAX;
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    if (c >= cnt) break;
+                    const float dnw_r = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d_new[u]), rl[c]));
+                    float dv[2];
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) dv[q] = (lane + 64 * q == mm_new) ? dnw_r : v[c][q];
+                    float v1 = FLT_MAX, v2 = FLT_MAX;
+                    int i1 = INT_MAX, i2 = INT_MAX;
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const int mm = lane + 64 * q;
+                        if (mm < k && (dv[q] < v1 || i1 == INT_MAX)) { v1 = dv[q]; i1 = mm; }
+                    }
+                    wave_first_min_valid(v1, i1);
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const int mm = lane + 64 * q;
+                        if (mm < k && mm != i1 && (dv[q] < v2 || i2 == INT_MAX)) { v2 = dv[q]; i2 = mm; }
+                    }
+                    wave_first_min_valid(v2, i2);
+                    const bool has1 = i1 != INT_MAX && v1 < FLT_MAX, has2 = i2 != INT_MAX && v2 < FLT_MAX;
+                    if (lane == rl[c]) s_pre[u] = pack_state(has1 ? v1 : FLT_MAX, has2 ? v2 : FLT_MAX, has1 ? i1 : -1, has2 ? i2 : -1);
+                }
+            } else { // more than 128 slots: every such lane scans its own column (the apply kernel's loop)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    if (c < cnt && lane == rl[c]) {
+                        const int pos = k + tid + 512 * u;
+                        const float dnw = d_new[u];
+                        Nearest2 nb;
+                        const float* col = a.DMt + pos;
+                        for (int m0 = 0; m0 < k; m0 += 8) {
+                            float vv[8];
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) vv[q] = col[(size_t)min(m0 + q, k - 1) * n];
+#pragma unroll
+                            for (int q = 0; q < 8; ++q)
+                                if (m0 + q < k) nb.feed(m0 + q == mm_new ? dnw : vv[q], m0 + q);
+                        }
+                        s_pre[u] = pack_state(nb.dn, nb.ds, nb.an, nb.as);
+                    }
+                }
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // A ROUND AS ONE LAUNCH.
 //
@@ -584,111 +701,9 @@ __global__ __launch_bounds__(512, 6) void clarans_round_kernel(ClaransBatch batc
                 addend[u] = s_pre[u].x;
                 continue;
             }
-            const float4 s0 = s_pre[u];
-            const float dn_y = s0.x, ds_y = s0.y;
-            const int an_y = __float_as_int(s0.z), as_y = __float_as_int(s0.w);
-            const float dnw = d_new[u];
-            float4 out = s0;
-            if (an_y == mm_new) { // its medoid is the one that left
-                if (dnw < ds_y) {
-                    out.x = dnw;
-                    addend[u] = __fsub_rn(dnw, dn_y);
-                } else {
-                    need[u] = true;
-                    addend[u] = __fsub_rn(ds_y, dn_y);
-                }
-            } else if (dnw < dn_y) {
-                out = pack_state(dnw, dn_y, mm_new, an_y);
-                addend[u] = __fsub_rn(dnw, dn_y);
-            } else if (as_y != mm_new && dnw < ds_y) {
-                out.y = dnw;
-                out.w = __int_as_float(mm_new);
-            } else if (as_y != mm_new && dnw > ds_y) {
-                // Neither of its two nearest slots is the one that changed, and the new medoid is strictly farther than the
-                // second: the reference rescans here (Clustering.cpp:228-232) and arrives at the same two distances.  Which
-                // SLOTS it names can differ from what is kept here only among slots at EQUAL distance (the reference's
-                // incremental branches themselves leave such states: d_new == dn with a smaller slot keeps `an`; a later
-                // rescan swaps them) -- and with dn == ds either order gives the same addends (own = other = 0 or both
-                // d - dn), the same cost and the same later branches' values; only the labels of a tie may differ.
-                // Equality with the second stays with the rescan: there the slot order decides what is stored.
-            } else {
-                need[u] = true;
-            }
-            s_pre[u] = out;
+            apply_accept_to_position(s_pre[u], d_new[u], mm_new, addend[u], need[u]);
         }
-        // The rescans (a few dozen positions per accept, but nearly every wave has one): a lane walking its position's k
-        // distances alone waits for k / 8 dependent batches of scattered loads.  Instead the WAVE takes each such position:
-        // lane m loads the distance to slot m (+ 64, ...), all of a group's loads in flight together, and the two nearest
-        // slots are two wave minima -- "first minimum over the slots, then first minimum over the rest", which is what
-        // the sequential scan of Clustering.cpp:262-305 arrives at.
-        const int kq = (k + 63) >> 6;
-#pragma unroll
-        for (int u = 0; u < PER; ++u) {
-            unsigned long long todo = __ballot(need[u]);
-            while (todo) {
-                int rl[4];
-                int cnt = 0;
-                while (cnt < 4 && todo) {
-                    rl[cnt++] = (int)__builtin_ctzll(todo);
-                    todo &= todo - 1;
-                }
-                if (kq <= 2) {
-                    float v[4][2];
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const int pos_r = k + wave * 64 + (c < cnt ? rl[c] : rl[0]) + 512 * u;
-#pragma unroll
-                        for (int q = 0; q < 2; ++q) {
-                            const int mm = lane + 64 * q;
-                            v[c][q] = (c < cnt && mm < k) ? a.DMt[(size_t)mm * n + pos_r] : FLT_MAX;
-                        }
-                    }
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        if (c >= cnt) break;
-                        const float dnw_r = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d_new[u]), rl[c]));
-                        float dv[2];
-#pragma unroll
-                        for (int q = 0; q < 2; ++q) dv[q] = (lane + 64 * q == mm_new) ? dnw_r : v[c][q];
-                        float v1 = FLT_MAX, v2 = FLT_MAX;
-                        int i1 = INT_MAX, i2 = INT_MAX;
-#pragma unroll
-                        for (int q = 0; q < 2; ++q) {
-                            const int mm = lane + 64 * q;
-                            if (mm < k && (dv[q] < v1 || i1 == INT_MAX)) { v1 = dv[q]; i1 = mm; }
-                        }
-                        wave_first_min_valid(v1, i1);
-#pragma unroll
-                        for (int q = 0; q < 2; ++q) {
-                            const int mm = lane + 64 * q;
-                            if (mm < k && mm != i1 && (dv[q] < v2 || i2 == INT_MAX)) { v2 = dv[q]; i2 = mm; }
-                        }
-                        wave_first_min_valid(v2, i2);
-                        const bool has1 = i1 != INT_MAX && v1 < FLT_MAX, has2 = i2 != INT_MAX && v2 < FLT_MAX;
-                        if (lane == rl[c]) s_pre[u] = pack_state(has1 ? v1 : FLT_MAX, has2 ? v2 : FLT_MAX, has1 ? i1 : -1, has2 ? i2 : -1);
-                    }
-                } else { // more than 128 slots: every such lane scans its own column (the apply kernel's loop)
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        if (c < cnt && lane == rl[c]) {
-                            const int pos = k + tid + 512 * u;
-                            const float dnw = d_new[u];
-                            Nearest2 nb;
-                            const float* col = a.DMt + pos;
-                            for (int m0 = 0; m0 < k; m0 += 8) {
-                                float vv[8];
-#pragma unroll
-                                for (int q = 0; q < 8; ++q) vv[q] = col[(size_t)min(m0 + q, k - 1) * n];
-#pragma unroll
-                                for (int q = 0; q < 8; ++q)
-                                    if (m0 + q < k) nb.feed(m0 + q == mm_new ? dnw : vv[q], m0 + q);
-                            }
-                            s_pre[u] = pack_state(nb.dn, nb.ds, nb.an, nb.as);
-                        }
-                    }
-                }
-            }
-        }
+        rescan_positions<PER>(a, need, d_new, s_pre, mm_new);
     }
     // ---- the committer: the applied state into the other parity ----
     if (committer) {
@@ -756,6 +771,237 @@ __global__ __launch_bounds__(512, 6) void clarans_round_kernel(ClaransBatch batc
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// A WHOLE LOCAL SEARCH IN ONE WORKGROUP, ONE LAUNCH (round 5).
+//
+// Since only the slots that can go negative are summed (evaluate_step), 85 % of the steps end after their loads and a
+// flag: a step is mostly latency, and what a round paid for -- a kernel boundary and four dependent load levels from a
+// cold cache per accept, 17 workgroups per search -- is more than the work between two accepts.  Here ONE workgroup runs
+// the reference's loop as it stands (Clustering.cpp:82-247: draw, evaluate, accept or count, stop after `corrected`
+// steps without an accept), the state of every position in its registers and the candidate order in LDS from the first
+// step to the last:
+//   * the next Q = 16 pending steps' rows of D are requested together (the draws do not depend on the state) and reduced
+//     to one bit per step, "some member is closer to the candidate than to its medoid"; one barrier for the group;
+//   * only the flagged steps are evaluated, in order, by evaluate_step as before (their rows come from the cache now);
+//     the first negative minimum is the accept, the rest of the group is dropped;
+//   * the accept is applied to the registers (the branches of Clustering.cpp:124-238, the code of the round kernel),
+//     the running cost takes the accept's addends in order, and the loop goes on with the next draw.
+// No other workgroup reads what this one writes, so there is nothing to wait for and nothing that can deadlock; a search
+// holds one workgroup instead of 17 per launch.  When the pre-drawn positions run out the kernel leaves its state where
+// the round kernel would and says so (state[7] = 1): the host draws more and starts it again.
+template <int KPT>
+__global__ __launch_bounds__(512, 2) void clarans_search_kernel(ClaransArgs a)
+{
+    constexpr int PER = 4, Q = 16;
+    __shared__ float4 s_e[1024];        // 16 KB   evaluate_step's staging
+    __shared__ float4 s_we[8][128];     // 16 KB
+    __shared__ float4 s_xx_state;       // the rebuilt state of the position that received the replaced medoid
+    __shared__ float s_x[CLARANS_MAX_MEDOIDS + 8];
+    __shared__ int s_cand[CLARANS_MAX_MEDOIDS + CLARANS_MAX_NONMEDOIDS]; // 12 KB   the candidate order (member at every position)
+    __shared__ unsigned s_flag[2][8];   // per wave: the steps of the group with a (b) entry, by group parity
+    __shared__ int s_res[4];            // an evaluation's result for everybody
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int k = a.n_medoids, n = a.n_elems, corrected = a.corrected, cnt = n - k;
+    __builtin_amdgcn_s_setprio(3); // a chain of short dependent phases next to the LCS kernels' waves on the same SIMDs
+    int P = __builtin_amdgcn_readfirstlane(a.state[ST_P]), off = __builtin_amdgcn_readfirstlane(a.state[ST_OFF]),
+        first = __builtin_amdgcn_readfirstlane(a.state[ST_FIRST]), accepts = __builtin_amdgcn_readfirstlane(a.state[ST_ROUNDS]);
+    const int fresh = __builtin_amdgcn_readfirstlane(a.state[ST_FRESH]);
+    float cost = __int_as_float(a.state[ST_COST]); // (kept by thread 0)
+    int n_groups = a.state[ST_N_ROUNDS], n_steps = a.state[ST_N_STEPS], n_useful = a.state[ST_N_USEFUL], n_nob = a.state[ST_N_NOB],
+        n_nop = a.state[ST_N_NOP];
+    for (int i = tid; i < n; i += 512) s_cand[i] = a.cand[i];
+    int y_pre[PER];
+    float4 s_pre[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int pos = k + tid + 512 * u;
+        y_pre[u] = pos < n ? a.cand[pos] : 0;
+        s_pre[u] = pos < n ? a.st[pos] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+    if (fresh) cost = cost_accumulate(a.cost_log, cnt, cost, reinterpret_cast<float*>(s_e), reinterpret_cast<float*>(s_we)); // the initial cost (Clustering.cpp:49-79)
+    int status = 0; // 1: the search is over   2: out of pre-drawn positions
+    for (unsigned g = 0;; ++g) {
+        const int W = window_size(corrected, first);
+        if (off >= W) { // `corrected` steps (corrected - 1 after an accept) without an accept
+            P += W;
+            off = 0;
+            status = 1;
+            break;
+        }
+        const int avail = a.draws_len - (P + off);
+        if (avail <= 0) {
+            status = 2;
+            break;
+        }
+        const int qn = min(Q, min(W - off, avail));
+        const int32_t* dr = a.draws + P + off;
+        // ---- the group's flags: all rows in flight together ----
+        unsigned m = 0;
+#pragma unroll
+        for (int s = 0; s < Q; ++s) {
+            const int xx = dr[min(s, qn - 1)];
+            const float* row = a.D + (size_t)s_cand[xx] * (size_t)n;
+#pragma unroll
+            for (int u = 0; u < PER; ++u) {
+                const int t = tid + 512 * u;
+                const float d = row[t < cnt ? y_pre[u] : 0];
+                if (t < cnt && k + t != xx && __fsub_rn(d, s_pre[u].x) < 0.0f) m |= 1u << s;
+            }
+        }
+        unsigned wm = 0;
+#pragma unroll
+        for (int s = 0; s < Q; ++s)
+            if (__ballot((m >> s) & 1u)) wm |= 1u << s;
+        if (lane == 0) s_flag[g & 1][wave] = wm;
+        __syncthreads();
+        unsigned flags = 0;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) flags |= s_flag[g & 1][w];
+        flags = (unsigned)__builtin_amdgcn_readfirstlane((int)flags) & ((1u << qn) - 1u);
+        // ---- the flagged steps, in order, up to the first accept ----
+        int acc_s = -1, mm_new = 0;
+        for (unsigned todo = flags; todo; todo &= todo - 1) {
+            const int s = __builtin_ctz(todo);
+            const int xx = dr[s];
+            float best = 0.0f;
+            int bk = INT_MAX, why = WHY_WALKED;
+            evaluate_step<KPT>(a, xx, s_cand[xx], y_pre, s_pre, s_e, s_we, s_x, best, bk, why);
+            if (tid == 0) {
+                s_res[0] = __float_as_int(best);
+                s_res[1] = bk;
+                s_res[2] = why;
+            }
+            __syncthreads();
+            const float r_delta = __int_as_float(__builtin_amdgcn_readfirstlane(s_res[0]));
+            mm_new = __builtin_amdgcn_readfirstlane(s_res[1]);
+            if (__builtin_amdgcn_readfirstlane(s_res[2]) == WHY_NO_P) ++n_nop;
+            if (r_delta < 0.0f) {
+                acc_s = s;
+                break;
+            }
+        }
+        const int upto = acc_s >= 0 ? acc_s + 1 : qn;
+        ++n_groups;
+        n_steps += qn;
+        n_useful += upto;
+        n_nob += __popc(~flags & ((1u << upto) - 1u));
+        if (acc_s < 0) {
+            off += qn;
+            continue;
+        }
+        // ---- the accept (Clustering.cpp:124-238, branch by branch) ----
+        const int xx_acc = dr[acc_s], x_acc = s_cand[xx_acc], m_old = s_cand[mm_new];
+        float d_new[PER], addend[PER];
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int pos = k + tid + 512 * u;
+            d_new[u] = (pos < n && pos != xx_acc) ? a.D[sq_at(n, x_acc, y_pre[u])] : 0.0f;
+            addend[u] = 0.0f;
+        }
+        float old_dn_xx = 0.0f;
+        // the position that receives the replaced medoid: distances to the new medoid set, a fresh assignment -- wave 0
+        if (wave == 0) {
+            float dv[CLARANS_MAX_MEDOIDS / 64];
+#pragma unroll
+            for (int u = 0; u < CLARANS_MAX_MEDOIDS / 64; ++u) {
+                const int mm = lane + 64 * u;
+                dv[u] = FLT_MAX;
+                if (mm < k) {
+                    dv[u] = a.D[sq_at(n, mm == mm_new ? x_acc : s_cand[mm], m_old)];
+                    a.DMt[(size_t)mm * n + xx_acc] = dv[u];
+                }
+            }
+            float v1 = FLT_MAX, v2 = FLT_MAX;
+            int i1 = INT_MAX, i2 = INT_MAX;
+#pragma unroll
+            for (int u = 0; u < CLARANS_MAX_MEDOIDS / 64; ++u) {
+                const int mm = lane + 64 * u;
+                if (mm < k && (dv[u] < v1 || i1 == INT_MAX)) { v1 = dv[u]; i1 = mm; }
+            }
+            wave_first_min_valid(v1, i1);
+#pragma unroll
+            for (int u = 0; u < CLARANS_MAX_MEDOIDS / 64; ++u) {
+                const int mm = lane + 64 * u;
+                if (mm < k && mm != i1 && (dv[u] < v2 || i2 == INT_MAX)) { v2 = dv[u]; i2 = mm; }
+            }
+            wave_first_min_valid(v2, i2);
+            if (lane == 0) {
+                const bool has1 = i1 != INT_MAX && v1 < FLT_MAX, has2 = i2 != INT_MAX && v2 < FLT_MAX;
+                s_xx_state = pack_state(has1 ? v1 : FLT_MAX, has2 ? v2 : FLT_MAX, has1 ? i1 : -1, has2 ? i2 : -1);
+            }
+        }
+        __syncthreads();
+        bool need[PER]; // this position has to look at all k slots again
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int pos = k + tid + 512 * u;
+            need[u] = false;
+            if (pos >= n) continue;
+            if (pos == xx_acc) {
+                old_dn_xx = s_pre[u].x;
+                s_pre[u] = s_xx_state;
+                y_pre[u] = m_old;
+                addend[u] = s_pre[u].x;
+                continue;
+            }
+            apply_accept_to_position(s_pre[u], d_new[u], mm_new, addend[u], need[u]);
+        }
+        rescan_positions<PER>(a, need, d_new, s_pre, mm_new);
+        // the new medoid's row of the member-to-medoid matrix, the accept's cost addends in position order
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int pos = k + tid + 512 * u;
+            if (pos >= n) continue;
+            a.cost_log[1 + pos - k] = addend[u];
+            if (pos == xx_acc) a.cost_log[0] = -old_dn_xx;
+            else a.DMt[(size_t)mm_new * n + pos] = d_new[u];
+        }
+        __syncthreads(); // (the order's old entries have been read; the log is where cost_accumulate reads it)
+        if (tid == 0) {
+            s_cand[mm_new] = x_acc;
+            s_cand[xx_acc] = m_old;
+        }
+        cost = cost_accumulate(a.cost_log, 1 + cnt, cost, reinterpret_cast<float*>(s_e), reinterpret_cast<float*>(s_we));
+        P += off + acc_s + 1;
+        off = 0;
+        first = 0;
+        ++accepts;
+    }
+    // ---- the state where the host (or the next launch) finds it ----
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int pos = k + tid + 512 * u;
+        if (pos >= n) continue;
+        a.cand[pos] = y_pre[u];
+        a.st[pos] = s_pre[u];
+    }
+    for (int mm = tid; mm < k; mm += 512) a.cand[mm] = s_cand[mm];
+    if (tid == 0) {
+        int32_t* out[2] = {a.state, a.host_state};
+        for (int o = 0; o < 2; ++o) {
+            int32_t* st = out[o];
+            if (!st) continue;
+            st[ST_P] = P;
+            st[ST_DONE] = status == 1;
+            st[ST_LOG_LEN] = 0;
+            st[ST_ROUNDS] = accepts;
+            st[ST_FRESH] = 0;
+            st[ST_COST] = __float_as_int(cost);
+            st[ST_ERR] = 0;
+            st[7] = status == 2;
+            st[ST_OFF] = off;
+            st[ST_STAGE] = 0;
+            st[ST_FIRST] = first;
+            st[ST_N_ROUNDS] = n_groups;
+            st[ST_N_STEPS] = n_steps;
+            st[ST_N_USEFUL] = n_useful;
+            st[ST_N_NOB] = n_nob;
+            st[ST_N_NOP] = n_nop;
+        }
+    }
+}
+
 hipError_t launch_subset_distances(const void* lcs, int elem_size, const int32_t* ids, const uint32_t* lens,
                                    const float* pow_f32, int kind, int n, float* D, hipStream_t stream)
 {
@@ -772,6 +1018,15 @@ hipError_t launch_subset_distances(const void* lcs, int elem_size, const int32_t
 hipError_t launch_clarans_init(const ClaransArgs& a, hipStream_t stream)
 {
     hipLaunchKernelGGL(clarans_init_kernel, dim3((a.n_elems + 255) / 256), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
+// the whole local search (or as far as the pre-drawn positions reach): one workgroup
+hipError_t launch_clarans_search(const ClaransArgs& a, hipStream_t stream)
+{
+    const int kpt = ((a.n_medoids + 7) / 8 + 63) / 64;
+    if (kpt <= 1) hipLaunchKernelGGL(clarans_search_kernel<1>, dim3(1), dim3(512), 0, stream, a);
+    else hipLaunchKernelGGL(clarans_search_kernel<2>, dim3(1), dim3(512), 0, stream, a);
     return hipGetLastError();
 }
 

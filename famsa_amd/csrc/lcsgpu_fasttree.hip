@@ -509,16 +509,45 @@ int lcsgpu_clarans(lcsgpu_ctx* ctx, const int32_t* ids, int32_t n_ids, int dista
             }
         }
         HIP_TRY(hipMemcpyAsync(a.cand, cand.data(), (size_t)n * 4, hipMemcpyHostToDevice, L.stream));
-        {   // the first rounds' draws (the init kernel checks that a window's worth is there)
-            int rc = clarans_extend_draws(job, (size_t)job.p_host + (size_t)std::max(corrected, 1), L.stream);
+        static const int form = tune_int("clarans_form", 1);
+        static const int draws_ahead = std::max(1, tune_int("clarans_draws", 8192));
+        {   // the first draws (the init kernel checks that a window's worth is there)
+            int rc = clarans_extend_draws(job, (size_t)job.p_host + (size_t)std::max(corrected, 1) + (form == 1 ? draws_ahead : 0), L.stream);
             if (rc) return rc;
         }
         HIP_TRY(lcsgpu::launch_clarans_init(job.a, L.stream));
+        if (form == 1) {
+            // the search: one workgroup, one launch -- or as many as it takes to draw the positions it asks for
+            for (size_t more = (size_t)draws_ahead;; more *= 2) {
+                HIP_TRY(lcsgpu::launch_clarans_search(job.a, L.stream));
+                HIP_TRY(hipMemcpyAsync(L.h_small.p, job.a.state, 64, hipMemcpyDeviceToHost, L.stream));
+                HIP_TRY(hipEventRecord(L.ev_done, L.stream));
+                HIP_TRY(hipEventSynchronize(L.ev_done));
+                memcpy(job.state, L.h_small.p, 64);
+                job.p_host = job.state[0];
+                if (!job.state[7]) break;
+                if (int rc = clarans_extend_draws(job, (size_t)job.p_host + (size_t)job.state[8] + more, L.stream)) return rc;
+            }
+            L.plan_in_flight = false;
+            if (!job.state[1]) return fail(LCSGPU_E_STATE, "CLARANS: the device search ended without finishing");
+            {
+                ClaransBatcher& B = ctx->clarans_groups[0];
+                std::lock_guard<std::mutex> lk(B.mu);
+                B.prof_searches += 1;
+                B.prof_accepts += job.state[3];
+                B.prof_rounds += job.state[11];
+                B.prof_steps += job.state[12];
+                B.prof_useful += job.state[13];
+                B.prof_no_b += job.state[14];
+                B.prof_no_p += job.state[15];
+            }
+        } else {
         HIP_TRY(hipEventRecord(L.ev_done, L.stream));
         HIP_TRY(hipEventSynchronize(L.ev_done)); // the rounds run on the batch stream
         L.plan_in_flight = false;
         int rc = clarans_run_search(ctx, job);
         if (rc) return rc;
+        }
         float cost;
         memcpy(&cost, &job.state[5], 4);
         HIP_TRY(hipMemcpy(cand.data(), a.cand, (size_t)n * 4, hipMemcpyDeviceToHost));
