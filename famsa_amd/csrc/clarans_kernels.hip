@@ -790,14 +790,17 @@ __global__ __launch_bounds__(512, 6) void clarans_round_kernel(ClaransBatch batc
 // holds one workgroup instead of 17 per launch.  When the pre-drawn positions run out the kernel leaves its state where
 // the round kernel would and says so (state[7] = 1): the host draws more and starts it again.
 template <int KPT>
-__global__ __launch_bounds__(512, 2) void clarans_search_kernel(ClaransArgs a)
+__global__ __launch_bounds__(512, 2) void clarans_search_kernel(ClaransBatch batch, long long slice_ticks)
 {
-    constexpr int PER = 4, Q = 16;
+    const ClaransArgs& a = batch.s[blockIdx.x];
+    constexpr int PER = 4, Q = 16, MEMBERS = CLARANS_MAX_MEDOIDS + CLARANS_MAX_NONMEDOIDS;
+    const long long t_begin = wall_clock64();
     __shared__ float4 s_e[1024];        // 16 KB   evaluate_step's staging
     __shared__ float4 s_we[8][128];     // 16 KB
     __shared__ float4 s_xx_state;       // the rebuilt state of the position that received the replaced medoid
     __shared__ float s_x[CLARANS_MAX_MEDOIDS + 8];
-    __shared__ int s_cand[CLARANS_MAX_MEDOIDS + CLARANS_MAX_NONMEDOIDS]; // 12 KB   the candidate order (member at every position)
+    __shared__ int s_cand[MEMBERS];     // 12 KB   the candidate order (member at every position)
+    __shared__ float s_dn[MEMBERS];     // 12 KB   by MEMBER: its distance to its medoid (0 for a medoid)
     __shared__ unsigned s_flag[2][8];   // per wave: the steps of the group with a (b) entry, by group parity
     __shared__ int s_res[4];            // an evaluation's result for everybody
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -817,7 +820,9 @@ __global__ __launch_bounds__(512, 2) void clarans_search_kernel(ClaransArgs a)
         const int pos = k + tid + 512 * u;
         y_pre[u] = pos < n ? a.cand[pos] : 0;
         s_pre[u] = pos < n ? a.st[pos] : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (pos < n) s_dn[y_pre[u]] = s_pre[u].x;
     }
+    for (int mm = tid; mm < k; mm += 512) s_dn[a.cand[mm]] = 0.0f;
     __syncthreads();
     if (fresh) cost = cost_accumulate(a.cost_log, cnt, cost, reinterpret_cast<float*>(s_e), reinterpret_cast<float*>(s_we)); // the initial cost (Clustering.cpp:49-79)
     int status = 0; // 1: the search is over   2: out of pre-drawn positions
@@ -834,19 +839,23 @@ __global__ __launch_bounds__(512, 2) void clarans_search_kernel(ClaransArgs a)
             status = 2;
             break;
         }
+        if (__builtin_amdgcn_readfirstlane((int)(wall_clock64() - t_begin > slice_ticks))) break; // this look's share of the time is used up
         const int qn = min(Q, min(W - off, avail));
         const int32_t* dr = a.draws + P + off;
-        // ---- the group's flags: all rows in flight together ----
+        // ---- the group's flags: all rows in flight together.  "Some non-medoid other than the candidate is closer to the
+        // candidate than to its medoid" does not depend on the order of the positions, so it is asked member by member:
+        // a row of D is read as it lies in memory (a wave's load = 2 cache lines; gathered by position it is 64, and the
+        // L1's one tag look-up per clock made that 12 of a group's 15 us). ----
         unsigned m = 0;
 #pragma unroll
         for (int s = 0; s < Q; ++s) {
-            const int xx = dr[min(s, qn - 1)];
-            const float* row = a.D + (size_t)s_cand[xx] * (size_t)n;
+            const int x = s_cand[dr[min(s, qn - 1)]];
+            const float* row = a.D + (size_t)x * (size_t)n;
 #pragma unroll
-            for (int u = 0; u < PER; ++u) {
-                const int t = tid + 512 * u;
-                const float d = row[t < cnt ? y_pre[u] : 0];
-                if (t < cnt && k + t != xx && __fsub_rn(d, s_pre[u].x) < 0.0f) m |= 1u << s;
+            for (int j = 0; j < MEMBERS / 512; ++j) {
+                if (512 * j >= n) break;
+                const int y = tid + 512 * j;
+                if (y < n && y != x && __fsub_rn(row[y], s_dn[y]) < 0.0f) m |= 1u << s;
             }
         }
         unsigned wm = 0;
@@ -958,9 +967,13 @@ __global__ __launch_bounds__(512, 2) void clarans_search_kernel(ClaransArgs a)
             else a.DMt[(size_t)mm_new * n + pos] = d_new[u];
         }
         __syncthreads(); // (the order's old entries have been read; the log is where cost_accumulate reads it)
+#pragma unroll
+        for (int u = 0; u < PER; ++u)
+            if (k + tid + 512 * u < n) s_dn[y_pre[u]] = s_pre[u].x;
         if (tid == 0) {
             s_cand[mm_new] = x_acc;
             s_cand[xx_acc] = m_old;
+            s_dn[x_acc] = 0.0f;
         }
         cost = cost_accumulate(a.cost_log, 1 + cnt, cost, reinterpret_cast<float*>(s_e), reinterpret_cast<float*>(s_we));
         P += off + acc_s + 1;
@@ -1021,12 +1034,14 @@ hipError_t launch_clarans_init(const ClaransArgs& a, hipStream_t stream)
     return hipGetLastError();
 }
 
-// the whole local search (or as far as the pre-drawn positions reach): one workgroup
-hipError_t launch_clarans_search(const ClaransArgs& a, hipStream_t stream)
+// every search of the batch in its own workgroup, for `slice_us` microseconds or to its end
+hipError_t launch_clarans_search(const ClaransBatch& b, int slice_us, hipStream_t stream)
 {
-    const int kpt = ((a.n_medoids + 7) / 8 + 63) / 64;
-    if (kpt <= 1) hipLaunchKernelGGL(clarans_search_kernel<1>, dim3(1), dim3(512), 0, stream, a);
-    else hipLaunchKernelGGL(clarans_search_kernel<2>, dim3(1), dim3(512), 0, stream, a);
+    int kpt = 1;
+    for (int i = 0; i < b.n; ++i) kpt = std::max(kpt, ((b.s[i].n_medoids + 7) / 8 + 63) / 64);
+    const long long ticks = (long long)slice_us * 100; // wall_clock64: 100 MHz
+    if (kpt <= 1) hipLaunchKernelGGL(clarans_search_kernel<1>, dim3(b.n), dim3(512), 0, stream, b, ticks);
+    else hipLaunchKernelGGL(clarans_search_kernel<2>, dim3(b.n), dim3(512), 0, stream, b, ticks);
     return hipGetLastError();
 }
 

@@ -298,7 +298,7 @@ struct ClaransBatch {
 hipError_t launch_subset_distances(const void* lcs, int elem_size, const int32_t* ids, const uint32_t* lens,
                                    const float* pow_f32, int kind, int n, float* D, hipStream_t stream);
 hipError_t launch_clarans_init(const ClaransArgs& a, hipStream_t stream);
-hipError_t launch_clarans_search(const ClaransArgs& a, hipStream_t stream);
+hipError_t launch_clarans_search(const ClaransBatch& b, int slice_us, hipStream_t stream);
 // rounds even; max_step_workgroups: step workgroups per search at most (fewer than a stage's steps: several steps each)
 hipError_t launch_clarans_rounds(const ClaransBatch& b, int rounds, int max_step_workgroups, hipStream_t stream);
 

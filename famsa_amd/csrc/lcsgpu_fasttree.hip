@@ -66,17 +66,21 @@ void clarans_drive(lcsgpu_ctx* ctx, ClaransBatcher& B, ClaransJob* mine)
             (void)hipGetLastError();
             hs_dev = nullptr;
         }
+        static const int form = tune_int("clarans_form", 1);
+        static const int draws_ahead = std::max(1, tune_int("clarans_draws", 8192)), slice_us = std::max(1, tune_int("clarans_slice_us", 1000));
         for (ClaransJob* j : now) {
-            // a round uses at most `corrected` draws and prepares the next window
+            // a round uses at most `corrected` draws and prepares the next window; a search on its own stops when they run out
             if (rc == LCSGPU_OK)
-                rc = clarans_extend_draws(*j, (size_t)j->p_host + (size_t)(rounds_per_look + 1) * std::max(j->a.corrected, 1), B.stream);
+                rc = clarans_extend_draws(*j, form == 1 ? (size_t)j->p_host + (size_t)j->state[8] + (size_t)draws_ahead
+                                                        : (size_t)j->p_host + (size_t)(rounds_per_look + 1) * std::max(j->a.corrected, 1), B.stream);
             lcsgpu::ClaransArgs& s1 = batch.s[batch.n];
             s1 = j->a;
             s1.host_state = hs_dev ? hs_dev + 64 * batch.n : nullptr;
             ++batch.n;
         }
         static const int step_wgs = std::max(1, tune_int("clarans_wgs", 64)); // step workgroups per search and launch at most
-        if (rc == LCSGPU_OK) hip_ok(lcsgpu::launch_clarans_rounds(batch, rounds_per_look, step_wgs, B.stream), "CLARANS rounds");
+        if (rc == LCSGPU_OK && form == 1) hip_ok(lcsgpu::launch_clarans_search(batch, slice_us, B.stream), "CLARANS searches");
+        else if (rc == LCSGPU_OK) hip_ok(lcsgpu::launch_clarans_rounds(batch, rounds_per_look, step_wgs, B.stream), "CLARANS rounds");
         if (!hs_dev)
             for (size_t i = 0; i < now.size() && rc == LCSGPU_OK; ++i)
                 hip_ok(hipMemcpyAsync(hs + 64 * i, now[i]->a.state, 64, hipMemcpyDeviceToHost, B.stream), "state read-back");
@@ -509,45 +513,16 @@ int lcsgpu_clarans(lcsgpu_ctx* ctx, const int32_t* ids, int32_t n_ids, int dista
             }
         }
         HIP_TRY(hipMemcpyAsync(a.cand, cand.data(), (size_t)n * 4, hipMemcpyHostToDevice, L.stream));
-        static const int form = tune_int("clarans_form", 1);
-        static const int draws_ahead = std::max(1, tune_int("clarans_draws", 8192));
         {   // the first draws (the init kernel checks that a window's worth is there)
-            int rc = clarans_extend_draws(job, (size_t)job.p_host + (size_t)std::max(corrected, 1) + (form == 1 ? draws_ahead : 0), L.stream);
+            int rc = clarans_extend_draws(job, (size_t)job.p_host + (size_t)std::max(corrected, 1), L.stream);
             if (rc) return rc;
         }
         HIP_TRY(lcsgpu::launch_clarans_init(job.a, L.stream));
-        if (form == 1) {
-            // the search: one workgroup, one launch -- or as many as it takes to draw the positions it asks for
-            for (size_t more = (size_t)draws_ahead;; more *= 2) {
-                HIP_TRY(lcsgpu::launch_clarans_search(job.a, L.stream));
-                HIP_TRY(hipMemcpyAsync(L.h_small.p, job.a.state, 64, hipMemcpyDeviceToHost, L.stream));
-                HIP_TRY(hipEventRecord(L.ev_done, L.stream));
-                HIP_TRY(hipEventSynchronize(L.ev_done));
-                memcpy(job.state, L.h_small.p, 64);
-                job.p_host = job.state[0];
-                if (!job.state[7]) break;
-                if (int rc = clarans_extend_draws(job, (size_t)job.p_host + (size_t)job.state[8] + more, L.stream)) return rc;
-            }
-            L.plan_in_flight = false;
-            if (!job.state[1]) return fail(LCSGPU_E_STATE, "CLARANS: the device search ended without finishing");
-            {
-                ClaransBatcher& B = ctx->clarans_groups[0];
-                std::lock_guard<std::mutex> lk(B.mu);
-                B.prof_searches += 1;
-                B.prof_accepts += job.state[3];
-                B.prof_rounds += job.state[11];
-                B.prof_steps += job.state[12];
-                B.prof_useful += job.state[13];
-                B.prof_no_b += job.state[14];
-                B.prof_no_p += job.state[15];
-            }
-        } else {
         HIP_TRY(hipEventRecord(L.ev_done, L.stream));
         HIP_TRY(hipEventSynchronize(L.ev_done)); // the rounds run on the batch stream
         L.plan_in_flight = false;
         int rc = clarans_run_search(ctx, job);
         if (rc) return rc;
-        }
         float cost;
         memcpy(&cost, &job.state[5], 4);
         HIP_TRY(hipMemcpy(cand.data(), a.cand, (size_t)n * 4, hipMemcpyDeviceToHost));

@@ -25,9 +25,11 @@ for rep in 1 2 3; do
   run "3M search" $F X=1
   run "3M rounds" $F LCSGPU_TUNE=clarans_form=0
   run "3M search,share=0" $F LCSGPU_TUNE=lcs_share_lds=0
-  run "3M search,share=36864" $F LCSGPU_TUNE=lcs_share_lds=36864
+  run "3M search,slice=300" $F LCSGPU_TUNE=clarans_slice_us=300
+  run "3M search,slice=3000" $F LCSGPU_TUNE=clarans_slice_us=3000
+  run "3M search,groups=8" $F LCSGPU_TUNE=clarans_groups=8
+  run "3M search,groups=2" $F LCSGPU_TUNE=clarans_groups=2
   run "3M search,pool=48" $F FAMSA_HOST_TEST=pool=48
-  run "3M search,pool=64" $F FAMSA_HOST_TEST=pool=64
   run "1M search" /tmp/family_1000000_300.fasta X=1
   run "1M rounds" /tmp/family_1000000_300.fasta LCSGPU_TUNE=clarans_form=0
 done

@@ -168,7 +168,7 @@ def test_concurrent_searches_share_the_batch(engine):
         assert together == alone
 
 
-@pytest.mark.parametrize("tune", ["clarans_draws=1", "clarans_draws=300", "clarans_form=0"])
+@pytest.mark.parametrize("tune", ["clarans_draws=40", "clarans_slice_us=20,clarans_groups=1", "clarans_form=0"])
 def test_round_shape_does_not_change_the_search(tune):
     """LCSGPU_TUNE (read once per process, hence the subprocess): how many pending steps a round evaluates first -- 1: every
     round is one step, the reference's own loop; 5 with 3 step workgroups: stages 5, 10, 20, 40, 64, up to 22 steps per
