@@ -801,7 +801,7 @@ __global__ __launch_bounds__(512, 2) void clarans_search_kernel(ClaransBatch bat
     __shared__ float s_x[CLARANS_MAX_MEDOIDS + 8];
     __shared__ int s_cand[MEMBERS];     // 12 KB   the candidate order (member at every position)
     __shared__ float s_dn[MEMBERS];     // 12 KB   by MEMBER: its distance to its medoid (0 for a medoid)
-    __shared__ unsigned s_flag[2][8];   // per wave: the steps of the group with a (b) entry, by group parity
+    __shared__ unsigned s_flag[2][9];   // per wave: the steps of the group with a (b) entry, by group parity; [8]: time is up
     __shared__ int s_res[4];            // an evaluation's result for everybody
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int k = a.n_medoids, n = a.n_elems, corrected = a.corrected, cnt = n - k;
@@ -826,6 +826,7 @@ __global__ __launch_bounds__(512, 2) void clarans_search_kernel(ClaransBatch bat
     __syncthreads();
     if (fresh) cost = cost_accumulate(a.cost_log, cnt, cost, reinterpret_cast<float*>(s_e), reinterpret_cast<float*>(s_we)); // the initial cost (Clustering.cpp:49-79)
     int status = 0; // 1: the search is over   2: out of pre-drawn positions
+    int expired = 0;
     for (unsigned g = 0;; ++g) {
         const int W = window_size(corrected, first);
         if (off >= W) { // `corrected` steps (corrected - 1 after an accept) without an accept
@@ -839,7 +840,7 @@ __global__ __launch_bounds__(512, 2) void clarans_search_kernel(ClaransBatch bat
             status = 2;
             break;
         }
-        if (__builtin_amdgcn_readfirstlane((int)(wall_clock64() - t_begin > slice_ticks))) break; // this look's share of the time is used up
+        if (expired) break; // this look's share of the time is used up (one reading of the clock for the whole workgroup, below)
         const int qn = min(Q, min(W - off, avail));
         const int32_t* dr = a.draws + P + off;
         // ---- the group's flags: all rows in flight together.  "Some non-medoid other than the candidate is closer to the
@@ -863,7 +864,9 @@ __global__ __launch_bounds__(512, 2) void clarans_search_kernel(ClaransBatch bat
         for (int s = 0; s < Q; ++s)
             if (__ballot((m >> s) & 1u)) wm |= 1u << s;
         if (lane == 0) s_flag[g & 1][wave] = wm;
+        if (tid == 0) s_flag[g & 1][8] = wall_clock64() - t_begin > slice_ticks;
         __syncthreads();
+        expired = __builtin_amdgcn_readfirstlane((int)s_flag[g & 1][8]);
         unsigned flags = 0;
 #pragma unroll
         for (int w = 0; w < 8; ++w) flags |= s_flag[g & 1][w];
