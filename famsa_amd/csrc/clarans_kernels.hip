@@ -29,6 +29,7 @@
 
 #include <cfloat>
 #include <algorithm>
+#include <type_traits>
 #include <climits>
 #include <cstdint>
 
@@ -790,7 +791,7 @@ __global__ __launch_bounds__(512, 6) void clarans_round_kernel(ClaransBatch batc
 // holds one workgroup instead of 17 per launch.  When the pre-drawn positions run out the kernel leaves its state where
 // the round kernel would and says so (state[7] = 1): the host draws more and starts it again.
 template <int KPT>
-__global__ __launch_bounds__(512, 2) void clarans_search_kernel(ClaransBatch batch, long long slice_ticks)
+__global__ __launch_bounds__(512, 4) void clarans_search_kernel(ClaransBatch batch, long long slice_ticks)
 {
     const ClaransArgs& a = batch.s[blockIdx.x];
     constexpr int PER = 4, Q = 16, MEMBERS = CLARANS_MAX_MEDOIDS + CLARANS_MAX_NONMEDOIDS;
@@ -799,8 +800,13 @@ __global__ __launch_bounds__(512, 2) void clarans_search_kernel(ClaransBatch bat
     __shared__ float4 s_we[8][128];     // 16 KB
     __shared__ float4 s_xx_state;       // the rebuilt state of the position that received the replaced medoid
     __shared__ float s_x[CLARANS_MAX_MEDOIDS + 8];
-    __shared__ int s_cand[MEMBERS];     // 12 KB   the candidate order (member at every position)
-    __shared__ float s_dn[MEMBERS];     // 12 KB   by MEMBER: its distance to its medoid (0 for a medoid)
+    // by MEMBER: its distance to its medoid (0 for a medoid) -- how a position's owner hands the value to the thread that
+    // holds the member in the flags phase; lives in the staging between an accept and the next evaluation
+    float* s_dn = reinterpret_cast<float*>(&s_we[0][0]);
+    static_assert(MEMBERS * sizeof(float) <= sizeof(s_we), "s_dn");
+    // the candidate order stays in memory (a.cand, kept current): read with workgroup-scope loads, never through the scalar cache
+    auto cand_at = [&](int i) { return __hip_atomic_load(a.cand + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+    auto cand_at_uniform = [&](int i) { return __builtin_amdgcn_readfirstlane(cand_at(i)); }; // (i wave-uniform: the row's base in scalar registers)
     __shared__ unsigned s_flag[2][9];   // per wave: the steps of the group with a (b) entry, by group parity; [8]: time is up
     __shared__ int s_res[4];            // an evaluation's result for everybody
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -812,7 +818,6 @@ __global__ __launch_bounds__(512, 2) void clarans_search_kernel(ClaransBatch bat
     float cost = __int_as_float(a.state[ST_COST]); // (kept by thread 0)
     int n_groups = a.state[ST_N_ROUNDS], n_steps = a.state[ST_N_STEPS], n_useful = a.state[ST_N_USEFUL], n_nob = a.state[ST_N_NOB],
         n_nop = a.state[ST_N_NOP];
-    for (int i = tid; i < n; i += 512) s_cand[i] = a.cand[i];
     int y_pre[PER];
     float4 s_pre[PER];
 #pragma unroll
@@ -824,6 +829,9 @@ __global__ __launch_bounds__(512, 2) void clarans_search_kernel(ClaransBatch bat
     }
     for (int mm = tid; mm < k; mm += 512) s_dn[a.cand[mm]] = 0.0f;
     __syncthreads();
+    float dnm[MEMBERS / 512]; // my members' (tid, tid + 512, ...) distances to their medoids; beyond n: never flagged
+#pragma unroll
+    for (int j = 0; j < MEMBERS / 512; ++j) dnm[j] = tid + 512 * j < n ? s_dn[tid + 512 * j] : -FLT_MAX;
     if (fresh) cost = cost_accumulate(a.cost_log, cnt, cost, reinterpret_cast<float*>(s_e), reinterpret_cast<float*>(s_we)); // the initial cost (Clustering.cpp:49-79)
     int status = 0; // 1: the search is over   2: out of pre-drawn positions
     int expired = 0;
@@ -848,16 +856,32 @@ __global__ __launch_bounds__(512, 2) void clarans_search_kernel(ClaransBatch bat
         // a row of D is read as it lies in memory (a wave's load = 2 cache lines; gathered by position it is 64, and the
         // L1's one tag look-up per clock made that 12 of a group's 15 us). ----
         unsigned m = 0;
+        {
+            const int jn = (n + 511) >> 9;
+            auto flags_of = [&](auto JN) { // (unconditional loads: four rows are requested before the first is looked at)
+                constexpr int J = decltype(JN)::value, QC = 4;
 #pragma unroll
-        for (int s = 0; s < Q; ++s) {
-            const int x = s_cand[dr[min(s, qn - 1)]];
-            const float* row = a.D + (size_t)x * (size_t)n;
+                for (int s0 = 0; s0 < Q; s0 += QC) {
+                    if (s0 >= qn) break;
+                    int x[QC];
+                    float d[QC][J];
 #pragma unroll
-            for (int j = 0; j < MEMBERS / 512; ++j) {
-                if (512 * j >= n) break;
-                const int y = tid + 512 * j;
-                if (y < n && y != x && __fsub_rn(row[y], s_dn[y]) < 0.0f) m |= 1u << s;
-            }
+                    for (int c = 0; c < QC; ++c) x[c] = cand_at_uniform(dr[min(s0 + c, qn - 1)]);
+#pragma unroll
+                    for (int c = 0; c < QC; ++c) {
+                        const float* row = a.D + (size_t)x[c] * (size_t)n;
+#pragma unroll
+                        for (int j = 0; j < J; ++j) d[c][j] = row[min(tid + 512 * j, n - 1)];
+                    }
+#pragma unroll
+                    for (int c = 0; c < QC; ++c)
+#pragma unroll
+                        for (int j = 0; j < J; ++j)
+                            if (tid + 512 * j != x[c] && __fsub_rn(d[c][j], dnm[j]) < 0.0f) m |= 1u << (s0 + c);
+                }
+            };
+            if (jn <= 4) flags_of(std::integral_constant<int, 4>());
+            else flags_of(std::integral_constant<int, MEMBERS / 512>());
         }
         unsigned wm = 0;
 #pragma unroll
@@ -878,7 +902,7 @@ __global__ __launch_bounds__(512, 2) void clarans_search_kernel(ClaransBatch bat
             const int xx = dr[s];
             float best = 0.0f;
             int bk = INT_MAX, why = WHY_WALKED;
-            evaluate_step<KPT>(a, xx, s_cand[xx], y_pre, s_pre, s_e, s_we, s_x, best, bk, why);
+            evaluate_step<KPT>(a, xx, cand_at_uniform(xx), y_pre, s_pre, s_e, s_we, s_x, best, bk, why);
             if (tid == 0) {
                 s_res[0] = __float_as_int(best);
                 s_res[1] = bk;
@@ -903,7 +927,7 @@ __global__ __launch_bounds__(512, 2) void clarans_search_kernel(ClaransBatch bat
             continue;
         }
         // ---- the accept (Clustering.cpp:124-238, branch by branch) ----
-        const int xx_acc = dr[acc_s], x_acc = s_cand[xx_acc], m_old = s_cand[mm_new];
+        const int xx_acc = dr[acc_s], x_acc = cand_at_uniform(xx_acc), m_old = cand_at_uniform(mm_new);
         float d_new[PER], addend[PER];
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
@@ -920,7 +944,7 @@ __global__ __launch_bounds__(512, 2) void clarans_search_kernel(ClaransBatch bat
                 const int mm = lane + 64 * u;
                 dv[u] = FLT_MAX;
                 if (mm < k) {
-                    dv[u] = a.D[sq_at(n, mm == mm_new ? x_acc : s_cand[mm], m_old)];
+                    dv[u] = a.D[sq_at(n, mm == mm_new ? x_acc : cand_at(mm), m_old)];
                     a.DMt[(size_t)mm * n + xx_acc] = dv[u];
                 }
             }
@@ -969,15 +993,18 @@ __global__ __launch_bounds__(512, 2) void clarans_search_kernel(ClaransBatch bat
             if (pos == xx_acc) a.cost_log[0] = -old_dn_xx;
             else a.DMt[(size_t)mm_new * n + pos] = d_new[u];
         }
-        __syncthreads(); // (the order's old entries have been read; the log is where cost_accumulate reads it)
+        __syncthreads(); // (the order's old entries have been read; the log is where cost_accumulate reads it; the staging is free)
 #pragma unroll
         for (int u = 0; u < PER; ++u)
             if (k + tid + 512 * u < n) s_dn[y_pre[u]] = s_pre[u].x;
         if (tid == 0) {
-            s_cand[mm_new] = x_acc;
-            s_cand[xx_acc] = m_old;
+            __hip_atomic_store(a.cand + mm_new, x_acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(a.cand + xx_acc, m_old, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             s_dn[x_acc] = 0.0f;
         }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < MEMBERS / 512; ++j) dnm[j] = tid + 512 * j < n ? s_dn[tid + 512 * j] : -FLT_MAX;
         cost = cost_accumulate(a.cost_log, 1 + cnt, cost, reinterpret_cast<float*>(s_e), reinterpret_cast<float*>(s_we));
         P += off + acc_s + 1;
         off = 0;
@@ -992,7 +1019,6 @@ __global__ __launch_bounds__(512, 2) void clarans_search_kernel(ClaransBatch bat
         a.cand[pos] = y_pre[u];
         a.st[pos] = s_pre[u];
     }
-    for (int mm = tid; mm < k; mm += 512) a.cand[mm] = s_cand[mm];
     if (tid == 0) {
         int32_t* out[2] = {a.state, a.host_state};
         for (int o = 0; o < 2; ++o) {

@@ -36,12 +36,54 @@ struct PhaseTimers {
     }
 } g_phase;
 std::mutex g_phase_mu;
+// LCSGPU_PROFILE: how many threads are in which phase over the time of the run, in steps of 50 ms (the recursion's timeline)
+struct Timeline {
+    enum { LCS, CLARANS, PARTIAL, ASSIGN, IDLE, CPU_WAIT, N };
+    struct Ev { double t; int8_t phase, delta; };
+    std::vector<Ev> ev;
+    const std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    void note(int phase, int delta)
+    {
+        if (!profile_on()) return;
+        const double t = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        std::lock_guard<std::mutex> lk(g_phase_mu);
+        ev.push_back(Ev{t, (int8_t)phase, (int8_t)delta});
+    }
+    void dump()
+    {
+        std::lock_guard<std::mutex> lk(g_phase_mu);
+        if (ev.empty()) return;
+        std::sort(ev.begin(), ev.end(), [](const Ev& a, const Ev& b) { return a.t < b.t; });
+        const double step = 0.05, begin = ev.front().t;
+        double cur[N] = {0}, acc[N] = {0};
+        double t_prev = begin, edge = begin + step;
+        fprintf(stderr, "fasttree.timeline (threads per phase, averages over %.0f ms):  t      lcs clarans partial assign  idle cpu_wait\n", 1e3 * step);
+        auto flush = [&](double upto) {
+            for (int p = 0; p < N; ++p) acc[p] += cur[p] * (upto - t_prev);
+            t_prev = upto;
+        };
+        for (const Ev& e : ev) {
+            while (e.t >= edge) {
+                flush(edge);
+                fprintf(stderr, "fasttree.timeline %6.2f  %6.1f %6.1f %6.1f %6.1f %6.1f %6.1f\n", edge - begin, acc[0] / step, acc[1] / step, acc[2] / step,
+                        acc[3] / step, acc[4] / step, acc[5] / step);
+                for (int p = 0; p < N; ++p) acc[p] = 0;
+                edge += step;
+            }
+            flush(e.t);
+            cur[e.phase] += e.delta;
+        }
+        ev.clear();
+    }
+} g_timeline;
 struct Scope { // thread-seconds, summed over the worker threads
     double& acc;
+    int phase;
     std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
-    explicit Scope(double& a) : acc(a) {}
+    Scope(double& a, int ph) : acc(a), phase(ph) { g_timeline.note(phase, +1); }
     ~Scope()
     {
+        g_timeline.note(phase, -1);
         const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         std::lock_guard<std::mutex> lk(g_phase_mu);
         acc += dt;
@@ -65,7 +107,11 @@ public:
     {
         std::unique_lock<std::mutex> lk(mu_);
         if (!enabled_) return;
-        cv_.wait(lk, [this] { return free_ > 0; });
+        if (free_ <= 0) {
+            note_cpu_wait(+1);
+            cv_.wait(lk, [this] { return free_ > 0; });
+            note_cpu_wait(-1);
+        }
         --free_;
     }
     void release()
@@ -79,11 +125,13 @@ public:
     }
 
 private:
+    static void note_cpu_wait(int delta);
     std::mutex mu_;
     std::condition_variable cv_;
     int free_ = 0;
     bool enabled_ = false;
 } g_cpu;
+void CpuSlots::note_cpu_wait(int delta) { g_timeline.note(Timeline::CPU_WAIT, delta); }
 struct OffCpu { // around a wait for the GPU
     OffCpu() { g_cpu.release(); }
     ~OffCpu() { g_cpu.acquire(); }
@@ -361,7 +409,11 @@ public:
             workers_.emplace_back([this] {
                 std::unique_lock<std::mutex> lk(mu_);
                 for (;;) {
-                    cv_.wait(lk, [this] { return stop_ || !q_.empty(); });
+                    if (!stop_ && q_.empty()) {
+                        g_timeline.note(Timeline::IDLE, +1);
+                        cv_.wait(lk, [this] { return stop_ || !q_.empty(); });
+                        g_timeline.note(Timeline::IDLE, -1);
+                    }
                     if (stop_) return;
                     lk.unlock();
                     g_cpu.acquire();
@@ -385,12 +437,16 @@ public:
         int remaining = 0;
         std::string error;
     };
-    void submit(Group& g, size_t weight, std::function<void()> fn)
+    // `leaf_work`: the task ends in host work on data that is (or is about to be) there -- a batch of leaf matrices, leaf
+    // trees.  Such tasks go before any split: a split's thread waits for the GPU most of its time and keeps no core busy,
+    // so leaf work that is left to the end runs on the cores alone while the GPU idles (3 x 10^6 sequences: the last
+    // 0.25 s of a 1.15 s stage, profiles/c5_timeline_r05.txt).
+    void submit(Group& g, size_t weight, std::function<void()> fn, bool leaf_work = false)
     {
         {
             std::lock_guard<std::mutex> lk(mu_);
             ++g.remaining;
-            q_.push_back(Item{weight, seq_++, &g, std::move(fn)});
+            q_.push_back(Item{leaf_work, weight, seq_++, &g, std::move(fn)});
             std::push_heap(q_.begin(), q_.end());
         }
         cv_.notify_one();
@@ -405,7 +461,9 @@ public:
                 continue;
             }
             g_cpu.release(); // idle until a sub-task finishes or new work arrives
+            g_timeline.note(Timeline::IDLE, +1);
             cv_.wait(lk, [&] { return g.remaining == 0 || !q_.empty(); });
+            g_timeline.note(Timeline::IDLE, -1);
             lk.unlock();
             g_cpu.acquire();
             lk.lock();
@@ -415,11 +473,16 @@ public:
 
 private:
     struct Item {
+        bool leaf_work;
         size_t weight;
         uint64_t seq;
         Group* group;
         std::function<void()> fn;
-        bool operator<(const Item& o) const { return weight != o.weight ? weight < o.weight : seq > o.seq; }
+        bool operator<(const Item& o) const
+        {
+            if (leaf_work != o.leaf_work) return !leaf_work;
+            return weight != o.weight ? weight < o.weight : seq > o.seq;
+        }
     };
     void run_top(std::unique_lock<std::mutex>& lk)
     { // called with the lock held; runs the heaviest queued task unlocked
@@ -459,7 +522,7 @@ struct FastTree {
         LcsBuf buf;
         const int ref = ids[ref_local];
         {
-            Scope t(g_phase.lcs);
+            Scope t(g_phase.lcs, Timeline::LCS);
             OffCpu w;
             src.rect(&ref, 1, ids.data(), (int)ids.size(), buf);
         }
@@ -504,7 +567,7 @@ struct FastTree {
         seed_ids.assign(n_seeds, 0);
         bool on_device;
         {   // sample matrix + CLARANS inside the engine when it offers that
-            Scope t(g_phase.clarans);
+            Scope t(g_phase.clarans, Timeline::CLARANS);
             OffCpu w;
             on_device = src.clarans(sample_global.data(), n_samples, (int)D, n_seeds, 1, prm.cluster_fraction,
                                     prm.cluster_iters, seed_ids.data());
@@ -516,7 +579,7 @@ struct FastTree {
                 SubsetSource sub(src, sample_global);
                 LcsBuf buf;
                 {
-                    Scope t(g_phase.lcs);
+                    Scope t(g_phase.lcs, Timeline::LCS);
                     OffCpu w;
                     sub.triangle(0, n_samples, buf);
                 }
@@ -524,7 +587,7 @@ struct FastTree {
                     for (int j = 0; j < i; ++j)
                         dist[tri(i, j)] = transform(buf[tri(i, j)], sub.length(i), sub.length(j));
             }
-            Scope t(g_phase.clarans);
+            Scope t(g_phase.clarans, Timeline::CLARANS);
             Clarans{prm.cluster_fraction, prm.cluster_iters}(dist.data(), n_samples, n_seeds, 1, seed_ids.data());
         }
         if (!sample_ids.empty())
@@ -560,7 +623,7 @@ struct FastTree {
         bool on_device = false;
         if (have_row0) {
             if (n_seeds > 1) { // the sweep inside the engine when it offers that: 8 bytes per column come back
-                Scope t(g_phase.assign);
+                Scope t(g_phase.assign, Timeline::ASSIGN);
                 OffCpu w;
                 on_device = src.assign_seeds(refs.data(), n_seeds - 1, ids.data(), n, (int)D, 1, dist_row.data(), assignments.data());
             }
@@ -571,7 +634,7 @@ struct FastTree {
             for (int k = 0; k < n_seeds; ++k) all_refs[k] = ids[seed_ids[k]];
             std::fill(dist_row.begin(), dist_row.end(), std::numeric_limits<float>::infinity());
             {
-                Scope t(g_phase.assign);
+                Scope t(g_phase.assign, Timeline::ASSIGN);
                 OffCpu w;
                 on_device = src.assign_seeds(all_refs.data(), n_seeds, ids.data(), n, (int)D, 0, dist_row.data(), assignments.data());
             }
@@ -582,11 +645,11 @@ struct FastTree {
         for (int c0 = 0; c0 < n && n_seeds > 1 && !on_device; c0 += chunk) {
             const int c1 = std::min(n, c0 + chunk);
             {
-                Scope t(g_phase.lcs);
+                Scope t(g_phase.lcs, Timeline::LCS);
                 OffCpu w;
                 src.rect(refs.data(), n_seeds - 1, ids.data() + c0, c1 - c0, buf);
             }
-            Scope t2(g_phase.assign);
+            Scope t2(g_phase.assign, Timeline::ASSIGN);
             for (int k = 1; k < n_seeds; ++k) {
                 const uint32_t len_k = src.length(refs[k - 1]);
                 for (int j = c0; j < c1; ++j) {
@@ -608,7 +671,7 @@ struct FastTree {
     {
         const int n = (int)ids.size();
         {
-            Scope t(g_phase.partial);
+            Scope t(g_phase.partial, Timeline::PARTIAL);
             build_tree_partial(sub, partial, D, tree);
         }
         if (previous_top > n) {
@@ -700,26 +763,41 @@ struct FastTree {
                         auto buf = std::make_shared<LcsBuf>();
                         bool have;
                         {
-                            Scope tm(g_phase.lcs);
+                            Scope tm(g_phase.lcs, Timeline::LCS);
                             OffCpu w;
                             have = src.triangles_batch(ids.data(), offs.data(), (int)batch.size(), *buf);
                         }
-                        size_t off = 0;
+                        // the leaves' trees: a task per ~1024 members (a leaf of 30 members is 20 us of work -- a task each
+                        // would spend as long in the pool's queue as in the tree)
+                        struct Piece { size_t t, off; };
+                        std::vector<Piece> pieces;
+                        size_t off = 0, members = 0;
+                        auto submit_pieces = [&] {
+                            if (pieces.empty()) return;
+                            pool->submit(group, members, [this, pieces, have, buf, &tasks, &subgroups, &locals] {
+                                FastTree<D> child{src, partial, prm, pool, {}};
+                                for (const Piece& pc : pieces) {
+                                    const auto& g = subgroups[tasks[pc.t].k];
+                                    if (have) {
+                                        PrecomputedSubset sub(src, g, buf, pc.off);
+                                        child.leaf_tree(g, sub, locals[pc.t], tasks[pc.t].top);
+                                    } else {
+                                        child.do_step(g, locals[pc.t], tasks[pc.t].top, false);
+                                    }
+                                }
+                            }, true);
+                            pieces.clear();
+                            members = 0;
+                        };
                         for (size_t t : batch) {
                             const size_t m = subgroups[tasks[t].k].size();
-                            pool->submit(group, m, [this, t, have, buf, off, &tasks, &subgroups, &locals] {
-                                FastTree<D> child{src, partial, prm, pool, {}};
-                                const auto& g = subgroups[tasks[t].k];
-                                if (have) {
-                                    PrecomputedSubset sub(src, g, buf, off);
-                                    child.leaf_tree(g, sub, locals[t], tasks[t].top);
-                                } else {
-                                    child.do_step(g, locals[t], tasks[t].top, false);
-                                }
-                            });
+                            pieces.push_back(Piece{t, off});
+                            members += m;
                             off += m * (m - 1) / 2;
+                            if (members >= 1024) submit_pieces();
                         }
-                    });
+                        submit_pieces();
+                    }, true);
                     batch.clear();
                     batch_size = batch_members = 0;
                 };
@@ -751,7 +829,7 @@ struct FastTree {
         tree_structure local;
         {
             SubsetSource sub(src, seeds);
-            Scope t(g_phase.partial);
+            Scope t(g_phase.partial, Timeline::PARTIAL);
             build_tree_partial(sub, partial, D, local);
         }
         for (int node = 0; node < n_seeds - 1; ++node) {
@@ -805,6 +883,11 @@ void build_tree_fast(LcsSource& src, GT partial, Distance dist, const FastTreePa
     if (dist == Distance::indel_div_lcs) run_fast<Distance::indel_div_lcs>(src, partial, p, tree);
     else if (dist == Distance::indel075_div_lcs) run_fast<Distance::indel075_div_lcs>(src, partial, p, tree);
     else throw std::runtime_error("Error: Illegal pairwise distance measure.");
+    if (profile_on()) {
+        fprintf(stderr, "fasttree.lcs_calls=%.3f\nfasttree.clarans=%.3f\nfasttree.partial_trees=%.3f\nfasttree.assign=%.3f\n", g_phase.lcs, g_phase.clarans,
+                g_phase.partial, g_phase.assign);
+        g_timeline.dump();
+    }
 }
 
 } // namespace famsa_host

@@ -1,3 +1,4 @@
+#include <sys/resource.h>
 #include "pipeline.h"
 
 #include <thread>
@@ -150,7 +151,16 @@ std::string newick_gpu(const SeqSet& s, SeqSet* consumable, int device, const Tr
     double t2 = now_s();
     if (t) t->rss_upload_kb = resident_kb();
     if (consumable) release_in_background(consumable->codes); // on the device now
+    struct rusage ru0, ru1;
+    getrusage(RUSAGE_SELF, &ru0);
     std::string nwk = guide_tree_newick(s, w, src, opt, t);
+    if (profile_on()) { // how much of the tree stage the host's cores were busy
+        getrusage(RUSAGE_SELF, &ru1);
+        auto sec = [](const timeval& a, const timeval& b) { return (double)(b.tv_sec - a.tv_sec) + 1e-6 * (double)(b.tv_usec - a.tv_usec); };
+        fprintf(stderr, "tree stage: %.3f s wall, host CPU %.3f s user + %.3f s system, %ld voluntary / %ld involuntary context switches\n",
+                now_s() - t2, sec(ru0.ru_utime, ru1.ru_utime), sec(ru0.ru_stime, ru1.ru_stime), ru1.ru_nvcsw - ru0.ru_nvcsw,
+                ru1.ru_nivcsw - ru0.ru_nivcsw);
+    }
     if (t) {
         t->sort_s = t1 - t0;
         t->init_s = t1b - t1;
