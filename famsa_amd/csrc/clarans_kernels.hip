@@ -4,15 +4,12 @@
 // FastTree::clusterSeeds (tree/FastTree.cpp:366-436) on the float distance triangle of the sample.
 // The search is a chain of "steps": draw a non-medoid position xx, evaluate for every medoid slot
 // k the cost change of replacing medoid k by candidate[xx], accept the best k if it lowers the
-// cost, and stop after `corrected` steps without an accept.  The state only changes on an accept,
-// and the positions xx come from a generator that does not look at the state, so ALL steps up to
-// the next accept can be evaluated at once from the same state.  One ROUND = one launch of
-// clarans_round_kernel: every pending step's workgroup applies the previous round's accept to its own register
-// copy of the state and then evaluates its step(s) -- lane = medoid slot, deltas[slot] accumulated over the
-// non-medoids in ascending position, the reference's float additions in the reference's order.  The host enqueues
-// rounds in batches ("looks") and reads the `done` flag between them.  Ties, comparison directions and float
-// operation order follow the reference line by line; the running cost is summed sequentially from a per-round log
-// of its addends.
+// cost, and stop after `corrected` steps without an accept.  ONE WORKGROUP RUNS ONE LOCAL SEARCH from its first step to
+// its last (clarans_search_kernel): every position's state in its registers, deltas[slot] accumulated over the
+// non-medoids in ascending position -- the reference's float additions in the reference's order; ties, comparison
+// directions and float operation order follow the reference line by line; the running cost is summed sequentially from
+// each accept's addends.  The searches of several host threads share a launch, one workgroup each, for a time slice; the
+// host reads the `done` flags between slices.
 //
 // Layout: D = the sample members' full symmetric float matrix (D[i*n + j]).  All search state is
 // kept per candidate POSITION (not per member), so the lanes of a wave read it coalesced:
@@ -21,10 +18,11 @@
 // is k coalesced loads instead of k scattered triangle entries per lane).
 //
 // Shapes: 1 <= n - k <= 2048 non-medoids (every position's state in the registers of one workgroup), k <= 1024; the
-// host side answers LCSGPU_E_UNSUPPORTED beyond that and the caller searches on the host.  (Rounds 1-4 also carried a
-// two-launch form of a round, an evaluation with per-slot lists and a one-XCD persistent kernel; each was measured
-// slower than this one -- profiles/clarans_rounds_r03.txt, clarans_rounds_r04.txt, clarans_lists_r04.txt, CHANGELOG.md --
-// and they were removed in round 5.)
+// host side answers LCSGPU_E_UNSUPPORTED beyond that and the caller searches on the host.  (Rounds 1-5 also carried:
+// a launch per round with a workgroup per pending step -- all steps up to the next accept evaluated at once from the
+// same state --, its two-launch form, an evaluation with per-slot lists and a one-XCD persistent kernel; each was
+// measured slower than what replaced it -- profiles/clarans_rounds_r03.txt, clarans_rounds_r04.txt,
+// clarans_lists_r04.txt, c5_search_r05.txt, CHANGELOG.md -- and removed.)
 #include <hip/hip_runtime.h>
 
 #include <cfloat>
@@ -69,28 +67,19 @@ __device__ __forceinline__ void wave_first_min_valid(float& v, int& i)
     i = __builtin_amdgcn_readlane(i, 63);
 }
 
-// the search's state block (16 words; both parities, and the copy the host reads)
-enum { ST_P = 0, ST_DONE = 1, ST_LOG_LEN = 2, ST_ROUNDS = 3, ST_FRESH = 4 /* 1 = no round has run yet */, ST_COST = 5, ST_ERR = 6,
-       ST_OFF = 8, ST_STAGE = 9, ST_FIRST = 10,
-       // statistics of the search (LCSGPU_PROFILE): rounds, steps evaluated, steps up to the accepted one, steps that ended
-       // without a walk because no member was closer to the candidate than to its medoid / because no slot could go negative
+// the search's state block (16 words; the host reads a copy after every launch)
+enum { ST_P = 0 /* next draw */, ST_DONE = 1, ST_ROUNDS = 3 /* accepts */, ST_FRESH = 4 /* 1 = nothing has run yet */, ST_COST = 5, ST_ERR = 6,
+       ST_MORE_DRAWS = 7 /* stopped for want of pre-drawn positions */, ST_OFF = 8 /* steps of the window already evaluated */,
+       ST_FIRST = 10 /* no accept yet in this search */,
+       // statistics of the search (LCSGPU_PROFILE): groups of steps, steps looked at, steps up to the accepted one, steps that
+       // ended without a walk because no member was closer to the candidate than to its medoid / because no slot could go negative
        ST_N_ROUNDS = 11, ST_N_STEPS = 12, ST_N_USEFUL = 13, ST_N_NOB = 14, ST_N_NOP = 15 };
-// why an evaluation ended (row 4 of the step results)
+// why an evaluation ended
 enum { WHY_WALKED = 0, WHY_NO_B = 1, WHY_NO_P = 2 };
 
-// A window of pending steps is evaluated in stages of 16, 32, 64, 64, ... steps (ClaransArgs::stage0 = 16): the steps
-// after the accepted one are wasted work.  Measured at 3 x 10^6 sequences in round 3 (LCSGPU_PROFILE prints the counts):
-// 878 searches, 282 000 rounds, 224 000 accepts, 5.9 M steps evaluated of which 2.7 M up to the accepted one (the
-// accepted step is the 8th of its round on average).  A launch has stage0 step workgroups per search; in the later
-// stages a workgroup takes the steps b, b + stage0, ... one after the other.
-constexpr int STAGE_MAX = 64; // one result per lane of the wave that reads them
-constexpr int RES_ROWS = 5;   // step results: best delta (bits), its slot, the step's position, its member, WHY_*
+// the first window of a local search has `corrected` steps, the later ones corrected - 1 (the reference resets its step
+// counter to 1 after an accept, Clustering.cpp:82-247)
 __device__ __forceinline__ int window_size(int corrected, int first) { return first ? corrected : (corrected > 0 ? corrected - 1 : 0); }
-__device__ __forceinline__ int stage_size(int stage, int left, int stage0)
-{
-    const int want = min(STAGE_MAX, stage0 << min(stage, 6));
-    return left < want ? (left < 0 ? 0 : left) : want;
-}
 
 } // namespace
 
@@ -150,13 +139,11 @@ __global__ __launch_bounds__(256) void clarans_init_kernel(ClaransArgs a)
     const int p = a.state[ST_P];
     if (pos == 0) {
         a.state[ST_DONE] = 0;
-        a.state[ST_LOG_LEN] = n - k;
         a.state[ST_ROUNDS] = 0;
         a.state[ST_FRESH] = 1;
         a.state[ST_COST] = __float_as_int(0.0f);
-        a.state[7] = 0;
+        a.state[ST_MORE_DRAWS] = 0;
         a.state[ST_OFF] = 0;
-        a.state[ST_STAGE] = 0;
         a.state[ST_FIRST] = 1;
         a.state[ST_N_ROUNDS] = 0;
         a.state[ST_N_STEPS] = 0;
@@ -524,272 +511,25 @@ __device__ __forceinline__ void rescan_positions(const ClaransArgs& a, const boo
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// A ROUND AS ONE LAUNCH.
-//
-// What the previous round's accept does to a position is small (one gather, a handful of comparisons, rarely a rescan
-// over the k slots), and a step's workgroup holds every position's state in registers, four positions per thread.  So
-// every step's workgroup APPLIES THE PREVIOUS ROUND'S ACCEPT ITSELF, to its own register copy of the state, and then
-// evaluates its step(s) of this round against it: one launch per round, no kernel boundary between apply and evaluate.
-//   * All buffers a workgroup reads at its first load level and another writes in the same launch exist twice, by round
-//     parity: state block, candidate order, per-position state, cost log, step results.  The host reads the parity-0
-//     copies (after an even number of rounds).
-//   * Workgroup 0 is also the COMMITTER: it writes the applied state to the other parity (whole arrays: every thread its
-//     four positions), the new column / row of the member-to-medoid matrix (in place: nobody consumes those entries in
-//     the same launch -- a rescan overrides the changed slot, the replaced medoid's position is rebuilt from D), the
-//     cost addends and the state block.  The last workgroup keeps the running cost.
-//   * The control flow (first improving step of the stage; stages 16, 32, 64, 64 ... of a window; corrected /
-//     corrected - 1 steps without an accept end the search) is recomputed by every workgroup from the same state block
-//     and step results.  The apply's branches are Clustering.cpp:124-238, line by line.
-template <int KPT>
-__global__ __launch_bounds__(512, 6) void clarans_round_kernel(ClaransBatch batch, int par, int last)
-{
-    const ClaransArgs& a = batch.s[blockIdx.y];
-    constexpr int PER = 4;
-    __shared__ float4 s_e[1024];        // 16 KB   evaluate_step's staging
-    __shared__ float4 s_we[8][128];     // 16 KB
-    __shared__ float4 s_xx_state;       // the rebuilt state of the position that received the replaced medoid
-    __shared__ float s_x[CLARANS_MAX_MEDOIDS + 8]; // evaluate_step: X_s per slot, then "slot in P"; Y at [CLARANS_MAX_MEDOIDS]
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int k = a.n_medoids, n = a.n_elems, corrected = a.corrected;
-    const int32_t* stA = par ? a.state1 : a.state;
-    int32_t* stB = par ? a.state : a.state1;
-    const int32_t* candA = par ? a.cand1 : a.cand;
-    int32_t* candB = par ? a.cand : a.cand1;
-    const float4* sA = par ? a.st1 : a.st;
-    float4* sB = par ? a.st : a.st1;
-    const float* logA = par ? a.log1 : a.cost_log;
-    float* logB = par ? a.cost_log : a.log1;
-    const int32_t* resA = a.res2 + par * (RES_ROWS * 64); // [RES_ROWS][64]: best delta (bits), its slot, the step's position, its member, WHY_*
-    int32_t* resB = a.res2 + (1 - par) * (RES_ROWS * 64);
-    // ---- level 1 ----
-    const int4 st0 = *reinterpret_cast<const int4*>(stA);
-    const int4 st1 = *reinterpret_cast<const int4*>(stA + 4);
-    const int4 st2 = *reinterpret_cast<const int4*>(stA + 8);
-    const int4 st3 = *reinterpret_cast<const int4*>(stA + 12);
-    const float r_delta = __int_as_float(resA[lane]);
-    const int r_mm = resA[64 + lane], r_xx = resA[128 + lane], r_x = resA[192 + lane], r_why = resA[256 + lane];
-    int y_pre[PER];
-    float4 s_pre[PER];
-#pragma unroll
-    for (int u = 0; u < PER; ++u) {
-        const int pos = k + tid + 512 * u;
-        y_pre[u] = pos < n ? candA[pos] : 0;
-        s_pre[u] = pos < n ? sA[pos] : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    int med_pre[CLARANS_MAX_MEDOIDS / 64]; // wave 0: the medoids before the swap, slots lane, lane + 64, ...
-#pragma unroll
-    for (int u = 0; u < CLARANS_MAX_MEDOIDS / 64; ++u) med_pre[u] = (wave == 0 && lane + 64 * u < k) ? candA[lane + 64 * u] : 0;
-    const bool cost_wg = b == (int)gridDim.x - 1;
-    const int P = st0.x, done = st0.y, log_len = st0.z, rounds = st0.w, fresh = st1.x, err = st1.z;
-    const int off = st2.x, stage = st2.y, first = st2.z;
-    // the last round of a look also leaves the state block where the host reads it without a copy (mapped host memory)
-    int32_t* host = last ? a.host_state : nullptr;
-    if (done) { // finished in an earlier round: the state travels on unchanged (both parities stay readable)
-        if (b == 0 && tid < 16) {
-            stB[tid] = stA[tid];
-            if (host) host[tid] = stA[tid];
-        }
-        return;
-    }
-    if (cost_wg) { // the running cost: + the addends the previous round's committer logged, in order
-        float c = __int_as_float(st1.y);
-        if (log_len > 0) {
-            c = cost_accumulate(logA, log_len, c, reinterpret_cast<float*>(s_e), reinterpret_cast<float*>(s_we));
-        }
-        if (tid == 0) {
-            stB[ST_COST] = __float_as_int(c);
-            if (host) host[ST_COST] = __float_as_int(c);
-        }
-        return;
-    }
-    // ---- what the previous round's results mean (every workgroup, the same) ----
-    const int W = window_size(corrected, first);
-    const int S_prev = fresh ? 0 : stage_size(stage, W - off, a.stage0);
-    const unsigned long long neg = __ballot(lane < S_prev && !err && r_delta < 0.0f);
-    const bool accept = neg != 0ull;
-    // (statistics) steps of the previous round that ended without a walk
-    const int n_nob = (int)__popcll(__ballot(lane < S_prev && !err && r_why == WHY_NO_B)),
-              n_nop = (int)__popcll(__ballot(lane < S_prev && !err && r_why == WHY_NO_P));
-    const int w = accept ? (int)__builtin_ctzll(neg) : 0;
-    const int mm_new = __builtin_amdgcn_readlane(r_mm, w), xx_acc = __builtin_amdgcn_readlane(r_xx, w),
-              x_acc = __builtin_amdgcn_readlane(r_x, w);
-    int P_n = P, done_n = 0, log_n = 0, rounds_n = rounds, err_n = err, off_n = off, stage_n = stage, first_n = first;
-    if (accept) {
-        P_n = P + off + w + 1;
-        log_n = 1 + n - k;
-        rounds_n = rounds + 1;
-        off_n = 0;
-        stage_n = 0;
-        first_n = 0;
-        if (P_n + window_size(corrected, 0) > a.draws_len) err_n = 1;
-    } else if (!fresh) {
-        if (err || off + S_prev >= W) { // error, or `corrected` steps without an accept: this local search is over
-            P_n = P + (err ? 0 : W);
-            done_n = 1;
-        } else {
-            off_n = off + S_prev;
-            stage_n = stage + 1;
-        }
-    }
-    const int W_n = window_size(corrected, first_n);
-    const int S_now = (done_n || err_n) ? 0 : stage_size(stage_n, W_n - off_n, a.stage0);
-    const bool committer = b == 0;
-    if (!committer && b >= S_now) return; // no step for this workgroup in this round
-    // ---- level 2: the accept's gathers, this round's draw ----
-    int m_old = 0;
-    float d_new[PER];
-#pragma unroll
-    for (int u = 0; u < PER; ++u) d_new[u] = 0.0f;
-    if (accept) {
-        m_old = candA[mm_new];
-#pragma unroll
-        for (int u = 0; u < PER; ++u) {
-            const int pos = k + tid + 512 * u;
-            if (pos < n && pos != xx_acc) d_new[u] = a.D[sq_at(n, x_acc, y_pre[u])];
-        }
-    }
-    const bool have_step = b < S_now;
-    const int G = (int)gridDim.x - 1; // step workgroups of a search; a stage beyond G steps: b, b + G, ... one after the other
-    int xx = have_step ? a.draws[P_n + off_n + b] : k;
-    // ---- the accept applied to my positions (Clustering.cpp:124-238, branch by branch) ----
-    float addend[PER];
-#pragma unroll
-    for (int u = 0; u < PER; ++u) addend[u] = 0.0f;
-    float old_dn_xx = 0.0f;
-    if (accept) {
-        // the position that receives the replaced medoid: distances to the new medoid set, a fresh assignment -- wave 0
-        if (wave == 0) {
-            float dv[CLARANS_MAX_MEDOIDS / 64];
-#pragma unroll
-            for (int u = 0; u < CLARANS_MAX_MEDOIDS / 64; ++u) {
-                const int mm = lane + 64 * u;
-                dv[u] = FLT_MAX;
-                if (mm < k) {
-                    dv[u] = a.D[sq_at(n, mm == mm_new ? x_acc : med_pre[u], m_old)];
-                    if (committer) a.DMt[(size_t)mm * n + xx_acc] = dv[u];
-                }
-            }
-            float v1 = FLT_MAX, v2 = FLT_MAX;
-            int i1 = INT_MAX, i2 = INT_MAX;
-#pragma unroll
-            for (int u = 0; u < CLARANS_MAX_MEDOIDS / 64; ++u) {
-                const int mm = lane + 64 * u;
-                if (mm < k && (dv[u] < v1 || i1 == INT_MAX)) { v1 = dv[u]; i1 = mm; }
-            }
-            wave_first_min_valid(v1, i1);
-#pragma unroll
-            for (int u = 0; u < CLARANS_MAX_MEDOIDS / 64; ++u) {
-                const int mm = lane + 64 * u;
-                if (mm < k && mm != i1 && (dv[u] < v2 || i2 == INT_MAX)) { v2 = dv[u]; i2 = mm; }
-            }
-            wave_first_min_valid(v2, i2);
-            if (lane == 0) {
-                const bool has1 = i1 != INT_MAX && v1 < FLT_MAX, has2 = i2 != INT_MAX && v2 < FLT_MAX;
-                s_xx_state = pack_state(has1 ? v1 : FLT_MAX, has2 ? v2 : FLT_MAX, has1 ? i1 : -1, has2 ? i2 : -1);
-            }
-        }
-        __syncthreads();
-        bool need[PER]; // this position has to look at all k slots again
-#pragma unroll
-        for (int u = 0; u < PER; ++u) {
-            const int pos = k + tid + 512 * u;
-            need[u] = false;
-            if (pos >= n) continue;
-            if (pos == xx_acc) {
-                old_dn_xx = s_pre[u].x;
-                s_pre[u] = s_xx_state;
-                y_pre[u] = m_old;
-                addend[u] = s_pre[u].x;
-                continue;
-            }
-            apply_accept_to_position(s_pre[u], d_new[u], mm_new, addend[u], need[u]);
-        }
-        rescan_positions<PER>(a, need, d_new, s_pre, mm_new);
-    }
-    // ---- the committer: the applied state into the other parity ----
-    if (committer) {
-#pragma unroll
-        for (int u = 0; u < PER; ++u) {
-            const int pos = k + tid + 512 * u;
-            if (pos >= n) continue;
-            candB[pos] = y_pre[u];
-            sB[pos] = s_pre[u];
-            if (accept) {
-                logB[1 + pos - k] = addend[u];
-                if (pos == xx_acc) logB[0] = -old_dn_xx;
-                else a.DMt[(size_t)mm_new * n + pos] = d_new[u];
-            }
-        }
-        for (int mm = tid; mm < k; mm += 512) candB[mm] = (accept && mm == mm_new) ? x_acc : candA[mm];
-        if (tid == 0) {
-            stB[ST_P] = P_n;
-            stB[ST_DONE] = done_n;
-            stB[ST_LOG_LEN] = log_n;
-            stB[ST_ROUNDS] = rounds_n;
-            stB[ST_FRESH] = 0;
-            // (ST_COST: the cost workgroup)
-            stB[ST_ERR] = err_n;
-            stB[7] = 0;
-            stB[ST_OFF] = off_n;
-            stB[ST_STAGE] = stage_n;
-            stB[ST_FIRST] = first_n;
-            stB[ST_N_ROUNDS] = st2.w + (fresh ? 0 : 1);
-            stB[ST_N_STEPS] = st3.x + (err ? 0 : S_prev);
-            stB[ST_N_USEFUL] = st3.y + (accept ? w + 1 : (err ? 0 : S_prev));
-            stB[ST_N_NOB] = st3.z + n_nob;
-            stB[ST_N_NOP] = st3.w + n_nop;
-            if (host) { // (every word but the cost, which the cost workgroup leaves there)
-                host[ST_P] = P_n; host[ST_DONE] = done_n; host[ST_LOG_LEN] = log_n; host[ST_ROUNDS] = rounds_n; host[ST_FRESH] = 0;
-                host[ST_ERR] = err_n; host[7] = 0; host[ST_OFF] = off_n; host[ST_STAGE] = stage_n; host[ST_FIRST] = first_n;
-                host[ST_N_ROUNDS] = st2.w + (fresh ? 0 : 1); host[ST_N_STEPS] = st3.x + (err ? 0 : S_prev);
-                host[ST_N_USEFUL] = st3.y + (accept ? w + 1 : (err ? 0 : S_prev)); host[ST_N_NOB] = st3.z + n_nob; host[ST_N_NOP] = st3.w + n_nop;
-            }
-        }
-    }
-    if (!have_step) return;
-    // ---- level 3 / 4: my step(s) of this round against the applied state ----
-    int x = (accept && xx == xx_acc) ? m_old : candA[xx];
-    for (int bj = b;;) {
-        const int bn = bj + G;
-        const bool more = bn < S_now;
-        const int xx_n = more ? a.draws[P_n + off_n + bn] : k; // (requested ahead of this step's evaluation)
-        const int x_n = more ? ((accept && xx_n == xx_acc) ? m_old : candA[xx_n]) : 0;
-        float best = 0.0f;
-        int bk = INT_MAX, why = WHY_WALKED;
-        __syncthreads(); // (s_xx_state / the previous step's staging have been consumed; evaluate_step stages through LDS)
-        evaluate_step<KPT>(a, xx, x, y_pre, s_pre, s_e, s_we, s_x, best, bk, why);
-        if (tid == 0) {
-            resB[bj] = __float_as_int(best);
-            resB[64 + bj] = bk;
-            resB[128 + bj] = xx;
-            resB[192 + bj] = x;
-            resB[256 + bj] = why;
-        }
-        if (!more) break;
-        bj = bn;
-        xx = xx_n;
-        x = x_n;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// A WHOLE LOCAL SEARCH IN ONE WORKGROUP, ONE LAUNCH (round 5).
+// A WHOLE LOCAL SEARCH IN ONE WORKGROUP (round 5).
 //
 // Since only the slots that can go negative are summed (evaluate_step), 85 % of the steps end after their loads and a
-// flag: a step is mostly latency, and what a round paid for -- a kernel boundary and four dependent load levels from a
-// cold cache per accept, 17 workgroups per search -- is more than the work between two accepts.  Here ONE workgroup runs
-// the reference's loop as it stands (Clustering.cpp:82-247: draw, evaluate, accept or count, stop after `corrected`
-// steps without an accept), the state of every position in its registers and the candidate order in LDS from the first
-// step to the last:
-//   * the next Q = 16 pending steps' rows of D are requested together (the draws do not depend on the state) and reduced
-//     to one bit per step, "some member is closer to the candidate than to its medoid"; one barrier for the group;
-//   * only the flagged steps are evaluated, in order, by evaluate_step as before (their rows come from the cache now);
-//     the first negative minimum is the accept, the rest of the group is dropped;
-//   * the accept is applied to the registers (the branches of Clustering.cpp:124-238, the code of the round kernel),
-//     the running cost takes the accept's addends in order, and the loop goes on with the next draw.
-// No other workgroup reads what this one writes, so there is nothing to wait for and nothing that can deadlock; a search
-// holds one workgroup instead of 17 per launch.  When the pre-drawn positions run out the kernel leaves its state where
-// the round kernel would and says so (state[7] = 1): the host draws more and starts it again.
+// flag: a step is mostly latency, and what the launch-per-round form paid per accept -- a kernel boundary, four dependent
+// load levels from a cold cache, 17 workgroups per search -- was more than the work between two accepts.  Here one
+// workgroup runs the reference's loop as it stands (Clustering.cpp:82-247: draw, evaluate, accept or count, stop after
+// `corrected` steps without an accept), the state of every position in its registers from the first step to the last:
+//   * the next Q = 16 pending steps' rows of D are read (the draws do not depend on the state) and reduced to one bit
+//     per step, "some member is closer to the candidate than to its medoid" -- asked member by member, so a row is read as
+//     it lies in memory; one barrier for the group;
+//   * only the flagged steps are evaluated, in order, by evaluate_step (their rows come from the cache now); the first
+//     negative minimum is the accept, the rest of the group is dropped;
+//   * the accept is applied to the registers (the branches of Clustering.cpp:124-238), the running cost takes the
+//     accept's addends in order, and the loop goes on with the next draw.
+// No other workgroup reads what this one writes: nothing to wait for, nothing that can deadlock.  128 VGPRs and 37 KB of
+// LDS, so that the workgroup finds room on a CU next to three workgroups of the LCS kernels (lcs_share_lds) -- with
+// 240 VGPRs / 62 KB it waited for a CU to drain and the stage was no faster than with the rounds
+// (profiles/c5_search_r05.txt).  A launch ends for a search when it is done, when the pre-drawn positions run out
+// (ST_MORE_DRAWS: the host draws more) or when its time slice is over; the state is where the next launch finds it.
 template <int KPT>
 __global__ __launch_bounds__(512, 4) void clarans_search_kernel(ClaransBatch batch, long long slice_ticks)
 {
@@ -1026,14 +766,12 @@ __global__ __launch_bounds__(512, 4) void clarans_search_kernel(ClaransBatch bat
             if (!st) continue;
             st[ST_P] = P;
             st[ST_DONE] = status == 1;
-            st[ST_LOG_LEN] = 0;
             st[ST_ROUNDS] = accepts;
             st[ST_FRESH] = 0;
             st[ST_COST] = __float_as_int(cost);
             st[ST_ERR] = 0;
-            st[7] = status == 2;
+            st[ST_MORE_DRAWS] = status == 2;
             st[ST_OFF] = off;
-            st[ST_STAGE] = 0;
             st[ST_FIRST] = first;
             st[ST_N_ROUNDS] = n_groups;
             st[ST_N_STEPS] = n_steps;
@@ -1071,26 +809,6 @@ hipError_t launch_clarans_search(const ClaransBatch& b, int slice_us, hipStream_
     const long long ticks = (long long)slice_us * 100; // wall_clock64: 100 MHz
     if (kpt <= 1) hipLaunchKernelGGL(clarans_search_kernel<1>, dim3(b.n), dim3(512), 0, stream, b, ticks);
     else hipLaunchKernelGGL(clarans_search_kernel<2>, dim3(b.n), dim3(512), 0, stream, b, ticks);
-    return hipGetLastError();
-}
-
-// `rounds` launches of clarans_round_kernel (an even number: the host reads the parity-0 buffers).  The first window of a
-// local search has `corrected` steps, the later ones corrected - 1 (the reference resets its step counter to 1 after an accept).
-hipError_t launch_clarans_rounds(const ClaransBatch& b, int rounds, int max_step_workgroups, hipStream_t stream)
-{
-    int kpt = 1, steps = 1;
-    for (int i = 0; i < b.n; ++i) {
-        const ClaransArgs& a = b.s[i];
-        kpt = std::max(kpt, ((a.n_medoids + 7) / 8 + 63) / 64);
-        steps = std::max(steps, std::min(std::min(a.corrected, STAGE_MAX), std::max(a.stage0, 1)));
-    }
-    steps = std::max(1, std::min(steps, max_step_workgroups));
-    const dim3 grid(steps + 1, b.n), block(512); // a first stage's steps (later stages: several steps per workgroup) + the cost workgroup
-    for (int r = 0; r < rounds; ++r) {
-        const int last = r == rounds - 1 ? 1 : 0;
-        if (kpt <= 1) hipLaunchKernelGGL(clarans_round_kernel<1>, grid, block, 0, stream, b, r & 1, last);
-        else hipLaunchKernelGGL(clarans_round_kernel<2>, grid, block, 0, stream, b, r & 1, last);
-    }
     return hipGetLastError();
 }
 

@@ -76,9 +76,9 @@ int quirk_h_class(uint32_t len);
 int refs_per_block(int h, bool quirk, bool fused = false);
 // ... reduced for launches that would otherwise have too few workgroups to fill the chip
 int refs_per_block_for(int h, bool quirk, long n_refs, long col_blocks, bool fused = false);
-// lds_min: the dynamic LDS a workgroup claims at least -- a launch that shares the chip with chains of small dependent
-// kernels (the CLARANS rounds of the FastTree recursion) claims more than it needs so that fewer of its workgroups fit a
-// CU and every CU keeps room for one of theirs (lcsgpu_fasttree.hip, LCS_SHARE_LDS)
+// lds_min: the dynamic LDS a workgroup claims at least -- a launch that shares the chip with the CLARANS searches of the
+// FastTree recursion (one latency-bound workgroup each) claims more than it needs so that fewer of its workgroups fit a
+// CU and every CU keeps room for one of theirs (lcsgpu_internal.h, lcs_share_lds)
 hipError_t launch_rows(int h, bool quirk, const RowsArgs& a, int grid_x, int grid_y, hipStream_t stream, size_t lds_min = 0);
 // refs longer than 2048 residues: needs grid_x*grid_y*n_chunks_max*512 bytes of carry scratch
 size_t long_carry_bytes(int grid_x, int grid_y, int n_chunks_max);
@@ -272,24 +272,14 @@ struct ClaransArgs {
     float4* st;          // [n_elems] by position: {d(nearest), d(second), slot(nearest), slot(second)}
     const int32_t* draws; // pre-drawn positions xx of the steps (the position generator's output)
     float* cost_log;     // [1 + n_elems] addends of the running cost, in the reference's order
-    int32_t* state;      // [0] next draw  [1] done  [2] log length  [3] accepts  [4] no round yet  [5] cost bits  [6] error
-                         // [8] steps of the window already evaluated  [9] stage  [10] no accept yet in this search  [11..15] statistics
+    int32_t* state;      // the search's state block (clarans_kernels.hip, ST_*): next draw, done, accepts, cost, window offset, statistics
     int32_t n_elems, n_medoids, n_fixed, draws_len;
     int32_t corrected;   // steps without an accept that end a local search (Clustering.cpp:21-29)
-    int32_t stage0;      // steps evaluated in the first round of a window; doubled per round without an accept, at most 64
-    // the second copy of everything a workgroup reads at its first load level and another writes in the same launch
-    // (by round parity); the parity-0 copies are cand / st / cost_log / state above
-    int32_t* cand1;
-    float4* st1;
-    float* log1;
-    int32_t* state1;
-    int32_t* res2;       // [2][5][64] step results by round parity: best delta (bits), its slot, the step's position, its member, why it ended
-    int32_t* host_state; // mapped host memory (16 words) the last round of a look leaves the state block in, or NULL
+    int32_t* host_state; // mapped host memory (16 words) a launch leaves the state block in as well, or NULL
 };
-constexpr size_t CLARANS_RES_BYTES = 2 * 5 * 64 * 4;
-// Searches that are advanced together, one grid row each: however many host threads are searching, a round costs one
-// launch in total instead of one per search -- with a launch per search the command processor, not the kernels,
-// bounded the throughput beyond ~4 searches.
+// Searches that are advanced together, one workgroup each: however many host threads are searching, a time slice costs
+// one launch in total instead of one per search (a launch per search keeps a hardware queue busy for the whole search and
+// whatever shares the queue waits behind it).
 constexpr int CLARANS_MAX_BATCH = 16;
 struct ClaransBatch {
     ClaransArgs s[CLARANS_MAX_BATCH];
@@ -298,8 +288,7 @@ struct ClaransBatch {
 hipError_t launch_subset_distances(const void* lcs, int elem_size, const int32_t* ids, const uint32_t* lens,
                                    const float* pow_f32, int kind, int n, float* D, hipStream_t stream);
 hipError_t launch_clarans_init(const ClaransArgs& a, hipStream_t stream);
+// every search of the batch for `slice_us` microseconds, or to its end, or until its pre-drawn positions run out
 hipError_t launch_clarans_search(const ClaransBatch& b, int slice_us, hipStream_t stream);
-// rounds even; max_step_workgroups: step workgroups per search at most (fewer than a stage's steps: several steps each)
-hipError_t launch_clarans_rounds(const ClaransBatch& b, int rounds, int max_step_workgroups, hipStream_t stream);
 
 } // namespace lcsgpu

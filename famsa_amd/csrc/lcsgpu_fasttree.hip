@@ -34,12 +34,12 @@ int clarans_extend_draws(ClaransJob& j, size_t want, hipStream_t stream)
     return LCSGPU_OK;
 }
 
-// One stint as the driver: rounds for everything joined, until nothing is left or `mine` is done.
+// One stint as the driver: looks for everything joined, until nothing is left or `mine` is done.
 void clarans_drive(lcsgpu_ctx* ctx, ClaransBatcher& B, ClaransJob* mine)
 {
-    // rounds between two looks at the done flags (even: the host reads the parity-0 buffers); 3 x 10^6 sequences,
-    // round 4: 16 / 32 / 64 -> 1.76-1.82 / 1.86 / 1.85-1.91 s of tree stage
-    static const int rounds_per_look = std::max(2, tune_int("clarans_look", 16)) & ~1;
+    // a look = one launch: every joined search advances for `slice_us` (3 x 10^6 sequences, tree stage: 500 us 1.09-1.11 s,
+    // 1000: 1.06-1.14 s, 2000: 1.22-1.30 s) with at least `draws_ahead` pre-drawn positions in front of it
+    static const int draws_ahead = std::max(1, tune_int("clarans_draws", 8192)), slice_us = std::max(1, tune_int("clarans_slice_us", 1000));
     for (;;) {
         std::vector<ClaransJob*> now;
         {
@@ -59,28 +59,22 @@ void clarans_drive(lcsgpu_ctx* ctx, ClaransBatcher& B, ClaransJob* mine)
             if (e != hipSuccess && rc == LCSGPU_OK) rc = fail(LCSGPU_E_HIP, "%s failed: %s", what, hipGetErrorString(e));
         };
         int32_t* hs = (int32_t*)B.h_states.p;
-        // The rounds leave their state block in the batch's pinned (device-mapped) buffer themselves: no copy per search
+        // The searches leave their state block in the batch's pinned (device-mapped) buffer themselves: no copy per search
         // and look (7-8 copies of 256 B were 110 us of a 2.4 ms look); without the mapping: a copy each.
         int32_t* hs_dev = nullptr;
         if (hipHostGetDevicePointer((void**)&hs_dev, B.h_states.p, 0) != hipSuccess) {
             (void)hipGetLastError();
             hs_dev = nullptr;
         }
-        static const int form = tune_int("clarans_form", 1);
-        static const int draws_ahead = std::max(1, tune_int("clarans_draws", 8192)), slice_us = std::max(1, tune_int("clarans_slice_us", 1000));
         for (ClaransJob* j : now) {
-            // a round uses at most `corrected` draws and prepares the next window; a search on its own stops when they run out
-            if (rc == LCSGPU_OK)
-                rc = clarans_extend_draws(*j, form == 1 ? (size_t)j->p_host + (size_t)j->state[8] + (size_t)draws_ahead
-                                                        : (size_t)j->p_host + (size_t)(rounds_per_look + 1) * std::max(j->a.corrected, 1), B.stream);
+            // (a search that runs out of positions stops and says so; the next look brings more)
+            if (rc == LCSGPU_OK) rc = clarans_extend_draws(*j, (size_t)j->p_host + (size_t)j->state[8] + (size_t)draws_ahead, B.stream);
             lcsgpu::ClaransArgs& s1 = batch.s[batch.n];
             s1 = j->a;
             s1.host_state = hs_dev ? hs_dev + 64 * batch.n : nullptr;
             ++batch.n;
         }
-        static const int step_wgs = std::max(1, tune_int("clarans_wgs", 64)); // step workgroups per search and launch at most
-        if (rc == LCSGPU_OK && form == 1) hip_ok(lcsgpu::launch_clarans_search(batch, slice_us, B.stream), "CLARANS searches");
-        else if (rc == LCSGPU_OK) hip_ok(lcsgpu::launch_clarans_rounds(batch, rounds_per_look, step_wgs, B.stream), "CLARANS rounds");
+        if (rc == LCSGPU_OK) hip_ok(lcsgpu::launch_clarans_search(batch, slice_us, B.stream), "CLARANS searches");
         if (!hs_dev)
             for (size_t i = 0; i < now.size() && rc == LCSGPU_OK; ++i)
                 hip_ok(hipMemcpyAsync(hs + 64 * i, now[i]->a.state, 64, hipMemcpyDeviceToHost, B.stream), "state read-back");
@@ -452,14 +446,11 @@ int lcsgpu_clarans(lcsgpu_ctx* ctx, const int32_t* ids, int32_t n_ids, int dista
     auto a256 = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const size_t o_D = 0, o_DM = o_D + a256((size_t)n * n * 4), o_cand = o_DM + a256((size_t)n * k * 4), o_st = o_cand + a256((size_t)n * 4),
                  o_log = o_st + a256((size_t)n * 16), o_state = o_log + a256((size_t)(n + 1) * 4), o_ids = o_state + 256,
-                 // the second copies (by round parity) and the step results: clarans_round_kernel
-                 o_cand1 = o_ids + a256((size_t)n * 4), o_st1 = o_cand1 + a256((size_t)n * 4), o_log1 = o_st1 + a256((size_t)n * 16),
-                 o_state1 = o_log1 + a256((size_t)(n + 1) * 4), o_res2 = o_state1 + 256, total = o_res2 + a256(lcsgpu::CLARANS_RES_BYTES);
+                 total = o_ids + a256((size_t)n * 4);
     HIP_TRY(L.d_work.reserve(total));
     HIP_TRY(L.h_small.reserve(64));
     char* base = (char*)L.d_work.p;
     HIP_TRY(hipMemsetAsync(base + o_state, 0, 256, L.stream));
-    HIP_TRY(hipMemsetAsync(base + o_state1, 0, 256 + a256(lcsgpu::CLARANS_RES_BYTES), L.stream));
     HIP_TRY(hipMemcpyAsync(base + o_ids, ids, (size_t)n * 4, hipMemcpyHostToDevice, L.stream));
     if (pairs > 0) {
         HIP_TRY(L.d_out.reserve(pairs * elem));
@@ -480,15 +471,6 @@ int lcsgpu_clarans(lcsgpu_ctx* ctx, const int32_t* ids, int32_t n_ids, int dista
     a.n_medoids = k;
     a.n_fixed = n_fixed;
     a.corrected = corrected;
-    // steps evaluated in the first round of a window (1: every round is one step, the reference's own loop; 64: whole
-    // windows) -- decides how much is evaluated speculatively, never which step is accepted
-    static const int stage0 = std::max(1, std::min(64, tune_int("clarans_stage0", 16)));
-    a.stage0 = stage0;
-    a.cand1 = (int32_t*)(base + o_cand1);
-    a.st1 = (float4*)(base + o_st1);
-    a.log1 = (float*)(base + o_log1);
-    a.state1 = (int32_t*)(base + o_state1);
-    a.res2 = (int32_t*)(base + o_res2);
     // The two generators of Clustering.cpp:43-44.  Neither looks at the search state, so the host
     // runs them: gen_nodes shuffles the candidate order before every local search, gen_positions
     // yields the step positions, handed to the device as a growing array of draws.
@@ -519,7 +501,7 @@ int lcsgpu_clarans(lcsgpu_ctx* ctx, const int32_t* ids, int32_t n_ids, int dista
         }
         HIP_TRY(lcsgpu::launch_clarans_init(job.a, L.stream));
         HIP_TRY(hipEventRecord(L.ev_done, L.stream));
-        HIP_TRY(hipEventSynchronize(L.ev_done)); // the rounds run on the batch stream
+        HIP_TRY(hipEventSynchronize(L.ev_done)); // the search runs on the batch's stream
         L.plan_in_flight = false;
         int rc = clarans_run_search(ctx, job);
         if (rc) return rc;

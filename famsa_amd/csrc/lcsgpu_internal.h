@@ -27,9 +27,10 @@ namespace lcsgpu_impl {
 
 // thread-local error text of lcsgpu_last_error(); returns `code`
 int fail(int code, const char* fmt, ...);
-// numeric tuning knobs, LCSGPU_TUNE="key=value,key=value" (no alternate code paths behind them): clarans_stage0 (steps a
-// round evaluates first, 16), clarans_look (rounds between two looks at the done flags, 16), clarans_groups (independent
-// batches of searches, 4), clarans_wgs (step workgroups per search and launch, 64), lcs_share_lds (below), upgma_spare (spare slots of the UPGMA matrix, n / 10)
+// numeric tuning knobs, LCSGPU_TUNE="key=value,key=value" (no alternate code paths behind them): clarans_slice_us (how long a
+// launch advances the searches of a batch, 1000), clarans_draws (pre-drawn step positions in front of a search at a launch,
+// 8192), clarans_groups (independent batches of searches, 4), lcs_share_lds (below), upgma_spare (spare slots of the
+// UPGMA matrix, n / 10)
 int tune_int(const char* key, int dflt);
 
 #define HIP_TRY(expr)                                                                           \
@@ -115,8 +116,8 @@ struct Lane {
 
 // Local searches of several host threads advanced together (lcs_kernels.h, ClaransBatch): every
 // search joins with its device state ready; whichever owner finds no driver becomes the driver and
-// enqueues the rounds for ALL joined searches, looking at their done flags every `rounds_per_look`
-// rounds; a driver whose own search has finished hands the role to one of the remaining owners.
+// launches ALL joined searches for a time slice at a time ("look"), reading their done flags in between;
+// a driver whose own search has finished hands the role to one of the remaining owners.
 struct ClaransJob {
     lcsgpu::ClaransArgs a;
     std::mt19937* gen_positions = nullptr; // the owner's position generator (Clustering.cpp:44)
@@ -178,8 +179,8 @@ struct lcsgpu_ctx {
         bool fused_ready = false;
     } mst;
     double total_kernel_ms = 0; // completed host-memory calls
-    // searches are spread over a few independent batches (each its own stream and driver): rounds of
-    // different batches overlap on the GPU, which hides part of a round's memory latency
+    // searches are spread over a few independent batches (each its own stream and driver): a search joins at the next
+    // look of its batch, so several batches out of step shorten the wait
     std::vector<ClaransBatcher> clarans_groups;
     std::atomic<unsigned> clarans_next{0};
 };
@@ -289,11 +290,11 @@ int run_rows(lcsgpu_ctx* ctx, Lane& L, int mode, const int32_t* ref_ids, int32_t
              int64_t out_offset, int elem_size, int64_t first_row = 0, const lcsgpu::FuseArgs* fuse = nullptr, size_t lds_min = 0);
 // The LDS an LCS launch of the FastTree recursion claims per workgroup at least (launch_rows, lds_min): 40.5 KB -> three
 // of its workgroups per CU instead of five, so that every CU keeps 12 wave slots, 230 VGPRs per lane and 38 KB of LDS
-// free -- room for one workgroup of a CLARANS round (8 waves, 80 VGPRs, 37 KB).  Without it a chip-filling launch
+// free -- room for the workgroup of a CLARANS search (8 waves, 128 VGPRs, 37 KB).  Without it a chip-filling launch
 // (seed assignment of a large split, a batch of leaf matrices: workgroups of 100-300 us, launches of up to 10 ms) leaves
-// the rounds' workgroups waiting for TWO of its workgroups on one CU to retire together: the rounds' p50 was their
-// time alone (39 us) but their mean 63 us (profiles/c5_rounds_r05.txt).  Costs those launches ~8 % of their rate
-// (3 instead of 5 waves per SIMD: 543 vs 592 Tcell/s).  LCSGPU_TUNE lcs_share_lds=<bytes> (0 = off).
+// a search's workgroup waiting for TWO of its workgroups on one CU to retire together (measured on the launch-per-round
+// form, profiles/c5_rounds_r05.txt: the rounds' p50 was their time alone, 39 us, their mean 63 us).  Costs those launches
+// ~8 % of their rate (3 instead of 5 waves per SIMD: 543 vs 592 Tcell/s).  LCSGPU_TUNE lcs_share_lds=<bytes> (0 = off).
 size_t lcs_share_lds();
 // which instantiation the refs of half-word class h run in (target[h] >= h), given wgs[h] = the workgroups class h would
 // have on its own, h = 1 .. 64: small neighbouring classes share a launch (lcsgpu_api.hip)

@@ -174,8 +174,8 @@ def test_c4_row_block_contexts_tree_and_sampled_triangle(oracle, synth100k):
             e.close()
 
 
-@pytest.mark.parametrize("n,env", [(200000, {}), (1000000, {}), (200000, {"LCSGPU_TUNE": "clarans_stage0=5,clarans_look=6,clarans_groups=2"})],
-                         ids=["200000", "1000000", "200000-other-round-shapes"])
+@pytest.mark.parametrize("n,env", [(200000, {}), (1000000, {}), (200000, {"LCSGPU_TUNE": "clarans_slice_us=150,clarans_draws=500,clarans_groups=2"})],
+                         ids=["200000", "1000000", "200000-short-slices"])
 def test_c5_medoid_tree(tmp_path, n, env):
     rec = META[f"family{n}"]
     path = str(tmp_path / f"family_{n}.fasta")

@@ -168,12 +168,11 @@ def test_concurrent_searches_share_the_batch(engine):
         assert together == alone
 
 
-@pytest.mark.parametrize("tune", ["clarans_draws=40", "clarans_slice_us=20,clarans_groups=1", "clarans_form=0"])
-def test_round_shape_does_not_change_the_search(tune):
-    """LCSGPU_TUNE (read once per process, hence the subprocess): how many pending steps a round evaluates first -- 1: every
-    round is one step, the reference's own loop; 5 with 3 step workgroups: stages 5, 10, 20, 40, 64, up to 22 steps per
-    workgroup; 64: whole windows -- how many rounds lie between two looks at the done flags, how many independent batches there
-    are: only how much is evaluated speculatively and when, never which step is accepted."""
+@pytest.mark.parametrize("tune", ["clarans_draws=40", "clarans_slice_us=20,clarans_groups=1", "clarans_slice_us=1000000"])
+def test_where_a_launch_ends_does_not_change_the_search(tune):
+    """LCSGPU_TUNE (read once per process, hence the subprocess): a search is stopped and started again where it stood --
+    every 40 pre-drawn positions; every 20 microseconds, all searches in one batch; or never (a slice longer than any
+    search).  Where a launch ends never changes which step is accepted."""
     import os
     import subprocess
     import sys
