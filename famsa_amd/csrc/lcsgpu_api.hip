@@ -510,6 +510,30 @@ int lcsgpu_reserve_lanes(lcsgpu_ctx* ctx, int32_t n_threads)
     }
     for (ClaransBatcher& B : ctx->clarans_groups)
         if (int rc = ensure_batcher(ctx, B)) return rc;
+    if (n_threads > 1 && !ctx->prep_streams[0]) {
+        int least = 0, greatest = 0;
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = greatest = 0;
+        static const int n_prep = std::max(0, std::min(2, tune_int("clarans_prep_streams", 2)));
+        for (int i = 0; i < n_prep && greatest != least; ++i)
+            HIP_TRY(hipStreamCreateWithPriority(&ctx->prep_streams[i], hipStreamNonBlocking, greatest));
+    }
+    // the lanes' CLARANS buffers out of one allocation: work area for the default MedoidTree shape (2000 sample members, 100
+    // medoids: 17 MB) and its LCS triangle (4 MB); a call that needs more allocates its own
+    if (n_threads > 1 && !ctx->d_lane_arena.p) {
+        constexpr size_t WORK = (size_t)24 << 20, OUT = (size_t)8 << 20;
+        const int n_slices = std::min(limit - 1, n_threads);
+        if (n_slices > 0 && ctx->d_lane_arena.reserve((size_t)n_slices * (WORK + OUT)) == hipSuccess) {
+            std::lock_guard<std::mutex> lk(ctx->mu);
+            for (int i = 0; i < n_slices; ++i) {
+                Lane& l = ctx->lanes[i + 1];
+                if (l.busy) continue;
+                char* slice = (char*)ctx->d_lane_arena.p + (size_t)i * (WORK + OUT);
+                if (!l.d_work.p) l.d_work.adopt(slice, WORK);
+                if (!l.d_out.p) l.d_out.adopt(slice + WORK, OUT);
+            }
+        } else
+            (void)hipGetLastError(); // (no arena: the lanes allocate as before)
+    }
     return LCSGPU_OK;
 }
 
@@ -532,6 +556,11 @@ int lcsgpu_destroy(lcsgpu_ctx* ctx)
         if (l.copy_stream) (void)hipStreamDestroy(l.copy_stream);
         if (l.stream) (void)hipStreamDestroy(l.stream);
     }
+    if (getenv("LCSGPU_PROFILE") && ctx->clarans_calls.load())
+        fprintf(stderr, "clarans.calls=%ld thread-ms per call: lane + buffers %.2f, sample triangle + distances + first start %.2f, later starts %.2f, "
+                        "searches (join to done) %.2f, results %.2f\n", ctx->clarans_calls.load(), 1e-3 * ctx->clarans_us[0] / ctx->clarans_calls,
+                1e-3 * ctx->clarans_us[1] / ctx->clarans_calls, 1e-3 * ctx->clarans_us[2] / ctx->clarans_calls, 1e-3 * ctx->clarans_us[3] / ctx->clarans_calls,
+                1e-3 * ctx->clarans_us[4] / ctx->clarans_calls);
     for (ClaransBatcher& B : ctx->clarans_groups) {
         if (getenv("LCSGPU_PROFILE"))
             for (int i = 1; i <= lcsgpu::CLARANS_MAX_BATCH; ++i)
@@ -546,6 +575,9 @@ int lcsgpu_destroy(lcsgpu_ctx* ctx)
         if (B.ev) (void)hipEventDestroy(B.ev);
         B.h_states.release();
     }
+    ctx->d_lane_arena.release();
+    for (hipStream_t& s : ctx->prep_streams)
+        if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); s = nullptr; }
     ctx->d_tiles.release();
     ctx->d_tile_base.release();
     ctx->d_lens.release();

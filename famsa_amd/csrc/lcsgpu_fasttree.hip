@@ -438,9 +438,23 @@ int lcsgpu_clarans(lcsgpu_ctx* ctx, const int32_t* ids, int32_t n_ids, int dista
                                  : std::max((int)(explore_fraction * n_swaps), min_max_neighbor);
     const int corrected = max_neighbor / k;
 
+    auto t_mark = std::chrono::steady_clock::now();
+    auto lap = [&](int what) { // (LCSGPU_PROFILE's account of the call; a few clock readings per call)
+        const auto t = std::chrono::steady_clock::now();
+        ctx->clarans_us[what] += std::chrono::duration_cast<std::chrono::microseconds>(t - t_mark).count();
+        t_mark = t;
+    };
     LaneGuard guard(ctx, LaneGuard::ANY);
     Lane& L = guard.lane();
     HIP_TRY(hipSetDevice(ctx->device));
+    // everything this call enqueues itself goes to one of the context's high-priority streams, if a multi-threaded caller
+    // has announced itself (lcsgpu_ctx::prep_streams); the lane's own stream is idle meanwhile
+    struct StreamSwap {
+        Lane& l;
+        hipStream_t own;
+        StreamSwap(Lane& lane, hipStream_t s) : l(lane), own(lane.stream) { if (s) l.stream = s; }
+        ~StreamSwap() { l.stream = own; }
+    } swap(L, ctx->prep_streams[0] ? ctx->prep_streams[ctx->prep_next++ % (ctx->prep_streams[1] ? 2 : 1)] : nullptr);
     const int elem = ctx->max_len > 65535 ? 4 : 2;
     const size_t pairs = (size_t)n * (n - 1) / 2;
     auto a256 = [](size_t x) { return (x + 255) & ~(size_t)255; };
@@ -448,12 +462,13 @@ int lcsgpu_clarans(lcsgpu_ctx* ctx, const int32_t* ids, int32_t n_ids, int dista
                  o_log = o_st + a256((size_t)n * 16), o_state = o_log + a256((size_t)(n + 1) * 4), o_ids = o_state + 256,
                  total = o_ids + a256((size_t)n * 4);
     HIP_TRY(L.d_work.reserve(total));
-    HIP_TRY(L.h_small.reserve(64));
+    HIP_TRY(L.h_small.reserve((size_t)n * 4 + 64));
     char* base = (char*)L.d_work.p;
+    if (pairs > 0) HIP_TRY(L.d_out.reserve(pairs * elem));
+    lap(0);
     HIP_TRY(hipMemsetAsync(base + o_state, 0, 256, L.stream));
     HIP_TRY(hipMemcpyAsync(base + o_ids, ids, (size_t)n * 4, hipMemcpyHostToDevice, L.stream));
     if (pairs > 0) {
-        HIP_TRY(L.d_out.reserve(pairs * elem));
         int rc = run_rows(ctx, L, lcsgpu::MODE_TRIANGLE, ids, 0, n, ids, 0, n - 1, L.d_out.p, 0, 0, elem, 0, nullptr, lcs_share_lds());
         if (rc) return rc;
         HIP_TRY(lcsgpu::launch_subset_distances(L.d_out.p, elem, (const int32_t*)(base + o_ids),
@@ -503,17 +518,24 @@ int lcsgpu_clarans(lcsgpu_ctx* ctx, const int32_t* ids, int32_t n_ids, int dista
         HIP_TRY(hipEventRecord(L.ev_done, L.stream));
         HIP_TRY(hipEventSynchronize(L.ev_done)); // the search runs on the batch's stream
         L.plan_in_flight = false;
+        lap(iter == 0 ? 1 : 2); // (the first wait of a call also covers the sample's triangle and distances)
         int rc = clarans_run_search(ctx, job);
         if (rc) return rc;
+        lap(3);
         float cost;
         memcpy(&cost, &job.state[5], 4);
-        HIP_TRY(hipMemcpy(cand.data(), a.cand, (size_t)n * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpyAsync(L.h_small.p, a.cand, (size_t)n * 4, hipMemcpyDeviceToHost, L.stream)); // (a blocking hipMemcpy was 0.4 ms under load)
+        HIP_TRY(hipEventRecord(L.ev_done, L.stream));
+        HIP_TRY(hipEventSynchronize(L.ev_done));
+        memcpy(cand.data(), L.h_small.p, (size_t)n * 4);
+        lap(4);
         if (cost < best_cost) {
             best_cost = cost;
             std::copy(cand.begin(), cand.begin() + k, medoids_out);
         }
     }
     finish_host_call(ctx, L);
+    ctx->clarans_calls += 1;
     return LCSGPU_OK;
 }
 

@@ -45,12 +45,21 @@ int tune_int(const char* key, int dflt);
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
+    bool owned = true; // false: a slice of somebody else's allocation (adopt); outgrown, it is replaced by an allocation of its own
+    void adopt(void* slice, size_t n)
+    {
+        release();
+        p = slice;
+        cap = n;
+        owned = false;
+    }
     hipError_t reserve(size_t n)
     {
         if (n <= cap) return hipSuccess;
-        if (p) (void)hipFree(p);
+        if (p && owned) (void)hipFree(p);
         p = nullptr;
         cap = 0;
+        owned = true;
         // 25% slack so that slowly growing requests do not reallocate every time -- but not on the
         // multi-GB result triangles, where the slack alone could be what does not fit
         size_t want = n + (n < ((size_t)256 << 20) ? n / 4 : 0) + 256;
@@ -60,9 +69,10 @@ struct DevBuf {
     }
     void release()
     {
-        if (p) (void)hipFree(p);
+        if (p && owned) (void)hipFree(p);
         p = nullptr;
         cap = 0;
+        owned = true;
     }
 };
 struct PinBuf {
@@ -183,6 +193,20 @@ struct lcsgpu_ctx {
     // look of its batch, so several batches out of step shorten the wait
     std::vector<ClaransBatcher> clarans_groups;
     std::atomic<unsigned> clarans_next{0};
+    // LCSGPU_PROFILE: where the time of the lcsgpu_clarans calls goes (microseconds, summed over the calling threads): the
+    // lane and its buffers, the sample's LCS triangle + distances, a search's start (order, draws, init kernel), the searches
+    // (join to done), reading the result
+    // one allocation for the CLARANS buffers of the lanes a multi-threaded caller announces (lcsgpu_reserve_lanes): 33 lanes
+    // each allocating 16 + 4 MB on first use, under load, was 3.3 ms per search call at 3 x 10^6 sequences
+    lcsgpu_impl::DevBuf d_lane_arena;
+    // Two high-priority streams for what a host thread of the FastTree recursion waits for before its search can join a
+    // batch -- the sample's triangle, its distances, the search's first state: ~0.6 ms of kernels that spent 5-8 ms behind
+    // the bulk launches (leaf matrices, seed assignment) on the lanes' own streams and shared hardware queues.  (A
+    // high-priority stream per lane: 33 more hardware queues, tree stage 1.08 -> 2.6-3.4 s.)
+    hipStream_t prep_streams[2] = {nullptr, nullptr};
+    std::atomic<unsigned> prep_next{0};
+    std::atomic<long> clarans_us[5] = {};
+    std::atomic<long> clarans_calls{0};
 };
 
 namespace lcsgpu_impl {
