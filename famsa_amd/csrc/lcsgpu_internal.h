@@ -29,8 +29,8 @@ namespace lcsgpu_impl {
 int fail(int code, const char* fmt, ...);
 // numeric tuning knobs, LCSGPU_TUNE="key=value,key=value" (no alternate code paths behind them): clarans_slice_us (how long a
 // launch advances the searches of a batch, 1000), clarans_draws (pre-drawn step positions in front of a search at a launch,
-// 8192), clarans_groups (independent batches of searches, 4), lcs_share_lds (below), upgma_spare (spare slots of the
-// UPGMA matrix, n / 10)
+// 8192), clarans_groups (independent batches of searches, 4), clarans_prep_streams (high-priority streams for what
+// precedes a search, 2; 0 = the lane's own stream), lcs_share_lds (below), upgma_spare (spare slots of the UPGMA matrix, n / 10)
 int tune_int(const char* key, int dflt);
 
 #define HIP_TRY(expr)                                                                           \
