@@ -104,7 +104,7 @@ struct PinBuf {
 // one CLCSBP per worker thread -- get their small LCS requests executed concurrently instead of
 // queueing behind one stream; device-memory calls and the tree reducers always use lane 0, whose
 // stream is the one lcsgpu_stream() hands out.
-constexpr int MAX_LANES = 128;
+constexpr int MAX_LANES = 64;
 struct Lane {
     hipStream_t stream = nullptr;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
