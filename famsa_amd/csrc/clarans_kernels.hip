@@ -526,9 +526,8 @@ __device__ __forceinline__ void rescan_positions(const ClaransArgs& a, const boo
 //   * the accept is applied to the registers (the branches of Clustering.cpp:124-238), the running cost takes the
 //     accept's addends in order, and the loop goes on with the next draw.
 // No other workgroup reads what this one writes: nothing to wait for, nothing that can deadlock.  128 VGPRs and 37 KB of
-// LDS, so that the workgroup finds room on a CU next to three workgroups of the LCS kernels (lcs_share_lds) -- with
-// 240 VGPRs / 62 KB it waited for a CU to drain and the stage was no faster than with the rounds
-// (profiles/c5_search_r05.txt).  A launch ends for a search when it is done, when the pre-drawn positions run out
+// LDS, so that the workgroup finds room on a CU that also runs workgroups of the LCS kernels -- with 240 VGPRs / 62 KB it
+// waited for a CU to drain and the stage was no faster than with the rounds (profiles/c5_search_r05.txt).  A launch ends for a search when it is done, when the pre-drawn positions run out
 // (ST_MORE_DRAWS: the host draws more) or when its time slice is over; the state is where the next launch finds it.
 template <int KPT>
 __global__ __launch_bounds__(512, 4) void clarans_search_kernel(ClaransBatch batch, long long slice_ticks)

@@ -76,10 +76,7 @@ int quirk_h_class(uint32_t len);
 int refs_per_block(int h, bool quirk, bool fused = false);
 // ... reduced for launches that would otherwise have too few workgroups to fill the chip
 int refs_per_block_for(int h, bool quirk, long n_refs, long col_blocks, bool fused = false);
-// lds_min: the dynamic LDS a workgroup claims at least -- a launch that shares the chip with the CLARANS searches of the
-// FastTree recursion (one latency-bound workgroup each) claims more than it needs so that fewer of its workgroups fit a
-// CU and every CU keeps room for one of theirs (lcsgpu_internal.h, lcs_share_lds)
-hipError_t launch_rows(int h, bool quirk, const RowsArgs& a, int grid_x, int grid_y, hipStream_t stream, size_t lds_min = 0);
+hipError_t launch_rows(int h, bool quirk, const RowsArgs& a, int grid_x, int grid_y, hipStream_t stream);
 // refs longer than 2048 residues: needs grid_x*grid_y*n_chunks_max*512 bytes of carry scratch
 size_t long_carry_bytes(int grid_x, int grid_y, int n_chunks_max);
 hipError_t launch_long(bool quirk, const RowsArgs& a, int grid_x, int grid_y, void* carry, int n_chunks_max,

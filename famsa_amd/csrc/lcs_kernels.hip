@@ -865,9 +865,9 @@ int refs_per_block_for(int h, bool quirk, long n_refs, long col_blocks, bool fus
 #endif // !LCS_FUSED_TU
 
 template <int H, int RG, bool QUIRK, bool FUSE>
-static hipError_t launch_one(const RowsArgs& a, dim3 grid, hipStream_t stream, size_t lds_min)
+static hipError_t launch_one(const RowsArgs& a, dim3 grid, hipStream_t stream)
 {
-    const size_t lds = std::max(lds_min, (size_t)a.refs_per_block * ((H + 1) / 2) * 256 + (FUSE ? FUSE_LDS_BYTES : 0));
+    const size_t lds = (size_t)a.refs_per_block * ((H + 1) / 2) * 256 + (FUSE ? FUSE_LDS_BYTES : 0);
     if constexpr (QUIRK)
         hipLaunchKernelGGL((lcs_rows_kernel_quirk<H, FUSE>), grid, dim3(256), lds, stream, a);
     else
@@ -876,20 +876,20 @@ static hipError_t launch_one(const RowsArgs& a, dim3 grid, hipStream_t stream, s
 }
 
 template <bool FUSE>
-static hipError_t launch_rows_t(int h, bool quirk, const RowsArgs& a, int grid_x, int grid_y, hipStream_t stream, size_t lds_min = 0)
+static hipError_t launch_rows_t(int h, bool quirk, const RowsArgs& a, int grid_x, int grid_y, hipStream_t stream)
 {
     const dim3 grid((unsigned)grid_x, (unsigned)grid_y);
     if (quirk) {
         switch (h) {
-        case 8: return launch_one<8, 1, true, FUSE>(a, grid, stream, lds_min);
-        case 16: return launch_one<16, 1, true, FUSE>(a, grid, stream, lds_min);
-        case 32: return launch_one<32, 1, true, FUSE>(a, grid, stream, lds_min);
-        case 64: return launch_one<64, 1, true, FUSE>(a, grid, stream, lds_min);
+        case 8: return launch_one<8, 1, true, FUSE>(a, grid, stream);
+        case 16: return launch_one<16, 1, true, FUSE>(a, grid, stream);
+        case 32: return launch_one<32, 1, true, FUSE>(a, grid, stream);
+        case 64: return launch_one<64, 1, true, FUSE>(a, grid, stream);
         default: return hipErrorInvalidValue;
         }
     }
     switch (h) {
-#define LCS_CASE(B, G) case B: return launch_one<B, G, false, FUSE>(a, grid, stream, lds_min);
+#define LCS_CASE(B, G) case B: return launch_one<B, G, false, FUSE>(a, grid, stream);
         LCS_CASE(1, 4) LCS_CASE(2, 4) LCS_CASE(3, 4) LCS_CASE(4, 4) LCS_CASE(5, 4) LCS_CASE(6, 4)
         LCS_CASE(7, 4) LCS_CASE(8, 4) LCS_CASE(9, 4) LCS_CASE(10, 4) LCS_CASE(11, 4) LCS_CASE(12, 4)
         LCS_CASE(13, LCS_RG13) LCS_CASE(14, 4) LCS_CASE(15, 4) LCS_CASE(16, 4)
@@ -936,10 +936,10 @@ hipError_t launch_long_fused(bool quirk, const RowsArgs& a, int grid_x, int grid
 hipError_t launch_rows_fused(int h, bool quirk, const RowsArgs& a, int grid_x, int grid_y, hipStream_t stream);
 hipError_t launch_long_fused(bool quirk, const RowsArgs& a, int grid_x, int grid_y, void* carry, int n_chunks_max,
                              hipStream_t stream);
-hipError_t launch_rows(int h, bool quirk, const RowsArgs& a, int grid_x, int grid_y, hipStream_t stream, size_t lds_min)
+hipError_t launch_rows(int h, bool quirk, const RowsArgs& a, int grid_x, int grid_y, hipStream_t stream)
 {
     if (a.fuse.on) return launch_rows_fused(h, quirk, a, grid_x, grid_y, stream);
-    return launch_rows_t<false>(h, quirk, a, grid_x, grid_y, stream, lds_min);
+    return launch_rows_t<false>(h, quirk, a, grid_x, grid_y, stream);
 }
 
 size_t long_carry_bytes(int grid_x, int grid_y, int n_chunks_max)

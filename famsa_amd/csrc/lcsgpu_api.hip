@@ -22,11 +22,6 @@ int tune_int(const char* key, int dflt)
     return dflt;
 }
 
-size_t lcs_share_lds()
-{
-    static const size_t v = (size_t)std::max(0, std::min(64 * 1024, tune_int("lcs_share_lds", 41472)));
-    return v;
-}
 
 int fail(int code, const char* fmt, ...)
 {
@@ -198,7 +193,7 @@ int reserve_big(lcsgpu_ctx* ctx, DevBuf& buf, size_t bytes, const char* what)
 // Core: plan + launch.  d_out is a device pointer.
 int run_rows(lcsgpu_ctx* ctx, Lane& L, int mode, const int32_t* ref_ids, int32_t ref_begin, int32_t n_refs,
              const int32_t* col_ids, int32_t col_begin, int32_t n_cols, void* d_out, int64_t ld,
-             int64_t out_offset, int elem_size, int64_t first_row, const lcsgpu::FuseArgs* fuse, size_t lds_min)
+             int64_t out_offset, int elem_size, int64_t first_row, const lcsgpu::FuseArgs* fuse)
 {
     if (ctx->n < 0) return fail(LCSGPU_E_STATE, "no sequence set uploaded");
     if (elem_size != 2 && elem_size != 4) return fail(LCSGPU_E_INVALID, "elem_size must be 2 or 4");
@@ -340,12 +335,12 @@ int run_rows(lcsgpu_ctx* ctx, Lane& L, int mode, const int32_t* ref_ids, int32_t
             a.tri_rows = (int32_t)tri_prefix[b].size() - 1;
             const int total = tri_prefix[b].back();
             if (total > 0) {
-                HIP_TRY(lcsgpu::launch_rows(bk.bv, bk.quirk, a, total, 1, st, lds_min));
+                HIP_TRY(lcsgpu::launch_rows(bk.bv, bk.quirk, a, total, 1, st));
                 ++L.last_launches;
             }
         } else if (bk.bv != 0) {
             if (gy > 65535) return fail(LCSGPU_E_INVALID, "too many ref tiles in one call (%d)", gy);
-            HIP_TRY(lcsgpu::launch_rows(bk.bv, bk.quirk, a, gx, gy, st, lds_min));
+            HIP_TRY(lcsgpu::launch_rows(bk.bv, bk.quirk, a, gx, gy, st));
             ++L.last_launches;
         } else {
             // long refs: slices of ref blocks so the carry scratch stays bounded

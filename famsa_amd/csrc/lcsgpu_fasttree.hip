@@ -189,7 +189,7 @@ static int batch_triangles_to_device(lcsgpu_ctx* ctx, Lane& L, const int32_t* id
             if (m < 2) continue;
             const int32_t* gi = ids + group_offsets[g];
             int rc = run_rows(ctx, L, lcsgpu::MODE_TRIANGLE, gi, 0, m, gi, 0, m - 1,
-                              (char*)L.d_out.p + (size_t)tri_base[g] * elem_size, 0, 0, elem_size, 0, nullptr, lcs_share_lds());
+                              (char*)L.d_out.p + (size_t)tri_base[g] * elem_size, 0, 0, elem_size);
             if (rc) return rc;
             HIP_TRY(hipStreamSynchronize(L.stream));
             finish_host_call(ctx, L);
@@ -313,7 +313,7 @@ static int batch_triangles_to_device(lcsgpu_ctx* ctx, Lane& L, const int32_t* id
         a.elem_size = elem_size;
         a.mode = lcsgpu::MODE_TRIANGLE;
         a.refs_per_block = b.refs_per_wg;
-        HIP_TRY(lcsgpu::launch_rows(b.bv, b.quirk, a, (int)b.jobs.size(), 1, run_stream, lcs_share_lds()));
+        HIP_TRY(lcsgpu::launch_rows(b.bv, b.quirk, a, (int)b.jobs.size(), 1, run_stream));
         ++L.last_launches;
     }
     HIP_TRY(hipEventRecord(L.ev_stop, run_stream));
@@ -378,7 +378,7 @@ int lcsgpu_assign_seeds(lcsgpu_ctx* ctx, const int32_t* seed_ids, int32_t n_seed
         HIP_TRY(hipMemcpyAsync(base + o_cols, col_ids + c0, (size_t)cn * 4, hipMemcpyHostToDevice, L.stream));
         HIP_TRY(hipMemcpyAsync(base + o_dist, dist + c0, (size_t)cn * 4, hipMemcpyHostToDevice, L.stream));
         HIP_TRY(hipMemcpyAsync(base + o_assign, assign + c0, (size_t)cn * 4, hipMemcpyHostToDevice, L.stream));
-        int rc = run_rows(ctx, L, lcsgpu::MODE_RECT, seed_ids, 0, n_seeds, col_ids + c0, 0, cn, L.d_out.p, cn, 0, elem, 0, nullptr, lcs_share_lds());
+        int rc = run_rows(ctx, L, lcsgpu::MODE_RECT, seed_ids, 0, n_seeds, col_ids + c0, 0, cn, L.d_out.p, cn, 0, elem);
         if (rc) return rc;
         HIP_TRY(lcsgpu::launch_assign_seeds(L.d_out.p, elem, cn, (const int32_t*)(base + o_seeds), n_seeds,
                                             (const int32_t*)(base + o_cols), cn, (const uint32_t*)ctx->d_lens.p,
@@ -469,7 +469,7 @@ int lcsgpu_clarans(lcsgpu_ctx* ctx, const int32_t* ids, int32_t n_ids, int dista
     HIP_TRY(hipMemsetAsync(base + o_state, 0, 256, L.stream));
     HIP_TRY(hipMemcpyAsync(base + o_ids, ids, (size_t)n * 4, hipMemcpyHostToDevice, L.stream));
     if (pairs > 0) {
-        int rc = run_rows(ctx, L, lcsgpu::MODE_TRIANGLE, ids, 0, n, ids, 0, n - 1, L.d_out.p, 0, 0, elem, 0, nullptr, lcs_share_lds());
+        int rc = run_rows(ctx, L, lcsgpu::MODE_TRIANGLE, ids, 0, n, ids, 0, n - 1, L.d_out.p, 0, 0, elem);
         if (rc) return rc;
         HIP_TRY(lcsgpu::launch_subset_distances(L.d_out.p, elem, (const int32_t*)(base + o_ids),
                                                 (const uint32_t*)ctx->d_lens.p, (const float*)ctx->d_powf.p,

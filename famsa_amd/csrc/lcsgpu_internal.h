@@ -30,7 +30,7 @@ int fail(int code, const char* fmt, ...);
 // numeric tuning knobs, LCSGPU_TUNE="key=value,key=value" (no alternate code paths behind them): clarans_slice_us (how long a
 // launch advances the searches of a batch, 1000), clarans_draws (pre-drawn step positions in front of a search at a launch,
 // 8192), clarans_groups (independent batches of searches, 4), clarans_prep_streams (high-priority streams for what
-// precedes a search, 2; 0 = the lane's own stream), lcs_share_lds (below), upgma_spare (spare slots of the UPGMA matrix, n / 10)
+// precedes a search, 2; 0 = the lane's own stream), upgma_spare (spare slots of the UPGMA matrix, n / 10)
 int tune_int(const char* key, int dflt);
 
 #define HIP_TRY(expr)                                                                           \
@@ -311,15 +311,7 @@ int order_edges_like_prim(lcsgpu_mst_edge* edges, int32_t n);
 // per-vertex best-edge records (lcs_kernels.h, FuseArgs); d_out may then be NULL (nothing is stored).
 int run_rows(lcsgpu_ctx* ctx, Lane& L, int mode, const int32_t* ref_ids, int32_t ref_begin, int32_t n_refs,
              const int32_t* col_ids, int32_t col_begin, int32_t n_cols, void* d_out, int64_t ld,
-             int64_t out_offset, int elem_size, int64_t first_row = 0, const lcsgpu::FuseArgs* fuse = nullptr, size_t lds_min = 0);
-// The LDS an LCS launch of the FastTree recursion claims per workgroup at least (launch_rows, lds_min): 40.5 KB -> three
-// of its workgroups per CU instead of five, so that every CU keeps 12 wave slots, 230 VGPRs per lane and 38 KB of LDS
-// free -- room for the workgroup of a CLARANS search (8 waves, 128 VGPRs, 37 KB).  Without it a chip-filling launch
-// (seed assignment of a large split, a batch of leaf matrices: workgroups of 100-300 us, launches of up to 10 ms) leaves
-// a search's workgroup waiting for TWO of its workgroups on one CU to retire together (measured on the launch-per-round
-// form, profiles/c5_rounds_r05.txt: the rounds' p50 was their time alone, 39 us, their mean 63 us).  Costs those launches
-// ~8 % of their rate (3 instead of 5 waves per SIMD: 543 vs 592 Tcell/s).  LCSGPU_TUNE lcs_share_lds=<bytes> (0 = off).
-size_t lcs_share_lds();
+             int64_t out_offset, int elem_size, int64_t first_row = 0, const lcsgpu::FuseArgs* fuse = nullptr);
 // which instantiation the refs of half-word class h run in (target[h] >= h), given wgs[h] = the workgroups class h would
 // have on its own, h = 1 .. 64: small neighbouring classes share a launch (lcsgpu_api.hip)
 void merge_small_classes(const double* wgs, int* target);

@@ -108,8 +108,7 @@ def test_c4_single_linkage_tree(synth100k, tmp_path):
     assert file_sha(out) == META["synth100k"]["sl_newick_sha256"]
 
 
-@pytest.mark.parametrize("gt,layout", [("upgma", "square"), ("upgma_modified", "square"), ("upgma", "triangle"),
-                                       ("upgma_modified", "square+steps")])
+@pytest.mark.parametrize("gt,layout", [("upgma", "square+steps"), ("upgma", "triangle"), ("upgma_modified", "square")])
 def test_c4_upgma_trees(synth100k, tmp_path, gt, layout):
     """100 000 merges on the device (one launch each) over the float distances -- the 40 GB symmetric matrix (default)
     or the 20 GB packed triangle: the per-workgroup minima are two per thread at this size (391 workgroups), which no
