@@ -18,7 +18,8 @@ namespace famsa_host {
 // any input), slink_from_mst (the MST -> SLINK conversion with Prim on the host), upgma_triangle (the leaf UPGMA's triangle
 // walk instead of the square matrix), no_device_mst (as if the triangle did not fit the device), clarans_host (the CLARANS
 // search on the host), threads=N (worker threads of the C test entry points), pool=N (threads of the FastTree recursion's task
-// pool instead of twice the cores: measurements).  Not read on any product default path.
+// pool instead of twice the cores: measurements), csv_input_order (-dist_export asks for its rectangles with the columns as
+// they were read instead of by length: measurements).  Not read on any product default path.
 bool host_test(const char* name);
 int host_test_int(const char* key, int dflt);
 // LCSGPU_PROFILE: stage / call statistics on stderr (the library prints its own under the same switch)

@@ -1008,21 +1008,36 @@ static void write_csv_d(LcsSource& src, const std::vector<std::string>& ids, boo
     const int n_threads = std::max(1, default_host_threads());
     const size_t value_text = 48; // upper bound of one formatted value: a saturated integer part has 20 digits
     const size_t row_text = 64 + (size_t)n * value_text;
-    const int block = (int)std::max<size_t>(1, std::min<size_t>({(size_t)n, (size_t)2048, ((size_t)256 << 20) / row_text}));
+    // The set is exported in the order it was read, i.e. NOT sorted by length, and a wave of the LCS kernels walks to the
+    // longest of its 64 partners (-15 % of the kernel's rate on a family set in input order, profiles/bench_workloads_r05.txt).
+    // So a block of rows is asked for as a rectangle whose COLUMNS are in length order -- for the triangle: the columns
+    // j < r1 -- and the text is written from it column by original column.  Blocks of n / 32 rows keep what the rectangle
+    // computes beyond the triangle (the part j >= i of the block's rows) at ~3 %.
+    const int block = (int)std::max<size_t>(1, std::min<size_t>({(size_t)n, (size_t)2048, ((size_t)256 << 20) / row_text,
+                                                                 square ? (size_t)2048 : std::max<size_t>(256, (size_t)n / 32)}));
+    std::vector<int> by_length(n);
+    for (int i = 0; i < n; ++i) by_length[i] = i;
+    if (!host_test("csv_input_order")) // (FAMSA_HOST_TEST: the columns as they were read -- what the length order is measured against)
+        std::stable_sort(by_length.begin(), by_length.end(), [&](int a, int b) { return src.length(a) > src.length(b); });
     LcsBuf buf;
-    std::vector<int> refs;
+    std::vector<int> refs, cols, where(n, -1); // where[j] = column of sequence j in the block's rectangle
     std::vector<std::vector<char>> text(n_threads);
     std::vector<std::vector<size_t>> row_end(n_threads);
     for (int r0 = 0; r0 < n; r0 += block) {
         const int r1 = std::min(n, r0 + block);
-        if (square) {
-            refs.resize(r1 - r0);
-            for (int i = r0; i < r1; ++i) refs[i - r0] = i;
-            src.rect(refs.data(), r1 - r0, nullptr, n, buf);
-        } else {
-            src.triangle(r0, r1, buf);
+        refs.resize(r1 - r0);
+        for (int i = r0; i < r1; ++i) refs[i - r0] = i;
+        const int col_limit = square ? n : r1 - 1; // the triangle's last row needs the columns j < r1 - 1
+        if ((int)cols.size() != col_limit || !square) {
+            cols.clear();
+            for (int j : by_length)
+                if (j < col_limit) {
+                    where[j] = (int)cols.size();
+                    cols.push_back(j);
+                }
         }
-        const size_t off = (size_t)r0 * (r0 > 0 ? r0 - 1 : 0) / 2;
+        const int n_cols = (int)cols.size();
+        if (n_cols > 0) src.rect(refs.data(), r1 - r0, cols.data(), n_cols, buf);
         // thread w formats the rows r0 + w, r0 + w + T, ... (triangle rows grow: interleaving balances them)
         const int T = std::min(n_threads, r1 - r0);
         auto format_rows = [&](int w) {
@@ -1040,7 +1055,7 @@ static void write_csv_d(LcsSource& src, const std::vector<std::string>& ids, boo
                 const int cols = square ? n : i;
                 const uint32_t len_i = src.length(i);
                 for (int j = 0; j < cols; ++j) {
-                    const uint32_t l = square ? buf[(size_t)(i - r0) * n + j] : buf[(size_t)i * (i - 1) / 2 + j - off];
+                    const uint32_t l = buf[(size_t)(i - r0) * n_cols + where[j]];
                     // the reference stores both kinds as float before printing (DistanceCalculator.cpp:44-76)
                     const float v = pid ? t_pid(l, len_i, src.length(j)) : (float)t_dist(l, len_i, src.length(j));
                     p += format_distance((double)v, p);
