@@ -3,7 +3,6 @@
 # whole command; the sets are exported as they were read): the real 13 774-record set, hemopexin, a 30 000-member family set
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
-timeout 600 python -m pytest tests/test_gpu_endtoend.py tests/test_gpu_realmix.py tests/test_gpu_adapter.py tests/test_gpu_multi.py -x -q -m gpu -k "dist_export or csv" 2>&1 | tail -3
 python - <<PY
 import sys, os
 sys.path.insert(0, '.')
@@ -19,8 +18,10 @@ PY
 for f in /tmp/realmix.fasta tests/golden/hemopexin/hemopexin /tmp/family30k_shuffled.fasta; do
   for rep in 1 2 3; do
     for hook in none csv_input_order; do
-      /usr/bin/time -f "%e" -o /tmp/t.txt env FAMSA_HOST_TEST=$hook famsa_amd/famsa-gpu -v -dist_export $f /tmp/o_$hook.csv 2> /tmp/o.err
-      echo "$(basename $f) columns=$([ $hook = none ] && echo by-length || echo input-order) $(grep -E 'gpu.lcs_kernel_ms|time.tree_build' /tmp/o.err | tr '\n' ' ') wall=$(cat /tmp/t.txt) sha=$(sha256sum /tmp/o_$hook.csv | cut -c1-12)" >> gpurun_out/j_dist_export.txt
+      t0=$(date +%s.%N)
+      FAMSA_HOST_TEST=$hook famsa_amd/famsa-gpu -v -dist_export $f /tmp/o_$hook.csv 2> /tmp/o.err
+      t1=$(date +%s.%N)
+      echo "$(basename $f) columns=$([ $hook = none ] && echo by-length || echo input-order) $(grep -E 'gpu.lcs_kernel_ms|time.tree_build' /tmp/o.err | tr '\n' ' ') wall=$(python -c "print(round($t1-$t0,3))") sha=$(sha256sum /tmp/o_$hook.csv | cut -c1-12)" >> gpurun_out/j_dist_export.txt
     done
   done
 done
