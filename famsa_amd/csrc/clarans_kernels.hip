@@ -550,9 +550,6 @@ __global__ __launch_bounds__(512, 4) void clarans_search_kernel(ClaransBatch bat
     __shared__ int s_res[4];            // an evaluation's result for everybody
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int k = a.n_medoids, n = a.n_elems, corrected = a.corrected, cnt = n - k;
-    // finished in the launch before this one (which was enqueued before that was known): nothing here is this workgroup's
-    // to touch any more -- the work area may already belong to the owner's next search or to another call
-    if (a.state[ST_DONE]) return;
     __builtin_amdgcn_s_setprio(3); // a chain of short dependent phases next to the LCS kernels' waves on the same SIMDs
     int P = __builtin_amdgcn_readfirstlane(a.state[ST_P]), off = __builtin_amdgcn_readfirstlane(a.state[ST_OFF]),
         first = __builtin_amdgcn_readfirstlane(a.state[ST_FIRST]), accepts = __builtin_amdgcn_readfirstlane(a.state[ST_ROUNDS]);

@@ -154,11 +154,8 @@ int ensure_batcher(lcsgpu_ctx* ctx, ClaransBatcher& B)
     if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = greatest = 0;
     if (greatest != least) HIP_TRY(hipStreamCreateWithPriority(&B.stream, hipStreamNonBlocking, greatest));
     else HIP_TRY(hipStreamCreateWithFlags(&B.stream, hipStreamNonBlocking));
-    for (int h = 0; h < 2; ++h) HIP_TRY(hipEventCreateWithFlags(&B.ev[h], hipEventBlockingSync | hipEventDisableTiming));
-    HIP_TRY(B.h_states.reserve((size_t)2 * lcsgpu::CLARANS_MAX_BATCH * 256));
-    HIP_TRY(B.d_slots.reserve((size_t)ClaransBatcher::N_SLOTS * 256));
-    B.free_slots.resize(ClaransBatcher::N_SLOTS);
-    for (int s = 0; s < ClaransBatcher::N_SLOTS; ++s) B.free_slots[s] = ClaransBatcher::N_SLOTS - 1 - s;
+    HIP_TRY(hipEventCreateWithFlags(&B.ev, hipEventBlockingSync | hipEventDisableTiming));
+    HIP_TRY(B.h_states.reserve(lcsgpu::CLARANS_MAX_BATCH * 256));
     return LCSGPU_OK;
 }
 
@@ -570,10 +567,8 @@ int lcsgpu_destroy(lcsgpu_ctx* ctx)
                             "steps_without_a_closer_member=%ld steps_without_a_slot_that_can_go_negative=%ld\n", B.prof_searches,
                     B.prof_accepts, B.prof_rounds, B.prof_steps, B.prof_useful, B.prof_no_b, B.prof_no_p);
         if (B.stream) { (void)hipStreamSynchronize(B.stream); (void)hipStreamDestroy(B.stream); }
-        for (int h = 0; h < 2; ++h)
-            if (B.ev[h]) (void)hipEventDestroy(B.ev[h]);
+        if (B.ev) (void)hipEventDestroy(B.ev);
         B.h_states.release();
-        B.d_slots.release();
     }
     ctx->d_lane_arena.release();
     for (hipStream_t& s : ctx->prep_streams)

@@ -34,170 +34,101 @@ int clarans_extend_draws(ClaransJob& j, size_t want, hipStream_t stream)
     return LCSGPU_OK;
 }
 
-// The driver's two moves.  Both are called by the one thread that holds the driver role, without the batcher's lock
-// (they take it where they touch what the owners see: the live table, the slots).
-
-// Enqueue a look over the (up to 16) oldest live searches.  false: nothing is live.
-bool clarans_enqueue_look(ClaransBatcher& B, int slice_us, int draws_ahead)
+// One stint as the driver: looks for everything joined, until nothing is left or `mine` is done.
+void clarans_drive(lcsgpu_ctx* ctx, ClaransBatcher& B, ClaransJob* mine)
 {
-    ClaransLook look;
-    std::vector<ClaransJob*> jobs;
-    {
-        std::lock_guard<std::mutex> lk(B.mu);
-        for (auto& e : B.live) {
-            if ((int)jobs.size() >= lcsgpu::CLARANS_MAX_BATCH) break;
-            look.tickets.push_back(e.first);
-            jobs.push_back(e.second); // (nobody but the driver finishes a search: the pointers stay good for this call)
-        }
-        if (jobs.empty()) return false;
-        look.half = (int)(B.looks_enqueued & 1);
-        ++B.looks_enqueued;
-    }
-    look.t0 = std::chrono::steady_clock::now();
-    int rc = LCSGPU_OK;
-    auto hip_ok = [&](hipError_t e, const char* what) {
-        if (e != hipSuccess && rc == LCSGPU_OK) rc = fail(LCSGPU_E_HIP, "%s failed: %s", what, hipGetErrorString(e));
-    };
-    int32_t* hs = (int32_t*)B.h_states.p + (size_t)look.half * lcsgpu::CLARANS_MAX_BATCH * 64;
-    // The searches leave their state block in the batch's pinned (device-mapped) buffer themselves: no copy per search
-    // and look (7-8 copies of 256 B were 110 us of a 2.4 ms look); without the mapping: a copy each.
-    int32_t* hs_dev = nullptr;
-    if (hipHostGetDevicePointer((void**)&hs_dev, B.h_states.p, 0) != hipSuccess) {
-        (void)hipGetLastError();
-        hs_dev = nullptr;
-    } else
-        hs_dev += (size_t)look.half * lcsgpu::CLARANS_MAX_BATCH * 64;
-    lcsgpu::ClaransBatch batch{};
-    for (ClaransJob* j : jobs) {
-        // p_host / state[8] are where the search stood after the last look that has been READ; one more may be in flight.
-        // (A search that runs out of positions stops and says so; a later look brings more.)
-        if (rc == LCSGPU_OK) rc = clarans_extend_draws(*j, (size_t)j->p_host + (size_t)j->state[8] + (size_t)draws_ahead, B.stream);
-        lcsgpu::ClaransArgs& s1 = batch.s[batch.n];
-        s1 = j->a;
-        s1.host_state = hs_dev ? hs_dev + 64 * batch.n : nullptr;
-        ++batch.n;
-    }
-    if (rc == LCSGPU_OK) hip_ok(lcsgpu::launch_clarans_search(batch, slice_us, B.stream), "CLARANS searches");
-    if (!hs_dev)
-        for (size_t i = 0; i < jobs.size() && rc == LCSGPU_OK; ++i)
-            hip_ok(hipMemcpyAsync(hs + 64 * i, jobs[i]->a.state, 64, hipMemcpyDeviceToHost, B.stream), "state read-back");
-    hip_ok(hipEventRecord(B.ev[look.half], B.stream), "hipEventRecord"); // (also after an error: whatever was queued ends there)
-    look.rc = rc;
-    if (rc != LCSGPU_OK) look.error = lcsgpu_last_error();
-    B.ring.push_back(std::move(look));
-    return true;
-}
-
-// Wait for the oldest look in flight and read it: states, finished searches (their owners are released at once; their
-// slots when every look that names them has completed).
-void clarans_read_look(ClaransBatcher& B)
-{
-    ClaransLook look = std::move(B.ring.front());
-    B.ring.pop_front();
-    int rc = look.rc;
-    std::string msg = look.error;
-    if (hipEventSynchronize(B.ev[look.half]) != hipSuccess && rc == LCSGPU_OK) {
-        rc = LCSGPU_E_HIP;
-        msg = "hipEventSynchronize failed in a CLARANS look";
-    }
-    const int32_t* hs = (const int32_t*)B.h_states.p + (size_t)look.half * lcsgpu::CLARANS_MAX_BATCH * 64;
-    std::lock_guard<std::mutex> lk(B.mu);
-    const size_t width = look.tickets.size();
-    B.prof_looks[width]++;
-    B.prof_seconds[width] += std::chrono::duration<double>(std::chrono::steady_clock::now() - look.t0).count();
-    for (size_t i = 0; i < width; ++i) {
-        auto it = B.live.find(look.tickets[i]);
-        if (it == B.live.end()) continue; // finished in the look before this one: its workgroup here ended at once and wrote nothing
-        ClaransJob* j = it->second;
-        if (rc == LCSGPU_OK) {
-            memcpy(j->state, hs + 64 * i, 64);
-            j->p_host = j->state[0];
-            if (j->state[6]) {
-                j->rc = LCSGPU_E_STATE;
-                j->error = "CLARANS: the device search reported an error";
-            }
-        } else {
-            j->rc = rc;
-            j->error = msg;
-        }
-        if (j->rc != LCSGPU_OK || j->state[1]) {
-            B.prof_searches += 1;
-            B.prof_accepts += j->state[3];
-            B.prof_rounds += j->state[11];
-            B.prof_steps += j->state[12];
-            B.prof_useful += j->state[13];
-            B.prof_no_b += j->state[14];
-            B.prof_no_p += j->state[15];
-            B.retiring.emplace_back(j->slot, B.looks_enqueued); // every look enqueued so far may still name it
-            j->done = true;                                     // (from here on *j is the owner's again)
-            B.live.erase(it);
-        }
-    }
-    ++B.looks_completed;
-    for (size_t r = 0; r < B.retiring.size();) {
-        if (B.retiring[r].second <= B.looks_completed) {
-            B.free_slots.push_back(B.retiring[r].first);
-            B.retiring[r] = B.retiring.back();
-            B.retiring.pop_back();
-        } else
-            ++r;
-    }
-    B.cv.notify_all();
-}
-
-// One stint as the driver: looks for everything live, two in flight, until nothing is live or `mine` is done (looks still
-// in flight then are the next driver's to read).
-void clarans_drive(ClaransBatcher& B, ClaransJob* mine)
-{
-    // a look = one launch: every joined search advances for `slice_us` with at least `draws_ahead` pre-drawn positions in
-    // front of where it stood when it was last read
-    static const int draws_ahead = std::max(1, tune_int("clarans_draws", 8192)), slice_us = std::max(1, tune_int("clarans_slice_us", 500));
-    static const int depth = std::max(1, std::min(2, tune_int("clarans_depth", 2))); // looks in flight
+    // a look = one launch: every joined search advances for `slice_us` (3 x 10^6 sequences, tree stage: 500 us 1.09-1.11 s,
+    // 1000: 1.06-1.14 s, 2000: 1.22-1.30 s) with at least `draws_ahead` pre-drawn positions in front of it
+    static const int draws_ahead = std::max(1, tune_int("clarans_draws", 8192)), slice_us = std::max(1, tune_int("clarans_slice_us", 1000));
     for (;;) {
-        while ((int)B.ring.size() < depth && clarans_enqueue_look(B, slice_us, draws_ahead)) {}
-        if (B.ring.empty()) { // nothing live, nothing in flight
+        std::vector<ClaransJob*> now;
+        {
             std::lock_guard<std::mutex> lk(B.mu);
-            B.driver_present = false;
-            B.cv.notify_all();
-            return;
+            for (ClaransJob* j : B.joined)
+                if ((int)now.size() < lcsgpu::CLARANS_MAX_BATCH) now.push_back(j);
+            if (now.empty() || mine->done) {
+                B.driver_present = false;
+                B.cv.notify_all();
+                return;
+            }
         }
-        clarans_read_look(B);
-        std::lock_guard<std::mutex> lk(B.mu);
-        if (mine->done) {
-            B.driver_present = false;
+        int rc = LCSGPU_OK;
+        const auto t_look = std::chrono::steady_clock::now();
+        lcsgpu::ClaransBatch batch{};
+        auto hip_ok = [&](hipError_t e, const char* what) {
+            if (e != hipSuccess && rc == LCSGPU_OK) rc = fail(LCSGPU_E_HIP, "%s failed: %s", what, hipGetErrorString(e));
+        };
+        int32_t* hs = (int32_t*)B.h_states.p;
+        // The searches leave their state block in the batch's pinned (device-mapped) buffer themselves: no copy per search
+        // and look (7-8 copies of 256 B were 110 us of a 2.4 ms look); without the mapping: a copy each.
+        int32_t* hs_dev = nullptr;
+        if (hipHostGetDevicePointer((void**)&hs_dev, B.h_states.p, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            hs_dev = nullptr;
+        }
+        for (ClaransJob* j : now) {
+            // (a search that runs out of positions stops and says so; the next look brings more)
+            if (rc == LCSGPU_OK) rc = clarans_extend_draws(*j, (size_t)j->p_host + (size_t)j->state[8] + (size_t)draws_ahead, B.stream);
+            lcsgpu::ClaransArgs& s1 = batch.s[batch.n];
+            s1 = j->a;
+            s1.host_state = hs_dev ? hs_dev + 64 * batch.n : nullptr;
+            ++batch.n;
+        }
+        if (rc == LCSGPU_OK) hip_ok(lcsgpu::launch_clarans_search(batch, slice_us, B.stream), "CLARANS searches");
+        if (!hs_dev)
+            for (size_t i = 0; i < now.size() && rc == LCSGPU_OK; ++i)
+                hip_ok(hipMemcpyAsync(hs + 64 * i, now[i]->a.state, 64, hipMemcpyDeviceToHost, B.stream), "state read-back");
+        if (rc == LCSGPU_OK) hip_ok(hipEventRecord(B.ev, B.stream), "hipEventRecord");
+        if (rc == LCSGPU_OK) hip_ok(hipEventSynchronize(B.ev), "hipEventSynchronize");
+        else (void)hipStreamSynchronize(B.stream);
+        {
+            std::lock_guard<std::mutex> lk(B.mu);
+            const std::string msg = rc == LCSGPU_OK ? std::string() : std::string(lcsgpu_last_error());
+            B.prof_looks[now.size()]++;
+            B.prof_seconds[now.size()] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_look).count();
+            for (size_t i = 0; i < now.size(); ++i) {
+                ClaransJob* j = now[i];
+                if (rc == LCSGPU_OK) {
+                    memcpy(j->state, hs + 64 * i, 64);
+                    j->p_host = j->state[0];
+                    if (j->state[6]) {
+                        j->rc = LCSGPU_E_STATE;
+                        j->error = "CLARANS: the device search ran out of pre-drawn steps";
+                    }
+                } else {
+                    j->rc = rc;
+                    j->error = msg;
+                }
+                if (j->rc != LCSGPU_OK || j->state[1]) {
+                    B.prof_searches += 1;
+                    B.prof_accepts += j->state[3];
+                    B.prof_rounds += j->state[11];
+                    B.prof_steps += j->state[12];
+                    B.prof_useful += j->state[13];
+                    B.prof_no_b += j->state[14];
+                    B.prof_no_p += j->state[15];
+                    j->done = true;
+                    B.joined.erase(std::find(B.joined.begin(), B.joined.end(), j));
+                }
+            }
             B.cv.notify_all();
-            return;
         }
     }
-}
-
-// A slot for a search's state block, cleared and holding the position of its first draw; 0 on success.
-int clarans_take_slot(ClaransBatcher& B, ClaransJob& job, hipStream_t stream)
-{
-    {
-        std::lock_guard<std::mutex> lk(B.mu);
-        if (B.free_slots.empty()) return fail(LCSGPU_E_STATE, "CLARANS: no free state slot in the batch (%d searches in flight?)", ClaransBatcher::N_SLOTS);
-        job.slot = B.free_slots.back();
-        B.free_slots.pop_back();
-    }
-    job.a.state = (int32_t*)B.d_slots.p + (size_t)job.slot * 64;
-    HIP_TRY(hipMemsetAsync(job.a.state, 0, 256, stream));
-    HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)job.a.state, job.p_host, 1, stream)); // (ST_P: the searches of a call share one stream of draws)
-    return LCSGPU_OK;
 }
 
 // Join the batch with a search whose device state is initialised; returns when it has finished.
-int clarans_run_search(ClaransBatcher& B, ClaransJob& job)
+int clarans_run_search(lcsgpu_ctx* ctx, ClaransJob& job)
 {
+    ClaransBatcher& B = ctx->clarans_groups[ctx->clarans_next++ % ctx->clarans_groups.size()];
+    if (int rc = ensure_batcher(ctx, B)) return rc;
     job.done = false;
     std::unique_lock<std::mutex> lk(B.mu);
-    job.ticket = B.next_ticket++;
-    B.live.emplace(job.ticket, &job);
+    B.joined.push_back(&job);
     while (!job.done) {
         if (!B.driver_present) {
             B.driver_present = true;
             lk.unlock();
-            clarans_drive(B, &job);
+            clarans_drive(ctx, B, &job);
             lk.lock();
         } else {
             B.cv.wait(lk, [&] { return job.done || !B.driver_present; });
@@ -528,13 +459,14 @@ int lcsgpu_clarans(lcsgpu_ctx* ctx, const int32_t* ids, int32_t n_ids, int dista
     const size_t pairs = (size_t)n * (n - 1) / 2;
     auto a256 = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const size_t o_D = 0, o_DM = o_D + a256((size_t)n * n * 4), o_cand = o_DM + a256((size_t)n * k * 4), o_st = o_cand + a256((size_t)n * 4),
-                 o_log = o_st + a256((size_t)n * 16), o_ids = o_log + a256((size_t)(n + 1) * 4), total = o_ids + a256((size_t)n * 4);
+                 o_log = o_st + a256((size_t)n * 16), o_state = o_log + a256((size_t)(n + 1) * 4), o_ids = o_state + 256,
+                 total = o_ids + a256((size_t)n * 4);
     HIP_TRY(L.d_work.reserve(total));
     HIP_TRY(L.h_small.reserve((size_t)n * 4 + 64));
     char* base = (char*)L.d_work.p;
     if (pairs > 0) HIP_TRY(L.d_out.reserve(pairs * elem));
-    HIP_TRY(L.d_draws.reserve((size_t)256 << 10)); // (room for the draws of nearly every search: the buffer must not have to grow under a look in flight)
     lap(0);
+    HIP_TRY(hipMemsetAsync(base + o_state, 0, 256, L.stream));
     HIP_TRY(hipMemcpyAsync(base + o_ids, ids, (size_t)n * 4, hipMemcpyHostToDevice, L.stream));
     if (pairs > 0) {
         int rc = run_rows(ctx, L, lcsgpu::MODE_TRIANGLE, ids, 0, n, ids, 0, n - 1, L.d_out.p, 0, 0, elem);
@@ -549,7 +481,8 @@ int lcsgpu_clarans(lcsgpu_ctx* ctx, const int32_t* ids, int32_t n_ids, int dista
     a.cand = (int32_t*)(base + o_cand);
     a.st = (float4*)(base + o_st);
     a.cost_log = (float*)(base + o_log);
-    a.n_elems = n; // (a.state: a slot of the batch the search joins, clarans_take_slot)
+    a.state = (int32_t*)(base + o_state);
+    a.n_elems = n;
     a.n_medoids = k;
     a.n_fixed = n_fixed;
     a.corrected = corrected;
@@ -577,9 +510,6 @@ int lcsgpu_clarans(lcsgpu_ctx* ctx, const int32_t* ids, int32_t n_ids, int dista
             }
         }
         HIP_TRY(hipMemcpyAsync(a.cand, cand.data(), (size_t)n * 4, hipMemcpyHostToDevice, L.stream));
-        ClaransBatcher& B = ctx->clarans_groups[ctx->clarans_next++ % ctx->clarans_groups.size()];
-        if (int rc = ensure_batcher(ctx, B)) return rc;
-        if (int rc = clarans_take_slot(B, job, L.stream)) return rc;
         {   // the first draws (the init kernel checks that a window's worth is there)
             int rc = clarans_extend_draws(job, (size_t)job.p_host + (size_t)std::max(corrected, 1), L.stream);
             if (rc) return rc;
@@ -589,7 +519,7 @@ int lcsgpu_clarans(lcsgpu_ctx* ctx, const int32_t* ids, int32_t n_ids, int dista
         HIP_TRY(hipEventSynchronize(L.ev_done)); // the search runs on the batch's stream
         L.plan_in_flight = false;
         lap(iter == 0 ? 1 : 2); // (the first wait of a call also covers the sample's triangle and distances)
-        int rc = clarans_run_search(B, job);
+        int rc = clarans_run_search(ctx, job);
         if (rc) return rc;
         lap(3);
         float cost;

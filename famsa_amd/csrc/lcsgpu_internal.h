@@ -12,7 +12,6 @@
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
-#include <deque>
 #include <limits>
 #include <map>
 #include <mutex>
@@ -29,7 +28,7 @@ namespace lcsgpu_impl {
 // thread-local error text of lcsgpu_last_error(); returns `code`
 int fail(int code, const char* fmt, ...);
 // numeric tuning knobs, LCSGPU_TUNE="key=value,key=value" (no alternate code paths behind them): clarans_slice_us (how long a
-// launch advances the searches of a batch, 500), clarans_depth (launches of a batch in flight, 2; 1 = read one before the next), clarans_draws (pre-drawn step positions in front of a search at a launch,
+// launch advances the searches of a batch, 1000), clarans_draws (pre-drawn step positions in front of a search at a launch,
 // 8192), clarans_groups (independent batches of searches, 4), clarans_prep_streams (high-priority streams for what
 // precedes a search, 2; 0 = the lane's own stream), upgma_spare (spare slots of the UPGMA matrix, n / 10)
 int tune_int(const char* key, int dflt);
@@ -129,47 +128,25 @@ struct Lane {
 // search joins with its device state ready; whichever owner finds no driver becomes the driver and
 // launches ALL joined searches for a time slice at a time ("look"), reading their done flags in between;
 // a driver whose own search has finished hands the role to one of the remaining owners.
-// TWO LOOKS ARE KEPT IN FLIGHT: the one behind the look being read is enqueued before any result is known, so the batch's
-// stream never waits for the host (0.15 ms per 1 ms look) and the slices can be short (joining / leaving a batch costs half a
-// slice on average).  A search that has finished is therefore still named by the look behind: its workgroup there sees the
-// done flag and ends at once.  For that to be safe the state blocks live in the BATCHER's memory (a slot per search, given
-// back only when every look that names it has completed -- a lane's work area may belong to another call by then), the
-// owner is released at once, and a look's records are matched to searches by ticket, never by pointer.
 struct ClaransJob {
     lcsgpu::ClaransArgs a;
     std::mt19937* gen_positions = nullptr; // the owner's position generator (Clustering.cpp:44)
     std::vector<int32_t>* draws = nullptr; // its output so far, as accepted draws
     lcsgpu_impl::DevBuf* d_draws = nullptr;
     int32_t p_host = 0;
-    uint64_t ticket = 0; // names this search in the batcher's looks
-    int slot = -1;       // its state block in the batcher's slot memory
     int32_t state[16] = {0};
     bool done = false;
     int rc = LCSGPU_OK;
     std::string error;
 };
-struct ClaransLook { // a look in flight
-    std::vector<uint64_t> tickets; // the searches it advances, in the order of its workgroups / state records
-    int half = 0;                  // which event and which half of the pinned state records it uses
-    int rc = 0;
-    std::string error;
-    std::chrono::steady_clock::time_point t0;
-};
 struct ClaransBatcher {
-    static constexpr int N_SLOTS = 256;
     std::mutex mu;
     std::condition_variable cv;
-    std::map<uint64_t, ClaransJob*> live; // joined and not finished, by ticket (= by age)
-    uint64_t next_ticket = 1;
+    std::vector<ClaransJob*> joined;
     bool driver_present = false;
     hipStream_t stream = nullptr;
-    hipEvent_t ev[2] = {nullptr, nullptr};
-    std::deque<ClaransLook> ring;         // looks in flight, oldest first (the driver's; at most two)
-    uint64_t looks_enqueued = 0, looks_completed = 0;
-    lcsgpu_impl::DevBuf d_slots;          // [N_SLOTS][64 words]: the searches' state blocks
-    std::vector<int> free_slots;
-    std::vector<std::pair<int, uint64_t>> retiring; // (slot, free once looks_completed reaches this)
-    lcsgpu_impl::PinBuf h_states;         // [2 halves][CLARANS_MAX_BATCH][64 words]
+    hipEvent_t ev = nullptr;
+    lcsgpu_impl::PinBuf h_states;
     // LCSGPU_PROFILE: looks and seconds by number of searches in the batch
     long prof_looks[lcsgpu::CLARANS_MAX_BATCH + 1] = {0};
     double prof_seconds[lcsgpu::CLARANS_MAX_BATCH + 1] = {0};

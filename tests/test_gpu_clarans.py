@@ -168,7 +168,7 @@ def test_concurrent_searches_share_the_batch(engine):
         assert together == alone
 
 
-@pytest.mark.parametrize("tune", ["clarans_draws=40,clarans_slice_us=20,clarans_groups=1", "clarans_slice_us=1000000,clarans_prep_streams=0,clarans_depth=1"])
+@pytest.mark.parametrize("tune", ["clarans_draws=40,clarans_slice_us=20,clarans_groups=1", "clarans_slice_us=1000000,clarans_prep_streams=0"])
 def test_where_a_launch_ends_does_not_change_the_search(tune):
     """LCSGPU_TUNE (read once per process, hence the subprocess): a search is stopped and started again where it stood --
     every 40 pre-drawn positions or 20 microseconds, all searches in one batch; or never (a slice longer than any search,
