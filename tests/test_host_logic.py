@@ -94,6 +94,33 @@ def test_prim_with_one_row_per_step(host, oracle, monkeypatch, name, gold):
     assert host.tree_from_matrix(f, m, "sl") == open(os.path.join(G, gold), "rb").read()
 
 
+@pytest.mark.parametrize("pid", [False, True])
+def test_dist_export_row_blocks_and_column_order(host, oracle, tmp_path, monkeypatch, pid):
+    """-dist_export asks for its rows in blocks, each as a rectangle whose columns are in LENGTH order, and writes the text
+    column by original column (host/trees.cpp, write_csv_d).  700 ragged sequences in no particular order = three row blocks
+    of the triangle form: every row of the triangle must be the head of the same row of the square form (one block; that form
+    with permuted columns is pinned to the reference's files by the tests above), and the export with the columns as they were
+    read must be the same bytes."""
+    rng = np.random.default_rng(77)
+    lens = rng.integers(5, 60, size=700)
+    fasta = str(tmp_path / "ragged.fasta")
+    with open(fasta, "w") as f:
+        for i, n in enumerate(lens):
+            f.write(f">r{i}\n" + "".join("ACDEFGHIKLMNPQRSTVWY"[c] for c in rng.integers(0, 20, size=int(n))) + "\n")
+    m = square(oracle, fasta, symmetric_ok=False)
+    tri, sq, tri_in = (str(tmp_path / n) for n in ("tri.csv", "sq.csv", "tri_input.csv"))
+    host.dist_export_from_matrix(fasta, m, tri, pid=pid)
+    host.dist_export_from_matrix(fasta, m, sq, square_matrix=True, pid=pid)
+    monkeypatch.setenv("FAMSA_HOST_TEST", "csv_input_order")
+    host.dist_export_from_matrix(fasta, m, tri_in, pid=pid)
+    assert open(tri, "rb").read() == open(tri_in, "rb").read()
+    rows_tri = open(tri).read().split("\n")[:-1]
+    rows_sq = open(sq).read().split("\n")[1:-1]  # (the square form starts with a header line)
+    assert len(rows_tri) == len(rows_sq) == 700
+    for i, (a, b) in enumerate(zip(rows_tri, rows_sq)):
+        assert a.split(",") == b.split(",")[: i + 1], i
+
+
 def test_adversarial_csv_zero_lcs(host, oracle, tmp_path):
     f = os.path.join(G, "adversarial.fasta")
     m = square(oracle, f, symmetric_ok=False)
