@@ -505,6 +505,7 @@ int lcsgpu_reserve_lanes(lcsgpu_ctx* ctx, int32_t n_threads)
     }
     for (ClaransBatcher& B : ctx->clarans_groups)
         if (int rc = ensure_batcher(ctx, B)) return rc;
+    HIP_TRY(hipSetDevice(ctx->device));
     if (n_threads > 1 && !ctx->prep_streams[0]) {
         int least = 0, greatest = 0;
         if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = greatest = 0;
