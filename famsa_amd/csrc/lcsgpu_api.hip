@@ -148,8 +148,8 @@ int ensure_batcher(lcsgpu_ctx* ctx, ClaransBatcher& B)
     std::lock_guard<std::mutex> lk(B.mu);
     if (B.stream) return LCSGPU_OK;
     HIP_TRY(hipSetDevice(ctx->device));
-    // the rounds are chains of small dependent kernels next to the lanes' LCS launches, which fill the chip for
-    // hundreds of microseconds each: their workgroups go first when slots free up
+    // a search is one latency-bound workgroup next to the lanes' LCS launches, which fill the chip for hundreds of
+    // microseconds each: its workgroup goes first when slots free up
     int least = 0, greatest = 0;
     if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = greatest = 0;
     if (greatest != least) HIP_TRY(hipStreamCreateWithPriority(&B.stream, hipStreamNonBlocking, greatest));
@@ -564,7 +564,7 @@ int lcsgpu_destroy(lcsgpu_ctx* ctx)
                     fprintf(stderr, "clarans.batch[%d searches]: %ld looks, %.3f s, %.1f us per look\n", i, B.prof_looks[i],
                             B.prof_seconds[i], 1e6 * B.prof_seconds[i] / B.prof_looks[i]);
         if (getenv("LCSGPU_PROFILE") && B.prof_searches)
-            fprintf(stderr, "clarans.searches=%ld accepts=%ld rounds=%ld steps_evaluated=%ld steps_up_to_the_accept=%ld "
+            fprintf(stderr, "clarans.searches=%ld accepts=%ld step_groups=%ld steps_looked_at=%ld steps_up_to_the_accept=%ld "
                             "steps_without_a_closer_member=%ld steps_without_a_slot_that_can_go_negative=%ld\n", B.prof_searches,
                     B.prof_accepts, B.prof_rounds, B.prof_steps, B.prof_useful, B.prof_no_b, B.prof_no_p);
         if (B.stream) { (void)hipStreamSynchronize(B.stream); (void)hipStreamDestroy(B.stream); }

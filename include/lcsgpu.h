@@ -363,7 +363,8 @@ int lcsgpu_assign_seeds(lcsgpu_ctx* ctx, const int32_t* seed_ids, int32_t n_seed
  * numbers the result refers to).  medoids_out (HOST, n_medoids entries): member numbers 0..n_ids-1
  * of the chosen medoids, slot order; slots < n_fixed are never swapped (the reference pins member 0).
  * Returns LCSGPU_E_UNSUPPORTED when the shape is outside what the device search handles
- * (n_medoids > 1024): the caller then runs its own host search.
+ * (n_medoids > 1024 or n_ids - n_medoids > 2048): the caller then runs its own host search.
+ * Thread-safe; the searches of concurrent callers share launches (one workgroup per search).
  * Replaces: the sample matrix + CLARANS::operator() in FastTree::clusterSeeds
  * (tree/FastTree.cpp:412-417, tree/Clustering.cpp:17-305). */
 int lcsgpu_clarans(lcsgpu_ctx* ctx, const int32_t* ids, int32_t n_ids, int distance_kind, int32_t n_medoids,
