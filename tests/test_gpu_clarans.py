@@ -60,6 +60,8 @@ CASES = [
     ("one-medoid-many-members", "family", 1300, 1200, 1, 0, 0.02, 2, 1),
     ("three-medoids", "family", 2100, 2040, 3, 1, 0.01, 2, 1),
     ("most-non-medoids-the-device-takes", "family", 2200, 2088, 40, 1, 0.01, 1, 1),
+    # more than 512 medoids: two slots per lane in the walk (the kernel's second instantiation)
+    ("more-than-512-medoids", "family", 1500, 1400, 600, 1, 0.02, 1, 1),
     # duplicate members: distances tie exactly (d_new == dn with a smaller slot, equal second-nearest medoids)
     ("duplicates-tie-exactly", "dups", 300, 280, 12, 1, 0.3, 2, 1),
 ]
