@@ -403,22 +403,22 @@ private:
 // dominant cluster; results do not depend on who builds a sub-tree or when.
 class TaskPool {
 public:
-    explicit TaskPool(int n_threads)
+    TaskPool(int n_threads, int leaf_max) : leaf_max_(leaf_max)
     {
         for (int w = 1; w < n_threads; ++w)
             workers_.emplace_back([this] {
                 std::unique_lock<std::mutex> lk(mu_);
                 for (;;) {
-                    if (!stop_ && q_.empty()) {
+                    if (!stop_ && nothing_queued()) {
                         g_timeline.note(Timeline::IDLE, +1);
-                        cv_.wait(lk, [this] { return stop_ || !q_.empty(); });
+                        cv_.wait(lk, [this] { return stop_ || !nothing_queued(); });
                         g_timeline.note(Timeline::IDLE, -1);
                     }
                     if (stop_) return;
                     lk.unlock();
                     g_cpu.acquire();
                     lk.lock();
-                    if (!q_.empty()) run_top(lk);
+                    if (!nothing_queued()) run_top(lk);
                     g_cpu.release();
                 }
             });
@@ -440,14 +440,16 @@ public:
     // `leaf_work`: the task ends in host work on data that is (or is about to be) there -- a batch of leaf matrices, leaf
     // trees.  Such tasks go before any split: a split's thread waits for the GPU most of its time and keeps no core busy,
     // so leaf work that is left to the end runs on the cores alone while the GPU idles (3 x 10^6 sequences: the last
-    // 0.25 s of a 1.15 s stage, profiles/c5_timeline_r05.txt).
+    // 0.25 s of a 1.15 s stage, profiles/c5_timeline_r05.txt) -- but on at most `leaf_max` threads at a time while splits are
+    // waiting, so that the searches of the splits keep the threads they need.
     void submit(Group& g, size_t weight, std::function<void()> fn, bool leaf_work = false)
     {
         {
             std::lock_guard<std::mutex> lk(mu_);
             ++g.remaining;
-            q_.push_back(Item{leaf_work, weight, seq_++, &g, std::move(fn)});
-            std::push_heap(q_.begin(), q_.end());
+            std::vector<Item>& q = leaf_work ? q_leaf_ : q_split_;
+            q.push_back(Item{leaf_work, weight, seq_++, &g, std::move(fn)});
+            std::push_heap(q.begin(), q.end());
         }
         cv_.notify_one();
     }
@@ -456,13 +458,13 @@ public:
     {
         std::unique_lock<std::mutex> lk(mu_);
         while (g.remaining > 0) {
-            if (!q_.empty()) {
+            if (!nothing_queued()) {
                 run_top(lk);
                 continue;
             }
             g_cpu.release(); // idle until a sub-task finishes or new work arrives
             g_timeline.note(Timeline::IDLE, +1);
-            cv_.wait(lk, [&] { return g.remaining == 0 || !q_.empty(); });
+            cv_.wait(lk, [&] { return g.remaining == 0 || !nothing_queued(); });
             g_timeline.note(Timeline::IDLE, -1);
             lk.unlock();
             g_cpu.acquire();
@@ -478,17 +480,17 @@ private:
         uint64_t seq;
         Group* group;
         std::function<void()> fn;
-        bool operator<(const Item& o) const
-        {
-            if (leaf_work != o.leaf_work) return !leaf_work;
-            return weight != o.weight ? weight < o.weight : seq > o.seq;
-        }
+        bool operator<(const Item& o) const { return weight != o.weight ? weight < o.weight : seq > o.seq; }
     };
+    bool nothing_queued() const { return q_leaf_.empty() && q_split_.empty(); }
     void run_top(std::unique_lock<std::mutex>& lk)
-    { // called with the lock held; runs the heaviest queued task unlocked
-        std::pop_heap(q_.begin(), q_.end());
-        Item it = std::move(q_.back());
-        q_.pop_back();
+    { // called with the lock held; runs the heaviest queued task of the kind whose turn it is, unlocked
+        const bool leaf = !q_leaf_.empty() && (leaf_running_ < leaf_max_ || q_split_.empty());
+        std::vector<Item>& q = leaf ? q_leaf_ : q_split_;
+        std::pop_heap(q.begin(), q.end());
+        Item it = std::move(q.back());
+        q.pop_back();
+        if (leaf) ++leaf_running_;
         lk.unlock();
         std::string err;
         try {
@@ -497,12 +499,15 @@ private:
             err = e.what();
         }
         lk.lock();
+        if (leaf) --leaf_running_;
         if (!err.empty() && it.group->error.empty()) it.group->error = err;
         if (--it.group->remaining == 0) cv_.notify_all();
     }
     std::mutex mu_;
     std::condition_variable cv_;
-    std::vector<Item> q_;
+    std::vector<Item> q_leaf_, q_split_;
+    int leaf_running_ = 0;
+    const int leaf_max_;
     std::vector<std::thread> workers_;
     uint64_t seq_ = 0;
     bool stop_ = false;
@@ -849,8 +854,8 @@ void run_fast(LcsSource& src, GT partial, const FastTreeParams& p, tree_structur
     const int n = src.n();
     tree.assign(n, node_t(-1, -1));
     if (n < 2) return;
-    // `n_threads` cores' worth of host work, twice as many threads to keep GPU requests in flight (3 x 10^6
-    // sequences, 16 cores, tree stage: 16 threads 2.6 s, 32: 2.2 s, 48: 2.15 s)
+    // `n_threads` cores' worth of host work, two and a half times as many threads to keep GPU requests in flight
+    // (trees.h, fasttree_pool_threads)
     const int n_cpu = std::max(1, p.n_threads);
     int n_pool = host_test_int("pool", fasttree_pool_threads(n_cpu)); // (FAMSA_HOST_TEST pool=N: sweeps)
     src.expect_threads(n_pool);
@@ -859,7 +864,7 @@ void run_fast(LcsSource& src, GT partial, const FastTreeParams& p, tree_structur
     struct Giveback {
         ~Giveback() { g_cpu.reset(0); }
     } giveback;
-    TaskPool pool(n_pool);
+    TaskPool pool(n_pool, host_test_int("leafmax", fasttree_leaf_threads(n_pool))); // (FAMSA_HOST_TEST leafmax=N: sweeps)
     FastTree<D> ft{src, partial, p, &pool, {}};
     std::vector<int> ids(n);
     std::iota(ids.begin(), ids.end(), 0);

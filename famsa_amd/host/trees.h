@@ -53,8 +53,12 @@ struct FastTreeParams { // CParams::medoid, reference core/params.h:88-97
     // split ends up with (depth 0 only), as ids of the source, in seed order
     std::vector<int>* top_seeds = nullptr;
 };
-// threads of the recursion's task pool for `n_cpu` cores: the ones waiting for the GPU cost no core
-inline int fasttree_pool_threads(int n_cpu) { return n_cpu > 1 ? 2 * n_cpu : 1; }
+// threads of the recursion's task pool for `n_cpu` cores: the ones waiting for the GPU cost no core.  A quarter of them at
+// most work on leaves while splits are waiting (fasttree.cpp, TaskPool).  3 x 10^6 sequences, 16 cores, tree stage: 32
+// threads, leaves on any number of them 1.09-1.13 s; 32 / 8: 0.99-1.01 s; 40 / 10: 0.92-0.95 s; 48 / 16: 1.05-1.09 s
+// (profiles/c5_pool_r05.txt).
+inline int fasttree_pool_threads(int n_cpu) { return n_cpu > 1 ? (5 * n_cpu + 1) / 2 : 1; }
+inline int fasttree_leaf_threads(int n_pool) { return n_pool > 4 ? n_pool / 4 : n_pool; }
 void build_tree_fast(LcsSource& src, GT partial, Distance dist, const FastTreeParams& p, tree_structure& tree);
 // the host form of the CLARANS search (used when the LcsSource does not run it itself)
 void clarans_host(const float* distances, int n_elems, int n_medoids, int n_fixed, float explore_fraction, int num_local,
