@@ -452,8 +452,15 @@ int lcsgpu_clarans(lcsgpu_ctx* ctx, const int32_t* ids, int32_t n_ids, int dista
     struct StreamSwap {
         Lane& l;
         hipStream_t own;
+        bool settled = false; // the call has waited for the last thing it queued
         StreamSwap(Lane& lane, hipStream_t s) : l(lane), own(lane.stream) { if (s) l.stream = s; }
-        ~StreamSwap() { l.stream = own; }
+        ~StreamSwap()
+        {
+            // an early return (an error) may leave work of this call queued on the shared stream: the lane and its buffers
+            // go back to the pool with this guard, so wait for it
+            if (!settled && l.stream != own) (void)hipStreamSynchronize(l.stream);
+            l.stream = own;
+        }
     } swap(L, ctx->prep_streams[0] ? ctx->prep_streams[ctx->prep_next++ % (ctx->prep_streams[1] ? 2 : 1)] : nullptr);
     const int elem = ctx->max_len > 65535 ? 4 : 2;
     const size_t pairs = (size_t)n * (n - 1) / 2;
@@ -535,6 +542,7 @@ int lcsgpu_clarans(lcsgpu_ctx* ctx, const int32_t* ids, int32_t n_ids, int dista
         }
     }
     finish_host_call(ctx, L);
+    swap.settled = true;
     ctx->clarans_calls += 1;
     return LCSGPU_OK;
 }
