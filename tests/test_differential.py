@@ -122,6 +122,28 @@ def test_medoid_and_parttree_match_reference(host, ref, oracle, tmp_path, seed):
         ref.close(h)
 
 
+@pytest.mark.parametrize("hooks", ["threads=1", "threads=2,pool=7,leafmax=1", "threads=4,pool=12,leafmax=12", "threads=3,pool=3"])
+def test_the_pools_shape_does_not_change_the_tree(host, oracle, tmp_path, monkeypatch, hooks):
+    """The FastTree recursion's task pool (host/fasttree.cpp, TaskPool): how many threads it has, how many of them may work
+    on leaves while splits wait, or no pool at all -- the tree is assembled by index, so every schedule gives the bytes the
+    default gives (which the test above pins to the reference)."""
+    rng = np.random.Generator(np.random.PCG64(501))
+    n = 600
+    ids, seqs = random_set(rng, n, 60, "ACDEFG", 0.1)
+    fasta = str(tmp_path / "in.fasta")
+    with open(fasta, "w") as f:
+        for i, s in zip(ids, seqs):
+            f.write(f"{i}\n{s}\n")
+    enc = [oracle.encode(s) for s in seqs]
+    codes, offsets = seqio.pack(enc)
+    sq = oracle.rect(codes, offsets, np.arange(n), np.arange(n))
+    kw = dict(heuristic="medoidtree", subtree_size=8, sample_size=60, threshold=30, cluster_fraction=0.3, cluster_iters=2)
+    want = {gt: host.tree_from_matrix(fasta, sq, gt, **kw) for gt in ("upgma", "sl")}
+    monkeypatch.setenv("FAMSA_HOST_TEST", hooks)
+    for gt in ("upgma", "sl"):
+        assert host.tree_from_matrix(fasta, sq, gt, **kw) == want[gt], gt
+
+
 @pytest.mark.parametrize("seed", range(3))
 def test_num_evals_and_dump_seeds_match_reference(host, ref, oracle, tmp_path, seed):
     """-num_evals 3 (reference core/params.cpp:206: three evaluations per split, the cheapest kept) and -dump_seeds
