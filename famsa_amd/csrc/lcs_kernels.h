@@ -288,4 +288,28 @@ hipError_t launch_clarans_init(const ClaransArgs& a, hipStream_t stream);
 // every search of the batch for `slice_us` microseconds, or to its end, or until its pre-drawn positions run out
 hipError_t launch_clarans_search(const ClaransBatch& b, int slice_us, hipStream_t stream);
 
+// ---- -dist_export rows as text, on the device (text_kernels.hip) ----
+struct TextArgs {
+    const void* lcs;         // the block's LCS rectangle: row r (sequence row_begin + r) x ld, elem_size 2 | 4
+    int64_t ld;
+    const int32_t* where;    // [n] column of sequence j inside the rectangle (the rectangle's columns are in length order); NULL = j
+    const uint32_t* lens;
+    const double* pow_f64;   // pow(i, 0.75) from the host's libm
+    const char* ids;         // the sequences' names without '>' ...
+    const uint64_t* id_off;  // ... name i = ids[id_off[i] .. id_off[i + 1])
+    uint32_t* seg_len;       // [n_rows x segs] bytes of a segment, then its offset inside the row
+    uint32_t* row_len;       // [n_rows]
+    unsigned long long* row_start; // [n_rows + 1] offset of a row inside the block's text; [n_rows] = the block's bytes
+    char* out;               // the block's text
+    int32_t elem_size;
+    int32_t kind;            // LCSGPU_DIST_* through Transform<double> -> float, or 2: Transform<float, pairwise_identity>
+    int32_t row_begin, n_rows;
+    int32_t n;
+    int32_t square;          // row i holds n values, else the i values j < i
+    int32_t segs;            // segments (text_segment_values() values each) per row
+};
+hipError_t launch_text_block(const TextArgs& t, hipStream_t stream);
+int text_segment_values();
+int text_max_value_bytes();
+
 } // namespace lcsgpu

@@ -537,6 +537,7 @@ int lcsgpu_destroy(lcsgpu_ctx* ctx)
 {
     if (!ctx) return LCSGPU_OK;
     (void)hipSetDevice(ctx->device);
+    text_release(ctx);
     for (Lane& l : ctx->lanes) {
         if (l.stream) (void)hipStreamSynchronize(l.stream);
         l.d_plan.release();
@@ -643,6 +644,7 @@ int lcsgpu_upload_ordered(lcsgpu_ctx* ctx, const uint8_t* codes, const uint64_t*
         if (l.created) HIP_TRY(hipStreamSynchronize(l.stream));
     ctx->n = -1;
     ctx->mst.active = false;
+    text_release(ctx); // row blocks of the previous set
     std::vector<uint32_t> lens(n);
     std::vector<uint8_t> quirk(n);
     uint32_t max_len = 0;

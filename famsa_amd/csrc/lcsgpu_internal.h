@@ -154,8 +154,11 @@ struct ClaransBatcher {
     long prof_no_b = 0, prof_no_p = 0; // steps that ended without a walk: no member closer to the candidate than to its medoid / no slot able to go negative
 };
 
+struct TextExport; // lcsgpu_text.hip: the state of lcsgpu_dist_text_begin .. _end
+
 struct lcsgpu_ctx {
     int device = 0;
+    TextExport* text = nullptr;
     std::mutex mu; // guards the lane table
     std::condition_variable cv;
     std::vector<Lane> lanes;  // MAX_LANES slots; a slot costs nothing until its lane is created
@@ -305,6 +308,9 @@ int reserve_big(lcsgpu_ctx* ctx, DevBuf& buf, size_t bytes, const char* what);
 int device_free_bytes(lcsgpu_ctx* ctx, size_t* out); // as reserve_big sees it (LCSGPU_FAKE_HBM_GB included)
 // The n-1 tree edges in the order Prim's algorithm adds them from vertex 0 (host; in place).
 int order_edges_like_prim(lcsgpu_mst_edge* edges, int32_t n);
+
+// frees what lcsgpu_dist_text_begin set up (lcsgpu_text.hip); the caller holds lane 0 or all lanes
+void text_release(lcsgpu_ctx* ctx);
 
 // Core: plan + launch.  d_out is a device pointer.
 // fuse != NULL (triangle mode, contiguous rows and columns): the launches also fold their results into the

@@ -222,6 +222,45 @@ void GpuLcsSource::rect(const int* refs, int n_refs, const int* cols, int n_cols
     add_kernel_ms(c);
 }
 
+// -dist_export: unit u = slot u / n_devices of context u % n_devices, so that consecutive blocks go to different GPUs
+int GpuLcsSource::text_begin(const std::vector<std::string>& ids, int distance_kind, bool square, bool pid)
+{
+    if (host_test("csv_host_format")) return 0; // test aid: the host formatter over lcsgpu_lcs_rect
+    std::string names;
+    std::vector<uint64_t> off(ids.size() + 1, 0);
+    for (size_t i = 0; i < ids.size(); ++i) {
+        const char* p = ids[i].c_str() + 1; // as the reference prints it: from the second character to the first NUL
+        names.append(p);
+        off[i + 1] = names.size();
+    }
+    const int slots = std::max(1, std::min(8, host_test_int("text_slots", 3)));
+    const int flags = (square ? LCSGPU_TEXT_SQUARE : 0) | (pid ? LCSGPU_TEXT_PID : 0);
+    for (lcsgpu_ctx* c : ctxs_) check(lcsgpu_dist_text_begin(c, names.data(), off.data(), distance_kind, flags, slots), "lcsgpu_dist_text_begin");
+    text_slots_ = slots;
+    return slots * (int)ctxs_.size();
+}
+
+void GpuLcsSource::text_submit(int unit, int r0, int r1)
+{
+    const int nd = (int)ctxs_.size();
+    check(lcsgpu_dist_text_submit(ctxs_[unit % nd], unit / nd, r0, r1), "lcsgpu_dist_text_submit");
+}
+
+void GpuLcsSource::text_wait(int unit, const char*& text, uint64_t& bytes)
+{
+    const int nd = (int)ctxs_.size();
+    const double t0 = now_s();
+    check(lcsgpu_dist_text_wait(ctxs_[unit % nd], unit / nd, &text, &bytes), "lcsgpu_dist_text_wait");
+    note(st_rect_, now_s() - t0, 0);
+    add_kernel_ms(ctxs_[unit % nd]);
+}
+
+void GpuLcsSource::text_end()
+{
+    for (lcsgpu_ctx* c : ctxs_) check(lcsgpu_dist_text_end(c), "lcsgpu_dist_text_end");
+    text_slots_ = 0;
+}
+
 void GpuLcsSource::triangle_ids(const int* ids, int n_ids, LcsBuf& out)
 {
     out.resize(n_ids > 1 ? (size_t)n_ids * (n_ids - 1) / 2 : 0, wide());

@@ -81,6 +81,14 @@ public:
     // seed first_k + r on a strictly smaller Transform<float> distance; dist / assign are updated in place.
     virtual bool assign_seeds(const int* /*seeds*/, int /*n_seeds*/, const int* /*cols*/, int /*n_cols*/, int /*distance_kind*/,
                               int /*first_k*/, float* /*dist*/, int* /*assign*/) { return false; }
+    // -dist_export rows as TEXT made by the source itself (the device formats them): text_begin returns the number of
+    // independent units blocks can be in flight on (0 = not offered: the caller formats LCS values on the host); a unit takes
+    // one block of rows [r0, r1) at a time: text_submit queues it, text_wait returns its bytes -- the rows one after the
+    // other exactly as the file holds them -- valid until the unit's next submit.  ids as read (with their '>').
+    virtual int text_begin(const std::vector<std::string>& /*ids*/, int /*distance_kind*/, bool /*square*/, bool /*pid*/) { return 0; }
+    virtual void text_submit(int /*unit*/, int /*r0*/, int /*r1*/) {}
+    virtual void text_wait(int /*unit*/, const char*& /*text*/, uint64_t& /*bytes*/) {}
+    virtual void text_end() {}
     // CLARANS k-medoids over the sample `ids` computed by the source itself (device): medoids[k] =
     // member numbers 0..n_ids-1.  False = not offered for this shape; the caller runs the host search.
     virtual bool clarans(const int* /*ids*/, int /*n_ids*/, int /*distance_kind*/, int /*n_medoids*/, int /*n_fixed*/,
@@ -117,6 +125,10 @@ public:
     bool triangles_batch(const int* ids, const int64_t* offsets, int n_groups, LcsBuf& out) override;
     bool assign_seeds(const int* seeds, int n_seeds, const int* cols, int n_cols, int distance_kind, int first_k, float* dist,
                       int* assign) override;
+    int text_begin(const std::vector<std::string>& ids, int distance_kind, bool square, bool pid) override;
+    void text_submit(int unit, int r0, int r1) override;
+    void text_wait(int unit, const char*& text, uint64_t& bytes) override;
+    void text_end() override;
     double kernel_ms_total() const { return kernel_ms_; }
     // several devices: lcsgpu_multi_transport's text (empty with one context)
     std::string transport() const;
@@ -132,6 +144,7 @@ private:
     std::vector<uint32_t> lens_;
     bool sensitive_ = false, wide_ = false;
     double kernel_ms_ = 0;
+    int text_slots_ = 0; // per context, between text_begin and text_end
     std::mutex mu_; // the tree builders may call from several threads
     // call statistics (printed at destruction when FAMSA_GPU_PROFILE is set)
     struct CallStat { long calls = 0; double seconds = 0; double pairs = 0; } st_rect_, st_tri_, st_triids_, st_clarans_, st_batch_, st_assign_;

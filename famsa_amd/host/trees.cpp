@@ -11,7 +11,12 @@
 #if defined(__SSE2__)
 #include <emmintrin.h>
 #endif
+#include <condition_variable>
+#include <deque>
+#include <fcntl.h>
 #include <fstream>
+#include <mutex>
+#include <unistd.h>
 #include <limits>
 #include <queue>
 #include <set>
@@ -992,6 +997,173 @@ int format_distance(double val, char* out)
     return r1 + r2;
 }
 
+// ---------------------------------------------------------------------------------------------
+// A team of threads that puts finished blocks of text into the file at known offsets (pwrite), so that writing block k
+// overlaps the device's work on block k + 1 and the page-cache copy is not one thread's job.
+namespace {
+class BlockWriter {
+public:
+    BlockWriter(int fd, int n_threads) : fd_(fd)
+    {
+        for (int t = 0; t < n_threads; ++t) team_.emplace_back([this] { work(); });
+    }
+    ~BlockWriter()
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (auto& t : team_) t.join();
+    }
+    // returns a ticket for wait(); the bytes must stay valid until then
+    size_t write(const char* p, uint64_t len, uint64_t offset)
+    {
+        const uint64_t chunk = 2u << 20;
+        std::lock_guard<std::mutex> lk(mu_);
+        const size_t ticket = left_.size();
+        const uint64_t pieces = (len + chunk - 1) / chunk;
+        left_.push_back((size_t)pieces);
+        for (uint64_t k = 0; k < pieces; ++k) queue_.push_back({p + k * chunk, std::min(chunk, len - k * chunk), offset + k * chunk, ticket});
+        cv_.notify_all();
+        return ticket;
+    }
+    void wait(size_t ticket)
+    {
+        std::unique_lock<std::mutex> lk(mu_);
+        done_.wait(lk, [&] { return left_[ticket] == 0; });
+        if (!error_.empty()) throw std::runtime_error(error_);
+    }
+
+private:
+    struct Piece { const char* p; uint64_t len, offset; size_t ticket; };
+    void work()
+    {
+        std::unique_lock<std::mutex> lk(mu_);
+        for (;;) {
+            cv_.wait(lk, [&] { return stop_ || !queue_.empty(); });
+            if (queue_.empty()) return;
+            Piece w = queue_.front();
+            queue_.pop_front();
+            lk.unlock();
+            std::string err;
+            while (w.len) {
+                const ssize_t k = pwrite(fd_, w.p, (size_t)w.len, (off_t)w.offset);
+                if (k < 0 && errno == EINTR) continue;
+                if (k <= 0) {
+                    err = std::string("writing the distance file failed: ") + (k < 0 ? strerror(errno) : "no progress (disk full?)");
+                    break;
+                }
+                w.p += k;
+                w.len -= (uint64_t)k;
+                w.offset += (uint64_t)k;
+            }
+            lk.lock();
+            if (!err.empty() && error_.empty()) error_ = err;
+            if (--left_[w.ticket] == 0) done_.notify_all();
+        }
+    }
+    int fd_;
+    std::mutex mu_;
+    std::condition_variable cv_, done_;
+    std::deque<Piece> queue_;
+    std::vector<size_t> left_;
+    std::vector<std::thread> team_;
+    std::string error_;
+    bool stop_ = false;
+};
+} // namespace
+
+// -dist_export with a source that makes the text itself (the GPU engine: lcsgpu_dist_text_*): this side only decides the
+// row blocks, keeps `units` of them in flight and puts every finished block into the file while the next ones are
+// computed, formatted and copied.  What DistanceCalculator::run (reference tree/DistanceCalculator.cpp:10-120) does with a
+// queue of row vectors and one writing thread.  Returns false if the source does not offer it.
+static bool write_csv_text(LcsSource& src, const std::vector<std::string>& ids, int distance_kind, bool square, bool pid,
+                           const std::string& path)
+{
+    const int n = src.n();
+    const int units = src.text_begin(ids, distance_kind, square, pid);
+    if (units <= 0) return false;
+    struct End {
+        LcsSource& s;
+        ~End() { try { s.text_end(); } catch (...) {} }
+    } end{src};
+    const int fd = open(path.c_str(), O_CREAT | O_TRUNC | O_WRONLY | O_CLOEXEC, 0666);
+    if (fd < 0) throw std::runtime_error("cannot open " + path);
+    struct Close {
+        int fd;
+        ~Close() { if (fd >= 0) close(fd); }
+    } closer{fd};
+    uint64_t offset = 0;
+    std::string header;
+    if (square) {
+        for (const auto& id : ids) {
+            header += ',';
+            header += id.c_str() + 1;
+        }
+        header += '\n';
+    }
+    // row blocks of about equal text: ~9 bytes per value; at most n / 8 rows, so that the part of a triangle block's
+    // rectangle that lies beyond the diagonal stays small
+    std::vector<double> row_bytes((size_t)n);
+    double total = 0;
+    for (int i = 0; i < n; ++i) total += row_bytes[(size_t)i] = (double)ids[(size_t)i].size() + 9.2 * (square ? n : i);
+    const double mb = 1024.0 * 1024.0;
+    const double target = std::min(std::max(total / 32, 4 * mb), (double)host_test_int("text_block_mb", 32) * mb);
+    const int max_rows = std::min(32768, std::max(512, n / 8));
+    std::vector<std::pair<int, int>> blocks;
+    for (int r0 = 0; r0 < n;) {
+        int r1 = r0;
+        double acc = 0;
+        while (r1 < n && r1 - r0 < max_rows && (r1 == r0 || acc + row_bytes[(size_t)r1] <= target)) acc += row_bytes[(size_t)r1++];
+        blocks.emplace_back(r0, r1);
+        r0 = r1;
+    }
+    const int nb = (int)blocks.size();
+    int next = 0;
+    for (int u = 0; u < units && next < nb; ++u, ++next) src.text_submit(u, blocks[(size_t)next].first, blocks[(size_t)next].second);
+    BlockWriter writer(fd, std::max(1, std::min(default_host_threads(), host_test_int("text_writers", 8))));
+    if (!header.empty()) {
+        writer.wait(writer.write(header.data(), header.size(), 0));
+        offset = header.size();
+    }
+    std::vector<size_t> ticket((size_t)nb);
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_wait = 0, t_write = 0, t_submit = 0, t_first = 0;
+    const double t_begin = now();
+    for (int k = 0; k < nb; ++k) {
+        const char* text = nullptr;
+        uint64_t bytes = 0;
+        double t0 = now();
+        src.text_wait(k % units, text, bytes); // block k is in host memory (its copy ran beside block k - 1's write)
+        t_wait += now() - t0;
+        if (k == 0) t_first = now() - t_begin;
+        ticket[(size_t)k] = writer.write(text, bytes, offset);
+        offset += bytes;
+        if (k >= 1) { // block k - 1 is in the file: its unit takes the next block
+            t0 = now();
+            writer.wait(ticket[(size_t)k - 1]);
+            t_write += now() - t0;
+            if (next < nb) {
+                t0 = now();
+                src.text_submit((k - 1) % units, blocks[(size_t)next].first, blocks[(size_t)next].second);
+                t_submit += now() - t0;
+                ++next;
+            }
+        }
+    }
+    double t0 = now();
+    if (nb > 0) writer.wait(ticket[(size_t)nb - 1]);
+    t_write += now() - t0;
+    closer.fd = -1;
+    if (close(fd) != 0) throw std::runtime_error("writing " + path + " failed (disk full?)");
+    if (profile_on())
+        fprintf(stderr, "dist_export.text: %d blocks on %d units, %.1f MB; first block ready after %.3f s; main thread waited %.3f s for "
+                        "blocks (device + copy), %.3f s for the writers, %.3f s in submits; loop %.3f s\n",
+                nb, units, offset / 1e6, t_first, t_wait, t_write, t_submit, now() - t_begin);
+    return true;
+}
+
 template <Distance D>
 static void write_csv_d(LcsSource& src, const std::vector<std::string>& ids, bool square, bool pid,
                         const std::string& path)
@@ -1086,6 +1258,8 @@ static void write_csv_d(LcsSource& src, const std::vector<std::string>& ids, boo
 void write_distance_csv(LcsSource& src, const std::vector<std::string>& ids, Distance dist, bool square, bool pid,
                         const std::string& path)
 {
+    if (write_csv_text(src, ids, (int)dist, square, pid, path)) return;
+    // a source without a formatter of its own (tests feed a matrix): format here
     if (dist == Distance::indel_div_lcs) write_csv_d<Distance::indel_div_lcs>(src, ids, square, pid, path);
     else write_csv_d<Distance::indel075_div_lcs>(src, ids, square, pid, path);
 }

@@ -73,6 +73,10 @@ def load_library():
         "lcsgpu_lcs_triangles_batch": (C.c_int, [vp, pi32, C.POINTER(C.c_int64), i32, vp, C.c_int]),
         "lcsgpu_assign_seeds": (C.c_int, [vp, pi32, i32, pi32, i32, C.c_int, i32, vp, vp]),
         "lcsgpu_clarans": (C.c_int, [vp, pi32, i32, C.c_int, i32, i32, C.c_float, i32, pi32]),
+        "lcsgpu_dist_text_begin": (C.c_int, [vp, C.c_char_p, vp, C.c_int, C.c_int, i32]),
+        "lcsgpu_dist_text_submit": (C.c_int, [vp, i32, i32, i32]),
+        "lcsgpu_dist_text_wait": (C.c_int, [vp, i32, C.POINTER(vp), C.POINTER(C.c_uint64)]),
+        "lcsgpu_dist_text_end": (C.c_int, [vp]),
         "lcsgpu_sync": (C.c_int, [vp]),
         "lcsgpu_last_kernel_ms": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(i32)]),
         "lcsgpu_total_kernel_ms": (C.c_int, [vp, C.POINTER(C.c_double)]),
@@ -318,6 +322,37 @@ class LcsGpu:
         self._check(self._lib.lcsgpu_clarans(self._ctx, ptr, len(arr), kind, n_medoids, n_fixed, explore_fraction,
                                              num_local, out.ctypes.data_as(C.POINTER(C.c_int32))))
         return out[:n_medoids]
+
+    def dist_text(self, names, blocks, kind=1, square=False, pid=False, n_slots=2):
+        """-dist_export rows as text made on the device (lcsgpu_dist_text_*): `names` without '>', `blocks` =
+        [(row_begin, row_end), ...] in order; returns the concatenated bytes of the blocks."""
+        raw = [x.encode("latin-1") if isinstance(x, str) else bytes(x) for x in names]
+        off = np.zeros(len(raw) + 1, dtype=np.uint64)
+        off[1:] = np.cumsum([len(x) for x in raw], dtype=np.uint64)
+        flags = (1 if square else 0) | (2 if pid else 0)
+        self._check(self._lib.lcsgpu_dist_text_begin(self._ctx, b"".join(raw), off.ctypes.data, kind, flags, n_slots))
+        out = []
+        try:
+            pending = []
+            todo = list(blocks)
+
+            def collect():
+                slot = pending.pop(0)
+                ptr, nb = C.c_void_p(0), C.c_uint64(0)
+                self._check(self._lib.lcsgpu_dist_text_wait(self._ctx, slot, C.byref(ptr), C.byref(nb)))
+                out.append(C.string_at(ptr.value, nb.value) if nb.value else b"")
+                return slot
+
+            free = list(range(n_slots))
+            for r0, r1 in todo:
+                slot = free.pop(0) if free else collect()
+                self._check(self._lib.lcsgpu_dist_text_submit(self._ctx, slot, int(r0), int(r1)))
+                pending.append(slot)
+            while pending:
+                collect()
+        finally:
+            self._lib.lcsgpu_dist_text_end(self._ctx)
+        return b"".join(out)
 
     def sync(self):
         self._check(self._lib.lcsgpu_sync(self._ctx))

@@ -370,6 +370,33 @@ int lcsgpu_assign_seeds(lcsgpu_ctx* ctx, const int32_t* seed_ids, int32_t n_seed
 int lcsgpu_clarans(lcsgpu_ctx* ctx, const int32_t* ids, int32_t n_ids, int distance_kind, int32_t n_medoids,
                    int32_t n_fixed, float explore_fraction, int32_t num_local, int32_t* medoids_out);
 
+/* ---- -dist_export: the rows of the distance matrix as TEXT, made on the device ------------------------------------
+ * Replaces: the row workers AND the single writer thread of DistanceCalculator::run (tree/DistanceCalculator.cpp:28-113):
+ * calculateDistanceVector per row, the float row vector, "<id>," + num2str over the row with
+ * NumericConversions::Double2PChar(v, 6) (utils/conversion.h:109-119) and the ',' -> '\n' at the row's end.  A row block
+ * goes LCS rectangle -> final bytes without leaving HBM as numbers; the caller receives the block's text -- rows
+ * row_begin .. row_end-1 one after the other, byte for byte what the reference writes for them -- in pinned host memory
+ * owned by the context and only has to put it into its file.  Rows are those of the set AS UPLOADED (the reference
+ * exports before it sorts: msa.cpp, DistanceCalculator runs on the input order); row i holds the values j < i, or all n
+ * with LCSGPU_TEXT_SQUARE (the header line of -square_matrix is the caller's: it needs no LCS).
+ *   begin : ids = the sequences' names without the leading '>', name i = ids[id_offsets[i] .. id_offsets[i+1]) (HOST;
+ *           copied); distance_kind as above, ignored with LCSGPU_TEXT_PID (Transform<float, pairwise_identity>, -pid);
+ *           n_slots (1..8) = how many blocks the caller wants to have in flight.  Replaces any earlier begin.
+ *   submit: queue rows [row_begin, row_end) (at most 32768) on a free slot; returns at once.  All slots of a context
+ *           compute on its stream in submit order; a finished block's text travels while the next one is computed.
+ *   wait  : block until the slot's text is in host memory; *text stays valid until the slot's next submit (or end).
+ *   end   : frees the slots (an upload or lcsgpu_destroy does so too).
+ * The slots of one context are driven from ONE host thread; different contexts are independent, so with several GPUs
+ * the caller deals its blocks round robin (host/trees.cpp).  Device memory per slot is sized for the longest value a
+ * row could hold (39 bytes, the lcs == 0 form), host memory for the block as it came out. */
+#define LCSGPU_TEXT_SQUARE 0x1
+#define LCSGPU_TEXT_PID 0x2
+int lcsgpu_dist_text_begin(lcsgpu_ctx* ctx, const char* ids, const uint64_t* id_offsets, int distance_kind, int flags,
+                           int32_t n_slots);
+int lcsgpu_dist_text_submit(lcsgpu_ctx* ctx, int32_t slot, int32_t row_begin, int32_t row_end);
+int lcsgpu_dist_text_wait(lcsgpu_ctx* ctx, int32_t slot, const char** text, uint64_t* n_bytes);
+int lcsgpu_dist_text_end(lcsgpu_ctx* ctx);
+
 /* Block until everything queued on the context's stream has finished. */
 int lcsgpu_sync(lcsgpu_ctx* ctx);
 
