@@ -387,6 +387,15 @@ void finish_host_call(lcsgpu_ctx* ctx, Lane& L)
 }
 
 
+void note_host_call(lcsgpu_ctx* ctx, double ms, int launches)
+{
+    g_last.ctx = ctx;
+    g_last.also.clear();
+    g_last.pending_on_lane0 = false;
+    g_last.ms = ms;
+    g_last.launches = launches;
+}
+
 void note_async_call(lcsgpu_ctx* ctx, bool also_this)
 {
     if (also_this) {

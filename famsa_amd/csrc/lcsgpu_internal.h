@@ -323,6 +323,8 @@ int run_rows(lcsgpu_ctx* ctx, Lane& L, int mode, const int32_t* ref_ids, int32_t
 void merge_small_classes(const double* wgs, int* target);
 // After a host-memory call has been synchronised: account its kernel time.
 void finish_host_call(lcsgpu_ctx* ctx, Lane& L);
+// a host-memory call that keeps its own events (lcsgpu_text.hip): this thread's answer to lcsgpu_last_kernel_ms
+void note_host_call(lcsgpu_ctx* ctx, double ms, int launches);
 // A *_dev call was queued on lane 0: its timing is read on demand.
 // also_this: a further context of the same multi-context call (the first one is noted without the flag).
 void note_async_call(lcsgpu_ctx* ctx, bool also_this = false);

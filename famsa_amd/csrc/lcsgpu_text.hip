@@ -212,11 +212,7 @@ int lcsgpu_dist_text_wait(lcsgpu_ctx* ctx, int32_t slot, const char** text, uint
         std::lock_guard<std::mutex> lk(ctx->mu);
         ctx->total_kernel_ms += ms;
     }
-    g_last.ctx = ctx; // lcsgpu_last_kernel_ms: the LCS launches of this block
-    g_last.also.clear();
-    g_last.pending_on_lane0 = false;
-    g_last.ms = ms;
-    g_last.launches = s.lane.last_launches;
+    note_host_call(ctx, ms, s.lane.last_launches); // lcsgpu_last_kernel_ms: the LCS launches of this block
     HIP_TRY(s.h_text.reserve((size_t)bytes + 16));
     if (bytes) {
         HIP_TRY(hipMemcpyAsync(s.h_text.p, s.d_text.p, (size_t)bytes, hipMemcpyDeviceToHost, x->copy_stream));

@@ -671,180 +671,323 @@ struct FastTree {
 
     bool is_leaf(size_t n) const { return !(prm.use_clustering ? (int)n > prm.threshold : (int)n > prm.subtree_size); }
 
-    // the sub-tree of a subset that is not split further: the partial generator over its members
-    void leaf_tree(const std::vector<int>& ids, LcsSource& sub, tree_structure& tree, int previous_top)
-    {
-        const int n = (int)ids.size();
-        {
-            Scope t(g_phase.partial, Timeline::PARTIAL);
-            build_tree_partial(sub, partial, D, tree);
-        }
-        if (previous_top > n) {
-            for (int node = 0; node < n - 1; ++node) {
-                node_t& nd = tree[node];
-                nd.first = nd.first < n ? ids[nd.first] : nd.first + previous_top - n;
-                nd.second = nd.second < n ? ids[nd.second] : nd.second + previous_top - n;
-            }
-        }
-    }
-
-    // FastTree::doStep, FastTree.cpp:56-266.  `ids` = global ids (sequence_no) of this subset.
-    // parallel = true only at the top level, like the reference: the sub-trees of the first split
-    // are built by worker threads (each with its own Transform tables; the GPU engine serialises
-    // their LCS calls internally), then gathered in seed order.
-    void do_step(const std::vector<int>& ids, tree_structure& tree, int previous_top, bool parallel = false)
-    {
-        const int n = (int)ids.size();
-        const bool split = prm.use_clustering ? n > prm.threshold : n > prm.subtree_size;
-        if (!split) {
-            SubsetSource sub(src, ids);
-            leaf_tree(ids, sub, tree, previous_top);
-            return;
-        }
-        float best_cost = std::numeric_limits<float>::max();
+    // ---- FastTree::doStep (reference tree/FastTree.cpp:56-266), LEVEL BY LEVEL -------------------------------------------
+    // The reference recurses: split a subset into its seeds' clusters, build every cluster's sub-tree (recursively),
+    // stitch them by a tree over the seeds.  Nothing a subset computes depends on its siblings, and the node ids of its
+    // sub-tree follow from sizes alone: a subset of m members entered with `top` owns the ids [top, top + m - 1) -- its
+    // clusters' sub-trees one after the other in seed order (a cluster of s members: s - 1 nodes, none for s == 1), then the
+    // n_seeds - 1 nodes of the tree over the seeds.  So the recursion is walked breadth first: ALL splits of a level are
+    // evaluated together -- their samples' searches share one launch wave on the device, their seed assignments one
+    // batched call (LcsSource::clarans_batch / assign_seeds_batch) -- and every finished piece (a leaf's tree, a split's
+    // seed tree) is written straight to its place in the final tree.  Leaf and seed trees are host work on LCS triangles
+    // that arrive in batched requests: they go to the task pool as they appear and run beside the next level.
+    struct Subset {
+        std::vector<int> ids; // global ids
+        int top;              // id of the first internal node of its sub-tree
+    };
+    // a tree to build with the partial generator over `ids`, written to tree[base ...]: local leaf x stands for node leaf_of[x]
+    struct Piece {
+        std::vector<int> ids, leaf_of;
+        int base;
+    };
+    struct Evaluation {
+        float cost = std::numeric_limits<float>::max();
         int n_seeds = -1;
-        std::vector<int> seed_ids, assignments;
-        const auto t_top0 = std::chrono::steady_clock::now();
-        for (int eval = 0; eval < prm.num_evaluations; ++eval) {
-            int ns;
-            std::vector<int> s, a;
-            const float cost = make_evaluation(ids, eval, ns, s, a);
-            if (cost < best_cost) {
-                best_cost = cost;
-                n_seeds = ns;
-                seed_ids.swap(s);
-                assignments.swap(a);
-            }
-        }
-        if (n_seeds < 0) throw std::runtime_error("FastTree: no evaluation produced a finite cost");
-        std::vector<int> seeds(n_seeds);
-        for (int k = 0; k < n_seeds; ++k) {
-            seeds[k] = ids[seed_ids[k]];
-            assignments[seed_ids[k]] = k; // seeds belong to themselves
-        }
-        if (parallel && prm.top_seeds) *prm.top_seeds = seeds; // the observers' notifySeedsSelected(seeds, depth 0), FastTree.cpp:120-123
-        std::vector<std::vector<int>> subgroups(n_seeds);
-        for (int j = 0; j < n; ++j) subgroups[assignments[j]].push_back(ids[j]);
+        std::vector<int> seed_ids, assignments; // local to the subset
+    };
 
-        std::vector<int> subroots(n_seeds, -1);
-        const auto t_top1 = std::chrono::steady_clock::now();
-        if (parallel && profile_on())
-            fprintf(stderr, "fasttree.top_evaluation_wall=%.3f\n", std::chrono::duration<double>(t_top1 - t_top0).count());
-        {
-            struct Task { int k, top; };
-            std::vector<Task> tasks;
-            for (int k = 0; k < n_seeds; ++k)
-                if (subgroups[k].size() > 1) {
-                    tasks.push_back(Task{k, previous_top});
-                    previous_top += (int)subgroups[k].size() - 1;
-                    subroots[k] = previous_top - 1;
-                }
-            std::vector<tree_structure> locals(tasks.size());
-            if (parallel && profile_on()) {
-                std::vector<size_t> sz;
-                for (auto& t : tasks) sz.push_back(subgroups[t.k].size());
-                std::sort(sz.rbegin(), sz.rend());
-                fprintf(stderr, "fasttree.top_groups=%zu largest:", sz.size());
-                for (size_t i = 0; i < std::min<size_t>(6, sz.size()); ++i) fprintf(stderr, " %zu", sz[i]);
-                fprintf(stderr, "\n");
-            }
-            if (pool && !tasks.empty()) {
-                TaskPool::Group group;
-                // the leaves' LCS triangles are requested in batches (one engine call each), the
-                // leaves of a batch then become tasks of their own; everything else is a task as it is
-                const size_t batch_pairs = (size_t)24 << 20;
-                std::vector<size_t> batch;
-                size_t batch_size = 0, batch_members = 0;
-                auto flush = [&] {
-                    if (batch.empty()) return;
-                    pool->submit(group, batch_members, [this, batch, &group, &tasks, &subgroups, &locals] {
-                        std::vector<int> ids;
-                        std::vector<int64_t> offs(1, 0);
-                        for (size_t t : batch) {
-                            const auto& g = subgroups[tasks[t].k];
-                            ids.insert(ids.end(), g.begin(), g.end());
-                            offs.push_back((int64_t)ids.size());
-                        }
-                        auto buf = std::make_shared<LcsBuf>();
-                        bool have;
-                        {
-                            Scope tm(g_phase.lcs, Timeline::LCS);
-                            OffCpu w;
-                            have = src.triangles_batch(ids.data(), offs.data(), (int)batch.size(), *buf);
-                        }
-                        // the leaves' trees: a task per ~1024 members (a leaf of 30 members is 20 us of work -- a task each
-                        // would spend as long in the pool's queue as in the tree)
-                        struct Piece { size_t t, off; };
-                        std::vector<Piece> pieces;
-                        size_t off = 0, members = 0;
-                        auto submit_pieces = [&] {
-                            if (pieces.empty()) return;
-                            pool->submit(group, members, [this, pieces, have, buf, &tasks, &subgroups, &locals] {
-                                FastTree<D> child{src, partial, prm, pool, {}};
-                                for (const Piece& pc : pieces) {
-                                    const auto& g = subgroups[tasks[pc.t].k];
-                                    if (have) {
-                                        PrecomputedSubset sub(src, g, buf, pc.off);
-                                        child.leaf_tree(g, sub, locals[pc.t], tasks[pc.t].top);
-                                    } else {
-                                        child.do_step(g, locals[pc.t], tasks[pc.t].top, false);
-                                    }
-                                }
-                            }, true);
-                            pieces.clear();
-                            members = 0;
-                        };
-                        for (size_t t : batch) {
-                            const size_t m = subgroups[tasks[t].k].size();
-                            pieces.push_back(Piece{t, off});
-                            members += m;
-                            off += m * (m - 1) / 2;
-                            if (members >= 1024) submit_pieces();
-                        }
-                        submit_pieces();
-                    }, true);
-                    batch.clear();
-                    batch_size = batch_members = 0;
-                };
-                for (size_t t = 0; t < tasks.size(); ++t) {
-                    const size_t m = subgroups[tasks[t].k].size();
-                    if (is_leaf(m) && partial != GT::MST_Prim) {
-                        batch.push_back(t);
-                        batch_size += m * (m - 1) / 2;
-                        batch_members += m;
-                        if (batch_size >= batch_pairs) flush();
-                        continue;
-                    }
-                    pool->submit(group, m, [this, t, &tasks, &subgroups, &locals] {
-                        FastTree<D> child{src, partial, prm, pool, {}};
-                        child.do_step(subgroups[tasks[t].k], locals[t], tasks[t].top, false);
-                    });
-                }
-                flush();
-                pool->wait(group);
-            } else {
-                for (size_t t = 0; t < tasks.size(); ++t)
-                    do_step(subgroups[tasks[t].k], locals[t], tasks[t].top, false);
-            }
-            for (const auto& lt : locals) tree.insert(tree.end(), lt.begin(), lt.end());
-            if (parallel && profile_on())
-                fprintf(stderr, "fasttree.top_subtrees_wall=%.3f\n",
-                        std::chrono::duration<double>(std::chrono::steady_clock::now() - t_top1).count());
-        }
+    void place_piece(const Piece& pc, LcsSource& sub, tree_structure& tree)
+    {
+        const int m = (int)pc.ids.size();
         tree_structure local;
         {
-            SubsetSource sub(src, seeds);
             Scope t(g_phase.partial, Timeline::PARTIAL);
             build_tree_partial(sub, partial, D, local);
         }
-        for (int node = 0; node < n_seeds - 1; ++node) {
-            node_t& nd = local[node];
-            nd.first = nd.first < n_seeds ? (subgroups[nd.first].size() > 1 ? subroots[nd.first] : seeds[nd.first])
-                                          : nd.first + previous_top - n_seeds;
-            nd.second = nd.second < n_seeds ? (subgroups[nd.second].size() > 1 ? subroots[nd.second] : seeds[nd.second])
-                                            : nd.second + previous_top - n_seeds;
+        for (int node = 0; node < m - 1; ++node) {
+            const node_t& nd = local[(size_t)node];
+            tree[(size_t)pc.base + node] = node_t(nd.first < m ? pc.leaf_of[(size_t)nd.first] : nd.first - m + pc.base,
+                                                  nd.second < m ? pc.leaf_of[(size_t)nd.second] : nd.second - m + pc.base);
         }
-        tree.insert(tree.end(), local.begin(), local.end());
+    }
+
+    // the pieces' LCS triangles in batched requests (one engine call per ~24 M pairs), their trees in tasks of ~1024 members
+    // (a leaf of 30 members is 20 us of work -- a task each would spend as long in the pool's queue as in the tree)
+    void submit_pieces(std::vector<std::shared_ptr<Piece>>& pieces, TaskPool::Group& group, tree_structure& tree)
+    {
+        const size_t batch_pairs = (size_t)24 << 20;
+        std::vector<std::shared_ptr<Piece>> batch;
+        size_t pairs = 0, members = 0;
+        auto flush = [&] {
+            if (batch.empty()) return;
+            pool->submit(group, members, [this, batch, &group, &tree] {
+                std::vector<int> ids;
+                std::vector<int64_t> offs(1, 0);
+                for (const auto& pc : batch) {
+                    ids.insert(ids.end(), pc->ids.begin(), pc->ids.end());
+                    offs.push_back((int64_t)ids.size());
+                }
+                auto buf = std::make_shared<LcsBuf>();
+                bool have;
+                {
+                    Scope tm(g_phase.lcs, Timeline::LCS);
+                    OffCpu w;
+                    have = src.triangles_batch(ids.data(), offs.data(), (int)batch.size(), *buf);
+                }
+                struct Part { std::shared_ptr<Piece> pc; size_t off; };
+                std::vector<Part> parts;
+                size_t off = 0, part_members = 0;
+                auto submit_parts = [&] {
+                    if (parts.empty()) return;
+                    pool->submit(group, part_members, [this, parts, have, buf, &tree] {
+                        FastTree<D> worker{src, partial, prm, pool, {}};
+                        for (const Part& pt : parts) {
+                            if (have) {
+                                PrecomputedSubset sub(src, pt.pc->ids, buf, pt.off);
+                                worker.place_piece(*pt.pc, sub, tree);
+                            } else {
+                                SubsetSource sub(src, pt.pc->ids);
+                                worker.place_piece(*pt.pc, sub, tree);
+                            }
+                        }
+                    }, true);
+                    parts.clear();
+                    part_members = 0;
+                };
+                for (const auto& pc : batch) {
+                    const size_t m = pc->ids.size();
+                    parts.push_back(Part{pc, off});
+                    part_members += m;
+                    off += m * (m - 1) / 2;
+                    if (part_members >= 1024) submit_parts();
+                }
+                submit_parts();
+            }, true);
+            batch.clear();
+            pairs = members = 0;
+        };
+        for (auto& pc : pieces) {
+            const size_t m = pc->ids.size();
+            batch.push_back(pc);
+            pairs += m * (m - 1) / 2;
+            members += m;
+            if (pairs >= batch_pairs) flush();
+        }
+        flush();
+        pieces.clear();
+    }
+
+    // the sample of one evaluation (FastTree::clusterSeeds, FastTree.cpp:366-411): local ids, sorted; empty = every member
+    void choose_sample(int n, int n_samples, uint32_t seed, std::vector<int>& sample_ids)
+    {
+        sample_ids.clear();
+        if (n_samples >= n) return;
+        std::mt19937 mt(seed);
+        std::vector<int> rnd(n);
+        std::iota(rnd.begin(), rnd.end(), 0);
+        partial_shuffle(rnd.data() + 1, rnd.data() + n_samples, rnd.data() + n, mt);
+        sample_ids.assign(rnd.begin(), rnd.begin() + n_samples);
+        std::sort(sample_ids.begin(), sample_ids.end());
+    }
+
+    // FastTree::makeEvaluation for every split of a level and every evaluation number at once, through the source's batched
+    // calls.  False = the source does not offer them (nothing has been computed).
+    bool evaluate_level_batched(const std::vector<Subset*>& splits, std::vector<Evaluation>& best)
+    {
+        if (!prm.use_clustering || host_test("no_level_batch")) return false;
+        const int n_splits = (int)splits.size(), n_evals = prm.num_evaluations, n_jobs = n_splits * n_evals;
+        const int k = prm.subtree_size;
+        // 1. the samples
+        std::vector<std::vector<int>> sample_ids((size_t)n_jobs);
+        parallel_for(n_jobs, [&](int j) {
+            const int s = j / n_evals, eval = j % n_evals;
+            const uint32_t seed = eval == 0 ? std::mt19937::default_seed : (uint32_t)std::hash<uint32_t>()((uint32_t)eval);
+            choose_sample((int)splits[(size_t)s]->ids.size(), prm.sample_size, seed, sample_ids[(size_t)j]);
+        });
+        std::vector<int64_t> off((size_t)n_jobs + 1, 0);
+        for (int j = 0; j < n_jobs; ++j) {
+            const size_t m = sample_ids[(size_t)j].empty() ? splits[(size_t)(j / n_evals)]->ids.size() : sample_ids[(size_t)j].size();
+            off[(size_t)j + 1] = off[(size_t)j] + (int64_t)m;
+        }
+        std::vector<int> sample_global((size_t)off[(size_t)n_jobs]);
+        parallel_for(n_jobs, [&](int j) {
+            const std::vector<int>& ids = splits[(size_t)(j / n_evals)]->ids;
+            int* out = sample_global.data() + off[(size_t)j];
+            if (sample_ids[(size_t)j].empty()) std::copy(ids.begin(), ids.end(), out);
+            else for (size_t t = 0; t < sample_ids[(size_t)j].size(); ++t) out[t] = ids[(size_t)sample_ids[(size_t)j][t]];
+        });
+        // 2. every sample's medoids
+        std::vector<int> n_medoids((size_t)n_jobs, k), medoids((size_t)n_jobs * k);
+        {
+            Scope t(g_phase.clarans, Timeline::CLARANS);
+            OffCpu w;
+            if (!src.clarans_batch(sample_global.data(), off.data(), n_jobs, (int)D, n_medoids.data(), 1, prm.cluster_fraction,
+                                   prm.cluster_iters, medoids.data()))
+                return false;
+        }
+        // 3. every evaluation's seed sweep: seeds x members of its split, from scratch (d(seed 0, j) < +inf for every j, so
+        //    starting one seed earlier from +inf leaves the row the reference starts from, FastTree.cpp:309-324)
+        std::vector<int64_t> seed_off((size_t)n_jobs + 1, 0), col_off((size_t)n_jobs + 1, 0);
+        for (int j = 0; j < n_jobs; ++j) {
+            seed_off[(size_t)j + 1] = seed_off[(size_t)j] + k;
+            col_off[(size_t)j + 1] = col_off[(size_t)j] + (int64_t)splits[(size_t)(j / n_evals)]->ids.size();
+        }
+        std::vector<int> seeds_global((size_t)n_jobs * k), seeds_local((size_t)n_jobs * k), cols((size_t)col_off[(size_t)n_jobs]);
+        std::atomic<bool> odd{false};
+        parallel_for(n_jobs, [&](int j) {
+            const std::vector<int>& ids = splits[(size_t)(j / n_evals)]->ids;
+            for (int q = 0; q < k; ++q) {
+                const int m = medoids[(size_t)j * k + q];
+                const int local = sample_ids[(size_t)j].empty() ? m : sample_ids[(size_t)j][(size_t)m];
+                seeds_local[(size_t)j * k + q] = local;
+                seeds_global[(size_t)j * k + q] = ids[(size_t)local];
+            }
+            if (seeds_local[(size_t)j * k] != 0) odd = true; // (cannot happen: slot 0 of the search is pinned to member 0)
+            std::copy(ids.begin(), ids.end(), cols.data() + col_off[(size_t)j]);
+        });
+        if (odd) return false; // the split-by-split form knows what the reference does then
+        std::vector<float> dist(cols.size());
+        std::vector<int> assign(cols.size());
+        {
+            Scope t(g_phase.assign, Timeline::ASSIGN);
+            OffCpu w;
+            if (!src.assign_seeds_batch(seeds_global.data(), seed_off.data(), cols.data(), col_off.data(), n_jobs, (int)D, dist.data(),
+                                        assign.data()))
+                return false;
+        }
+        // 4. the cheapest evaluation of every split (the first one among equals: strict <, FastTree.cpp:126-138)
+        std::vector<float> cost((size_t)n_jobs);
+        parallel_for(n_jobs, [&](int j) {
+            cost[(size_t)j] = std::accumulate(dist.begin() + col_off[(size_t)j], dist.begin() + col_off[(size_t)j + 1], 0.0f);
+        });
+        parallel_for(n_splits, [&](int s) {
+            Evaluation& b = best[(size_t)s];
+            for (int eval = 0; eval < n_evals; ++eval) {
+                const int j = s * n_evals + eval;
+                if (!(cost[(size_t)j] < b.cost)) continue;
+                b.cost = cost[(size_t)j];
+                b.n_seeds = k;
+                b.seed_ids.assign(seeds_local.begin() + (size_t)j * k, seeds_local.begin() + (size_t)(j + 1) * k);
+                b.assignments.assign(assign.begin() + col_off[(size_t)j], assign.begin() + col_off[(size_t)j + 1]);
+            }
+        });
+        return true;
+    }
+
+    // fn(i) for i in [0, count) on the pool's threads (the caller works too); small counts run here
+    template <class Fn>
+    void parallel_for(int count, Fn fn)
+    {
+        if (!pool || count < 2) {
+            for (int i = 0; i < count; ++i) fn(i);
+            return;
+        }
+        TaskPool::Group group;
+        std::atomic<int> next{0};
+        const int workers = std::min(count, std::max(1, prm.n_threads));
+        for (int w = 0; w < workers; ++w)
+            pool->submit(group, (size_t)count, [&] {
+                for (int i = next++; i < count; i = next++) fn(i);
+            });
+        pool->wait(group);
+    }
+
+    void run_levels(int n, tree_structure& tree)
+    {
+        std::vector<std::unique_ptr<Subset>> frontier;
+        frontier.emplace_back(new Subset{std::vector<int>((size_t)n), n});
+        std::iota(frontier[0]->ids.begin(), frontier[0]->ids.end(), 0);
+        TaskPool::Group trees; // the leaf and seed trees of all levels
+        std::vector<std::shared_ptr<Piece>> pieces;
+        for (int depth = 0; !frontier.empty(); ++depth) {
+            const auto t_level = std::chrono::steady_clock::now();
+            std::vector<Subset*> splits;
+            for (auto& sp : frontier) {
+                if (is_leaf(sp->ids.size())) {
+                    auto pc = std::make_shared<Piece>();
+                    pc->ids = sp->ids;
+                    pc->leaf_of = std::move(sp->ids);
+                    pc->base = sp->top;
+                    pieces.push_back(std::move(pc));
+                } else
+                    splits.push_back(sp.get());
+            }
+            if (pool) submit_pieces(pieces, trees, tree); // this level's leaves: their triangles and trees run beside what follows
+            const int n_splits = (int)splits.size();
+            std::vector<Evaluation> best((size_t)n_splits);
+            if (!splits.empty() && !evaluate_level_batched(splits, best)) {
+                parallel_for(n_splits, [&](int s) { // split by split: FastTree::makeEvaluation as it stands
+                    FastTree<D> worker{src, partial, prm, pool, {}};
+                    Evaluation& b = best[(size_t)s];
+                    for (int eval = 0; eval < prm.num_evaluations; ++eval) {
+                        int ns;
+                        std::vector<int> sd, as;
+                        const float cost = worker.make_evaluation(splits[(size_t)s]->ids, eval, ns, sd, as);
+                        if (cost < b.cost) {
+                            b.cost = cost;
+                            b.n_seeds = ns;
+                            b.seed_ids.swap(sd);
+                            b.assignments.swap(as);
+                        }
+                    }
+                });
+            }
+            // the clusters of every split: the next level's subsets, and the split's own tree over its seeds
+            std::vector<std::vector<std::unique_ptr<Subset>>> children((size_t)n_splits);
+            std::vector<std::shared_ptr<Piece>> seed_trees((size_t)n_splits);
+            parallel_for(n_splits, [&](int s) {
+                Subset& sp = *splits[(size_t)s];
+                Evaluation& b = best[(size_t)s];
+                if (b.n_seeds < 0) throw std::runtime_error("FastTree: no evaluation produced a finite cost");
+                const int n_seeds = b.n_seeds, m = (int)sp.ids.size();
+                for (int q = 0; q < n_seeds; ++q) b.assignments[(size_t)b.seed_ids[(size_t)q]] = q; // seeds belong to themselves
+                std::vector<int> size((size_t)n_seeds, 0);
+                for (int j = 0; j < m; ++j) ++size[(size_t)b.assignments[(size_t)j]];
+                std::vector<std::unique_ptr<Subset>> groups((size_t)n_seeds);
+                int top = sp.top;
+                auto pc = std::make_shared<Piece>();
+                pc->ids.resize((size_t)n_seeds);
+                pc->leaf_of.resize((size_t)n_seeds);
+                for (int q = 0; q < n_seeds; ++q) {
+                    const int seed = sp.ids[(size_t)b.seed_ids[(size_t)q]];
+                    pc->ids[(size_t)q] = seed;
+                    pc->leaf_of[(size_t)q] = seed;
+                    if (size[(size_t)q] > 1) {
+                        groups[(size_t)q].reset(new Subset{{}, top});
+                        groups[(size_t)q]->ids.reserve((size_t)size[(size_t)q]);
+                        top += size[(size_t)q] - 1;
+                        pc->leaf_of[(size_t)q] = top - 1; // the cluster's root: the last node of its range
+                    }
+                }
+                pc->base = top;
+                for (int j = 0; j < m; ++j) {
+                    auto& g = groups[(size_t)b.assignments[(size_t)j]];
+                    if (g) g->ids.push_back(sp.ids[(size_t)j]);
+                }
+                for (auto& g : groups)
+                    if (g) children[(size_t)s].push_back(std::move(g));
+                seed_trees[(size_t)s] = std::move(pc);
+                if (depth == 0 && prm.top_seeds) *prm.top_seeds = seed_trees[(size_t)s]->ids; // notifySeedsSelected(seeds, depth 0), FastTree.cpp:120-123
+            });
+            std::vector<std::unique_ptr<Subset>> next;
+            for (int s = 0; s < n_splits; ++s) {
+                for (auto& c : children[(size_t)s]) next.push_back(std::move(c));
+                pieces.push_back(std::move(seed_trees[(size_t)s]));
+            }
+            if (profile_on())
+                fprintf(stderr, "fasttree.level %d: %zu subsets, %d splits -> %zu subsets, %.3f s\n", depth, frontier.size(), n_splits, next.size(),
+                        std::chrono::duration<double>(std::chrono::steady_clock::now() - t_level).count());
+            frontier.swap(next);
+        }
+        if (pool) {
+            submit_pieces(pieces, trees, tree);
+            pool->wait(trees);
+        } else {
+            for (auto& pc : pieces) {
+                SubsetSource sub(src, pc->ids);
+                place_piece(*pc, sub, tree);
+            }
+        }
     }
 };
 
@@ -854,6 +997,7 @@ void run_fast(LcsSource& src, GT partial, const FastTreeParams& p, tree_structur
     const int n = src.n();
     tree.assign(n, node_t(-1, -1));
     if (n < 2) return;
+    tree.resize((size_t)2 * n - 1, node_t(-1, -1));
     // `n_threads` cores' worth of host work, two and a half times as many threads to keep GPU requests in flight
     // (trees.h, fasttree_pool_threads)
     const int n_cpu = std::max(1, p.n_threads);
@@ -866,11 +1010,7 @@ void run_fast(LcsSource& src, GT partial, const FastTreeParams& p, tree_structur
     } giveback;
     TaskPool pool(n_pool, host_test_int("leafmax", fasttree_leaf_threads(n_pool))); // (FAMSA_HOST_TEST leafmax=N: sweeps)
     FastTree<D> ft{src, partial, p, &pool, {}};
-    std::vector<int> ids(n);
-    std::iota(ids.begin(), ids.end(), 0);
-    tree_structure local;
-    ft.do_step(ids, local, (int)tree.size(), true);
-    tree.insert(tree.end(), local.begin(), local.end());
+    ft.run_levels(n, tree);
 }
 
 } // namespace

@@ -257,6 +257,8 @@ void GpuLcsSource::text_wait(int unit, const char*& text, uint64_t& bytes)
 
 void GpuLcsSource::text_end()
 {
+    text_slots_ = 0;
+    if (keep_text_buffers) return; // lcsgpu_destroy / the next upload / the next begin frees them
     for (lcsgpu_ctx* c : ctxs_) check(lcsgpu_dist_text_end(c), "lcsgpu_dist_text_end");
     text_slots_ = 0;
 }

@@ -81,6 +81,16 @@ public:
     // seed first_k + r on a strictly smaller Transform<float> distance; dist / assign are updated in place.
     virtual bool assign_seeds(const int* /*seeds*/, int /*n_seeds*/, const int* /*cols*/, int /*n_cols*/, int /*distance_kind*/,
                               int /*first_k*/, float* /*dist*/, int* /*assign*/) { return false; }
+    // The same for several samples at once (all splits of a level of the FastTree recursion): sample g =
+    // ids[offsets[g] .. offsets[g + 1]) with n_medoids[g] medoids; medoids_out holds the samples' medoids one after the other.
+    // False = not offered: nothing has been computed, ask sample by sample.
+    virtual bool clarans_batch(const int* /*ids*/, const int64_t* /*offsets*/, int /*n_jobs*/, int /*distance_kind*/, const int* /*n_medoids*/,
+                               int /*n_fixed*/, float /*explore_fraction*/, int /*num_local*/, int* /*medoids_out*/) { return false; }
+    // Seed assignment of several evaluations at once, each from scratch: job g has the seeds seeds[seed_off[g] .. seed_off[g + 1])
+    // and the columns cols[col_off[g] .. col_off[g + 1]); per column (dist / assign laid out like cols): the smallest
+    // Transform<float> distance to a seed of its job and the number (0-based within the job) of the FIRST seed that attains it.
+    virtual bool assign_seeds_batch(const int* /*seeds*/, const int64_t* /*seed_off*/, const int* /*cols*/, const int64_t* /*col_off*/, int /*n_jobs*/,
+                                    int /*distance_kind*/, float* /*dist*/, int* /*assign*/) { return false; }
     // -dist_export rows as TEXT made by the source itself (the device formats them): text_begin returns the number of
     // independent units blocks can be in flight on (0 = not offered: the caller formats LCS values on the host); a unit takes
     // one block of rows [r0, r1) at a time: text_submit queues it, text_wait returns its bytes -- the rows one after the
@@ -145,6 +155,11 @@ private:
     bool sensitive_ = false, wide_ = false;
     double kernel_ms_ = 0;
     int text_slots_ = 0; // per context, between text_begin and text_end
+public:
+    // a caller that is about to abandon the engine (a command-line tool at its end) lets text_end leave the slots' buffers
+    // to the engine's destruction: freeing pinned and device memory is ~15 ms it would only wait for
+    bool keep_text_buffers = false;
+private:
     std::mutex mu_; // the tree builders may call from several threads
     // call statistics (printed at destruction when FAMSA_GPU_PROFILE is set)
     struct CallStat { long calls = 0; double seconds = 0; double pairs = 0; } st_rect_, st_tri_, st_triids_, st_clarans_, st_batch_, st_assign_;

@@ -186,6 +186,7 @@ void dist_export_gpu(const SeqSet& s, int device, Distance dist, bool square, bo
     GpuLcsSource& src = *held;
     src.upload(s.codes.data(), s.offsets); // input order, no sort, no dedup: the set as it was read
     double t2 = now_s();
+    src.keep_text_buffers = g_abandon_engine_at_return && !profile_on();
     write_distance_csv(src, s.ids, dist, square, pid, path);
     double t3 = now_s();
     if (t) {

@@ -1082,12 +1082,23 @@ static bool write_csv_text(LcsSource& src, const std::vector<std::string>& ids, 
                            const std::string& path)
 {
     const int n = src.n();
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_enter = now();
     const int units = src.text_begin(ids, distance_kind, square, pid);
     if (units <= 0) return false;
     struct End {
         LcsSource& s;
-        ~End() { try { s.text_end(); } catch (...) {} }
-    } end{src};
+        double t0;
+        ~End()
+        {
+            const double t = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+            try { s.text_end(); } catch (...) {}
+            if (profile_on())
+                fprintf(stderr, "dist_export.text: text_end %.3f s; stage %.3f s\n",
+                        std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - t, t - t0);
+        }
+    } end{src, t_enter};
+    const double t_begun = now();
     const int fd = open(path.c_str(), O_CREAT | O_TRUNC | O_WRONLY | O_CLOEXEC, 0666);
     if (fd < 0) throw std::runtime_error("cannot open " + path);
     struct Close {
@@ -1128,8 +1139,7 @@ static bool write_csv_text(LcsSource& src, const std::vector<std::string>& ids, 
         offset = header.size();
     }
     std::vector<size_t> ticket((size_t)nb);
-    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    double t_wait = 0, t_write = 0, t_submit = 0, t_first = 0;
+    double t_wait = 0, t_write = 0, t_submit = 0, t_first = 0, t_queue = 0;
     const double t_begin = now();
     for (int k = 0; k < nb; ++k) {
         const char* text = nullptr;
@@ -1138,7 +1148,9 @@ static bool write_csv_text(LcsSource& src, const std::vector<std::string>& ids, 
         src.text_wait(k % units, text, bytes); // block k is in host memory (its copy ran beside block k - 1's write)
         t_wait += now() - t0;
         if (k == 0) t_first = now() - t_begin;
+        t0 = now();
         ticket[(size_t)k] = writer.write(text, bytes, offset);
+        t_queue += now() - t0;
         offset += bytes;
         if (k >= 1) { // block k - 1 is in the file: its unit takes the next block
             t0 = now();
@@ -1158,9 +1170,11 @@ static bool write_csv_text(LcsSource& src, const std::vector<std::string>& ids, 
     closer.fd = -1;
     if (close(fd) != 0) throw std::runtime_error("writing " + path + " failed (disk full?)");
     if (profile_on())
+        fprintf(stderr, "dist_export.text: text_begin %.3f s, file + first submits + writer team %.3f s\n", t_begun - t_enter, t_begin - t_begun);
+    if (profile_on())
         fprintf(stderr, "dist_export.text: %d blocks on %d units, %.1f MB; first block ready after %.3f s; main thread waited %.3f s for "
-                        "blocks (device + copy), %.3f s for the writers, %.3f s in submits; loop %.3f s\n",
-                nb, units, offset / 1e6, t_first, t_wait, t_write, t_submit, now() - t_begin);
+                        "blocks (device + copy), %.3f s for the writers, %.3f s in submits, %.3f s queueing writes; loop %.3f s\n",
+                nb, units, offset / 1e6, t_first, t_wait, t_write, t_submit, t_queue, now() - t_begin);
     return true;
 }
 
