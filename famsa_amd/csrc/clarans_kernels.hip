@@ -32,6 +32,7 @@
 #include <cstdint>
 
 #include "lcs_kernels.h"
+#include "fasttree_kernels.h"
 
 namespace lcsgpu {
 
@@ -73,7 +74,9 @@ enum { ST_P = 0 /* next draw */, ST_DONE = 1, ST_ROUNDS = 3 /* accepts */, ST_FR
        ST_FIRST = 10 /* no accept yet in this search */,
        // statistics of the search (LCSGPU_PROFILE): groups of steps, steps looked at, steps up to the accepted one, steps that
        // ended without a walk because no member was closer to the candidate than to its medoid / because no slot could go negative
-       ST_N_ROUNDS = 11, ST_N_STEPS = 12, ST_N_USEFUL = 13, ST_N_NOB = 14, ST_N_NOP = 15 };
+       ST_N_ROUNDS = 11, ST_N_STEPS = 12, ST_N_USEFUL = 13, ST_N_NOB = 14, ST_N_NOP = 15,
+       // the chain (clarans_chain_kernel): the local search it is in, the cheapest search's cost so far, whether the search it is in has to be started
+       ST_ITER = 16, ST_BEST = 17, ST_NEED_INIT = 18 };
 // why an evaluation ended
 enum { WHY_WALKED = 0, WHY_NO_B = 1, WHY_NO_P = 2 };
 
@@ -129,40 +132,42 @@ struct Nearest2 {
     }
 };
 
-// Start of one local search (Clustering.cpp:49-79): every non-medoid's distances to the medoid
-// slots (DMt[mm * n + pos]) and assignment, the addends of the initial cost in position order.
-__global__ __launch_bounds__(256) void clarans_init_kernel(ClaransArgs a)
+// Start of one local search (Clustering.cpp:49-79), by the search's own workgroup: every non-medoid's distances to the
+// medoid slots (DMt[mm * n + pos]) and assignment, the addends of the initial cost in position order.  The candidate
+// order has just been written by this workgroup: it is read with workgroup-scope loads (never through the scalar cache).
+__device__ __forceinline__ void chain_init(const ClaransArgs& a)
 {
-    const int W = a.corrected;
-    const int pos = blockIdx.x * 256 + threadIdx.x;
-    const int k = a.n_medoids, n = a.n_elems;
-    const int p = a.state[ST_P];
-    if (pos == 0) {
-        a.state[ST_DONE] = 0;
-        a.state[ST_ROUNDS] = 0;
-        a.state[ST_FRESH] = 1;
-        a.state[ST_COST] = __float_as_int(0.0f);
-        a.state[ST_MORE_DRAWS] = 0;
-        a.state[ST_OFF] = 0;
-        a.state[ST_FIRST] = 1;
-        a.state[ST_N_ROUNDS] = 0;
-        a.state[ST_N_STEPS] = 0;
-        a.state[ST_N_USEFUL] = 0;
-        a.state[ST_N_NOB] = 0;
-        a.state[ST_N_NOP] = 0;
-        if (p + W > a.draws_len) a.state[ST_ERR] = 1;
+    constexpr int PER = 4;
+    const int k = a.n_medoids, n = a.n_elems, tid = threadIdx.x;
+    int y[PER];
+    Nearest2 nb[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int pos = k + tid + 512 * u;
+        y[u] = pos < n ? __hip_atomic_load(a.cand + pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0;
     }
-    if (pos < k || pos >= n) return;
-    const int y = a.cand[pos];
-    Nearest2 nb;
-#pragma unroll 4
     for (int mm = 0; mm < k; ++mm) {
-        const float d = a.D[sq_at(n, a.cand[mm], y)];
-        a.DMt[(size_t)mm * n + pos] = d;
-        nb.feed(d, mm);
+        const int med = __builtin_amdgcn_readfirstlane(__hip_atomic_load(a.cand + mm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+        const float* row = a.D + (size_t)med * (size_t)n;
+        float d[PER];
+#pragma unroll
+        for (int u = 0; u < PER; ++u) d[u] = row[y[u]];
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int pos = k + tid + 512 * u;
+            if (pos < n) {
+                a.DMt[(size_t)mm * n + pos] = d[u];
+                nb[u].feed(d[u], mm);
+            }
+        }
     }
-    a.st[pos] = pack_state(nb.dn, nb.ds, nb.an, nb.as);
-    a.cost_log[pos - k] = nb.dn;
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int pos = k + tid + 512 * u;
+        if (pos >= n) continue;
+        a.st[pos] = pack_state(nb[u].dn, nb[u].ds, nb[u].an, nb[u].as);
+        a.cost_log[pos - k] = nb[u].dn;
+    }
 }
 
 // running cost: c += addend for every logged addend, in order; zeros are the identity (c starts at +0.0f and can
@@ -510,6 +515,14 @@ __device__ __forceinline__ void rescan_positions(const ClaransArgs& a, const boo
     }
 }
 
+// what a search keeps between launches (the state block) -- in registers while a workgroup runs: a chain's second search
+// must not read back through the scalar cache what the first one has just stored
+struct SearchRegs {
+    int P, off, first, accepts, fresh;
+    float cost; // (kept by thread 0)
+    int n_groups, n_steps, n_useful, n_nob, n_nop;
+};
+
 // ---------------------------------------------------------------------------------------------------------------
 // A WHOLE LOCAL SEARCH IN ONE WORKGROUP (round 5).
 //
@@ -529,12 +542,11 @@ __device__ __forceinline__ void rescan_positions(const ClaransArgs& a, const boo
 // LDS, so that the workgroup finds room on a CU that also runs workgroups of the LCS kernels -- with 240 VGPRs / 62 KB it
 // waited for a CU to drain and the stage was no faster than with the rounds (profiles/c5_search_r05.txt).  A launch ends for a search when it is done, when the pre-drawn positions run out
 // (ST_MORE_DRAWS: the host draws more) or when its time slice is over; the state is where the next launch finds it.
+// Returns 1: the local search is over, 2: out of pre-drawn positions, 0: the time slice is over.
 template <int KPT>
-__global__ __launch_bounds__(512, 4) void clarans_search_kernel(ClaransBatch batch, long long slice_ticks)
+__device__ __forceinline__ int clarans_search_body(const ClaransArgs& a, SearchRegs& R, long long slice_ticks, long long t_begin)
 {
-    const ClaransArgs& a = batch.s[blockIdx.x];
     constexpr int PER = 4, Q = 16, MEMBERS = CLARANS_MAX_MEDOIDS + CLARANS_MAX_NONMEDOIDS;
-    const long long t_begin = wall_clock64();
     __shared__ float4 s_e[1024];        // 16 KB   evaluate_step's staging
     __shared__ float4 s_we[8][128];     // 16 KB
     __shared__ float4 s_xx_state;       // the rebuilt state of the position that received the replaced medoid
@@ -550,23 +562,20 @@ __global__ __launch_bounds__(512, 4) void clarans_search_kernel(ClaransBatch bat
     __shared__ int s_res[4];            // an evaluation's result for everybody
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int k = a.n_medoids, n = a.n_elems, corrected = a.corrected, cnt = n - k;
-    __builtin_amdgcn_s_setprio(3); // a chain of short dependent phases next to the LCS kernels' waves on the same SIMDs
-    int P = __builtin_amdgcn_readfirstlane(a.state[ST_P]), off = __builtin_amdgcn_readfirstlane(a.state[ST_OFF]),
-        first = __builtin_amdgcn_readfirstlane(a.state[ST_FIRST]), accepts = __builtin_amdgcn_readfirstlane(a.state[ST_ROUNDS]);
-    const int fresh = __builtin_amdgcn_readfirstlane(a.state[ST_FRESH]);
-    float cost = __int_as_float(a.state[ST_COST]); // (kept by thread 0)
-    int n_groups = a.state[ST_N_ROUNDS], n_steps = a.state[ST_N_STEPS], n_useful = a.state[ST_N_USEFUL], n_nob = a.state[ST_N_NOB],
-        n_nop = a.state[ST_N_NOP];
+    int P = R.P, off = R.off, first = R.first, accepts = R.accepts;
+    const int fresh = R.fresh;
+    float cost = R.cost;
+    int n_groups = R.n_groups, n_steps = R.n_steps, n_useful = R.n_useful, n_nob = R.n_nob, n_nop = R.n_nop;
     int y_pre[PER];
     float4 s_pre[PER];
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
         const int pos = k + tid + 512 * u;
-        y_pre[u] = pos < n ? a.cand[pos] : 0;
+        y_pre[u] = pos < n ? cand_at(pos) : 0;
         s_pre[u] = pos < n ? a.st[pos] : make_float4(0.f, 0.f, 0.f, 0.f);
         if (pos < n) s_dn[y_pre[u]] = s_pre[u].x;
     }
-    for (int mm = tid; mm < k; mm += 512) s_dn[a.cand[mm]] = 0.0f;
+    for (int mm = tid; mm < k; mm += 512) s_dn[cand_at(mm)] = 0.0f;
     __syncthreads();
     float dnm[MEMBERS / 512]; // my members' (tid, tid + 512, ...) distances to their medoids; beyond n: never flagged
 #pragma unroll
@@ -758,26 +767,144 @@ __global__ __launch_bounds__(512, 4) void clarans_search_kernel(ClaransBatch bat
         a.cand[pos] = y_pre[u];
         a.st[pos] = s_pre[u];
     }
-    if (tid == 0) {
-        int32_t* out[2] = {a.state, a.host_state};
-        for (int o = 0; o < 2; ++o) {
-            int32_t* st = out[o];
-            if (!st) continue;
-            st[ST_P] = P;
-            st[ST_DONE] = status == 1;
-            st[ST_ROUNDS] = accepts;
-            st[ST_FRESH] = 0;
-            st[ST_COST] = __float_as_int(cost);
-            st[ST_ERR] = 0;
-            st[ST_MORE_DRAWS] = status == 2;
-            st[ST_OFF] = off;
-            st[ST_FIRST] = first;
-            st[ST_N_ROUNDS] = n_groups;
-            st[ST_N_STEPS] = n_steps;
-            st[ST_N_USEFUL] = n_useful;
-            st[ST_N_NOB] = n_nob;
-            st[ST_N_NOP] = n_nop;
+    __syncthreads(); // (the order and the states are where the next search of the chain, or the next launch, finds them)
+    R.P = P;
+    R.off = off;
+    R.first = first;
+    R.accepts = accepts;
+    R.fresh = 0;
+    R.cost = cost;
+    R.n_groups = n_groups;
+    R.n_steps = n_steps;
+    R.n_useful = n_useful;
+    R.n_nob = n_nob;
+    R.n_nop = n_nop;
+    return status;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// A CHAIN OF LOCAL SEARCHES IN ONE WORKGROUP (round 6): CLARANS::operator() from its first shuffle to its last comparison
+// (Clustering.cpp:31-258) without the host in between.  Per local search: the candidate order is permuted (the
+// partial_shuffle of cpp:46 moves POSITIONS, whatever they hold, and its generator does not look at the search: the host
+// hands over the composed permutation), the search starts (chain_init), runs (clarans_search_body), and its medoids
+// replace the kept ones if it is strictly cheaper (cpp:239-257).  All splits of a level of the FastTree recursion run as
+// one launch, a workgroup each -- up to 512 resident at once -- and nothing else competes for the CUs meanwhile
+// (lcsgpu_clarans_batch).  A workgroup leaves early only for want of pre-drawn positions or at the end of a time slice
+// (a test aid); the state block says where it was.
+template <int KPT>
+__global__ __launch_bounds__(512, 4) void clarans_chain_kernel(const ClaransChain* __restrict__ chains, long long slice_ticks)
+{
+    const ClaransChain& ch = chains[blockIdx.x];
+    const ClaransArgs& a = ch.a;
+    const long long t_begin = wall_clock64();
+    __shared__ int s_better;
+    const int tid = threadIdx.x, k = a.n_medoids, n = a.n_elems;
+    __builtin_amdgcn_s_setprio(3);
+    SearchRegs R;
+    R.P = __builtin_amdgcn_readfirstlane(a.state[ST_P]);
+    R.off = __builtin_amdgcn_readfirstlane(a.state[ST_OFF]);
+    R.first = __builtin_amdgcn_readfirstlane(a.state[ST_FIRST]);
+    R.accepts = __builtin_amdgcn_readfirstlane(a.state[ST_ROUNDS]);
+    R.fresh = __builtin_amdgcn_readfirstlane(a.state[ST_FRESH]);
+    R.cost = __int_as_float(a.state[ST_COST]);
+    R.n_groups = a.state[ST_N_ROUNDS];
+    R.n_steps = a.state[ST_N_STEPS];
+    R.n_useful = a.state[ST_N_USEFUL];
+    R.n_nob = a.state[ST_N_NOB];
+    R.n_nop = a.state[ST_N_NOP];
+    int iter = __builtin_amdgcn_readfirstlane(a.state[ST_ITER]), need_init = __builtin_amdgcn_readfirstlane(a.state[ST_NEED_INIT]);
+    float best = __int_as_float(a.state[ST_BEST]); // (kept by thread 0)
+    int status = 0;
+    while (iter < ch.num_local) {
+        if (need_init) {
+            // the order before this search: position i takes what position perm[i] held (the first search starts from 0, 1, 2, ...)
+            const int32_t* perm = ch.perm + (size_t)iter * (size_t)n;
+            int v[(CLARANS_MAX_MEDOIDS + CLARANS_MAX_NONMEDOIDS) / 512];
+#pragma unroll
+            for (int u = 0; u < (CLARANS_MAX_MEDOIDS + CLARANS_MAX_NONMEDOIDS) / 512; ++u) {
+                const int i = tid + 512 * u;
+                if (i < n) {
+                    const int from = perm[i];
+                    v[u] = iter == 0 ? from : __hip_atomic_load(a.cand + from, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < (CLARANS_MAX_MEDOIDS + CLARANS_MAX_NONMEDOIDS) / 512; ++u) {
+                const int i = tid + 512 * u;
+                if (i < n) __hip_atomic_store(a.cand + i, v[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            __syncthreads();
+            chain_init(a);
+            __syncthreads();
+            R.off = 0;
+            R.first = 1;
+            R.fresh = 1;
+            R.cost = 0.0f;
+            need_init = 0;
         }
+        status = clarans_search_body<KPT>(a, R, slice_ticks, t_begin);
+        if (status != 1) break;
+        // the search is over: its medoids stand if it is strictly cheaper than the best so far (Clustering.cpp:239-257)
+        if (tid == 0) {
+            s_better = R.cost < best;
+            if (R.cost < best) best = R.cost;
+        }
+        __syncthreads();
+        if (s_better)
+            for (int mm = tid; mm < k; mm += 512) ch.best[mm] = __hip_atomic_load(a.cand + mm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __syncthreads();
+        ++iter;
+        need_init = 1;
+    }
+    if (tid == 0) {
+        int32_t* st = a.state;
+        st[ST_P] = R.P;
+        st[ST_DONE] = iter >= ch.num_local;
+        st[ST_ROUNDS] = R.accepts;
+        st[ST_FRESH] = R.fresh;
+        st[ST_COST] = __float_as_int(R.cost);
+        st[ST_ERR] = 0;
+        st[ST_MORE_DRAWS] = status == 2;
+        st[ST_OFF] = R.off;
+        st[ST_FIRST] = R.first;
+        st[ST_N_ROUNDS] = R.n_groups;
+        st[ST_N_STEPS] = R.n_steps;
+        st[ST_N_USEFUL] = R.n_useful;
+        st[ST_N_NOB] = R.n_nob;
+        st[ST_N_NOP] = R.n_nop;
+        st[ST_ITER] = iter;
+        st[ST_BEST] = __float_as_int(best);
+        st[ST_NEED_INIT] = need_init;
+    }
+}
+
+// the samples' float matrices, all jobs in one launch (grid.y = job)
+template <typename T>
+__global__ __launch_bounds__(256) void subset_dist_batch_kernel(const T* __restrict__ lcs, const ClaransChain* __restrict__ chains,
+                                                                const uint32_t* __restrict__ lens, const float* __restrict__ pow_f32, int kind)
+{
+    const ClaransChain& ch = chains[blockIdx.y];
+    const int n = ch.a.n_elems, i = blockIdx.x + 1;
+    if (i >= n) return;
+    float* D = const_cast<float*>(ch.a.D);
+    const int32_t* ids = ch.ids;
+    const T* tri = lcs + ch.tri0;
+    if (threadIdx.x == 0) {
+        D[(size_t)i * n + i] = 0.0f; // (never read)
+        if (i == 1) D[0] = 0.0f;
+    }
+    const uint32_t len_i = lens[ids[i]];
+    const size_t row = (size_t)i * (i - 1) / 2;
+    for (int j = threadIdx.x; j < i; j += 256) {
+        const uint32_t l = tri[row + j];
+        const uint32_t indel = len_i + lens[ids[j]] - 2u * l;
+        float d;
+        if (l == 0) d = FLT_MAX;
+        else if (kind == 1) d = __fdiv_rn(pow_f32[indel], (float)l);
+        else d = __fdiv_rn((float)indel, (float)l);
+        D[(size_t)i * n + j] = d;
+        D[(size_t)j * n + i] = d;
     }
 }
 
@@ -794,20 +921,24 @@ hipError_t launch_subset_distances(const void* lcs, int elem_size, const int32_t
     return hipGetLastError();
 }
 
-hipError_t launch_clarans_init(const ClaransArgs& a, hipStream_t stream)
+hipError_t launch_subset_distances_batch(const void* lcs, int elem_size, const ClaransChain* chains, int n_chains, int max_n,
+                                         const uint32_t* lens, const float* pow_f32, int kind, hipStream_t stream)
 {
-    hipLaunchKernelGGL(clarans_init_kernel, dim3((a.n_elems + 255) / 256), dim3(256), 0, stream, a);
+    if (n_chains <= 0 || max_n < 2) return hipSuccess;
+    const dim3 grid((unsigned)(max_n - 1), (unsigned)n_chains);
+    if (elem_size == 2) hipLaunchKernelGGL(subset_dist_batch_kernel<uint16_t>, grid, dim3(256), 0, stream, (const uint16_t*)lcs, chains, lens, pow_f32, kind);
+    else hipLaunchKernelGGL(subset_dist_batch_kernel<uint32_t>, grid, dim3(256), 0, stream, (const uint32_t*)lcs, chains, lens, pow_f32, kind);
     return hipGetLastError();
 }
 
-// every search of the batch in its own workgroup, for `slice_us` microseconds or to its end
-hipError_t launch_clarans_search(const ClaransBatch& b, int slice_us, hipStream_t stream)
+// every chain in its own workgroup, to its end (or for `slice_us` microseconds, 0 = no limit)
+hipError_t launch_clarans_chains(const ClaransChain* chains, int n_chains, int max_medoids, int slice_us, hipStream_t stream)
 {
-    int kpt = 1;
-    for (int i = 0; i < b.n; ++i) kpt = std::max(kpt, ((b.s[i].n_medoids + 7) / 8 + 63) / 64);
-    const long long ticks = (long long)slice_us * 100; // wall_clock64: 100 MHz
-    if (kpt <= 1) hipLaunchKernelGGL(clarans_search_kernel<1>, dim3(b.n), dim3(512), 0, stream, b, ticks);
-    else hipLaunchKernelGGL(clarans_search_kernel<2>, dim3(b.n), dim3(512), 0, stream, b, ticks);
+    if (n_chains <= 0) return hipSuccess;
+    const int kpt = std::max(1, ((max_medoids + 7) / 8 + 63) / 64);
+    const long long ticks = slice_us > 0 ? (long long)slice_us * 100 : LLONG_MAX; // wall_clock64: 100 MHz
+    if (kpt <= 1) hipLaunchKernelGGL(clarans_chain_kernel<1>, dim3(n_chains), dim3(512), 0, stream, chains, ticks);
+    else hipLaunchKernelGGL(clarans_chain_kernel<2>, dim3(n_chains), dim3(512), 0, stream, chains, ticks);
     return hipGetLastError();
 }
 

@@ -56,6 +56,8 @@ struct RowsArgs {
     // tri_prefix[tri_rows] = grid size.  NULL = plain 2-D grid (x = column block, y = ref tile).
     const int32_t* tri_prefix;
     int32_t tri_rows;
+    // (MODE_RECT with jobs -- lcsgpu_assign_seeds_batch: several rectangles in one launch; ref k writes the row
+    // out + ref_out0[k], column c of the concatenated list at its offset c - ref_col0[k].)
     // Several triangles in one launch (lcsgpu_lcs_triangles_batch): 1-D grid, workgroup b does
     // jobs[b] = {first ref k0, ref count, first column, column limit}; rows and columns are positions
     // in the concatenated id list col_ids, ref k belongs to the list that starts at position

@@ -149,7 +149,9 @@ __device__ __forceinline__ void store_result(const RowsArgs& a, int k, int c, ui
 {
     const int64_t row = a.ref_rows ? a.ref_rows[k] : (int64_t)k + a.row0;
     int64_t idx;
-    if (a.jobs) { // batched triangles: positions relative to the start of the ref's own id list
+    if (a.jobs && a.mode == MODE_RECT) { // batched rectangles: a row of its own per ref, columns relative to the job's first
+        idx = a.ref_out0[k] + (c - a.ref_col0[k]);
+    } else if (a.jobs) { // batched triangles: positions relative to the start of the ref's own id list
         if (c >= row)
             return;
         const int64_t g0 = a.ref_col0[k], lr = row - g0;

@@ -143,21 +143,6 @@ bool create_lane(lcsgpu_ctx* ctx, Lane& l)
     return ok;
 }
 
-int ensure_batcher(lcsgpu_ctx* ctx, ClaransBatcher& B)
-{
-    std::lock_guard<std::mutex> lk(B.mu);
-    if (B.stream) return LCSGPU_OK;
-    HIP_TRY(hipSetDevice(ctx->device));
-    // a search is one latency-bound workgroup next to the lanes' LCS launches, which fill the chip for hundreds of
-    // microseconds each: its workgroup goes first when slots free up
-    int least = 0, greatest = 0;
-    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = greatest = 0;
-    if (greatest != least) HIP_TRY(hipStreamCreateWithPriority(&B.stream, hipStreamNonBlocking, greatest));
-    else HIP_TRY(hipStreamCreateWithFlags(&B.stream, hipStreamNonBlocking));
-    HIP_TRY(hipEventCreateWithFlags(&B.ev, hipEventBlockingSync | hipEventDisableTiming));
-    HIP_TRY(B.h_states.reserve(lcsgpu::CLARANS_MAX_BATCH * 256));
-    return LCSGPU_OK;
-}
 
 // free device memory as reserve_big sees it (LCSGPU_FAKE_HBM_GB included)
 int device_free_bytes(lcsgpu_ctx* ctx, size_t* out)
@@ -479,9 +464,6 @@ int lcsgpu_create(int device_id, lcsgpu_ctx** out_ctx)
     if (profile)
         fprintf(stderr, "lcsgpu_create: HIP runtime start (hipGetDeviceCount) %.3f s, device properties %.3f s, context + first lane %.3f s\n",
                 t1 - t0, t2 - t1, now() - t2);
-    // 3 x 10^6-sequence MedoidTree, tree stage (round 2): 1 group 2.92 s, 2: 2.79 s, 4: 2.71 s, 8: 4.13 s
-    const int n_groups = std::max(1, std::min(16, tune_int("clarans_groups", 4)));
-    ctx->clarans_groups = std::vector<ClaransBatcher>(n_groups);
     *out_ctx = ctx;
     return LCSGPU_OK;
 }
@@ -512,33 +494,6 @@ int lcsgpu_reserve_lanes(lcsgpu_ctx* ctx, int32_t n_threads)
         }
         ctx->cv.notify_all();
     }
-    for (ClaransBatcher& B : ctx->clarans_groups)
-        if (int rc = ensure_batcher(ctx, B)) return rc;
-    HIP_TRY(hipSetDevice(ctx->device));
-    if (n_threads > 1 && !ctx->prep_streams[0]) {
-        int least = 0, greatest = 0;
-        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = greatest = 0;
-        static const int n_prep = std::max(0, std::min(2, tune_int("clarans_prep_streams", 2)));
-        for (int i = 0; i < n_prep && greatest != least; ++i)
-            HIP_TRY(hipStreamCreateWithPriority(&ctx->prep_streams[i], hipStreamNonBlocking, greatest));
-    }
-    // the lanes' CLARANS buffers out of one allocation: work area for the default MedoidTree shape (2000 sample members, 100
-    // medoids: 17 MB) and its LCS triangle (4 MB); a call that needs more allocates its own
-    if (n_threads > 1 && !ctx->d_lane_arena.p) {
-        constexpr size_t WORK = (size_t)24 << 20, OUT = (size_t)8 << 20;
-        const int n_slices = std::min(limit - 1, n_threads);
-        if (n_slices > 0 && ctx->d_lane_arena.reserve((size_t)n_slices * (WORK + OUT)) == hipSuccess) {
-            std::lock_guard<std::mutex> lk(ctx->mu);
-            for (int i = 0; i < n_slices; ++i) {
-                Lane& l = ctx->lanes[i + 1];
-                if (l.busy) continue;
-                char* slice = (char*)ctx->d_lane_arena.p + (size_t)i * (WORK + OUT);
-                if (!l.d_work.p) l.d_work.adopt(slice, WORK);
-                if (!l.d_out.p) l.d_out.adopt(slice + WORK, OUT);
-            }
-        } else
-            (void)hipGetLastError(); // (no arena: the lanes allocate as before)
-    }
     return LCSGPU_OK;
 }
 
@@ -562,28 +517,6 @@ int lcsgpu_destroy(lcsgpu_ctx* ctx)
         if (l.copy_stream) (void)hipStreamDestroy(l.copy_stream);
         if (l.stream) (void)hipStreamDestroy(l.stream);
     }
-    if (getenv("LCSGPU_PROFILE") && ctx->clarans_calls.load())
-        fprintf(stderr, "clarans.calls=%ld thread-ms per call: lane + buffers %.2f, sample triangle + distances + first start %.2f, later starts %.2f, "
-                        "searches (join to done) %.2f, results %.2f\n", ctx->clarans_calls.load(), 1e-3 * ctx->clarans_us[0] / ctx->clarans_calls,
-                1e-3 * ctx->clarans_us[1] / ctx->clarans_calls, 1e-3 * ctx->clarans_us[2] / ctx->clarans_calls, 1e-3 * ctx->clarans_us[3] / ctx->clarans_calls,
-                1e-3 * ctx->clarans_us[4] / ctx->clarans_calls);
-    for (ClaransBatcher& B : ctx->clarans_groups) {
-        if (getenv("LCSGPU_PROFILE"))
-            for (int i = 1; i <= lcsgpu::CLARANS_MAX_BATCH; ++i)
-                if (B.prof_looks[i])
-                    fprintf(stderr, "clarans.batch[%d searches]: %ld looks, %.3f s, %.1f us per look\n", i, B.prof_looks[i],
-                            B.prof_seconds[i], 1e6 * B.prof_seconds[i] / B.prof_looks[i]);
-        if (getenv("LCSGPU_PROFILE") && B.prof_searches)
-            fprintf(stderr, "clarans.searches=%ld accepts=%ld step_groups=%ld steps_looked_at=%ld steps_up_to_the_accept=%ld "
-                            "steps_without_a_closer_member=%ld steps_without_a_slot_that_can_go_negative=%ld\n", B.prof_searches,
-                    B.prof_accepts, B.prof_rounds, B.prof_steps, B.prof_useful, B.prof_no_b, B.prof_no_p);
-        if (B.stream) { (void)hipStreamSynchronize(B.stream); (void)hipStreamDestroy(B.stream); }
-        if (B.ev) (void)hipEventDestroy(B.ev);
-        B.h_states.release();
-    }
-    ctx->d_lane_arena.release();
-    for (hipStream_t& s : ctx->prep_streams)
-        if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); s = nullptr; }
     ctx->d_tiles.release();
     ctx->d_tile_base.release();
     ctx->d_lens.release();

@@ -2,148 +2,10 @@
 // of a split in one call, the seed assignment of an evaluation, CLARANS (kernels in
 // clarans_kernels.hip; here the host side: the two mt19937 streams and the batch of searches).
 #include "lcsgpu_internal.h"
+#include "fasttree_kernels.h"
 
 using namespace lcsgpu_impl;
 using lcsgpu::RowsArgs;
-
-namespace {
-
-// det_uniform_int_distribution<int>(n_medoids, n_elems - 1) over the owner's generator
-// (deterministic_random.h:62-76), appended to the job's draws and copied to the device.
-int clarans_extend_draws(ClaransJob& j, size_t want, hipStream_t stream)
-{
-    std::vector<int32_t>& draws = *j.draws;
-    if (draws.size() < want) {
-        const uint32_t k = (uint32_t)j.a.n_medoids, diff = (uint32_t)(j.a.n_elems - j.a.n_medoids);
-        const uint32_t bad = 0xffffffffu / diff;
-        const size_t old = draws.size();
-        want = std::max(want, old * 2);
-        draws.reserve(want);
-        while (draws.size() < want) {
-            const uint32_t r = (*j.gen_positions)();
-            if (r / diff < bad) draws.push_back((int32_t)(r % diff + k));
-        }
-        const bool regrow = j.d_draws->cap < want * 4;
-        HIP_TRY(j.d_draws->reserve(want * 4));
-        const size_t from = regrow ? 0 : old;
-        HIP_TRY(hipMemcpyAsync((int32_t*)j.d_draws->p + from, draws.data() + from, (draws.size() - from) * 4,
-                               hipMemcpyHostToDevice, stream));
-    }
-    j.a.draws = (const int32_t*)j.d_draws->p;
-    j.a.draws_len = (int32_t)draws.size();
-    return LCSGPU_OK;
-}
-
-// One stint as the driver: looks for everything joined, until nothing is left or `mine` is done.
-void clarans_drive(lcsgpu_ctx* ctx, ClaransBatcher& B, ClaransJob* mine)
-{
-    // a look = one launch: every joined search advances for `slice_us` (3 x 10^6 sequences, tree stage: 500 us 1.09-1.11 s,
-    // 1000: 1.06-1.14 s, 2000: 1.22-1.30 s) with at least `draws_ahead` pre-drawn positions in front of it
-    static const int draws_ahead = std::max(1, tune_int("clarans_draws", 8192)), slice_us = std::max(1, tune_int("clarans_slice_us", 1000));
-    for (;;) {
-        std::vector<ClaransJob*> now;
-        {
-            std::lock_guard<std::mutex> lk(B.mu);
-            for (ClaransJob* j : B.joined)
-                if ((int)now.size() < lcsgpu::CLARANS_MAX_BATCH) now.push_back(j);
-            if (now.empty() || mine->done) {
-                B.driver_present = false;
-                B.cv.notify_all();
-                return;
-            }
-        }
-        int rc = LCSGPU_OK;
-        const auto t_look = std::chrono::steady_clock::now();
-        lcsgpu::ClaransBatch batch{};
-        auto hip_ok = [&](hipError_t e, const char* what) {
-            if (e != hipSuccess && rc == LCSGPU_OK) rc = fail(LCSGPU_E_HIP, "%s failed: %s", what, hipGetErrorString(e));
-        };
-        int32_t* hs = (int32_t*)B.h_states.p;
-        // The searches leave their state block in the batch's pinned (device-mapped) buffer themselves: no copy per search
-        // and look (7-8 copies of 256 B were 110 us of a 2.4 ms look); without the mapping: a copy each.
-        int32_t* hs_dev = nullptr;
-        if (hipHostGetDevicePointer((void**)&hs_dev, B.h_states.p, 0) != hipSuccess) {
-            (void)hipGetLastError();
-            hs_dev = nullptr;
-        }
-        for (ClaransJob* j : now) {
-            // (a search that runs out of positions stops and says so; the next look brings more)
-            if (rc == LCSGPU_OK) rc = clarans_extend_draws(*j, (size_t)j->p_host + (size_t)j->state[8] + (size_t)draws_ahead, B.stream);
-            lcsgpu::ClaransArgs& s1 = batch.s[batch.n];
-            s1 = j->a;
-            s1.host_state = hs_dev ? hs_dev + 64 * batch.n : nullptr;
-            ++batch.n;
-        }
-        if (rc == LCSGPU_OK) hip_ok(lcsgpu::launch_clarans_search(batch, slice_us, B.stream), "CLARANS searches");
-        if (!hs_dev)
-            for (size_t i = 0; i < now.size() && rc == LCSGPU_OK; ++i)
-                hip_ok(hipMemcpyAsync(hs + 64 * i, now[i]->a.state, 64, hipMemcpyDeviceToHost, B.stream), "state read-back");
-        if (rc == LCSGPU_OK) hip_ok(hipEventRecord(B.ev, B.stream), "hipEventRecord");
-        if (rc == LCSGPU_OK) hip_ok(hipEventSynchronize(B.ev), "hipEventSynchronize");
-        else (void)hipStreamSynchronize(B.stream);
-        {
-            std::lock_guard<std::mutex> lk(B.mu);
-            const std::string msg = rc == LCSGPU_OK ? std::string() : std::string(lcsgpu_last_error());
-            B.prof_looks[now.size()]++;
-            B.prof_seconds[now.size()] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_look).count();
-            for (size_t i = 0; i < now.size(); ++i) {
-                ClaransJob* j = now[i];
-                if (rc == LCSGPU_OK) {
-                    memcpy(j->state, hs + 64 * i, 64);
-                    j->p_host = j->state[0];
-                    if (j->state[6]) {
-                        j->rc = LCSGPU_E_STATE;
-                        j->error = "CLARANS: the device search ran out of pre-drawn steps";
-                    }
-                } else {
-                    j->rc = rc;
-                    j->error = msg;
-                }
-                if (j->rc != LCSGPU_OK || j->state[1]) {
-                    B.prof_searches += 1;
-                    B.prof_accepts += j->state[3];
-                    B.prof_rounds += j->state[11];
-                    B.prof_steps += j->state[12];
-                    B.prof_useful += j->state[13];
-                    B.prof_no_b += j->state[14];
-                    B.prof_no_p += j->state[15];
-                    j->done = true;
-                    B.joined.erase(std::find(B.joined.begin(), B.joined.end(), j));
-                }
-            }
-            B.cv.notify_all();
-        }
-    }
-}
-
-// Join the batch with a search whose device state is initialised; returns when it has finished.
-int clarans_run_search(lcsgpu_ctx* ctx, ClaransJob& job)
-{
-    ClaransBatcher& B = ctx->clarans_groups[ctx->clarans_next++ % ctx->clarans_groups.size()];
-    if (int rc = ensure_batcher(ctx, B)) return rc;
-    job.done = false;
-    std::unique_lock<std::mutex> lk(B.mu);
-    B.joined.push_back(&job);
-    while (!job.done) {
-        if (!B.driver_present) {
-            B.driver_present = true;
-            lk.unlock();
-            clarans_drive(ctx, B, &job);
-            lk.lock();
-        } else {
-            B.cv.wait(lk, [&] { return job.done || !B.driver_present; });
-        }
-    }
-    lk.unlock();
-    if (job.rc != LCSGPU_OK) return fail(job.rc, "%s", job.error.c_str());
-    return LCSGPU_OK;
-}
-
-} // namespace
-
-extern "C" {
-
-} // extern "C"
 
 // The packed LCS triangles of several id lists into lane L's result buffer (device memory), list g at pair offset
 // tri_base[g]: validation, planning and the launches of lcsgpu_lcs_triangles_batch.  *count = pairs in total (0: nothing to do).  On return the
@@ -397,154 +259,478 @@ int lcsgpu_assign_seeds(lcsgpu_ctx* ctx, const int32_t* seed_ids, int32_t n_seed
     return LCSGPU_OK;
 }
 
-int lcsgpu_clarans(lcsgpu_ctx* ctx, const int32_t* ids, int32_t n_ids, int distance_kind, int32_t n_medoids,
-                   int32_t n_fixed, float explore_fraction, int32_t num_local, int32_t* medoids_out)
+int lcsgpu_assign_seeds_batch(lcsgpu_ctx* ctx, const int32_t* seed_ids, const int64_t* seed_offsets, const int32_t* col_ids,
+                              const int64_t* col_offsets, int32_t n_jobs, int distance_kind, float* dist, int32_t* assign)
 {
     if (!ctx) return fail(LCSGPU_E_INVALID, "NULL ctx");
     if (ctx->n < 0) return fail(LCSGPU_E_STATE, "no sequence set uploaded");
     if (distance_kind != LCSGPU_DIST_INDEL_DIV_LCS && distance_kind != LCSGPU_DIST_INDEL075_DIV_LCS)
         return fail(LCSGPU_E_INVALID, "unknown distance kind %d", distance_kind);
-    if (!ids || !medoids_out || n_ids < 1) return fail(LCSGPU_E_INVALID, "bad sample / output");
-    if (n_medoids < 1 || n_medoids > n_ids || n_fixed < 0 || n_fixed >= n_medoids || num_local < 1)
-        return fail(LCSGPU_E_INVALID, "bad CLARANS shape: %d medoids (%d fixed) of %d, %d searches", n_medoids, n_fixed,
-                    n_ids, num_local);
-    for (int32_t i = 0; i < n_ids; ++i)
-        if (ids[i] < 0 || ids[i] >= ctx->n) return fail(LCSGPU_E_INVALID, "sample id %d out of range", ids[i]);
-    if (n_medoids > lcsgpu::CLARANS_MAX_MEDOIDS || n_ids - n_medoids > lcsgpu::CLARANS_MAX_NONMEDOIDS)
-        return fail(LCSGPU_E_UNSUPPORTED, "device CLARANS handles at most %d medoids and %d other sample members (asked: %d, %d)",
-                    lcsgpu::CLARANS_MAX_MEDOIDS, lcsgpu::CLARANS_MAX_NONMEDOIDS, n_medoids, n_ids - n_medoids);
-    if (n_ids == n_medoids) {
-        // every member is a medoid: no step is ever drawn (corrected = 0), every search costs 0, the first one stands
-        // (Clustering.cpp:239-257: a later search has to be cheaper) -- its medoids are the order after the first shuffle
-        std::mt19937 gen_nodes;
-        std::vector<int32_t> cand(n_ids);
-        for (int32_t i = 0; i < n_ids; ++i) cand[i] = i;
-        int32_t* first = cand.data() + n_fixed;
-        const long cnt = n_ids - n_fixed, N = cnt - 1;
-        for (long i = 0; i < cnt; ++i) {
-            const unsigned long d = (unsigned long)N - (unsigned long)i + 1;
-            std::swap(first[i], first[((unsigned long)gen_nodes() % d) + (unsigned long)i]);
+    if (n_jobs < 0 || (n_jobs > 0 && (!seed_offsets || !col_offsets))) return fail(LCSGPU_E_INVALID, "bad job tables");
+    if (n_jobs == 0) return LCSGPU_OK;
+    if (seed_offsets[0] != 0 || col_offsets[0] != 0) return fail(LCSGPU_E_INVALID, "offsets must start at 0");
+    for (int32_t j = 0; j < n_jobs; ++j)
+        if (seed_offsets[j + 1] < seed_offsets[j] || col_offsets[j + 1] < col_offsets[j] || seed_offsets[j + 1] - seed_offsets[j] > 0x7fffffff)
+            return fail(LCSGPU_E_INVALID, "offsets not ascending at job %d", j);
+    const int64_t n_seeds_all = seed_offsets[n_jobs], n_cols_all = col_offsets[n_jobs];
+    if (n_cols_all == 0) return LCSGPU_OK;
+    if (!col_ids || !dist || !assign || (n_seeds_all > 0 && !seed_ids)) return fail(LCSGPU_E_INVALID, "NULL argument");
+    if (n_seeds_all > 0x7fffffff) return fail(LCSGPU_E_INVALID, "too many seeds");
+    bool any_long = false;
+    for (int64_t s = 0; s < n_seeds_all; ++s) {
+        if (seed_ids[s] < 0 || seed_ids[s] >= ctx->n) return fail(LCSGPU_E_INVALID, "seed id %d out of range", seed_ids[s]);
+        any_long |= ctx->lens[seed_ids[s]] > 2048;
+    }
+    for (int64_t c = 0; c < n_cols_all; ++c)
+        if (col_ids[c] < 0 || col_ids[c] >= ctx->n) return fail(LCSGPU_E_INVALID, "col id %d out of range", col_ids[c]);
+    if (any_long) { // the long-ref kernel keeps its 2-D grid: evaluation by evaluation
+        for (int32_t j = 0; j < n_jobs; ++j) {
+            const int64_t c0 = col_offsets[j], nc = col_offsets[j + 1] - c0;
+            if (nc > 0x7fffffff) return fail(LCSGPU_E_INVALID, "too many columns in job %d", j);
+            for (int64_t c = 0; c < nc; ++c) {
+                dist[c0 + c] = std::numeric_limits<float>::infinity();
+                assign[c0 + c] = 0;
+            }
+            int rc = lcsgpu_assign_seeds(ctx, seed_ids + seed_offsets[j], (int32_t)(seed_offsets[j + 1] - seed_offsets[j]), col_ids + c0, (int32_t)nc,
+                                         distance_kind, 0, dist + c0, assign + c0);
+            if (rc) return rc;
         }
-        std::copy(cand.begin(), cand.end(), medoids_out);
         return LCSGPU_OK;
     }
-
-    const int32_t n = n_ids, k = n_medoids;
-    // Clustering.cpp:21-29: how many non-improving steps end a local search
-    const int n_swaps = (n - k) * k;
-    const int min_max_neighbor = 250;
-    const int max_neighbor = n_swaps < min_max_neighbor
-                                 ? n_swaps
-                                 : std::max((int)(explore_fraction * n_swaps), min_max_neighbor);
-    const int corrected = max_neighbor / k;
-
-    auto t_mark = std::chrono::steady_clock::now();
-    auto lap = [&](int what) { // (LCSGPU_PROFILE's account of the call; a few clock readings per call)
-        const auto t = std::chrono::steady_clock::now();
-        ctx->clarans_us[what] += std::chrono::duration_cast<std::chrono::microseconds>(t - t_mark).count();
-        t_mark = t;
-    };
     LaneGuard guard(ctx, LaneGuard::ANY);
     Lane& L = guard.lane();
     HIP_TRY(hipSetDevice(ctx->device));
-    // everything this call enqueues itself goes to one of the context's high-priority streams, if a multi-threaded caller
-    // has announced itself (lcsgpu_ctx::prep_streams); the lane's own stream is idle meanwhile
-    struct StreamSwap {
-        Lane& l;
-        hipStream_t own;
-        bool settled = false; // the call has waited for the last thing it queued
-        StreamSwap(Lane& lane, hipStream_t s) : l(lane), own(lane.stream) { if (s) l.stream = s; }
-        ~StreamSwap()
-        {
-            // an early return (an error) may leave work of this call queued on the shared stream: the lane and its buffers
-            // go back to the pool with this guard, so wait for it
-            if (!settled && l.stream != own) (void)hipStreamSynchronize(l.stream);
-            l.stream = own;
-        }
-    } swap(L, ctx->prep_streams[0] ? ctx->prep_streams[ctx->prep_next++ % (ctx->prep_streams[1] ? 2 : 1)] : nullptr);
     const int elem = ctx->max_len > 65535 ? 4 : 2;
-    const size_t pairs = (size_t)n * (n - 1) / 2;
-    auto a256 = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    const size_t o_D = 0, o_DM = o_D + a256((size_t)n * n * 4), o_cand = o_DM + a256((size_t)n * k * 4), o_st = o_cand + a256((size_t)n * 4),
-                 o_log = o_st + a256((size_t)n * 16), o_state = o_log + a256((size_t)(n + 1) * 4), o_ids = o_state + 256,
-                 total = o_ids + a256((size_t)n * 4);
-    HIP_TRY(L.d_work.reserve(total));
-    HIP_TRY(L.h_small.reserve((size_t)n * 4 + 64));
-    char* base = (char*)L.d_work.p;
-    if (pairs > 0) HIP_TRY(L.d_out.reserve(pairs * elem));
-    lap(0);
-    HIP_TRY(hipMemsetAsync(base + o_state, 0, 256, L.stream));
-    HIP_TRY(hipMemcpyAsync(base + o_ids, ids, (size_t)n * 4, hipMemcpyHostToDevice, L.stream));
-    if (pairs > 0) {
-        int rc = run_rows(ctx, L, lcsgpu::MODE_TRIANGLE, ids, 0, n, ids, 0, n - 1, L.d_out.p, 0, 0, elem);
-        if (rc) return rc;
-        HIP_TRY(lcsgpu::launch_subset_distances(L.d_out.p, elem, (const int32_t*)(base + o_ids),
-                                                (const uint32_t*)ctx->d_lens.p, (const float*)ctx->d_powf.p,
-                                                distance_kind, n, (float*)(base + o_D), L.stream));
+    // pieces = (job, column range), taken in order, so that a launch covers one contiguous range of the caller's columns;
+    // a launch's rectangles stay below `cap` bytes
+    const int64_t cap = (int64_t)std::max(1, tune_int("assign_batch_kb", 2048 << 10)) << 10;
+    struct Piece { int32_t job; int64_t c0, c1; };
+    std::vector<Piece> pieces;
+    for (int32_t j = 0; j < n_jobs; ++j) {
+        const int64_t ns = seed_offsets[j + 1] - seed_offsets[j], c0 = col_offsets[j], c1 = col_offsets[j + 1];
+        if (c1 == c0) continue;
+        if (ns == 0) { // no seed: nothing beats +inf
+            for (int64_t c = c0; c < c1; ++c) { dist[c] = std::numeric_limits<float>::infinity(); assign[c] = 0; }
+            continue;
+        }
+        const int64_t step = std::max<int64_t>(256, (cap / (ns * elem)) & ~(int64_t)255);
+        for (int64_t a = c0; a < c1; a += step) pieces.push_back(Piece{j, a, std::min(c1, a + step)});
     }
-    lcsgpu::ClaransArgs a{};
-    a.D = (const float*)(base + o_D);
-    a.DMt = (float*)(base + o_DM);
-    a.cand = (int32_t*)(base + o_cand);
-    a.st = (float4*)(base + o_st);
-    a.cost_log = (float*)(base + o_log);
-    a.state = (int32_t*)(base + o_state);
-    a.n_elems = n;
-    a.n_medoids = k;
-    a.n_fixed = n_fixed;
-    a.corrected = corrected;
-    // The two generators of Clustering.cpp:43-44.  Neither looks at the search state, so the host
-    // runs them: gen_nodes shuffles the candidate order before every local search, gen_positions
-    // yields the step positions, handed to the device as a growing array of draws.
-    std::mt19937 gen_nodes, gen_positions;
-    std::vector<int32_t> cand(n), draws;
-    for (int32_t i = 0; i < n; ++i) cand[i] = i;
-    ClaransJob job;
-    job.a = a;
-    job.gen_positions = &gen_positions;
-    job.draws = &draws;
-    job.d_draws = &L.d_draws;
-    float best_cost = std::numeric_limits<float>::max();
-    for (int iter = 0; iter < num_local; ++iter) {
-        // partial_shuffle(candidate + n_fixed, candidate + n, candidate + n, gen_nodes), deterministic_random.h:113-127
+    HIP_TRY(L.d_draws.reserve((size_t)n_seeds_all * 4 + 16)); // (the lane's spare buffer: the seeds of all jobs)
+    HIP_TRY(hipMemcpyAsync(L.d_draws.p, seed_ids, (size_t)n_seeds_all * 4, hipMemcpyHostToDevice, L.stream));
+    double ms = 0;
+    int launches = 0;
+    auto a256 = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    for (size_t p0 = 0; p0 < pieces.size();) {
+        // the launch: pieces [p0, p1) as far as their columns are contiguous and the rectangles fit
+        size_t p1 = p0;
+        int64_t bytes = 0;
+        while (p1 < pieces.size()) {
+            const Piece& pc = pieces[p1];
+            const int64_t ns = seed_offsets[pc.job + 1] - seed_offsets[pc.job];
+            const int64_t b = ns * (pc.c1 - pc.c0) * elem;
+            if (p1 > p0 && (bytes + b > cap || pieces[p1 - 1].c1 != pc.c0 || pc.c1 - pieces[p0].c0 > 0x7fffff00)) break;
+            bytes += b;
+            ++p1;
+        }
+        const int64_t C0 = pieces[p0].c0, C1 = pieces[p1 - 1].c1, nc = C1 - C0;
+        if (nc > 0x7fffff00) return fail(LCSGPU_E_INVALID, "a job's column range is too long for one launch");
+        const int32_t np = (int32_t)(p1 - p0);
+        // per instantiated kernel: its refs and jobs
+        struct Bucket {
+            int bv;
+            bool quirk;
+            std::vector<int32_t> ref_id, ref_col0, ref_piece;
+            std::vector<int64_t> ref_out0;
+            std::vector<int4> jobs;
+            int refs_per_wg = 0;
+        };
+        std::vector<Bucket> buckets;
+        int index_of[160];
+        std::fill(index_of, index_of + 160, -1);
+        std::vector<lcsgpu::AssignPiece> table((size_t)np);
+        int target[65];
         {
-            int32_t* first = cand.data() + n_fixed;
-            const long cnt = n - n_fixed, N = cnt - 1;
-            for (long i = 0; i < cnt; ++i) {
-                const unsigned long d = (unsigned long)N - (unsigned long)i + 1;
-                const unsigned long r = (unsigned long)gen_nodes(); // < 2^32: never in the rejected tail of a 64-bit range
-                std::swap(first[i], first[(r % d) + (unsigned long)i]);
+            double wgs[65] = {0};
+            for (size_t p = p0; p < p1; ++p) {
+                const Piece& pc = pieces[p];
+                for (int64_t s = seed_offsets[pc.job]; s < seed_offsets[pc.job + 1]; ++s) {
+                    if (ctx->quirk[seed_ids[s]]) continue;
+                    const int h = lcsgpu::h_class(ctx->lens[seed_ids[s]]);
+                    wgs[h] += (double)((pc.c1 - pc.c0 + 255) / 256) / lcsgpu::refs_per_block_for(h, false, 1, 1);
+                }
             }
+            merge_small_classes(wgs, target);
         }
-        HIP_TRY(hipMemcpyAsync(a.cand, cand.data(), (size_t)n * 4, hipMemcpyHostToDevice, L.stream));
-        {   // the first draws (the init kernel checks that a window's worth is there)
-            int rc = clarans_extend_draws(job, (size_t)job.p_host + (size_t)std::max(corrected, 1), L.stream);
-            if (rc) return rc;
+        int64_t out_at = 0;
+        for (size_t p = p0; p < p1; ++p) {
+            const Piece& pc = pieces[p];
+            const int64_t s0 = seed_offsets[pc.job], ns = seed_offsets[pc.job + 1] - s0, w = pc.c1 - pc.c0;
+            table[p - p0] = lcsgpu::AssignPiece{out_at, (int32_t)(pc.c0 - C0), (int32_t)w, (int32_t)s0, (int32_t)ns};
+            for (int64_t r = 0; r < ns; ++r) {
+                const int32_t id = seed_ids[s0 + r];
+                const bool q = ctx->quirk[id] != 0;
+                const int bv = q ? lcsgpu::quirk_h_class(ctx->lens[id]) : target[lcsgpu::h_class(ctx->lens[id])];
+                const int key = bv * 2 + (q ? 1 : 0);
+                if (index_of[key] < 0) {
+                    index_of[key] = (int)buckets.size();
+                    buckets.push_back(Bucket{bv, q, {}, {}, {}, {}, {}, 0});
+                }
+                Bucket& b = buckets[index_of[key]];
+                b.ref_id.push_back(id);
+                b.ref_col0.push_back((int32_t)(pc.c0 - C0));
+                b.ref_piece.push_back((int32_t)(p - p0));
+                b.ref_out0.push_back(out_at + r * w);
+            }
+            out_at += ns * w;
         }
-        HIP_TRY(lcsgpu::launch_clarans_init(job.a, L.stream));
-        HIP_TRY(hipEventRecord(L.ev_done, L.stream));
-        HIP_TRY(hipEventSynchronize(L.ev_done)); // the search runs on the batch's stream
-        L.plan_in_flight = false;
-        lap(iter == 0 ? 1 : 2); // (the first wait of a call also covers the sample's triangle and distances)
-        int rc = clarans_run_search(ctx, job);
+        size_t plan = 0;
+        const size_t o_table = plan; plan += a256((size_t)np * sizeof(lcsgpu::AssignPiece));
+        std::vector<size_t> o_id(buckets.size()), o_c0(buckets.size()), o_out(buckets.size()), o_job(buckets.size());
+        for (size_t bi = 0; bi < buckets.size(); ++bi) {
+            Bucket& b = buckets[bi];
+            const size_t nr = b.ref_id.size();
+            const int R = b.refs_per_wg = lcsgpu::refs_per_block_for(b.bv, b.quirk, (long)nr, (long)std::max<int64_t>(1, nc / 256 / std::max(1, np)));
+            for (size_t k0 = 0; k0 < nr;) {
+                size_t k1 = k0 + 1;
+                while (k1 < nr && k1 - k0 < (size_t)R && b.ref_piece[k1] == b.ref_piece[k0]) ++k1;
+                const lcsgpu::AssignPiece& tp = table[(size_t)b.ref_piece[k0]];
+                for (int32_t c = tp.col0; c < tp.col0 + tp.n_cols; c += 256) b.jobs.push_back(make_int4((int)k0, (int)(k1 - k0), c, tp.col0 + tp.n_cols));
+                k0 = k1;
+            }
+            if (b.jobs.size() > 0x7fffffffu) return fail(LCSGPU_E_INVALID, "batch too large");
+            o_id[bi] = plan; plan += a256(nr * 4);
+            o_c0[bi] = plan; plan += a256(nr * 4);
+            o_out[bi] = plan; plan += a256(nr * 8);
+            o_job[bi] = plan; plan += a256(b.jobs.size() * sizeof(int4));
+        }
+        if (L.plan_in_flight) {
+            HIP_TRY(hipStreamSynchronize(L.stream));
+            L.plan_in_flight = false;
+        }
+        HIP_TRY(L.h_plan.reserve(plan));
+        HIP_TRY(L.d_plan.reserve(plan));
+        char* h = (char*)L.h_plan.p;
+        memcpy(h + o_table, table.data(), (size_t)np * sizeof(lcsgpu::AssignPiece));
+        for (size_t bi = 0; bi < buckets.size(); ++bi) {
+            const Bucket& b = buckets[bi];
+            memcpy(h + o_id[bi], b.ref_id.data(), b.ref_id.size() * 4);
+            memcpy(h + o_c0[bi], b.ref_col0.data(), b.ref_col0.size() * 4);
+            memcpy(h + o_out[bi], b.ref_out0.data(), b.ref_out0.size() * 8);
+            memcpy(h + o_job[bi], b.jobs.data(), b.jobs.size() * sizeof(int4));
+        }
+        HIP_TRY(hipMemcpyAsync(L.d_plan.p, h, plan, hipMemcpyHostToDevice, L.stream));
+        L.plan_in_flight = true;
+        // columns, distances, assignments of the launch
+        const size_t o_cols = 0, o_dist = o_cols + a256((size_t)nc * 4), o_assign = o_dist + a256((size_t)nc * 4), work = o_assign + a256((size_t)nc * 4);
+        HIP_TRY(L.d_work.reserve(work));
+        int rc = reserve_big(ctx, L.d_out, (size_t)out_at * elem, "assign_seeds_batch rectangles");
         if (rc) return rc;
-        lap(3);
-        float cost;
-        memcpy(&cost, &job.state[5], 4);
-        HIP_TRY(hipMemcpyAsync(L.h_small.p, a.cand, (size_t)n * 4, hipMemcpyDeviceToHost, L.stream)); // (a blocking hipMemcpy was 0.4 ms under load)
+        char* base = (char*)L.d_work.p;
+        HIP_TRY(hipMemcpyAsync(base + o_cols, col_ids + C0, (size_t)nc * 4, hipMemcpyHostToDevice, L.stream));
+        L.last_launches = 0;
+        HIP_TRY(hipEventRecord(L.ev_start, L.stream));
+        for (size_t bi = 0; bi < buckets.size(); ++bi) {
+            const Bucket& b = buckets[bi];
+            if (b.jobs.empty()) continue;
+            RowsArgs a{};
+            a.tiles = (const uint8_t*)ctx->d_tiles.p;
+            a.tile_base = (const uint64_t*)ctx->d_tile_base.p;
+            a.lens = (const uint32_t*)ctx->d_lens.p;
+            a.masks = (const uint64_t*)ctx->d_masks.p;
+            a.mask_base = (const uint64_t*)ctx->d_mask_base.p;
+            a.n_refs = (int32_t)b.ref_id.size();
+            char* d = (char*)L.d_plan.p;
+            a.ref_ids = (const int32_t*)(d + o_id[bi]);
+            a.ref_rows = nullptr;
+            a.ref_col0 = (const int32_t*)(d + o_c0[bi]);
+            a.ref_out0 = (const int64_t*)(d + o_out[bi]);
+            a.jobs = (const int4*)(d + o_job[bi]);
+            a.col_ids = (const int32_t*)(base + o_cols);
+            a.n_cols = (int32_t)nc;
+            a.out = L.d_out.p;
+            a.elem_size = elem;
+            a.mode = lcsgpu::MODE_RECT;
+            a.refs_per_block = b.refs_per_wg;
+            HIP_TRY(lcsgpu::launch_rows(b.bv, b.quirk, a, (int)b.jobs.size(), 1, L.stream));
+            ++L.last_launches;
+        }
+        HIP_TRY(hipEventRecord(L.ev_stop, L.stream));
+        L.timing_valid = true;
+        HIP_TRY(lcsgpu::launch_assign_seeds_batch(L.d_out.p, elem, (const lcsgpu::AssignPiece*)((char*)L.d_plan.p + o_table), np,
+                                                  (const int32_t*)L.d_draws.p, (const int32_t*)(base + o_cols), nc, (const uint32_t*)ctx->d_lens.p,
+                                                  (const float*)ctx->d_powf.p, distance_kind, (float*)(base + o_dist), (int32_t*)(base + o_assign), L.stream));
+        HIP_TRY(hipMemcpyAsync(dist + C0, base + o_dist, (size_t)nc * 4, hipMemcpyDeviceToHost, L.stream));
+        HIP_TRY(hipMemcpyAsync(assign + C0, base + o_assign, (size_t)nc * 4, hipMemcpyDeviceToHost, L.stream));
         HIP_TRY(hipEventRecord(L.ev_done, L.stream));
         HIP_TRY(hipEventSynchronize(L.ev_done));
-        memcpy(cand.data(), L.h_small.p, (size_t)n * 4);
-        lap(4);
-        if (cost < best_cost) {
-            best_cost = cost;
-            std::copy(cand.begin(), cand.begin() + k, medoids_out);
-        }
+        finish_host_call(ctx, L);
+        ms += g_last.ms;
+        launches += g_last.launches;
+        p0 = p1;
     }
-    finish_host_call(ctx, L);
-    swap.settled = true;
-    ctx->clarans_calls += 1;
+    g_last.ms = ms;
+    g_last.launches = launches;
     return LCSGPU_OK;
+}
+
+// CLARANS for many samples in one go: all sample triangles in one batched LCS launch, all float matrices in one launch,
+// then ONE workgroup per sample runs that sample's whole chain of local searches (clarans_chain_kernel); the host only
+// pre-draws the step positions and composes the shuffles (neither generator looks at a search, Clustering.cpp:43-46) --
+// both depend on the shape (members, medoids) alone, so samples of one shape share them.
+int lcsgpu_clarans_batch(lcsgpu_ctx* ctx, const int32_t* ids, const int64_t* offsets, int32_t n_jobs, int distance_kind,
+                         const int32_t* n_medoids, int32_t n_fixed, float explore_fraction, int32_t num_local, int32_t* medoids_out)
+{
+    if (!ctx) return fail(LCSGPU_E_INVALID, "NULL ctx");
+    if (ctx->n < 0) return fail(LCSGPU_E_STATE, "no sequence set uploaded");
+    if (distance_kind != LCSGPU_DIST_INDEL_DIV_LCS && distance_kind != LCSGPU_DIST_INDEL075_DIV_LCS)
+        return fail(LCSGPU_E_INVALID, "unknown distance kind %d", distance_kind);
+    if (n_jobs < 0 || num_local < 1 || n_fixed < 0) return fail(LCSGPU_E_INVALID, "bad CLARANS batch");
+    if (n_jobs == 0) return LCSGPU_OK;
+    if (!ids || !offsets || !n_medoids || !medoids_out) return fail(LCSGPU_E_INVALID, "NULL argument");
+    if (offsets[0] != 0) return fail(LCSGPU_E_INVALID, "offsets[0] must be 0");
+    std::vector<int64_t> med_off((size_t)n_jobs + 1, 0);
+    for (int32_t j = 0; j < n_jobs; ++j) {
+        const int64_t n = offsets[j + 1] - offsets[j];
+        const int32_t k = n_medoids[j];
+        if (n < 1 || n > 0x7fffffff) return fail(LCSGPU_E_INVALID, "bad sample %d", j);
+        if (k < 1 || k > n || n_fixed >= k)
+            return fail(LCSGPU_E_INVALID, "bad CLARANS shape: %d medoids (%d fixed) of %lld, %d searches", k, n_fixed, (long long)n, num_local);
+        if (k > lcsgpu::CLARANS_MAX_MEDOIDS || n - k > lcsgpu::CLARANS_MAX_NONMEDOIDS)
+            return fail(LCSGPU_E_UNSUPPORTED, "device CLARANS handles at most %d medoids and %d other sample members (asked: %d, %lld)",
+                        lcsgpu::CLARANS_MAX_MEDOIDS, lcsgpu::CLARANS_MAX_NONMEDOIDS, k, (long long)(n - k));
+        med_off[j + 1] = med_off[j] + k;
+    }
+    for (int64_t i = 0; i < offsets[n_jobs]; ++i)
+        if (ids[i] < 0 || ids[i] >= ctx->n) return fail(LCSGPU_E_INVALID, "sample id %d out of range", ids[i]);
+
+    // what depends on a sample's shape alone: the composed shuffles and the step positions
+    struct Shape {
+        int32_t n, k;
+        std::vector<int32_t> perm; // [num_local][n]
+        std::mt19937 gen_positions;
+        std::vector<int32_t> draws;
+        DevBuf d_perm, d_draws;
+        int corrected = 0;
+    };
+    std::vector<std::unique_ptr<Shape>> shapes;
+    struct Release {
+        std::vector<std::unique_ptr<Shape>>& v;
+        ~Release() { for (auto& s : v) { s->d_perm.release(); s->d_draws.release(); } }
+    } release{shapes};
+    std::vector<int> shape_of((size_t)n_jobs, -1);
+    std::vector<int32_t> live; // the samples that need a search
+    for (int32_t j = 0; j < n_jobs; ++j) {
+        const int32_t n = (int32_t)(offsets[j + 1] - offsets[j]), k = n_medoids[j];
+        int si = -1;
+        for (size_t t = 0; t < shapes.size(); ++t)
+            if (shapes[t]->n == n && shapes[t]->k == k) si = (int)t;
+        if (si < 0) {
+            shapes.emplace_back(new Shape);
+            Shape& sh = *shapes.back();
+            sh.n = n;
+            sh.k = k;
+            // Clustering.cpp:21-29: how many non-improving steps end a local search
+            const int n_swaps = (n - k) * k, min_max_neighbor = 250;
+            const int max_neighbor = n_swaps < min_max_neighbor ? n_swaps : std::max((int)(explore_fraction * n_swaps), min_max_neighbor);
+            sh.corrected = max_neighbor / k;
+            // partial_shuffle(candidate + n_fixed, candidate + n, candidate + n, gen_nodes) before every local search
+            // (deterministic_random.h:113-127), applied to positions: where[i] = the position whose content ends up at i
+            std::mt19937 gen_nodes;
+            sh.perm.resize((size_t)num_local * n);
+            std::vector<int32_t> where((size_t)n);
+            for (int it = 0; it < num_local; ++it) {
+                for (int32_t i = 0; i < n; ++i) where[(size_t)i] = i;
+                int32_t* first = where.data() + n_fixed;
+                const long cnt = n - n_fixed, N = cnt - 1;
+                for (long i = 0; i < cnt; ++i) {
+                    const unsigned long d = (unsigned long)N - (unsigned long)i + 1;
+                    const unsigned long r = (unsigned long)gen_nodes(); // < 2^32: never in the rejected tail of a 64-bit range
+                    std::swap(first[i], first[(r % d) + (unsigned long)i]);
+                }
+                std::copy(where.begin(), where.end(), sh.perm.begin() + (size_t)it * n);
+            }
+            si = (int)shapes.size() - 1;
+        }
+        shape_of[(size_t)j] = si;
+        if (n == k) {
+            // every member is a medoid: no step is ever drawn, every search costs 0, the first one stands
+            // (Clustering.cpp:239-257: a later search has to be cheaper) -- its medoids are the order after the first shuffle
+            std::copy(shapes[(size_t)si]->perm.begin(), shapes[(size_t)si]->perm.begin() + n, medoids_out + med_off[j]);
+        } else
+            live.push_back(j);
+    }
+    if (live.empty()) return LCSGPU_OK;
+
+    const auto t_call = std::chrono::steady_clock::now();
+    LaneGuard guard(ctx, LaneGuard::ANY);
+    Lane& L = guard.lane();
+    HIP_TRY(hipSetDevice(ctx->device));
+    const int elem = ctx->max_len > 65535 ? 4 : 2;
+    std::vector<int64_t> tri_base;
+    int64_t count = 0;
+    bool had_long = false;
+    int rc = batch_triangles_to_device(ctx, L, ids, offsets, n_jobs, elem, tri_base, &count, &had_long);
+    if (rc) return rc;
+    double lcs_ms = 0;
+    int lcs_launches = 0;
+    if (had_long) { // (synchronised list by list: the timing is in g_last)
+        lcs_ms = g_last.ms;
+        lcs_launches = g_last.launches;
+    }
+    // the samples' buffers, one allocation
+    auto a256 = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const int n_live = (int)live.size();
+    const int64_t n_total = offsets[n_jobs];
+    size_t at = 0;
+    const size_t o_chains = at; at += a256((size_t)n_live * sizeof(lcsgpu::ClaransChain));
+    const size_t o_states = at; at += a256((size_t)n_live * lcsgpu::CLARANS_STATE_WORDS * 4);
+    const size_t o_ids = at; at += a256((size_t)n_total * 4);
+    const size_t o_best = at; at += a256((size_t)med_off[n_jobs] * 4);
+    struct Place { size_t D, DM, cand, st, log; };
+    std::vector<Place> place((size_t)n_live);
+    int max_n = 0, max_k = 0;
+    for (int q = 0; q < n_live; ++q) {
+        const int32_t j = live[(size_t)q];
+        const size_t n = (size_t)(offsets[j + 1] - offsets[j]), k = (size_t)n_medoids[j];
+        Place& p = place[(size_t)q];
+        p.D = at; at += a256(n * n * 4);
+        p.DM = at; at += a256(n * k * 4);
+        p.cand = at; at += a256(n * 4);
+        p.st = at; at += a256(n * 16);
+        p.log = at; at += a256((n + 1) * 4);
+        max_n = std::max(max_n, (int)n);
+        max_k = std::max(max_k, (int)k);
+    }
+    rc = reserve_big(ctx, L.d_work, at, "CLARANS batch");
+    if (rc) return rc;
+    char* base = (char*)L.d_work.p;
+    const size_t host_bytes = a256((size_t)n_live * sizeof(lcsgpu::ClaransChain)) + a256((size_t)n_live * lcsgpu::CLARANS_STATE_WORDS * 4);
+    HIP_TRY(L.h_small.reserve(host_bytes));
+    lcsgpu::ClaransChain* h_chains = (lcsgpu::ClaransChain*)L.h_small.p;
+    int32_t* h_states = (int32_t*)((char*)L.h_small.p + a256((size_t)n_live * sizeof(lcsgpu::ClaransChain)));
+    static const int draws_first = std::max(16, tune_int("clarans_draws", 65536)), slice_us = std::max(0, tune_int("clarans_slice_us", 0));
+    for (auto& shp : shapes) {
+        Shape& sh = *shp;
+        if (sh.n == sh.k) continue;
+        HIP_TRY(sh.d_perm.reserve(sh.perm.size() * 4));
+        HIP_TRY(hipMemcpyAsync(sh.d_perm.p, sh.perm.data(), sh.perm.size() * 4, hipMemcpyHostToDevice, L.stream));
+    }
+    // det_uniform_int_distribution<int>(k, n - 1) over gen_positions (deterministic_random.h:62-76), `want` of them
+    auto extend_draws = [&](Shape& sh, size_t want) -> int {
+        if (sh.draws.size() >= want) return LCSGPU_OK;
+        const uint32_t k = (uint32_t)sh.k, diff = (uint32_t)(sh.n - sh.k);
+        const uint32_t bad = 0xffffffffu / diff;
+        sh.draws.reserve(want);
+        while (sh.draws.size() < want) {
+            const uint32_t r = sh.gen_positions();
+            if (r / diff < bad) sh.draws.push_back((int32_t)(r % diff + k));
+        }
+        HIP_TRY(sh.d_draws.reserve(want * 4)); // (only between launches: nothing reads the old array)
+        HIP_TRY(hipMemcpyAsync(sh.d_draws.p, sh.draws.data(), sh.draws.size() * 4, hipMemcpyHostToDevice, L.stream));
+        return LCSGPU_OK;
+    };
+    for (auto& shp : shapes)
+        if (shp->n != shp->k) {
+            rc = extend_draws(*shp, (size_t)draws_first);
+            if (rc) return rc;
+        }
+    HIP_TRY(hipMemcpyAsync(base + o_ids, ids, (size_t)n_total * 4, hipMemcpyHostToDevice, L.stream));
+    memset(h_states, 0, (size_t)n_live * lcsgpu::CLARANS_STATE_WORDS * 4);
+    const float flt_max = std::numeric_limits<float>::max();
+    for (int q = 0; q < n_live; ++q) {
+        const int32_t j = live[(size_t)q];
+        const Shape& sh = *shapes[(size_t)shape_of[(size_t)j]];
+        lcsgpu::ClaransChain& c = h_chains[q];
+        memset(&c, 0, sizeof c);
+        const Place& p = place[(size_t)q];
+        c.a.D = (const float*)(base + p.D);
+        c.a.DMt = (float*)(base + p.DM);
+        c.a.cand = (int32_t*)(base + p.cand);
+        c.a.st = (float4*)(base + p.st);
+        c.a.cost_log = (float*)(base + p.log);
+        c.a.state = (int32_t*)(base + o_states) + (size_t)q * lcsgpu::CLARANS_STATE_WORDS;
+        c.a.n_elems = sh.n;
+        c.a.n_medoids = sh.k;
+        c.a.n_fixed = n_fixed;
+        c.a.corrected = sh.corrected;
+        c.a.draws = (const int32_t*)sh.d_draws.p;
+        c.a.draws_len = (int32_t)sh.draws.size();
+        c.perm = (const int32_t*)sh.d_perm.p;
+        c.ids = (const int32_t*)(base + o_ids) + offsets[j];
+        c.best = (int32_t*)(base + o_best) + med_off[j];
+        c.tri0 = tri_base[(size_t)j];
+        c.num_local = num_local;
+        int32_t* st = h_states + (size_t)q * lcsgpu::CLARANS_STATE_WORDS;
+        st[4] = 1;  // ST_FRESH
+        st[10] = 1; // ST_FIRST
+        memcpy(&st[17], &flt_max, 4); // ST_BEST
+        st[18] = 1; // ST_NEED_INIT
+    }
+    HIP_TRY(hipMemcpyAsync(base + o_states, h_states, (size_t)n_live * lcsgpu::CLARANS_STATE_WORDS * 4, hipMemcpyHostToDevice, L.stream));
+    HIP_TRY(hipMemcpyAsync(base + o_chains, h_chains, (size_t)n_live * sizeof(lcsgpu::ClaransChain), hipMemcpyHostToDevice, L.stream));
+    HIP_TRY(lcsgpu::launch_subset_distances_batch(L.d_out.p, elem, (const lcsgpu::ClaransChain*)(base + o_chains), n_live, max_n,
+                                                  (const uint32_t*)ctx->d_lens.p, (const float*)ctx->d_powf.p, distance_kind, L.stream));
+    // the chains: normally one launch; a chain that runs out of positions (or, under LCSGPU_TUNE clarans_slice_us, of time)
+    // comes back for another
+    std::vector<int> todo((size_t)n_live);
+    for (int q = 0; q < n_live; ++q) todo[(size_t)q] = q;
+    std::vector<lcsgpu::ClaransChain> all(h_chains, h_chains + n_live);
+    int launches = 0;
+    long accepts = 0, steps = 0;
+    while (!todo.empty()) {
+        const int nt = (int)todo.size();
+        for (int t = 0; t < nt; ++t) {
+            lcsgpu::ClaransChain& c = h_chains[t];
+            c = all[(size_t)todo[(size_t)t]];
+            const Shape& sh = *shapes[(size_t)shape_of[(size_t)live[(size_t)todo[(size_t)t]]]];
+            c.a.draws = (const int32_t*)sh.d_draws.p;
+            c.a.draws_len = (int32_t)sh.draws.size();
+        }
+        HIP_TRY(hipMemcpyAsync(base + o_chains, h_chains, (size_t)nt * sizeof(lcsgpu::ClaransChain), hipMemcpyHostToDevice, L.stream));
+        HIP_TRY(lcsgpu::launch_clarans_chains((const lcsgpu::ClaransChain*)(base + o_chains), nt, max_k, slice_us, L.stream));
+        HIP_TRY(hipMemcpyAsync(h_states, base + o_states, (size_t)n_live * lcsgpu::CLARANS_STATE_WORDS * 4, hipMemcpyDeviceToHost, L.stream));
+        HIP_TRY(hipEventRecord(L.ev_done, L.stream));
+        HIP_TRY(hipEventSynchronize(L.ev_done));
+        L.plan_in_flight = false;
+        ++launches;
+        std::vector<int> again;
+        for (int q : todo) {
+            const int32_t* st = h_states + (size_t)q * lcsgpu::CLARANS_STATE_WORDS;
+            if (st[1]) { // ST_DONE: the whole chain
+                accepts += st[3];
+                steps += st[12];
+                continue;
+            }
+            again.push_back(q);
+            if (st[7]) { // ST_MORE_DRAWS
+                Shape& sh = *shapes[(size_t)shape_of[(size_t)live[(size_t)q]]];
+                rc = extend_draws(sh, std::max(sh.draws.size() * 2, (size_t)st[0] + (size_t)st[8] + (size_t)draws_first));
+                if (rc) return rc;
+            }
+        }
+        todo.swap(again);
+        if (launches > 100000) return fail(LCSGPU_E_STATE, "CLARANS batch does not finish");
+    }
+    // the results: live samples' medoids (the others were written above)
+    std::vector<int32_t> best((size_t)med_off[n_jobs]);
+    HIP_TRY(hipMemcpyAsync(best.data(), base + o_best, best.size() * 4, hipMemcpyDeviceToHost, L.stream));
+    HIP_TRY(hipStreamSynchronize(L.stream));
+    for (int32_t j : live) std::copy(best.begin() + med_off[j], best.begin() + med_off[j + 1], medoids_out + med_off[j]);
+    if (!had_long) finish_host_call(ctx, L);
+    else note_host_call(ctx, lcs_ms, lcs_launches);
+    if (getenv("LCSGPU_PROFILE"))
+        fprintf(stderr, "clarans.batch: %d samples (%d searched, %zu shapes), %d launch(es), %ld accepts, %ld steps looked at, %.3f s\n", n_jobs, n_live,
+                shapes.size(), launches, accepts, steps, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_call).count());
+    return LCSGPU_OK;
+}
+
+int lcsgpu_clarans(lcsgpu_ctx* ctx, const int32_t* ids, int32_t n_ids, int distance_kind, int32_t n_medoids,
+                   int32_t n_fixed, float explore_fraction, int32_t num_local, int32_t* medoids_out)
+{
+    if (!ids || !medoids_out || n_ids < 1) return fail(LCSGPU_E_INVALID, "bad sample / output");
+    const int64_t offsets[2] = {0, n_ids};
+    return lcsgpu_clarans_batch(ctx, ids, offsets, 1, distance_kind, &n_medoids, n_fixed, explore_fraction, num_local, medoids_out);
 }
 
 } // extern "C"

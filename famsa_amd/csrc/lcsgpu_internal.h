@@ -27,10 +27,10 @@ namespace lcsgpu_impl {
 
 // thread-local error text of lcsgpu_last_error(); returns `code`
 int fail(int code, const char* fmt, ...);
-// numeric tuning knobs, LCSGPU_TUNE="key=value,key=value" (no alternate code paths behind them): clarans_slice_us (how long a
-// launch advances the searches of a batch, 1000), clarans_draws (pre-drawn step positions in front of a search at a launch,
-// 8192), clarans_groups (independent batches of searches, 4), clarans_prep_streams (high-priority streams for what
-// precedes a search, 2; 0 = the lane's own stream), upgma_spare (spare slots of the UPGMA matrix, n / 10)
+// numeric tuning knobs, LCSGPU_TUNE="key=value,key=value" (no alternate code paths behind them): clarans_slice_us (a launch of
+// search chains ends after that long and the chains continue in the next: 0 = none, a test aid), clarans_draws (step positions
+// drawn for a sample shape before its first launch, 65536), assign_batch_kb (LCS rectangles of one launch of the batched seed
+// assignment, 2 GB), upgma_spare (spare slots of the UPGMA matrix, n / 10)
 int tune_int(const char* key, int dflt);
 
 #define HIP_TRY(expr)                                                                           \
@@ -111,7 +111,7 @@ struct Lane {
     hipEvent_t ev_done = nullptr; // blocking-sync event: host-memory calls sleep on it instead of spinning
     hipStream_t copy_stream = nullptr; // large host-buffer results leave in slices while the next slice is computed
     lcsgpu_impl::DevBuf d_plan, d_out, d_carry;
-    lcsgpu_impl::DevBuf d_work, d_draws; // CLARANS state and its pre-drawn step positions
+    lcsgpu_impl::DevBuf d_work, d_draws; // work areas of the batched calls (CLARANS state; seeds of an assignment)
     lcsgpu_impl::PinBuf h_plan, h_small;
     bool plan_in_flight = false;
     int last_launches = 0;
@@ -123,36 +123,6 @@ struct Lane {
     bool unusable = false; // creation failed: never offered again
 };
 
-
-// Local searches of several host threads advanced together (lcs_kernels.h, ClaransBatch): every
-// search joins with its device state ready; whichever owner finds no driver becomes the driver and
-// launches ALL joined searches for a time slice at a time ("look"), reading their done flags in between;
-// a driver whose own search has finished hands the role to one of the remaining owners.
-struct ClaransJob {
-    lcsgpu::ClaransArgs a;
-    std::mt19937* gen_positions = nullptr; // the owner's position generator (Clustering.cpp:44)
-    std::vector<int32_t>* draws = nullptr; // its output so far, as accepted draws
-    lcsgpu_impl::DevBuf* d_draws = nullptr;
-    int32_t p_host = 0;
-    int32_t state[16] = {0};
-    bool done = false;
-    int rc = LCSGPU_OK;
-    std::string error;
-};
-struct ClaransBatcher {
-    std::mutex mu;
-    std::condition_variable cv;
-    std::vector<ClaransJob*> joined;
-    bool driver_present = false;
-    hipStream_t stream = nullptr;
-    hipEvent_t ev = nullptr;
-    lcsgpu_impl::PinBuf h_states;
-    // LCSGPU_PROFILE: looks and seconds by number of searches in the batch
-    long prof_looks[lcsgpu::CLARANS_MAX_BATCH + 1] = {0};
-    double prof_seconds[lcsgpu::CLARANS_MAX_BATCH + 1] = {0};
-    long prof_rounds = 0, prof_steps = 0, prof_useful = 0, prof_accepts = 0, prof_searches = 0; // over finished searches
-    long prof_no_b = 0, prof_no_p = 0; // steps that ended without a walk: no member closer to the candidate than to its medoid / no slot able to go negative
-};
 
 struct TextExport; // lcsgpu_text.hip: the state of lcsgpu_dist_text_begin .. _end
 
@@ -192,24 +162,6 @@ struct lcsgpu_ctx {
         bool fused_ready = false;
     } mst;
     double total_kernel_ms = 0; // completed host-memory calls
-    // searches are spread over a few independent batches (each its own stream and driver): a search joins at the next
-    // look of its batch, so several batches out of step shorten the wait
-    std::vector<ClaransBatcher> clarans_groups;
-    std::atomic<unsigned> clarans_next{0};
-    // LCSGPU_PROFILE: where the time of the lcsgpu_clarans calls goes (microseconds, summed over the calling threads): the
-    // lane and its buffers, the sample's LCS triangle + distances, a search's start (order, draws, init kernel), the searches
-    // (join to done), reading the result
-    // one allocation for the CLARANS buffers of the lanes a multi-threaded caller announces (lcsgpu_reserve_lanes): 33 lanes
-    // each allocating 16 + 4 MB on first use, under load, was 3.3 ms per search call at 3 x 10^6 sequences
-    lcsgpu_impl::DevBuf d_lane_arena;
-    // Two high-priority streams for what a host thread of the FastTree recursion waits for before its search can join a
-    // batch -- the sample's triangle, its distances, the search's first state: ~0.6 ms of kernels that spent 5-8 ms behind
-    // the bulk launches (leaf matrices, seed assignment) on the lanes' own streams and shared hardware queues.  (A
-    // high-priority stream per lane: 33 more hardware queues, tree stage 1.08 -> 2.6-3.4 s.)
-    hipStream_t prep_streams[2] = {nullptr, nullptr};
-    std::atomic<unsigned> prep_next{0};
-    std::atomic<long> clarans_us[5] = {};
-    std::atomic<long> clarans_calls{0};
 };
 
 namespace lcsgpu_impl {
@@ -225,8 +177,6 @@ extern thread_local LastCall g_last;
 
 // streams / events of one lane (lcsgpu_api.hip); false on failure
 bool create_lane(lcsgpu_ctx* ctx, Lane& l);
-// stream / event / pinned state block of a CLARANS batch, on first use
-int ensure_batcher(lcsgpu_ctx* ctx, ClaransBatcher& B);
 
 // RAII ownership of one lane (index 0 on request, else any free one) or of all lanes.
 class LaneGuard {

@@ -14,6 +14,7 @@
 #include <stdint.h>
 
 #include "lcs_kernels.h"
+#include "fasttree_kernels.h"
 
 namespace lcsgpu {
 
@@ -816,6 +817,56 @@ __global__ __launch_bounds__(256) void assign_seeds_kernel(const T* __restrict__
     }
     dist[j] = best;
     assign[j] = who;
+}
+
+// The same for SEVERAL evaluations in one launch (lcsgpu_assign_seeds_batch), each from scratch: piece p = columns
+// [col0, col0 + n_cols) of the launch's concatenated column list against the seeds [seed0, seed0 + n_seeds) of the
+// concatenated seed list, its LCS rectangle (n_seeds x n_cols) at element out0.
+template <typename T>
+__global__ __launch_bounds__(256) void assign_seeds_batch_kernel(const T* __restrict__ lcs, const AssignPiece* __restrict__ pieces, int32_t n_pieces,
+                                                                 const int32_t* __restrict__ seed_ids, const int32_t* __restrict__ col_ids,
+                                                                 int64_t n_cols, const uint32_t* __restrict__ lens,
+                                                                 const float* __restrict__ pow_f32, int kind,
+                                                                 float* __restrict__ dist, int32_t* __restrict__ assign)
+{
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= n_cols) return;
+    int lo = 0, hi = n_pieces - 1; // the last piece that starts at or before c
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (pieces[mid].col0 <= c) lo = mid; else hi = mid - 1;
+    }
+    const AssignPiece p = pieces[lo];
+    const uint32_t len_j = lens[col_ids[c]];
+    const T* col = lcs + p.out0 + (c - p.col0);
+    float best = __int_as_float(0x7f800000); // +inf: the first seed always takes the column (its distance is finite)
+    int32_t who = 0;
+    for (int r = 0; r < p.n_seeds; ++r) {
+        const uint32_t l = col[(int64_t)r * p.n_cols];
+        const uint32_t indel = lens[seed_ids[p.seed0 + r]] + len_j - 2u * l;
+        float d;
+        if (l == 0) d = 3.40282347e38f;
+        else if (kind == 1) d = __fdiv_rn(pow_f32[indel], (float)l);
+        else d = __fdiv_rn((float)indel, (float)l);
+        if (d < best) { best = d; who = r; }
+    }
+    dist[c] = best;
+    assign[c] = who;
+}
+
+hipError_t launch_assign_seeds_batch(const void* lcs, int elem_size, const AssignPiece* pieces, int32_t n_pieces, const int32_t* seed_ids,
+                                     const int32_t* col_ids, int64_t n_cols, const uint32_t* lens, const float* pow_f32, int kind,
+                                     float* dist, int32_t* assign, hipStream_t stream)
+{
+    if (n_cols <= 0 || n_pieces <= 0) return hipSuccess;
+    const dim3 grid((unsigned)((n_cols + 255) / 256));
+    if (elem_size == 2)
+        hipLaunchKernelGGL(assign_seeds_batch_kernel<uint16_t>, grid, dim3(256), 0, stream, (const uint16_t*)lcs, pieces, n_pieces,
+                           seed_ids, col_ids, n_cols, lens, pow_f32, kind, dist, assign);
+    else
+        hipLaunchKernelGGL(assign_seeds_batch_kernel<uint32_t>, grid, dim3(256), 0, stream, (const uint32_t*)lcs, pieces, n_pieces,
+                           seed_ids, col_ids, n_cols, lens, pow_f32, kind, dist, assign);
+    return hipGetLastError();
 }
 
 hipError_t launch_assign_seeds(const void* lcs, int elem_size, int64_t ld, const int32_t* seed_ids, int32_t n_seeds,

@@ -3,6 +3,7 @@
 #include <mutex>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -389,6 +390,93 @@ bool GpuLcsSource::clarans(const int* ids, int n_ids, int distance_kind, int n_m
     check(rc, "lcsgpu_clarans");
     note(st_clarans_, now_s() - t0, (double)n_ids * (n_ids - 1) / 2);
     add_kernel_ms(c);
+    return true;
+}
+
+void GpuLcsSource::over_contexts(int n_jobs, const std::vector<double>& weight, const std::function<void(int, int, int)>& fn)
+{
+    const int nd = (int)ctxs_.size();
+    if (nd == 1 || n_jobs < 2) {
+        fn(0, 0, n_jobs);
+        return;
+    }
+    double total = 0;
+    for (double w : weight) total += w;
+    std::vector<int> cut(1, 0);
+    double acc = 0;
+    for (int j = 0; j < n_jobs; ++j) {
+        acc += weight[(size_t)j];
+        while ((int)cut.size() < nd && acc >= total * (double)cut.size() / nd) cut.push_back(j + 1);
+    }
+    while ((int)cut.size() <= nd) cut.push_back(n_jobs);
+    std::vector<std::thread> th;
+    std::vector<std::string> err((size_t)nd);
+    for (int d = 0; d < nd; ++d) {
+        if (cut[(size_t)d + 1] <= cut[(size_t)d]) continue;
+        th.emplace_back([&, d] {
+            try {
+                fn(d, cut[(size_t)d], cut[(size_t)d + 1]);
+            } catch (const std::exception& e) {
+                err[(size_t)d] = e.what();
+            }
+        });
+    }
+    for (auto& t : th) t.join();
+    for (const auto& e : err)
+        if (!e.empty()) throw std::runtime_error(e);
+}
+
+bool GpuLcsSource::clarans_batch(const int* ids, const int64_t* offsets, int n_jobs, int distance_kind, const int* n_medoids, int n_fixed,
+                                 float explore_fraction, int num_local, int* medoids_out)
+{
+    if (host_test("clarans_host")) return false;
+    const double t0 = now_s();
+    std::vector<double> weight((size_t)n_jobs);
+    std::vector<int64_t> med_off((size_t)n_jobs + 1, 0);
+    double pairs = 0;
+    for (int j = 0; j < n_jobs; ++j) {
+        const double m = (double)(offsets[j + 1] - offsets[j]);
+        weight[(size_t)j] = m * m;
+        pairs += m * (m - 1) / 2;
+        med_off[(size_t)j + 1] = med_off[(size_t)j] + n_medoids[j];
+    }
+    std::atomic<bool> unsupported{false};
+    over_contexts(n_jobs, weight, [&](int d, int j0, int j1) {
+        std::vector<int64_t> off((size_t)(j1 - j0) + 1);
+        for (int j = j0; j <= j1; ++j) off[(size_t)(j - j0)] = offsets[j] - offsets[j0];
+        const int rc = lcsgpu_clarans_batch(ctxs_[(size_t)d], ids + offsets[j0], off.data(), j1 - j0, distance_kind, n_medoids + j0, n_fixed,
+                                            explore_fraction, num_local, medoids_out + med_off[(size_t)j0]);
+        if (rc == LCSGPU_E_UNSUPPORTED) {
+            unsupported = true;
+            return;
+        }
+        check(rc, "lcsgpu_clarans_batch");
+        add_kernel_ms(ctxs_[(size_t)d]);
+    });
+    if (unsupported) return false;
+    note(st_clarans_, now_s() - t0, pairs);
+    return true;
+}
+
+bool GpuLcsSource::assign_seeds_batch(const int* seeds, const int64_t* seed_off, const int* cols, const int64_t* col_off, int n_jobs,
+                                      int distance_kind, float* dist, int* assign)
+{
+    const double t0 = now_s();
+    std::vector<double> weight((size_t)n_jobs);
+    double pairs = 0;
+    for (int j = 0; j < n_jobs; ++j) pairs += weight[(size_t)j] = (double)(seed_off[j + 1] - seed_off[j]) * (double)(col_off[j + 1] - col_off[j]);
+    over_contexts(n_jobs, weight, [&](int d, int j0, int j1) {
+        std::vector<int64_t> so((size_t)(j1 - j0) + 1), co((size_t)(j1 - j0) + 1);
+        for (int j = j0; j <= j1; ++j) {
+            so[(size_t)(j - j0)] = seed_off[j] - seed_off[j0];
+            co[(size_t)(j - j0)] = col_off[j] - col_off[j0];
+        }
+        check(lcsgpu_assign_seeds_batch(ctxs_[(size_t)d], seeds + seed_off[j0], so.data(), cols + col_off[j0], co.data(), j1 - j0, distance_kind,
+                                        dist + col_off[j0], assign + col_off[j0]),
+              "lcsgpu_assign_seeds_batch");
+        add_kernel_ms(ctxs_[(size_t)d]);
+    });
+    note(st_assign_, now_s() - t0, pairs);
     return true;
 }
 

@@ -5,6 +5,7 @@
 #pragma once
 #include <atomic>
 #include <cstdint>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -135,6 +136,10 @@ public:
     bool triangles_batch(const int* ids, const int64_t* offsets, int n_groups, LcsBuf& out) override;
     bool assign_seeds(const int* seeds, int n_seeds, const int* cols, int n_cols, int distance_kind, int first_k, float* dist,
                       int* assign) override;
+    bool clarans_batch(const int* ids, const int64_t* offsets, int n_jobs, int distance_kind, const int* n_medoids, int n_fixed,
+                       float explore_fraction, int num_local, int* medoids_out) override;
+    bool assign_seeds_batch(const int* seeds, const int64_t* seed_off, const int* cols, const int64_t* col_off, int n_jobs,
+                            int distance_kind, float* dist, int* assign) override;
     int text_begin(const std::vector<std::string>& ids, int distance_kind, bool square, bool pid) override;
     void text_submit(int unit, int r0, int r1) override;
     void text_wait(int unit, const char*& text, uint64_t& bytes) override;
@@ -163,6 +168,8 @@ private:
     std::mutex mu_; // the tree builders may call from several threads
     // call statistics (printed at destruction when FAMSA_GPU_PROFILE is set)
     struct CallStat { long calls = 0; double seconds = 0; double pairs = 0; } st_rect_, st_tri_, st_triids_, st_clarans_, st_batch_, st_assign_;
+    // contiguous job ranges of about equal weight, one per context; fn(context index, first job, end job) on a thread each
+    void over_contexts(int n_jobs, const std::vector<double>& weight, const std::function<void(int, int, int)>& fn);
     void note(CallStat& s, double sec, double pairs);
 };
 

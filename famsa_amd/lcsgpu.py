@@ -73,6 +73,8 @@ def load_library():
         "lcsgpu_lcs_triangles_batch": (C.c_int, [vp, pi32, C.POINTER(C.c_int64), i32, vp, C.c_int]),
         "lcsgpu_assign_seeds": (C.c_int, [vp, pi32, i32, pi32, i32, C.c_int, i32, vp, vp]),
         "lcsgpu_clarans": (C.c_int, [vp, pi32, i32, C.c_int, i32, i32, C.c_float, i32, pi32]),
+        "lcsgpu_clarans_batch": (C.c_int, [vp, pi32, C.POINTER(C.c_int64), i32, C.c_int, pi32, i32, C.c_float, i32, pi32]),
+        "lcsgpu_assign_seeds_batch": (C.c_int, [vp, pi32, C.POINTER(C.c_int64), pi32, C.POINTER(C.c_int64), i32, C.c_int, vp, vp]),
         "lcsgpu_dist_text_begin": (C.c_int, [vp, C.c_char_p, vp, C.c_int, C.c_int, i32]),
         "lcsgpu_dist_text_submit": (C.c_int, [vp, i32, i32, i32]),
         "lcsgpu_dist_text_wait": (C.c_int, [vp, i32, C.POINTER(vp), C.POINTER(C.c_uint64)]),
@@ -322,6 +324,35 @@ class LcsGpu:
         self._check(self._lib.lcsgpu_clarans(self._ctx, ptr, len(arr), kind, n_medoids, n_fixed, explore_fraction,
                                              num_local, out.ctypes.data_as(C.POINTER(C.c_int32))))
         return out[:n_medoids]
+
+    def clarans_batch(self, samples, n_medoids, n_fixed=1, explore_fraction=0.1, num_local=2, kind=1):
+        """lcsgpu_clarans_batch: `samples` = list of id arrays, `n_medoids` = one count or a list; returns a list of arrays."""
+        ks = np.ascontiguousarray([n_medoids] * len(samples) if np.isscalar(n_medoids) else n_medoids, dtype=np.int32)
+        off = np.zeros(len(samples) + 1, dtype=np.int64)
+        off[1:] = np.cumsum([len(s) for s in samples])
+        ids = np.ascontiguousarray(np.concatenate([np.asarray(s, np.int32) for s in samples]) if samples else np.zeros(0, np.int32), dtype=np.int32)
+        out = np.zeros(max(int(ks.sum()), 1), dtype=np.int32)
+        p32 = C.POINTER(C.c_int32)
+        self._check(self._lib.lcsgpu_clarans_batch(self._ctx, ids.ctypes.data_as(p32), off.ctypes.data_as(C.POINTER(C.c_int64)), len(samples), kind,
+                                                   ks.ctypes.data_as(p32), n_fixed, explore_fraction, num_local, out.ctypes.data_as(p32)))
+        cuts = np.concatenate([[0], np.cumsum(ks)])
+        return [out[cuts[i]:cuts[i + 1]].copy() for i in range(len(samples))]
+
+    def assign_seeds_batch(self, seeds, cols, kind=1):
+        """lcsgpu_assign_seeds_batch: lists of seed id arrays and column id arrays (one pair per evaluation); returns
+        (dist, assign) lists."""
+        p32, p64 = C.POINTER(C.c_int32), C.POINTER(C.c_int64)
+        so = np.zeros(len(seeds) + 1, dtype=np.int64)
+        so[1:] = np.cumsum([len(s) for s in seeds])
+        co = np.zeros(len(cols) + 1, dtype=np.int64)
+        co[1:] = np.cumsum([len(c) for c in cols])
+        s_all = np.ascontiguousarray(np.concatenate([np.asarray(s, np.int32) for s in seeds]), dtype=np.int32)
+        c_all = np.ascontiguousarray(np.concatenate([np.asarray(c, np.int32) for c in cols]), dtype=np.int32)
+        dist = np.zeros(len(c_all), dtype=np.float32)
+        assign = np.zeros(len(c_all), dtype=np.int32)
+        self._check(self._lib.lcsgpu_assign_seeds_batch(self._ctx, s_all.ctypes.data_as(p32), so.ctypes.data_as(p64), c_all.ctypes.data_as(p32),
+                                                        co.ctypes.data_as(p64), len(seeds), kind, dist.ctypes.data, assign.ctypes.data))
+        return ([dist[co[i]:co[i + 1]] for i in range(len(cols))], [assign[co[i]:co[i + 1]] for i in range(len(cols))])
 
     def dist_text(self, names, blocks, kind=1, square=False, pid=False, n_slots=2):
         """-dist_export rows as text made on the device (lcsgpu_dist_text_*): `names` without '>', `blocks` =

@@ -364,7 +364,7 @@ int lcsgpu_assign_seeds(lcsgpu_ctx* ctx, const int32_t* seed_ids, int32_t n_seed
  * of the chosen medoids, slot order; slots < n_fixed are never swapped (the reference pins member 0).
  * Returns LCSGPU_E_UNSUPPORTED when the shape is outside what the device search handles
  * (n_medoids > 1024 or n_ids - n_medoids > 2048): the caller then runs its own host search.
- * Thread-safe; the searches of concurrent callers share launches (one workgroup per search).
+ * Thread-safe (each call runs its own launches; lcsgpu_clarans_batch is the form for many samples).
  * Replaces: the sample matrix + CLARANS::operator() in FastTree::clusterSeeds
  * (tree/FastTree.cpp:412-417, tree/Clustering.cpp:17-305). */
 int lcsgpu_clarans(lcsgpu_ctx* ctx, const int32_t* ids, int32_t n_ids, int distance_kind, int32_t n_medoids,
@@ -396,6 +396,27 @@ int lcsgpu_dist_text_begin(lcsgpu_ctx* ctx, const char* ids, const uint64_t* id_
 int lcsgpu_dist_text_submit(lcsgpu_ctx* ctx, int32_t slot, int32_t row_begin, int32_t row_end);
 int lcsgpu_dist_text_wait(lcsgpu_ctx* ctx, int32_t slot, const char** text, uint64_t* n_bytes);
 int lcsgpu_dist_text_end(lcsgpu_ctx* ctx);
+
+/* ---- The FastTree recursion level by level: all splits of a level in one call ------------------------------------
+ * lcsgpu_clarans_batch: lcsgpu_clarans for n_jobs samples at once -- sample g = ids[offsets[g] .. offsets[g+1]) with
+ *   n_medoids[g] medoids (slots < n_fixed pinned); medoids_out receives the samples' medoids one after the other.  One
+ *   batched LCS launch computes every sample's triangle, one launch their float matrices, and ONE workgroup per sample
+ *   runs that sample's whole chain of num_local local searches (shuffle, start, search, keep the cheaper one) without
+ *   the host in between; up to 512 chains are resident at once and nothing else competes for the CUs meanwhile.
+ *   LCSGPU_E_UNSUPPORTED (nothing computed) if any sample is outside the device search's shapes.
+ *   Replaces: FastTree::clusterSeeds' sample matrix + CLARANS::operator() (tree/FastTree.cpp:412-417,
+ *   tree/Clustering.cpp:17-305) for every sub-tree the reference's recursion visits at one depth (FastTree.cpp:56-266).
+ * lcsgpu_assign_seeds_batch: the seed sweep of FastTree::makeEvaluation (tree/FastTree.cpp:309-324) for n_jobs evaluations,
+ *   each FROM SCRATCH: job g has the seeds seed_ids[seed_offsets[g] ..) and the columns col_ids[col_offsets[g] ..); per
+ *   column (dist / assign, HOST, laid out like col_ids) the smallest Transform<float> distance to a seed of its job and
+ *   the 0-based number of the FIRST seed attaining it -- what the reference's sweep arrives at from its first seed's row
+ *   with strict '<'.  All rectangles of a call are one LCS launch per word-count class (as far as 2 GB of LCS values
+ *   hold them; LCSGPU_TUNE assign_batch_kb), then one assignment launch. */
+int lcsgpu_clarans_batch(lcsgpu_ctx* ctx, const int32_t* ids, const int64_t* offsets, int32_t n_jobs, int distance_kind,
+                         const int32_t* n_medoids, int32_t n_fixed, float explore_fraction, int32_t num_local,
+                         int32_t* medoids_out);
+int lcsgpu_assign_seeds_batch(lcsgpu_ctx* ctx, const int32_t* seed_ids, const int64_t* seed_offsets, const int32_t* col_ids,
+                              const int64_t* col_offsets, int32_t n_jobs, int distance_kind, float* dist, int32_t* assign);
 
 /* Block until everything queued on the context's stream has finished. */
 int lcsgpu_sync(lcsgpu_ctx* ctx);

@@ -137,10 +137,63 @@ def test_assign_seeds_matches_the_host_sweep(engine, oracle, kind):
     assert (got_d.view(np.uint32) == want_d.view(np.uint32)).all()
 
 
+def test_many_samples_in_one_call(engine, oracle, searcher):
+    """lcsgpu_clarans_batch: samples of several shapes (some shared, one with every member a medoid, a single member) in
+    one call = every sample searched alone; three of them also against the reference's own search."""
+    rng = np.random.default_rng(99)
+    seqs = _family(rng, 2600, 150, 0.25)
+    engine.upload_seqs(seqs)
+    shapes = [(2000, 100)] * 3 + [(600, 30)] * 2 + [(24, 24), (1, 1), (310, 7), (2050, 2), (1500, 600)]
+    samples = [np.sort(rng.permutation(len(seqs))[:m]).astype(np.int32) for m, _ in shapes]
+    ks = [k for _, k in shapes]
+    got = engine.clarans_batch(samples, ks, 1, 0.1, 2)
+    for i in (0, 3, 7):
+        want = searcher(_expected_triangle(oracle, seqs, samples[i], 1), len(samples[i]), ks[i], 1, 0.1, 2)
+        assert got[i].tolist() == want.tolist(), i
+    for i, (ids, k) in enumerate(zip(samples, ks)):
+        assert got[i].tolist() == engine.clarans(ids, k, 1, 0.1, 2).tolist(), i
+    # a sample outside the device search's shapes: the whole call is refused, nothing is approximated
+    import famsa_amd
+    with pytest.raises(famsa_amd.LcsGpuError) as e:
+        engine.clarans_batch(samples + [np.arange(2500, dtype=np.int32)], ks + [3], 1, 0.1, 1)
+    assert "at most" in str(e.value)
+
+
+@pytest.mark.parametrize("kind", [0, 1])
+def test_assign_seeds_batch_matches_the_host_sweep(engine, oracle, kind):
+    """lcsgpu_assign_seeds_batch: several evaluations from scratch in one call against the sweep restated with the oracle's
+    LCS and float transform (first seed's row, then strict '<' in seed order); ties on short sequences; an evaluation
+    without columns; seeds of many lengths (several word-count classes in one call)."""
+    rng = np.random.default_rng(177 + kind)
+    seqs = _family(rng, 500, 120, 0.3) + _short(rng, 300, 4, 9, 3) + _family(rng, 60, 400, 0.2)
+    engine.upload_seqs(seqs)
+    codes, offsets = seqio.pack(seqs)
+    n = len(seqs)
+    lens = [len(s) for s in seqs]
+    fn = oracle.lib.oracle_dist_indel075_f32 if kind == 1 else oracle.lib.oracle_dist_indel_f32
+    seeds, cols = [], []
+    for m, k in [(700, 13), (1, 1), (0, 4), (300, 40), (860, 5), (90, 90)]:
+        cols.append(rng.permutation(n)[:m].astype(np.int32))
+        seeds.append(rng.permutation(n)[:k].astype(np.int32))
+    got_d, got_a = engine.assign_seeds_batch(seeds, cols, kind=kind)
+    for g, (sd, cl) in enumerate(zip(seeds, cols)):
+        if len(cl) == 0:
+            continue
+        lcs = oracle.rect(codes, offsets, sd, cl)
+        want_d = np.full(len(cl), np.inf, np.float32)
+        want_a = np.zeros(len(cl), np.int32)
+        for r, sid in enumerate(sd):
+            d = np.array([fn(int(lcs[r, j]), lens[sid], lens[c]) for j, c in enumerate(cl)], np.float32)
+            better = d < want_d
+            want_d[better] = d[better]
+            want_a[better] = r
+        assert (got_a[g] == want_a).all(), g
+        assert (got_d[g].view(np.uint32) == want_d.view(np.uint32)).all(), g
+
+
 def test_concurrent_searches_share_the_batch(engine):
-    """Searches of several host threads are advanced together by whichever thread drives the batch:
-    every thread must get exactly what it gets when it searches alone (different shapes, so searches
-    join and leave the batch at different times and the driver role changes hands)."""
+    """Searches of several host threads at once: every thread must get exactly what it gets when it searches alone
+    (different shapes; each call runs its own launches on its own lane)."""
     import threading
     rng = np.random.default_rng(2024)
     seqs = _family(rng, 2500, 160, 0.25)
@@ -170,11 +223,12 @@ def test_concurrent_searches_share_the_batch(engine):
         assert together == alone
 
 
-@pytest.mark.parametrize("tune", ["clarans_draws=40,clarans_slice_us=20,clarans_groups=1", "clarans_slice_us=1000000,clarans_prep_streams=0"])
+@pytest.mark.parametrize("tune", ["clarans_draws=40,clarans_slice_us=20,assign_batch_kb=16", "clarans_slice_us=1000000"])
 def test_where_a_launch_ends_does_not_change_the_search(tune):
-    """LCSGPU_TUNE (read once per process, hence the subprocess): a search is stopped and started again where it stood --
-    every 40 pre-drawn positions or 20 microseconds, all searches in one batch; or never (a slice longer than any search,
-    and what precedes a search on the lane's own stream).  Where a launch ends never changes which step is accepted."""
+    """LCSGPU_TUNE (read once per process, hence the subprocess): a chain of searches is stopped and started again where it
+    stood -- after 40 pre-drawn positions (then twice as many, ...) or 20 microseconds; or with a slice longer than any
+    search.  Where a launch ends never changes which step is accepted.  (assign_batch_kb=16: the batched seed assignment
+    cut into many launches, jobs split between them.)"""
     import os
     import subprocess
     import sys
@@ -184,5 +238,5 @@ def test_where_a_launch_ends_does_not_change_the_search(tune):
     env["LCSGPU_TUNE"] = tune
     p = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-x", "-k",
                         "concurrent or family-small or family-indel or two-registers or no-fixed or three-fixed or whole-neighbourhood or ties-everywhere "
-                        "or duplicates-tie or tiny or one-medoid"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+                        "or duplicates-tie or tiny or one-medoid or batch"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert p.returncode == 0 and " passed" in p.stdout, p.stdout[-3000:]
