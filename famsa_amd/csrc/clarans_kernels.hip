@@ -76,7 +76,8 @@ enum { ST_P = 0 /* next draw */, ST_DONE = 1, ST_ROUNDS = 3 /* accepts */, ST_FR
        // ended without a walk because no member was closer to the candidate than to its medoid / because no slot could go negative
        ST_N_ROUNDS = 11, ST_N_STEPS = 12, ST_N_USEFUL = 13, ST_N_NOB = 14, ST_N_NOP = 15,
        // the chain (clarans_chain_kernel): the local search it is in, the cheapest search's cost so far, whether the search it is in has to be started
-       ST_ITER = 16, ST_BEST = 17, ST_NEED_INIT = 18 };
+       ST_ITER = 16, ST_BEST = 17, ST_NEED_INIT = 18,
+       ST_TICKS = 19 /* 100 MHz ticks the chain's workgroup has run (LCSGPU_PROFILE) */, ST_CU = 20 /* where its last launch ran: XCC id << 8 | CU id */ };
 // why an evaluation ended
 enum { WHY_WALKED = 0, WHY_NO_B = 1, WHY_NO_P = 2 };
 
@@ -85,33 +86,6 @@ enum { WHY_WALKED = 0, WHY_NO_B = 1, WHY_NO_P = 2 };
 __device__ __forceinline__ int window_size(int corrected, int first) { return first ? corrected : (corrected > 0 ? corrected - 1 : 0); }
 
 } // namespace
-
-// float distances of the sample as a full symmetric matrix: D[i * n + j] = D[j * n + i] = transform(LCS(ref = ids[i],
-// partner = ids[j])), j < i (Transform<float, ...>, tree/AbstractTreeGenerator.hpp:28-82, the float table built at upload)
-template <typename T>
-__global__ __launch_bounds__(256) void subset_dist_kernel(const T* __restrict__ lcs, const int32_t* __restrict__ ids,
-                                                          const uint32_t* __restrict__ lens,
-                                                          const float* __restrict__ pow_f32, int kind, int n,
-                                                          float* __restrict__ D)
-{
-    const int i = blockIdx.x + 1;
-    if (threadIdx.x == 0) {
-        D[(size_t)i * n + i] = 0.0f; // (never read)
-        if (i == 1) D[0] = 0.0f;
-    }
-    const uint32_t len_i = lens[ids[i]];
-    const size_t row = (size_t)i * (i - 1) / 2;
-    for (int j = threadIdx.x; j < i; j += 256) {
-        const uint32_t l = lcs[row + j];
-        const uint32_t indel = len_i + lens[ids[j]] - 2u * l;
-        float d;
-        if (l == 0) d = FLT_MAX;
-        else if (kind == 1) d = __fdiv_rn(pow_f32[indel], (float)l);
-        else d = __fdiv_rn((float)indel, (float)l);
-        D[(size_t)i * n + j] = d;
-        D[(size_t)j * n + i] = d;
-    }
-}
 
 // Per-position state: st[pos] = {distance to the nearest medoid, to the second nearest, slot of the
 // nearest, slot of the second} of the member at candidate position pos (only positions >= n_medoids
@@ -876,10 +850,14 @@ __global__ __launch_bounds__(512, 4) void clarans_chain_kernel(const ClaransChai
         st[ST_ITER] = iter;
         st[ST_BEST] = __float_as_int(best);
         st[ST_NEED_INIT] = need_init;
+        st[ST_TICKS] += (int)(wall_clock64() - t_begin);
+        st[ST_CU] = (int)((__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) << 8) | (__builtin_amdgcn_s_getreg((4 << 0) | (8 << 6) | (7 << 11))));
     }
 }
 
-// the samples' float matrices, all jobs in one launch (grid.y = job)
+// the samples' float distances as full symmetric matrices, D[i * n + j] = D[j * n + i] = transform(LCS(ref = ids[i], partner =
+// ids[j])), j < i (Transform<float, ...>, tree/AbstractTreeGenerator.hpp:28-82, the float table built at upload); all samples in
+// one launch (grid.y = sample)
 template <typename T>
 __global__ __launch_bounds__(256) void subset_dist_batch_kernel(const T* __restrict__ lcs, const ClaransChain* __restrict__ chains,
                                                                 const uint32_t* __restrict__ lens, const float* __restrict__ pow_f32, int kind)
@@ -906,19 +884,6 @@ __global__ __launch_bounds__(256) void subset_dist_batch_kernel(const T* __restr
         D[(size_t)i * n + j] = d;
         D[(size_t)j * n + i] = d;
     }
-}
-
-hipError_t launch_subset_distances(const void* lcs, int elem_size, const int32_t* ids, const uint32_t* lens,
-                                   const float* pow_f32, int kind, int n, float* D, hipStream_t stream)
-{
-    if (n < 2) return hipSuccess;
-    if (elem_size == 2)
-        hipLaunchKernelGGL(subset_dist_kernel<uint16_t>, dim3(n - 1), dim3(256), 0, stream, (const uint16_t*)lcs, ids,
-                           lens, pow_f32, kind, n, D);
-    else
-        hipLaunchKernelGGL(subset_dist_kernel<uint32_t>, dim3(n - 1), dim3(256), 0, stream, (const uint32_t*)lcs, ids,
-                           lens, pow_f32, kind, n, D);
-    return hipGetLastError();
 }
 
 hipError_t launch_subset_distances_batch(const void* lcs, int elem_size, const ClaransChain* chains, int n_chains, int max_n,

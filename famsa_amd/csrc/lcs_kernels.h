@@ -65,6 +65,11 @@ struct RowsArgs {
     const int4* jobs;
     const int32_t* ref_col0;
     const int64_t* ref_out0;
+    // Threads per workgroup: 0 / 256 = four waves sharing the refs' masks; 64 = ONE wave per workgroup (jobs only, plain refs):
+    // the lists of a leaf batch are mostly shorter than 256 members, and a 256-lane workgroup over a 60-member list computes
+    // with a quarter of its lanes (3 x 10^6 sequences: the leaves' 8.5 x 10^8 pairs took 0.4 s of GPU time, four times
+    // their share at the large-launch rate).  Column blocks are block_threads wide then.
+    int32_t block_threads;
     FuseArgs fuse; // fuse.on: MODE_TRIANGLE, contiguous columns, row == ref id; `out` may then be NULL (nothing stored)
 };
 
@@ -274,21 +279,7 @@ struct ClaransArgs {
     int32_t* state;      // the search's state block (clarans_kernels.hip, ST_*): next draw, done, accepts, cost, window offset, statistics
     int32_t n_elems, n_medoids, n_fixed, draws_len;
     int32_t corrected;   // steps without an accept that end a local search (Clustering.cpp:21-29)
-    int32_t* host_state; // mapped host memory (16 words) a launch leaves the state block in as well, or NULL
 };
-// Searches that are advanced together, one workgroup each: however many host threads are searching, a time slice costs
-// one launch in total instead of one per search (a launch per search keeps a hardware queue busy for the whole search and
-// whatever shares the queue waits behind it).
-constexpr int CLARANS_MAX_BATCH = 16;
-struct ClaransBatch {
-    ClaransArgs s[CLARANS_MAX_BATCH];
-    int32_t n;
-};
-hipError_t launch_subset_distances(const void* lcs, int elem_size, const int32_t* ids, const uint32_t* lens,
-                                   const float* pow_f32, int kind, int n, float* D, hipStream_t stream);
-hipError_t launch_clarans_init(const ClaransArgs& a, hipStream_t stream);
-// every search of the batch for `slice_us` microseconds, or to its end, or until its pre-drawn positions run out
-hipError_t launch_clarans_search(const ClaransBatch& b, int slice_us, hipStream_t stream);
 
 // ---- -dist_export rows as text, on the device (text_kernels.hip) ----
 struct TextArgs {

@@ -132,8 +132,9 @@ template <int W>
 __device__ __forceinline__ void fill_tile_masks(const RowsArgs& a, int ref0, int nr, int nr_pad, lds_u64* dst, int tid)
 {
     const int total = nr_pad * (W * 32);
+    const int step = (int)blockDim.x; // 256, or 64 in the one-wave form (RowsArgs::block_threads)
 #pragma unroll 4
-    for (int idx = tid; idx < total; idx += 256) {
+    for (int idx = tid; idx < total; idx += step) {
         const int r = idx / (W * 32), rem = idx - r * (W * 32), w = rem >> 5;
         uint64_t m = 0;
         if (r < nr) {
@@ -870,10 +871,13 @@ template <int H, int RG, bool QUIRK, bool FUSE>
 static hipError_t launch_one(const RowsArgs& a, dim3 grid, hipStream_t stream)
 {
     const size_t lds = (size_t)a.refs_per_block * ((H + 1) / 2) * 256 + (FUSE ? FUSE_LDS_BYTES : 0);
-    if constexpr (QUIRK)
+    if constexpr (QUIRK) {
+        if (a.block_threads != 0 && a.block_threads != 256) return hipErrorInvalidValue;
         hipLaunchKernelGGL((lcs_rows_kernel_quirk<H, FUSE>), grid, dim3(256), lds, stream, a);
-    else
-        hipLaunchKernelGGL((lcs_rows_kernel_pipe<H, RG, LCS_LOOKAHEAD, FUSE>), grid, dim3(256), lds, stream, a);
+    } else {
+        if (a.block_threads != 0 && a.block_threads != 256 && (a.block_threads != 64 || !a.jobs || FUSE)) return hipErrorInvalidValue;
+        hipLaunchKernelGGL((lcs_rows_kernel_pipe<H, RG, LCS_LOOKAHEAD, FUSE>), grid, dim3(a.block_threads == 64 ? 64 : 256), lds, stream, a);
+    }
     return hipGetLastError();
 }
 

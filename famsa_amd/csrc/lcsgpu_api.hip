@@ -131,9 +131,21 @@ bool contiguous(const Bucket& b)
     return true;
 }
 
-bool create_lane(lcsgpu_ctx* ctx, Lane& l)
+bool create_lane(lcsgpu_ctx* ctx, Lane& l, bool high_priority)
 {
     if (hipSetDevice(ctx->device) != hipSuccess) return false;
+    if (high_priority) {
+        int least = 0, greatest = 0;
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess || least == greatest) {
+            (void)hipGetLastError();
+            return false;
+        }
+        const bool ok = hipStreamCreateWithPriority(&l.stream, hipStreamNonBlocking, greatest) == hipSuccess &&
+                        hipEventCreate(&l.ev_start) == hipSuccess && hipEventCreate(&l.ev_stop) == hipSuccess &&
+                        hipEventCreateWithFlags(&l.ev_done, hipEventBlockingSync | hipEventDisableTiming) == hipSuccess;
+        if (!ok) (void)hipGetLastError();
+        return ok;
+    }
     // (the copy stream of the sliced host-buffer triangle is made by its first user: a stream costs ~100 MB of resident
     //  host memory and some milliseconds on this runtime, and the FastTree recursion's 16+ lanes never need it)
     const bool ok = hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking) == hipSuccess &&
@@ -453,7 +465,7 @@ int lcsgpu_create(int device_id, lcsgpu_ctx** out_ctx)
     lcsgpu_ctx* ctx = new (std::nothrow) lcsgpu_ctx;
     if (!ctx) return fail(LCSGPU_E_NOMEM, "out of host memory");
     ctx->device = device_id;
-    ctx->lanes.resize(MAX_LANES);
+    ctx->lanes.resize(MAX_LANES + 1); // (the last slot: LaneGuard::FRONT)
     ctx->lane_limit = n_lanes;
     // lane 0 now; the others (and the streams of the CLARANS batches) when first needed -- see Lane::created
     if (!create_lane(ctx, ctx->lanes[0])) {
@@ -675,6 +687,8 @@ int lcsgpu_upload_ordered(lcsgpu_ctx* ctx, const uint8_t* codes, const uint64_t*
     }
     ctx->lens.swap(lens);
     ctx->quirk.swap(quirk);
+    ctx->ref_class.resize((size_t)n);
+    for (int32_t i = 0; i < n; ++i) ctx->ref_class[(size_t)i] = (uint8_t)(lcsgpu::h_class(ctx->lens[(size_t)i]) | (ctx->quirk[(size_t)i] ? 0x80 : 0));
     ctx->max_len = max_len;
     ctx->n = n;
     return LCSGPU_OK;

@@ -4,14 +4,20 @@
 #include "lcsgpu_internal.h"
 #include "fasttree_kernels.h"
 
+#include <functional>
+#include <memory>
+
 using namespace lcsgpu_impl;
 using lcsgpu::RowsArgs;
 
 // The packed LCS triangles of several id lists into lane L's result buffer (device memory), list g at pair offset
 // tri_base[g]: validation, planning and the launches of lcsgpu_lcs_triangles_batch.  *count = pairs in total (0: nothing to do).  On return the
 // launches are queued on L.stream (or, with a ref beyond 2048 residues in the batch, already finished).
+// `before_launch` (may be empty) is called once the plan is made, before the first thing goes to the device: the caller's moment
+// to take the compute gate (planning a few hundred lists is tens of milliseconds of host work nobody should wait for).
 static int batch_triangles_to_device(lcsgpu_ctx* ctx, Lane& L, const int32_t* ids, const int64_t* group_offsets, int32_t n_groups,
-                                     int elem_size, std::vector<int64_t>& tri_base, int64_t* count_out, bool* had_long)
+                                     int elem_size, std::vector<int64_t>& tri_base, int64_t* count_out, bool* had_long,
+                                     const std::function<void()>& before_launch = nullptr)
 {
     if (!ctx) return fail(LCSGPU_E_INVALID, "NULL ctx");
     if (ctx->n < 0) return fail(LCSGPU_E_STATE, "no sequence set uploaded");
@@ -35,15 +41,26 @@ static int batch_triangles_to_device(lcsgpu_ctx* ctx, Lane& L, const int32_t* id
     const int64_t count = tri_base[n_groups];
     if (count <= 0) return LCSGPU_OK;
     if (!ids) return fail(LCSGPU_E_INVALID, "NULL ids");
+    std::vector<uint8_t> cls((size_t)n_total); // lcsgpu_ctx::ref_class of every id: the one pass over the set's tables
     for (int64_t p = 0; p < n_total; ++p) {
         if (ids[p] < 0 || ids[p] >= ctx->n) return fail(LCSGPU_E_INVALID, "id %d out of range", ids[p]);
-        any_long |= ctx->lens[ids[p]] > 2048;
+        cls[(size_t)p] = ctx->ref_class[(size_t)ids[p]];
+        any_long |= (cls[(size_t)p] & 0x7f) == 0;
     }
     *count_out = count;
     *had_long = any_long;
     HIP_TRY(hipSetDevice(ctx->device));
+    static std::atomic<long> plan_us[4], plan_calls{0}; // LCSGPU_PROFILE
+    auto t_mark = std::chrono::steady_clock::now();
+    auto lap = [&](int what) {
+        const auto t = std::chrono::steady_clock::now();
+        plan_us[what] += std::chrono::duration_cast<std::chrono::microseconds>(t - t_mark).count();
+        t_mark = t;
+    };
     HIP_TRY(L.d_out.reserve((size_t)count * elem_size));
+    lap(0);
     if (any_long) { // the long-ref kernel keeps its 2-D grid: list by list
+        if (before_launch) before_launch();
         double ms = 0;
         int launches = 0;
         for (int32_t g = 0; g < n_groups; ++g) {
@@ -67,6 +84,7 @@ static int batch_triangles_to_device(lcsgpu_ctx* ctx, Lane& L, const int32_t* id
     struct BatchBucket {
         int bv;
         bool quirk;
+        bool narrow; // one-wave workgroups, column blocks of 64: the refs of short lists (RowsArgs::block_threads)
         std::vector<int32_t> ref_id, ref_col0;
         std::vector<int64_t> ref_row, ref_out0;
         std::vector<int32_t> ref_group;
@@ -74,17 +92,18 @@ static int batch_triangles_to_device(lcsgpu_ctx* ctx, Lane& L, const int32_t* id
         int refs_per_wg = 0;
     };
     std::vector<BatchBucket> buckets;
-    int index_of[160];
-    std::fill(index_of, index_of + 160, -1);
+    int index_of[320];
+    std::fill(index_of, index_of + 320, -1);
+    static const int narrow_max = tune_int("narrow_lists", 192); // lists up to that many members run in one-wave workgroups
     int target[65];
     {   // small neighbouring half-word classes share a launch (merge_small_classes, lcsgpu_api.hip)
-        double wgs[65] = {0};
+        double wgs[65] = {0}, inv_refs[65];
+        for (int h = 0; h <= 64; ++h) inv_refs[h] = 1.0 / lcsgpu::refs_per_block_for(h, false, 1, 1);
         for (int32_t g = 0; g < n_groups; ++g)
             for (int64_t p = group_offsets[g] + 1; p < group_offsets[g + 1]; ++p) {
-                const int32_t id = ids[p];
-                if (ctx->quirk[id]) continue;
-                const int h = lcsgpu::h_class(ctx->lens[id]);
-                wgs[h] += (double)((p - group_offsets[g] + 255) / 256) / lcsgpu::refs_per_block_for(h, false, 1, 1);
+                if (cls[(size_t)p] & 0x80) continue;
+                const int h = cls[(size_t)p];
+                wgs[h] += (double)((p - group_offsets[g] + 255) / 256) * inv_refs[h];
             }
         merge_small_classes(wgs, target);
     }
@@ -92,12 +111,20 @@ static int batch_triangles_to_device(lcsgpu_ctx* ctx, Lane& L, const int32_t* id
         for (int64_t p = group_offsets[g]; p < group_offsets[g + 1]; ++p) {
             if (p == group_offsets[g]) continue; // the first member of a list has no partner
             const int32_t id = ids[p];
-            const bool q = ctx->quirk[id] != 0;
-            const int bv = q ? lcsgpu::quirk_h_class(ctx->lens[id]) : target[lcsgpu::h_class(ctx->lens[id])];
-            const int key = bv * 2 + (q ? 1 : 0);
+            const bool q = (cls[(size_t)p] & 0x80) != 0;
+            const int bv = q ? lcsgpu::quirk_h_class(ctx->lens[id]) : target[cls[(size_t)p]];
+            const bool narrow = !q && group_offsets[g + 1] - group_offsets[g] <= narrow_max;
+            const int key = bv * 2 + (q ? 1 : 0) + (narrow ? 160 : 0);
             if (index_of[key] < 0) {
                 index_of[key] = (int)buckets.size();
-                buckets.push_back(BatchBucket{bv, q, {}, {}, {}, {}, {}, {}, 0});
+                buckets.push_back(BatchBucket{bv, q, narrow, {}, {}, {}, {}, {}, {}, 0});
+                BatchBucket& nb = buckets.back(); // (hundreds of lists: growing these step by step was a third of the planning time)
+                const size_t room = (size_t)n_total / (buckets.size() > 1 ? 4 : 1) + 16;
+                nb.ref_id.reserve(room);
+                nb.ref_row.reserve(room);
+                nb.ref_col0.reserve(room);
+                nb.ref_out0.reserve(room);
+                nb.ref_group.reserve(room);
             }
             BatchBucket& b = buckets[index_of[key]];
             b.ref_id.push_back(id);
@@ -116,12 +143,13 @@ static int batch_triangles_to_device(lcsgpu_ctx* ctx, Lane& L, const int32_t* id
         BatchBucket& b = buckets[bi];
         const int R = b.refs_per_wg = lcsgpu::refs_per_block_for(b.bv, b.quirk, (long)b.ref_id.size(), 1);
         const size_t nr_all = b.ref_id.size();
+        b.jobs.reserve(nr_all / (size_t)std::max(1, R) * (b.narrow ? 3 : 5) + 16);
         for (size_t k0 = 0; k0 < nr_all;) {
             size_t k1 = k0 + 1;
             while (k1 < nr_all && k1 - k0 < (size_t)R && b.ref_group[k1] == b.ref_group[k0]) ++k1;
             const int32_t g0 = b.ref_col0[k0];
             const int32_t max_row = (int32_t)b.ref_row[k1 - 1]; // rows ascend inside a list
-            for (int32_t c0 = g0; c0 < max_row; c0 += 256)
+            for (int32_t c0 = g0; c0 < max_row; c0 += b.narrow ? 64 : 256)
                 b.jobs.push_back(make_int4((int)k0, (int)(k1 - k0), c0, max_row));
             k0 = k1;
         }
@@ -132,12 +160,14 @@ static int batch_triangles_to_device(lcsgpu_ctx* ctx, Lane& L, const int32_t* id
         o_out[bi] = bytes; bytes += align16(nr_all * 8);
         o_job[bi] = bytes; bytes += align16(b.jobs.size() * sizeof(int4));
     }
+    lap(1);
     if (L.plan_in_flight) {
         HIP_TRY(hipStreamSynchronize(L.stream));
         L.plan_in_flight = false;
     }
     HIP_TRY(L.h_plan.reserve(bytes));
     HIP_TRY(L.d_plan.reserve(bytes));
+    lap(2);
     char* h = (char*)L.h_plan.p;
     memcpy(h + col_off, ids, (size_t)n_total * 4);
     for (size_t bi = 0; bi < buckets.size(); ++bi) {
@@ -148,6 +178,12 @@ static int batch_triangles_to_device(lcsgpu_ctx* ctx, Lane& L, const int32_t* id
         memcpy(h + o_out[bi], b.ref_out0.data(), b.ref_out0.size() * 8);
         memcpy(h + o_job[bi], b.jobs.data(), b.jobs.size() * sizeof(int4));
     }
+    lap(3);
+    if (getenv("LCSGPU_PROFILE") && (++plan_calls % 20) == 0)
+        fprintf(stderr, "triangle batches planned: %ld, thread-ms each: result buffer %.1f, lists + jobs %.1f, plan buffers %.1f, filling them %.1f (last: %lld ids, %d lists)\n",
+                plan_calls.load(), 1e-3 * plan_us[0] / plan_calls, 1e-3 * plan_us[1] / plan_calls, 1e-3 * plan_us[2] / plan_calls, 1e-3 * plan_us[3] / plan_calls,
+                (long long)n_total, n_groups);
+    if (before_launch) before_launch();
     HIP_TRY(hipMemcpyAsync(L.d_plan.p, h, bytes, hipMemcpyHostToDevice, L.stream));
     L.plan_in_flight = true;
     L.last_launches = 0;
@@ -175,6 +211,7 @@ static int batch_triangles_to_device(lcsgpu_ctx* ctx, Lane& L, const int32_t* id
         a.elem_size = elem_size;
         a.mode = lcsgpu::MODE_TRIANGLE;
         a.refs_per_block = b.refs_per_wg;
+        a.block_threads = b.narrow ? 64 : 0;
         HIP_TRY(lcsgpu::launch_rows(b.bv, b.quirk, a, (int)b.jobs.size(), 1, run_stream));
         ++L.last_launches;
     }
@@ -189,13 +226,40 @@ int lcsgpu_lcs_triangles_batch(lcsgpu_ctx* ctx, const int32_t* ids, const int64_
                                void* out, int elem_size)
 {
     if (!ctx) return fail(LCSGPU_E_INVALID, "NULL ctx");
+    // LCSGPU_PROFILE: where the calls' time goes, summed over the calling threads (printed by the 64th, 128th, ... call)
+    static std::atomic<long> prof_us[5], prof_calls{0};
+    auto t_mark = std::chrono::steady_clock::now();
+    auto lap = [&](int what) {
+        const auto t = std::chrono::steady_clock::now();
+        prof_us[what] += std::chrono::duration_cast<std::chrono::microseconds>(t - t_mark).count();
+        t_mark = t;
+    };
     LaneGuard guard(ctx, LaneGuard::ANY);
     Lane& L = guard.lane();
+    lap(0);
     std::vector<int64_t> tri_base;
     int64_t count = 0;
     bool had_long = false;
-    int rc = batch_triangles_to_device(ctx, L, ids, group_offsets, n_groups, elem_size, tri_base, &count, &had_long);
-    if (rc || count <= 0) return rc;
+    int rc;
+    {
+        struct Shared { // from the first launch until the kernels have run; the plan is made before, the results travel after
+            ComputeGate& g;
+            bool held = false;
+            ~Shared() { if (held) g.unlock_shared(); }
+        } hold{ctx->gate};
+        rc = batch_triangles_to_device(ctx, L, ids, group_offsets, n_groups, elem_size, tri_base, &count, &had_long, [&] {
+            lap(1);
+            hold.g.lock_shared();
+            hold.held = true;
+            lap(2);
+        });
+        if (rc || count <= 0) return rc;
+        if (!had_long) {
+            HIP_TRY(hipEventRecord(L.ev_done, L.stream));
+            HIP_TRY(hipEventSynchronize(L.ev_done));
+        }
+        lap(3);
+    }
     if (!out) return fail(LCSGPU_E_INVALID, "NULL out");
     if (had_long) { // every list was synchronised already; the timing is in g_last
         HIP_TRY(hipMemcpy(out, L.d_out.p, (size_t)count * elem_size, hipMemcpyDeviceToHost));
@@ -205,6 +269,11 @@ int lcsgpu_lcs_triangles_batch(lcsgpu_ctx* ctx, const int32_t* ids, const int64_
     HIP_TRY(hipEventRecord(L.ev_done, L.stream));
     HIP_TRY(hipEventSynchronize(L.ev_done));
     finish_host_call(ctx, L);
+    lap(4);
+    if (getenv("LCSGPU_PROFILE") && (++prof_calls % 19) == 0)
+        fprintf(stderr, "triangles_batch: %ld calls so far, thread-ms per call: lane %.1f, plan %.1f, gate %.1f, kernels %.1f, results to the host %.1f\n",
+                prof_calls.load(), 1e-3 * prof_us[0] / prof_calls, 1e-3 * prof_us[1] / prof_calls, 1e-3 * prof_us[2] / prof_calls,
+                1e-3 * prof_us[3] / prof_calls, 1e-3 * prof_us[4] / prof_calls);
     return LCSGPU_OK;
 }
 
@@ -297,7 +366,7 @@ int lcsgpu_assign_seeds_batch(lcsgpu_ctx* ctx, const int32_t* seed_ids, const in
         }
         return LCSGPU_OK;
     }
-    LaneGuard guard(ctx, LaneGuard::ANY);
+    LaneGuard guard(ctx, LaneGuard::FRONT);
     Lane& L = guard.lane();
     HIP_TRY(hipSetDevice(ctx->device));
     const int elem = ctx->max_len > 65535 ? 4 : 2;
@@ -563,15 +632,32 @@ int lcsgpu_clarans_batch(lcsgpu_ctx* ctx, const int32_t* ids, const int64_t* off
     if (live.empty()) return LCSGPU_OK;
 
     const auto t_call = std::chrono::steady_clock::now();
-    LaneGuard guard(ctx, LaneGuard::ANY);
+    LaneGuard guard(ctx, LaneGuard::FRONT);
     Lane& L = guard.lane();
     HIP_TRY(hipSetDevice(ctx->device));
+    const bool profile = getenv("LCSGPU_PROFILE") != nullptr;
+    double t_prof[6] = {0};
+    auto t_mark = std::chrono::steady_clock::now();
+    auto lap = [&](int what, bool sync) {
+        if (!profile) return;
+        if (sync) (void)hipStreamSynchronize(L.stream);
+        const auto t = std::chrono::steady_clock::now();
+        t_prof[what] += std::chrono::duration<double>(t - t_mark).count();
+        t_mark = t;
+    };
+    std::unique_lock<ComputeGate> wave(ctx->gate, std::defer_lock); // the chip to the chains (lcsgpu_internal.h, ComputeGate)
     const int elem = ctx->max_len > 65535 ? 4 : 2;
     std::vector<int64_t> tri_base;
     int64_t count = 0;
     bool had_long = false;
-    int rc = batch_triangles_to_device(ctx, L, ids, offsets, n_jobs, elem, tri_base, &count, &had_long);
+    int rc = batch_triangles_to_device(ctx, L, ids, offsets, n_jobs, elem, tri_base, &count, &had_long, [&] {
+        lap(1, false);
+        wave.lock();
+        lap(0, false);
+    });
     if (rc) return rc;
+    if (!wave.owns_lock()) wave.lock();
+    lap(2, true);
     double lcs_ms = 0;
     int lcs_launches = 0;
     if (had_long) { // (synchronised list by list: the timing is in g_last)
@@ -604,6 +690,7 @@ int lcsgpu_clarans_batch(lcsgpu_ctx* ctx, const int32_t* ids, const int64_t* off
     }
     rc = reserve_big(ctx, L.d_work, at, "CLARANS batch");
     if (rc) return rc;
+    lap(3, false);
     char* base = (char*)L.d_work.p;
     const size_t host_bytes = a256((size_t)n_live * sizeof(lcsgpu::ClaransChain)) + a256((size_t)n_live * lcsgpu::CLARANS_STATE_WORDS * 4);
     HIP_TRY(L.h_small.reserve(host_bytes));
@@ -671,6 +758,7 @@ int lcsgpu_clarans_batch(lcsgpu_ctx* ctx, const int32_t* ids, const int64_t* off
     HIP_TRY(hipMemcpyAsync(base + o_chains, h_chains, (size_t)n_live * sizeof(lcsgpu::ClaransChain), hipMemcpyHostToDevice, L.stream));
     HIP_TRY(lcsgpu::launch_subset_distances_batch(L.d_out.p, elem, (const lcsgpu::ClaransChain*)(base + o_chains), n_live, max_n,
                                                   (const uint32_t*)ctx->d_lens.p, (const float*)ctx->d_powf.p, distance_kind, L.stream));
+    lap(4, true);
     // the chains: normally one launch; a chain that runs out of positions (or, under LCSGPU_TUNE clarans_slice_us, of time)
     // comes back for another
     std::vector<int> todo((size_t)n_live);
@@ -678,6 +766,7 @@ int lcsgpu_clarans_batch(lcsgpu_ctx* ctx, const int32_t* ids, const int64_t* off
     std::vector<lcsgpu::ClaransChain> all(h_chains, h_chains + n_live);
     int launches = 0;
     long accepts = 0, steps = 0;
+    std::vector<int32_t> ticks, where;
     while (!todo.empty()) {
         const int nt = (int)todo.size();
         for (int t = 0; t < nt; ++t) {
@@ -700,6 +789,8 @@ int lcsgpu_clarans_batch(lcsgpu_ctx* ctx, const int32_t* ids, const int64_t* off
             if (st[1]) { // ST_DONE: the whole chain
                 accepts += st[3];
                 steps += st[12];
+                ticks.push_back(st[19]);
+                where.push_back(st[20]);
                 continue;
             }
             again.push_back(q);
@@ -719,6 +810,26 @@ int lcsgpu_clarans_batch(lcsgpu_ctx* ctx, const int32_t* ids, const int64_t* off
     for (int32_t j : live) std::copy(best.begin() + med_off[j], best.begin() + med_off[j + 1], medoids_out + med_off[j]);
     if (!had_long) finish_host_call(ctx, L);
     else note_host_call(ctx, lcs_ms, lcs_launches);
+    if (getenv("LCSGPU_PROFILE") && !ticks.empty()) {
+        std::vector<int32_t> sorted(ticks);
+        std::sort(sorted.begin(), sorted.end());
+        std::map<int, int> per_cu;
+        for (int32_t w : where) ++per_cu[w];
+        int shared_cu = 0;
+        for (auto& kv : per_cu) shared_cu += kv.second > 1 ? kv.second : 0;
+        double slow_shared = 0, slow_alone = 0;
+        int n_sh = 0, n_al = 0;
+        for (size_t i = 0; i < ticks.size(); ++i) {
+            if (per_cu[where[i]] > 1) { slow_shared += ticks[i]; ++n_sh; } else { slow_alone += ticks[i]; ++n_al; }
+        }
+        fprintf(stderr, "clarans.batch chains: run time min %.1f median %.1f max %.1f ms; %d of %zu shared a CU (mean %.1f ms against %.1f ms alone)\n",
+                sorted.front() * 1e-5, sorted[sorted.size() / 2] * 1e-5, sorted.back() * 1e-5, shared_cu, ticks.size(),
+                n_sh ? slow_shared / n_sh * 1e-5 : 0.0, n_al ? slow_alone / n_al * 1e-5 : 0.0);
+    }
+    lap(5, false);
+    if (profile)
+        fprintf(stderr, "clarans.batch parts: gate %.1f ms, planning the triangles %.1f, their kernels %.1f, work area (%.2f GB) %.1f, tables + distances %.1f, chains + results %.1f\n",
+                1e3 * t_prof[0], 1e3 * t_prof[1], 1e3 * t_prof[2], at / 1e9, 1e3 * t_prof[3], 1e3 * t_prof[4], 1e3 * t_prof[5]);
     if (getenv("LCSGPU_PROFILE"))
         fprintf(stderr, "clarans.batch: %d samples (%d searched, %zu shapes), %d launch(es), %ld accepts, %ld steps looked at, %.3f s\n", n_jobs, n_live,
                 shapes.size(), launches, accepts, steps, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_call).count());

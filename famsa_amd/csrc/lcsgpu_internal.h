@@ -126,9 +126,52 @@ struct Lane {
 
 struct TextExport; // lcsgpu_text.hip: the state of lcsgpu_dist_text_begin .. _end
 
+// Who may have kernels on the chip: a wave of CLARANS chains (lcsgpu_clarans_batch: one workgroup per sample, each a long
+// chain of short dependent phases) wants the CUs to itself -- bulk LCS launches of other host threads on the same CUs make
+// every chain, and so the wave, several times slower (3 x 10^6 sequences: 278 chains 0.39 s beside the leaves' LCS batches,
+// 0.1 s alone).  Bulk LCS calls hold the gate shared while their kernels run (not while their results travel), a wave holds
+// it exclusively; a waiting wave goes first.
+struct ComputeGate {
+    std::mutex mu;
+    std::condition_variable cv;
+    int shared = 0, waiting_exclusive = 0;
+    bool exclusive = false;
+    void lock_shared()
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return !exclusive && waiting_exclusive == 0; });
+        ++shared;
+    }
+    void unlock_shared()
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            --shared;
+        }
+        cv.notify_all();
+    }
+    void lock()
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        ++waiting_exclusive;
+        cv.wait(lk, [&] { return !exclusive && shared == 0; });
+        --waiting_exclusive;
+        exclusive = true;
+    }
+    void unlock()
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            exclusive = false;
+        }
+        cv.notify_all();
+    }
+};
+
 struct lcsgpu_ctx {
     int device = 0;
     TextExport* text = nullptr;
+    ComputeGate gate;
     std::mutex mu; // guards the lane table
     std::condition_variable cv;
     std::vector<Lane> lanes;  // MAX_LANES slots; a slot costs nothing until its lane is created
@@ -139,6 +182,10 @@ struct lcsgpu_ctx {
     uint32_t max_len = 0;
     std::vector<uint32_t> lens;
     std::vector<uint8_t> quirk; // ref needs the literal (V2 < V) carry rule
+    // per sequence: the half-word class its kernels are instantiated for (lcsgpu::h_class, 0 = beyond 2048 residues) | 0x80 if
+    // quirk -- what the planners of the batched calls ask per id: one byte out of a table that stays in the host's cache
+    // (lens + quirk: two cache misses per id, 3 x 10^6 sequences)
+    std::vector<uint8_t> ref_class;
     lcsgpu_impl::DevBuf d_tiles, d_tile_base, d_lens, d_pow, d_powf, d_masks, d_mask_base;
     lcsgpu_impl::DevBuf d_minlen; // shortest sequence per aligned block of 16 vertices [ceil(n/16)], then of 1024 [ceil(n/1024)]
     const uint32_t* minlen16() const { return (const uint32_t*)d_minlen.p; }
@@ -176,12 +223,15 @@ struct LastCall { // timing of this thread's most recent call, for lcsgpu_last_k
 extern thread_local LastCall g_last;
 
 // streams / events of one lane (lcsgpu_api.hip); false on failure
-bool create_lane(lcsgpu_ctx* ctx, Lane& l);
+bool create_lane(lcsgpu_ctx* ctx, Lane& l, bool high_priority = false);
 
 // RAII ownership of one lane (index 0 on request, else any free one) or of all lanes.
 class LaneGuard {
 public:
-    enum Which { ANY, LANE0, ALL };
+    // FRONT: the context's one lane on a HIGH-PRIORITY stream (slot MAX_LANES, created on first use): the calls a
+    // level-by-level caller waits for one after the other (lcsgpu_clarans_batch, lcsgpu_assign_seeds_batch) -- their
+    // workgroups go before the pending ones of the bulk requests other host threads have queued on the ordinary lanes
+    enum Which { ANY, LANE0, ALL, FRONT };
     LaneGuard(lcsgpu_ctx* ctx, Which which) : ctx_(ctx), which_(which)
     {
         std::unique_lock<std::mutex> lk(ctx->mu);
@@ -196,7 +246,44 @@ public:
             ctx->cv.wait(lk, [&] { return !ctx->lanes[0].busy; });
             ctx->lanes[0].busy = true;
             idx_ = 0;
+        } else if (which == FRONT) {
+            Lane& l = ctx->lanes[MAX_LANES];
+            ctx->cv.wait(lk, [&] { return !l.busy; });
+            l.busy = true;
+            idx_ = MAX_LANES;
+            if (!l.created && !l.unusable) {
+                lk.unlock();
+                const bool ok = create_lane(ctx, l, true);
+                lk.lock();
+                l.created = ok;
+                l.unusable = !ok;
+            }
+            if (l.unusable) { // no such stream on this runtime: an ordinary lane serves
+                l.busy = false;
+                ctx->cv.notify_all();
+                which_ = ANY;
+                acquire_any(lk);
+            }
         } else {
+            acquire_any(lk);
+        }
+    }
+    ~LaneGuard()
+    {
+        {
+            std::lock_guard<std::mutex> lk(ctx_->mu);
+            if (which_ == ALL) for (auto& l : ctx_->lanes) l.busy = false;
+            else ctx_->lanes[idx_].busy = false;
+        }
+        ctx_->cv.notify_all();
+    }
+    Lane& lane() { return ctx_->lanes[idx_]; }
+
+private:
+    void acquire_any(std::unique_lock<std::mutex>& lk)
+    {
+        lcsgpu_ctx* ctx = ctx_;
+        {
             // a created free lane other than lane 0 (device-memory calls and the tree reducers queue there);
             // else a lane that does not exist yet -- unless lane 0 is free and nothing else has been needed
             // so far (a single-threaded caller never pays for a second lane); else lane 0; else wait
@@ -236,18 +323,6 @@ public:
             }
         }
     }
-    ~LaneGuard()
-    {
-        {
-            std::lock_guard<std::mutex> lk(ctx_->mu);
-            if (which_ == ALL) for (auto& l : ctx_->lanes) l.busy = false;
-            else ctx_->lanes[idx_].busy = false;
-        }
-        ctx_->cv.notify_all();
-    }
-    Lane& lane() { return ctx_->lanes[idx_]; }
-
-private:
     lcsgpu_ctx* ctx_;
     Which which_;
     int idx_ = 0;

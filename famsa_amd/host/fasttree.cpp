@@ -132,6 +132,35 @@ private:
     bool enabled_ = false;
 } g_cpu;
 void CpuSlots::note_cpu_wait(int delta) { g_timeline.note(Timeline::CPU_WAIT, delta); }
+// How many batched leaf requests are with the engine at a time: each takes a lane of the engine, and a lane brings its own
+// staging and result buffers (tens of MB of pinned and device memory, allocated -- slowly -- when first needed and when
+// outgrown).  Three requests in flight keep the GPU's queue filled; thirty paid for thirty sets of buffers
+// (3 x 10^6 sequences: 20-45 ms of allocations per request).
+class Slots {
+public:
+    explicit Slots(int n) : free_(n) {}
+    void acquire()
+    {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [this] { return free_ > 0; });
+        --free_;
+    }
+    void release()
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            ++free_;
+        }
+        cv_.notify_one();
+    }
+
+private:
+    std::mutex mu_;
+    std::condition_variable cv_;
+    int free_;
+};
+Slots g_leaf_requests(3);
+
 struct OffCpu { // around a wait for the GPU
     OffCpu() { g_cpu.release(); }
     ~OffCpu() { g_cpu.acquire(); }
@@ -732,6 +761,10 @@ struct FastTree {
                 {
                     Scope tm(g_phase.lcs, Timeline::LCS);
                     OffCpu w;
+                    g_leaf_requests.acquire();
+                    struct Back {
+                        ~Back() { g_leaf_requests.release(); }
+                    } back;
                     have = src.triangles_batch(ids.data(), offs.data(), (int)batch.size(), *buf);
                 }
                 struct Part { std::shared_ptr<Piece> pc; size_t off; };
@@ -797,6 +830,13 @@ struct FastTree {
         if (!prm.use_clustering || host_test("no_level_batch")) return false;
         const int n_splits = (int)splits.size(), n_evals = prm.num_evaluations, n_jobs = n_splits * n_evals;
         const int k = prm.subtree_size;
+        auto t_mark = std::chrono::steady_clock::now();
+        double t_part[5] = {0};
+        auto lap = [&](int what) {
+            const auto t = std::chrono::steady_clock::now();
+            t_part[what] += std::chrono::duration<double>(t - t_mark).count();
+            t_mark = t;
+        };
         // 1. the samples
         std::vector<std::vector<int>> sample_ids((size_t)n_jobs);
         parallel_for(n_jobs, [&](int j) {
@@ -816,6 +856,7 @@ struct FastTree {
             if (sample_ids[(size_t)j].empty()) std::copy(ids.begin(), ids.end(), out);
             else for (size_t t = 0; t < sample_ids[(size_t)j].size(); ++t) out[t] = ids[(size_t)sample_ids[(size_t)j][t]];
         });
+        lap(0);
         // 2. every sample's medoids
         std::vector<int> n_medoids((size_t)n_jobs, k), medoids((size_t)n_jobs * k);
         {
@@ -825,6 +866,7 @@ struct FastTree {
                                    prm.cluster_iters, medoids.data()))
                 return false;
         }
+        lap(1);
         // 3. every evaluation's seed sweep: seeds x members of its split, from scratch (d(seed 0, j) < +inf for every j, so
         //    starting one seed earlier from +inf leaves the row the reference starts from, FastTree.cpp:309-324)
         std::vector<int64_t> seed_off((size_t)n_jobs + 1, 0), col_off((size_t)n_jobs + 1, 0);
@@ -848,6 +890,7 @@ struct FastTree {
         if (odd) return false; // the split-by-split form knows what the reference does then
         std::vector<float> dist(cols.size());
         std::vector<int> assign(cols.size());
+        lap(2);
         {
             Scope t(g_phase.assign, Timeline::ASSIGN);
             OffCpu w;
@@ -855,6 +898,7 @@ struct FastTree {
                                         assign.data()))
                 return false;
         }
+        lap(3);
         // 4. the cheapest evaluation of every split (the first one among equals: strict <, FastTree.cpp:126-138)
         std::vector<float> cost((size_t)n_jobs);
         parallel_for(n_jobs, [&](int j) {
@@ -871,25 +915,55 @@ struct FastTree {
                 b.assignments.assign(assign.begin() + col_off[(size_t)j], assign.begin() + col_off[(size_t)j + 1]);
             }
         });
+        lap(4);
+        if (profile_on())
+            fprintf(stderr, "fasttree.level parts: %d evaluations: samples %.3f s, searches %.3f s, seed lists %.3f s, assignment %.3f s, costs %.3f s\n", n_jobs,
+                    t_part[0], t_part[1], t_part[2], t_part[3], t_part[4]);
         return true;
     }
 
-    // fn(i) for i in [0, count) on the pool's threads (the caller works too); small counts run here
+    // fn(i) for i in [0, count): the caller and up to n_threads - 1 helpers from the pool take the indices.  The caller never
+    // picks up other tasks meanwhile (a leaf batch waits for the GPU for tens of milliseconds), and helpers that get their turn
+    // late find nothing left to do.
     template <class Fn>
     void parallel_for(int count, Fn fn)
     {
-        if (!pool || count < 2) {
+        if (!pool || count < 2 || prm.n_threads < 2) {
             for (int i = 0; i < count; ++i) fn(i);
             return;
         }
-        TaskPool::Group group;
-        std::atomic<int> next{0};
-        const int workers = std::min(count, std::max(1, prm.n_threads));
-        for (int w = 0; w < workers; ++w)
-            pool->submit(group, (size_t)count, [&] {
-                for (int i = next++; i < count; i = next++) fn(i);
-            });
-        pool->wait(group);
+        struct Shared {
+            std::atomic<int> next{0};
+            int done = 0, count = 0;
+            std::function<void(int)> fn;
+            std::mutex mu;
+            std::condition_variable cv;
+            std::string error;
+            TaskPool::Group group;
+            void work()
+            {
+                for (int i = next++; i < count; i = next++) {
+                    std::string err;
+                    try {
+                        fn(i);
+                    } catch (const std::exception& e) {
+                        err = e.what();
+                    }
+                    std::lock_guard<std::mutex> lk(mu);
+                    if (!err.empty() && error.empty()) error = err;
+                    if (++done == count) cv.notify_all();
+                }
+            }
+        };
+        auto st = std::make_shared<Shared>();
+        st->count = count;
+        st->fn = fn;
+        const int helpers = std::min(count, prm.n_threads) - 1;
+        for (int w = 0; w < helpers; ++w) pool->submit(st->group, (size_t)1 << 40, [st] { st->work(); }); // (heaviest: next in the queue)
+        st->work();
+        std::unique_lock<std::mutex> lk(st->mu);
+        st->cv.wait(lk, [&] { return st->done == st->count; });
+        if (!st->error.empty()) throw std::runtime_error(st->error);
     }
 
     void run_levels(int n, tree_structure& tree)
@@ -912,7 +986,7 @@ struct FastTree {
                 } else
                     splits.push_back(sp.get());
             }
-            if (pool) submit_pieces(pieces, trees, tree); // this level's leaves: their triangles and trees run beside what follows
+            if (pool && !host_test("leaves_last")) submit_pieces(pieces, trees, tree); // this level's leaves: their triangles and trees run beside what follows
             const int n_splits = (int)splits.size();
             std::vector<Evaluation> best((size_t)n_splits);
             if (!splits.empty() && !evaluate_level_batched(splits, best)) {
@@ -980,8 +1054,11 @@ struct FastTree {
             frontier.swap(next);
         }
         if (pool) {
+            const auto t_tail = std::chrono::steady_clock::now();
             submit_pieces(pieces, trees, tree);
             pool->wait(trees);
+            if (profile_on())
+                fprintf(stderr, "fasttree.tail: %.3f s after the last level\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_tail).count());
         } else {
             for (auto& pc : pieces) {
                 SubsetSource sub(src, pc->ids);

@@ -143,11 +143,11 @@ def test_many_samples_in_one_call(engine, oracle, searcher):
     rng = np.random.default_rng(99)
     seqs = _family(rng, 2600, 150, 0.25)
     engine.upload_seqs(seqs)
-    shapes = [(2000, 100)] * 3 + [(600, 30)] * 2 + [(24, 24), (1, 1), (310, 7), (2050, 2), (1500, 600)]
+    shapes = [(2000, 100)] * 3 + [(600, 30)] * 2 + [(24, 24), (2, 2), (310, 7), (2050, 2), (1500, 600)]
     samples = [np.sort(rng.permutation(len(seqs))[:m]).astype(np.int32) for m, _ in shapes]
     ks = [k for _, k in shapes]
     got = engine.clarans_batch(samples, ks, 1, 0.1, 2)
-    for i in (0, 3, 7):
+    for i in (0, 3, 7):  # (7: 310 members, 7 medoids)
         want = searcher(_expected_triangle(oracle, seqs, samples[i], 1), len(samples[i]), ks[i], 1, 0.1, 2)
         assert got[i].tolist() == want.tolist(), i
     for i, (ids, k) in enumerate(zip(samples, ks)):
