@@ -134,6 +134,9 @@ bool contiguous(const Bucket& b)
 bool create_lane(lcsgpu_ctx* ctx, Lane& l, bool high_priority)
 {
     if (hipSetDevice(ctx->device) != hipSuccess) return false;
+    if (high_priority) // a lane that works while other lanes keep the GPU fed: no hipFree when a buffer grows
+        l.d_plan.keep_outgrown = l.d_out.keep_outgrown = l.d_carry.keep_outgrown = l.d_work.keep_outgrown = l.d_draws.keep_outgrown =
+            l.h_plan.keep_outgrown = l.h_small.keep_outgrown = true;
     if (high_priority) {
         int least = 0, greatest = 0;
         if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess || least == greatest) {
@@ -465,7 +468,7 @@ int lcsgpu_create(int device_id, lcsgpu_ctx** out_ctx)
     lcsgpu_ctx* ctx = new (std::nothrow) lcsgpu_ctx;
     if (!ctx) return fail(LCSGPU_E_NOMEM, "out of host memory");
     ctx->device = device_id;
-    ctx->lanes.resize(MAX_LANES + 1); // (the last slot: LaneGuard::FRONT)
+    ctx->lanes.resize(LANE_SLOTS); // (beyond MAX_LANES: LaneGuard::FRONT)
     ctx->lane_limit = n_lanes;
     // lane 0 now; the others (and the streams of the CLARANS batches) when first needed -- see Lane::created
     if (!create_lane(ctx, ctx->lanes[0])) {
@@ -506,6 +509,7 @@ int lcsgpu_reserve_lanes(lcsgpu_ctx* ctx, int32_t n_threads)
         }
         ctx->cv.notify_all();
     }
+    if (n_threads > 1) { LaneGuard front(ctx, LaneGuard::FRONT); } // a level-by-level caller: its front lane
     return LCSGPU_OK;
 }
 

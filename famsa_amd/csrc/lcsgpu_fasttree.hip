@@ -639,25 +639,20 @@ int lcsgpu_clarans_batch(lcsgpu_ctx* ctx, const int32_t* ids, const int64_t* off
     double t_prof[6] = {0};
     auto t_mark = std::chrono::steady_clock::now();
     auto lap = [&](int what, bool sync) {
-        if (!profile) return;
         if (sync) (void)hipStreamSynchronize(L.stream);
+        if (!profile) return;
         const auto t = std::chrono::steady_clock::now();
         t_prof[what] += std::chrono::duration<double>(t - t_mark).count();
         t_mark = t;
     };
-    std::unique_lock<ComputeGate> wave(ctx->gate, std::defer_lock); // the chip to the chains (lcsgpu_internal.h, ComputeGate)
+    std::unique_lock<ComputeGate> wave(ctx->gate, std::defer_lock);
     const int elem = ctx->max_len > 65535 ? 4 : 2;
     std::vector<int64_t> tri_base;
     int64_t count = 0;
     bool had_long = false;
-    int rc = batch_triangles_to_device(ctx, L, ids, offsets, n_jobs, elem, tri_base, &count, &had_long, [&] {
-        lap(1, false);
-        wave.lock();
-        lap(0, false);
-    });
+    int rc = batch_triangles_to_device(ctx, L, ids, offsets, n_jobs, elem, tri_base, &count, &had_long, [&] { lap(1, false); });
     if (rc) return rc;
-    if (!wave.owns_lock()) wave.lock();
-    lap(2, true);
+    lap(2, profile);
     double lcs_ms = 0;
     int lcs_launches = 0;
     if (had_long) { // (synchronised list by list: the timing is in g_last)
@@ -758,7 +753,13 @@ int lcsgpu_clarans_batch(lcsgpu_ctx* ctx, const int32_t* ids, const int64_t* off
     HIP_TRY(hipMemcpyAsync(base + o_chains, h_chains, (size_t)n_live * sizeof(lcsgpu::ClaransChain), hipMemcpyHostToDevice, L.stream));
     HIP_TRY(lcsgpu::launch_subset_distances_batch(L.d_out.p, elem, (const lcsgpu::ClaransChain*)(base + o_chains), n_live, max_n,
                                                   (const uint32_t*)ctx->d_lens.p, (const float*)ctx->d_powf.p, distance_kind, L.stream));
-    lap(4, true);
+    // the triangles and distances ran beside the other lanes' work (this lane's stream goes first); the chains run alone:
+    // the chip to them (lcsgpu_internal.h, ComputeGate)
+    HIP_TRY(hipEventRecord(L.ev_done, L.stream));
+    HIP_TRY(hipEventSynchronize(L.ev_done));
+    lap(4, false);
+    wave.lock();
+    lap(0, false);
     // the chains: normally one launch; a chain that runs out of positions (or, under LCSGPU_TUNE clarans_slice_us, of time)
     // comes back for another
     std::vector<int> todo((size_t)n_live);

@@ -14,6 +14,7 @@
 #include <cstring>
 #include <limits>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <random>
 #include <string>
@@ -46,6 +47,11 @@ struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
     bool owned = true; // false: a slice of somebody else's allocation (adopt); outgrown, it is replaced by an allocation of its own
+    // hipFree waits for the whole device.  A buffer that grows while other host threads keep the GPU fed (the FRONT lane of
+    // a level-by-level caller beside the leaf batches: 166 ms for one such free at 3 x 10^6 sequences) keeps what it has
+    // outgrown until release() instead -- at most as much again as it ends up with.
+    bool keep_outgrown = false;
+    std::vector<void*> outgrown;
     void adopt(void* slice, size_t n)
     {
         release();
@@ -56,7 +62,10 @@ struct DevBuf {
     hipError_t reserve(size_t n)
     {
         if (n <= cap) return hipSuccess;
-        if (p && owned) (void)hipFree(p);
+        if (p && owned) {
+            if (keep_outgrown) outgrown.push_back(p);
+            else (void)hipFree(p);
+        }
         p = nullptr;
         cap = 0;
         owned = true;
@@ -70,6 +79,8 @@ struct DevBuf {
     void release()
     {
         if (p && owned) (void)hipFree(p);
+        for (void* q : outgrown) (void)hipFree(q);
+        outgrown.clear();
         p = nullptr;
         cap = 0;
         owned = true;
@@ -78,10 +89,15 @@ struct DevBuf {
 struct PinBuf {
     void* p = nullptr;
     size_t cap = 0;
+    bool keep_outgrown = false; // as DevBuf's
+    std::vector<void*> outgrown;
     hipError_t reserve(size_t n)
     {
         if (n <= cap) return hipSuccess;
-        if (p) (void)hipHostFree(p);
+        if (p) {
+            if (keep_outgrown) outgrown.push_back(p);
+            else (void)hipHostFree(p);
+        }
         p = nullptr;
         cap = 0;
         size_t want = n + n / 4 + 256;
@@ -92,6 +108,8 @@ struct PinBuf {
     void release()
     {
         if (p) (void)hipHostFree(p);
+        for (void* q : outgrown) (void)hipHostFree(q);
+        outgrown.clear();
         p = nullptr;
         cap = 0;
     }
@@ -105,6 +123,8 @@ struct PinBuf {
 // queueing behind one stream; device-memory calls and the tree reducers always use lane 0, whose
 // stream is the one lcsgpu_stream() hands out.
 constexpr int MAX_LANES = 64;
+// Beyond the ordinary lanes: slot MAX_LANES = the FRONT lane (LaneGuard::FRONT).
+constexpr int LANE_SLOTS = MAX_LANES + 1;
 struct Lane {
     hipStream_t stream = nullptr;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
@@ -129,8 +149,9 @@ struct TextExport; // lcsgpu_text.hip: the state of lcsgpu_dist_text_begin .. _e
 // Who may have kernels on the chip: a wave of CLARANS chains (lcsgpu_clarans_batch: one workgroup per sample, each a long
 // chain of short dependent phases) wants the CUs to itself -- bulk LCS launches of other host threads on the same CUs make
 // every chain, and so the wave, several times slower (3 x 10^6 sequences: 278 chains 0.39 s beside the leaves' LCS batches,
-// 0.1 s alone).  Bulk LCS calls hold the gate shared while their kernels run (not while their results travel), a wave holds
-// it exclusively; a waiting wave goes first.
+// 0.04 s alone).  Bulk LCS calls hold the gate shared while their kernels run (not while their results travel), a wave holds
+// it exclusively; a waiting wave goes first.  (Keeping 64 CUs for small waves by CU-masked streams instead -- the bulk
+// launches masked to the other 192 -- did not keep the chains at their pace: 46-60 ms against 24, profiles/c5_levels_r06.txt.)
 struct ComputeGate {
     std::mutex mu;
     std::condition_variable cv;

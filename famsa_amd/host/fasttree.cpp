@@ -1079,7 +1079,7 @@ void run_fast(LcsSource& src, GT partial, const FastTreeParams& p, tree_structur
     // (trees.h, fasttree_pool_threads)
     const int n_cpu = std::max(1, p.n_threads);
     int n_pool = host_test_int("pool", fasttree_pool_threads(n_cpu)); // (FAMSA_HOST_TEST pool=N: sweeps)
-    src.expect_threads(n_pool);
+    src.expect_threads(4); // (the engine's lanes: the level-by-level walk asks from this thread, the leaf batches from three others)
     g_cpu.reset(n_pool > n_cpu ? n_cpu : 0);
     g_cpu.acquire(); // this thread works too
     struct Giveback {
