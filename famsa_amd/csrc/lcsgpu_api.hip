@@ -533,6 +533,8 @@ int lcsgpu_destroy(lcsgpu_ctx* ctx)
         if (l.copy_stream) (void)hipStreamDestroy(l.copy_stream);
         if (l.stream) (void)hipStreamDestroy(l.stream);
     }
+    for (DevBuf& c : ctx->sample_chunks) c.release();
+    ctx->sample_chunks.clear();
     ctx->d_tiles.release();
     ctx->d_tile_base.release();
     ctx->d_lens.release();
@@ -603,6 +605,8 @@ int lcsgpu_upload_ordered(lcsgpu_ctx* ctx, const uint8_t* codes, const uint64_t*
     ctx->n = -1;
     ctx->mst.active = false;
     text_release(ctx); // row blocks of the previous set
+    for (DevBuf& c : ctx->sample_chunks) c.release();
+    ctx->sample_chunks.clear();
     std::vector<uint32_t> lens(n);
     std::vector<uint8_t> quirk(n);
     uint32_t max_len = 0;

@@ -57,7 +57,8 @@ static int batch_triangles_to_device(lcsgpu_ctx* ctx, Lane& L, const int32_t* id
         plan_us[what] += std::chrono::duration_cast<std::chrono::microseconds>(t - t_mark).count();
         t_mark = t;
     };
-    HIP_TRY(L.d_out.reserve((size_t)count * elem_size));
+    // (a lane that serves these calls serves many of them, of the caller's batch size give or take: one allocation each)
+    HIP_TRY(L.d_out.reserve(L.d_out.cap ? (size_t)count * elem_size : (size_t)count * elem_size * 3 / 2));
     lap(0);
     if (any_long) { // the long-ref kernel keeps its 2-D grid: list by list
         if (before_launch) before_launch();
@@ -165,8 +166,8 @@ static int batch_triangles_to_device(lcsgpu_ctx* ctx, Lane& L, const int32_t* id
         HIP_TRY(hipStreamSynchronize(L.stream));
         L.plan_in_flight = false;
     }
-    HIP_TRY(L.h_plan.reserve(bytes));
-    HIP_TRY(L.d_plan.reserve(bytes));
+    HIP_TRY(L.h_plan.reserve(L.h_plan.cap ? bytes : bytes * 3 / 2));
+    HIP_TRY(L.d_plan.reserve(L.d_plan.cap ? bytes : bytes * 3 / 2));
     lap(2);
     char* h = (char*)L.h_plan.p;
     memcpy(h + col_off, ids, (size_t)n_total * 4);
@@ -668,23 +669,53 @@ int lcsgpu_clarans_batch(lcsgpu_ctx* ctx, const int32_t* ids, const int64_t* off
     const size_t o_states = at; at += a256((size_t)n_live * lcsgpu::CLARANS_STATE_WORDS * 4);
     const size_t o_ids = at; at += a256((size_t)n_total * 4);
     const size_t o_best = at; at += a256((size_t)med_off[n_jobs] * 4);
-    struct Place { size_t D, DM, cand, st, log; };
+    struct Place { char* D; char* DM; char* cand; char* st; char* log; };
     std::vector<Place> place((size_t)n_live);
     int max_n = 0, max_k = 0;
-    for (int q = 0; q < n_live; ++q) {
-        const int32_t j = live[(size_t)q];
-        const size_t n = (size_t)(offsets[j + 1] - offsets[j]), k = (size_t)n_medoids[j];
-        Place& p = place[(size_t)q];
-        p.D = at; at += a256(n * n * 4);
-        p.DM = at; at += a256(n * k * 4);
-        p.cand = at; at += a256(n * 4);
-        p.st = at; at += a256(n * 16);
-        p.log = at; at += a256((n + 1) * 4);
-        max_n = std::max(max_n, (int)n);
-        max_k = std::max(max_k, (int)k);
+    size_t sample_bytes = 0;
+    {   // every sample's work area out of the context's chunks (this call owns them: it holds the FRONT lane); what the chunks
+        // there are cannot hold comes out of ONE new chunk
+        auto area = [&](int q, size_t* o_DM, size_t* o_cand, size_t* o_st, size_t* o_log) {
+            const int32_t j = live[(size_t)q];
+            const size_t n = (size_t)(offsets[j + 1] - offsets[j]), k = (size_t)n_medoids[j];
+            *o_DM = a256(n * n * 4);
+            *o_cand = *o_DM + a256(n * k * 4);
+            *o_st = *o_cand + a256(n * 4);
+            *o_log = *o_st + a256(n * 16);
+            return *o_log + a256((n + 1) * 4);
+        };
+        size_t chunk = 0, used = 0; // the chunk being filled
+        for (int q = 0; q < n_live; ++q) {
+            const int32_t j = live[(size_t)q];
+            const size_t n = (size_t)(offsets[j + 1] - offsets[j]), k = (size_t)n_medoids[j];
+            size_t o_DM, o_cand, o_st, o_log;
+            const size_t o_D = 0, need = area(q, &o_DM, &o_cand, &o_st, &o_log);
+            while (chunk < ctx->sample_chunks.size() && ctx->sample_chunks[chunk].cap - used < need) {
+                ++chunk;
+                used = 0;
+            }
+            if (chunk == ctx->sample_chunks.size()) {
+                ctx->sample_chunks.emplace_back();
+                size_t rest = 0, a, b, c, d;
+                for (int r = q; r < n_live; ++r) rest += area(r, &a, &b, &c, &d);
+                rc = reserve_big(ctx, ctx->sample_chunks.back(), rest, "CLARANS samples");
+                if (rc) {
+                    ctx->sample_chunks.pop_back();
+                    return rc;
+                }
+                used = 0;
+            }
+            char* b = (char*)ctx->sample_chunks[chunk].p + used;
+            place[(size_t)q] = Place{b + o_D, b + o_DM, b + o_cand, b + o_st, b + o_log};
+            used += need;
+            sample_bytes += need;
+            max_n = std::max(max_n, (int)n);
+            max_k = std::max(max_k, (int)k);
+        }
     }
-    rc = reserve_big(ctx, L.d_work, at, "CLARANS batch");
+    rc = reserve_big(ctx, L.d_work, at, "CLARANS batch tables");
     if (rc) return rc;
+    at += sample_bytes; // (the profile line's figure)
     lap(3, false);
     char* base = (char*)L.d_work.p;
     const size_t host_bytes = a256((size_t)n_live * sizeof(lcsgpu::ClaransChain)) + a256((size_t)n_live * lcsgpu::CLARANS_STATE_WORDS * 4);
@@ -726,11 +757,11 @@ int lcsgpu_clarans_batch(lcsgpu_ctx* ctx, const int32_t* ids, const int64_t* off
         lcsgpu::ClaransChain& c = h_chains[q];
         memset(&c, 0, sizeof c);
         const Place& p = place[(size_t)q];
-        c.a.D = (const float*)(base + p.D);
-        c.a.DMt = (float*)(base + p.DM);
-        c.a.cand = (int32_t*)(base + p.cand);
-        c.a.st = (float4*)(base + p.st);
-        c.a.cost_log = (float*)(base + p.log);
+        c.a.D = (const float*)p.D;
+        c.a.DMt = (float*)p.DM;
+        c.a.cand = (int32_t*)p.cand;
+        c.a.st = (float4*)p.st;
+        c.a.cost_log = (float*)p.log;
         c.a.state = (int32_t*)(base + o_states) + (size_t)q * lcsgpu::CLARANS_STATE_WORDS;
         c.a.n_elems = sh.n;
         c.a.n_medoids = sh.k;

@@ -193,6 +193,9 @@ struct lcsgpu_ctx {
     int device = 0;
     TextExport* text = nullptr;
     ComputeGate gate;
+    // lcsgpu_clarans_batch: the samples' work areas (17 MB for 2000 members) come out of chunks that are kept from call to
+    // call and only ever added to -- a fresh multi-GB hipMalloc is ~26 ms per GB, and a free waits for the whole device
+    std::vector<lcsgpu_impl::DevBuf> sample_chunks;
     std::mutex mu; // guards the lane table
     std::condition_variable cv;
     std::vector<Lane> lanes;  // MAX_LANES slots; a slot costs nothing until its lane is created

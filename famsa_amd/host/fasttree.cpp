@@ -859,9 +859,9 @@ struct FastTree {
         lap(0);
         // 2. every sample's medoids
         std::vector<int> n_medoids((size_t)n_jobs, k), medoids((size_t)n_jobs * k);
-        {
+        {   // (this thread is the recursion's critical path: it keeps its core slot while it waits for the engine -- getting it
+            //  back from sixteen leaf-tree tasks cost up to 70 ms a level)
             Scope t(g_phase.clarans, Timeline::CLARANS);
-            OffCpu w;
             if (!src.clarans_batch(sample_global.data(), off.data(), n_jobs, (int)D, n_medoids.data(), 1, prm.cluster_fraction,
                                    prm.cluster_iters, medoids.data()))
                 return false;
@@ -893,7 +893,6 @@ struct FastTree {
         lap(2);
         {
             Scope t(g_phase.assign, Timeline::ASSIGN);
-            OffCpu w;
             if (!src.assign_seeds_batch(seeds_global.data(), seed_off.data(), cols.data(), col_off.data(), n_jobs, (int)D, dist.data(),
                                         assign.data()))
                 return false;
@@ -1080,8 +1079,8 @@ void run_fast(LcsSource& src, GT partial, const FastTreeParams& p, tree_structur
     const int n_cpu = std::max(1, p.n_threads);
     int n_pool = host_test_int("pool", fasttree_pool_threads(n_cpu)); // (FAMSA_HOST_TEST pool=N: sweeps)
     src.expect_threads(4); // (the engine's lanes: the level-by-level walk asks from this thread, the leaf batches from three others)
-    g_cpu.reset(n_pool > n_cpu ? n_cpu : 0);
-    g_cpu.acquire(); // this thread works too
+    g_cpu.reset(n_pool > n_cpu ? n_cpu + 1 : 0); // (+ 1: this thread's own, kept through the levels)
+    g_cpu.acquire();
     struct Giveback {
         ~Giveback() { g_cpu.reset(0); }
     } giveback;
