@@ -80,6 +80,13 @@ static int shard_begin(lcsgpu_ctx* ctx, Lane& L, void* d_tri, int elem, int32_t 
     // rows (the DRAM pages they share): n = 100 000, column passes of one tree: 2 chunks 21.2 ms, 8: 18.2, 16: 16.6,
     // 32: 15.4, 64: 14.1, 128: 13.7 (+0.5 fold), 256: 13.7 (+0.9), 512: 14.2 (+1.8) -> about 1024 rows per chunk
     int n_chunks = std::max(1, std::min(96, (rows + 1023) / 1024));
+    {   // a small block has too few column blocks to fill the chip with 1024-row chunks (13 774 sequences: 54 x 14 workgroups,
+        // half of them above the diagonal, 62 dependent batches each: 275 us a pass, 0.7 TB/s): shorter chunks until there are
+        // ~4096 workgroups, down to 64 rows
+        const int col_blocks = std::max(1, (r1 + 255) / 256);
+        const int want = std::min({256, (4096 + col_blocks - 1) / col_blocks, std::max(1, rows / 64)});
+        n_chunks = std::max(n_chunks, want);
+    }
     if (!d_tri) n_chunks = 0; // no passes, no partials
     const int rows_per_chunk = std::max(1, (rows + std::max(n_chunks, 1) - 1) / std::max(n_chunks, 1));
     const size_t key = sizeof(lcsgpu::MstKey);
