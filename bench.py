@@ -16,7 +16,7 @@ same for every N.
     python bench.py [--gpus N --steps K --warmup W] [--n-seqs 100000 --seq-len 400]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
     python bench.py --workload family|realmix [--order sorted|input]     ragged lengths (below)
-    python bench.py --pmc                                                roofline.traffic measured by this run (below)
+    python bench.py --pmc off                                            without the two profiled passes behind roofline.traffic (below)
 
 Workloads.  The default (`uniform`: BASELINE.json's configs[3], 100 000 x 400 aa) and its line are what they always
 were.  `--workload family` (one ancestor of --seq-len 300 residues, 25 % substitutions, lengths uniform in [0.7 L, L]:
@@ -26,10 +26,11 @@ descending: what every tree generator uploads) or `--order input` as read (what 
 has the same fields; cells, algorithmic bytes and VALU operations are summed over the actual lengths
 (sum over pairs of len_partner x ceil(len_ref / 32) x 3 lane-ops), `config.workload` names the set and the order.
 
-`--pmc` (one rank): after the timed loop this command is run again twice under `rocprofv3 --kernel-trace --pmc FETCH_SIZE`
-resp. `WRITE_SIZE` (one step each, separate passes as MI355X_MICROARCH.md prescribes), and `roofline.traffic` =
-(2 x FETCH_SIZE + WRITE_SIZE) x 1024 summed over the LCS kernels of the step (gfx950: FETCH_SIZE counts half of a
-wide streaming read).  Without the flag, or without rocprofv3 on PATH, `traffic` is null -- it is never imported.
+`roofline.traffic` (one rank): after the timed loop this command is run again twice under `rocprofv3 --kernel-trace --pmc
+FETCH_SIZE` resp. `WRITE_SIZE` (one step each, separate passes as MI355X_MICROARCH.md prescribes; ~15 s each), and
+`roofline.traffic` = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 summed over the LCS kernels of the step (gfx950: FETCH_SIZE counts
+half of a wide streaming read).  By default whenever rocprofv3 is on PATH (`--pmc auto`); with `--pmc off`, with more than one
+rank, or without rocprofv3 `traffic` is null -- it is never imported from a file.
 
 Both forms work for N > 1: started plainly (no WORLD_SIZE in the environment), `bench.py --gpus N` starts its
 N ranks itself (one process per GPU, LOCAL_RANK binding, rendezvous on 127.0.0.1) and relays rank 0's line.
@@ -190,15 +191,22 @@ def measure_traffic(argv):
     exe = shutil.which("rocprofv3")
     if not exe:
         return None, "rocprofv3 is not on PATH"
-    keep = [a for a in argv if a not in ("--pmc",)]
+    keep, skip = [], False
+    for a in argv:  # the command as it was given, without its own --pmc [value]
+        if skip and a in ("auto", "on", "off"):
+            skip = False
+            continue
+        skip = a == "--pmc"
+        if not skip and not a.startswith("--pmc="):
+            keep.append(a)
     sums = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="bench_pmc_", dir="/tmp")
         cmd = [exe, "--kernel-trace", "--pmc", counter, "-d", d, "-o", "run", "--", sys.executable, os.path.abspath(__file__)] + keep + \
-              ["--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-parity"]
+              ["--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-parity", "--pmc", "off"]
         try:
             subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
-                           timeout=900, check=True)
+                           timeout=300, check=True)
             dbs = [os.path.join(r, f) for r, _, fs in os.walk(d) for f in fs if f.endswith(".db")]
             total = 0.0
             for path in dbs:
@@ -389,8 +397,9 @@ def main():
                          "(the C5 shape; --seq-len defaults to 300 then); realmix: the 13 774 upstream real sequences")
     ap.add_argument("--order", choices=["sorted", "input"], default="sorted",
                     help="ragged workloads: FAMSA's working order (length descending) or the order as read")
-    ap.add_argument("--pmc", action="store_true",
-                    help="measure roofline.traffic: this command again under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (one rank)")
+    ap.add_argument("--pmc", nargs="?", const="on", default="auto", choices=["auto", "on", "off"],
+                    help="roofline.traffic: this command again under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, one step each, after the "
+                         "timed loop (one rank).  auto (default): when rocprofv3 is on PATH; on: report why if it cannot; off: traffic = null")
     ap.add_argument("--phase-timeout-s", type=float, default=600.0,
                     help="rendezvous, self-check and every other untimed phase with more than one rank: give up after this long, naming the rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -593,7 +602,8 @@ def main():
         out["ranks"] = {"mode": "ranks", "world": world, "rccl_ranks": rccl_ranks, "transport": transport, "transport_report": report,
                         "kernel_ms_per_rank": per_rank_kernel_ms, "kernel_ms_min": float(min(per_rank_kernel_ms)),
                         "kernel_ms_max": float(max(per_rank_kernel_ms)), "self_check": check}
-        if args.pmc and world == 1:
+        import shutil
+        if world == 1 and (args.pmc == "on" or (args.pmc == "auto" and shutil.which("rocprofv3"))):
             eng.close()  # the profiled child gets the device to itself
             out["roofline"]["traffic"], out["roofline"]["traffic_source"] = measure_traffic(sys.argv[1:])
         if not args.no_cpu_baseline and world == 1:
@@ -644,7 +654,7 @@ def result_line(args, n, L, world, elapsed, k_ms, my_pairs, total_pairs, fused, 
     value = cells * args.steps / elapsed / 1e9
     achieved = algo_bytes / (k_ms * 1e-3) / 1e9
     valu_rate = my_ops / (k_ms * 1e-3)
-    traffic, traffic_source = None, "not measured: run with --pmc (this command again under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
+    traffic, traffic_source = None, "not measured (--pmc off, more than one rank, or no rocprofv3 on PATH)"
     return {
         "metric": "lcs_gcell_updates_per_s",
         "value": value,

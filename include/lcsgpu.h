@@ -7,6 +7,13 @@
  * reference's src/).  A maintainer would bind these from the batch-distance templates
  * of tree/AbstractTreeGenerator.hpp -- INTEGRATION.md shows the binding.
  *
+ * NO GPU, NO RESULT: this library is the gfx950 path and nothing else.  Without a usable device lcsgpu_create answers
+ * LCSGPU_E_NODEVICE, and a HIP error inside any call comes back as LCSGPU_E_HIP -- there is no CPU implementation behind
+ * this ABI and none is substituted silently (SURVEY.md 8b sketched one as "plumbing"; the build has none: a caller that
+ * wants a CPU path keeps the reference's own CLCSBP).  The only calls that work without a device are the pure host
+ * helpers: lcsgpu_version, lcsgpu_last_error, lcsgpu_device_count, lcsgpu_encode, lcsgpu_mst_merge_host,
+ * lcsgpu_mst_order_edges.
+ *
  * Conventions: plain C types only; every function returns 0 on success or a negative
  * LCSGPU_E_* code, never throws; lcsgpu_last_error() gives a thread-local message.
  * The caller owns every buffer it passes.  A context is bound to one GPU and may be used from
@@ -36,6 +43,8 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* the library is built with -fvisibility=hidden: what is declared here is what it exports */
+#pragma GCC visibility push(default)
 
 #define LCSGPU_OK 0
 #define LCSGPU_E_INVALID (-1)  /* bad argument */
@@ -48,8 +57,9 @@ extern "C" {
 typedef struct lcsgpu_ctx lcsgpu_ctx;
 
 /* Library / build information: "lcsgpu <version> gfx950 recolor=<on|off|failed> kernels=<id>/<id>" -- kernels= names the
- * device code of the two LCS translation units (sha256 prefix of the listings they were assembled from: equal ids =
- * the same kernels instruction for instruction; bench.py matches committed profiles to the running library by it);
+ * device code of the two LCS translation units (sha256 prefix of the listings they were assembled from, without the
+ * __hip_cuid_<hash> symbol the compiler derives from the output path: equal ids = the same kernels instruction for
+ * instruction wherever they were built; bench.py matches committed profiles to the running library by it);
  * recolor= says how the hot kernels were built: with the register-bank renaming pass and its equivalence check passed ("on"), without the pass
  * on request ("off", make RECOLOR=0), or as compiled because the pass or its check failed ("failed": results are the
  * same, the LCS kernels ~5 % slower). */
@@ -274,10 +284,12 @@ int lcsgpu_mst_order_edges(lcsgpu_mst_edge* edges, int32_t n);
  * out_left/out_right (HOST, n-1 entries each): children of internal node n+k, k = 0..n-2, ids as in
  * tree_structure (leaves 0..n-1).  Returns LCSGPU_E_INVALID for inputs on which the reference's
  * algorithm is undefined (no finite nearest neighbour, e.g. a sequence with LCS 0 to all others).
- * How the n-1 merges run (all forms give the reference's tree bit for bit): while n x 2n floats fit next to
- * the LCS triangle (n <= ~158 000 on 288 GB) in batches of up to 32 merges per three launches -- the next picks are the
- * next entries of the rows' sorted (min_dist, index) order, checked afterwards against the keys of the clusters the batch
- * created (LCSGPU_UPGMA_BATCH=0|8|16|32); else on the n x n matrix, or on the packed triangle, with one launch per merge.
+ * How the n-1 merges run (all forms give the reference's tree bit for bit): on an n x (n + n/10) float matrix
+ * -- live clusters keep a row, new clusters take the next free column, the columns are compacted in place when they run
+ * out; 45 GB at 100 000 sequences, the LCS triangle itself only ever exists block-wise -- in batches of up to 32 merges per
+ * three launches: the next picks are the next entries of the rows' sorted (min_dist, index) order, checked afterwards
+ * against the keys of the clusters the batch created (LCSGPU_UPGMA_BATCH=0|8|16|32).  Where that matrix does not fit: the
+ * n x n matrix, then the packed float triangle, with one launch per merge (LCSGPU_UPGMA_LAYOUT=square|triangle forces one).
  * Replaces: UPGMA::computeDistances + UPGMA::computeTree (tree/UPGMA.cpp:75-109, 114-295). */
 int lcsgpu_upgma(lcsgpu_ctx* ctx, int distance_kind, int modified, int32_t* out_left, int32_t* out_right);
 
@@ -318,8 +330,8 @@ int lcsgpu_nj(lcsgpu_ctx* ctx, int distance_kind, int32_t* out_left, int32_t* ou
  *   EVERY context of the call (its own block's LCS launch), so a caller sees how balanced the row blocks ran.
  * Device-to-device copies between contexts switch peer access on for the device pair at first use; where the
  * devices cannot address each other the copy is staged through pinned host memory (slower, same result).  Test
- * switches (environment): LCSGPU_FORCE_PEER_COPY=1 makes same-device contexts take the peer-copy branch,
- * LCSGPU_FORCE_HOST_STAGING=1 makes every inter-context copy take the host-staging branch. */
+ * switch (environment): LCSGPU_TRANSPORT=peer makes same-device contexts take the hipMemcpyPeerAsync branch too (so a
+ * one-GPU box runs it), LCSGPU_TRANSPORT=host makes every copy between contexts take the pinned-host path. */
 int lcsgpu_multi_lcs_triangle(lcsgpu_ctx* const* ctxs, int32_t n_ctx, int32_t row_begin, int32_t row_end, void* out,
                               int elem_size);
 int lcsgpu_multi_upgma(lcsgpu_ctx* const* ctxs, int32_t n_ctx, int distance_kind, int modified, int32_t* out_left,
@@ -433,6 +445,7 @@ int lcsgpu_total_kernel_ms(lcsgpu_ctx* ctx, double* ms);
  * work behind the engine's. */
 void* lcsgpu_stream(lcsgpu_ctx* ctx);
 
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

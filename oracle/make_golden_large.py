@@ -5,6 +5,7 @@ only; minutes of CPU.  Writes tests/golden/meta_large.json (sha256 values only -
 regenerated deterministically by famsa_amd/seqio.py on the GPU box).
 
     python oracle/make_golden_large.py [c3] [c4] [c5] [c5huge] [c4upgma] [realmix] [c4slink] [c3indel] [c4indel] [realmixnj]
+                                       [familyindel] [realmixindel]
                                                                                     (default: c3 c5 c4)
 
 c5huge = the 3 000 000-sequence family set (BASELINE config C5's size); c4upgma = -gt upgma / upgma_modified at
@@ -163,6 +164,39 @@ def realmix(ref, meta):
     save(meta)
 
 
+def family_indel(ref, meta, n=100000):
+    """-dist indel_div_lcs on a RAGGED set (family, lengths 210-300): at one fixed length both distances are monotone in the
+    LCS length and single linkage gives the same tree for either (synth10k / synth100k: sl_indel == sl by construction);
+    here the two Transforms order the pairs differently (reference tree/AbstractTreeGenerator.hpp:65-75)."""
+    path = f"/tmp/golden_family_{n}_300.fasta"
+    seqio.family_fasta(n, 300, path)
+    h = ref.open_fasta(path)
+    key = f"family{n}"
+    rec = meta.get(key, {"n": n, "len": 300})
+    for gt, distance in (("sl", 0), ("upgma", 0), ("sl", 1)):
+        tag = "" if distance == 1 else "_indel"
+        t0 = time.time()
+        rec[f"{gt}{tag}_newick_sha256"] = sha(ref.tree(h, gt, distance=distance, threads=THREADS, cap=max(1 << 25, 24 * n)))
+        rec[f"{gt}{tag}_reference_seconds_{THREADS}_threads"] = round(time.time() - t0, 1)
+        print(key, gt + tag, "%.0f s" % (time.time() - t0), flush=True)
+        meta[key] = rec
+        save(meta)
+    ref.close(h)
+
+
+def realmix_indel(ref, meta):
+    """-dist indel_div_lcs -gt sl / upgma on the 13 774-record real set (lengths 21-210)."""
+    path = "/tmp/golden_realmix.fasta"
+    seqio.realmix_fasta(oracle_bind.GOLDEN, path)
+    h = ref.open_fasta(path)
+    for gt in ("sl", "upgma"):
+        t0 = time.time()
+        meta["realmix"][f"{gt}_indel_newick_sha256"] = sha(ref.tree(h, gt, distance=0, threads=THREADS))
+        print("realmix", gt, "indel %.0f s" % (time.time() - t0), flush=True)
+    ref.close(h)
+    save(meta)
+
+
 def realmix_nj_keepdups(ref, meta):
     """-gt nj -keep-duplicates on the 13 774-record real set (the reference's O(n^3) loop on one thread)."""
     path = "/tmp/golden_realmix.fasta"
@@ -186,7 +220,7 @@ def main():
          "c4slink": lambda r, m: c4(r, m, ("slink",)),
          "c3indel": lambda r, m: c4(r, m, ("sl", "upgma"), distance=0, n=10000, key="synth10k"),
          "c4indel": lambda r, m: c4(r, m, ("sl", "upgma"), distance=0),
-         "realmixnj": realmix_nj_keepdups}[w](ref, meta)
+         "realmixnj": realmix_nj_keepdups, "familyindel": family_indel, "realmixindel": realmix_indel}[w](ref, meta)
     print(json.dumps(load(), indent=1))
 
 
