@@ -26,14 +26,8 @@ namespace famsa_host {
 namespace {
 
 // coarse phase timers, printed when LCSGPU_PROFILE is set
-struct PhaseTimers {
+struct PhaseTimers { // printed and zeroed by build_tree_fast
     double lcs = 0, clarans = 0, partial = 0, assign = 0;
-    ~PhaseTimers()
-    {
-        if (profile_on() && (lcs + clarans + partial + assign) > 0)
-            fprintf(stderr, "fasttree.lcs_calls=%.3f\nfasttree.clarans=%.3f\nfasttree.partial_trees=%.3f\nfasttree.assign=%.3f\n",
-                    lcs, clarans, partial, assign);
-    }
 } g_phase;
 std::mutex g_phase_mu;
 // LCSGPU_PROFILE: how many threads are in which phase over the time of the run, in steps of 50 ms (the recursion's timeline)
@@ -1107,6 +1101,7 @@ void build_tree_fast(LcsSource& src, GT partial, Distance dist, const FastTreePa
     if (profile_on()) {
         fprintf(stderr, "fasttree.lcs_calls=%.3f\nfasttree.clarans=%.3f\nfasttree.partial_trees=%.3f\nfasttree.assign=%.3f\n", g_phase.lcs, g_phase.clarans,
                 g_phase.partial, g_phase.assign);
+        g_phase = PhaseTimers(); // (a library caller's next tree starts from zero)
         g_timeline.dump();
     }
 }

@@ -386,7 +386,12 @@ bool GpuLcsSource::clarans(const int* ids, int n_ids, int distance_kind, int n_m
     const double t0 = now_s();
     lcsgpu_ctx* c = pick();
     const int rc = lcsgpu_clarans(c, ids, n_ids, distance_kind, n_medoids, n_fixed, explore_fraction, num_local, medoids);
-    if (rc == LCSGPU_E_UNSUPPORTED) return false;
+    if (rc == LCSGPU_E_UNSUPPORTED) {
+        static std::atomic<bool> told{false};
+        if (profile_on() && !told.exchange(true))
+            fprintf(stderr, "[famsa-gpu] %s -- such samples are searched on the host (one thread each)\n", lcsgpu_last_error());
+        return false;
+    }
     check(rc, "lcsgpu_clarans");
     note(st_clarans_, now_s() - t0, (double)n_ids * (n_ids - 1) / 2);
     add_kernel_ms(c);
@@ -448,6 +453,9 @@ bool GpuLcsSource::clarans_batch(const int* ids, const int64_t* offsets, int n_j
                                             explore_fraction, num_local, medoids_out + med_off[(size_t)j0]);
         if (rc == LCSGPU_E_UNSUPPORTED) {
             unsupported = true;
+            static std::atomic<bool> told{false};
+            if (profile_on() && !told.exchange(true))
+                fprintf(stderr, "[famsa-gpu] %s -- such samples are searched on the host (one thread each)\n", lcsgpu_last_error());
             return;
         }
         check(rc, "lcsgpu_clarans_batch");

@@ -43,7 +43,8 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
-/* the library is built with -fvisibility=hidden: what is declared here is what it exports */
+typedef struct lcsgpu_ctx lcsgpu_ctx; /* (opaque; declared before the push below: the type itself exports nothing) */
+/* the library is built with -fvisibility=hidden: the functions declared here are the functions it exports */
 #pragma GCC visibility push(default)
 
 #define LCSGPU_OK 0
@@ -53,8 +54,6 @@ extern "C" {
 #define LCSGPU_E_NOMEM (-4)
 #define LCSGPU_E_STATE (-5)    /* e.g. compute before upload */
 #define LCSGPU_E_UNSUPPORTED (-6) /* shape outside what a device reducer handles; the host form applies */
-
-typedef struct lcsgpu_ctx lcsgpu_ctx;
 
 /* Library / build information: "lcsgpu <version> gfx950 recolor=<on|off|failed> kernels=<id>/<id>" -- kernels= names the
  * device code of the two LCS translation units (sha256 prefix of the listings they were assembled from, without the
