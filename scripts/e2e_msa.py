@@ -57,6 +57,11 @@ def main():
     realmix = "/tmp/realmix.fasta"
     seqio.realmix_fasta(os.path.join(ROOT, "tests/golden"), realmix)
     sets.append(("real sets as one input (13774 seqs)", realmix))
+    codes, offsets = seqio.synth_uniform(10000, 400)
+    seqio.to_fasta(codes, offsets, "/tmp/synth10k.fasta")
+    sets.append(("synthetic 10000 x 400 aa (C3)", "/tmp/synth10k.fasta"))
+    seqio.family_fasta(50000, 300, "/tmp/family50k.fasta")
+    sets.append(("synthetic family 50000 x 210-300 aa", "/tmp/family50k.fasta"))
     rows = []
     for name, fasta in sets:
         for gt in ("sl", "upgma"):

@@ -173,7 +173,7 @@ def test_c4_row_block_contexts_tree_and_sampled_triangle(oracle, synth100k):
             e.close()
 
 
-@pytest.mark.parametrize("n,env", [(200000, {}), (1000000, {}), (200000, {"LCSGPU_TUNE": "clarans_slice_us=150,clarans_draws=500,clarans_groups=2"})],
+@pytest.mark.parametrize("n,env", [(200000, {}), (1000000, {}), (200000, {"LCSGPU_TUNE": "clarans_slice_us=150,clarans_draws=500,assign_batch_kb=4096,narrow_lists=0"})],
                          ids=["200000", "1000000", "200000-short-slices"])
 def test_c5_medoid_tree(tmp_path, n, env):
     rec = META[f"family{n}"]
@@ -183,6 +183,34 @@ def test_c5_medoid_tree(tmp_path, n, env):
     out = str(tmp_path / "medoid.dnd")
     cli("-medoidtree", "-gt", "upgma", "-gt_export", path, out, env=env)
     assert os.path.getsize(out) == rec["newick_bytes"]
+    assert file_sha(out) == rec["medoid_upgma_newick_sha256"]
+
+
+@pytest.mark.parametrize("gt,dist", [("sl", "indel_div_lcs"), ("upgma", "indel_div_lcs"), ("sl", "indel075_div_lcs")])
+def test_ragged_100000_with_both_distances(tmp_path, gt, dist):
+    """-dist indel_div_lcs where it DISCRIMINATES: at one fixed length (synth10k / synth100k) both Transforms are monotone
+    in the LCS length, so single linkage gives the same tree for either and those sl_indel pins equal the sl pins by
+    construction; on the ragged family set (lengths 210-300) the two order the pairs differently
+    (reference tree/AbstractTreeGenerator.hpp:65-75; the pins: oracle/make_golden_large.py familyindel)."""
+    tag = "_indel" if dist == "indel_div_lcs" else ""
+    want = pinned("family100000", f"{gt}{tag}_newick_sha256")
+    if "sl_indel_newick_sha256" in META.get("family100000", {}) and "sl_newick_sha256" in META["family100000"]:
+        assert META["family100000"]["sl_indel_newick_sha256"] != META["family100000"]["sl_newick_sha256"]  # it does discriminate
+    path = str(tmp_path / "family_100000.fasta")
+    seqio.family_fasta(100000, 300, path)
+    out = str(tmp_path / "t.dnd")
+    cli("-gt", gt, "-dist", dist, "-gt_export", path, out)
+    assert file_sha(out) == want
+
+
+def test_c5_level_batches_against_split_by_split(tmp_path):
+    """The level-by-level walk with the engine's batched calls (lcsgpu_clarans_batch, lcsgpu_assign_seeds_batch) and the same
+    walk asking split by split (lcsgpu_clarans, lcsgpu_assign_seeds): one tree, the reference's."""
+    rec = META["family200000"]
+    path = str(tmp_path / "family_200000.fasta")
+    seqio.family_fasta(200000, rec["len"], path)
+    out = str(tmp_path / "split_by_split.dnd")
+    cli("-medoidtree", "-gt", "upgma", "-gt_export", path, out, env={"FAMSA_HOST_TEST": "no_level_batch"})
     assert file_sha(out) == rec["medoid_upgma_newick_sha256"]
 
 

@@ -56,6 +56,17 @@ def test_trees(fasta, tmp_path, gt, keep):
     assert file_sha(out) == REC[f"{gt}{'_keepdups' if keep else ''}_newick_sha256"]
 
 
+@pytest.mark.parametrize("gt", ["sl", "upgma"])
+def test_trees_with_the_other_distance(fasta, tmp_path, gt):
+    """-dist indel_div_lcs on ragged lengths (21-210 aa): the pins differ from the default distance's."""
+    if f"{gt}_indel_newick_sha256" not in REC:
+        pytest.skip("the reference run is not committed yet (oracle/make_golden_large.py realmixindel)")
+    assert REC[f"{gt}_indel_newick_sha256"] != REC[f"{gt}_newick_sha256"]
+    out = str(tmp_path / "t.dnd")
+    cli("-gt", gt, "-dist", "indel_div_lcs", "-gt_export", fasta, out)
+    assert file_sha(out) == REC[f"{gt}_indel_newick_sha256"]
+
+
 @pytest.mark.parametrize("keep", [False, True], ids=["unique", "keep-duplicates"])
 @pytest.mark.parametrize("gt", ["sl", "upgma"])
 def test_medoid_trees(fasta, tmp_path, gt, keep):
