@@ -15,14 +15,14 @@ echo "# kernel-trace: rocprofv3 --kernel-trace --stats -- python bench.py --step
 echo "# PMC passes:  rocprofv3 --kernel-trace --pmc <counters> -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-parity"
 echo "# durations in MICROSECONDS (rocpd top_kernels); FETCH_SIZE / WRITE_SIZE in KiB, FETCH_SIZE reads 1/2 of a wide streaming read on gfx950"
 } > "$S"
-rm -rf /tmp/prof_kt; rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -o run -- python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-parity > $OUT/bench_${TAG}_under_rocprof.json 2>/dev/null
+rm -rf /tmp/prof_kt; rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -o run -- python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-parity --pmc off > $OUT/bench_${TAG}_under_rocprof.json 2>/dev/null
 python $ROOT/scripts/rocpd_summary.py $(find /tmp/prof_kt -name "*.db") >> "$S"
 i=0
 for set in "FETCH_SIZE" "WRITE_SIZE" \
            "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES SQ_BUSY_CYCLES" \
            "GRBM_GUI_ACTIVE SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS"; do
   i=$((i+1)); rm -rf /tmp/prof_pmc$i
-  rocprofv3 --kernel-trace --pmc $set -d /tmp/prof_pmc$i -o run -- python $ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-parity > /dev/null 2>&1
+  rocprofv3 --kernel-trace --pmc $set -d /tmp/prof_pmc$i -o run -- python $ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-parity --pmc off > /dev/null 2>&1
   python $ROOT/scripts/rocpd_summary.py $(find /tmp/prof_pmc$i -name "*.db") >> "$S"
 done
 python - "$S" "$OUT/pmc_${TAG}.json" <<'EOP'
