@@ -965,6 +965,15 @@ struct FastTree {
         frontier.emplace_back(new Subset{std::vector<int>((size_t)n), n});
         std::iota(frontier[0]->ids.begin(), frontier[0]->ids.end(), 0);
         TaskPool::Group trees; // the leaf and seed trees of all levels
+        struct Drain { // an error on the way out must not leave tasks behind that write to `tree` and count down `trees`
+            TaskPool* pool;
+            TaskPool::Group& g;
+            ~Drain()
+            {
+                if (!pool) return;
+                try { pool->wait(g); } catch (...) {}
+            }
+        } drain{pool, trees};
         std::vector<std::shared_ptr<Piece>> pieces;
         for (int depth = 0; !frontier.empty(); ++depth) {
             const auto t_level = std::chrono::steady_clock::now();
