@@ -22,8 +22,13 @@ struct FuseArgs {
     const double* pow_table;     // pow(i, 0.75) from the host's libm
     int32_t kind;                // LCSGPU_DIST_*
     int32_t on;
+    // LENGTH BOUND (MSTPrim's pruning, reference tree/MSTPrim.cpp:450-467, for whole tiles): a pair of lengths (a, b) cannot
+    // be closer than Transform(lcs = min(a, b)); a workgroup whose tile's smallest such bound is STRICTLY greater than the
+    // distance of every record its rows and columns already hold can change none of them and skips its LCS work.
+    int32_t prune;
+    unsigned long long* stats;   // [0] workgroups that computed, [1] workgroups the bound let go (or NULL)
 };
-constexpr size_t FUSE_LDS_BYTES = 256 * 8 + 4 * 32 * 8; // per-column records + per-(wave, row) records
+constexpr size_t FUSE_LDS_BYTES = 256 * 8 + 4 * 32 * 8 + 4 * 32; // per-column records + per-(wave, row) records + the bound's reductions
 
 struct RowsArgs {
     // the uploaded sequence set (device)
@@ -56,6 +61,11 @@ struct RowsArgs {
     // tri_prefix[tri_rows] = grid size.  NULL = plain 2-D grid (x = column block, y = ref tile).
     const int32_t* tri_prefix;
     int32_t tri_rows;
+    // ... walked by DIAGONALS instead (fused launches with the length bound on: the tiles next to the diagonal pair
+    // sequences of like lengths -- they make the records mature that let the far tiles go): diag_prefix[d] = first block of
+    // the tiles d column blocks away from their row's last one, diag_prefix[diag_count] = grid size.  NULL = row by row.
+    const int32_t* diag_prefix;
+    int32_t diag_count;
     // (MODE_RECT with jobs -- lcsgpu_assign_seeds_batch: several rectangles in one launch; ref k writes the row
     // out + ref_out0[k], column c of the concatenated list at its offset c - ref_col0[k].)
     // Several triangles in one launch (lcsgpu_lcs_triangles_batch): 1-D grid, workgroup b does
@@ -167,7 +177,7 @@ struct BoruvkaArgs {
 hipError_t launch_boruvka_init(const BoruvkaArgs& a, hipStream_t stream);
 // local half by the LCS launch (run_rows with FuseArgs over the block's rows): reset the records before it,
 // turn them into a.best afterwards
-hipError_t launch_boruvka_fuse_reset(const BoruvkaArgs& a, hipStream_t stream);
+hipError_t launch_boruvka_fuse_reset(const BoruvkaArgs& a, bool keep, hipStream_t stream);
 hipError_t launch_boruvka_fuse_fold(const BoruvkaArgs& a, hipStream_t stream);
 // local half of a round: a.best[v] = best edge of v to another component among the pairs of this row block
 hipError_t launch_boruvka_best(const BoruvkaArgs& a, int elem_size, hipStream_t stream);

@@ -307,6 +307,105 @@ __device__ __forceinline__ void fuse_group(const RowsArgs& a, lds_u64* f_col, ld
     f_col[tid] = crec;
 }
 
+// The length bound for a whole tile (FuseArgs::prune; call after fuse_init and a barrier): true if no pair of the tile can
+// improve a record.  A pair's distance is at least Transform(lcs = lmax, indel = gap) with gap = the distance between the
+// length ranges of the tile's rows and columns and lmax = the longest LCS their lengths allow: the pow table and IEEE
+// division are monotone, so the bound never exceeds a pair's distance; the comparison is STRICT, so an equal distance --
+// which the id order might prefer -- is never let go.  Records only improve: a stale (larger) one only makes the test weaker.
+__device__ __forceinline__ bool fuse_tile_is_useless(const RowsArgs& a, const lds_u64* f_col, const lds_u64* f_row, uint32_t* red,
+                                                     int ref0, int nr, int c, int col_limit, int tid)
+{
+    const FuseArgs& f = a.fuse;
+    int rid_last = 0; // the tile's largest row (fused launches: row == ref id; the refs of a class need not be contiguous)
+    for (int r = 0; r < nr; ++r) {
+        const int rid = a.ref_ids ? a.ref_ids[ref0 + r] : a.ref_begin + ref0 + r;
+        rid_last = rid > rid_last ? rid : rid_last;
+    }
+    const int pid = a.col_begin + c;
+    const bool has = c < col_limit && pid < rid_last; // this column has a pair in the tile
+    uint32_t lmin = 0xffffffffu, lmax = 0u, open = 0u; // open: a vertex without a record (nothing bounds it)
+    unsigned long long dmax = 0ull;                    // distances are >= 0: their bits order like the values
+    auto take = [&](fuse_rec rec, uint32_t len_v) {
+        lmin = len_v < lmin ? len_v : lmin;
+        lmax = len_v > lmax ? len_v : lmax;
+        if (rec == FUSE_NONE) {
+            open = 1u;
+            return;
+        }
+        const uint32_t l = fuse_l(rec);
+        const unsigned long long d = (unsigned long long)__double_as_longlong(fuse_dist(f, l, len_v + fuse_len(rec) - 2u * l));
+        dmax = d > dmax ? d : dmax;
+    };
+    if (has) take(f_col[tid], a.lens[pid]);
+    // the columns' ranges: wave by wave, then through LDS
+    uint32_t cmin = lmin, cmax = lmax, copen = open;
+    unsigned long long cd = dmax;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t m2 = __shfl_xor(cmin, o, 64), x2 = __shfl_xor(cmax, o, 64), o2 = __shfl_xor(copen, o, 64);
+        const unsigned long long d2 = __shfl_xor(cd, o, 64);
+        cmin = m2 < cmin ? m2 : cmin;
+        cmax = x2 > cmax ? x2 : cmax;
+        copen |= o2;
+        cd = d2 > cd ? d2 : cd;
+    }
+    const int wave = tid >> 6;
+    if ((tid & 63) == 0) {
+        red[wave * 8 + 0] = cmin;
+        red[wave * 8 + 1] = cmax;
+        red[wave * 8 + 2] = copen;
+        red[wave * 8 + 3] = (uint32_t)cd;
+        red[wave * 8 + 4] = (uint32_t)(cd >> 32);
+    }
+    // the rows (at most 32: the first wave's lanes), every wave's view of a row folded
+    lmin = 0xffffffffu; lmax = 0u; open = 0u; dmax = 0ull;
+    if (tid < nr) {
+        const int rid = a.ref_ids ? a.ref_ids[ref0 + tid] : a.ref_begin + ref0 + tid;
+        const uint32_t len_r = a.lens[rid];
+        fuse_rec best = f_row[tid]; // (all four waves' copies start equal: fuse_init)
+        take(best, len_r);
+    }
+    if (wave == 0) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const uint32_t m2 = __shfl_xor(lmin, o, 64), x2 = __shfl_xor(lmax, o, 64), o2 = __shfl_xor(open, o, 64);
+            const unsigned long long d2 = __shfl_xor(dmax, o, 64);
+            lmin = m2 < lmin ? m2 : lmin;
+            lmax = x2 > lmax ? x2 : lmax;
+            open |= o2;
+            dmax = d2 > dmax ? d2 : dmax;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t kmin = 0xffffffffu, kmax = 0u, kopen = 0u;
+        unsigned long long kd = 0ull;
+        for (int w = 0; w < 4; ++w) {
+            kmin = red[w * 8 + 0] < kmin ? red[w * 8 + 0] : kmin;
+            kmax = red[w * 8 + 1] > kmax ? red[w * 8 + 1] : kmax;
+            kopen |= red[w * 8 + 2];
+            const unsigned long long d = ((unsigned long long)red[w * 8 + 4] << 32) | red[w * 8 + 3];
+            kd = d > kd ? d : kd;
+        }
+        bool useless = false;
+        if (kmax == 0u) useless = true; // no pair at all in this tile
+        else if (!kopen && !open && lmax != 0u) {
+            // rows [lmin, lmax], columns [kmin, kmax]
+            const uint32_t gap = kmin > lmax ? kmin - lmax : (lmin > kmax ? lmin - kmax : 0u);
+            const uint32_t l_most = lmax < kmax ? lmax : kmax;
+            if (gap > 0u && l_most > 0u) {
+                const unsigned long long bound = (unsigned long long)__double_as_longlong(fuse_dist(f, l_most, gap));
+                const unsigned long long worst = kd > dmax ? kd : dmax;
+                useless = bound > worst;
+            }
+        }
+        red[7] = useless ? 1u : 0u;
+        if (f.stats) atomicAdd(f.stats + (useless ? 1 : 0), 1ull);
+    }
+    __syncthreads();
+    return red[7] != 0u;
+}
+
 // after the workgroup's last result (and a barrier): fold the records back into the global ones
 __device__ __forceinline__ void fuse_flush(const RowsArgs& a, const lds_u64* f_col, const lds_u64* f_row, int ref0, int nr, int c,
                                            bool valid, int tid)
@@ -346,6 +445,17 @@ __device__ __forceinline__ void block_coords(const RowsArgs& a, int& x, int& y)
         return;
     }
     const int bid = blockIdx.x;
+    if (a.diag_prefix) { // by diagonals: the d-th tile from the row's end, rows in the compact grid's order (fullest first)
+        int lo = 0, hi = a.diag_count - 1; // largest d with diag_prefix[d] <= bid
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (a.diag_prefix[mid] <= bid) lo = mid; else hi = mid - 1;
+        }
+        const int k = bid - a.diag_prefix[lo]; // rows with more than `lo` column blocks are a prefix of the order
+        y = a.tri_rows - 1 - k;
+        x = a.tri_prefix[k + 1] - a.tri_prefix[k] - 1 - lo;
+        return;
+    }
     int lo = 0, hi = a.tri_rows - 1; // largest k with tri_prefix[k] <= bid
     while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
@@ -584,6 +694,9 @@ __global__ __launch_bounds__(256) void lcs_rows_kernel_pipe(RowsArgs a)
     [[maybe_unused]] lds_u64* f_row = f_col + 256;
     if constexpr (FUSE) fuse_init(a, f_col, f_row, ref0, nr, c, valid, tid);
     __syncthreads();
+    if constexpr (FUSE) {
+        if (a.fuse.prune && fuse_tile_is_useless(a, f_col, f_row, (uint32_t*)(f_row + 4 * 32), ref0, nr, c, col_limit, tid)) return;
+    }
 
     const int pid = a.col_ids ? a.col_ids[valid ? c : 0] : a.col_begin + (valid ? c : 0);
     const uint32_t len_p = valid ? a.lens[pid] : 0u;

@@ -229,7 +229,8 @@ int run_rows(lcsgpu_ctx* ctx, Lane& L, int mode, const int32_t* ref_ids, int32_t
     if (col_ids) bytes += align8((size_t)n_cols * 4);
     std::vector<size_t> row_off(buckets.size(), 0), id_off(buckets.size(), 0), pre_off(buckets.size(), 0);
     std::vector<char> is_contig(buckets.size(), 0);
-    std::vector<std::vector<int32_t>> tri_prefix(buckets.size());
+    std::vector<std::vector<int32_t>> tri_prefix(buckets.size()), diag_prefix(buckets.size());
+    std::vector<size_t> diag_off(buckets.size(), 0);
     std::vector<int> refs_per_wg(buckets.size(), 0);
     for (size_t b = 0; b < buckets.size(); ++b) {
         const long col_blocks = call_col_blocks;
@@ -255,6 +256,32 @@ int run_rows(lcsgpu_ctx* ctx, Lane& L, int mode, const int32_t* ref_ids, int32_t
             pre[gy] = (int32_t)acc;
             pre_off[b] = bytes;
             bytes += align8(pre.size() * 4);
+            if (fuse && fuse->prune && acc > 0) {
+                // the same workgroups by diagonals (RowsArgs::diag_prefix): rows with more than d column blocks are a prefix
+                // of the order above (fullest first), so the tiles d blocks from their row's end are diag[d] .. diag[d + 1]
+                const int widest = pre[1] - pre[0];
+                std::vector<int32_t>& dg = diag_prefix[b];
+                dg.assign((size_t)widest + 1, 0);
+                for (int k = 0; k < gy; ++k) {
+                    const int cols_k = pre[k + 1] - pre[k];
+                    if (cols_k > 0) dg[(size_t)cols_k - 1] += 1; // rows whose LAST diagonal index is cols_k - 1
+                }
+                // rows with more than d blocks = sum over e >= d of dg[e]; prefix over d of that count
+                int64_t rows_with_more = 0;
+                std::vector<int32_t> cnt((size_t)widest, 0);
+                for (int d = widest - 1; d >= 0; --d) {
+                    rows_with_more += dg[(size_t)d];
+                    cnt[(size_t)d] = (int32_t)rows_with_more;
+                }
+                int64_t at = 0;
+                for (int d = 0; d < widest; ++d) {
+                    dg[(size_t)d] = (int32_t)at;
+                    at += cnt[(size_t)d];
+                }
+                dg[(size_t)widest] = (int32_t)at; // == acc
+                diag_off[b] = bytes;
+                bytes += align8(dg.size() * 4);
+            }
         }
         if (is_contig[b]) continue;
         row_off[b] = bytes;
@@ -274,6 +301,7 @@ int run_rows(lcsgpu_ctx* ctx, Lane& L, int mode, const int32_t* ref_ids, int32_t
         if (col_ids) memcpy(h + col_off, col_ids, (size_t)n_cols * 4);
         for (size_t b = 0; b < buckets.size(); ++b) {
             if (!tri_prefix[b].empty()) memcpy(h + pre_off[b], tri_prefix[b].data(), tri_prefix[b].size() * 4);
+            if (!diag_prefix[b].empty()) memcpy(h + diag_off[b], diag_prefix[b].data(), diag_prefix[b].size() * 4);
             if (is_contig[b]) continue;
             int64_t* hr = (int64_t*)(h + row_off[b]);
             int32_t* hi = (int32_t*)(h + id_off[b]);
@@ -333,6 +361,10 @@ int run_rows(lcsgpu_ctx* ctx, Lane& L, int mode, const int32_t* ref_ids, int32_t
         if (bk.bv != 0 && !tri_prefix[b].empty()) {
             a.tri_prefix = (const int32_t*)((char*)L.d_plan.p + pre_off[b]);
             a.tri_rows = (int32_t)tri_prefix[b].size() - 1;
+            if (!diag_prefix[b].empty()) {
+                a.diag_prefix = (const int32_t*)((char*)L.d_plan.p + diag_off[b]);
+                a.diag_count = (int32_t)diag_prefix[b].size() - 1;
+            }
             const int total = tri_prefix[b].back();
             if (total > 0) {
                 HIP_TRY(lcsgpu::launch_rows(bk.bv, bk.quirk, a, total, 1, st));

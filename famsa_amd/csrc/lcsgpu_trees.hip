@@ -57,13 +57,18 @@ int lcsgpu_row_minima_dev(lcsgpu_ctx* ctx, const void* d_triangle, int elem_size
 // stored to d_out as well, or -- d_out NULL -- only folded
 static int fused_rows(lcsgpu_ctx* ctx, Lane& L, const lcsgpu::BoruvkaArgs& b, void* d_out, int elem, bool with_labels)
 {
-    HIP_TRY(lcsgpu::launch_boruvka_fuse_reset(b, L.stream));
+    // (with labels: a record of the last round whose edge still leaves its vertex's component is this round's best already --
+    //  the edges that cross now are a subset of those that crossed then -- and stays; the others start empty)
+    HIP_TRY(lcsgpu::launch_boruvka_fuse_reset(b, with_labels, L.stream));
     lcsgpu::FuseArgs f{};
     f.row_rec = b.fuse_row;
     f.col_rec = b.fuse_col;
     f.comp = with_labels ? b.comp : nullptr; // round 0: every vertex is its own component
     f.pow_table = b.pow_table;
     f.kind = b.kind;
+    static const int prune = tune_int("mst_length_bound", 1);
+    f.prune = prune && !d_out ? 1 : 0; // (a launch that also stores the triangle computes every value)
+    f.stats = (unsigned long long*)(b.counters + 8);
     return run_rows(ctx, L, lcsgpu::MODE_TRIANGLE, nullptr, b.r0, b.r1 - b.r0, nullptr, 0, std::max(0, b.r1 - 1), d_out, 0, b.off,
                     elem, b.r0, &f);
 }
@@ -131,6 +136,7 @@ static int shard_begin(lcsgpu_ctx* ctx, Lane& L, void* d_tri, int elem, int32_t 
     b.n_chunks = n_chunks;
     b.rows_per_chunk = rows_per_chunk;
     HIP_TRY(lcsgpu::launch_boruvka_init(b, L.stream));
+    HIP_TRY(hipMemsetAsync(b.counters + 8, 0, 16, L.stream)); // the fused launches' tile counts (FuseArgs::stats)
     ctx->mst.active = true;
     ctx->mst.b = b;
     ctx->mst.elem = elem;
@@ -522,9 +528,15 @@ int lcsgpu_mst_prim(lcsgpu_ctx* ctx, int distance_kind, lcsgpu_mst_edge* out_edg
         }
         const auto t_fin = std::chrono::steady_clock::now();
         if (!rc) rc = shard_finish(ctx, L, out_edges);
-        if (getenv("LCSGPU_PROFILE"))
+        if (getenv("LCSGPU_PROFILE") || getenv("LCSGPU_MST_COUNTS")) {
             fprintf(stderr, "lcsgpu_mst_prim: %d rounds; edges to the host + Prim's order %.3f s\n", ctx->mst.rounds,
                     std::chrono::duration<double>(std::chrono::steady_clock::now() - t_fin).count());
+            unsigned long long st[2] = {0, 0};
+            if (!rc && hipMemcpy(st, ctx->mst.b.counters + 8, 16, hipMemcpyDeviceToHost) == hipSuccess && st[0] + st[1] > 0)
+                // (the reference's "No. comp. necessary / useless", tree/MSTPrim.cpp:544-546, by workgroup tiles of <= 256 x 32 pairs)
+                fprintf(stderr, "lcsgpu_mst_prim: LCS tiles of the rounds that recompute: %llu computed, %llu let go by the length bound (%.1f %%)\n",
+                        st[0], st[1], 100.0 * (double)st[1] / (double)(st[0] + st[1]));
+        }
         ctx->mst.active = false; // the triangle it points to belongs to this call
         if (rc) return rc;
         note_async_call(ctx);

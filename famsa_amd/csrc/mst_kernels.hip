@@ -460,12 +460,21 @@ __global__ __launch_bounds__(256) void boruvka_fold_kernel(BoruvkaArgs a)
 }
 
 // ---- the local half done by the LCS launch itself (lcs_kernels.hip, FuseArgs): reset / conversion of the records ----
-__global__ __launch_bounds__(256) void boruvka_fuse_reset_kernel(BoruvkaArgs a)
+// keep: the records of the last round stay where their edge still leaves the vertex's component (a.comp = this round's labels)
+__global__ __launch_bounds__(256) void boruvka_fuse_reset_kernel(BoruvkaArgs a, int keep)
 {
     const int v = blockIdx.x * 256 + threadIdx.x;
     if (v >= a.n) return;
-    a.fuse_row[v] = ~0ull;
-    a.fuse_col[v] = ~0ull;
+    unsigned long long r = ~0ull, c = ~0ull;
+    if (keep) {
+        const int cv = a.comp[v];
+        r = a.fuse_row[v];
+        c = a.fuse_col[v];
+        if (r != ~0ull && a.comp[(uint32_t)r] == cv) r = ~0ull;
+        if (c != ~0ull && a.comp[(uint32_t)c] == cv) c = ~0ull;
+    }
+    a.fuse_row[v] = r;
+    a.fuse_col[v] = c;
 }
 
 // (l, length of the other endpoint, other endpoint) -> MSTPrim's key, with the arithmetic of exact_update above
@@ -660,9 +669,9 @@ hipError_t launch_boruvka_best(const BoruvkaArgs& a, int elem_size, hipStream_t 
     return hipGetLastError();
 }
 
-hipError_t launch_boruvka_fuse_reset(const BoruvkaArgs& a, hipStream_t stream)
+hipError_t launch_boruvka_fuse_reset(const BoruvkaArgs& a, bool keep, hipStream_t stream)
 {
-    hipLaunchKernelGGL(boruvka_fuse_reset_kernel, dim3((a.n + 255) / 256), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(boruvka_fuse_reset_kernel, dim3((a.n + 255) / 256), dim3(256), 0, stream, a, keep ? 1 : 0);
     return hipGetLastError();
 }
 

@@ -134,6 +134,7 @@ int main(int argc, char** argv)
         if (n_threads <= 0) n_threads = default_host_threads(); // respects a container's cpu.max
         opt.fast.n_threads = n_threads;
         const bool very_verbose = find_switch(params, "-vv");
+        if (very_verbose) setenv("LCSGPU_MST_COUNTS", "1", 0); // the engine's "tiles computed / let go" line (the reference's -vv prints its counts)
         const bool verbose = find_switch(params, "-v") || very_verbose;
         const bool export_tree = find_switch(params, "-gt_export");
         const bool export_dist = find_switch(params, "-dist_export");

@@ -236,3 +236,42 @@ def test_c4_with_part_of_the_triangle(tmp_path):
     p = _cli("-v", "-gt", "sl", "-gt_export", path, out, env={"LCSGPU_FAKE_HBM_GB": "8.5", "LCSGPU_PROFILE": "1"})
     h = hashlib.sha256(open(out, "rb").read()).hexdigest()
     assert h == META_LARGE["synth100k"]["sl_newick_sha256"], p.stderr
+
+
+def test_the_length_bound_lets_tiles_go_and_changes_nothing(tmp_path):
+    """MSTPrim's length bound (reference tree/MSTPrim.cpp:450-467) for whole tiles of the rounds that recompute their LCS
+    values (FuseArgs::prune): on a set of very different lengths most far-from-the-diagonal tiles are let go -- `-vv` says how
+    many -- and the tree is the one the passes over a resident triangle give, and the one without the bound."""
+    rng = np.random.Generator(np.random.PCG64(23))
+    fams = []
+    for length, members in ((60, 2500), (150, 2500), (420, 2500), (900, 1500)):
+        anc = rng.integers(0, 20, size=length, dtype=np.uint8)
+        for _ in range(members):
+            s = anc.copy()
+            m = rng.random(length) < 0.2
+            s[m] = rng.integers(0, 20, size=int(m.sum()), dtype=np.uint8)
+            fams.append(s[: int(rng.integers(int(length * 0.9), length + 1))].copy())
+    order = rng.permutation(len(fams))
+    fams = [fams[i] for i in order]
+    codes, offsets = seqio.pack(fams)
+    path = str(tmp_path / "ragged.fasta")
+    seqio.to_fasta(codes, offsets, path)
+
+    def run(env):
+        out = str(tmp_path / ("t_%d.dnd" % len(env)))
+        e = dict(os.environ)
+        e.update(env)
+        p = subprocess.run([CLI, "-vv", "-gt", "sl", "-gt_export", path, out], stderr=subprocess.PIPE, text=True, env=e, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        return hashlib.sha256(open(out, "rb").read()).hexdigest(), p.stderr
+
+    want, _ = run({"LCSGPU_MST_MODE": "passes"})
+    got, log = run({"LCSGPU_MST_MODE": "recompute", "X": "1"})
+    assert got == want
+    line = [l for l in log.splitlines() if "let go by the length bound" in l]
+    assert line, log[-1500:]
+    computed, gone = [int(x) for x in __import__("re").findall(r"(\d+) computed, (\d+) let go", line[0])[0]]
+    assert gone > computed // 4, line[0]  # the four families are far apart in length: most cross-family tiles go
+    off, log_off = run({"LCSGPU_MST_MODE": "recompute", "LCSGPU_TUNE": "mst_length_bound=0", "Y": "22"})
+    assert off == want
+    assert not any("let go" in l and " 0 let go" not in l for l in log_off.splitlines() if "let go" in l)
