@@ -262,6 +262,7 @@ struct NjArgs {
     int32_t n;
 };
 hipError_t launch_nj(const NjArgs& a, hipStream_t stream);
+hipError_t launch_nj_init(const NjArgs& a, hipStream_t stream);
 hipError_t launch_float_distances(const void* lcs, int elem_size, const uint32_t* lens, const float* pow_f32, int kind,
                                   int n, float* D, hipStream_t stream);
 

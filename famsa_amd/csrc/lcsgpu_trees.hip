@@ -1,6 +1,7 @@
 // lcsgpu_trees.hip -- C-ABI entry points of the whole-set tree reducers (Prim, UPGMA, NJ) and the
 // per-row minima: the LCS triangle stays in HBM, the kernels of tree_kernels.hip consume it there.
 #include "lcsgpu_internal.h"
+#include "nj_loop.h"
 
 #include <dlfcn.h>
 
@@ -1157,16 +1158,33 @@ int nj_reduce(lcsgpu_ctx* ctx, Lane& L, int elem, int distance_kind, int32_t* ou
 {
     const int32_t n = ctx->n;
     HIP_TRY(hipSetDevice(ctx->device));
-    int rc = reserve_big(ctx, ctx->d_dist, (size_t)tri_offset(n) * sizeof(float), "the float distance triangle");
+    const bool profile = getenv("LCSGPU_PROFILE") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_lap[5] = {0, 0, 0, 0, 0};
+    if (profile) { HIP_TRY(hipStreamSynchronize(L.stream)); t_lap[0] = now(); }
+    // One resident launch for all the merges (nj_loop_kernels.hip) while the rows' sums fit a workgroup's LDS and the
+    // kernel fits a CU; else four launches per merge (tree_kernels.hip).  The same floats either way.
+    const int cap = lcsgpu::nj_loop_cap(n);
+    int grid = 0;
+    if (n >= 3 && n <= lcsgpu::NJ_LOOP_MAX_N && tune_int("nj_loop", 1)) {
+        HIP_TRY(lcsgpu::nj_loop_grid(cap, &grid));
+        const int g = tune_int("nj_groups", 0);
+        if (g > 0 && g < grid) grid = g;
+    }
+    const size_t tri_floats = ((size_t)tri_offset(n) + 3 + 4) & ~(size_t)3; // whole 16-byte loads at the end
+    int rc = reserve_big(ctx, ctx->d_dist, tri_floats * sizeof(float) * (grid ? 2 : 1), "the float distance triangle");
     if (rc) return rc;
     auto a16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
     const size_t o_sum = 0, o_tmp = o_sum + a16((size_t)n * 4), o_pq = o_tmp + a16((size_t)n * 4),
                  o_pi = o_pq + a16((size_t)n * 4), o_node = o_pi + a16((size_t)n * 4), o_act = o_node + a16((size_t)n * 4),
                  o_sel = o_act + a16((size_t)n), o_left = o_sel + 16, o_right = o_left + a16((size_t)n * 4),
-                 total = o_right + a16((size_t)n * 4);
+                 o_slots = o_right + a16((size_t)n * 4), o_u = o_slots + (size_t)grid * 32 + 64,
+                 total = o_u + (grid ? a16((size_t)n * 8) : 0);
     HIP_TRY(ctx->d_prim.reserve(total));
     char* base = (char*)ctx->d_prim.p;
     HIP_TRY(hipMemsetAsync(base + o_sel, 0, 16, L.stream));
+    if (grid) HIP_TRY(hipMemsetAsync(base + o_slots, 0, total - o_slots, L.stream));
+    if (profile) t_lap[1] = now();
     lcsgpu::NjArgs a{};
     a.D = (float*)ctx->d_dist.p;
     a.sum = (float*)(base + o_sum);
@@ -1181,7 +1199,32 @@ int nj_reduce(lcsgpu_ctx* ctx, Lane& L, int elem, int distance_kind, int32_t* ou
     a.n = n;
     HIP_TRY(lcsgpu::launch_float_distances(L.d_out.p, elem, (const uint32_t*)ctx->d_lens.p, (const float*)ctx->d_powf.p,
                                            distance_kind, n, a.D, L.stream));
-    HIP_TRY(lcsgpu::launch_nj(a, L.stream));
+    if (profile) { HIP_TRY(hipStreamSynchronize(L.stream)); t_lap[2] = now(); }
+    if (grid) {
+        lcsgpu::NjLoopArgs p{};
+        p.a = a;
+        p.D2 = a.D + tri_floats;
+        p.slots = (uint64_t*)(base + o_slots);
+        p.u = (uint64_t*)(base + o_u);
+        p.err = a.sel + 3;
+        p.prof = profile ? (long long*)(base + o_slots + (size_t)grid * 32) : nullptr;
+        p.cap = cap;
+        p.compact_min = tune_int("nj_squeeze_min", 256);
+        HIP_TRY(lcsgpu::launch_nj_loop(p, grid, L.stream));
+        if (p.prof) {
+            long long lap[6];
+            HIP_TRY(hipMemcpyAsync(lap, p.prof, sizeof lap, hipMemcpyDeviceToHost, L.stream));
+            HIP_TRY(hipStreamSynchronize(L.stream));
+            t_lap[3] = now();
+            fprintf(stderr, "lcsgpu_nj: LCS triangle ready -> buffers %.1f ms, float distances %.1f ms, initial sums + the launch %.1f ms\n",
+                    (t_lap[1] - t_lap[0]) * 1e3, (t_lap[2] - t_lap[1]) * 1e3, (t_lap[3] - t_lap[2]) * 1e3);
+            fprintf(stderr, "lcsgpu_nj: one resident launch of %d workgroups for %d merges; workgroup 0: squeezes %.1f ms, scan + chain %.1f, "
+                            "(the chain alone %.1f), exchange %.1f, updates %.1f, polls %.1f\n", grid, n - 2, lap[0] * 1e-5, lap[1] * 1e-5,
+                    lap[5] * 1e-5, lap[2] * 1e-5, lap[3] * 1e-5, lap[4] * 1e-5);
+        }
+    } else {
+        HIP_TRY(lcsgpu::launch_nj(a, L.stream));
+    }
     int32_t sel[4] = {0, 0, 0, 0};
     HIP_TRY(hipMemcpyAsync(out_left, a.left, (size_t)(n - 1) * 4, hipMemcpyDeviceToHost, L.stream));
     HIP_TRY(hipMemcpyAsync(out_right, a.right, (size_t)(n - 1) * 4, hipMemcpyDeviceToHost, L.stream));
@@ -1189,6 +1232,9 @@ int nj_reduce(lcsgpu_ctx* ctx, Lane& L, int elem, int distance_kind, int32_t* ou
     HIP_TRY(hipStreamSynchronize(L.stream));
     L.plan_in_flight = false;
     note_async_call(ctx);
+    if (sel[3])
+        return fail(LCSGPU_E_HIP, "NJ: the workgroups of the resident launch did not meet at a barrier (LCSGPU_TUNE=nj_loop=0 "
+                                  "runs the merges as separate launches)");
     if (sel[2])
         return fail(LCSGPU_E_INVALID, "NJ: no finite q (a pair with LCS 0?) -- the reference's result is degenerate "
                                       "for this input");

@@ -754,6 +754,12 @@ __global__ void nj_final_kernel(NjArgs a, int iter)
     a.right[iter] = second >= 0 ? a.node[second] : a.node[first];
 }
 
+hipError_t launch_nj_init(const NjArgs& a, hipStream_t stream)
+{
+    hipLaunchKernelGGL(nj_init_kernel, dim3((a.n + 255) / 256), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
 hipError_t launch_nj(const NjArgs& a, hipStream_t stream)
 {
     const int n = a.n, blocks = (n + 255) / 256;

@@ -1,0 +1,12 @@
+#!/bin/bash
+# round 6: neighbour joining as one resident launch against four launches per merge (hemopexin, 4188 sequences)
+cd "$(dirname "$0")/.."
+mkdir -p gpurun_out
+OUT=gpurun_out/nj_r06.txt
+: > $OUT
+for tune in ${NJ_TUNES:-"nj_loop=1" "nj_loop=1,nj_squeeze_min=100000" "nj_loop=1,nj_groups=128" "nj_loop=1,nj_groups=64" "nj_loop=0"}; do
+  for i in 1 2 3; do
+    line=$(LCSGPU_TUNE=$tune timeout 120 famsa_amd/famsa-gpu -v -gt nj -gt_export tests/golden/hemopexin/hemopexin /tmp/nj.dnd 2>&1 | grep -E "tree_build|rror|NJ" | tr '\n' ' ')
+    echo "$tune $line sha=$(sha256sum /tmp/nj.dnd | cut -c1-12)" | tee -a $OUT
+  done
+done
