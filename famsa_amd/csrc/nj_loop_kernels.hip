@@ -37,6 +37,7 @@
 
 #include "nj_loop.h"
 #include "ordered_sum.h"
+#include "dpp_min.h"
 
 namespace lcsgpu {
 
@@ -65,15 +66,18 @@ __device__ __forceinline__ void cand_take(Cand& c, float q, int i, int j)
     if (q < NJ_QMAX && cand_less(q, i, j, c)) { c.q = q; c.i = i; c.j = j; }
 }
 
+// the wave's smallest candidate in every lane: dpp_min.h's (value, index) first minimum with (i, j) as one index
+// (i and j are below 2^14; "none" packs to the largest index and has the largest q)
 __device__ __forceinline__ Cand wave_min(Cand c)
 {
-#pragma unroll
-    for (int s = 32; s > 0; s >>= 1) {
-        const float q2 = __shfl_xor(c.q, s);
-        const int i2 = __shfl_xor(c.i, s), j2 = __shfl_xor(c.j, s);
-        if (cand_less(q2, i2, j2, c)) { c.q = q2; c.i = i2; c.j = j2; }
-    }
-    return c;
+    float q = c.q;
+    uint32_t ij = c.i == 0x7fffffff ? 0xffffffffu : ((uint32_t)c.i << 16 | (uint32_t)c.j);
+    wave_first_min(q, ij);
+    Cand r;
+    r.q = q;
+    r.i = ij == 0xffffffffu ? 0x7fffffff : (int)(ij >> 16);
+    r.j = ij == 0xffffffffu ? 0x7fffffff : (int)(ij & 0xffff);
+    return r;
 }
 
 // all threads get the workgroup's minimum; scratch: 16 candidates
@@ -84,14 +88,7 @@ __device__ __forceinline__ Cand block_min(Cand c, Cand* scratch)
     __syncthreads(); // scratch may still be read from the previous use
     if (lane == 0) scratch[wave] = c;
     __syncthreads();
-    Cand r = scratch[lane & 15];
-#pragma unroll
-    for (int s = 8; s > 0; s >>= 1) {
-        const float q2 = __shfl_xor(r.q, s);
-        const int i2 = __shfl_xor(r.i, s), j2 = __shfl_xor(r.j, s);
-        if (cand_less(q2, i2, j2, r)) { r.q = q2; r.i = i2; r.j = j2; }
-    }
-    return r;
+    return wave_min(scratch[lane & 15]);
 }
 
 __device__ __forceinline__ size_t tri(uint32_t i, uint32_t j) // TriangleMatrix::access
@@ -346,7 +343,8 @@ __global__ __launch_bounds__(NJ_THREADS) void nj_loop_kernel(NjLoopArgs p)
                 }
                 arrived = __builtin_amdgcn_readfirstlane(arrived);
                 if (arrived == nw - 1) { // the last scanning wave: the workgroup's candidate out, everybody's in
-                    Cand c = S.cand[first_wave + (lane < nw ? lane : 0)];
+                    Cand c{NJ_QMAX, 0x7fffffff, 0x7fffffff};
+                    if (lane >= first_wave && lane < 16) c = S.cand[lane];
                     c = wave_min(c);
                     uint64_t* buf = p.slots + (size_t)(epoch & 1) * 2 * G;
                     const uint64_t tag = (uint64_t)epoch << 32;

@@ -1,20 +1,30 @@
 // ordered_sum.h -- the float sum  s = (((0 + x0) + x1) + x2) + ...  rounded after every addition, computed by one wave
 // faster than one addition after the other, and bit for bit the same.  Device code only.
 //
-// NeighborJoining::computeTree (reference tree/NeighborJoining.cpp:88-108) adds the merged cluster's new distances
-// up in ascending cluster order, in float: n dependent additions per merge, ~13 cycles each on one lane of a CDNA4
-// SIMD -- 58 of the 111 ms of hemopexin's resident NJ launch (profiles/nj_r06.txt).  The additions are not associative,
-// but most of them happen while the sum stays inside one binade [2^e, 2^(e+1)): there the sum is an integer S (24 bits)
-// times u = 2^(e-23), and
+// NeighborJoining::computeTree (reference tree/NeighborJoining.cpp:44-55, 88-108) adds distances up in ascending
+// cluster order, in float: n dependent additions per merge, 8-13 cycles each on one lane of a CDNA4 SIMD -- 58 of the
+// 111 ms of hemopexin's resident NJ launch when done that way (profiles/nj_r06.txt).  The additions are not
+// associative, but most of them happen while the sum stays inside one binade [2^e, 2^(e+1)): there the sum is an
+// integer S (24 bits) times u = 2^(e-23), and
 //
-//      fl(S u + x) = (S + round(x / u)) u        as long as the result stays below 2^(e+1),
+//      fl(S u + x) = (S + round(x / u)) u        while the exact sum stays inside [2^e, 2^(e+1)),
 //
-// round() to nearest, a tie (x / u = k + 1/2 exactly) to the neighbour that makes S + k even -- the only place where
-// the ORDER of the additions matters.  So for a block of addends without a tie, whose steps up added to S stay below
-// 2^24 and whose steps down leave S above 2^23 (every partial sum, in any order, lies between the two), the sequential
-// result is S plus the integer total of the round(x / u) -- 64 lanes at a time.  x / u is exact (a power of two), so are
-// floor and the fraction.  A block that has a tie, a huge or non-finite addend, or that could leave the binade is taken
-// in pieces of 64 and, failing that too, one addition after the other: nothing is approximated anywhere.
+// round() to nearest -- a tie (x / u = k + 1/2 exactly) goes to the neighbour that makes S + k even, the only place
+// where the sum so far decides.  x / u is exact (a power of two), so are floor and the fraction.  So for a block of
+// addends without a tie, whose steps up added to S stay below 2^24 and whose steps down leave S above 2^23 (every
+// partial sum, in ANY order, lies between the two; one step of margin at the lower edge when an addend is negative:
+// below 2^e the grid is u / 2 and the exact sum may lie half a step under the rounded one), the sequential result is S
+// plus the integer total of the round(x / u): 64 lanes, four addends each, two wave reductions.  A block of 256 that
+// has a tie, a huge or non-finite addend, or that could leave the binade is taken in pieces of 64 and, failing that
+// too, one addition after the other: nothing is approximated anywhere (tests/gpu_src/ordered_sum_check.hip compares
+// bit patterns with a host loop over vectors made to hit every branch).
+//
+// What it buys (profiles/nj_r06.txt): a block costs ~650 cycles of latency whatever its length and a plain addition 8,
+// a tie turns up every ~2^11 addends of NJ's kind (ten to twelve fraction bits below u) and the binade changes
+// log2(n) times per sum -- 39 ms instead of 58 inside the loaded NJ launch, no gain on an idle CU.  Variants that were
+// built, found exact and slower there: prefix sums over 512 addends with the offending addend added for real and
+// the rest continued (a round costs 1400+ cycles, and every tie and change of binade costs a round), block lengths
+// guessed from the distance to the next power of two (ties cut the long blocks down).
 //
 // Call with all 64 lanes of ONE wave; `x` (LDS or global) must be readable and +0.0f from n up to
 // ordered_sum_padded(n).  Every lane returns the sum.
@@ -57,11 +67,12 @@ __device__ __forceinline__ bool block(const float* x, int t, float& s)
     const float lim = __uint_as_float((eb + 1u) << 23);            // 2^(e + 1)
     const int lane = threadIdx.x & 63;
     uint32_t up = 0, down = 0; // the steps up and the steps down, added up apart: every partial sum lies between S - down and S + up
-    bool bad = false;
+    bool bad = false, neg = false;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const float v = x[t + lane + 64 * u];
         bad = bad || !(__builtin_fabsf(v) < lim);                  // too large, inf, NaN
+        neg = neg || v < 0.0f;
         const float y = v * scale;                                 // exact
         const float fl = __builtin_floorf(y);
         const float fr = y - fl;                                   // exact, in [0, 1)
@@ -73,10 +84,13 @@ __device__ __forceinline__ bool block(const float* x, int t, float& s)
     if (__ballot(bad)) return false;
     const uint64_t hi = (uint64_t)S + wave_total(up);
     if (hi >= (1u << 24)) return false;                            // a partial sum could leave the binade upwards
-    const uint32_t dn = wave_total(down);
-    // ... or downwards: one step of margin, because below 2^e the grid is u / 2 and the exact sum may lie half a step
-    // under the rounded one
-    if (dn != 0 && (uint64_t)dn + (1u << 23) + 1 > (uint64_t)S) return false;
+    uint32_t dn = 0;
+    if (__ballot(neg)) {
+        // ... or downwards: one step of margin, because below 2^e the grid is u / 2 and the exact sum of a negative
+        // addend may lie half a step under the rounded one (also when the addend itself rounds to no step at all)
+        dn = wave_total(down);
+        if ((uint64_t)dn + (1u << 23) + 1 > (uint64_t)S) return false;
+    }
     s = __uint_as_float((eb << 23) | ((uint32_t)(hi - dn) & 0x7fffffu));
     return true;
 }
@@ -89,8 +103,16 @@ __device__ __forceinline__ float wave_ordered_sum(const float* x, int n, uint32_
     using namespace ordered_sum_detail;
     float s = 0.0f;
     int t = 0;
-    const int head = n < 64 ? n : 64; // a young sum changes its binade every few additions
-    for (; t < head; ++t) s = __fadd_rn(s, x[t]);
+    auto plain64 = [&] { // 64 additions one after the other, 8 loads in flight (the +0.0f beyond n change nothing: s is never -0.0f)
+        for (int k = 0; k < 64; k += 8) {
+            float g[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) g[q] = x[t + k + q];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) s = __fadd_rn(s, g[q]);
+        }
+    };
+    plain64(); // a young sum changes its binade every few additions
     t = 64;
     while (t < n) {
         if (block<4>(x, t, s)) {
@@ -105,13 +127,7 @@ __device__ __forceinline__ float wave_ordered_sum(const float* x, int n, uint32_
                 continue;
             }
             if (stats) ++stats[2];
-            for (int k = 0; k < 64; k += 8) { // (the +0.0f beyond n change nothing: s is never -0.0f)
-                float g[8];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) g[q] = x[t + k + q];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) s = __fadd_rn(s, g[q]);
-            }
+            plain64();
         }
     }
     return s;

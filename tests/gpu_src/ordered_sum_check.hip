@@ -4,22 +4,51 @@
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <random>
 #include <vector>
 
 #include "../../famsa_amd/csrc/ordered_sum.h"
 
+constexpr int MAX_N = 5000;
+
 __global__ __launch_bounds__(64) void sum_kernel(const float* x, const int* off, const int* len, float* out, uint32_t* stats,
                                                  long long* ticks)
 {
+    __shared__ __attribute__((aligned(16))) float row[lcsgpu::ordered_sum_padded(MAX_N)]; // as the callers have it: in LDS
+    const int n = len[blockIdx.x];
+    for (int t = threadIdx.x; t < lcsgpu::ordered_sum_padded(n); t += 64) row[t] = x[off[blockIdx.x] + t];
+    __syncthreads();
     uint32_t st[3] = {0, 0, 0};
     const long long t0 = wall_clock64();
-    const float s = lcsgpu::wave_ordered_sum(x + off[blockIdx.x], len[blockIdx.x], st);
+    const float s = lcsgpu::wave_ordered_sum(row, n, st);
     const long long t1 = wall_clock64();
     if (threadIdx.x == 0) {
         out[blockIdx.x] = s;
         for (int k = 0; k < 3; ++k) stats[3 * blockIdx.x + k] = st[k];
+        ticks[blockIdx.x] = t1 - t0;
+    }
+}
+
+__global__ __launch_bounds__(64) void seq_kernel(const float* x, const int* off, const int* len, float* out, long long* ticks)
+{
+    __shared__ __attribute__((aligned(16))) float row[lcsgpu::ordered_sum_padded(MAX_N)];
+    const int n = len[blockIdx.x];
+    for (int t = threadIdx.x; t < lcsgpu::ordered_sum_padded(n); t += 64) row[t] = x[off[blockIdx.x] + t];
+    __syncthreads();
+    const long long t0 = wall_clock64();
+    float s = 0.0f;
+    for (int i = 0; i < n; i += 8) { // (n padded with +0.0f)
+        float g[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) g[q] = row[i + q];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) s = __fadd_rn(s, g[q]);
+    }
+    const long long t1 = wall_clock64();
+    if (threadIdx.x == 0) {
+        out[blockIdx.x] = s;
         ticks[blockIdx.x] = t1 - t0;
     }
 }
@@ -31,16 +60,16 @@ static float host_sum(const float* x, int n)
     return s;
 }
 
-int main()
+int main(int argc, char** argv)
 {
     std::mt19937 rng(20260601);
     std::vector<float> x;
     std::vector<int> off, len, kind;
     auto uni = [&](double a, double b) { return (float)std::uniform_real_distribution<double>(a, b)(rng); };
-    const int n_cases = 6000;
+    const int n_cases = argc > 1 ? atoi(argv[1]) : 6000; // (a few hundred: one wave per CU, the time of a lone wave)
     for (int c = 0; c < n_cases; ++c) {
         const int k = c % 8;
-        int n = (int)(rng() % 5000) + 1;
+        int n = (int)(rng() % MAX_N) + 1;
         if (c % 97 == 0) n = (int)(rng() % 70) + 1;
         off.push_back((int)x.size());
         len.push_back(n);
@@ -98,6 +127,14 @@ int main()
         for (int c = k; c < n_cases; c += 8) { a += stats[3 * c]; b += stats[3 * c + 1]; q += stats[3 * c + 2]; elems += len[c]; tk += ticks[c]; }
         printf("kind %d: %llu blocks of 256 at once, %llu pieces of 64 at once, %llu pieces one by one; %.2f ns per addend\n", k, a, b, q,
                (double)tk * 10.0 / (double)elems);
+    }
+    {
+        hipLaunchKernelGGL(seq_kernel, dim3(n_cases), dim3(64), 0, 0, dx, doff, dlen, dout, dticks);
+        std::vector<long long> tk(n_cases);
+        hipMemcpy(tk.data(), dticks, n_cases * 8, hipMemcpyDeviceToHost);
+        long long all = 0, elems = 0;
+        for (int c = 0; c < n_cases; ++c) { all += tk[c]; elems += len[c]; }
+        printf("one addition after the other on the device: %.2f ns per addend\n", (double)all * 10.0 / (double)elems);
     }
     int bad = 0;
     for (int c = 0; c < n_cases; ++c) {
