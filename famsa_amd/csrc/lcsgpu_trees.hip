@@ -905,6 +905,23 @@ int whole_triangle(lcsgpu_ctx* const* ctxs, int32_t n_ctx, MultiGuard& g, int el
     return LCSGPU_OK;
 }
 
+// The merges of a reducer back on the host: flags | left | right lie next to each other on the device, so ONE copy into the
+// lane's pinned buffer brings them (three copies into pageable memory took 8 ms after NJ's 66-ms launch: each is staged
+// and waited for on its own).
+int fetch_merges(Lane& L, const char* d_flags, size_t flags_bytes, size_t left_at, size_t right_at, int32_t n, void* flags,
+                 int32_t* out_left, int32_t* out_right)
+{
+    const size_t total = right_at + (size_t)(n - 1) * 4;
+    HIP_TRY(L.h_small.reserve(total));
+    HIP_TRY(hipMemcpyAsync(L.h_small.p, d_flags, total, hipMemcpyDeviceToHost, L.stream));
+    HIP_TRY(hipStreamSynchronize(L.stream));
+    const char* h = (const char*)L.h_small.p;
+    memcpy(flags, h, flags_bytes);
+    memcpy(out_left, h + left_at, (size_t)(n - 1) * 4);
+    memcpy(out_right, h + right_at, (size_t)(n - 1) * 4);
+    return LCSGPU_OK;
+}
+
 // resident: the whole LCS triangle sits in L.d_out already (the multi-context gather); else this function computes it
 // itself, in row blocks that are turned into float distances one after the other -- 2 B per pair never exist all at once.
 int upgma_reduce(lcsgpu_ctx* ctx, Lane& L, int elem, int distance_kind, int modified, int32_t* out_left, int32_t* out_right, bool resident)
@@ -1120,10 +1137,8 @@ int upgma_reduce(lcsgpu_ctx* ctx, Lane& L, int elem, int distance_kind, int modi
     }
     const bool batched = n_batches > 0;
     if (!merged) HIP_TRY(lcsgpu::launch_upgma_steps(a, modified != 0, L.stream));
-    HIP_TRY(hipMemcpyAsync(out_left, a.left, (size_t)(n - 1) * 4, hipMemcpyDeviceToHost, L.stream));
-    HIP_TRY(hipMemcpyAsync(out_right, a.right, (size_t)(n - 1) * 4, hipMemcpyDeviceToHost, L.stream));
-    HIP_TRY(hipMemcpyAsync(sel, a.sel, 48, hipMemcpyDeviceToHost, L.stream));
-    HIP_TRY(hipStreamSynchronize(L.stream));
+    rc = fetch_merges(L, base + o_sel, 48, o_left - o_sel, o_right - o_sel, n, sel, out_left, out_right);
+    if (rc) return rc;
     L.plan_in_flight = false;
     if (profile)
         fprintf(stderr, "lcsgpu_upgma: n = %d, %s layout, distances + row minima %.3f s, %d merges %.3f s = %.2f us each (%s)\n", n,
@@ -1226,10 +1241,9 @@ int nj_reduce(lcsgpu_ctx* ctx, Lane& L, int elem, int distance_kind, int32_t* ou
         HIP_TRY(lcsgpu::launch_nj(a, L.stream));
     }
     int32_t sel[4] = {0, 0, 0, 0};
-    HIP_TRY(hipMemcpyAsync(out_left, a.left, (size_t)(n - 1) * 4, hipMemcpyDeviceToHost, L.stream));
-    HIP_TRY(hipMemcpyAsync(out_right, a.right, (size_t)(n - 1) * 4, hipMemcpyDeviceToHost, L.stream));
-    HIP_TRY(hipMemcpyAsync(sel, a.sel, 16, hipMemcpyDeviceToHost, L.stream));
-    HIP_TRY(hipStreamSynchronize(L.stream));
+    rc = fetch_merges(L, base + o_sel, 16, o_left - o_sel, o_right - o_sel, n, sel, out_left, out_right);
+    if (rc) return rc;
+    if (profile) fprintf(stderr, "lcsgpu_nj: results on the host %.1f ms after the launch was over (%.1f ms since the triangle was ready)\n", (now() - t_lap[3]) * 1e3, (now() - t_lap[0]) * 1e3);
     L.plan_in_flight = false;
     note_async_call(ctx);
     if (sel[3])
@@ -1276,11 +1290,25 @@ int lcsgpu_multi_nj(lcsgpu_ctx* const* ctxs, int32_t n_ctx, int distance_kind, i
     const int32_t n = ctxs[0]->n;
     if (n < 2) return LCSGPU_OK;
     if (!out_left || !out_right) return fail(LCSGPU_E_INVALID, "NULL output");
+    const bool profile = getenv("LCSGPU_PROFILE") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
     MultiGuard g(ctxs, n_ctx);
+    const auto t1 = std::chrono::steady_clock::now();
     const int elem = ctxs[0]->max_len > 65535 ? 4 : 2;
     rc = whole_triangle(ctxs, n_ctx, g, elem);
     if (rc) return rc;
-    return nj_reduce(ctxs[0], *g.lanes[0], elem, distance_kind, out_left, out_right);
+    if (profile) {
+        const auto t2 = std::chrono::steady_clock::now();
+        (void)hipStreamSynchronize(g.lanes[0]->stream);
+        const auto t3 = std::chrono::steady_clock::now();
+        fprintf(stderr, "lcsgpu_nj: lanes %.1f ms, the LCS triangle: host side %.1f ms, then %.1f ms until the device is done\n",
+                std::chrono::duration<double>(t1 - t0).count() * 1e3, std::chrono::duration<double>(t2 - t1).count() * 1e3,
+                std::chrono::duration<double>(t3 - t2).count() * 1e3);
+    }
+    rc = nj_reduce(ctxs[0], *g.lanes[0], elem, distance_kind, out_left, out_right);
+    if (profile)
+        fprintf(stderr, "lcsgpu_nj: the call %.1f ms\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() * 1e3);
+    return rc;
 }
 
 int lcsgpu_nj(lcsgpu_ctx* ctx, int distance_kind, int32_t* out_left, int32_t* out_right)
