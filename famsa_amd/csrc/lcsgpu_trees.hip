@@ -1188,6 +1188,10 @@ int nj_reduce(lcsgpu_ctx* ctx, Lane& L, int elem, int distance_kind, int32_t* ou
     }
     const size_t tri_floats = ((size_t)tri_offset(n) + 3 + 4) & ~(size_t)3; // whole 16-byte loads at the end
     int rc = reserve_big(ctx, ctx->d_dist, tri_floats * sizeof(float) * (grid ? 2 : 1), "the float distance triangle");
+    if (rc == LCSGPU_E_NOMEM && grid) { // no room for the second triangle the resident launch squeezes into: the launches need one
+        grid = 0;
+        rc = reserve_big(ctx, ctx->d_dist, tri_floats * sizeof(float), "the float distance triangle");
+    }
     if (rc) return rc;
     auto a16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
     const size_t o_sum = 0, o_tmp = o_sum + a16((size_t)n * 4), o_pq = o_tmp + a16((size_t)n * 4),
