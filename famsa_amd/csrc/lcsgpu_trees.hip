@@ -1169,7 +1169,12 @@ int upgma_reduce(lcsgpu_ctx* ctx, Lane& L, int elem, int distance_kind, int modi
     return LCSGPU_OK;
 }
 
-int nj_reduce(lcsgpu_ctx* ctx, Lane& L, int elem, int distance_kind, int32_t* out_left, int32_t* out_right)
+// One resident launch at a time in this process: each wants every CU's LDS, and two of them -- two host threads with a context
+// each on one device -- would hold half the chip each and wait for the other half.  (Another PROCESS on the same device can
+// still do that: the workgroups give up after ~1 s and the call below runs the merges as launches.)
+static std::mutex g_resident_launch;
+
+int nj_reduce(lcsgpu_ctx* ctx, Lane& L, int elem, int distance_kind, int32_t* out_left, int32_t* out_right, bool resident = true)
 {
     const int32_t n = ctx->n;
     HIP_TRY(hipSetDevice(ctx->device));
@@ -1181,10 +1186,11 @@ int nj_reduce(lcsgpu_ctx* ctx, Lane& L, int elem, int distance_kind, int32_t* ou
     // kernel fits a CU; else four launches per merge (tree_kernels.hip).  The same floats either way.
     const int cap = lcsgpu::nj_loop_cap(n);
     int grid = 0;
-    if (n >= 3 && n <= lcsgpu::NJ_LOOP_MAX_N && tune_int("nj_loop", 1)) {
+    if (resident && n >= 3 && n <= lcsgpu::NJ_LOOP_MAX_N && tune_int("nj_loop", 1)) {
         HIP_TRY(lcsgpu::nj_loop_grid(cap, &grid));
         const int g = tune_int("nj_groups", 0);
         if (g > 0 && g < grid) grid = g;
+        if (grid > 0 && tune_int("nj_oversubscribe", 0)) grid *= 2; // a test aid: half the workgroups cannot be resident -- the others give up, the merges run as launches
     }
     const size_t tri_floats = ((size_t)tri_offset(n) + 3 + 4) & ~(size_t)3; // whole 16-byte loads at the end
     int rc = reserve_big(ctx, ctx->d_dist, tri_floats * sizeof(float) * (grid ? 2 : 1), "the float distance triangle");
@@ -1219,7 +1225,9 @@ int nj_reduce(lcsgpu_ctx* ctx, Lane& L, int elem, int distance_kind, int32_t* ou
     HIP_TRY(lcsgpu::launch_float_distances(L.d_out.p, elem, (const uint32_t*)ctx->d_lens.p, (const float*)ctx->d_powf.p,
                                            distance_kind, n, a.D, L.stream));
     if (profile) { HIP_TRY(hipStreamSynchronize(L.stream)); t_lap[2] = now(); }
+    std::unique_lock<std::mutex> lock(g_resident_launch, std::defer_lock);
     if (grid) {
+        lock.lock();
         lcsgpu::NjLoopArgs p{};
         p.a = a;
         p.D2 = a.D + tri_floats;
@@ -1250,9 +1258,11 @@ int nj_reduce(lcsgpu_ctx* ctx, Lane& L, int elem, int distance_kind, int32_t* ou
     if (profile) fprintf(stderr, "lcsgpu_nj: results on the host %.1f ms after the launch was over (%.1f ms since the triangle was ready)\n", (now() - t_lap[3]) * 1e3, (now() - t_lap[0]) * 1e3);
     L.plan_in_flight = false;
     note_async_call(ctx);
-    if (sel[3])
-        return fail(LCSGPU_E_HIP, "NJ: the workgroups of the resident launch did not meet at a barrier (LCSGPU_TUNE=nj_loop=0 "
-                                  "runs the merges as separate launches)");
+    if (sel[3]) { // the workgroups of the resident launch did not meet (the CUs were not theirs alone): as launches, from the LCS values
+        if (profile || getenv("LCSGPU_VERBOSE")) fprintf(stderr, "lcsgpu_nj: the resident launch gave up waiting; the merges run as launches\n");
+        lock.unlock();
+        return nj_reduce(ctx, L, elem, distance_kind, out_left, out_right, false);
+    }
     if (sel[2])
         return fail(LCSGPU_E_INVALID, "NJ: no finite q (a pair with LCS 0?) -- the reference's result is degenerate "
                                       "for this input");

@@ -62,3 +62,13 @@ def test_shapes_of_the_resident_launch(engine, tune):
         want = _nj(engine, 1, "nj_loop=0")
         got = _nj(engine, 1, tune)
         assert (got[0] == want[0]).all() and (got[1] == want[1]).all()
+
+
+def test_a_resident_launch_that_cannot_meet_gives_up_and_the_merges_run_as_launches(engine):
+    """Twice as many workgroups as CUs: the resident half waits for words that cannot come, gives up after ~1 s (nothing hangs),
+    and lcsgpu_nj runs the merges as launches from the same LCS values -- what happens when another process holds CUs."""
+    seqs = _family(500, 100, seed=11)
+    engine.upload_seqs(seqs)
+    want = _nj(engine, 1, "nj_loop=0")
+    got = _nj(engine, 1, "nj_loop=1,nj_oversubscribe=1")
+    assert (got[0] == want[0]).all() and (got[1] == want[1]).all()
