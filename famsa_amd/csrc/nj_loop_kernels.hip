@@ -6,17 +6,18 @@
 // The arithmetic is tree_kernels.hip's nj_*_kernel operation for operation (the reference's float
 // association, its sequential sums in ascending cluster order, the first strict minimum of q in
 // (i, j) lexicographic order); what changes is where the work waits.  Every workgroup OWNS a
-// share of the flat triangle (every G-th block of 1 KB) -- it alone reads those distances with ordinary loads and
-// it alone rewrites them -- and keeps the n cluster sums and active flags as copies in its LDS.
+// share of the flat triangle (every G-th block of 1 KB) -- it alone reads those distances with
+// ordinary loads and it alone rewrites them -- and keeps the n cluster sums and active flags as
+// copies in its LDS.
 // Per merge:
 //
 //   1  scan the own share for the smallest q (16-byte loads; a row that is gone has NaN for its sum
-//      and loses by itself), WHILE wave 0 adds up the merged cluster's sum of the previous merge in
-//      ascending order, rounding as the reference's one-after-the-other float additions do
-//      (ordered_sum.h); every workgroup runs its own copy.  The pairs of the merged cluster are
-//      evaluated afterwards, from LDS.
-//   2  post the candidate (two tagged 64-bit words), poll everybody's: every workgroup reduces the
-//      G candidates itself and knows the pair (mi, mj).
+//      and loses by itself); the last wave to finish posts the workgroup's candidate (two tagged 64-bit
+//      words) and polls everybody's -- WHILE wave 0 adds up the merged cluster's sum of the previous
+//      merge in ascending order, rounding as the reference's one-after-the-other float additions do
+//      (ordered_sum.h): the chain runs beside the scan AND the exchange, in every workgroup's own copy.
+//   2  the pairs of the merged cluster (its distances are the chain's addends, in LDS) are the same in
+//      every workgroup and need no exchange: their smallest q against the exchanged one -> (mi, mj).
 //   3  for the entries (mi, k) of the own share: u = Dik + Djk, post u tagged, store the new distance.
 //   4  poll the u of all active k; everybody derives the same new distances (u - Dij) / 2 and the
 //      same sums (sum - u) + d from them in its own LDS.
@@ -31,7 +32,7 @@
 // what is alive: n^3/3 x 2 B in total instead of n^3 x 2 B.
 //
 // One workgroup per CU, so that all are resident at once; a word that does not arrive within ~1 s
-// sets an error flag and every workgroup leaves.
+// sets an error flag and every workgroup leaves (lcsgpu_nj then runs the merges as launches).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
