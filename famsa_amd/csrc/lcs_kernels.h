@@ -173,6 +173,9 @@ struct BoruvkaArgs {
     int32_t n, kind, n_chunks, rows_per_chunk;
     unsigned long long* fuse_row; // [n] the records of a local half done by the LCS launch itself (FuseArgs)
     unsigned long long* fuse_col; // [n]
+    int32_t keep;                 // row_best / row_aux / part hold the LAST round's results of the same block and chunks: a record
+                                  // whose edge still leaves its vertex's component stands (mst_kernels.hip, record_stands)
+    int32_t crossmul;             // the exact path proves most candidates worse with one multiplication before it divides
 };
 hipError_t launch_boruvka_init(const BoruvkaArgs& a, hipStream_t stream);
 // local half by the LCS launch (run_rows with FuseArgs over the block's rows): reset the records before it,

@@ -231,6 +231,9 @@ struct lcsgpu_ctx {
         // NULL -- by recomputing the block's LCS values with the fold fused into the launch (O(n) memory);
         // fused_ready: the launch that filled b.tri has already done round 0's local half
         bool fused_ready = false;
+        // passes_stand: row_best / part hold the passes' results of the round before, and the labels have only merged since
+        // (a device merge; labels handed in by the caller end it): records whose edges still cross stand (BoruvkaArgs::keep)
+        bool passes_stand = false;
     } mst;
     double total_kernel_ms = 0; // completed host-memory calls
 };

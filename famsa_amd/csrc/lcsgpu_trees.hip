@@ -144,6 +144,7 @@ static int shard_begin(lcsgpu_ctx* ctx, Lane& L, void* d_tri, int elem, int32_t 
     ctx->mst.found = 0;
     ctx->mst.rounds = 0;
     ctx->mst.fused_ready = false;
+    ctx->mst.passes_stand = false;
     if (d_tri && compute) {
         rc = fused_rows(ctx, L, b, d_tri, elem, false);
         if (rc) {
@@ -167,8 +168,13 @@ static int shard_best(lcsgpu_ctx* ctx, Lane& L, void* d_keys, lcsgpu_mst_key* h_
     } else if (ctx->mst.fused_ready && ctx->mst.rounds == 0) {
         HIP_TRY(lcsgpu::launch_boruvka_fuse_fold(b, L.stream)); // the launch that filled the triangle did round 0
         ctx->mst.fused_ready = false;                           // its records are spent: from here on the passes
-    } else
+    } else {
+        static const int keep = tune_int("mst_keep", 1), crossmul = tune_int("mst_crossmul", 1);
+        b.keep = keep && ctx->mst.passes_stand ? 1 : 0;
+        b.crossmul = crossmul ? 1 : 0;
         HIP_TRY(lcsgpu::launch_boruvka_best(b, ctx->mst.elem, L.stream));
+        ctx->mst.passes_stand = true;
+    }
     if (h_keys) {
         HIP_TRY(hipMemcpyAsync(h_keys, b.best, (size_t)b.n * sizeof(lcsgpu::MstKey), hipMemcpyDeviceToHost, L.stream));
         HIP_TRY(hipStreamSynchronize(L.stream));
@@ -334,6 +340,7 @@ int lcsgpu_mst_shard_set_components(lcsgpu_ctx* ctx, const int32_t* comp)
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipMemcpyAsync(ctx->mst.b.comp, comp, (size_t)ctx->n * 4, hipMemcpyHostToDevice, L.stream));
     HIP_TRY(hipStreamSynchronize(L.stream));
+    ctx->mst.passes_stand = false; // the caller's labels need not be a coarsening of the ones the passes saw
     // A round of the host-merge protocol ends here (shard_best -> lcsgpu_mst_merge_host -> this call), as a round of the
     // device protocol ends in shard_merge_async: from now on the labels count (the fused launches fold with them, the
     // records round 0's launch left behind are spent and the passes take over).

@@ -96,9 +96,16 @@ __device__ __forceinline__ uint32_t l_threshold(uint32_t l_b, uint32_t len_b, ui
 // The exact comparison: Transform<double, KIND> (hpp:28-82) and MSTPrim's key order.  A candidate with the
 // best's own (l, indel) has the best's distance bit for bit: only the ids decide, no division.  Returns true
 // if the best's (l, length) changed.
-template <int KIND, typename PW>
-__device__ __forceinline__ bool exact_update(const PW& pw, Best& b, uint32_t l, uint32_t indel, uint32_t lo, uint32_t hi,
-                                             uint32_t len_other)
+//
+// Before the division, one multiplication (CROSSMUL): with p = the numerator (exact in f64: a table entry or an integer),
+// the quotient q = p / l rounds to fl(q) >= q (1 - 2^-53).  If p > fl(fl(d_b * l) * (1 + 2^-50)) then, the two roundings of
+// the right-hand side being at most 2^-52 relative together, p > d_b l (1 + 2^-51), so q > d_b (1 + 2^-51) and
+// fl(q) > d_b (1 + 2^-51)(1 - 2^-53) > d_b: the candidate is strictly worse and never reaches the ids.  (No best yet:
+// d_b = DBL_MAX, the product is inf or DBL_MAX-sized and nothing is dropped.)  On ragged sets the integer pre-filter lets
+// most candidates through (its slack is half the difference of lengths); this test ends them without the ~30
+// instructions of an IEEE f64 division.
+__device__ __forceinline__ bool exact_update_p(Best& b, uint32_t l, uint32_t indel, double p, uint32_t lo, uint32_t hi,
+                                               uint32_t len_other, bool crossmul)
 {
     const unsigned long long id = ~(((unsigned long long)lo << 32) + hi);
     if (l == b.l && indel == b.indel) {
@@ -107,8 +114,10 @@ __device__ __forceinline__ bool exact_update(const PW& pw, Best& b, uint32_t l, 
     }
     double d;
     if (l == 0) d = 1.7976931348623155e308; // nextafter(DBL_MAX, 0), hpp:61,73
-    else if (KIND == 1) d = pw(indel) / (double)l;
-    else d = (double)indel / (double)l;
+    else {
+        if (crossmul && p > (__longlong_as_double((long long)b.d) * (double)l) * (1.0 + 0x1p-50)) return false;
+        d = p / (double)l;
+    }
     const unsigned long long db = (unsigned long long)__double_as_longlong(d);
     if (!key_less(db, id, b.d, b.id)) return false;
     b.d = db;
@@ -117,6 +126,25 @@ __device__ __forceinline__ bool exact_update(const PW& pw, Best& b, uint32_t l, 
     b.indel = indel;
     b.len_o = len_other;
     return true;
+}
+
+template <int KIND, typename PW>
+__device__ __forceinline__ bool exact_update(const PW& pw, Best& b, uint32_t l, uint32_t indel, uint32_t lo, uint32_t hi,
+                                             uint32_t len_other, bool crossmul = true)
+{
+    return exact_update_p(b, l, indel, KIND == 1 ? pw(indel) : (double)indel, lo, hi, len_other, crossmul);
+}
+
+// A record of the LAST round stands in this one when its edge still leaves its vertex's component: components only
+// merge, so the edges that cross now are a subset of those that crossed then, and the smallest of then that is still
+// among them is the smallest of now.  (Same subset of pairs both times: the same row, the same chunk of the same block.)
+__device__ __forceinline__ bool record_stands(const BoruvkaArgs& a, const MstKey& k, int v, int cv)
+{
+    if (k.id == NO_ID) return false;
+    const unsigned long long packed = ~k.id;
+    const uint32_t lo = (uint32_t)(packed >> 32), hi = (uint32_t)packed;
+    const uint32_t other = lo == (uint32_t)v ? hi : lo;
+    return other < (uint32_t)a.n && a.comp[other] != cv;
 }
 
 // smallest key of the wave, in every lane
@@ -172,6 +200,8 @@ __global__ __launch_bounds__(256) void boruvka_row_kernel(BoruvkaArgs a)
         return;
     }
     const int cv = a.comp[v];
+    if (a.keep && record_stands(a, a.row_best[v], v, cv)) return; // (uniform: every lane looks at the same record)
+    const bool crossmul = a.crossmul != 0;
     const uint32_t len_v = a.lens[v];
     const T* row = (const T*)a.tri + ((int64_t)v * (v - 1) / 2 - a.off);
     const int last = v - 1;
@@ -196,7 +226,7 @@ __global__ __launch_bounds__(256) void boruvka_row_kernel(BoruvkaArgs a)
             if (lv >= thr && u < v) {
                 if (a.comp[u] != cv) {
                     const uint32_t lu = a.lens[u];
-                    changed |= exact_update<KIND>(pw, b, lv, len_v + lu - 2u * lv, (uint32_t)u, (uint32_t)v, lu);
+                    changed |= exact_update<KIND>(pw, b, lv, len_v + lu - 2u * lv, (uint32_t)u, (uint32_t)v, lu, crossmul);
                 }
             }
         }
@@ -264,6 +294,9 @@ __global__ __launch_bounds__(256) void boruvka_col_kernel(BoruvkaArgs a)
     if (v >= a.n) return;
     Best b;
     const int cv = a.comp[v];
+    // the last round's partial of this chunk (the smaller of the row's and the chunk's own) stands: this lane is done
+    if (a.keep && record_stands(a, a.part[(size_t)chunk * a.n + v], v, cv)) return;
+    const bool crossmul = a.crossmul != 0;
     const uint32_t len_v = a.lens[v];
     const T* tri = (const T*)a.tri - a.off;
     if (v >= a.r0 && v < a.r1) {
@@ -286,7 +319,7 @@ __global__ __launch_bounds__(256) void boruvka_col_kernel(BoruvkaArgs a)
             if (u > v && cu != cv) {
                 const uint32_t lv = tri[(int64_t)u * (u - 1) / 2 + v];
                 if (lv >= l_threshold(b.l, b.len_o, len_u))
-                    exact_update<KIND>(pw, b, lv, len_u + len_v - 2u * lv, (uint32_t)v, (uint32_t)u, len_u);
+                    exact_update<KIND>(pw, b, lv, len_u + len_v - 2u * lv, (uint32_t)v, (uint32_t)u, len_u, crossmul);
             }
         }
     };
@@ -321,7 +354,7 @@ __global__ __launch_bounds__(256) void boruvka_col_kernel(BoruvkaArgs a)
                     const int u = ub + k;
                     if (a.comp[u] != cv) {
                         const uint32_t len_u = a.lens[u];
-                        if (exact_update<KIND>(pw, b, lv, len_u + len_v - 2u * lv, (uint32_t)v, (uint32_t)u, len_u))
+                        if (exact_update<KIND>(pw, b, lv, len_u + len_v - 2u * lv, (uint32_t)v, (uint32_t)u, len_u, crossmul))
                             thr = l_threshold(b.l, b.len_o, mb);
                     }
                 }

@@ -275,3 +275,39 @@ def test_the_length_bound_lets_tiles_go_and_changes_nothing(tmp_path):
     off, log_off = run({"LCSGPU_MST_MODE": "recompute", "LCSGPU_TUNE": "mst_length_bound=0", "Y": "22"})
     assert off == want
     assert not any("let go" in l and " 0 let go" not in l for l in log_off.splitlines() if "let go" in l)
+
+
+def test_kept_records_and_the_multiplication_test_change_no_tree(tmp_path):
+    """The passes over a resident triangle take two shortcuts (mst_kernels.hip): a vertex's record of the round before stands
+    when its edge still leaves the vertex's component (BoruvkaArgs::keep), and a candidate is proved worse by one
+    multiplication before the IEEE division (exact_update_p).  Neither may move an edge: a ragged, tie-heavy set (short
+    sequences over four letters: many equal distances, so the id order decides often; lengths 8-70: the integer filter's
+    slack is wide) and a family set, each with both shortcuts, with each alone and with none -- and against the rounds that
+    recompute, which share neither."""
+    rng = np.random.Generator(np.random.PCG64(31))
+    seqs = [rng.integers(0, 4, size=int(rng.integers(8, 71)), dtype=np.uint8) for _ in range(3000)]
+    anc = rng.integers(0, 20, size=120, dtype=np.uint8)
+    for _ in range(1500):
+        s = anc.copy()
+        m = rng.random(120) < 0.15
+        s[m] = rng.integers(0, 20, size=int(m.sum()), dtype=np.uint8)
+        seqs.append(s[: int(rng.integers(90, 121))].copy())
+    seqs = [seqs[i] for i in rng.permutation(len(seqs))]
+    codes, offsets = seqio.pack(seqs)
+    path = str(tmp_path / "ties.fasta")
+    seqio.to_fasta(codes, offsets, path)
+
+    def run(tag, env, dist="indel075_div_lcs"):
+        out = str(tmp_path / ("t_%s.dnd" % tag))
+        e = dict(os.environ)
+        e.update(env)
+        p = subprocess.run([CLI, "-gt", "sl", "-dist", dist, "-gt_export", path, out], stderr=subprocess.PIPE, text=True, env=e, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        return hashlib.sha256(open(out, "rb").read()).hexdigest()
+
+    for dist in ("indel075_div_lcs", "indel_div_lcs"):
+        want = run("none" + dist, {"LCSGPU_MST_MODE": "passes", "LCSGPU_TUNE": "mst_keep=0,mst_crossmul=0"}, dist)
+        assert run("both" + dist, {"LCSGPU_MST_MODE": "passes"}, dist) == want
+        assert run("keep" + dist, {"LCSGPU_MST_MODE": "passes", "LCSGPU_TUNE": "mst_crossmul=0"}, dist) == want
+        assert run("mul" + dist, {"LCSGPU_MST_MODE": "passes", "LCSGPU_TUNE": "mst_keep=0"}, dist) == want
+        assert run("rec" + dist, {"LCSGPU_MST_MODE": "recompute"}, dist) == want
