@@ -97,7 +97,8 @@ __device__ __forceinline__ uint32_t l_threshold(uint32_t l_b, uint32_t len_b, ui
 // best's own (l, indel) has the best's distance bit for bit: only the ids decide, no division.  Returns true
 // if the best's (l, length) changed.
 //
-// Before the division, one multiplication (CROSSMUL): with p = the numerator (exact in f64: a table entry or an integer),
+// Before the division, one multiplication (CROSSMUL): with p = the numerator (a table entry or an integer: 0 or >= 1, so no
+// quotient is subnormal),
 // the quotient q = p / l rounds to fl(q) >= q (1 - 2^-53).  If p > fl(fl(d_b * l) * (1 + 2^-50)) then, the two roundings of
 // the right-hand side being at most 2^-52 relative together, p > d_b l (1 + 2^-51), so q > d_b (1 + 2^-51) and
 // fl(q) > d_b (1 + 2^-51)(1 - 2^-53) > d_b: the candidate is strictly worse and never reaches the ids.  (No best yet:

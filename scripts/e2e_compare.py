@@ -46,9 +46,15 @@ def ref_tree(fasta, gt, heuristic, limit=150):
     return res
 
 
+WORK = []
+
+
 def gpu(args, fasta, runs=2):
-    """famsa-gpu `runs` times: (walls, tree-stage times, the Newick)"""
+    """famsa-gpu `runs` times: (walls, tree-stage times, the Newick); WORK[-1] = the sums of the command's own stage timers
+    (load, sort, upload, tree, Newick, store): wall - work = what starting a process that uses HIP costs (device discovery,
+    context, the code objects' first use, exit), reported beside the rest so that a small case compares like with like"""
     walls, stages, text = [], [], None
+    work = []
     for _ in range(runs):
         # the driver hands the device memory of a process that has ended back only after a while, and a process started
         # meanwhile waits for it (scripts/back_to_back.sh: -gt upgma at 100 000 sequences 1.6 s after a rest, 2.5-4 s right
@@ -60,7 +66,9 @@ def gpu(args, fasta, runs=2):
         walls.append(time.time() - t0)
         kv = dict(l.split("=") for l in p.stderr.split() if "=" in l)
         stages.append(float(kv["time.tree_build"]))
+        work.append(sum(float(kv.get("time." + k, 0)) for k in ("load", "sort", "gpu_upload", "tree_build", "newick", "store")))
         text = open("/tmp/cmp_gpu.dnd", "rb").read()
+    WORK.append(work)
     return walls, stages, text
 
 
@@ -81,7 +89,9 @@ def case(name, fasta, gt, heuristic=0, cli_args=(), with_reference=True, limit=1
            "identical_to": "the reference run beside it" if want is not None else ("the committed pin of the reference's output" if pin is not None else None),
            "reference_tree_s": round(t_ref, 3) if t_ref else ("> %d (stopped)" % limit if with_reference else "not run"),
            "gpu_tree_build_s": round(tb, 3), "gpu_cli_wall_s": round(min(walls), 3),
-           "gpu_runs": [{"tree_build_s": round(a, 3), "cli_wall_s": round(b, 3)} for a, b in zip(stages, walls)],
+           "gpu_runs": [{"tree_build_s": round(a, 3), "cli_wall_s": round(b, 3), "stages_s": round(w, 3), "startup_s": round(b - w, 3)}
+                        for a, b, w in zip(stages, walls, WORK[-1])],
+           "gpu_startup_s": round(min(b - w for b, w in zip(walls, WORK[-1])), 3),
            "speedup_tree_stage": round(t_ref / tb, 1) if t_ref else None}
     print(rec, flush=True)
     out["cases"].append(rec)

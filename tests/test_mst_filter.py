@@ -76,3 +76,55 @@ def test_filter_never_drops_a_winner_random(kind, spread):
     thr = l_threshold(l_b, len_b, len_u)
     l = np.clip(thr + rng.integers(-3, 2, m), 0, np.minimum(len_v, len_u))
     assert _check(kind, len_v, len_b, l_b, len_u, l) > m // 20
+
+
+# ---- the multiplication before the division (mst_kernels.hip, exact_update_p) --------------------------------------------
+# Claim: with p = the numerator (a double that is 0 or >= 1), l = the LCS length and d_b = the best distance so far,
+#     p > fl(fl(d_b * l) * (1 + 2^-50))   =>   fl(p / l) > d_b,
+# so a candidate the test drops can neither win nor tie.  numpy's float64 arithmetic is IEEE like the device's (no
+# contraction: a product and a second product).  Checked where it is tight: numerators within a few ulp of d_b * l.
+def _crossmul_drops(p, l, d_b):
+    return p > (d_b * l.astype(np.float64)) * (1.0 + 2.0 ** -50)
+
+
+@pytest.mark.parametrize("kind", [0, 1])
+def test_the_multiplication_never_drops_a_winner_or_a_tie(kind):
+    rng = np.random.Generator(np.random.PCG64(77 + kind))
+    m = 3_000_000
+    l_b = rng.integers(1, 4000, m)
+    indel_b = rng.integers(0, 8000, m)
+    p_b = indel_b.astype(np.float64) ** 0.75 if kind == 1 else indel_b.astype(np.float64)
+    d_b = p_b / l_b.astype(np.float64)  # a best as the kernel holds it: a rounded quotient
+    l = rng.integers(1, 4000, m)
+    # numerators at, just above and just below d_b * l: steps of 0..40 ulp either way (not table entries -- any double
+    # is allowed by the claim, and real table entries are never this close without being equal)
+    t = d_b * l.astype(np.float64)
+    p = t + rng.integers(-40, 41, m) * np.spacing(t)
+    small = p < 1.0  # a numerator is 0 or >= 1 (indel or indel^0.75 of an integer): no quotient is subnormal
+    p[small] = rng.integers(0, 2, int(small.sum())).astype(np.float64)
+    dropped = _crossmul_drops(p, l, d_b)
+    q = p / l.astype(np.float64)
+    assert not (dropped & ~(q > d_b)).any()
+    assert dropped.sum() > m // 4 and (~dropped).sum() > m // 4  # both sides of the test were exercised
+    # and it is not vacuous the other way: a candidate it lets through by a wide margin is indeed not worse
+    far = p < t * (1 - 1e-9)
+    assert (q[far] <= d_b[far]).all()
+
+
+def test_the_multiplication_with_no_best_yet_and_with_real_table_entries():
+    l = np.arange(1, 70000, dtype=np.int64)
+    big = np.full(l.shape, np.finfo(np.float64).max)
+    with np.errstate(over="ignore"):
+        assert not _crossmul_drops(np.full(l.shape, 1e300), l, big).any()  # DBL_MAX as "no candidate": nothing is dropped
+    # all pairs of real candidates of small sets: dropped => strictly greater as the kernel compares them
+    L = 40
+    lv, lb, lu, x, y = np.mgrid[1:L:3, 1:L:2, 1:L:2, 1:L:2, 1:L:2].reshape(5, -1)
+    ok = (x <= np.minimum(lv, lb)) & (y <= np.minimum(lv, lu))
+    lv, lb, lu, x, y = (a[ok] for a in (lv, lb, lu, x, y))
+    for kind in (0, 1):
+        d_b = dist(kind, x, lv, lb)
+        indel = (lv + lu - 2 * y).astype(np.float64)
+        p = indel ** 0.75 if kind == 1 else indel
+        dropped = _crossmul_drops(p, y, d_b)
+        assert not (dropped & ~(p / y.astype(np.float64) > d_b)).any()
+        assert dropped.any()
