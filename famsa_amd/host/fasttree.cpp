@@ -1074,6 +1074,8 @@ template <Distance D>
 void run_fast(LcsSource& src, GT partial, const FastTreeParams& p, tree_structure& tree)
 {
     const int n = src.n();
+    const auto t_in = std::chrono::steady_clock::now();
+    auto since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); };
     tree.assign(n, node_t(-1, -1));
     if (n < 2) return;
     tree.resize((size_t)2 * n - 1, node_t(-1, -1));
@@ -1087,9 +1089,19 @@ void run_fast(LcsSource& src, GT partial, const FastTreeParams& p, tree_structur
     struct Giveback {
         ~Giveback() { g_cpu.reset(0); }
     } giveback;
-    TaskPool pool(n_pool, host_test_int("leafmax", fasttree_leaf_threads(n_pool))); // (FAMSA_HOST_TEST leafmax=N: sweeps)
-    FastTree<D> ft{src, partial, p, &pool, {}};
-    ft.run_levels(n, tree);
+    double t_setup = 0, t_levels = 0;
+    const auto t_out = [&] {
+        TaskPool pool(n_pool, host_test_int("leafmax", fasttree_leaf_threads(n_pool))); // (FAMSA_HOST_TEST leafmax=N: sweeps)
+        FastTree<D> ft{src, partial, p, &pool, {}};
+        t_setup = since(t_in);
+        const auto t0 = std::chrono::steady_clock::now();
+        ft.run_levels(n, tree);
+        t_levels = since(t0);
+        return std::chrono::steady_clock::now();
+    }();
+    if (profile_on())
+        fprintf(stderr, "fasttree.stage: before the levels %.3f s (tree, engine lanes, pool), levels %.3f s, pool shut down %.3f s\n", t_setup, t_levels,
+                since(t_out));
 }
 
 } // namespace
