@@ -1076,14 +1076,17 @@ void run_fast(LcsSource& src, GT partial, const FastTreeParams& p, tree_structur
     const int n = src.n();
     const auto t_in = std::chrono::steady_clock::now();
     auto since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); };
+    if (n >= 2) tree.reserve((size_t)2 * n - 1); // (one block: assign + resize would fill n nodes, move them and fill the rest)
     tree.assign(n, node_t(-1, -1));
     if (n < 2) return;
     tree.resize((size_t)2 * n - 1, node_t(-1, -1));
+    const double t_tree = since(t_in);
     // `n_threads` cores' worth of host work, two and a half times as many threads to keep GPU requests in flight
     // (trees.h, fasttree_pool_threads)
     const int n_cpu = std::max(1, p.n_threads);
     int n_pool = host_test_int("pool", fasttree_pool_threads(n_cpu)); // (FAMSA_HOST_TEST pool=N: sweeps)
     src.expect_threads(4); // (the engine's lanes: the level-by-level walk asks from this thread, the leaf batches from three others)
+    const double t_lanes = since(t_in);
     g_cpu.reset(n_pool > n_cpu ? n_cpu + 1 : 0); // (+ 1: this thread's own, kept through the levels)
     g_cpu.acquire();
     struct Giveback {
@@ -1100,8 +1103,8 @@ void run_fast(LcsSource& src, GT partial, const FastTreeParams& p, tree_structur
         return std::chrono::steady_clock::now();
     }();
     if (profile_on())
-        fprintf(stderr, "fasttree.stage: before the levels %.3f s (tree, engine lanes, pool), levels %.3f s, pool shut down %.3f s\n", t_setup, t_levels,
-                since(t_out));
+        fprintf(stderr, "fasttree.stage: before the levels %.3f s (the empty tree %.3f, the engine's lanes %.3f, the pool %.3f), levels %.3f s, pool shut down %.3f s\n",
+                t_setup, t_tree, t_lanes - t_tree, t_setup - t_lanes, t_levels, since(t_out));
 }
 
 } // namespace

@@ -1,3 +1,4 @@
+#include <sys/mman.h>
 #include <sys/resource.h>
 #include "pipeline.h"
 
@@ -27,11 +28,12 @@ static double now_s()
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
-std::string guide_tree_newick(const SeqSet& s, const WorkSet& w, LcsSource& src, const TreeOptions& opt, Timings* t)
+std::string guide_tree_newick(const SeqSet& s, const WorkSet& w, LcsSource& src, const TreeOptions& opt, Timings* t, tree_structure* spare)
 {
     const double t0 = now_s();
     if (w.n_unique() == 1) return std::string(); // the reference skips the tree stage entirely (msa.cpp:549-556)
     tree_structure tree;
+    if (spare) tree.swap(*spare);
     // CFAMSA::adjustParams (msa.cpp:83-88): the heuristic is dropped for inputs below the threshold
     // (counted on ALL input records); createTreeGenerator (msa.cpp:134-239) wraps the partial generator
     int heuristic = opt.heuristic;
@@ -126,7 +128,16 @@ void release_in_background(Bytes& bytes)
         Bytes().swap(bytes);
         return;
     }
-    std::thread([held = std::move(bytes)]() mutable { Bytes().swap(held); }).detach();
+    std::thread([held = std::move(bytes)]() mutable {
+        // The pages go first, a piece at a time (MADV_DONTNEED takes the address space's lock shared, like a page fault); freeing
+        // the block then unmaps an empty range.  Unmapping 765 MB (3 x 10^6 sequences) in one go held that lock exclusively for
+        // 0.1 s, and the tree stage's first allocations on the main thread -- the empty tree: 48 MB -- stood still behind it.
+        const uintptr_t page = 4096, piece = (uintptr_t)32 << 20;
+        uintptr_t a = ((uintptr_t)held.data() + page - 1) & ~(page - 1);
+        const uintptr_t end = ((uintptr_t)held.data() + held.size()) & ~(page - 1);
+        for (; a < end; a += piece) (void)madvise((void*)a, (size_t)std::min(piece, end - a), MADV_DONTNEED);
+        Bytes().swap(held);
+    }).detach();
     Bytes().swap(bytes);
 }
 
@@ -156,16 +167,31 @@ std::string newick_gpu(const SeqSet& s, SeqSet* consumable, int device, const Tr
     std::vector<int> in_of(w.n_unique());
     for (int a = 0; a < w.n_unique(); ++a) in_of[a] = w.sorted2input[w.unique2sorted[a]];
     double t1 = now_s();
+    // The heuristics' tree has 2n - 1 nodes (48 MB at 3 x 10^6 sequences): its pages are touched now, by a thread of its own,
+    // while this one waits for the engine and the upload -- in front of the tree stage they cost 0.04 s, 0.11 s beside the
+    // release of the residues below (both work on the address space: profiles/c5_stage_r06.txt).
+    tree_structure spare;
+    std::future<void> spare_ready;
+    const bool fast_tree = opt.heuristic != 0 && (int)s.size() >= opt.fast.threshold && w.n_unique() >= 2;
+    if (fast_tree && w.n_unique() >= 100000 && !host_test("no_spare_tree"))
+        spare_ready = std::async(std::launch::async, [&spare, n = (size_t)w.n_unique()] { spare.assign(2 * n - 1, node_t(-1, -1)); });
     std::unique_ptr<GpuLcsSource> held = engine->get(); // waits only for what the sort did not cover
     GpuLcsSource& src = *held;
     double t1b = now_s();
     src.upload_ordered(s.codes.data(), s.offsets, in_of); // the records as they were read; the engine gathers the working order's on the device
+    if (spare_ready.valid()) spare_ready.get();
     double t2 = now_s();
     if (t) t->rss_upload_kb = resident_kb();
-    if (consumable) release_in_background(consumable->codes); // on the device now
+    // The residues are on the device now; they go back to the system AFTER the tree stage, while the Newick is made.  Released
+    // here, beside the levels of the heuristics, the unmapping of 765 MB (3 x 10^6 sequences) disturbed every thread of the tree
+    // stage: 0.86-0.99 s against 0.71-0.89 s, and the whole command was 0.14 s slower (profiles/c5_stage_r06.txt;
+    // FAMSA_HOST_TEST release_early / release_never: the other two ways).
+    const int release_when = host_test("release_never") ? 2 : host_test("release_early") ? 0 : 1;
+    if (consumable && release_when == 0) release_in_background(consumable->codes);
     struct rusage ru0, ru1;
     getrusage(RUSAGE_SELF, &ru0);
-    std::string nwk = guide_tree_newick(s, w, src, opt, t);
+    std::string nwk = guide_tree_newick(s, w, src, opt, t, spare.empty() ? nullptr : &spare);
+    if (consumable && release_when == 1) release_in_background(consumable->codes);
     if (profile_on()) { // how much of the tree stage the host's cores were busy
         getrusage(RUSAGE_SELF, &ru1);
         auto sec = [](const timeval& a, const timeval& b) { return (double)(b.tv_sec - a.tv_sec) + 1e-6 * (double)(b.tv_usec - a.tv_usec); };

@@ -33,8 +33,9 @@ struct TreeOptions {
 };
 
 long resident_kb(); // VmRSS of this process
+// spare: storage the caller has set up for the tree meanwhile (its content does not matter, its capacity and touched pages do)
 std::string guide_tree_newick(const SeqSet& s, const WorkSet& w, LcsSource& src_of_unique, const TreeOptions& opt,
-                              Timings* t = nullptr);
+                              Timings* t = nullptr, tree_structure* spare = nullptr);
 
 std::string guide_tree_newick_from_matrix(const SeqSet& s, const uint32_t* square_input_order, const TreeOptions& opt);
 // The engine context takes ~0.2 s to create (HIP initialisation): a caller may start that early, on another
@@ -47,9 +48,9 @@ EngineFuture start_engine(int device);
 EngineFuture start_engine(const std::vector<int>& devices, int expect_threads = 0); // one context per entry (entries may repeat)
 std::string guide_tree_newick_gpu(const SeqSet& s, int device, const TreeOptions& opt, Timings* t,
                                   EngineFuture* engine = nullptr);
-// The same for a caller that does not need the residues afterwards: once they are on the device, `s.codes` and the
-// packed copy are given back to the system by a background thread while the tree is built (at 3 x 10^6 records the
-// process otherwise carries 1.5 GB to its exit, and the exit takes that much longer).  Ids, offsets and lengths stay.
+// The same for a caller that does not need the residues afterwards: once the tree is built, `s.codes` is given back to
+// the system by a background thread while the Newick is made (at 3 x 10^6 records the process otherwise carries 0.8 GB
+// to its exit, and the exit takes that much longer).  Ids, offsets and lengths stay.
 std::string guide_tree_newick_gpu_consuming(SeqSet& s, int device, const TreeOptions& opt, Timings* t,
                                             EngineFuture* engine = nullptr);
 void dist_export_gpu(const SeqSet& s, int device, Distance dist, bool square, bool pid, const std::string& path,
