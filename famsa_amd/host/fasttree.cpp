@@ -155,6 +155,44 @@ private:
 };
 Slots g_leaf_requests(3);
 
+// The buffers the leaf requests' LCS values arrive in (up to 48 MB each, ~40 requests at 3 x 10^6 sequences) are used again:
+// a fresh vector per request meant 12 000 first-touch page faults, a fill with zeros and, when the last tree over it was done,
+// an unmapping that stops every thread of the process for a moment -- 1.3 s of system time in a tree stage of 0.9 s.  A buffer
+// comes back to the list when the last task that reads it lets go of it.
+class LeafBuffers {
+public:
+    std::shared_ptr<LcsBuf> take()
+    {
+        std::unique_ptr<LcsBuf> b;
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            if (!free_.empty()) {
+                b = std::move(free_.back());
+                free_.pop_back();
+            }
+        }
+        if (!b) b.reset(new LcsBuf);
+        return std::shared_ptr<LcsBuf>(b.release(), [this](LcsBuf* p) {
+            std::unique_ptr<LcsBuf> back(p);
+            std::lock_guard<std::mutex> lk(mu_);
+            if (free_.size() < 8) free_.push_back(std::move(back));
+        });
+    }
+    void release_in_background() // after the tree: a caller that goes on does not keep them, and this thread does not unmap them
+    {
+        std::vector<std::unique_ptr<LcsBuf>> held;
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            held.swap(free_);
+        }
+        if (!held.empty()) std::thread([h = std::move(held)]() mutable { h.clear(); }).detach();
+    }
+
+private:
+    std::mutex mu_;
+    std::vector<std::unique_ptr<LcsBuf>> free_;
+} g_leaf_bufs;
+
 struct OffCpu { // around a wait for the GPU
     OffCpu() { g_cpu.release(); }
     ~OffCpu() { g_cpu.acquire(); }
@@ -543,6 +581,10 @@ struct FastTree {
     FastTreeParams prm;
     TaskPool* pool;
     Transform<float, D> transform; // FastTree uses float distances throughout
+    struct LevelScratch { // evaluate_level_batched's arrays over all members of a level's splits, kept from level to level
+        std::vector<int, NoInit<int>> sample_global, cols, assign;
+        std::vector<float, NoInit<float>> dist;
+    } scratch;
 
     // distances of subset member `ref_local` to every member: calculateDistanceVector(ref, all)
     void row_distances(const std::vector<int>& ids, int ref_local, float* out)
@@ -750,7 +792,7 @@ struct FastTree {
                     ids.insert(ids.end(), pc->ids.begin(), pc->ids.end());
                     offs.push_back((int64_t)ids.size());
                 }
-                auto buf = std::make_shared<LcsBuf>();
+                std::shared_ptr<LcsBuf> buf = g_leaf_bufs.take();
                 bool have;
                 {
                     Scope tm(g_phase.lcs, Timeline::LCS);
@@ -767,7 +809,7 @@ struct FastTree {
                 auto submit_parts = [&] {
                     if (parts.empty()) return;
                     pool->submit(group, part_members, [this, parts, have, buf, &tree] {
-                        FastTree<D> worker{src, partial, prm, pool, {}};
+                        FastTree<D> worker{src, partial, prm, pool, {}, {}};
                         for (const Part& pt : parts) {
                             if (have) {
                                 PrecomputedSubset sub(src, pt.pc->ids, buf, pt.off);
@@ -810,7 +852,8 @@ struct FastTree {
         sample_ids.clear();
         if (n_samples >= n) return;
         std::mt19937 mt(seed);
-        std::vector<int> rnd(n);
+        static thread_local std::vector<int, NoInit<int>> rnd; // (kept per thread: 12 MB of first touches for the top split otherwise)
+        rnd.resize((size_t)n);
         std::iota(rnd.begin(), rnd.end(), 0);
         partial_shuffle(rnd.data() + 1, rnd.data() + n_samples, rnd.data() + n, mt);
         sample_ids.assign(rnd.begin(), rnd.begin() + n_samples);
@@ -843,7 +886,8 @@ struct FastTree {
             const size_t m = sample_ids[(size_t)j].empty() ? splits[(size_t)(j / n_evals)]->ids.size() : sample_ids[(size_t)j].size();
             off[(size_t)j + 1] = off[(size_t)j] + (int64_t)m;
         }
-        std::vector<int> sample_global((size_t)off[(size_t)n_jobs]);
+        auto& sample_global = scratch.sample_global; // (the level's large arrays are kept from level to level: no first touch, no zeros)
+        sample_global.resize((size_t)off[(size_t)n_jobs]);
         parallel_for(n_jobs, [&](int j) {
             const std::vector<int>& ids = splits[(size_t)(j / n_evals)]->ids;
             int* out = sample_global.data() + off[(size_t)j];
@@ -868,7 +912,9 @@ struct FastTree {
             seed_off[(size_t)j + 1] = seed_off[(size_t)j] + k;
             col_off[(size_t)j + 1] = col_off[(size_t)j] + (int64_t)splits[(size_t)(j / n_evals)]->ids.size();
         }
-        std::vector<int> seeds_global((size_t)n_jobs * k), seeds_local((size_t)n_jobs * k), cols((size_t)col_off[(size_t)n_jobs]);
+        std::vector<int> seeds_global((size_t)n_jobs * k), seeds_local((size_t)n_jobs * k);
+        auto& cols = scratch.cols;
+        cols.resize((size_t)col_off[(size_t)n_jobs]);
         std::atomic<bool> odd{false};
         parallel_for(n_jobs, [&](int j) {
             const std::vector<int>& ids = splits[(size_t)(j / n_evals)]->ids;
@@ -882,8 +928,10 @@ struct FastTree {
             std::copy(ids.begin(), ids.end(), cols.data() + col_off[(size_t)j]);
         });
         if (odd) return false; // the split-by-split form knows what the reference does then
-        std::vector<float> dist(cols.size());
-        std::vector<int> assign(cols.size());
+        auto& dist = scratch.dist;
+        auto& assign = scratch.assign;
+        dist.resize(cols.size());
+        assign.resize(cols.size());
         lap(2);
         {
             Scope t(g_phase.assign, Timeline::ASSIGN);
@@ -993,7 +1041,7 @@ struct FastTree {
             std::vector<Evaluation> best((size_t)n_splits);
             if (!splits.empty() && !evaluate_level_batched(splits, best)) {
                 parallel_for(n_splits, [&](int s) { // split by split: FastTree::makeEvaluation as it stands
-                    FastTree<D> worker{src, partial, prm, pool, {}};
+                    FastTree<D> worker{src, partial, prm, pool, {}, {}};
                     Evaluation& b = best[(size_t)s];
                     for (int eval = 0; eval < prm.num_evaluations; ++eval) {
                         int ns;
@@ -1095,11 +1143,12 @@ void run_fast(LcsSource& src, GT partial, const FastTreeParams& p, tree_structur
     double t_setup = 0, t_levels = 0;
     const auto t_out = [&] {
         TaskPool pool(n_pool, host_test_int("leafmax", fasttree_leaf_threads(n_pool))); // (FAMSA_HOST_TEST leafmax=N: sweeps)
-        FastTree<D> ft{src, partial, p, &pool, {}};
+        FastTree<D> ft{src, partial, p, &pool, {}, {}};
         t_setup = since(t_in);
         const auto t0 = std::chrono::steady_clock::now();
         ft.run_levels(n, tree);
         t_levels = since(t0);
+        g_leaf_bufs.release_in_background();
         return std::chrono::steady_clock::now();
     }();
     if (profile_on())

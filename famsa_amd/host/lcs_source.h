@@ -11,6 +11,8 @@
 #include <string>
 #include <vector>
 
+#include "noinit.h"
+
 struct lcsgpu_ctx;
 
 namespace famsa_host {
@@ -28,10 +30,10 @@ int host_test_int(const char* key, int dflt);
 bool profile_on();
 
 // LCS values as uint16 (all sequences <= 65535 residues) or uint32.
-struct LcsBuf {
+struct LcsBuf { // (a resize leaves new elements unset: whoever resizes fills all of them)
     bool wide = false;
-    std::vector<uint16_t> v16;
-    std::vector<uint32_t> v32;
+    std::vector<uint16_t, NoInit<uint16_t>> v16;
+    std::vector<uint32_t, NoInit<uint32_t>> v32;
     void resize(size_t n, bool wide_)
     {
         wide = wide_;

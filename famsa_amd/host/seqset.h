@@ -13,18 +13,12 @@
 #include <utility>
 #include <vector>
 
+#include "noinit.h"
+
 namespace famsa_host {
 
 // A byte buffer whose resize does not zero what it adds: the reader writes every byte itself, on all cores, and a
 // std::vector<uint8_t> would first fill 765 MB (3 x 10^6 records) with zeros on one thread -- a quarter of the load stage.
-template <class T>
-struct NoInit : std::allocator<T> {
-    template <class U> struct rebind { using other = NoInit<U>; };
-    NoInit() = default;
-    template <class U> NoInit(const NoInit<U>&) {}
-    template <class U> void construct(U* p) noexcept { ::new ((void*)p) U; } // default-init: nothing for a byte
-    template <class U, class... A> void construct(U* p, A&&... a) { ::new ((void*)p) U(std::forward<A>(a)...); }
-};
 using Bytes = std::vector<uint8_t, NoInit<uint8_t>>;
 
 struct SeqSet {
