@@ -155,44 +155,6 @@ private:
 };
 Slots g_leaf_requests(3);
 
-// The buffers the leaf requests' LCS values arrive in (up to 48 MB each, ~40 requests at 3 x 10^6 sequences) are used again:
-// a fresh vector per request meant 12 000 first-touch page faults, a fill with zeros and, when the last tree over it was done,
-// an unmapping that stops every thread of the process for a moment -- 1.3 s of system time in a tree stage of 0.9 s.  A buffer
-// comes back to the list when the last task that reads it lets go of it.
-class LeafBuffers {
-public:
-    std::shared_ptr<LcsBuf> take()
-    {
-        std::unique_ptr<LcsBuf> b;
-        {
-            std::lock_guard<std::mutex> lk(mu_);
-            if (!free_.empty()) {
-                b = std::move(free_.back());
-                free_.pop_back();
-            }
-        }
-        if (!b) b.reset(new LcsBuf);
-        return std::shared_ptr<LcsBuf>(b.release(), [this](LcsBuf* p) {
-            std::unique_ptr<LcsBuf> back(p);
-            std::lock_guard<std::mutex> lk(mu_);
-            if (free_.size() < 8) free_.push_back(std::move(back));
-        });
-    }
-    void release_in_background() // after the tree: a caller that goes on does not keep them, and this thread does not unmap them
-    {
-        std::vector<std::unique_ptr<LcsBuf>> held;
-        {
-            std::lock_guard<std::mutex> lk(mu_);
-            held.swap(free_);
-        }
-        if (!held.empty()) std::thread([h = std::move(held)]() mutable { h.clear(); }).detach();
-    }
-
-private:
-    std::mutex mu_;
-    std::vector<std::unique_ptr<LcsBuf>> free_;
-} g_leaf_bufs;
-
 struct OffCpu { // around a wait for the GPU
     OffCpu() { g_cpu.release(); }
     ~OffCpu() { g_cpu.acquire(); }
@@ -584,7 +546,8 @@ struct FastTree {
     struct LevelScratch { // evaluate_level_batched's arrays over all members of a level's splits, kept from level to level
         std::vector<int, NoInit<int>> sample_global, cols, assign;
         std::vector<float, NoInit<float>> dist;
-    } scratch;
+    };
+    LevelScratch scratch;
 
     // distances of subset member `ref_local` to every member: calculateDistanceVector(ref, all)
     void row_distances(const std::vector<int>& ids, int ref_local, float* out)
@@ -792,7 +755,7 @@ struct FastTree {
                     ids.insert(ids.end(), pc->ids.begin(), pc->ids.end());
                     offs.push_back((int64_t)ids.size());
                 }
-                std::shared_ptr<LcsBuf> buf = g_leaf_bufs.take();
+                auto buf = std::make_shared<LcsBuf>(); // (kept and used again, these buffers made the stage SLOWER: 0.83 against 0.75 s, profiles/c5_stage_r06.txt)
                 bool have;
                 {
                     Scope tm(g_phase.lcs, Timeline::LCS);
@@ -886,6 +849,7 @@ struct FastTree {
             const size_t m = sample_ids[(size_t)j].empty() ? splits[(size_t)(j / n_evals)]->ids.size() : sample_ids[(size_t)j].size();
             off[(size_t)j + 1] = off[(size_t)j] + (int64_t)m;
         }
+        if (host_test("no_level_scratch")) scratch = LevelScratch(); // (measurements: fresh arrays every level, as it was)
         auto& sample_global = scratch.sample_global; // (the level's large arrays are kept from level to level: no first touch, no zeros)
         sample_global.resize((size_t)off[(size_t)n_jobs]);
         parallel_for(n_jobs, [&](int j) {
@@ -1148,7 +1112,7 @@ void run_fast(LcsSource& src, GT partial, const FastTreeParams& p, tree_structur
         const auto t0 = std::chrono::steady_clock::now();
         ft.run_levels(n, tree);
         t_levels = since(t0);
-        g_leaf_bufs.release_in_background();
+        std::thread([held = std::move(ft.scratch)]() mutable { (void)held; }).detach(); // (its 50 MB are not unmapped by this thread either)
         return std::chrono::steady_clock::now();
     }();
     if (profile_on())

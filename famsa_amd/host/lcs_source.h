@@ -37,7 +37,9 @@ struct LcsBuf { // (a resize leaves new elements unset: whoever resizes fills al
     void resize(size_t n, bool wide_)
     {
         wide = wide_;
-        if (wide) { v32.resize(n); v16.clear(); } else { v16.resize(n); v32.clear(); }
+        v16.clear(); // (first: growing would otherwise move the old values to the new block)
+        v32.clear();
+        if (wide) v32.resize(n); else v16.resize(n);
     }
     size_t size() const { return wide ? v32.size() : v16.size(); }
     uint32_t operator[](size_t i) const { return wide ? v32[i] : v16[i]; }

@@ -20,7 +20,7 @@ for rep in 1 2; do
   echo "== $n profiled run $rep" >> $R
   LCSGPU_PROFILE=1 famsa_amd/famsa-gpu -v -medoidtree -gt upgma -gt_export /tmp/family_${n}_300.fasta /tmp/o.dnd 2>&1 | grep -E "fasttree.stage|fasttree.level [0-9]|fasttree.level parts|fasttree.tail|newick:|tree stage:|^time\." >> $R
 done
-for how in late release_early release_never no_spare_tree late release_early release_never; do
+for how in late no_level_scratch late no_level_scratch late no_level_scratch; do
 for rep in 1 2 3; do
   t0=$(date +%s.%N)
   FAMSA_HOST_TEST=$how famsa_amd/famsa-gpu -v -medoidtree -gt upgma -gt_export /tmp/family_${n}_300.fasta /tmp/o.dnd 2> /tmp/o.err
