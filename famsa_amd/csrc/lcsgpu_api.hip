@@ -181,7 +181,11 @@ int reserve_big(lcsgpu_ctx* ctx, DevBuf& buf, size_t bytes, const char* what)
     if (known && bytes > free_b + buf.cap)
         return fail(LCSGPU_E_NOMEM, "%s needs %.1f GB of device memory, %.1f GB are free on device %d (of %.1f GB)", what,
                     bytes / 1e9, (free_b + buf.cap) / 1e9, ctx->device, total_b / 1e9);
+    const auto t0 = std::chrono::steady_clock::now();
     const hipError_t e = buf.reserve(bytes);
+    if (bytes >= ((size_t)1 << 30) && getenv("LCSGPU_PROFILE")) // (right after another process has ended, 44 GB can take a second or two)
+        fprintf(stderr, "lcsgpu: %.1f GB for %s allocated in %.3f s\n", bytes / 1e9, what,
+                std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
     if (e != hipSuccess) {
         (void)hipGetLastError(); // an allocation failure is not sticky
         return fail(LCSGPU_E_NOMEM, "%s: allocating %.1f GB of device memory failed: %s", what, bytes / 1e9,

@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <future>
 #include <cstdarg>
 #include <cstdio>
 #include <cmath>

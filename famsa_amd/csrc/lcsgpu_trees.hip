@@ -962,7 +962,35 @@ int upgma_reduce(lcsgpu_ctx* ctx, Lane& L, int elem, int distance_kind, int modi
     }
     size_t ld = (size_t)n;
     int rc = LCSGPU_E_NOMEM;
-    if (square && batch_k) {
+    // The matrix's allocation beside the LCS launches.  44 GB (100 000 sequences) are handed out in tens of milliseconds on a
+    // device that has rested, and in one to two SECONDS when another process has just given that much back
+    // (profiles/upgma_modes_r06.txt: the same command 1.63 or 2.6-3.7 s).  Where there is room for the whole uint16 triangle
+    // as well (10 GB), a helper thread allocates the matrix while this one computes the triangle, and the values become
+    // distances in one launch afterwards; else -- and if the helper fails -- row block by row block as below.
+    bool own_triangle = false;
+    if (!resident && square && batch_k && tune_int("upgma_async_alloc", 1) && tune_int("upgma_spare", 0) == 0) {
+        const size_t spare = std::max<size_t>({2048, (size_t)n / 10, (size_t)2 * batch_k});
+        const size_t ld_a = ((size_t)n + spare + 63) & ~(size_t)63;
+        const size_t matrix = (size_t)n * ld_a * sizeof(float), whole = (size_t)tri_offset(n) * elem;
+        if (matrix >= ((size_t)4 << 30) && matrix + whole + ((size_t)2 << 30) <= avail + block_bytes) {
+            std::future<int> matrix_rc = std::async(std::launch::async, [&] {
+                return reserve_big(ctx, ctx->d_dist, matrix, "the float distance matrix (rows x slots)");
+            });
+            int rc_t = reserve_big(ctx, L.d_out, whole, "the LCS triangle of the UPGMA matrix");
+            if (!rc_t) rc_t = run_rows(ctx, L, lcsgpu::MODE_TRIANGLE, nullptr, 0, n, nullptr, 0, n - 1, L.d_out.p, 0, 0, elem);
+            const int rc_m = matrix_rc.get();
+            if (rc_t && rc_t != LCSGPU_E_NOMEM) return rc_t;
+            if (!rc_t && !rc_m) {
+                own_triangle = true;
+                ld = ld_a;
+                rc = LCSGPU_OK;
+            } else if (L.d_out.cap >= whole) {
+                HIP_TRY(hipStreamSynchronize(L.stream));
+                L.d_out.release(); // the block-wise way needs the room
+            }
+        }
+    }
+    if (!own_triangle && square && batch_k) {
         const int forced = tune_int("upgma_spare", 0);
         for (size_t div : {10, 20, 40}) {
             size_t spare = forced > 0 ? (size_t)forced : std::max<size_t>(2048, (size_t)n / div);
@@ -988,7 +1016,7 @@ int upgma_reduce(lcsgpu_ctx* ctx, Lane& L, int elem, int distance_kind, int modi
         rc = reserve_big(ctx, ctx->d_dist, (size_t)tri_offset(n) * sizeof(float), "the float distance triangle");
     }
     if (rc) return rc;
-    if (!resident) {
+    if (!resident && !own_triangle) {
         rc = reserve_big(ctx, L.d_out, block_bytes, "a row block of the LCS triangle");
         if (rc) return rc;
     }
@@ -1030,7 +1058,8 @@ int upgma_reduce(lcsgpu_ctx* ctx, Lane& L, int elem, int distance_kind, int modi
         ~EvGuard() { for (hipEvent_t e : v) if (e) (void)hipEventDestroy(e); }
     } ev_guard{t_ev};
     int lcs_launches = 0;
-    if (resident) {
+    if (own_triangle) lcs_launches = L.last_launches;
+    if (resident || own_triangle) {
         HIP_TRY(lcsgpu::launch_upgma_distances(a, L.d_out.p, elem, (const uint32_t*)ctx->d_lens.p, (const float*)ctx->d_powf.p,
                                                distance_kind, 0, n, L.stream));
     } else {
@@ -1122,7 +1151,7 @@ int upgma_reduce(lcsgpu_ctx* ctx, Lane& L, int elem, int distance_kind, int modi
             n_batches += want;
             HIP_TRY(hipMemcpyAsync(st, ba.state + 8 * (n_batches & 1), 32, hipMemcpyDeviceToHost, L.stream));
             HIP_TRY(hipStreamSynchronize(L.stream));
-            if (resident && L.d_out.cap >= ((size_t)1 << 30)) L.d_out.release(); // the gathered triangle has been consumed
+            if ((resident || own_triangle) && L.d_out.cap >= ((size_t)1 << 30)) L.d_out.release(); // the triangle has been consumed
             if (st[2]) {
                 sel[8] = 1;
                 break;
@@ -1157,8 +1186,8 @@ int upgma_reduce(lcsgpu_ctx* ctx, Lane& L, int elem, int distance_kind, int modi
     if (sel[8])
         return fail(LCSGPU_E_INVALID, "UPGMA: no finite nearest neighbour (a pair with LCS 0?) -- the reference's "
                                       "algorithm is undefined for this input");
-    if (resident) {
-        note_async_call(ctx);
+    if (resident || own_triangle) {
+        note_async_call(ctx); // (own_triangle: the one run_rows call above, timed by the lane's events)
     } else { // this call's LCS launches, block by block (the stream has been synchronised)
         double ms = 0;
         for (size_t k = 0; k + 1 < t_ev.size(); k += 2) {
