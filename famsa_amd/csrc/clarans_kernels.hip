@@ -34,6 +34,10 @@
 #include "lcs_kernels.h"
 #include "fasttree_kernels.h"
 
+#ifndef CLARANS_QC
+#define CLARANS_QC 8 // (4: 27.3 ms for a chain of 2000 members / 100 medoids, 8: 25.9, 16: 31.0 -- profiles/qc_r06.txt)
+#endif
+
 namespace lcsgpu {
 
 namespace {
@@ -581,7 +585,7 @@ __device__ __forceinline__ int clarans_search_body(const ClaransArgs& a, SearchR
         {
             const int jn = (n + 511) >> 9;
             auto flags_of = [&](auto JN) { // (unconditional loads: four rows are requested before the first is looked at)
-                constexpr int J = decltype(JN)::value, QC = 4;
+                constexpr int J = decltype(JN)::value, QC = CLARANS_QC; // rows in flight per batch of the flags phase
 #pragma unroll
                 for (int s0 = 0; s0 < Q; s0 += QC) {
                     if (s0 >= qn) break;

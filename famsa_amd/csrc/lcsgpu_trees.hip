@@ -937,6 +937,8 @@ int upgma_reduce(lcsgpu_ctx* ctx, Lane& L, int elem, int distance_kind, int modi
     HIP_TRY(hipSetDevice(ctx->device));
     // The distances as a full symmetric matrix where that fits: both rows a merge reads are then contiguous
     // (tree_kernels.hip).  Else the packed triangle.  LCSGPU_UPGMA_LAYOUT=triangle|square forces one (tests, measurements).
+    const auto t_entry = std::chrono::steady_clock::now();
+    auto since_entry = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_entry).count(); };
     bool square = true;
     if (const char* e = getenv("LCSGPU_UPGMA_LAYOUT")) square = !strcmp(e, "square");
     // Several merges per launch (upgma_batch_kernels.hip) -- the default while its layout fits: n rows x (n + spare) SLOTS (a
@@ -962,35 +964,12 @@ int upgma_reduce(lcsgpu_ctx* ctx, Lane& L, int elem, int distance_kind, int modi
     }
     size_t ld = (size_t)n;
     int rc = LCSGPU_E_NOMEM;
-    // The matrix's allocation beside the LCS launches.  44 GB (100 000 sequences) are handed out in tens of milliseconds on a
-    // device that has rested, and in one to two SECONDS when another process has just given that much back
-    // (profiles/upgma_modes_r06.txt: the same command 1.63 or 2.6-3.7 s).  Where there is room for the whole uint16 triangle
-    // as well (10 GB), a helper thread allocates the matrix while this one computes the triangle, and the values become
-    // distances in one launch afterwards; else -- and if the helper fails -- row block by row block as below.
-    bool own_triangle = false;
-    if (!resident && square && batch_k && tune_int("upgma_async_alloc", 1) && tune_int("upgma_spare", 0) == 0) {
-        const size_t spare = std::max<size_t>({2048, (size_t)n / 10, (size_t)2 * batch_k});
-        const size_t ld_a = ((size_t)n + spare + 63) & ~(size_t)63;
-        const size_t matrix = (size_t)n * ld_a * sizeof(float), whole = (size_t)tri_offset(n) * elem;
-        if (matrix >= ((size_t)4 << 30) && matrix + whole + ((size_t)2 << 30) <= avail + block_bytes) {
-            std::future<int> matrix_rc = std::async(std::launch::async, [&] {
-                return reserve_big(ctx, ctx->d_dist, matrix, "the float distance matrix (rows x slots)");
-            });
-            int rc_t = reserve_big(ctx, L.d_out, whole, "the LCS triangle of the UPGMA matrix");
-            if (!rc_t) rc_t = run_rows(ctx, L, lcsgpu::MODE_TRIANGLE, nullptr, 0, n, nullptr, 0, n - 1, L.d_out.p, 0, 0, elem);
-            const int rc_m = matrix_rc.get();
-            if (rc_t && rc_t != LCSGPU_E_NOMEM) return rc_t;
-            if (!rc_t && !rc_m) {
-                own_triangle = true;
-                ld = ld_a;
-                rc = LCSGPU_OK;
-            } else if (L.d_out.cap >= whole) {
-                HIP_TRY(hipStreamSynchronize(L.stream));
-                L.d_out.release(); // the block-wise way needs the room
-            }
-        }
-    }
-    if (!own_triangle && square && batch_k) {
+    // (Round 6 tried to hide the matrix's allocation: 44 GB are handed out at once on a device that has rested and in 1.2-2.1 s when
+    //  another process has just given that much back.  A helper thread allocating while this one computed the whole uint16
+    //  triangle hid nothing -- the launches of this process stand still while the driver hands the memory out: 1.21 s of
+    //  allocation + 1.37 s of LCS = 2.84 s to the first distance launch, as before -- and cost 10 GB more;
+    //  profiles/upgma_modes_r06.txt.)
+    if (square && batch_k) {
         const int forced = tune_int("upgma_spare", 0);
         for (size_t div : {10, 20, 40}) {
             size_t spare = forced > 0 ? (size_t)forced : std::max<size_t>(2048, (size_t)n / div);
@@ -1016,7 +995,7 @@ int upgma_reduce(lcsgpu_ctx* ctx, Lane& L, int elem, int distance_kind, int modi
         rc = reserve_big(ctx, ctx->d_dist, (size_t)tri_offset(n) * sizeof(float), "the float distance triangle");
     }
     if (rc) return rc;
-    if (!resident && !own_triangle) {
+    if (!resident) {
         rc = reserve_big(ctx, L.d_out, block_bytes, "a row block of the LCS triangle");
         if (rc) return rc;
     }
@@ -1050,7 +1029,11 @@ int upgma_reduce(lcsgpu_ctx* ctx, Lane& L, int elem, int distance_kind, int modi
     const bool profile = getenv("LCSGPU_PROFILE") != nullptr;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double t_pro = 0, t_merge = 0;
-    if (profile) { HIP_TRY(hipStreamSynchronize(L.stream)); t_pro = now(); }
+    if (profile) {
+        HIP_TRY(hipStreamSynchronize(L.stream));
+        t_pro = now();
+        fprintf(stderr, "lcsgpu_upgma: %.3f s from the call to the first launch of the distances (the buffers' allocation)\n", since_entry());
+    }
     // the LCS values -> float distances, row block by row block (whole tile rows of 32 in the square layout)
     std::vector<hipEvent_t> t_ev;
     struct EvGuard {
@@ -1058,8 +1041,7 @@ int upgma_reduce(lcsgpu_ctx* ctx, Lane& L, int elem, int distance_kind, int modi
         ~EvGuard() { for (hipEvent_t e : v) if (e) (void)hipEventDestroy(e); }
     } ev_guard{t_ev};
     int lcs_launches = 0;
-    if (own_triangle) lcs_launches = L.last_launches;
-    if (resident || own_triangle) {
+    if (resident) {
         HIP_TRY(lcsgpu::launch_upgma_distances(a, L.d_out.p, elem, (const uint32_t*)ctx->d_lens.p, (const float*)ctx->d_powf.p,
                                                distance_kind, 0, n, L.stream));
     } else {
@@ -1151,7 +1133,7 @@ int upgma_reduce(lcsgpu_ctx* ctx, Lane& L, int elem, int distance_kind, int modi
             n_batches += want;
             HIP_TRY(hipMemcpyAsync(st, ba.state + 8 * (n_batches & 1), 32, hipMemcpyDeviceToHost, L.stream));
             HIP_TRY(hipStreamSynchronize(L.stream));
-            if ((resident || own_triangle) && L.d_out.cap >= ((size_t)1 << 30)) L.d_out.release(); // the triangle has been consumed
+            if (resident && L.d_out.cap >= ((size_t)1 << 30)) L.d_out.release(); // the gathered triangle has been consumed
             if (st[2]) {
                 sel[8] = 1;
                 break;
@@ -1176,6 +1158,7 @@ int upgma_reduce(lcsgpu_ctx* ctx, Lane& L, int elem, int distance_kind, int modi
     rc = fetch_merges(L, base + o_sel, 48, o_left - o_sel, o_right - o_sel, n, sel, out_left, out_right);
     if (rc) return rc;
     L.plan_in_flight = false;
+    if (profile) fprintf(stderr, "lcsgpu_upgma: %.3f s from the call to the merges on the host\n", since_entry());
     if (profile)
         fprintf(stderr, "lcsgpu_upgma: n = %d, %s layout, distances + row minima %.3f s, %d merges %.3f s = %.2f us each (%s)\n", n,
                 square ? "square" : "triangle", t_merge - t_pro, n - 1, now() - t_merge, 1e6 * (now() - t_merge) / std::max(n - 1, 1),
@@ -1186,8 +1169,8 @@ int upgma_reduce(lcsgpu_ctx* ctx, Lane& L, int elem, int distance_kind, int modi
     if (sel[8])
         return fail(LCSGPU_E_INVALID, "UPGMA: no finite nearest neighbour (a pair with LCS 0?) -- the reference's "
                                       "algorithm is undefined for this input");
-    if (resident || own_triangle) {
-        note_async_call(ctx); // (own_triangle: the one run_rows call above, timed by the lane's events)
+    if (resident) {
+        note_async_call(ctx);
     } else { // this call's LCS launches, block by block (the stream has been synchronised)
         double ms = 0;
         for (size_t k = 0; k + 1 < t_ev.size(); k += 2) {

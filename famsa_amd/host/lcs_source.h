@@ -23,7 +23,8 @@ namespace famsa_host {
 // search on the host), threads=N (worker threads of the C test entry points), pool=N (threads of the FastTree recursion's task
 // pool instead of twice the cores: measurements), csv_input_order (-dist_export asks for its rectangles with the columns as
 // they were read instead of by length: measurements), leafmax=N (threads of that pool that may work on leaves while splits wait:
-// measurements).  Not read on any product default path.
+// measurements), release_early / release_never / no_spare_tree / no_level_scratch (host memory of the tree heuristics as it was
+// before the second session of round 6: measurements).  Not read on any product default path.
 bool host_test(const char* name);
 int host_test_int(const char* key, int dflt);
 // LCSGPU_PROFILE: stage / call statistics on stderr (the library prints its own under the same switch)

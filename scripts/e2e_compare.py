@@ -49,6 +49,9 @@ def ref_tree(fasta, gt, heuristic, limit=150):
 WORK = []
 
 
+REST_S = 6
+
+
 def gpu(args, fasta, runs=2):
     """famsa-gpu `runs` times: (walls, tree-stage times, the Newick); WORK[-1] = the sums of the command's own stage timers
     (load, sort, upload, tree, Newick, store): wall - work = what starting a process that uses HIP costs (device discovery,
@@ -59,7 +62,9 @@ def gpu(args, fasta, runs=2):
         # the driver hands the device memory of a process that has ended back only after a while, and a process started
         # meanwhile waits for it (scripts/back_to_back.sh: -gt upgma at 100 000 sequences 1.6 s after a rest, 2.5-4 s right
         # after another such run): every run starts from a rested device
-        time.sleep(6)
+        # (6 s are enough after a small run; after one that held tens of GB the next 44 GB allocation takes 1-2 s for another
+        #  ~20 s -- profiles/upgma_modes_r06.txt --, so the cases that allocate that much rest REST_S = 25 s)
+        time.sleep(REST_S)
         t0 = time.time()
         p = subprocess.run([cli, "-v", *args, "-gt_export", fasta, "/tmp/cmp_gpu.dnd"], stderr=subprocess.PIPE, text=True)
         assert p.returncode == 0, p.stderr
@@ -148,8 +153,11 @@ dist_case("hemopexin (4188 seqs)", os.path.join(ROOT, "tests", "golden", "hemope
 dist_case("synthetic 10000 x 400 aa", "/tmp/cmp_10k.fasta")
 codes, offsets = seqio.synth_uniform(100000, 400)
 seqio.to_fasta(codes, offsets, "/tmp/cmp_100k.fasta")
+REST_S = 25
+out["rest_before_each_large_run_s"] = REST_S
 for gt in ("sl", "slink", "upgma"):
     case("synthetic 100000 x 400 aa", "/tmp/cmp_100k.fasta", gt, with_reference=False, pin=META["synth100k"].get(gt + "_newick_sha256"))
+REST_S = 6
 for n, ref_limit in ((200000, 150), (1000000, 240), (3000000, 0)):
     fam = "/tmp/family_%d_300.fasta" % n
     if not os.path.exists(fam):
