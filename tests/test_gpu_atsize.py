@@ -173,9 +173,12 @@ def test_c4_row_block_contexts_tree_and_sampled_triangle(oracle, synth100k):
             e.close()
 
 
-@pytest.mark.parametrize("n,env", [(200000, {}), (1000000, {}), (200000, {"LCSGPU_TUNE": "clarans_slice_us=150,clarans_draws=500,assign_batch_kb=4096,narrow_lists=0"})],
-                         ids=["200000", "1000000", "200000-short-slices"])
+@pytest.mark.parametrize("n,env", [(200000, {}), (1000000, {}), (200000, {"LCSGPU_TUNE": "clarans_slice_us=150,clarans_draws=500,assign_batch_kb=4096,narrow_lists=0"}),
+                                   (200000, {"FAMSA_HOST_TEST": "release_early,no_spare_tree,no_level_scratch"})],
+                         ids=["200000", "1000000", "200000-short-slices", "200000-host-memory-as-it-was"])
 def test_c5_medoid_tree(tmp_path, n, env):
+    """(the last case: the residues released beside the levels, no tree set up during the upload, the levels' arrays allocated
+    anew -- how the host side held its memory before the second session of round 6; where memory comes from changes no tree)"""
     rec = META[f"family{n}"]
     path = str(tmp_path / f"family_{n}.fasta")
     seqio.family_fasta(n, rec["len"], path)
