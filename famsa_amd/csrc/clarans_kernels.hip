@@ -422,86 +422,76 @@ __device__ __forceinline__ void rescan_positions(const ClaransArgs& a, const boo
     // distances alone waits for k / 8 dependent batches of scattered loads.  Instead the WAVE takes each such position:
     // lane m loads the distance to slot m (+ 64, ...), all of a group's loads in flight together, and the two nearest
     // slots are two wave minima -- "first minimum over the slots, then first minimum over the rest", which is what
-    // the sequential scan of Clustering.cpp:262-305 arrives at.
+    // the sequential scan of Clustering.cpp:262-305 arrives at.  (Slice by slice: taking a wave's positions of all four
+    // slices four at a time -- fewer rounds -- made a chain SLOWER, 27.9 against 25.9 ms: the kernel sits at its 128
+    // registers and the shared loop spilled more; round 6, second session.)
     const int kq = (k + 63) >> 6;
-    if (kq <= 2) {
-        // (the wave's positions of ALL its PER slices are taken four at a time: slice by slice, a wave with one such position in
-        //  each of its four slices -- the usual case: ~40 positions per accept over 32 (wave, slice) cells -- went round four times)
-        static_assert(PER == 4, "four slices");
-        unsigned long long t0 = __ballot(need[0]), t1 = __ballot(need[1]), t2 = __ballot(need[2]), t3 = __ballot(need[3]);
-        for (;;) {
-            int rl[4] = {0, 0, 0, 0}, ru[4] = {0, 0, 0, 0};
-            int cnt = 0;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) { // the next position: from the first slice that still has one
-                unsigned long long& t = t0 ? t0 : t1 ? t1 : t2 ? t2 : t3;
-                if (!t) break;
-                rl[c] = (int)__builtin_ctzll(t);
-                ru[c] = t0 ? 0 : t1 ? 1 : t2 ? 2 : 3;
-                t &= t - 1;
-                cnt = c + 1;
-            }
-            if (!cnt) break;
-            float v[4][2];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int pos_r = k + wave * 64 + (c < cnt ? rl[c] + 512 * ru[c] : rl[0] + 512 * ru[0]);
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const int mm = lane + 64 * q;
-                    v[c][q] = (c < cnt && mm < k) ? a.DMt[(size_t)mm * n + pos_r] : FLT_MAX;
-                }
-            }
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                if (c >= cnt) break;
-                float dsel = d_new[0];
-#pragma unroll
-                for (int uu = 1; uu < PER; ++uu) dsel = ru[c] == uu ? d_new[uu] : dsel; // (ru[c] is wave-uniform)
-                const float dnw_r = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dsel), rl[c]));
-                float dv[2];
-#pragma unroll
-                for (int q = 0; q < 2; ++q) dv[q] = (lane + 64 * q == mm_new) ? dnw_r : v[c][q];
-                float v1 = FLT_MAX, v2 = FLT_MAX;
-                int i1 = INT_MAX, i2 = INT_MAX;
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const int mm = lane + 64 * q;
-                    if (mm < k && (dv[q] < v1 || i1 == INT_MAX)) { v1 = dv[q]; i1 = mm; }
-                }
-                wave_first_min_valid(v1, i1);
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const int mm = lane + 64 * q;
-                    if (mm < k && mm != i1 && (dv[q] < v2 || i2 == INT_MAX)) { v2 = dv[q]; i2 = mm; }
-                }
-                wave_first_min_valid(v2, i2);
-                const bool has1 = i1 != INT_MAX && v1 < FLT_MAX, has2 = i2 != INT_MAX && v2 < FLT_MAX;
-                const float4 found = pack_state(has1 ? v1 : FLT_MAX, has2 ? v2 : FLT_MAX, has1 ? i1 : -1, has2 ? i2 : -1);
-#pragma unroll
-                for (int uu = 0; uu < PER; ++uu)
-                    if (ru[c] == uu && lane == rl[c]) s_pre[uu] = found;
-            }
-        }
-        return;
-    }
-    // more than 128 slots: every such lane scans its own column
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
-        if (!need[u]) continue;
-        const int pos = k + tid + 512 * u;
-        const float dnw = d_new[u];
-        Nearest2 nb;
-        const float* col = a.DMt + pos;
-        for (int m0 = 0; m0 < k; m0 += 8) {
-            float vv[8];
+        unsigned long long todo = __ballot(need[u]);
+        while (todo) {
+            int rl[4];
+            int cnt = 0;
+            while (cnt < 4 && todo) {
+                rl[cnt++] = (int)__builtin_ctzll(todo);
+                todo &= todo - 1;
+            }
+            if (kq <= 2) {
+                float v[4][2];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) vv[q] = col[(size_t)min(m0 + q, k - 1) * n];
+                for (int c = 0; c < 4; ++c) {
+                    const int pos_r = k + wave * 64 + (c < cnt ? rl[c] : rl[0]) + 512 * u;
 #pragma unroll
-            for (int q = 0; q < 8; ++q)
-                if (m0 + q < k) nb.feed(m0 + q == mm_new ? dnw : vv[q], m0 + q);
+                    for (int q = 0; q < 2; ++q) {
+                        const int mm = lane + 64 * q;
+                        v[c][q] = (c < cnt && mm < k) ? a.DMt[(size_t)mm * n + pos_r] : FLT_MAX;
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    if (c >= cnt) break;
+                    const float dnw_r = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d_new[u]), rl[c]));
+                    float dv[2];
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) dv[q] = (lane + 64 * q == mm_new) ? dnw_r : v[c][q];
+                    float v1 = FLT_MAX, v2 = FLT_MAX;
+                    int i1 = INT_MAX, i2 = INT_MAX;
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const int mm = lane + 64 * q;
+                        if (mm < k && (dv[q] < v1 || i1 == INT_MAX)) { v1 = dv[q]; i1 = mm; }
+                    }
+                    wave_first_min_valid(v1, i1);
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const int mm = lane + 64 * q;
+                        if (mm < k && mm != i1 && (dv[q] < v2 || i2 == INT_MAX)) { v2 = dv[q]; i2 = mm; }
+                    }
+                    wave_first_min_valid(v2, i2);
+                    const bool has1 = i1 != INT_MAX && v1 < FLT_MAX, has2 = i2 != INT_MAX && v2 < FLT_MAX;
+                    if (lane == rl[c]) s_pre[u] = pack_state(has1 ? v1 : FLT_MAX, has2 ? v2 : FLT_MAX, has1 ? i1 : -1, has2 ? i2 : -1);
+                }
+            } else { // more than 128 slots: every such lane scans its own column (the apply kernel's loop)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    if (c < cnt && lane == rl[c]) {
+                        const int pos = k + tid + 512 * u;
+                        const float dnw = d_new[u];
+                        Nearest2 nb;
+                        const float* col = a.DMt + pos;
+                        for (int m0 = 0; m0 < k; m0 += 8) {
+                            float vv[8];
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) vv[q] = col[(size_t)min(m0 + q, k - 1) * n];
+#pragma unroll
+                            for (int q = 0; q < 8; ++q)
+                                if (m0 + q < k) nb.feed(m0 + q == mm_new ? dnw : vv[q], m0 + q);
+                        }
+                        s_pre[u] = pack_state(nb.dn, nb.ds, nb.an, nb.as);
+                    }
+                }
+            }
         }
-        s_pre[u] = pack_state(nb.dn, nb.ds, nb.an, nb.as);
     }
 }
 
