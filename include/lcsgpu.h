@@ -285,7 +285,7 @@ int lcsgpu_mst_order_edges(lcsgpu_mst_edge* edges, int32_t n);
  * algorithm is undefined (no finite nearest neighbour, e.g. a sequence with LCS 0 to all others).
  * How the n-1 merges run (all forms give the reference's tree bit for bit): on an n x (n + n/10) float matrix
  * -- live clusters keep a row, new clusters take the next free column, the columns are compacted in place when they run
- * out; 45 GB at 100 000 sequences, the LCS triangle itself only ever exists block-wise -- in batches of up to 32 merges per
+ * out; 46 GB at 100 000 sequences, the LCS triangle itself only ever exists block-wise -- in batches of up to 32 merges per
  * three launches: the next picks are the next entries of the rows' sorted (min_dist, index) order, checked afterwards
  * against the keys of the clusters the batch created (LCSGPU_UPGMA_BATCH=0|8|16|32).  Where that matrix does not fit: the
  * n x n matrix, then the packed float triangle, with one launch per merge (LCSGPU_UPGMA_LAYOUT=square|triangle forces one).
